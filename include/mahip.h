@@ -1,0 +1,98 @@
+/* mahip.h -- thin C ABI between the host C code and the hand-written HIP kernels (gfx950).
+ *
+ * One mahip_ctx_t per GPU (one process per GPU).  Hits live in HBM as SoA columns between calls; every
+ * pass is an in-place "flag + rewrite" pass (no compaction until something is exported), arcs are a dense
+ * SoA edge list + CSR index.  Each entry cites the reference function whose result it reproduces
+ * (file:line under the reference tree).  All functions return 0 on success, non-zero on failure with the
+ * message available from mahip_strerror(); there is NO CPU fallback: without a usable GPU mahip_create fails.
+ */
+#ifndef MAHIP_H
+#define MAHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "miniasm_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mahip_ctx mahip_ctx_t;
+
+int mahip_device_count(void);
+/* stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL to create a private one */
+mahip_ctx_t *mahip_create(int device, void *stream);
+void mahip_destroy(mahip_ctx_t *c);
+const char *mahip_strerror(void);
+int mahip_sync(mahip_ctx_t *c);
+
+/* ---- hits ------------------------------------------------------------------------------------------ */
+/* n unsorted (or sorted) 32-byte ma_hit_t records, reads numbered [0,n_seq).  upload = H2D copy of a host
+ * array; adopt = the records already sit in HBM at d_hits (not owned, never written). */
+int mahip_hits_upload(mahip_ctx_t *c, const ma_hit_t *h, size_t n, uint32_t n_seq);
+int mahip_hits_adopt(mahip_ctx_t *c, const void *d_hits, size_t n, uint32_t n_seq);
+/* Multi-GPU: this context owns the hits whose query id lies in [q_beg,q_end); call before sort/index. */
+int mahip_set_shard(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end);
+
+/* hit.c:19-22 ma_hit_sort: LSD radix sort by (query id, query start, input order) -> SoA + group offsets */
+int mahip_hits_sort(mahip_ctx_t *c);
+/* same layout change without sorting (input already grouped by query id: the per-symbol ABI path) */
+int mahip_hits_index(mahip_ctx_t *c);
+
+/* hit.c:109-160 ma_hit_sub into sub slot 0 or 1 */
+int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int end_clip, int slot, size_t *n_remained);
+/* hit.c:162-193 ma_hit_cut against sub slot */
+int mahip_hits_cut(mahip_ctx_t *c, int slot, int min_span, size_t *n_live);
+/* hit.c:195-216 ma_hit_flt (int_frac fixed at .5 there) */
+int mahip_hits_flt(mahip_ctx_t *c, int slot, int max_hang, int min_ovlp, size_t *n_live, float *cov);
+/* hit.c:218-223 ma_sub_merge: slot0 <- compose(slot0, slot1) */
+int mahip_sub_merge(mahip_ctx_t *c);
+/* hit.c:225-256 ma_hit_contained (+ hit.c:24-36 mark_unused, sdict.c:69-86 squeeze map).
+ * seq_del: optional host array [n_seq] of reads already flagged d->seq[i].del. */
+int mahip_hits_contained(mahip_ctx_t *c, const ma_opt_t *opt, const uint8_t *seq_del, uint32_t *n_seq_new, size_t *n_live);
+
+int mahip_sub_upload(mahip_ctx_t *c, int slot, const ma_sub_t *sub, size_t n_sub);
+int mahip_sub_download(mahip_ctx_t *c, int slot, ma_sub_t *sub, int squeezed); /* squeezed: compacted by the contained map */
+int mahip_seqdel_download(mahip_ctx_t *c, uint8_t *del);                       /* per old read id, after contained */
+int mahip_map_download(mahip_ctx_t *c, int32_t *map);                          /* old -> new id (-1 dropped) */
+size_t mahip_hits_live(mahip_ctx_t *c);
+/* live hits, compacted in array order, ids renumbered if contained has run; out must hold mahip_hits_live() */
+int mahip_hits_download(mahip_ctx_t *c, ma_hit_t *out, size_t *n);
+
+/* ---- string graph ---------------------------------------------------------------------------------- */
+/* asm.c:9-39 ma_sg_gen (+ asg.c:72-80 asg_cleanup with the reference's arc order) from the resident hits.
+ * use_sub: lengths from sub slot 0 (else seq_len).  seq_len/seq_del: optional host arrays indexed by the
+ * CURRENT read numbering (needed when use_sub == 0; seq_del may be NULL). */
+int mahip_sg_gen(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, const uint32_t *seq_len, const uint8_t *seq_del, uint32_t *n_arc);
+/* per-symbol path: take a host graph (dense, sorted, indexed) */
+int mahip_asg_upload(mahip_ctx_t *c, const asg_t *g);
+/* asg.c:148-193 asg_arc_del_trans marking + asg_cleanup (symm is a separate call, as in the reference) */
+int mahip_asg_del_trans(mahip_ctx_t *c, int fuzz, uint32_t *n_reduced);
+/* asg.c:104-145 asg_arc_del_multi / asg_arc_del_asymm, each followed by asg_cleanup when it removed arcs */
+int mahip_asg_symm(mahip_ctx_t *c, uint32_t *n_multi, uint32_t *n_asymm);
+/* asg.c:83-101 asg_arc_del_short marking + cleanup (symm separate) */
+int mahip_asg_del_short(mahip_ctx_t *c, float drop_ratio, uint32_t *n_short);
+uint32_t mahip_asg_n_arc(mahip_ctx_t *c);
+/* fills g (arc/seq/idx malloc'ed, is_srt=1) in the squeezed numbering */
+int mahip_asg_download(mahip_ctx_t *c, asg_t *g);
+
+/* ---- instrumentation -------------------------------------------------------------------------------- */
+/* Per-kernel timing with HIP events on the launch stream.  enable=1 brackets every kernel launch with
+ * events (adds launch overhead; use for measurement runs only). */
+int mahip_prof_enable(mahip_ctx_t *c, int enable);
+int mahip_prof_reset(mahip_ctx_t *c);
+/* writes up to max entries; returns the number of distinct kernels seen */
+typedef struct { const char *name; uint64_t launches; double total_ms; double alg_bytes; } mahip_prof_t;
+int mahip_prof_get(mahip_ctx_t *c, mahip_prof_t *out, int max);
+/* bytes of HBM currently held by the context */
+size_t mahip_mem_bytes(mahip_ctx_t *c);
+/* device pointers for multi-GPU exchanges done outside (RCCL via torch.distributed): which = MAHIP_PTR_* */
+#define MAHIP_PTR_SUB0    0
+#define MAHIP_PTR_SUB1    1
+#define MAHIP_PTR_RDFLAG  2
+void *mahip_devptr(mahip_ctx_t *c, int which, size_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

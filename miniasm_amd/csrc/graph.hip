@@ -1,0 +1,545 @@
+// graph.hip -- string-graph construction and reduction on a dense SoA edge list + CSR index in HBM.
+//
+//   arcs : au av alen aol(del<<31) u32 columns [n_arc], sorted by (u, len) like reference asg.c:22-25
+//   idx  : u64 [2*n_seq], idx[v] = first<<32 | count      (reference asg.c:27-36)
+//   sdel / slen : per read seq.del / seq.len               (reference asg.h:13-15)
+// Vertex ids use the ORIGINAL read numbering; the squeeze map (sdict.c:69-86) is applied at export only
+// (it is monotone, so every order is preserved).
+//
+//   mahip_sg_gen       : reference asm.c:9-39  ma_sg_gen + asg.c:72-80 asg_cleanup
+//   mahip_asg_del_trans: reference asg.c:148-193 asg_arc_del_trans (Myers) : one wave per vertex, own
+//                        neighbour list and an open-addressing mark table in LDS, neighbours' lists streamed
+//   mahip_asg_symm     : reference asg.c:104-145 asg_arc_del_multi + asg_arc_del_asymm
+//   mahip_asg_del_short: reference asg.c:83-101
+#include "mahip_internal.hpp"
+
+#define DEAD 0x80000000u
+#define ADEL 0x80000000u
+
+struct HitColsG { const uint32_t *qid, *qs, *qe, *tn, *ts, *te, *ml, *bl; };
+struct ArcCols { uint32_t *u, *v, *len, *ol; };
+
+static HitColsG gcols_of(mahip_ctx *c)
+{
+	HitColsG h;
+	h.qid = P<uint32_t>(c->col[0]); h.qs = P<uint32_t>(c->col[1]); h.qe = P<uint32_t>(c->col[2]); h.tn = P<uint32_t>(c->col[3]);
+	h.ts = P<uint32_t>(c->col[4]); h.te = P<uint32_t>(c->col[5]); h.ml = P<uint32_t>(c->col[6]); h.bl = P<uint32_t>(c->col[7]);
+	return h;
+}
+static ArcCols arcs_of(mahip_ctx *c, int g)
+{
+	ArcCols a;
+	a.u = P<uint32_t>(c->au[g]); a.v = P<uint32_t>(c->av[g]); a.len = P<uint32_t>(c->alen[g]); a.ol = P<uint32_t>(c->aol[g]);
+	return a;
+}
+static int reserve_arcs(mahip_ctx *c, size_t n)
+{
+	for (int g = 0; g < 2; ++g) {
+		CHK(dev_reserve(c, c->au[g], (n + 4) * 4)); CHK(dev_reserve(c, c->av[g], (n + 4) * 4));
+		CHK(dev_reserve(c, c->alen[g], (n + 4) * 4)); CHK(dev_reserve(c, c->aol[g], (n + 4) * 4));
+	}
+	CHK(dev_reserve(c, c->keep, (n + 16) * 4)); CHK(dev_reserve(c, c->pos, (n + 16) * 4));
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ ma_sg_gen
+// asm.c:14-17 : seq.len / seq.del per read.  ql used by the classifier keeps all 32 bits (asm.c:23-24).
+__global__ __launch_bounds__(256) void k_sg_seq(const uint2 *__restrict__ sub, const uint8_t *__restrict__ r_del, const uint32_t *__restrict__ seq_len,
+                                                 const uint8_t *__restrict__ seq_del, uint32_t n_seq, uint32_t *__restrict__ slen, uint8_t *__restrict__ sdel)
+{
+	uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	if (r >= n_seq) return;
+	uint32_t len; int del;
+	if (sub) { uint2 s = sub[r]; len = s.y - (s.x & 0x7fffffffu); del = s.x >> 31; }
+	else len = seq_len[r], del = 0;
+	if (seq_del) del |= seq_del[r];
+	if (r_del) del |= r_del[r];
+	slen[r] = len; sdel[r] = (uint8_t)del;
+}
+
+// asm.c:18-35 per hit: candidate arc at the hit's own slot (push order = hit order), seq.del side effects
+__global__ __launch_bounds__(256) void k_sg_arcs(HitColsG h, size_t n, const uint32_t *__restrict__ slen, uint8_t *__restrict__ sdel,
+                                                  int max_hang, float int_frac, int min_ovlp, ArcCols a, uint32_t *__restrict__ keep,
+                                                  unsigned long long *__restrict__ ctr)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	uint32_t mx = 0;
+	if (i < n) {
+		int k = 0;
+		if (!(h.bl[i] & DEAD)) {
+			uint32_t q = h.qid[i], t = h.tn[i], qs = h.qs[i], qe = h.qe[i], ts = h.ts[i], te = h.te[i];
+			int rev = h.ml[i] >> 31;
+			mc_arc_t x;
+			int r = mc_hit2arc(q, qs, qe, t, ts, te, rev, (int)slen[q], (int)slen[t], max_hang, int_frac, min_ovlp, &x);
+			if (r >= 0) {
+				if (q == t) { if (qs == ts && qe == te && rev) sdel[q] = 1; } // asm.c:27-31
+				else { a.u[i] = x.u; a.v[i] = x.v; a.len[i] = x.len; a.ol[i] = x.ol; k = 1; mx = x.len; }
+			} else if (r == MC_HT_QCONT) sdel[q] = 1; // asm.c:34
+		}
+		keep[i] = k;
+	}
+	for (int o = 32; o > 0; o >>= 1) { uint32_t y = __shfl_xor(mx, o, 64); mx = y > mx ? y : mx; }
+	if ((threadIdx.x & 63) == 0 && mx) atomicMax(&ctr[CT_MAXLEN], (unsigned long long)mx);
+}
+
+// asg.c:57-70 asg_arc_rm predicate: arc survives unless del or an endpoint read is deleted
+__global__ __launch_bounds__(256) void k_arc_keep(ArcCols a, size_t n, const uint8_t *__restrict__ sdel, uint32_t *__restrict__ keep, int use_keep_in)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	int k = use_keep_in ? (int)keep[i] : 1;
+	if (k) k = !(a.ol[i] & ADEL) && !sdel[a.u[i] >> 1] && !sdel[a.v[i] >> 1];
+	keep[i] = k;
+}
+
+__global__ __launch_bounds__(256) void k_arc_compact(ArcCols in, size_t n, const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, ArcCols out)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n && keep[i]) {
+		uint32_t p = pos[i];
+		out.u[p] = in.u[i]; out.v[p] = in.v[i]; out.len[p] = in.len[i]; out.ol[p] = in.ol[i];
+	}
+}
+
+__global__ __launch_bounds__(256) void k_arc_keys(ArcCols a, size_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) { key[i] = (uint64_t)a.u[i] << 32 | a.len[i]; val[i] = (uint32_t)i; }
+}
+
+__global__ __launch_bounds__(256) void k_arc_permute(ArcCols in, size_t n, const uint32_t *__restrict__ perm, ArcCols out)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) {
+		uint32_t j = perm[i];
+		out.u[i] = in.u[j]; out.v[i] = in.v[j]; out.len[i] = in.len[j]; out.ol[i] = in.ol[j];
+	}
+}
+
+// asg.c:27-36 asg_arc_index_core on a zeroed idx
+__global__ __launch_bounds__(256) void k_arc_index(const uint32_t *__restrict__ au, size_t n, unsigned long long *__restrict__ idx)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	uint32_t u = au[i];
+	if (i == 0 || au[i - 1] != u) { // first arc of u: count the run
+		size_t j = i + 1;
+		while (j < n && au[j] == u) ++j;
+		idx[u] = (unsigned long long)i << 32 | (unsigned long long)(j - i);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ asg_arc_del_trans
+#define TR_CAP 512
+#define TR_HASH 1024
+#define TR_EMPTY 0xffffffffu
+
+__device__ __forceinline__ uint32_t tr_hash(uint32_t x, uint32_t hbits) { return (x * 0x9E3779B1u) >> (32 - hbits); }
+__device__ __forceinline__ int tr_find(const uint32_t *hk, uint32_t x, uint32_t hbits)
+{
+	uint32_t mask = (1u << hbits) - 1, s = tr_hash(x, hbits);
+	for (;;) {
+		uint32_t k = hk[s];
+		if (k == x) return (int)s;
+		if (k == TR_EMPTY) return -1;
+		s = (s + 1) & mask;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ av, const uint32_t *__restrict__ alen, uint32_t *__restrict__ aol,
+                                                    const unsigned long long *__restrict__ idx, const uint8_t *__restrict__ sdel, uint32_t n_vtx,
+                                                    uint32_t fuzz, uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr)
+{
+	__shared__ uint32_t s_v[4][TR_CAP], s_l[4][TR_CAP], s_hk[4][TR_HASH], s_hm[4][TR_HASH];
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t *lv = s_v[wave], *ll = s_l[wave], *hk = s_hk[wave], *hm = s_hm[wave];
+	uint32_t n_red = 0;
+	for (uint32_t v = blockIdx.x * 4 + wave; v < n_vtx; v += gridDim.x * 4) {
+		unsigned long long x = idx[v];
+		uint32_t st = (uint32_t)(x >> 32), nv = (uint32_t)x;
+		if (nv == 0) continue;
+		if (sdel[v >> 1]) { // asg.c:158-161
+			for (uint32_t i = lane; i < nv; i += 64) aol[st + i] |= ADEL, ++n_red;
+			continue;
+		}
+		if (nv > TR_CAP) { if (lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF2], 1ull); ovf[k] = v; } continue; }
+		uint32_t hbits = 6; while ((1u << hbits) < 2 * nv) ++hbits;
+		uint32_t hsize = 1u << hbits, hmask = hsize - 1;
+		for (uint32_t i = lane; i < nv; i += 64) lv[i] = av[st + i], ll[i] = alen[st + i];
+		for (uint32_t s = lane; s < hsize; s += 64) hk[s] = TR_EMPTY, hm[s] = 0;
+		wv_sync();
+		for (uint32_t i = lane; i < nv; i += 64) { // mark all neighbours 1 (asg.c:162); duplicates share a slot
+			uint32_t key = lv[i], s = tr_hash(key, hbits);
+			for (;;) {
+				uint32_t old = atomicCAS(&hk[s], TR_EMPTY, key);
+				if (old == TR_EMPTY || old == key) { hm[s] = 1; break; }
+				s = (s + 1) & hmask;
+			}
+		}
+		wv_sync();
+		uint32_t L = ll[nv - 1] + fuzz; // asg.c:163
+		for (uint32_t i = 0; i < nv; ++i) { // sequential over v's arcs: the skip below is order dependent (asg.c:168)
+			uint32_t w = lv[i], li = ll[i];
+			int sw = tr_find(hk, w, hbits);
+			if (hm[sw] != 1) continue;
+			unsigned long long xw = idx[w];
+			uint32_t ws = (uint32_t)(xw >> 32), nw = (uint32_t)xw;
+			for (uint32_t j0 = 0; j0 < nw; j0 += 64) { // lanes over w's arcs; sorted by len => the loop of asg.c:169 is a prefix
+				uint32_t j = j0 + lane;
+				int ok = j < nw;
+				uint32_t lx = ok ? alen[ws + j] : 0;
+				int cond = ok && lx + li <= L;
+				uint64_t fail = wv_ballot(ok && !cond);
+				if (fail) cond = cond && lane < (unsigned)(__ffsll((long long)fail) - 1);
+				if (cond) {
+					int sx = tr_find(hk, av[ws + j], hbits);
+					if (sx >= 0) hm[sx] = 2;
+				}
+				if (fail) break;
+			}
+			wv_sync();
+		}
+		for (uint32_t i = lane; i < nv; i += 64) // asg.c:181-184
+			if (hm[tr_find(hk, lv[i], hbits)] == 2) aol[st + i] |= ADEL, ++n_red;
+		wv_sync();
+	}
+	n_red = wv_sum_u32(n_red);
+	if (lane == 0 && n_red) atomicAdd(&ctr[CT_NRED], (unsigned long long)n_red);
+}
+
+// second tier: vertices with more than TR_CAP arcs; one block per vertex with a private global mark array
+// (the reference's own data structure, asg.c:153), lanes over the inner loop.
+__global__ __launch_bounds__(256) void k_asg_trans_big(const uint32_t *__restrict__ av, const uint32_t *__restrict__ alen, uint32_t *__restrict__ aol,
+                                                        const unsigned long long *__restrict__ idx, uint32_t n_vtx, uint32_t fuzz,
+                                                        const uint32_t *__restrict__ ovf, uint32_t n_ovf, uint8_t *__restrict__ marks, unsigned long long *__restrict__ ctr)
+{
+	uint8_t *mark = marks + (size_t)blockIdx.x * n_vtx;
+	__shared__ uint32_t s_red, s_go;
+	for (uint32_t k = blockIdx.x; k < n_ovf; k += gridDim.x) {
+		uint32_t v = ovf[k];
+		unsigned long long x = idx[v];
+		uint32_t st = (uint32_t)(x >> 32), nv = (uint32_t)x;
+		if (threadIdx.x == 0) s_red = 0;
+		for (uint32_t i = threadIdx.x; i < nv; i += 256) mark[av[st + i]] = 1;
+		__syncthreads();
+		uint32_t L = alen[st + nv - 1] + fuzz;
+		for (uint32_t i = 0; i < nv; ++i) {
+			uint32_t w = av[st + i], li = alen[st + i];
+			if (threadIdx.x == 0) s_go = mark[w] == 1; // asg.c:168
+			__syncthreads();
+			if (s_go) {
+				unsigned long long xw = idx[w];
+				uint32_t ws = (uint32_t)(xw >> 32), nw = (uint32_t)xw;
+				for (uint32_t j = threadIdx.x; j < nw; j += 256)
+					if (alen[ws + j] + li <= L) { uint32_t y = av[ws + j]; if (mark[y]) mark[y] = 2; } // lengths ascending: a prefix
+			}
+			__syncthreads();
+		}
+		uint32_t cnt = 0;
+		for (uint32_t i = threadIdx.x; i < nv; i += 256) if (mark[av[st + i]] == 2) aol[st + i] |= ADEL, ++cnt;
+		if (cnt) atomicAdd(&s_red, cnt);
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < nv; i += 256) mark[av[st + i]] = 0;
+		if (threadIdx.x == 0 && s_red) atomicAdd(&ctr[CT_NRED], (unsigned long long)s_red);
+		__syncthreads();
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ asg_symm
+// asg.c:104-121: within one vertex keep the first arc to each target, delete the later ones
+__global__ __launch_bounds__(256) void k_asg_multi(ArcCols a, size_t n, const unsigned long long *__restrict__ idx, unsigned long long *__restrict__ ctr)
+{
+	size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+	int del = 0;
+	if (e < n) {
+		uint32_t st = (uint32_t)(idx[a.u[e]] >> 32), v = a.v[e];
+		for (uint32_t j = st; j < e; ++j) if (a.v[j] == v) { del = 1; break; }
+		if (del) a.ol[e] |= ADEL;
+	}
+	wv_count_add(&ctr[CT_NMULTI], del);
+}
+
+// asg.c:124-138: u->v survives only if v^1 -> u^1 is present (del bits are not consulted, as in the reference)
+__global__ __launch_bounds__(256) void k_asg_asymm(ArcCols a, size_t n, const unsigned long long *__restrict__ idx, unsigned long long *__restrict__ ctr)
+{
+	size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+	int del = 0;
+	if (e < n) {
+		uint32_t v = a.v[e] ^ 1, u = a.u[e] ^ 1;
+		unsigned long long x = idx[v];
+		uint32_t st = (uint32_t)(x >> 32), nv = (uint32_t)x, i;
+		for (i = 0; i < nv; ++i) if (a.v[st + i] == u) break;
+		del = (i == nv);
+	}
+	// all reads of a.v precede the writes below only per thread; a.ol is a different column, so no hazard
+	if (del) a.ol[e] |= ADEL;
+	wv_count_add(&ctr[CT_NASYMM], del);
+}
+
+// asg.c:83-101
+__global__ __launch_bounds__(256) void k_asg_short(ArcCols a, const unsigned long long *__restrict__ idx, uint32_t n_vtx, float drop_ratio, unsigned long long *__restrict__ ctr)
+{
+	uint32_t v = blockIdx.x * 256 + threadIdx.x, cnt = 0;
+	if (v < n_vtx) {
+		unsigned long long x = idx[v];
+		uint32_t st = (uint32_t)(x >> 32), nv = (uint32_t)x;
+		if (nv >= 2) {
+			float p = (float)(int32_t)(a.ol[st] & 0x7fffffffu) * drop_ratio;
+			uint32_t thres = (uint32_t)((double)p + .499), i;
+			for (i = nv - 1; i >= 1 && (a.ol[st + i] & 0x7fffffffu) < thres; --i);
+			for (i = i + 1; i < nv; ++i) a.ol[st + i] |= ADEL, ++cnt;
+		}
+	}
+	cnt = wv_sum_u32(cnt);
+	if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&ctr[CT_NSHORT], (unsigned long long)cnt);
+}
+
+// ------------------------------------------------------------------------------------------------ import / export
+__global__ __launch_bounds__(256) void k_arc_from_aos(const asg_arc_t *__restrict__ in, size_t n, ArcCols a)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) { uint4 r = *(const uint4*)(in + i); a.len[i] = r.x; a.u[i] = r.y; a.v[i] = r.z; a.ol[i] = r.w; }
+}
+__global__ __launch_bounds__(256) void k_seq_from_aos(const uint32_t *__restrict__ seq, uint32_t n_seq, uint32_t *__restrict__ slen, uint8_t *__restrict__ sdel)
+{
+	uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	if (r < n_seq) { uint32_t x = seq[r]; slen[r] = x & 0x7fffffffu; sdel[r] = (uint8_t)(x >> 31); }
+}
+__global__ __launch_bounds__(256) void k_arc_to_aos(ArcCols a, size_t n, const int32_t *__restrict__ map, asg_arc_t *__restrict__ out)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	uint32_t u = a.u[i], v = a.v[i];
+	if (map) u = (uint32_t)map[u >> 1] << 1 | (u & 1), v = (uint32_t)map[v >> 1] << 1 | (v & 1);
+	*(uint4*)(out + i) = make_uint4(a.len[i], u, v, a.ol[i]);
+}
+__global__ __launch_bounds__(256) void k_seq_to_aos(const uint32_t *__restrict__ slen, const uint8_t *__restrict__ sdel, const unsigned long long *__restrict__ idx,
+                                                     const int32_t *__restrict__ map, uint32_t n_seq, uint32_t *__restrict__ seq, unsigned long long *__restrict__ idx_out)
+{
+	uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	if (r >= n_seq) return;
+	int32_t m = map ? map[r] : (int32_t)r;
+	if (m < 0) return;
+	seq[m] = (slen[r] & 0x7fffffffu) | (uint32_t)sdel[r] << 31;
+	idx_out[2 * (size_t)m] = idx[2 * (size_t)r]; idx_out[2 * (size_t)m + 1] = idx[2 * (size_t)r + 1];
+}
+
+// ================================================================================================ host side
+
+static int arc_reindex(mahip_ctx *c)
+{
+	size_t V = 2 * (size_t)c->n_seq;
+	CHK(dev_reserve(c, c->idx, (V + 2) * 8));
+	HIPCHK(hipMemsetAsync(c->idx.p, 0, V * 8, c->st));
+	if (c->n_arc) {
+		ProfScope ps(c, "k_arc_index", 16.0 * (double)c->n_arc);
+		hipLaunchKernelGGL(k_arc_index, dim3(grid_for(c->n_arc, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->au[c->ag]), (size_t)c->n_arc, P<unsigned long long>(c->idx));
+	}
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+// asg.c:72-80 asg_cleanup on the dense list: drop (del | deleted endpoint), keep order, re-index if anything went.
+// keep_in: keep[] already holds a pre-filter (ma_sg_gen's candidate flags).
+// index_mode: 0 = re-index when something was removed, 1 = always, -1 = never (caller indexes later)
+static int arc_cleanup(mahip_ctx *c, size_t n_in, int keep_in, int index_mode)
+{
+	uint32_t *d_tot = (uint32_t*)(P<unsigned long long>(c->ctr) + CT_TOTAL);
+	if (n_in == 0) { c->n_arc = 0; return index_mode < 0 ? 0 : arc_reindex(c); }
+	ArcCols in = arcs_of(c, c->ag), out = arcs_of(c, c->ag ^ 1);
+	{
+		ProfScope ps(c, "k_arc_rm", 32.0 * (double)n_in); // asg_arc_rm 32 B per arc
+		hipLaunchKernelGGL(k_arc_keep, dim3(grid_for(n_in, 256)), dim3(256), 0, c->st, in, n_in, (const uint8_t*)P<uint8_t>(c->sdel), P<uint32_t>(c->keep), keep_in);
+		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), n_in, d_tot));
+		hipLaunchKernelGGL(k_arc_compact, dim3(grid_for(n_in, 256)), dim3(256), 0, c->st, in, n_in, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), out);
+	}
+	CHK(ctr_fetch(c));
+	uint32_t n_out = (uint32_t)(c->h_ctr[CT_TOTAL] & 0xffffffffu);
+	c->ag ^= 1;
+	int changed = n_out != n_in;
+	c->n_arc = n_out;
+	if (index_mode > 0 || (index_mode == 0 && changed)) CHK(arc_reindex(c));
+	return 0;
+}
+
+static int bitlen_u64(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
+
+extern "C" int mahip_sg_gen(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, const uint32_t *seq_len, const uint8_t *seq_del, uint32_t *n_arc)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->soa_ready) { mahip_set_error("mahip_sg_gen: hits not indexed"); return -1; }
+	size_t n = c->n_hits;
+	uint32_t R = c->n_seq;
+	CHK(reserve_arcs(c, n));
+	CHK(dev_reserve(c, c->slen, ((size_t)R + 4) * 4)); CHK(dev_reserve(c, c->sdel, (size_t)R + 16));
+	CHK(ctr_zero(c));
+	unsigned long long *ctr = P<unsigned long long>(c->ctr);
+	// host-side per-read arrays (per-symbol path) go through the scratch buffers
+	const uint32_t *d_len = nullptr; const uint8_t *d_del = nullptr;
+	if (seq_len) { CHK(dev_reserve(c, c->big0, ((size_t)R + 4) * 4)); HIPCHK(hipMemcpyAsync(c->big0.p, seq_len, (size_t)R * 4, hipMemcpyHostToDevice, c->st)); d_len = P<uint32_t>(c->big0); }
+	if (seq_del) { CHK(dev_reserve(c, c->big1, (size_t)R + 16)); HIPCHK(hipMemcpyAsync(c->big1.p, seq_del, R, hipMemcpyHostToDevice, c->st)); d_del = P<uint8_t>(c->big1); }
+	if (!use_sub && !d_len) { mahip_set_error("mahip_sg_gen: need sub or seq_len"); return -1; }
+	if (R) hipLaunchKernelGGL(k_sg_seq, dim3(grid_for(R, 256)), dim3(256), 0, c->st, use_sub ? (const uint2*)P<uint2>(c->sub[0]) : (const uint2*)nullptr,
+	                          c->has_map ? (const uint8_t*)P<uint8_t>(c->r_del) : (const uint8_t*)nullptr, d_len, d_del, R, P<uint32_t>(c->slen), P<uint8_t>(c->sdel));
+	c->ag = 0;
+	ArcCols a0 = arcs_of(c, 0);
+	if (n) {
+		ProfScope ps(c, "k_sg_arcs", 64.0 * (double)c->n_live); // ma_sg_gen 32 r + 16 look-ups + 16 w
+		hipLaunchKernelGGL(k_sg_arcs, dim3(grid_for(n, 256)), dim3(256), 0, c->st, gcols_of(c), n, (const uint32_t*)P<uint32_t>(c->slen), P<uint8_t>(c->sdel),
+		                   opt->max_hang, opt->int_frac, opt->min_ovlp, a0, P<uint32_t>(c->keep), ctr);
+	}
+	// asg_cleanup: arc_rm (order preserving) ...
+	CHK(arc_cleanup(c, n, 1, -1));
+	// ... sort by (u, len) ...
+	if (c->n_arc > 1) {
+		size_t m = c->n_arc;
+		for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }
+		ArcCols in = arcs_of(c, c->ag), out = arcs_of(c, c->ag ^ 1);
+		hipLaunchKernelGGL(k_arc_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
+		int gen = 0;
+		CHK(radix_sort_pairs(c, m, 0, bitlen_u64(c->h_ctr[CT_MAXLEN]), 32, 32 + bitlen_u64(2ull * R), &gen));
+		{
+			ProfScope ps(c, "k_arc_permute", 36.0 * (double)m);
+			hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, (const uint32_t*)P<uint32_t>(c->val[gen]), out);
+		}
+		c->ag ^= 1;
+	}
+	// ... and index
+	CHK(arc_reindex(c));
+	HIPCHK(hipGetLastError());
+	c->graph_ready = true;
+	if (n_arc) *n_arc = c->n_arc;
+	return 0;
+}
+
+extern "C" int mahip_asg_upload(mahip_ctx_t *c, const asg_t *g)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	size_t n = g->n_arc;
+	uint32_t R = g->n_seq;
+	c->n_seq = R; c->n_seq_new = R; c->has_map = false; c->soa_ready = false;
+	CHK(reserve_arcs(c, n));
+	CHK(dev_reserve(c, c->slen, ((size_t)R + 4) * 4)); CHK(dev_reserve(c, c->sdel, (size_t)R + 16));
+	CHK(dev_reserve(c, c->idx, (2 * (size_t)R + 2) * 8));
+	CHK(dev_reserve(c, c->key[0], (n + 1) * 16 + ((size_t)R + 4) * 4));
+	if (n) {
+		HIPCHK(hipMemcpyAsync(c->key[0].p, g->arc, n * 16, hipMemcpyHostToDevice, c->st));
+		hipLaunchKernelGGL(k_arc_from_aos, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const asg_arc_t*)c->key[0].p, n, arcs_of(c, 0));
+	}
+	if (R) {
+		uint32_t *d_seq = (uint32_t*)((char*)c->key[0].p + (n + 1) * 16);
+		HIPCHK(hipMemcpyAsync(d_seq, g->seq, (size_t)R * 4, hipMemcpyHostToDevice, c->st));
+		hipLaunchKernelGGL(k_seq_from_aos, dim3(grid_for(R, 256)), dim3(256), 0, c->st, (const uint32_t*)d_seq, R, P<uint32_t>(c->slen), P<uint8_t>(c->sdel));
+	}
+	c->ag = 0; c->n_arc = (uint32_t)n;
+	if (g->idx) { if (R) HIPCHK(hipMemcpyAsync(c->idx.p, g->idx, 2 * (size_t)R * 8, hipMemcpyHostToDevice, c->st)); }
+	else CHK(arc_reindex(c));
+	HIPCHK(hipGetLastError());
+	c->graph_ready = true;
+	return 0;
+}
+
+extern "C" int mahip_asg_del_trans(mahip_ctx_t *c, int fuzz, uint32_t *n_reduced)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->graph_ready) { mahip_set_error("mahip_asg_del_trans: no graph"); return -1; }
+	uint32_t V = 2 * c->n_seq;
+	CHK(ctr_zero(c));
+	CHK(dev_reserve(c, c->ovf, ((size_t)V + 1) * 4));
+	ArcCols a = arcs_of(c, c->ag);
+	unsigned long long *ctr = P<unsigned long long>(c->ctr);
+	if (V && c->n_arc) {
+		ProfScope ps(c, "k_asg_trans", 32.0 * (double)c->n_arc); // 16*(A+I)/A per arc, I ~ A on clean data
+		hipLaunchKernelGGL(k_asg_trans, dim3(grid_for(V, 4, 256 * 12)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
+		                   (const unsigned long long*)P<unsigned long long>(c->idx), (const uint8_t*)P<uint8_t>(c->sdel), V, (uint32_t)fuzz, P<uint32_t>(c->ovf), ctr);
+	}
+	CHK(ctr_fetch(c));
+	uint32_t n_ovf = (uint32_t)c->h_ctr[CT_OVF2];
+	if (n_ovf) {
+		unsigned nblk = n_ovf < 64 ? n_ovf : 64;
+		CHK(dev_reserve(c, c->marks, (size_t)nblk * V + 16));
+		HIPCHK(hipMemsetAsync(c->marks.p, 0, (size_t)nblk * V, c->st));
+		ProfScope ps(c, "k_asg_trans_big", 0);
+		hipLaunchKernelGGL(k_asg_trans_big, dim3(nblk), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
+		                   (const unsigned long long*)P<unsigned long long>(c->idx), V, (uint32_t)fuzz, (const uint32_t*)P<uint32_t>(c->ovf), n_ovf, P<uint8_t>(c->marks), ctr);
+		CHK(ctr_fetch(c));
+	}
+	HIPCHK(hipGetLastError());
+	uint32_t nr = (uint32_t)c->h_ctr[CT_NRED];
+	if (n_reduced) *n_reduced = nr;
+	if (nr) CHK(arc_cleanup(c, c->n_arc, 0, 0)); // asg.c:188-189
+	return 0;
+}
+
+extern "C" int mahip_asg_symm(mahip_ctx_t *c, uint32_t *n_multi, uint32_t *n_asymm)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->graph_ready) { mahip_set_error("mahip_asg_symm: no graph"); return -1; }
+	unsigned long long *ctr = P<unsigned long long>(c->ctr);
+	const unsigned long long *idx = P<unsigned long long>(c->idx);
+	uint32_t nm = 0, na = 0;
+	CHK(ctr_zero(c));
+	if (c->n_arc) {
+		ProfScope ps(c, "k_asg_multi", 16.0 * (double)c->n_arc);
+		hipLaunchKernelGGL(k_asg_multi, dim3(grid_for(c->n_arc, 256)), dim3(256), 0, c->st, arcs_of(c, c->ag), (size_t)c->n_arc, idx, ctr);
+	}
+	CHK(ctr_fetch(c));
+	nm = (uint32_t)c->h_ctr[CT_NMULTI];
+	if (nm) CHK(arc_cleanup(c, c->n_arc, 0, 0));
+	CHK(ctr_zero(c));
+	if (c->n_arc) {
+		ProfScope ps(c, "k_asg_asymm", 32.0 * (double)c->n_arc);
+		hipLaunchKernelGGL(k_asg_asymm, dim3(grid_for(c->n_arc, 256)), dim3(256), 0, c->st, arcs_of(c, c->ag), (size_t)c->n_arc, idx, ctr);
+	}
+	CHK(ctr_fetch(c));
+	na = (uint32_t)c->h_ctr[CT_NASYMM];
+	if (na) CHK(arc_cleanup(c, c->n_arc, 0, 0));
+	if (n_multi) *n_multi = nm;
+	if (n_asymm) *n_asymm = na;
+	return 0;
+}
+
+extern "C" int mahip_asg_del_short(mahip_ctx_t *c, float drop_ratio, uint32_t *n_short)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->graph_ready) { mahip_set_error("mahip_asg_del_short: no graph"); return -1; }
+	uint32_t V = 2 * c->n_seq;
+	CHK(ctr_zero(c));
+	if (V && c->n_arc) hipLaunchKernelGGL(k_asg_short, dim3(grid_for(V, 256)), dim3(256), 0, c->st, arcs_of(c, c->ag), (const unsigned long long*)P<unsigned long long>(c->idx), V, drop_ratio, P<unsigned long long>(c->ctr));
+	CHK(ctr_fetch(c));
+	uint32_t ns = (uint32_t)c->h_ctr[CT_NSHORT];
+	if (n_short) *n_short = ns;
+	if (ns) CHK(arc_cleanup(c, c->n_arc, 0, 0));
+	return 0;
+}
+
+extern "C" uint32_t mahip_asg_n_arc(mahip_ctx_t *c) { return c->n_arc; }
+
+extern "C" int mahip_asg_download(mahip_ctx_t *c, asg_t *g)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->graph_ready) { mahip_set_error("mahip_asg_download: no graph"); return -1; }
+	size_t n = c->n_arc;
+	uint32_t R = c->n_seq, Rn = c->has_map ? c->n_seq_new : R;
+	const int32_t *map = c->has_map ? (const int32_t*)P<int32_t>(c->map) : (const int32_t*)nullptr;
+	size_t off_seq = (n + 1) * 16, off_idx = off_seq + (((size_t)Rn + 4) * 4 + 15) / 16 * 16;
+	CHK(dev_reserve(c, c->key[0], off_idx + (2 * (size_t)Rn + 2) * 8));
+	char *stg = (char*)c->key[0].p;
+	HIPCHK(hipMemsetAsync(stg + off_idx, 0, 2 * (size_t)Rn * 8 + 8, c->st));
+	if (n) hipLaunchKernelGGL(k_arc_to_aos, dim3(grid_for(n, 256)), dim3(256), 0, c->st, arcs_of(c, c->ag), n, map, (asg_arc_t*)stg);
+	if (R) hipLaunchKernelGGL(k_seq_to_aos, dim3(grid_for(R, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->slen), (const uint8_t*)P<uint8_t>(c->sdel),
+	                          (const unsigned long long*)P<unsigned long long>(c->idx), map, R, (uint32_t*)(stg + off_seq), (unsigned long long*)(stg + off_idx));
+	HIPCHK(hipGetLastError());
+	g->arc = (asg_arc_t*)malloc((n ? n : 1) * sizeof(asg_arc_t));
+	g->seq = (asg_seq_t*)malloc(((size_t)Rn ? Rn : 1) * sizeof(asg_seq_t));
+	g->idx = (uint64_t*)malloc((2 * (size_t)Rn + 1) * 8);
+	if (!g->arc || !g->seq || !g->idx) { mahip_set_error("mahip_asg_download: out of host memory"); return -1; }
+	if (n) HIPCHK(hipMemcpyAsync(g->arc, stg, n * 16, hipMemcpyDeviceToHost, c->st));
+	if (Rn) HIPCHK(hipMemcpyAsync(g->seq, stg + off_seq, (size_t)Rn * 4, hipMemcpyDeviceToHost, c->st));
+	if (Rn) HIPCHK(hipMemcpyAsync(g->idx, stg + off_idx, 2 * (size_t)Rn * 8, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	g->n_arc = (uint32_t)n; g->m_arc = (uint32_t)(n ? n : 1);
+	g->n_seq = Rn; g->m_seq = Rn ? Rn : 1;
+	g->is_srt = 1;
+	return 0;
+}

@@ -1,0 +1,628 @@
+// hits.hip -- the hit ingest/filter passes of reference hit.c on SoA columns resident in HBM.
+//
+// Layout: 8 u32 columns [n_hits] (qid qs qe tn ts te ml|rev<<31 bl|dead<<31), grouped by query id after the
+// sort, goff[n_seq+1] = first slot of each query group.  Passes never move records: a removed hit gets its
+// dead bit set (the reference compacts in place after every pass; compaction here happens only at export),
+// so group boundaries stay valid from the sort to ma_sg_gen.  sub slots are uint2 {s | del<<31, e} = the
+// bits of ma_sub_t (reference miniasm.h:38-40).
+#include "mahip_internal.hpp"
+
+#define COL_QID 0
+#define COL_QS 1
+#define COL_QE 2
+#define COL_TN 3
+#define COL_TS 4
+#define COL_TE 5
+#define COL_ML 6
+#define COL_BL 7
+#define DEAD 0x80000000u
+
+// ------------------------------------------------------------------------------------------------ sort
+// keys for ma_hit_sort (hit.c:12-22: key = qns), value = input position; max qid / max qs for the digit plan.
+// Hits outside the shard [q_beg,q_end) get the all-ones key and sort to the tail.
+__global__ __launch_bounds__(256) void k_hit_keys(const ma_hit_t *__restrict__ h, size_t n, uint64_t *__restrict__ key,
+                                                   uint32_t *__restrict__ val, unsigned long long *__restrict__ ctr,
+                                                   uint32_t q_beg, uint32_t q_end)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	uint32_t mq = 0, ms = 0;
+	int in = 0;
+	if (i < n) {
+		uint64_t k = h[i].qns;
+		uint32_t q = (uint32_t)(k >> 32);
+		in = q >= q_beg && q < q_end;
+		if (in) mq = q, ms = (uint32_t)k; else k = ~0ull;
+		key[i] = k;
+		val[i] = (uint32_t)i;
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		uint32_t a = __shfl_xor(mq, o, 64), b = __shfl_xor(ms, o, 64);
+		mq = a > mq ? a : mq, ms = b > ms ? b : ms;
+	}
+	if ((threadIdx.x & 63) == 0) { atomicMax(&ctr[CT_MAXQID], (unsigned long long)mq); atomicMax(&ctr[CT_MAXQS], (unsigned long long)ms); }
+	wv_count_add(&ctr[CT_LIVE], in);
+}
+
+struct HitCols { uint32_t *qid, *qs, *qe, *tn, *ts, *te, *ml, *bl; };
+
+// AoS (input order) -> SoA (sorted order), one 32-byte record per lane as 2 x dwordx4; group offsets from
+// key boundaries.  perm == nullptr: identity (input already grouped).
+__global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__ h, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ skey,
+                                                     size_t n, uint32_t n_seq, HitCols c, uint32_t *__restrict__ goff)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i > n) return;
+	uint32_t q = n_seq, qprev = 0;
+	int first = (i == 0);
+	if (i < n) {
+		size_t j = perm ? perm[i] : i;
+		const uint4 *p = (const uint4*)(h + j);
+		uint4 a = p[0], b = p[1]; // a = {qs, qid, qe, tn}  b = {ts, te, ml|rev, bl|del}
+		q = a.y;
+		c.qid[i] = a.y; c.qs[i] = a.x; c.qe[i] = a.z; c.tn[i] = a.w;
+		c.ts[i] = b.x; c.te[i] = b.y; c.ml[i] = b.z; c.bl[i] = b.w & ~DEAD;
+	}
+	if (!first) qprev = skey ? (uint32_t)(skey[i - 1] >> 32) : (uint32_t)(h[i - 1].qns >> 32); // sorted keys, or the grouped input itself
+	// reads qprev+1 .. q start at slot i (reads without hits get empty groups)
+	uint32_t r0 = first ? 0 : qprev + 1;
+	if (q > n_seq) q = n_seq;
+	for (uint32_t r = r0; r <= q && r <= n_seq; ++r) goff[r] = (uint32_t)i;
+}
+
+// ------------------------------------------------------------------------------------------------ ma_hit_sub
+// reference hit.c:109-160.  One wave per query group: events (start<<1, end<<1|1) into LDS, wave bitonic
+// sort, depth sweep by ballot prefix counts, first-longest run with depth >= min_dp by a wave max-reduce.
+#define SUB_CAP 2048 // events per wave held in LDS
+
+template <typename EV, typename UP>
+__device__ __forceinline__ uint64_t sub_sweep(const EV ev, UP up, uint32_t nev, int min_dp, unsigned tid, unsigned stride_is_wave)
+{
+	// wave-only sweep over the sorted events; returns best = len<<32 | (~rank)
+	unsigned lane = tid & 63;
+	const uint64_t lt = wv_lt(lane), le = wv_le(lane);
+	int carry = 0;
+	uint32_t nup = 0, ndown = 0;
+	uint64_t best = 0;
+	for (uint32_t base = 0; base < nev; base += 64) {
+		uint32_t i = base + lane;
+		int valid = i < nev;
+		uint32_t e = valid ? ev[i] : 0;
+		int is_end = e & 1;
+		uint64_t ms = wv_ballot(valid && !is_end), me = wv_ballot(valid && is_end);
+		int dp = carry + __popcll(ms & le) - __popcll(me & le);
+		int old = dp - (is_end ? -1 : 1);
+		int isup = valid && old < min_dp && dp >= min_dp;
+		int isdn = valid && old >= min_dp && dp < min_dp;
+		uint64_t mu = wv_ballot(isup), md = wv_ballot(isdn);
+		uint32_t ur = nup + __popcll(mu & lt), dr = ndown + __popcll(md & lt);
+		if (isup) up[ur] = e >> 1;
+		wv_sync();
+		if (isdn) {
+			uint32_t len = (e >> 1) - up[dr];
+			uint64_t cand = (uint64_t)len << 32 | (0xffffffffu - dr);
+			best = cand > best ? cand : best;
+		}
+		carry += __popcll(ms) - __popcll(me);
+		nup += __popcll(mu), ndown += __popcll(md);
+		wv_sync();
+	}
+	return wv_max_u64(best);
+}
+
+__device__ __forceinline__ void sub_store(uint2 *sub, uint32_t q, uint64_t best, const uint32_t *up, int end_clip, int any_ev_group,
+                                          unsigned long long *ctr)
+{
+	uint32_t len = (uint32_t)(best >> 32);
+	if (len > 0) {
+		uint32_t s = up[0xffffffffu - (uint32_t)best];
+		sub[q] = make_uint2((s - (uint32_t)end_clip) & 0x7fffffffu, s + len + (uint32_t)end_clip);
+		atomicAdd(&ctr[CT_REMAIN], 1ull);
+	} else sub[q] = make_uint2(DEAD, 0);
+}
+
+__global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
+                                                  int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
+                                                  uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr)
+{
+	__shared__ uint32_t s_ev[4][SUB_CAP];
+	__shared__ uint32_t s_up[4][SUB_CAP / 2];
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint64_t lt = wv_lt(lane);
+	uint32_t *ev = s_ev[wave], *up = s_up[wave];
+	for (uint32_t q = blockIdx.x * 4 + wave; q < n_seq; q += gridDim.x * 4) {
+		uint32_t beg = goff[q], end = goff[q + 1];
+		if (beg == end) { if (lane == 0) sub[q] = make_uint2(0, 0); continue; } // never a query: calloc'ed zero (hit.c:115)
+		uint32_t nev = 0;
+		int any_live = 0;
+		for (uint32_t b = beg; b < end; b += 64) {
+			uint32_t i = b + lane;
+			int ok = 0, live = 0;
+			uint32_t es = 0, ee = 0;
+			if (i < end) {
+				uint32_t bl = c.bl[i];
+				live = !(bl & DEAD);
+				if (live) {
+					uint32_t ml = c.ml[i];
+					ok = mc_sub_ok(q, c.qs[i], c.qe[i], c.tn[i], (int32_t)(ml & 0x7fffffffu), (int32_t)bl, min_iden, end_clip, &es, &ee);
+				}
+			}
+			uint64_t m = wv_ballot(ok);
+			any_live |= wv_ballot(live) != 0;
+			uint32_t p = nev + 2 * (uint32_t)__popcll(m & lt);
+			if (ok && p + 1 < SUB_CAP) ev[p] = es, ev[p + 1] = ee;
+			nev += 2 * (uint32_t)__popcll(m);
+		}
+		if (!any_live) { if (lane == 0) sub[q] = make_uint2(0, 0); continue; } // no surviving hit: not a group for the reference
+		if (nev > SUB_CAP) { // oversized group: second tier
+			if (lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF], 1ull); ovf[k] = q; }
+			continue;
+		}
+		wv_sync();
+		MA_BITONIC(uint32_t, ev, nev, lane, 64, wv_sync());
+		uint64_t best = sub_sweep(ev, up, nev, min_dp, lane, 1);
+		if (lane == 0) sub_store(sub, q, best, up, end_clip, 1, ctr);
+		wv_sync();
+	}
+}
+
+// second tier: one 256-thread block per oversized group, events and run starts in global scratch
+// (ev at 2*goff[q], up at goff[q]: disjoint per group by construction)
+__global__ __launch_bounds__(256) void k_hit_sub_big(HitCols c, const uint32_t *__restrict__ goff, const uint32_t *__restrict__ ovf, uint32_t n_ovf,
+                                                      int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
+                                                      uint32_t *__restrict__ gev, uint32_t *__restrict__ gup, unsigned long long *__restrict__ ctr)
+{
+	__shared__ uint32_t s_n;
+	for (uint32_t k = blockIdx.x; k < n_ovf; k += gridDim.x) {
+		uint32_t q = ovf[k], beg = goff[q], end = goff[q + 1];
+		uint32_t *ev = gev + 2 * (size_t)beg, *up = gup + beg;
+		if (threadIdx.x == 0) s_n = 0;
+		__syncthreads();
+		for (uint32_t i = beg + threadIdx.x; i < end; i += 256) {
+			uint32_t bl = c.bl[i], es, ee;
+			if (bl & DEAD) continue;
+			if (mc_sub_ok(q, c.qs[i], c.qe[i], c.tn[i], (int32_t)(c.ml[i] & 0x7fffffffu), (int32_t)bl, min_iden, end_clip, &es, &ee)) {
+				uint32_t p = atomicAdd(&s_n, 2u); // order irrelevant: sorted next
+				ev[p] = es, ev[p + 1] = ee;
+			}
+		}
+		__syncthreads();
+		uint32_t nev = s_n;
+		MA_BITONIC(uint32_t, ev, nev, threadIdx.x, 256, __syncthreads());
+		if (threadIdx.x < 64) {
+			uint64_t best = sub_sweep(ev, up, nev, min_dp, threadIdx.x, 1);
+			if (threadIdx.x == 0) sub_store(sub, q, best, up, end_clip, 1, ctr);
+		}
+		__syncthreads();
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ ma_hit_cut
+// reference hit.c:162-193, one thread per hit; removed hits only get their dead bit
+__global__ __launch_bounds__(256) void k_hit_cut(HitCols c, size_t n, const uint2 *__restrict__ sub, int min_span, unsigned long long *__restrict__ ctr)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	int keep = 0;
+	if (i < n) {
+		uint32_t bl = c.bl[i];
+		if (!(bl & DEAD)) {
+			uint2 rq = sub[c.qid[i]], rt = sub[c.tn[i]];
+			if (!(rq.x & DEAD) && !(rt.x & DEAD)) {
+				uint32_t qs = c.qs[i], qe = c.qe[i], ts = c.ts[i], te = c.te[i];
+				keep = mc_cut(&qs, &qe, &ts, &te, c.ml[i] >> 31, (int32_t)rq.x, rq.y, (int32_t)rt.x, rt.y, min_span);
+				if (keep) c.qs[i] = qs, c.qe[i] = qe, c.ts[i] = ts, c.te[i] = te;
+			}
+			if (!keep) c.bl[i] = bl | DEAD;
+		}
+	}
+	wv_count_add(&ctr[CT_LIVE], keep);
+}
+
+// ------------------------------------------------------------------------------------------------ ma_hit_flt
+// reference hit.c:195-216 (int_frac is the literal .5 there); r_live[q] marks query groups that keep a hit
+__global__ __launch_bounds__(256) void k_hit_flt(HitCols c, size_t n, const uint2 *__restrict__ sub, int max_hang, int min_ovlp,
+                                                  uint8_t *__restrict__ r_live, unsigned long long *__restrict__ ctr)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	int keep = 0;
+	uint64_t dp = 0;
+	if (i < n) {
+		uint32_t bl = c.bl[i];
+		if (!(bl & DEAD)) {
+			uint32_t q = c.qid[i], t = c.tn[i];
+			uint2 sq = sub[q], st = sub[t];
+			if (!(sq.x & DEAD) && !(st.x & DEAD)) {
+				mc_arc_t a;
+				uint32_t ql = sq.y - (sq.x & 0x7fffffffu), tl = st.y - (st.x & 0x7fffffffu);
+				int r = mc_hit2arc(q, c.qs[i], c.qe[i], t, c.ts[i], c.te[i], c.ml[i] >> 31, (int)ql, (int)tl, max_hang, .5f, min_ovlp, &a);
+				if (r >= 0 || r == MC_HT_QCONT || r == MC_HT_TCONT) {
+					keep = 1;
+					dp = r >= 0 ? (uint32_t)r : r == MC_HT_QCONT ? ql : tl;
+					r_live[q] = 1;
+				}
+			}
+			if (!keep) c.bl[i] = bl | DEAD;
+		}
+	}
+	wv_count_add(&ctr[CT_LIVE], keep);
+	dp = wv_sum_u64(dp);
+	if ((threadIdx.x & 63) == 0 && dp) atomicAdd(&ctr[CT_TOTDP], (unsigned long long)dp);
+}
+
+__global__ __launch_bounds__(256) void k_flt_totlen(const uint2 *__restrict__ sub, const uint8_t *__restrict__ r_live, uint32_t n_seq, unsigned long long *__restrict__ ctr)
+{
+	uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	uint64_t x = 0;
+	if (r < n_seq && r_live[r]) { uint2 s = sub[r]; x = (uint32_t)(s.y - (s.x & 0x7fffffffu)); }
+	x = wv_sum_u64(x);
+	if ((threadIdx.x & 63) == 0 && x) atomicAdd(&ctr[CT_TOTLEN], (unsigned long long)x);
+}
+
+// ------------------------------------------------------------------------------------------------ ma_sub_merge
+// reference hit.c:218-223: a.e = a.s + b.e ; a.s += b.s  (a.del kept, b.del ignored; s is a 31-bit field)
+__global__ __launch_bounds__(256) void k_sub_merge(uint2 *__restrict__ a, const uint2 *__restrict__ b, uint32_t n_seq)
+{
+	uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	if (r < n_seq) {
+		uint2 x = a[r], y = b[r];
+		uint32_t as = x.x & 0x7fffffffu;
+		a[r] = make_uint2((x.x & DEAD) | ((as + (y.x & 0x7fffffffu)) & 0x7fffffffu), as + y.y);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ ma_hit_contained
+// reference hit.c:225-256.  Pass 1 (per hit): classify with the final thresholds, flag contained reads,
+// flag reads touched by any hit (hit.c:24-36).  Pass 2 (per read): del = sub.del | contained | seq.del | unused,
+// keep flags for the squeeze scan (sdict.c:69-86).  Pass 3 (per hit): drop hits that lost an endpoint.
+__global__ __launch_bounds__(256) void k_hit_contained(HitCols c, size_t n, const uint2 *__restrict__ sub, int max_hang, float int_frac, int min_ovlp,
+                                                        uint8_t *__restrict__ r_cont, uint8_t *__restrict__ r_used)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	if (c.bl[i] & DEAD) return;
+	uint32_t q = c.qid[i], t = c.tn[i];
+	uint2 sq = sub[q], st = sub[t];
+	mc_arc_t a;
+	int r = mc_hit2arc(q, c.qs[i], c.qe[i], t, c.ts[i], c.te[i], c.ml[i] >> 31, (int)(sq.y - (sq.x & 0x7fffffffu)),
+	                   (int)(st.y - (st.x & 0x7fffffffu)), max_hang, int_frac, min_ovlp, &a);
+	if (r == MC_HT_QCONT) r_cont[q] = 1;
+	else if (r == MC_HT_TCONT) r_cont[t] = 1;
+	r_used[q] = 1; r_used[t] = 1;
+}
+
+__global__ __launch_bounds__(256) void k_read_del(const uint2 *__restrict__ sub, const uint8_t *__restrict__ r_cont, const uint8_t *__restrict__ r_used,
+                                                   uint8_t *__restrict__ r_del, uint32_t *__restrict__ keep, uint32_t n_seq)
+{
+	uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	if (r < n_seq) {
+		int del = (sub[r].x >> 31) | r_cont[r] | r_del[r] | !r_used[r]; // r_del holds the caller's d->seq[].del on entry
+		r_del[r] = (uint8_t)del;
+		keep[r] = !del;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_map_fix(int32_t *__restrict__ map, const uint8_t *__restrict__ r_del, uint32_t n_seq)
+{
+	uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	if (r < n_seq && r_del[r]) map[r] = -1;
+}
+
+__global__ __launch_bounds__(256) void k_hit_squeeze(HitCols c, size_t n, const uint8_t *__restrict__ r_del, unsigned long long *__restrict__ ctr)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	int keep = 0;
+	if (i < n) {
+		uint32_t bl = c.bl[i];
+		if (!(bl & DEAD)) {
+			keep = !r_del[c.qid[i]] && !r_del[c.tn[i]];
+			if (!keep) c.bl[i] = bl | DEAD;
+		}
+	}
+	wv_count_add(&ctr[CT_LIVE], keep);
+}
+
+// ------------------------------------------------------------------------------------------------ export
+__global__ __launch_bounds__(256) void k_hit_keepflags(const uint32_t *__restrict__ bl, size_t n, uint32_t *__restrict__ keep)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) keep[i] = !(bl[i] & DEAD);
+}
+
+// live hits -> dense AoS in array order, ids renumbered through map (if any)
+__global__ __launch_bounds__(256) void k_hit_export(HitCols c, size_t n, const uint32_t *__restrict__ pos, const int32_t *__restrict__ map,
+                                                     ma_hit_t *__restrict__ out)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	uint32_t bl = c.bl[i];
+	if (bl & DEAD) return;
+	uint32_t q = c.qid[i], t = c.tn[i];
+	if (map) q = (uint32_t)map[q], t = (uint32_t)map[t];
+	uint4 *o = (uint4*)(out + pos[i]);
+	o[0] = make_uint4(c.qs[i], q, c.qe[i], t);
+	o[1] = make_uint4(c.ts[i], c.te[i], c.ml[i], bl);
+}
+
+__global__ __launch_bounds__(256) void k_sub_squeeze(const uint2 *__restrict__ sub, const int32_t *__restrict__ map, uint32_t n_seq, uint2 *__restrict__ out)
+{
+	uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	if (r < n_seq && map[r] >= 0) out[map[r]] = sub[r];
+}
+
+// ================================================================================================ host side
+
+static HitCols cols_of(mahip_ctx *c)
+{
+	HitCols h;
+	h.qid = P<uint32_t>(c->col[0]); h.qs = P<uint32_t>(c->col[1]); h.qe = P<uint32_t>(c->col[2]); h.tn = P<uint32_t>(c->col[3]);
+	h.ts = P<uint32_t>(c->col[4]); h.te = P<uint32_t>(c->col[5]); h.ml = P<uint32_t>(c->col[6]); h.bl = P<uint32_t>(c->col[7]);
+	return h;
+}
+
+static int reserve_read_arrays(mahip_ctx *c)
+{
+	size_t R = c->n_seq;
+	CHK(dev_reserve(c, c->goff, (R + 2) * 4));
+	for (int k = 0; k < 2; ++k) CHK(dev_reserve(c, c->sub[k], (R + 1) * 8));
+	CHK(dev_reserve(c, c->r_cont, R + 16)); CHK(dev_reserve(c, c->r_used, R + 16));
+	CHK(dev_reserve(c, c->r_del, R + 16)); CHK(dev_reserve(c, c->r_live, R + 16));
+	CHK(dev_reserve(c, c->map, (R + 1) * 4));
+	return 0;
+}
+
+static int hits_common_setup(mahip_ctx *c, size_t n, uint32_t n_seq)
+{
+	c->n_hits = n; c->n_live = n; c->n_seq = n_seq; c->n_seq_new = n_seq;
+	c->soa_ready = false; c->has_map = false; c->graph_ready = false;
+	CHK(reserve_read_arrays(c));
+	for (int k = 0; k < 8; ++k) CHK(dev_reserve(c, c->col[k], (n + 1) * 4));
+	return 0;
+}
+
+extern "C" int mahip_hits_upload(mahip_ctx_t *c, const ma_hit_t *h, size_t n, uint32_t n_seq)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	CHK(hits_common_setup(c, n, n_seq));
+	CHK(dev_reserve(c, c->aos_own, (n + 1) * sizeof(ma_hit_t)));
+	if (n) HIPCHK(hipMemcpyAsync(c->aos_own.p, h, n * sizeof(ma_hit_t), hipMemcpyHostToDevice, c->st));
+	c->d_aos = (const ma_hit_t*)c->aos_own.p;
+	return 0;
+}
+
+extern "C" int mahip_hits_adopt(mahip_ctx_t *c, const void *d_hits, size_t n, uint32_t n_seq)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	CHK(hits_common_setup(c, n, n_seq));
+	c->d_aos = (const ma_hit_t*)d_hits;
+	return 0;
+}
+
+extern "C" int mahip_set_shard(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end)
+{
+	c->q_beg = q_beg; c->q_end = q_end;
+	return 0;
+}
+
+static int bitlen(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
+
+extern "C" int mahip_hits_sort(mahip_ctx_t *c)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	size_t n = c->n_hits;
+	HitCols h = cols_of(c);
+	if (n == 0) {
+		HIPCHK(hipMemsetAsync(c->goff.p, 0, ((size_t)c->n_seq + 1) * 4, c->st));
+		c->soa_ready = true; c->n_live = 0;
+		return 0;
+	}
+	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (n + 1) * 8)); CHK(dev_reserve(c, c->val[k], (n + 1) * 4)); }
+	CHK(ctr_zero(c));
+	unsigned long long *ctr = P<unsigned long long>(c->ctr);
+	{
+		ProfScope ps(c, "k_hit_keys", 20.0 * (double)n); // reads qns (8 B), writes key+val (12 B)
+		hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]), ctr, c->q_beg, c->q_end);
+	}
+	CHK(ctr_fetch(c));
+	size_t n_in = (size_t)c->h_ctr[CT_LIVE];
+	int bq = bitlen(c->h_ctr[CT_MAXQID]), bs = bitlen(c->h_ctr[CT_MAXQS]);
+	int gen = 0;
+	if (n_in < n) bq = 32, bs = 32; // out-of-shard hits carry the all-ones key: sort every bit
+	CHK(radix_sort_pairs(c, n, 0, bs, 32, 32 + bq, &gen));
+	// out-of-shard hits sorted to the tail: drop them
+	c->n_hits = c->n_live = n = n_in;
+	{
+		ProfScope ps(c, "k_hit_gather", 76.0 * (double)n); // perm 4 + key 8 + record 32 + columns 32
+		hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint32_t*)P<uint32_t>(c->val[gen]), (const uint64_t*)P<uint64_t>(c->key[gen]), n, c->n_seq, h, P<uint32_t>(c->goff));
+	}
+	HIPCHK(hipGetLastError());
+	c->soa_ready = true;
+	return 0;
+}
+
+extern "C" int mahip_hits_index(mahip_ctx_t *c)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	size_t n = c->n_hits;
+	HitCols h = cols_of(c);
+	ProfScope ps(c, "k_hit_gather", 64.0 * (double)n);
+	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint32_t*)nullptr, (const uint64_t*)nullptr, n, c->n_seq, h, P<uint32_t>(c->goff));
+	HIPCHK(hipGetLastError());
+	c->soa_ready = true;
+	return 0;
+}
+
+extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int end_clip, int slot, size_t *n_remained)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->soa_ready) { mahip_set_error("mahip_hits_sub: hits not indexed"); return -1; }
+	HitCols h = cols_of(c);
+	uint32_t R = c->n_seq;
+	CHK(ctr_zero(c));
+	CHK(dev_reserve(c, c->ovf, ((size_t)R + 1) * 4));
+	unsigned long long *ctr = P<unsigned long long>(c->ctr);
+	uint2 *sub = P<uint2>(c->sub[slot]);
+	if (R) {
+		ProfScope ps(c, "k_hit_sub", 24.0 * (double)c->n_hits + 8.0 * R);
+		hipLaunchKernelGGL(k_hit_sub, dim3(grid_for(R, 4, 256 * 20)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		                   sub, P<uint32_t>(c->ovf), ctr);
+	}
+	CHK(ctr_fetch(c));
+	uint32_t n_ovf = (uint32_t)c->h_ctr[CT_OVF];
+	if (n_ovf) {
+		CHK(dev_reserve(c, c->big0, (2 * c->n_hits + 8) * 4));
+		CHK(dev_reserve(c, c->big1, (c->n_hits + 8) * 4));
+		ProfScope ps(c, "k_hit_sub_big", 0);
+		hipLaunchKernelGGL(k_hit_sub_big, dim3(n_ovf < 1024 ? n_ovf : 1024), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), (const uint32_t*)P<uint32_t>(c->ovf), n_ovf,
+		                   min_dp, min_iden, end_clip, sub, P<uint32_t>(c->big0), P<uint32_t>(c->big1), ctr);
+		CHK(ctr_fetch(c));
+	}
+	HIPCHK(hipGetLastError());
+	if (n_remained) *n_remained = (size_t)c->h_ctr[CT_REMAIN];
+	return 0;
+}
+
+extern "C" int mahip_hits_cut(mahip_ctx_t *c, int slot, int min_span, size_t *n_live)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->soa_ready) { mahip_set_error("mahip_hits_cut: hits not indexed"); return -1; }
+	size_t n = c->n_hits;
+	CHK(ctr_zero(c));
+	if (n) {
+		ProfScope ps(c, "k_hit_cut", 80.0 * (double)c->n_live); // 32 r + 2x8 sub look-ups + 32 w per hit
+		hipLaunchKernelGGL(k_hit_cut, dim3(grid_for(n, 256)), dim3(256), 0, c->st, cols_of(c), n, (const uint2*)P<uint2>(c->sub[slot]), min_span, P<unsigned long long>(c->ctr));
+	}
+	CHK(ctr_fetch(c));
+	c->n_live = (size_t)c->h_ctr[CT_LIVE];
+	if (n_live) *n_live = c->n_live;
+	return 0;
+}
+
+extern "C" int mahip_hits_flt(mahip_ctx_t *c, int slot, int max_hang, int min_ovlp, size_t *n_live, float *cov)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->soa_ready) { mahip_set_error("mahip_hits_flt: hits not indexed"); return -1; }
+	size_t n = c->n_hits;
+	uint32_t R = c->n_seq;
+	CHK(ctr_zero(c));
+	HIPCHK(hipMemsetAsync(c->r_live.p, 0, R, c->st));
+	if (n) {
+		ProfScope ps(c, "k_hit_flt", 80.0 * (double)c->n_live);
+		hipLaunchKernelGGL(k_hit_flt, dim3(grid_for(n, 256)), dim3(256), 0, c->st, cols_of(c), n, (const uint2*)P<uint2>(c->sub[slot]), max_hang, min_ovlp,
+		                   P<uint8_t>(c->r_live), P<unsigned long long>(c->ctr));
+	}
+	if (R) hipLaunchKernelGGL(k_flt_totlen, dim3(grid_for(R, 256)), dim3(256), 0, c->st, (const uint2*)P<uint2>(c->sub[slot]), (const uint8_t*)P<uint8_t>(c->r_live), R, P<unsigned long long>(c->ctr));
+	CHK(ctr_fetch(c));
+	c->n_live = (size_t)c->h_ctr[CT_LIVE];
+	if (n_live) *n_live = c->n_live;
+	if (cov) *cov = (float)((double)c->h_ctr[CT_TOTDP] / (double)c->h_ctr[CT_TOTLEN]); // hit.c:212
+	return 0;
+}
+
+extern "C" int mahip_sub_merge(mahip_ctx_t *c)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	uint32_t R = c->n_seq;
+	if (R) hipLaunchKernelGGL(k_sub_merge, dim3(grid_for(R, 256)), dim3(256), 0, c->st, P<uint2>(c->sub[0]), (const uint2*)P<uint2>(c->sub[1]), R);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int mahip_hits_contained(mahip_ctx_t *c, const ma_opt_t *opt, const uint8_t *seq_del, uint32_t *n_seq_new, size_t *n_live)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->soa_ready) { mahip_set_error("mahip_hits_contained: hits not indexed"); return -1; }
+	size_t n = c->n_hits;
+	uint32_t R = c->n_seq;
+	CHK(ctr_zero(c));
+	CHK(dev_reserve(c, c->keep, ((size_t)R + 16) * 4));
+	HIPCHK(hipMemsetAsync(c->r_cont.p, 0, R, c->st));
+	HIPCHK(hipMemsetAsync(c->r_used.p, 0, R, c->st));
+	if (seq_del) HIPCHK(hipMemcpyAsync(c->r_del.p, seq_del, R, hipMemcpyHostToDevice, c->st));
+	else HIPCHK(hipMemsetAsync(c->r_del.p, 0, R, c->st));
+	HitCols h = cols_of(c);
+	const uint2 *sub = P<uint2>(c->sub[0]);
+	if (n) {
+		ProfScope ps(c, "k_hit_contained", 48.0 * (double)c->n_live);
+		hipLaunchKernelGGL(k_hit_contained, dim3(grid_for(n, 256)), dim3(256), 0, c->st, h, n, sub, opt->max_hang, opt->int_frac, opt->min_ovlp,
+		                   P<uint8_t>(c->r_cont), P<uint8_t>(c->r_used));
+	}
+	uint32_t *d_tot = (uint32_t*)(P<unsigned long long>(c->ctr) + CT_TOTAL);
+	if (R) {
+		hipLaunchKernelGGL(k_read_del, dim3(grid_for(R, 256)), dim3(256), 0, c->st, sub, (const uint8_t*)P<uint8_t>(c->r_cont), (const uint8_t*)P<uint8_t>(c->r_used),
+		                   P<uint8_t>(c->r_del), P<uint32_t>(c->keep), R);
+		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), (uint32_t*)c->map.p, R, d_tot));
+		hipLaunchKernelGGL(k_map_fix, dim3(grid_for(R, 256)), dim3(256), 0, c->st, P<int32_t>(c->map), (const uint8_t*)P<uint8_t>(c->r_del), R);
+	}
+	if (n) {
+		ProfScope ps(c, "k_hit_squeeze", 72.0 * (double)c->n_live);
+		hipLaunchKernelGGL(k_hit_squeeze, dim3(grid_for(n, 256)), dim3(256), 0, c->st, h, n, (const uint8_t*)P<uint8_t>(c->r_del), P<unsigned long long>(c->ctr));
+	}
+	CHK(ctr_fetch(c));
+	c->n_live = (size_t)c->h_ctr[CT_LIVE];
+	c->n_seq_new = R ? (uint32_t)(c->h_ctr[CT_TOTAL] & 0xffffffffu) : 0;
+	c->has_map = true;
+	if (n_seq_new) *n_seq_new = c->n_seq_new;
+	if (n_live) *n_live = c->n_live;
+	return 0;
+}
+
+extern "C" int mahip_sub_upload(mahip_ctx_t *c, int slot, const ma_sub_t *sub, size_t n_sub)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (n_sub > c->n_seq) n_sub = c->n_seq;
+	HIPCHK(hipMemsetAsync(c->sub[slot].p, 0, (size_t)c->n_seq * 8, c->st));
+	if (n_sub) HIPCHK(hipMemcpyAsync(c->sub[slot].p, sub, n_sub * 8, hipMemcpyHostToDevice, c->st));
+	return 0;
+}
+
+extern "C" int mahip_sub_download(mahip_ctx_t *c, int slot, ma_sub_t *sub, int squeezed)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	uint32_t R = c->n_seq;
+	if (R == 0) return 0;
+	if (squeezed && c->has_map) {
+		CHK(dev_reserve(c, c->pos, ((size_t)R + 1) * 8));
+		hipLaunchKernelGGL(k_sub_squeeze, dim3(grid_for(R, 256)), dim3(256), 0, c->st, (const uint2*)P<uint2>(c->sub[slot]), (const int32_t*)P<int32_t>(c->map), R, P<uint2>(c->pos));
+		if (c->n_seq_new) HIPCHK(hipMemcpyAsync(sub, c->pos.p, (size_t)c->n_seq_new * 8, hipMemcpyDeviceToHost, c->st));
+	} else HIPCHK(hipMemcpyAsync(sub, c->sub[slot].p, (size_t)R * 8, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+extern "C" int mahip_seqdel_download(mahip_ctx_t *c, uint8_t *del)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (c->n_seq) HIPCHK(hipMemcpyAsync(del, c->r_del.p, c->n_seq, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+extern "C" int mahip_map_download(mahip_ctx_t *c, int32_t *map)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->has_map) { mahip_set_error("mahip_map_download: no squeeze map"); return -1; }
+	if (c->n_seq) HIPCHK(hipMemcpyAsync(map, c->map.p, (size_t)c->n_seq * 4, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+extern "C" size_t mahip_hits_live(mahip_ctx_t *c) { return c->n_live; }
+
+extern "C" int mahip_hits_download(mahip_ctx_t *c, ma_hit_t *out, size_t *n_out)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->soa_ready) { mahip_set_error("mahip_hits_download: hits not indexed"); return -1; }
+	size_t n = c->n_hits;
+	if (n_out) *n_out = c->n_live;
+	if (n == 0 || c->n_live == 0) return 0;
+	HitCols h = cols_of(c);
+	CHK(dev_reserve(c, c->keep, (n + 16) * 4));
+	CHK(dev_reserve(c, c->pos, (n + 16) * 4));
+	CHK(dev_reserve(c, c->key[0], (c->n_live + 1) * sizeof(ma_hit_t))); // staging for the dense AoS
+	hipLaunchKernelGGL(k_hit_keepflags, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint32_t*)h.bl, n, P<uint32_t>(c->keep));
+	CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), n, nullptr));
+	hipLaunchKernelGGL(k_hit_export, dim3(grid_for(n, 256)), dim3(256), 0, c->st, h, n, (const uint32_t*)P<uint32_t>(c->pos),
+	                   c->has_map ? (const int32_t*)P<int32_t>(c->map) : (const int32_t*)nullptr, (ma_hit_t*)c->key[0].p);
+	HIPCHK(hipMemcpyAsync(out, c->key[0].p, c->n_live * sizeof(ma_hit_t), hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}

@@ -1,0 +1,165 @@
+// mahip_api.hip -- context lifetime, device memory, counters and event-based kernel timing behind include/mahip.h
+#include "mahip_internal.hpp"
+#include <stdarg.h>
+
+static thread_local char g_err[1024] = "";
+
+void mahip_set_error(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+extern "C" const char *mahip_strerror(void) { return g_err; }
+
+extern "C" int mahip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int dev_reserve(mahip_ctx *c, DevBuf &b, size_t bytes)
+{
+	if (bytes <= b.cap) return 0;
+	if (b.p) { HIPCHK(hipStreamSynchronize(c->st)); HIPCHK(hipFree(b.p)); c->mem_bytes -= b.cap; b.p = nullptr; b.cap = 0; }
+	size_t want = (bytes + 255) & ~(size_t)255;
+	hipError_t e = hipMalloc(&b.p, want);
+	if (e != hipSuccess) { b.p = nullptr; mahip_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e)); return -1; }
+	b.cap = want;
+	c->mem_bytes += want;
+	return 0;
+}
+
+void dev_free(mahip_ctx *c, DevBuf &b)
+{
+	if (b.p) { (void)hipFree(b.p); c->mem_bytes -= b.cap; }
+	b.p = nullptr; b.cap = 0;
+}
+
+int ctr_zero(mahip_ctx *c)
+{
+	HIPCHK(hipMemsetAsync(c->ctr.p, 0, 64 * 8, c->st));
+	return 0;
+}
+
+int ctr_fetch(mahip_ctx *c)
+{
+	HIPCHK(hipMemcpyAsync(c->h_ctr, c->ctr.p, 64 * 8, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+extern "C" mahip_ctx_t *mahip_create(int device, void *stream)
+{
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) {
+		mahip_set_error("mahip_create: no HIP device available (%s); this library has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+		return nullptr;
+	}
+	if (device < 0 || device >= n) { mahip_set_error("mahip_create: device %d out of range (0..%d)", device, n - 1); return nullptr; }
+	if (hipSetDevice(device) != hipSuccess) { mahip_set_error("mahip_create: hipSetDevice(%d) failed", device); return nullptr; }
+	mahip_ctx *c = new mahip_ctx();
+	c->dev = device;
+	if (stream) c->st = (hipStream_t)stream, c->own_stream = false;
+	else {
+		if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { mahip_set_error("mahip_create: hipStreamCreate failed"); delete c; return nullptr; }
+		c->own_stream = true;
+	}
+	if (dev_reserve(c, c->ctr, 64 * 8) != 0) { delete c; return nullptr; }
+	if (hipHostMalloc((void**)&c->h_ctr, 64 * 8, hipHostMallocDefault) != hipSuccess) { mahip_set_error("mahip_create: hipHostMalloc failed"); delete c; return nullptr; }
+	memset(c->h_ctr, 0, 64 * 8);
+	return c;
+}
+
+extern "C" void mahip_destroy(mahip_ctx_t *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->dev);
+	(void)hipStreamSynchronize(c->st);
+	for (auto &e : c->pev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+	DevBuf *all[] = { &c->aos_own, &c->goff, &c->sub[0], &c->sub[1], &c->r_cont, &c->r_used, &c->r_del, &c->r_live, &c->map,
+		&c->au[0], &c->au[1], &c->av[0], &c->av[1], &c->alen[0], &c->alen[1], &c->aol[0], &c->aol[1], &c->idx, &c->sdel, &c->slen,
+		&c->keep, &c->pos, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->hist, &c->scan_tmp[0], &c->scan_tmp[1], &c->scan_tmp[2],
+		&c->ctr, &c->ovf, &c->big0, &c->big1, &c->marks };
+	for (DevBuf *b : all) dev_free(c, *b);
+	for (int k = 0; k < 8; ++k) dev_free(c, c->col[k]);
+	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+	if (c->own_stream) (void)hipStreamDestroy(c->st);
+	delete c;
+}
+
+extern "C" int mahip_sync(mahip_ctx_t *c)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+extern "C" size_t mahip_mem_bytes(mahip_ctx_t *c) { return c->mem_bytes; }
+
+extern "C" void *mahip_devptr(mahip_ctx_t *c, int which, size_t *bytes)
+{
+	DevBuf *b = which == MAHIP_PTR_SUB0 ? &c->sub[0] : which == MAHIP_PTR_SUB1 ? &c->sub[1] : which == MAHIP_PTR_RDFLAG ? &c->r_del : nullptr;
+	if (!b) return nullptr;
+	if (bytes) *bytes = which == MAHIP_PTR_RDFLAG ? (size_t)c->n_seq : (size_t)c->n_seq * 8;
+	return b->p;
+}
+
+// ---- profiling: an event pair per instrumented launch, resolved lazily ----
+void prof_begin(mahip_ctx *c, const char *name, double alg_bytes)
+{
+	ProfEvent e;
+	e.name = name; e.alg_bytes = alg_bytes;
+	if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+	(void)hipEventRecord(e.a, c->st);
+	c->pstack.push_back(c->pev.size());
+	c->pev.push_back(e);
+}
+
+void prof_end(mahip_ctx *c)
+{
+	if (c->pstack.empty()) return; // scopes may nest (a compaction contains a scan)
+	size_t k = c->pstack.back();
+	c->pstack.pop_back();
+	(void)hipEventRecord(c->pev[k].b, c->st);
+}
+
+int prof_collect(mahip_ctx *c)
+{
+	HIPCHK(hipStreamSynchronize(c->st));
+	for (auto &e : c->pev) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) ms = 0;
+		size_t k;
+		for (k = 0; k < c->pacc.size(); ++k) if (strcmp(c->pacc[k].name, e.name) == 0) break;
+		if (k == c->pacc.size()) { ProfAcc a; a.name = e.name; a.launches = 0; a.ms = 0; a.alg_bytes = 0; c->pacc.push_back(a); }
+		c->pacc[k].launches += 1; c->pacc[k].ms += ms; c->pacc[k].alg_bytes += e.alg_bytes;
+		(void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+	}
+	c->pev.clear();
+	return 0;
+}
+
+extern "C" int mahip_prof_enable(mahip_ctx_t *c, int enable) { c->prof = enable != 0; return 0; }
+
+extern "C" int mahip_prof_reset(mahip_ctx_t *c)
+{
+	CHK(prof_collect(c));
+	c->pacc.clear();
+	return 0;
+}
+
+extern "C" int mahip_prof_get(mahip_ctx_t *c, mahip_prof_t *out, int max)
+{
+	if (prof_collect(c) != 0) return -1;
+	int n = (int)c->pacc.size();
+	for (int i = 0; i < n && i < max; ++i) {
+		out[i].name = c->pacc[i].name; out[i].launches = c->pacc[i].launches;
+		out[i].total_ms = c->pacc[i].ms; out[i].alg_bytes = c->pacc[i].alg_bytes;
+	}
+	return n;
+}

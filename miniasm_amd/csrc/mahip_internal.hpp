@@ -1,0 +1,170 @@
+// mahip_internal.hpp -- context, device buffers, wave64 helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <string>
+#include "mahip.h"
+#include "ma_core.h"
+
+void mahip_set_error(const char *fmt, ...);
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+	mahip_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); return -1; } } while (0)
+#define CHK(expr) do { int r_ = (expr); if (r_ != 0) return r_; } while (0)
+
+// ---- grow-only device buffer ----
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+};
+
+struct ProfEvent { const char *name; hipEvent_t a, b; double alg_bytes; };
+struct ProfAcc { const char *name; uint64_t launches; double ms; double alg_bytes; };
+
+struct mahip_ctx {
+	int dev = 0;
+	hipStream_t st = nullptr;
+	bool own_stream = false;
+	size_t mem_bytes = 0;
+
+	// ---- hits ----
+	size_t n_hits = 0;        // slots (live + dead)
+	size_t n_live = 0;
+	uint32_t n_seq = 0;       // reads, original numbering
+	uint32_t q_beg = 0, q_end = 0xffffffffu; // shard
+	const ma_hit_t *d_aos = nullptr; // input records (adopted or aos_own)
+	DevBuf aos_own;
+	DevBuf col[8];            // qid qs qe tn ts te mlrev bl(dead<<31)
+	DevBuf goff;              // [n_seq+1]
+	DevBuf sub[2];            // uint2 [n_seq]   word0 = s | del<<31, word1 = e
+	DevBuf r_cont, r_used, r_del, r_live; // u8 [n_seq]
+	DevBuf map;               // int32 [n_seq]
+	bool soa_ready = false, has_map = false;
+	uint32_t n_seq_new = 0;
+
+	// ---- arcs (dense SoA, two generations for compaction) ----
+	DevBuf au[2], av[2], alen[2], aol[2]; // u32 [n_arc]   aol MSB = del
+	int ag = 0;               // current generation
+	uint32_t n_arc = 0;
+	DevBuf idx;               // u64 [2*n_seq]  start<<32 | count
+	DevBuf sdel;              // u8 [n_seq] seq.del
+	DevBuf slen;              // u32 [n_seq] seq.len
+	bool graph_ready = false;
+
+	// ---- scratch ----
+	DevBuf keep, pos;         // u32 flags / scanned positions
+	DevBuf key[2], val[2];    // radix sort ping-pong
+	DevBuf hist;              // radix block histograms
+	DevBuf scan_tmp[3];       // scan levels
+	DevBuf ctr;               // u64 [64] device counters
+	DevBuf ovf;               // overflow lists
+	DevBuf big0, big1;        // lazily allocated global scratch for oversized groups
+	DevBuf marks;             // trans-reduce tier-2 mark arrays
+	uint64_t *h_ctr = nullptr; // pinned host mirror of ctr
+
+	// ---- profiling ----
+	bool prof = false;
+	std::vector<ProfEvent> pev;
+	std::vector<size_t> pstack;
+	std::vector<ProfAcc> pacc;
+};
+
+int dev_reserve(mahip_ctx *c, DevBuf &b, size_t bytes);
+void dev_free(mahip_ctx *c, DevBuf &b);
+void prof_begin(mahip_ctx *c, const char *name, double alg_bytes);
+void prof_end(mahip_ctx *c);
+int prof_collect(mahip_ctx *c);
+
+struct ProfScope {
+	mahip_ctx *c;
+	ProfScope(mahip_ctx *c_, const char *name, double alg_bytes) : c(c_) { if (c->prof) prof_begin(c, name, alg_bytes); }
+	~ProfScope() { if (c->prof) prof_end(c); }
+};
+
+template <typename T> static inline T *P(DevBuf &b) { return (T*)b.p; }
+
+// counters (indices into ctx->ctr)
+enum { CT_LIVE = 0, CT_REMAIN, CT_TOTDP, CT_TOTLEN, CT_OVF, CT_NRED, CT_NMULTI, CT_NASYMM, CT_NSHORT, CT_MAXQID, CT_MAXQS, CT_TOTAL, CT_OVF2, CT_MAXLEN, CT_N };
+int ctr_zero(mahip_ctx *c);
+int ctr_fetch(mahip_ctx *c); // D2H + sync into c->h_ctr
+
+// ---- primitives (scan.hip / radix.hip) ----
+// exclusive prefix sum of n u32; if d_total != nullptr the grand total is written there (may alias out+n)
+int scan_exclusive_u32(mahip_ctx *c, const uint32_t *in, uint32_t *out, size_t n, uint32_t *d_total);
+// stable LSD radix sort of (u64 key, u32 val) pairs on key bits [lo0,hi0) and [lo1,hi1); result in key[*gen], val[*gen]
+int radix_sort_pairs(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1, int *gen);
+
+static inline unsigned grid_for(size_t n, unsigned per_block, unsigned cap = 0x7fffffffu)
+{
+	size_t g = (n + per_block - 1) / per_block;
+	if (g < 1) g = 1;
+	if (g > cap) g = cap;
+	return (unsigned)g;
+}
+
+// ---- wave64 device helpers ----
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned wv_lane() { return __lane_id(); }
+__device__ __forceinline__ uint64_t wv_lt(unsigned lane) { return (1ull << lane) - 1ull; }
+__device__ __forceinline__ uint64_t wv_le(unsigned lane) { return lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull); }
+__device__ __forceinline__ uint64_t wv_ballot(int p) { return __ballot(p); }
+// make LDS/global writes of this wave visible to its other lanes, and stop the compiler from reordering
+__device__ __forceinline__ void wv_sync()
+{
+	// workgroup scope: also drains this wave's outstanding LDS/global stores (s_waitcnt), which the
+	// global-scratch second tiers rely on; the L1 is per CU and write-through, so no invalidate is needed
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ uint32_t wv_bcast(uint32_t x, int src) { return __shfl(x, src, 64); }
+__device__ __forceinline__ uint64_t wv_max_u64(uint64_t x)
+{
+	for (int o = 32; o > 0; o >>= 1) {
+		uint32_t lo = __shfl_xor((uint32_t)x, o, 64), hi = __shfl_xor((uint32_t)(x >> 32), o, 64);
+		uint64_t y = (uint64_t)hi << 32 | lo;
+		x = y > x ? y : x;
+	}
+	return x;
+}
+__device__ __forceinline__ uint32_t wv_sum_u32(uint32_t x)
+{
+	for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+	return x;
+}
+__device__ __forceinline__ uint64_t wv_sum_u64(uint64_t x)
+{
+	for (int o = 32; o > 0; o >>= 1) {
+		uint32_t lo = __shfl_xor((uint32_t)x, o, 64), hi = __shfl_xor((uint32_t)(x >> 32), o, 64);
+		x += (uint64_t)hi << 32 | lo;
+	}
+	return x;
+}
+// one atomicAdd per wave of the number of lanes with p set
+__device__ __forceinline__ void wv_count_add(unsigned long long *ctr, int p)
+{
+	uint64_t m = __ballot(p);
+	if (m && wv_lane() == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(ctr, (unsigned long long)__popcll(m));
+}
+
+// All-ascending bitonic network on a[0..n) (n need not be a power of two: indices >= n act as +inf).
+// STRIDE threads cooperate (tid in [0,STRIDE)); SYNC() separates the stages.
+#define MA_BITONIC(T, a, n, tid, STRIDE, SYNC) do { \
+	uint32_t P_ = 1; while (P_ < (uint32_t)(n)) P_ <<= 1; \
+	for (uint32_t k_ = 2; k_ <= P_; k_ <<= 1) { \
+		{ uint32_t h_ = k_ >> 1; \
+		  for (uint32_t t_ = (tid); t_ < (P_ >> 1); t_ += (STRIDE)) { \
+			uint32_t lo_ = (t_ / h_) * k_ + (t_ % h_), hi_ = lo_ ^ (k_ - 1); \
+			if (hi_ < (uint32_t)(n)) { T x_ = (a)[lo_], y_ = (a)[hi_]; if (y_ < x_) (a)[lo_] = y_, (a)[hi_] = x_; } \
+		  } SYNC; } \
+		for (uint32_t j_ = k_ >> 2; j_ > 0; j_ >>= 1) { \
+		  for (uint32_t t_ = (tid); t_ < (P_ >> 1); t_ += (STRIDE)) { \
+			uint32_t lo_ = ((t_ & ~(j_ - 1)) << 1) | (t_ & (j_ - 1)), hi_ = lo_ | j_; \
+			if (hi_ < (uint32_t)(n)) { T x_ = (a)[lo_], y_ = (a)[hi_]; if (y_ < x_) (a)[lo_] = y_, (a)[hi_] = x_; } \
+		  } SYNC; } \
+	} } while (0)
+#endif

@@ -1,0 +1,35 @@
+/* ma_host.h -- internal declarations shared by the host C files (not part of the drop-in ABI) */
+#ifndef MA_HOST_H
+#define MA_HOST_H
+
+#include "miniasm_amd.h"
+#include "mahip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* log sink of the [M::...] lines (stderr unless redirected; bench.py silences it) */
+extern FILE *ma_log_fp;
+#define MA_LOG (ma_log_fp ? ma_log_fp : stderr)
+void ma_set_log_path(const char *path);
+
+/* everything after ingest, hits resident in HBM (pipeline.c) */
+int ma_pipeline_device(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, FILE *out);
+
+/* the process-wide GPU context of the per-symbol entry points; exits with an error if no GPU is usable */
+mahip_ctx_t *ma_gpu(void);
+void ma_gpu_fail(const char *where); /* prints mahip_strerror() and exits */
+
+int ma_paf_parse_line(int l, char *s, paf_rec_t *pr);
+
+/* ingest without the sort: reference hit.c:70-101 (everything of ma_hit_read before ma_hit_sort) */
+ma_hit_t *ma_hit_ingest(const char *fn, int min_span, int min_match, sdict_t *d, size_t *n, int bi_dir, const sdict_t *excl);
+
+/* literal emulation of the reference's in-place MSD radix sort (ksort.h:134-183) on arcs keyed by ul */
+void ma_refsort_arcs(asg_arc_t *beg, asg_arc_t *end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

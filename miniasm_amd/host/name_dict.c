@@ -1,0 +1,122 @@
+/* sdict.c -- read-name <-> dense id dictionary (reference sdict.h:21-25, sdict.c:27-86).
+ *
+ * Contract kept from the reference: ids are dense and assigned in order of first appearance; the first
+ * length seen for a name wins; sd_squeeze() drops reads flagged del, renumbers the rest in order, frees
+ * the dropped names, rebuilds the index and returns a calloc'ed old->new map (-1 = dropped).
+ * The index itself is our own: open addressing over (hash, id) slots with linear probing, FNV-1a hash,
+ * names compared through seq[id].name -- only the resulting mapping is observable.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "miniasm_amd.h"
+
+typedef struct {
+	uint32_t n_slot, n_used; /* n_slot is a power of two */
+	uint32_t *id;            /* id+1, 0 = empty */
+	uint32_t *hv;            /* cached hash */
+} sd_index_t;
+
+static inline uint32_t sd_hash_str(const char *s)
+{
+	uint32_t h = 2166136261u;
+	for (; *s; ++s) h = (h ^ (uint8_t)*s) * 16777619u;
+	return h;
+}
+
+static sd_index_t *ix_new(uint32_t n_slot)
+{
+	sd_index_t *ix = (sd_index_t*)calloc(1, sizeof(sd_index_t));
+	ix->n_slot = n_slot;
+	ix->id = (uint32_t*)calloc(n_slot, 4);
+	ix->hv = (uint32_t*)malloc((size_t)n_slot * 4);
+	return ix;
+}
+
+static void ix_free(sd_index_t *ix)
+{
+	if (!ix) return;
+	free(ix->id); free(ix->hv); free(ix);
+}
+
+static void ix_insert_raw(sd_index_t *ix, uint32_t h, uint32_t id)
+{
+	uint32_t m = ix->n_slot - 1, s = h & m;
+	while (ix->id[s]) s = (s + 1) & m;
+	ix->id[s] = id + 1; ix->hv[s] = h;
+	++ix->n_used;
+}
+
+static void ix_grow(sd_index_t *ix)
+{
+	uint32_t i, old_n = ix->n_slot, *oid = ix->id, *ohv = ix->hv;
+	ix->n_slot <<= 1; ix->n_used = 0;
+	ix->id = (uint32_t*)calloc(ix->n_slot, 4);
+	ix->hv = (uint32_t*)malloc((size_t)ix->n_slot * 4);
+	for (i = 0; i < old_n; ++i)
+		if (oid[i]) ix_insert_raw(ix, ohv[i], oid[i] - 1);
+	free(oid); free(ohv);
+}
+
+sdict_t *sd_init(void)
+{
+	sdict_t *d = (sdict_t*)calloc(1, sizeof(sdict_t));
+	d->h = ix_new(1024);
+	return d;
+}
+
+void sd_destroy(sdict_t *d)
+{
+	uint32_t i;
+	if (d == 0) return;
+	ix_free((sd_index_t*)d->h);
+	for (i = 0; i < d->n_seq; ++i) free(d->seq[i].name);
+	free(d->seq);
+	free(d);
+}
+
+int32_t sd_get(const sdict_t *d, const char *name)
+{
+	const sd_index_t *ix = (const sd_index_t*)d->h;
+	uint32_t h = sd_hash_str(name), m, s;
+	if (ix == 0) return -1;
+	m = ix->n_slot - 1;
+	for (s = h & m; ix->id[s]; s = (s + 1) & m)
+		if (ix->hv[s] == h && strcmp(d->seq[ix->id[s] - 1].name, name) == 0) return (int32_t)(ix->id[s] - 1);
+	return -1;
+}
+
+int32_t sd_put(sdict_t *d, const char *name, uint32_t len)
+{
+	sd_index_t *ix = (sd_index_t*)d->h;
+	uint32_t h = sd_hash_str(name), m = ix->n_slot - 1, s;
+	sd_seq_t *q;
+	for (s = h & m; ix->id[s]; s = (s + 1) & m)
+		if (ix->hv[s] == h && strcmp(d->seq[ix->id[s] - 1].name, name) == 0) return (int32_t)(ix->id[s] - 1);
+	if (d->n_seq == d->m_seq) {
+		d->m_seq = d->m_seq ? d->m_seq << 1 : 16;
+		d->seq = (sd_seq_t*)realloc(d->seq, (size_t)d->m_seq * sizeof(sd_seq_t));
+	}
+	q = &d->seq[d->n_seq];
+	q->name = strdup(name); q->len = len; q->aux = 0; q->del = 0;
+	ix->id[s] = d->n_seq + 1; ix->hv[s] = h;
+	if (++ix->n_used > (ix->n_slot >> 1) + (ix->n_slot >> 3)) ix_grow(ix);
+	return (int32_t)d->n_seq++;
+}
+
+int32_t *sd_squeeze(sdict_t *d)
+{
+	int32_t *map = (int32_t*)calloc(d->n_seq ? d->n_seq : 1, 4);
+	uint32_t i, j, n_slot = 1024;
+	sd_index_t *ix;
+	ix_free((sd_index_t*)d->h);
+	for (i = j = 0; i < d->n_seq; ++i) {
+		if (d->seq[i].del) { free(d->seq[i].name); map[i] = -1; }
+		else { d->seq[j] = d->seq[i]; map[i] = (int32_t)j++; }
+	}
+	d->n_seq = j;
+	while (n_slot < 2 * (uint64_t)j + 16) n_slot <<= 1;
+	ix = ix_new(n_slot);
+	for (i = 0; i < j; ++i) ix_insert_raw(ix, sd_hash_str(d->seq[i].name), i);
+	d->h = ix;
+	return map;
+}

@@ -1,0 +1,221 @@
+/* pipeline.c -- the whole hot path with the hits resident in HBM between passes.
+ *
+ * Mirrors the driver logic of the reference's main.c:108-199 (steps, -S stage gates, -p output modes, log
+ * lines) but never brings the hits back to the host: ingest (host) -> upload -> sort -> sub/cut/flt ->
+ * sub/cut/merge/contained -> ma_sg_gen -> transitive reduction + symm (all HIP, data stays in HBM) ->
+ * download of the small reduced graph -> sequential cleaners, unitigs and GFA text (host).
+ *
+ * ma_pipeline_device() is the part after ingest; bench.py times exactly that function with the unsorted hit
+ * records already sitting in HBM.
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "ma_host.h"
+
+#define GPU(call) do { if ((call) != 0) ma_gpu_fail(__func__); } while (0)
+
+FILE *ma_log_fp = 0;
+
+void ma_set_log_path(const char *path)
+{
+	if (ma_log_fp && ma_log_fp != stderr) fclose(ma_log_fp);
+	ma_log_fp = path && *path ? fopen(path, "w") : 0;
+}
+
+static void print_subs(const sdict_t *d, const ma_sub_t *sub, FILE *out) /* main.c:13-19 */
+{
+	uint32_t i;
+	for (i = 0; i < d->n_seq; ++i)
+		if (!d->seq[i].del && sub[i].s != sub[i].e)
+			fprintf(out, "%s\t%d\t%d\n", d->seq[i].name, sub[i].s, sub[i].e);
+}
+
+static void print_hits(size_t n_hits, const ma_hit_t *hit, const sdict_t *d, const ma_sub_t *sub, FILE *out) /* main.c:21-30 */
+{
+	size_t i;
+	for (i = 0; i < n_hits; ++i) {
+		const ma_hit_t *p = &hit[i];
+		const ma_sub_t *rq = &sub[p->qns >> 32], *rt = &sub[p->tn];
+		fprintf(out, "%s:%d-%d\t%d\t%d\t%d\t%c\t%s:%d-%d\t%d\t%d\t%d\t%d\t%d\t255\n", d->seq[p->qns >> 32].name, rq->s + 1, rq->e, rq->e - rq->s,
+				(uint32_t)p->qns, p->qe, "+-"[p->rev], d->seq[p->tn].name, rt->s + 1, rt->e, rt->e - rt->s, p->ts, p->te, p->ml, p->bl);
+	}
+}
+
+/* Everything after ingest.  c holds n unsorted hits (uploaded or adopted) over the reads of d.
+ * d is not modified: after containment removal a shallow view of the surviving reads is used for output.
+ * flags as in ma_pipeline_run.  Returns the number of input hits processed. */
+int ma_pipeline_device(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, FILE *out)
+{
+	int no_first = flags & 1, no_second = flags & 2, have_sub = 0, squeezed = 0, i;
+	size_t n_hits = 0, n_rem = 0;
+	uint32_t R = d->n_seq, n_seq_new = R;
+	float cov = 40.0f;
+	sdict_t view; /* surviving reads: names shared with d */
+	ma_sub_t *sub = 0;
+	FILE *lg = MA_LOG;
+
+	memset(&view, 0, sizeof(view));
+	view.n_seq = R; view.seq = d->seq;
+	GPU(mahip_hits_sort(c)); /* hit.c:104 */
+
+	if (!no_first) {
+		fprintf(lg, "[M::%s] ===> Step 2: 1-pass (crude) read selection <===\n", "main");
+		if (stage >= 2) {
+			GPU(mahip_hits_sub(c, opt->min_dp, opt->min_iden, 0, 0, &n_rem));
+			if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)n_rem);
+			GPU(mahip_hits_cut(c, 0, opt->min_span, &n_hits));
+			if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld hits remain after cut\n", "ma_hit_cut", sys_timestamp(), (long)n_hits);
+			have_sub = 1;
+		}
+		if (stage >= 3) {
+			GPU(mahip_hits_flt(c, 0, (int)(opt->max_hang * 1.5), (int)(opt->min_ovlp * .5), &n_hits, &cov)); /* main.c:125 */
+			if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld hits remain after filtering; crude coverage after filtering: %.2f\n", "ma_hit_flt", sys_timestamp(), (long)n_hits, cov);
+		}
+	}
+	if (!no_second) {
+		fprintf(lg, "[M::%s] ===> Step 3: 2-pass (fine) read selection <===\n", "main");
+		if (stage >= 4) {
+			int slot = no_first ? 0 : 1;
+			GPU(mahip_hits_sub(c, opt->min_dp, opt->min_iden, opt->min_span / 2, slot, &n_rem));
+			if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)n_rem);
+			GPU(mahip_hits_cut(c, slot, opt->min_span, &n_hits));
+			if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld hits remain after cut\n", "ma_hit_cut", sys_timestamp(), (long)n_hits);
+			if (!no_first) GPU(mahip_sub_merge(c));
+			have_sub = 1;
+		}
+		if (stage >= 5 && have_sub) {
+			uint8_t *del = (uint8_t*)malloc(R ? R : 1);
+			uint32_t r, k;
+			GPU(mahip_hits_contained(c, opt, 0, &n_seq_new, &n_hits));
+			GPU(mahip_seqdel_download(c, del));
+			view.seq = (sd_seq_t*)malloc((n_seq_new ? n_seq_new : 1) * sizeof(sd_seq_t));
+			for (r = k = 0; r < R; ++r)
+				if (!del[r]) view.seq[k] = d->seq[r], view.seq[k].del = 0, view.seq[k].aux = 0, ++k;
+			view.n_seq = k; squeezed = 1;
+			free(del);
+			if (k != n_seq_new) { fprintf(stderr, "[E::%s] squeeze mismatch: host %u vs device %u\n", __func__, k, n_seq_new); exit(1); }
+			if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %d sequences and %ld hits remain after containment removal\n", "ma_hit_contained", sys_timestamp(), n_seq_new, (long)n_hits);
+		}
+	}
+	if (have_sub) {
+		sub = (ma_sub_t*)calloc(R ? R : 1, sizeof(ma_sub_t));
+		GPU(mahip_sub_download(c, 0, sub, squeezed));
+	}
+
+	if (strcmp(outfmt, "bed") == 0) {
+		if (sub) print_subs(&view, sub, out);
+	} else if (strcmp(outfmt, "paf") == 0) {
+		size_t m = mahip_hits_live(c);
+		ma_hit_t *hit = (ma_hit_t*)malloc((m ? m : 1) * sizeof(ma_hit_t));
+		GPU(mahip_hits_download(c, hit, &m));
+		if (sub) print_hits(m, hit, &view, sub, out);
+		free(hit);
+	} else if (strcmp(outfmt, "ug") == 0 || strcmp(outfmt, "sg") == 0) {
+		asg_t *sg = asg_init();
+		ma_ug_t *ug = 0;
+		uint32_t n_arc = 0, n_red = 0, *len = 0;
+		uint8_t *sdel = 0;
+		fprintf(lg, "[M::%s] ===> Step 4: graph cleaning <===\n", "main");
+		if (!have_sub) {
+			uint32_t r;
+			len = (uint32_t*)malloc((R ? R : 1) * 4);
+			for (r = 0; r < R; ++r) len[r] = d->seq[r].len;
+		}
+		if (!squeezed) {
+			uint32_t r;
+			sdel = (uint8_t*)malloc(R ? R : 1);
+			for (r = 0; r < R; ++r) sdel[r] = d->seq[r].del;
+		}
+		GPU(mahip_sg_gen(c, opt, have_sub, len, sdel, &n_arc));
+		free(len); free(sdel);
+		fprintf(lg, "[M::%s] read %d arcs\n", "ma_sg_gen", n_arc);
+		if (stage >= 6) {
+			fprintf(lg, "[M::%s] ===> Step 4.1: transitive reduction <===\n", "main");
+			GPU(mahip_asg_del_trans(c, opt->gap_fuzz, &n_red));
+			fprintf(lg, "[M::%s] transitively reduced %d arcs\n", "asg_arc_del_trans", n_red);
+			if (n_red) {
+				uint32_t n_multi = 0, n_asymm = 0;
+				GPU(mahip_asg_symm(c, &n_multi, &n_asymm));
+				fprintf(lg, "[M::%s] removed %d multi-arcs\n", "asg_arc_del_multi", n_multi);
+				fprintf(lg, "[M::%s] removed %d asymmetric arcs\n", "asg_arc_del_asymm", n_asymm);
+			}
+		}
+		GPU(mahip_asg_download(c, sg)); /* the reduced graph is small: the sequential cleaners run on the host */
+		sg->is_symm = n_red > 0;
+		if (stage >= 7) {
+			fprintf(lg, "[M::%s] ===> Step 4.2: initial tip cutting and bubble popping <===\n", "main");
+			asg_cut_tip(sg, opt->max_ext);
+			asg_pop_bubble(sg, opt->bub_dist);
+		}
+		if (stage >= 9) {
+			fprintf(lg, "[M::%s] ===> Step 4.3: cutting short overlaps (%d rounds in total) <===\n", "main", opt->n_rounds + 1);
+			for (i = 0; i <= opt->n_rounds; ++i) {
+				float r = opt->min_ovlp_drop_ratio + (opt->max_ovlp_drop_ratio - opt->min_ovlp_drop_ratio) / opt->n_rounds * i;
+				if (asg_arc_del_short(sg, r) != 0) {
+					asg_cut_tip(sg, opt->max_ext);
+					asg_pop_bubble(sg, opt->bub_dist);
+				}
+			}
+		}
+		if (stage >= 10) {
+			fprintf(lg, "[M::%s] ===> Step 4.4: removing short internal sequences and bi-loops <===\n", "main");
+			asg_cut_internal(sg, 1);
+			asg_cut_biloop(sg, opt->max_ext);
+			asg_cut_tip(sg, opt->max_ext);
+			asg_pop_bubble(sg, opt->bub_dist);
+		}
+		if (stage >= 11) {
+			fprintf(lg, "[M::%s] ===> Step 4.5: aggressively cutting short overlaps <===\n", "main");
+			if (asg_arc_del_short(sg, opt->final_ovlp_drop_ratio) != 0) {
+				asg_cut_tip(sg, opt->max_ext);
+				asg_pop_bubble(sg, opt->bub_dist);
+			}
+		}
+		if (strcmp(outfmt, "ug") == 0) {
+			fprintf(lg, "[M::%s] ===> Step 5: generating unitigs <===\n", "main");
+			ug = ma_ug_gen(sg);
+			ma_ug_print(ug, &view, sub, out);
+		} else ma_sg_print(sg, &view, sub, out);
+		asg_destroy(sg);
+		ma_ug_destroy(ug);
+	}
+	free(sub);
+	if (squeezed) free(view.seq);
+	return 0;
+}
+
+/* same, with the output text returned in a malloc'ed buffer (bench.py / tests) */
+int ma_pipeline_device_mem(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, char **buf, size_t *len)
+{
+	FILE *fp = open_memstream(buf, len);
+	int rc;
+	if (fp == 0) return -1;
+	rc = ma_pipeline_device(c, opt, d, outfmt, stage, flags, fp);
+	fclose(fp);
+	return rc;
+}
+
+int ma_pipeline_run(const ma_opt_t *opt, const char *fn, const char *outfmt, int stage, int flags, FILE *out)
+{
+	sdict_t *d = sd_init(), *excl = 0;
+	mahip_ctx_t *c = ma_gpu(); /* fail before parsing gigabytes of text if there is no GPU */
+	ma_hit_t *hit;
+	size_t n_hits = 0;
+	FILE *lg = MA_LOG;
+	if (flags & 8) {
+		fprintf(lg, "[M::%s] ===> Step 0: removing contained reads <===\n", "main");
+		excl = ma_hit_no_cont(fn, opt->min_span, opt->min_match, opt->max_hang, opt->int_frac);
+	}
+	fprintf(lg, "[M::%s] ===> Step 1: reading read mappings <===\n", "main");
+	hit = ma_hit_ingest(fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), excl);
+	GPU(mahip_set_shard(c, 0, 0xffffffffu));
+	GPU(mahip_hits_upload(c, hit, n_hits, d->n_seq));
+	GPU(mahip_sync(c));
+	free(hit);
+	ma_pipeline_device(c, opt, d, outfmt, stage, flags, out);
+	sd_destroy(d);
+	if (excl) sd_destroy(excl);
+	return 0;
+}

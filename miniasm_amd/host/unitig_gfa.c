@@ -1,0 +1,216 @@
+/* asm.c -- hits -> string graph bridge (GPU), unitig construction and the GFA / string-graph writers (host).
+ * Reference: asm.c:9-39 (ma_sg_gen), :41-55 (ma_sg_print), :64-116 (ma_ug_destroy, ma_ug_print),
+ * :121-210 (ma_ug_gen).  ma_ug_seq (asm.c:216-290, needs the read sequences) is not on the PAF->GFA path.
+ * The output line formats are the contract with downstream tools and are reproduced byte for byte.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "ma_host.h"
+
+#define GPU(call) do { if ((call) != 0) ma_gpu_fail(__func__); } while (0)
+
+asg_arc_t *ma_asg_arc_pushp(asg_t *g);
+
+asg_t *ma_sg_gen(const ma_opt_t *opt, const sdict_t *d, const ma_sub_t *sub, size_t n_hits, const ma_hit_t *hit)
+{
+	mahip_ctx_t *c = ma_gpu();
+	asg_t *g = asg_init();
+	uint32_t i, n_arc = 0, R = d->n_seq;
+	uint8_t *del = (uint8_t*)malloc(R ? R : 1);
+	uint32_t *len = 0;
+	for (i = 0; i < R; ++i) del[i] = d->seq[i].del;
+	if (!sub) {
+		len = (uint32_t*)malloc((R ? R : 1) * 4);
+		for (i = 0; i < R; ++i) len[i] = d->seq[i].len;
+	}
+	GPU(mahip_set_shard(c, 0, 0xffffffffu));
+	GPU(mahip_hits_upload(c, hit, n_hits, R));
+	GPU(mahip_hits_index(c));
+	if (sub) GPU(mahip_sub_upload(c, 0, sub, R));
+	GPU(mahip_sg_gen(c, opt, sub != 0, len, del, &n_arc));
+	GPU(mahip_asg_download(c, g));
+	free(del); free(len);
+	fprintf(MA_LOG, "[M::%s] read %d arcs\n", __func__, g->n_arc);
+	return g;
+}
+
+void ma_sg_print(const asg_t *g, const sdict_t *d, const ma_sub_t *sub, FILE *fp)
+{
+	uint32_t i;
+	for (i = 0; i < g->n_arc; ++i) {
+		const asg_arc_t *p = &g->arc[i];
+		uint32_t q = (uint32_t)(p->ul >> 33), t = p->v >> 1;
+		char so = "+-"[p->ul >> 32 & 1], to = "+-"[p->v & 1];
+		if (sub)
+			fprintf(fp, "L\t%s:%d-%d\t%c\t%s:%d-%d\t%c\t%d:\tL1:i:%d\n", d->seq[q].name, sub[q].s + 1, sub[q].e, so,
+					d->seq[t].name, sub[t].s + 1, sub[t].e, to, p->ol, (uint32_t)p->ul);
+		else
+			fprintf(fp, "L\t%s\t%c\t%s\t%c\t%d:\tL1:i:%d\n", d->seq[q].name, so, d->seq[t].name, to, p->ol, (uint32_t)p->ul);
+	}
+}
+
+/* ---------------------------------------------------------------------------------------------- unitigs */
+
+void ma_ug_destroy(ma_ug_t *ug)
+{
+	size_t i;
+	if (ug == 0) return;
+	for (i = 0; i < ug->u.n; ++i) { free(ug->u.a[i].a); free(ug->u.a[i].s); }
+	free(ug->u.a);
+	asg_destroy(ug->g);
+	free(ug);
+}
+
+/* a double-ended queue of u64 over one growable array */
+typedef struct { uint64_t *a; size_t cap, head, n; } dq64_t;
+
+static void dq_reserve(dq64_t *q)
+{
+	if (q->n == q->cap) {
+		size_t ncap = q->cap ? q->cap << 1 : 64, i;
+		uint64_t *b = (uint64_t*)malloc(ncap * 8);
+		for (i = 0; i < q->n; ++i) b[i] = q->a[(q->head + i) & (q->cap - 1)];
+		free(q->a);
+		q->a = b; q->cap = ncap; q->head = 0;
+	}
+}
+static inline void dq_push_back(dq64_t *q, uint64_t x) { dq_reserve(q); q->a[(q->head + q->n++) & (q->cap - 1)] = x; }
+static inline void dq_push_front(dq64_t *q, uint64_t x) { dq_reserve(q); q->head = (q->head + q->cap - 1) & (q->cap - 1); q->a[q->head] = x; ++q->n; }
+static inline uint64_t dq_at(const dq64_t *q, size_t i) { return q->a[(q->head + i) & (q->cap - 1)]; }
+
+#define out_deg(g, v) ((uint32_t)(g)->idx[(v)])
+#define out_first(g, v) ((g)->arc[(g)->idx[(v)] >> 32])
+
+ma_ug_t *ma_ug_gen(asg_t *g) /* asm.c:121-210 */
+{
+	uint32_t v, n_vtx = g->n_seq * 2;
+	int32_t *mark = (int32_t*)calloc(n_vtx ? n_vtx : 1, 4);
+	dq64_t q = {0, 0, 0, 0};
+	ma_ug_t *ug = (ma_ug_t*)calloc(1, sizeof(ma_ug_t));
+	size_t i;
+	ug->g = asg_init();
+
+	for (v = 0; v < n_vtx; ++v) { /* maximal non-branching paths */
+		uint32_t w, x, l, start, end, len;
+		ma_utg_t *p;
+		if (g->seq[v >> 1].del || out_deg(g, v) == 0 || mark[v]) continue;
+		mark[v] = 1;
+		q.n = 0; q.head = 0;
+		start = v, end = v ^ 1, len = 0;
+		for (w = v;;) { /* walk forward while both ends of the arc are unambiguous */
+			if (out_deg(g, w) != 1) break;
+			x = out_first(g, w).v;
+			if (out_deg(g, x ^ 1) != 1) break;
+			mark[x] = mark[w ^ 1] = 1;
+			l = asg_arc_len(out_first(g, w));
+			dq_push_back(&q, (uint64_t)w << 32 | l);
+			end = x ^ 1, len += l;
+			w = x;
+			if (x == v) break;
+		}
+		if (start != (end ^ 1) || q.n == 0) { /* linear: the last read contributes its full length */
+			l = g->seq[end >> 1].len;
+			dq_push_back(&q, (uint64_t)(end ^ 1) << 32 | l);
+			len += l;
+			for (x = v;;) { /* walk backward */
+				if (out_deg(g, x ^ 1) != 1) break;
+				w = out_first(g, x ^ 1).v ^ 1;
+				if (out_deg(g, w) != 1) break;
+				mark[x] = mark[w ^ 1] = 1;
+				l = asg_arc_len(out_first(g, w));
+				dq_push_front(&q, (uint64_t)w << 32 | l);
+				start = w, len += l;
+				x = w;
+			}
+		} else start = end = UINT32_MAX; /* circular */
+		if (start != UINT32_MAX) mark[start] = mark[end] = 1;
+		if (ug->u.n == ug->u.m) {
+			ug->u.m = ug->u.m ? ug->u.m << 1 : 2;
+			ug->u.a = (ma_utg_t*)realloc(ug->u.a, ug->u.m * sizeof(ma_utg_t));
+		}
+		p = &ug->u.a[ug->u.n++];
+		p->s = 0, p->start = start, p->end = end, p->len = len, p->n = (uint32_t)q.n, p->circ = (start == UINT32_MAX);
+		p->m = p->n;
+		if (p->m) { uint32_t m = p->m; --m; m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16; p->m = m + 1; }
+		p->a = (uint64_t*)malloc(8 * (size_t)(p->m ? p->m : 1));
+		for (i = 0; i < q.n; ++i) p->a[i] = dq_at(&q, i);
+	}
+	free(q.a);
+
+	/* arcs between unitig ends */
+	for (v = 0; v < n_vtx; ++v) mark[v] = -1;
+	for (i = 0; i < ug->u.n; ++i) {
+		if (ug->u.a[i].circ) continue;
+		mark[ug->u.a[i].start] = (int32_t)(i << 1 | 0);
+		mark[ug->u.a[i].end] = (int32_t)(i << 1 | 1);
+	}
+	for (i = 0; i < g->n_arc; ++i) {
+		const asg_arc_t *p = &g->arc[i];
+		uint32_t pu = (uint32_t)(p->ul >> 32) ^ 1;
+		if (p->del) continue;
+		if (mark[pu] >= 0 && mark[p->v] >= 0) {
+			uint32_t u = (uint32_t)mark[pu] ^ 1;
+			int l = (int)ug->u.a[u >> 1].len - (int)p->ol;
+			asg_arc_t *e;
+			if (l < 0) l = 1;
+			e = ma_asg_arc_pushp(ug->g);
+			e->ol = p->ol, e->del = 0;
+			e->ul = (uint64_t)u << 32 | (uint32_t)l;
+			e->v = (uint32_t)mark[p->v];
+		}
+	}
+	for (i = 0; i < ug->u.n; ++i) asg_seq_set(ug->g, (int)i, ug->u.a[i].len, 0);
+	asg_cleanup(ug->g);
+	free(mark);
+	return ug;
+}
+
+void ma_ug_print(const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, FILE *fp) /* asm.c:77-116 */
+{
+	uint32_t i, j, l;
+	char name[32];
+	for (i = 0; i < ug->u.n; ++i) { /* S lines, circularising L lines, per-read a lines */
+		const ma_utg_t *p = &ug->u.a[i];
+		sprintf(name, "utg%.6d%c", i + 1, "lc"[p->circ]);
+		fprintf(fp, "S\t%s\t%s\tLN:i:%d\n", name, p->s ? p->s : "*", p->len);
+		if (p->circ) {
+			fprintf(fp, "L\t%s\t+\t%s\t+\t0M\n", name, name);
+			fprintf(fp, "L\t%s\t-\t%s\t-\t0M\n", name, name);
+		}
+		for (j = l = 0; j < p->n; l += (uint32_t)p->a[j++]) {
+			uint32_t x = (uint32_t)(p->a[j] >> 33);
+			char o = "+-"[p->a[j] >> 32 & 1];
+			if (sub) fprintf(fp, "a\t%s\t%d\t%s:%d-%d\t%c\t%d\n", name, l, d->seq[x].name, sub[x].s + 1, sub[x].e, o, (uint32_t)p->a[j]);
+			else fprintf(fp, "a\t%s\t%d\t%s\t%c\t%d\n", name, l, d->seq[x].name, o, (uint32_t)p->a[j]);
+		}
+	}
+	for (i = 0; i < ug->g->n_arc; ++i) { /* L lines between unitigs */
+		const asg_arc_t *e = &ug->g->arc[i];
+		uint32_t u = (uint32_t)(e->ul >> 32), v = e->v;
+		fprintf(fp, "L\tutg%.6d%c\t%c\tutg%.6d%c\t%c\t%dM\tSD:i:%d\n", (u >> 1) + 1, "lc"[ug->u.a[u >> 1].circ], "+-"[u & 1],
+				(v >> 1) + 1, "lc"[ug->u.a[v >> 1].circ], "+-"[v & 1], e->ol, asg_arc_len(*e));
+	}
+	for (i = 0; i < ug->u.n; ++i) { /* x lines: unitig summary */
+		const ma_utg_t *u = &ug->u.a[i];
+		if (u->start == UINT32_MAX) {
+			fprintf(fp, "x\tutg%.6dc\t%d\t%d\n", i + 1, u->len, u->n);
+		} else {
+			uint32_t c0 = asg_arc_n(ug->g, i << 1 | 0), c1 = asg_arc_n(ug->g, i << 1 | 1);
+			uint32_t rs = u->start >> 1, re = u->end >> 1;
+			if (sub)
+				fprintf(fp, "x\tutg%.6dl\t%d\t%d\t%d\t%d\t%s:%d-%d\t%c\t%s:%d-%d\t%c\n", i + 1, u->len, u->n, c1, c0,
+						d->seq[rs].name, sub[rs].s + 1, sub[rs].e, "+-"[u->start & 1], d->seq[re].name, sub[re].s + 1, sub[re].e, "+-"[u->end & 1]);
+			else
+				fprintf(fp, "x\tutg%.6dl\t%d\t%d\t%d\t%d\t%s\t%c\t%s\t%c\n", i + 1, u->len, u->n, c1, c0,
+						d->seq[rs].name, "+-"[u->start & 1], d->seq[re].name, "+-"[u->end & 1]);
+		}
+	}
+}
+
+int ma_ug_seq(ma_ug_t *g, const sdict_t *d, const ma_sub_t *sub, const char *fn)
+{ /* reference asm.c:216-290: unitig sequences from the reads file; not on the PAF->GFA hot path */
+	(void)g; (void)d; (void)sub;
+	fprintf(stderr, "[W::%s] unitig sequence stitching (-f %s) is not part of this build; S lines carry '*'\n", __func__, fn ? fn : "-");
+	return -1;
+}

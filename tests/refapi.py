@@ -1,0 +1,180 @@
+"""Test-side access to the checkers: oracle/libma_oracle.so (the C restatement) and, when it has been built,
+oracle/_ref/ (the unmodified reference compiled from /root/reference).  Nothing here is imported by the
+product.  /root/reference itself is never read at test time -- only the prebuilt artefacts under oracle/_ref."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+
+import miniasm_amd as ma
+
+ROOT = ma.ROOT
+ORC_PATH = os.path.join(ROOT, "oracle", "libma_oracle.so")
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+REF_LIB = os.path.join(REF_DIR, "libminiasm_ref.so")
+REF_BIN = os.path.join(REF_DIR, "miniasm_ref")
+DROPIN_BIN = os.path.join(REF_DIR, "miniasm_dropin")
+
+HIT_DT, SUB_DT, ARC_DT = ma.HIT_DT, ma.SUB_DT, ma.ARC_DT
+vp, sz, u32, i32, f32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_float
+
+_orc = None
+_ref = None
+
+
+def orc():
+    global _orc
+    if _orc is None:
+        L = C.CDLL(ORC_PATH)
+        L.orc_hit_sort.argtypes = [sz, vp]
+        L.orc_hit2arc.argtypes = [vp, i32, i32, i32, f32, i32, vp]
+        L.orc_hit_sub.restype = sz
+        L.orc_hit_sub.argtypes = [i32, f32, i32, sz, vp, sz, vp]
+        L.orc_hit_cut.restype = sz
+        L.orc_hit_cut.argtypes = [vp, i32, sz, vp]
+        L.orc_hit_flt.restype = sz
+        L.orc_hit_flt.argtypes = [vp, i32, i32, sz, vp, C.POINTER(f32)]
+        L.orc_sub_merge.argtypes = [sz, vp, vp]
+        L.orc_hit_contained.restype = sz
+        L.orc_hit_contained.argtypes = [C.POINTER(ma.MaOpt), u32, vp, vp, sz, vp, vp, C.POINTER(u32)]
+        L.orc_sg_gen.restype = sz
+        L.orc_sg_gen.argtypes = [C.POINTER(ma.MaOpt), u32, vp, vp, vp, sz, vp, vp, vp, vp]
+        L.orc_arc_index.argtypes = [u32, sz, vp, vp]
+        L.orc_arc_rm.restype = sz
+        L.orc_arc_rm.argtypes = [sz, vp, vp]
+        L.orc_arc_del_trans.restype = u32
+        L.orc_arc_del_trans.argtypes = [u32, sz, vp, vp, vp, i32, C.POINTER(C.c_uint64)]
+        for f in (L.orc_arc_del_multi, L.orc_arc_del_asymm):
+            f.restype = u32
+            f.argtypes = [u32, sz, vp, vp]
+        L.orc_arc_del_short.restype = u32
+        L.orc_arc_del_short.argtypes = [u32, sz, vp, vp, f32]
+        _orc = L
+    return _orc
+
+
+def have_ref():
+    return os.path.exists(REF_LIB) and os.path.exists(REF_BIN)
+
+
+def ref():
+    """The unmodified reference objects as a shared library (built by oracle/Makefile)."""
+    global _ref
+    if _ref is None:
+        L = C.CDLL(REF_LIB)
+        L.sd_init.restype = C.POINTER(ma.Sdict)
+        L.sd_destroy.argtypes = [C.POINTER(ma.Sdict)]
+        L.sd_put.restype = C.c_int32
+        L.sd_put.argtypes = [C.POINTER(ma.Sdict), C.c_char_p, u32]
+        L.ma_hit_read.restype = vp
+        L.ma_hit_read.argtypes = [C.c_char_p, i32, i32, C.POINTER(ma.Sdict), C.POINTER(sz), i32, vp]
+        L.ma_hit_sort.argtypes = [sz, vp]
+        L.ma_hit_sub.restype = vp
+        L.ma_hit_sub.argtypes = [i32, f32, i32, sz, vp, sz]
+        L.ma_hit_cut.restype = sz
+        L.ma_hit_cut.argtypes = [vp, i32, sz, vp]
+        L.ma_hit_flt.restype = sz
+        L.ma_hit_flt.argtypes = [vp, i32, i32, sz, vp, C.POINTER(f32)]
+        L.ma_sub_merge.argtypes = [sz, vp, vp]
+        L.ma_hit_contained.restype = sz
+        L.ma_hit_contained.argtypes = [C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), vp, sz, vp]
+        L.ma_sg_gen.restype = C.POINTER(ma.Asg)
+        L.ma_sg_gen.argtypes = [C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), vp, sz, vp]
+        L.asg_destroy.argtypes = [C.POINTER(ma.Asg)]
+        for name in ("asg_arc_del_trans", "asg_cut_tip", "asg_cut_internal", "asg_cut_biloop", "asg_pop_bubble"):
+            f = getattr(L, name)
+            f.restype = i32
+            f.argtypes = [C.POINTER(ma.Asg), i32]
+        L.asg_arc_del_short.restype = i32
+        L.asg_arc_del_short.argtypes = [C.POINTER(ma.Asg), f32]
+        L.asg_symm.argtypes = [C.POINTER(ma.Asg)]
+        L.asg_cleanup.argtypes = [C.POINTER(ma.Asg)]
+        L.ma_ug_gen.restype = vp
+        L.ma_ug_gen.argtypes = [C.POINTER(ma.Asg)]
+        L.ma_ug_destroy.argtypes = [vp]
+        L.free_buf = C.CDLL(None).free
+        L.free_buf.argtypes = [vp]
+        _ref = L
+    return _ref
+
+
+def np_from(ptr, n, dt):
+    return np.frombuffer(C.string_at(ptr, n * dt.itemsize), dtype=dt).copy() if n else np.zeros(0, dt)
+
+
+def asg_arrays(g):
+    """copy arcs / seq / idx out of an asg_t (either library's)"""
+    g = g.contents if hasattr(g, "contents") else g
+    na, ns = g.n_arc, g.n_seq
+    arcs = np_from(g.arc, na, ARC_DT)
+    seq = np_from(g.seq, ns, np.dtype("<u4"))
+    idx = np_from(g.idx, 2 * ns, np.dtype("<u8")) if g.idx else np.zeros(0, "<u8")
+    return arcs, seq, idx
+
+
+def canon(rec):
+    """records in a canonical order (independent of how ties were left by a sort)"""
+    a = np.ascontiguousarray(rec)
+    if a.size == 0:
+        return a
+    raw = a.view(np.uint8).reshape(len(a), a.dtype.itemsize)
+    order = np.lexsort(raw.T[::-1])
+    return a[order]
+
+
+def pafgen(path, reads, lines, seed=1, extra=()):
+    cmd = [ma.PAFGEN_PATH, "-r", str(reads), "-n", str(lines), "-s", str(seed), "-o", path] + list(extra)
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    return path
+
+
+def run_cli(binary, args, paf, timeout=600):
+    r = subprocess.run([binary] + list(args) + [paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    if r.returncode != 0:
+        raise RuntimeError("%s %s failed (%d): %s" % (binary, " ".join(args), r.returncode, r.stderr.decode()[-2000:]))
+    return r.stdout, r.stderr.decode()
+
+
+def norm_lines(text):
+    """line-order normalisation used for every text comparison (LC_ALL=C sort)"""
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    lines.sort()
+    return lines
+
+
+def digest(text):
+    h = hashlib.sha256()
+    for ln in norm_lines(text):
+        h.update(ln)
+        h.update(b"\n")
+    return h.hexdigest()
+
+
+def counters(log):
+    """the [M::...] counter lines without their timestamps: cheap per-stage checksums"""
+    out = []
+    for ln in log.splitlines():
+        if not ln.startswith("[M::"):
+            continue
+        if "Real time" in ln or "CMD" in ln or "Version" in ln:
+            continue
+        head, _, rest = ln.partition("] ")
+        fn = head[4:].split("::")[0]
+        out.append(fn + ": " + rest)
+    return out
+
+
+def arc_tie_groups(sg_text):
+    """number of (u, len) tie groups among the L lines of a -p sg dump (SURVEY appendix A census)"""
+    seen = {}
+    for ln in sg_text.split(b"\n"):
+        f = ln.split(b"\t")
+        if len(f) < 7 or f[0] != b"L":
+            continue
+        k = (f[1], f[2], f[6])
+        seen[k] = seen.get(k, 0) + 1
+    return sum(1 for v in seen.values() if v > 1)

@@ -1,0 +1,191 @@
+"""Run the hit/graph passes stage by stage through (a) the unmodified reference library, (b) the C oracle,
+(c) the HIP library, returning comparable snapshots after every pass."""
+import ctypes as C
+
+import numpy as np
+
+import miniasm_amd as ma
+import refapi as R
+
+HIT_DT, SUB_DT, ARC_DT = ma.HIT_DT, ma.SUB_DT, ma.ARC_DT
+
+
+def flt_params(opt):
+    return int(opt.max_hang * 1.5), int(opt.min_ovlp * .5)  # reference main.c:125
+
+
+# --------------------------------------------------------------------------------------------- reference
+def ref_stages(paf, opt, upto="trans"):
+    L = R.ref()
+    d = L.sd_init()
+    n = C.c_size_t(0)
+    p = L.ma_hit_read(paf.encode(), opt.min_span, opt.min_match, d, C.byref(n), 1, None)
+    S = {"n_seq": d.contents.n_seq}
+    n = n.value
+    def snap(m):
+        a = R.np_from(p, m, HIT_DT)
+        a["bldel"] &= 0x7FFFFFFF  # the reference never initialises ma_hit_t.del (hit.c:87-91): heap garbage, unused everywhere
+        return a
+    S["sorted"] = snap(n)
+    sub = L.ma_hit_sub(opt.min_dp, opt.min_iden, 0, n, p, S["n_seq"])
+    S["sub1"] = R.np_from(sub, S["n_seq"], SUB_DT)
+    n = L.ma_hit_cut(sub, opt.min_span, n, p)
+    S["cut1"] = snap(n)
+    cov = C.c_float(0)
+    mh, mo = flt_params(opt)
+    n = L.ma_hit_flt(sub, mh, mo, n, p, C.byref(cov))
+    S["flt"], S["cov"] = snap(n), cov.value
+    sub2 = L.ma_hit_sub(opt.min_dp, opt.min_iden, opt.min_span // 2, n, p, S["n_seq"])
+    S["sub2"] = R.np_from(sub2, S["n_seq"], SUB_DT)
+    n = L.ma_hit_cut(sub2, opt.min_span, n, p)
+    S["cut2"] = snap(n)
+    L.ma_sub_merge(S["n_seq"], sub, sub2)
+    S["subm"] = R.np_from(sub, S["n_seq"], SUB_DT)
+    L.free_buf(sub2)
+    n = L.ma_hit_contained(C.byref(opt), d, sub, n, p)
+    S["n_seq_new"] = d.contents.n_seq
+    S["cont"] = snap(n)
+    S["cont_sub"] = R.np_from(sub, S["n_seq_new"], SUB_DT)
+    S["names"] = [d.contents.seq[i].name.decode() for i in range(S["n_seq_new"])]
+    if upto != "hits":
+        g = L.ma_sg_gen(C.byref(opt), d, sub, n, p)
+        S["sg_arcs"], S["sg_seq"], S["sg_idx"] = R.asg_arrays(g)
+        S["n_red"] = L.asg_arc_del_trans(g, opt.gap_fuzz)
+        S["tr_arcs"], S["tr_seq"], S["tr_idx"] = R.asg_arrays(g)
+        S["g"] = g  # caller may keep cleaning; caller frees with asg_destroy
+    L.free_buf(sub)
+    L.free_buf(p)
+    L.sd_destroy(d)
+    return S
+
+
+# --------------------------------------------------------------------------------------------- oracle
+def _ptr(a):
+    return a.ctypes.data
+
+
+def orc_reduce(n_seq, arcs, seq_del, fuzz):
+    """asg_arc_del_trans + cleanup + symm exactly as reference asg.c:148-193 strings them together"""
+    O = R.orc()
+    arcs = arcs.copy()
+    idx = np.zeros(2 * n_seq, dtype="<u8")
+    O.orc_arc_index(n_seq, len(arcs), _ptr(arcs), _ptr(idx))
+    inner = C.c_uint64(0)
+    n_red = O.orc_arc_del_trans(n_seq, len(arcs), _ptr(arcs), _ptr(idx), _ptr(seq_del), fuzz, C.byref(inner))
+    n_multi = n_asymm = 0
+    if n_red:
+        m = O.orc_arc_rm(len(arcs), _ptr(arcs), _ptr(seq_del)); arcs = arcs[:m].copy()
+        O.orc_arc_index(n_seq, len(arcs), _ptr(arcs), _ptr(idx))
+        n_multi = O.orc_arc_del_multi(n_seq, len(arcs), _ptr(arcs), _ptr(idx))
+        if n_multi:
+            m = O.orc_arc_rm(len(arcs), _ptr(arcs), _ptr(seq_del)); arcs = arcs[:m].copy()
+            O.orc_arc_index(n_seq, len(arcs), _ptr(arcs), _ptr(idx))
+        n_asymm = O.orc_arc_del_asymm(n_seq, len(arcs), _ptr(arcs), _ptr(idx))
+        if n_asymm:
+            m = O.orc_arc_rm(len(arcs), _ptr(arcs), _ptr(seq_del)); arcs = arcs[:m].copy()
+            O.orc_arc_index(n_seq, len(arcs), _ptr(arcs), _ptr(idx))
+    return arcs, idx, dict(n_red=n_red, n_multi=n_multi, n_asymm=n_asymm, n_inner=inner.value)
+
+
+def orc_stages(hits, n_seq, opt, upto="trans"):
+    O = R.orc()
+    a = np.ascontiguousarray(hits, dtype=HIT_DT).copy()
+    S = {"n_seq": n_seq}
+    O.orc_hit_sort(len(a), _ptr(a))
+    S["sorted"] = a.copy()
+    sub = np.zeros(n_seq, dtype=SUB_DT)
+    S["n_rem1"] = O.orc_hit_sub(opt.min_dp, opt.min_iden, 0, len(a), _ptr(a), n_seq, _ptr(sub))
+    S["sub1"] = sub.copy()
+    n = O.orc_hit_cut(_ptr(sub), opt.min_span, len(a), _ptr(a)); a = a[:n].copy()
+    S["cut1"] = a.copy()
+    cov = C.c_float(0)
+    mh, mo = flt_params(opt)
+    n = O.orc_hit_flt(_ptr(sub), mh, mo, len(a), _ptr(a), C.byref(cov)); a = a[:n].copy()
+    S["flt"], S["cov"] = a.copy(), cov.value
+    sub2 = np.zeros(n_seq, dtype=SUB_DT)
+    S["n_rem2"] = O.orc_hit_sub(opt.min_dp, opt.min_iden, opt.min_span // 2, len(a), _ptr(a), n_seq, _ptr(sub2))
+    S["sub2"] = sub2.copy()
+    n = O.orc_hit_cut(_ptr(sub2), opt.min_span, len(a), _ptr(a)); a = a[:n].copy()
+    S["cut2"] = a.copy()
+    O.orc_sub_merge(n_seq, _ptr(sub), _ptr(sub2))
+    S["subm"] = sub.copy()
+    seq_del = np.zeros(max(n_seq, 1), dtype=np.uint8)
+    mp = np.zeros(max(n_seq, 1), dtype=np.int32)
+    nn = C.c_uint32(0)
+    n = O.orc_hit_contained(C.byref(opt), n_seq, _ptr(seq_del), _ptr(sub), len(a), _ptr(a), _ptr(mp), C.byref(nn)); a = a[:n].copy()
+    S["n_seq_new"], S["cont"], S["cont_sub"], S["map"] = nn.value, a.copy(), sub[:nn.value].copy(), mp[:n_seq].copy()
+    if upto != "hits":
+        ns = nn.value
+        arcs = np.zeros(max(len(a), 1), dtype=ARC_DT)
+        slen = np.zeros(max(ns, 1), dtype="<u4")
+        sdel = np.zeros(max(ns, 1), dtype=np.uint8)
+        m = O.orc_sg_gen(C.byref(opt), ns, _ptr(S["cont_sub"]) if ns else None, None, None, len(a), _ptr(a), _ptr(arcs), _ptr(slen), _ptr(sdel))
+        arcs = arcs[:m].copy()
+        S["sg_arcs"], S["sg_seq"] = arcs.copy(), (slen[:ns] | (sdel[:ns].astype("<u4") << 31))
+        tr, idx, cnt = orc_reduce(ns, arcs, sdel, opt.gap_fuzz)
+        S["tr_arcs"], S["tr_idx"], S["tr_cnt"] = tr, idx, cnt
+        S["n_red"] = cnt["n_red"]
+    return S
+
+
+# --------------------------------------------------------------------------------------------- HIP
+def gpu_stages(ctx, hits, n_seq, opt, upto="trans"):
+    S = {"n_seq": n_seq}
+    ctx.hits_upload(hits, n_seq)
+    ctx.sort()
+    S["sorted"] = ctx.hits_download()
+    S["n_rem1"] = ctx.sub(opt.min_dp, opt.min_iden, 0, 0)
+    S["sub1"] = ctx.sub_download(0, n_seq)
+    ctx.cut(0, opt.min_span)
+    S["cut1"] = ctx.hits_download()
+    mh, mo = flt_params(opt)
+    _, S["cov"] = ctx.flt(0, mh, mo)
+    S["flt"] = ctx.hits_download()
+    S["n_rem2"] = ctx.sub(opt.min_dp, opt.min_iden, opt.min_span // 2, 1)
+    S["sub2"] = ctx.sub_download(1, n_seq)
+    ctx.cut(1, opt.min_span)
+    S["cut2"] = ctx.hits_download()
+    ctx.sub_merge()
+    S["subm"] = ctx.sub_download(0, n_seq)
+    S["n_seq_new"], _ = ctx.contained(opt)
+    S["cont"] = ctx.hits_download()
+    S["cont_sub"] = ctx.sub_download(0, n_seq, squeezed=True)[:S["n_seq_new"]]
+    S["map"] = ctx.map_download(n_seq)
+    if upto != "hits":
+        ctx.sg_gen(opt, True)
+        S["sg_arcs"], S["sg_seq"], S["sg_idx"] = ctx.asg_download()
+        S["n_red"] = ctx.del_trans(opt.gap_fuzz)
+        if S["n_red"]:
+            ctx.symm()
+        S["tr_arcs"], S["tr_seq"], S["tr_idx"] = ctx.asg_download()
+    return S
+
+
+HIT_KEYS = ["sorted", "cut1", "flt", "cut2", "cont"]
+SUB_KEYS = ["sub1", "sub2", "subm", "cont_sub"]
+
+
+def compare(A, B, what, exact_order=False, graph=True):
+    """assert two stage dicts agree; hit arrays are compared in canonical order unless exact_order"""
+    assert A["n_seq"] == B["n_seq"], what
+    for k in HIT_KEYS:
+        a, b = A[k], B[k]
+        assert len(a) == len(b), "%s: %s count %d vs %d" % (what, k, len(a), len(b))
+        if not exact_order:
+            a, b = R.canon(a), R.canon(b)
+        if a.tobytes() != b.tobytes():
+            diff = {f: int((a[f] != b[f]).sum()) for f in a.dtype.names}
+            raise AssertionError("%s: %s records differ: per-field mismatches %r" % (what, k, diff))
+    for k in SUB_KEYS:
+        assert A[k].tobytes() == B[k].tobytes(), "%s: %s differs" % (what, k)
+    assert A["n_seq_new"] == B["n_seq_new"], what
+    assert abs(A["cov"] - B["cov"]) <= 1e-6 * max(1.0, abs(A["cov"])), "%s: cov %r vs %r" % (what, A["cov"], B["cov"])
+    if graph and "sg_arcs" in A and "sg_arcs" in B:
+        for k in ("sg_arcs", "tr_arcs"):
+            a, b = A[k], B[k]
+            assert len(a) == len(b), "%s: %s count %d vs %d" % (what, k, len(a), len(b))
+            if not exact_order:
+                a, b = R.canon(a), R.canon(b)
+            assert a.tobytes() == b.tobytes(), "%s: %s differ" % (what, k)
+        assert A["sg_seq"].tobytes() == B["sg_seq"].tobytes(), "%s: seq differ" % what
+        assert A["n_red"] == B["n_red"], what
