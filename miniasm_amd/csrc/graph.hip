@@ -166,13 +166,14 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 		uint32_t hbits = 6; while ((1u << hbits) < 2 * nv) ++hbits;
 		uint32_t hsize = 1u << hbits, hmask = hsize - 1;
 		for (uint32_t i = lane; i < nv; i += 64) lv[i] = av[st + i], ll[i] = alen[st + i];
-		for (uint32_t s = lane; s < hsize; s += 64) hk[s] = TR_EMPTY, hm[s] = 0;
+		// hm[slot] = (index of the FIRST arc to this target) << 2 | mark
+		for (uint32_t s = lane; s < hsize; s += 64) hk[s] = TR_EMPTY, hm[s] = 0xffffffffu;
 		wv_sync();
 		for (uint32_t i = lane; i < nv; i += 64) { // mark all neighbours 1 (asg.c:162); duplicates share a slot
 			uint32_t key = lv[i], s = tr_hash(key, hbits);
 			for (;;) {
 				uint32_t old = atomicCAS(&hk[s], TR_EMPTY, key);
-				if (old == TR_EMPTY || old == key) { hm[s] = 1; break; }
+				if (old == TR_EMPTY || old == key) { atomicMin(&hm[s], i << 2 | 1u); break; }
 				s = (s + 1) & hmask;
 			}
 		}
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 		for (uint32_t i = 0; i < nv; ++i) { // sequential over v's arcs: the skip below is order dependent (asg.c:168)
 			uint32_t w = lv[i], li = ll[i];
 			int sw = tr_find(hk, w, hbits);
-			if (hm[sw] != 1) continue;
+			if ((hm[sw] & 3u) != 1) continue;
 			unsigned long long xw = idx[w];
 			uint32_t ws = (uint32_t)(xw >> 32), nw = (uint32_t)xw;
 			for (uint32_t j0 = 0; j0 < nw; j0 += 64) { // lanes over w's arcs; sorted by len => the loop of asg.c:169 is a prefix
@@ -193,14 +194,16 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 				if (fail) cond = cond && lane < (unsigned)(__ffsll((long long)fail) - 1);
 				if (cond) {
 					int sx = tr_find(hk, av[ws + j], hbits);
-					if (sx >= 0) hm[sx] = 2;
+					if (sx >= 0) hm[sx] = (hm[sx] & ~3u) | 2u; // every writer stores the same word
 				}
 				if (fail) break;
 			}
 			wv_sync();
 		}
-		for (uint32_t i = lane; i < nv; i += 64) // asg.c:181-184
-			if (hm[tr_find(hk, lv[i], hbits)] == 2) aol[st + i] |= ADEL, ++n_red;
+		// asg.c:181-184: the sweep resets mark[target] at the first arc to a target, so of several arcs to one
+		// reduced target (multi-arcs are still present here) only the first is deleted
+		for (uint32_t i = lane; i < nv; i += 64)
+			if (hm[tr_find(hk, lv[i], hbits)] == (i << 2 | 2u)) aol[st + i] |= ADEL, ++n_red;
 		wv_sync();
 	}
 	n_red = wv_sum_u32(n_red);
@@ -235,12 +238,15 @@ __global__ __launch_bounds__(256) void k_asg_trans_big(const uint32_t *__restric
 			}
 			__syncthreads();
 		}
-		uint32_t cnt = 0;
-		for (uint32_t i = threadIdx.x; i < nv; i += 256) if (mark[av[st + i]] == 2) aol[st + i] |= ADEL, ++cnt;
-		if (cnt) atomicAdd(&s_red, cnt);
-		__syncthreads();
-		for (uint32_t i = threadIdx.x; i < nv; i += 256) mark[av[st + i]] = 0;
-		if (threadIdx.x == 0 && s_red) atomicAdd(&ctr[CT_NRED], (unsigned long long)s_red);
+		if (threadIdx.x == 0) { // asg.c:181-184 literally (the reset makes the sweep order dependent for multi-arcs)
+			uint32_t cnt = 0;
+			for (uint32_t i = 0; i < nv; ++i) {
+				uint32_t y = av[st + i];
+				if (mark[y] == 2) aol[st + i] |= ADEL, ++cnt;
+				mark[y] = 0;
+			}
+			if (cnt) atomicAdd(&ctr[CT_NRED], (unsigned long long)cnt);
+		}
 		__syncthreads();
 	}
 }

@@ -1,0 +1,90 @@
+"""End-to-end parity on the GPU: the miniasm CLI (resident pipeline) and the link-level drop-in (the
+reference's own main.o linked against libminiasm_amd.so, per-symbol ABI) against the unmodified reference
+binary, for every dump the reference can produce (-p bed|paf|sg|ug x -S stage), plus committed golden digests."""
+import json
+import os
+
+import pytest
+
+import miniasm_amd as ma
+import refapi as R
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.json")
+
+DUMPS = [["-p", "bed"], ["-p", "paf", "-S2"], ["-p", "paf", "-S3"], ["-p", "paf", "-S4"], ["-p", "paf"],
+         ["-p", "sg", "-S5"], ["-p", "sg", "-S6"], ["-p", "sg", "-S7"], ["-p", "sg", "-S9"], ["-p", "sg", "-S10"], ["-p", "sg"], ["-p", "ug"]]
+
+INPUTS = {  # name -> pafgen arguments (all arc-tie-free: checked when the golden file was made)
+    "lognormal": dict(reads=3000, lines=80000, seed=41, extra=[]),
+    "fixed": dict(reads=2500, lines=70000, seed=42, extra=["-L", "fixed"]),
+    "noisy": dict(reads=4000, lines=90000, seed=63, extra=["-L", "uniform", "-d", "0.35", "-x", "0.03"]),
+}
+
+EXTRA_ARGS = [["-1"], ["-2", "-p", "sg"], ["-b"], ["-R"], ["-c", "2", "-s", "1500", "-h", "500", "-I", "0.7", "-g", "500", "-e", "3", "-d", "30000"],
+              ["-n", "4", "-r", "0.8,0.4", "-F", "0.9"], ["-o", "1000", "-m", "200", "-i", "0.1"], ["-1", "-2", "-p", "sg"]]
+
+
+def _gen(tmpdir_s, name):
+    cfg = INPUTS[name]
+    return R.pafgen(os.path.join(tmpdir_s, "cli_%s.paf" % name), cfg["reads"], cfg["lines"], cfg["seed"], cfg["extra"])
+
+
+def _same(binary, args, paf, ref_out, ref_log, what):
+    out, log = R.run_cli(binary, args, paf)
+    assert R.norm_lines(out) == R.norm_lines(ref_out), "%s %s: output differs from the reference" % (what, " ".join(args))
+    mine, theirs = R.counters(log), R.counters(ref_log)
+    mine = [x for x in mine if not x.startswith("main: Version")]
+    assert mine == theirs, "%s %s: log counters differ\n%s\nvs\n%s" % (what, " ".join(args), "\n".join(mine), "\n".join(theirs))
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name", list(INPUTS))
+def test_cli_and_dropin_match_reference_binary(name, tmpdir_s):
+    paf = _gen(tmpdir_s, name)
+    for args in DUMPS:
+        ref_out, ref_log = R.run_cli(R.REF_BIN, args, paf)
+        _same(ma.CLI_PATH, args, paf, ref_out, ref_log, "cli[%s]" % name)
+    for args in (["-p", "bed"], ["-p", "paf"], ["-p", "sg", "-S5"], ["-p", "sg", "-S6"], ["-p", "ug"]):
+        ref_out, ref_log = R.run_cli(R.REF_BIN, args, paf)
+        _same(R.DROPIN_BIN, args, paf, ref_out, ref_log, "dropin[%s]" % name)
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+def test_cli_options_match_reference_binary(tmpdir_s):
+    paf = _gen(tmpdir_s, "noisy")
+    for args in EXTRA_ARGS:
+        ref_out, ref_log = R.run_cli(R.REF_BIN, args, paf)
+        if "-p" in args and "sg" in args and R.arc_tie_groups(ref_out):
+            continue
+        _same(ma.CLI_PATH, args, paf, ref_out, ref_log, "cli-opts")
+
+
+def test_cli_matches_golden_digests(tmpdir_s):
+    """digests of the reference's normalised dumps, committed under tests/golden (made by tests/golden/make_golden.py)"""
+    gold = json.load(open(GOLDEN))
+    n = 0
+    for name, entry in gold["inputs"].items():
+        cfg = entry["pafgen"]
+        paf = R.pafgen(os.path.join(tmpdir_s, "gold_%s.paf" % name), cfg["reads"], cfg["lines"], cfg["seed"], cfg["extra"])
+        assert R.digest(open(paf, "rb").read()) == entry["paf_digest"], "pafgen is not reproducing the golden input"
+        for key, want in entry["dumps"].items():
+            out, _ = R.run_cli(ma.CLI_PATH, key.split(), paf)
+            assert R.digest(out) == want, "golden mismatch: %s %s" % (name, key)
+            n += 1
+    assert n >= 10
+
+
+def test_cli_gz_and_stdin(tmpdir_s):
+    import gzip
+    import subprocess
+    paf = _gen(tmpdir_s, "lognormal")
+    base, _ = R.run_cli(ma.CLI_PATH, [], paf)
+    gz = paf + ".gz"
+    with open(paf, "rb") as f, gzip.open(gz, "wb") as g:
+        g.write(f.read())
+    out, _ = R.run_cli(ma.CLI_PATH, [], gz)
+    assert out == base
+    r = subprocess.run([ma.CLI_PATH, "-"], stdin=open(paf, "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout == base

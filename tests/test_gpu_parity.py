@@ -1,0 +1,143 @@
+"""GPU parity tests proper: every HIP pass, called through the C ABI (include/mahip.h), against the C oracle
+(bit-exact, order included: both use the total order) and against the unmodified reference library (records
+compared as multisets because the reference's sort leaves ties in a data-dependent order; the graph compared
+exactly on arc-tie-free inputs).  Run with `pytest -m gpu` on an MI355X."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import miniasm_amd as ma
+import refapi as R
+import stages as ST
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("lognormal", 3000, 80000, 41, []),
+    ("fixed", 2500, 70000, 42, ["-L", "fixed"]),
+    ("lowid", 2000, 50000, 43, ["-i", "0.2"]),
+    ("genome_order", 2000, 50000, 44, ["-g"]),
+    ("noisy", 4000, 90000, 45, ["-L", "uniform", "-d", "0.35", "-x", "0.03"]),
+    ("deep_groups", 400, 300000, 46, []),                 # ~1500 hits per read: second tier of the coverage kernel
+    ("deep_vertices", 1500, 1200000, 47, ["-L", "fixed"]),  # ~800 arcs per vertex: second tier of the reduction kernel
+]
+
+
+@pytest.mark.parametrize("name,reads,lines,seed,extra", CASES, ids=[c[0] for c in CASES])
+def test_stages_match_oracle_and_reference(name, reads, lines, seed, extra, tmpdir_s, gpu_ctx):
+    paf = R.pafgen(os.path.join(tmpdir_s, "g_%s.paf" % name), reads, lines, seed, extra)
+    opt = ma.default_opt()
+    ing = ma.Ingest(paf, opt)
+    gpu = ST.gpu_stages(gpu_ctx, ing.hits, ing.n_seq, opt)
+    orc = ST.orc_stages(ing.hits, ing.n_seq, opt)
+    ST.compare(orc, gpu, "oracle vs gpu [%s]" % name, exact_order=True, graph=True)
+    assert orc["n_rem1"] == gpu["n_rem1"] and orc["n_rem2"] == gpu["n_rem2"]
+    assert orc["map"].tobytes() == gpu["map"].tobytes()
+    if "sg_idx" in gpu:
+        idx = np.zeros(2 * gpu["n_seq_new"], dtype="<u8")
+        R.orc().orc_arc_index(gpu["n_seq_new"], len(gpu["tr_arcs"]), gpu["tr_arcs"].ctypes.data, idx.ctypes.data)
+        assert idx.tobytes() == gpu["tr_idx"].tobytes(), "CSR index differs"
+    if R.have_ref():
+        ref = ST.ref_stages(paf, opt)
+        ST.compare(ref, gpu, "reference vs gpu [%s]" % name, exact_order=False, graph=False)
+        assert R.canon(ref["sg_arcs"]).tobytes() == R.canon(gpu["sg_arcs"]).tobytes()
+        keys = ref["sg_arcs"]["ul"]
+        if len(np.unique(keys)) == len(keys):  # no (u,len) ties: the reference order is unique
+            assert ref["sg_arcs"].tobytes() == gpu["sg_arcs"].tobytes()
+            assert ref["tr_arcs"].tobytes() == gpu["tr_arcs"].tobytes()
+            assert ref["tr_idx"].tobytes() == gpu["tr_idx"].tobytes()
+        R.ref().asg_destroy(ref["g"])
+    ing.close()
+
+
+def test_sort_random_keys_and_ties(gpu_ctx):
+    """radix sort on adversarial keys: heavy ties, wide query ids, zero starts, sizes around tile boundaries"""
+    rng = np.random.default_rng(9)
+    for n, nq, ns in ((1, 1, 1), (2, 1, 1), (63, 5, 3), (2048, 7, 2), (2049, 300, 50), (100000, 70000, 60000), (300001, 17, 5), (50000, 1 << 24, 1 << 20)):
+        h = np.zeros(n, dtype=ma.HIT_DT)
+        h["qns"] = (rng.integers(0, nq, n).astype(np.uint64) << 32) | rng.integers(0, ns, n).astype(np.uint64)
+        h["qe"] = np.arange(n)  # distinguishes tied records: stability is observable
+        h["tn"] = rng.integers(0, nq, n)
+        gpu_ctx.hits_upload(h, int(nq))
+        gpu_ctx.sort()
+        got = gpu_ctx.hits_download()
+        exp = h.copy()
+        R.orc().orc_hit_sort(n, exp.ctypes.data)
+        assert got.tobytes() == exp.tobytes(), "sort differs for n=%d" % n
+
+
+def test_empty_and_degenerate_inputs(gpu_ctx):
+    opt = ma.default_opt()
+    # no hits at all
+    S = ST.gpu_stages(gpu_ctx, np.zeros(0, dtype=ma.HIT_DT), 5, opt)
+    assert len(S["sorted"]) == 0 and S["n_seq_new"] == 0 and len(S["tr_arcs"]) == 0
+    assert S["sub1"].tobytes() == np.zeros(5, ma.SUB_DT).tobytes()
+    # only self hits, reads that never appear as a query, a read with a single hit
+    h = np.zeros(4, dtype=ma.HIT_DT)
+    h["qns"] = [(0 << 32) | 0, (0 << 32) | 10, (2 << 32) | 0, (3 << 32) | 100]
+    h["qe"] = [5000, 6000, 4000, 4100]
+    h["tn"] = [0, 0, 2, 1]
+    h["ts"], h["te"] = [0, 10, 0, 0], [5000, 6000, 4000, 4000]
+    h["mlrev"], h["bldel"] = [900, 900, 900, 900], [5000, 5990, 4000, 4000]
+    G = ST.gpu_stages(gpu_ctx, h, 6, opt)
+    O = ST.orc_stages(h, 6, opt)
+    ST.compare(O, G, "degenerate", exact_order=True)
+
+
+def test_flags_and_ragged_groups_vs_oracle(gpu_ctx, tmpdir_s):
+    """ragged group sizes (1 .. >64 .. >2048 events) in one input, -b style input (no mirrored hits)"""
+    paf = R.pafgen(os.path.join(tmpdir_s, "rag.paf"), 900, 120000, 51, ["-S", "0.9"])
+    opt = ma.default_opt()
+    for bi_dir in (True, False):
+        ing = ma.Ingest(paf, opt, bi_dir=bi_dir)
+        sizes = np.bincount((ing.hits["qns"] >> 32).astype(np.int64))
+        assert sizes.max() > 64
+        G = ST.gpu_stages(gpu_ctx, ing.hits, ing.n_seq, opt)
+        O = ST.orc_stages(ing.hits, ing.n_seq, opt)
+        ST.compare(O, G, "ragged bi_dir=%s" % bi_dir, exact_order=True)
+        ing.close()
+
+
+def test_custom_thresholds_vs_oracle(gpu_ctx, tmpdir_s):
+    paf = R.pafgen(os.path.join(tmpdir_s, "thr.paf"), 2000, 50000, 52, ["-L", "uniform", "-d", "0.2", "-x", "0.05", "-i", "0.1"])
+    for (dp, iden, span, hang, frac, fuzz) in ((2, .05, 1500, 500, .7, 500), (5, .1, 2500, 2000, .9, 0), (3, .2, 2000, 1000, .8, 3000)):
+        opt = ma.default_opt()
+        opt.min_dp, opt.min_iden, opt.min_span, opt.max_hang, opt.int_frac, opt.gap_fuzz = dp, iden, span, hang, frac, fuzz
+        opt.min_ovlp = span
+        ing = ma.Ingest(paf, opt)
+        G = ST.gpu_stages(gpu_ctx, ing.hits, ing.n_seq, opt)
+        O = ST.orc_stages(ing.hits, ing.n_seq, opt)
+        ST.compare(O, G, "thresholds %r" % ((dp, iden, span, hang, frac, fuzz),), exact_order=True)
+        ing.close()
+
+
+def test_graph_passes_on_uploaded_graph(gpu_ctx, tmpdir_s):
+    """per-symbol graph path: upload a host graph, del_short / del_trans / symm, compare with the oracle"""
+    paf = R.pafgen(os.path.join(tmpdir_s, "gr.paf"), 2500, 60000, 53, ["-L", "fixed", "-d", "0.3", "-x", "0.04"])
+    opt = ma.default_opt()
+    ing = ma.Ingest(paf, opt)
+    O = ST.orc_stages(ing.hits, ing.n_seq, opt)
+    ns, arcs = O["n_seq_new"], O["sg_arcs"].copy()
+    seq = O["sg_seq"].astype("<u4").copy()
+    idx = np.zeros(2 * ns, dtype="<u8")
+    R.orc().orc_arc_index(ns, len(arcs), arcs.ctypes.data, idx.ctypes.data)
+    g = ma.Asg()
+    g.arc, g.n_arc_srt, g.m_arc = arcs.ctypes.data, len(arcs) | 1 << 31, len(arcs)
+    g.seq, g.n_seq_symm, g.m_seq = seq.ctypes.data, ns, ns
+    g.idx = idx.ctypes.data
+    ma._chk(ma.lib().mahip_asg_upload(gpu_ctx.h, C.byref(g)), "asg_upload")
+    a0, s0, i0 = gpu_ctx.asg_download()
+    assert a0.tobytes() == arcs.tobytes() and s0.tobytes() == seq.tobytes() and i0.tobytes() == idx.tobytes()
+    for ratio in (.5, .7, .9):
+        exp = arcs.copy()
+        n0 = R.orc().orc_arc_del_short(ns, len(exp), exp.ctypes.data, idx.ctypes.data, ratio)
+        ma._chk(ma.lib().mahip_asg_upload(gpu_ctx.h, C.byref(g)), "asg_upload")
+        n1 = gpu_ctx.del_short(ratio)
+        assert n0 == n1
+        sdel = (seq >> 31).astype(np.uint8)
+        m = R.orc().orc_arc_rm(len(exp), exp.ctypes.data, sdel.ctypes.data)
+        got, _, _ = gpu_ctx.asg_download()
+        assert got.tobytes() == exp[:m].tobytes()
+    ing.close()

@@ -1,0 +1,211 @@
+"""Host-side C of the product (PAF reader + dictionary, sequential graph cleaners, unitigs, GFA writer) against
+the unmodified reference library, on the CPU.  These parts run on the host by design (they are text ingest or
+sequential sweeps over the small reduced graph), so they can be pinned without a GPU."""
+import ctypes as C
+import gzip
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import miniasm_amd as ma
+import refapi as R
+import stages as ST
+
+needs_ref = pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+libc = C.CDLL(None)
+libc.malloc.restype = C.c_void_p
+libc.malloc.argtypes = [C.c_size_t]
+libc.fopen.restype = C.c_void_p
+libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+libc.fclose.argtypes = [C.c_void_p]
+
+
+def clone_graph(g):
+    """deep copy of an asg_t into libc-malloc memory (both libraries free() their graphs)"""
+    src = g.contents
+    dst = ma.Asg()
+    na, ns = src.n_arc, src.n_seq
+    for field, nbytes in (("arc", max(na, 1) * 16), ("seq", max(ns, 1) * 4), ("idx", max(ns, 1) * 16)):
+        p = libc.malloc(nbytes)
+        C.memmove(p, getattr(src, field), nbytes if getattr(src, field) else 0)
+        setattr(dst, field, p)
+    dst.m_arc, dst.n_arc_srt = max(na, 1), src.n_arc_srt
+    dst.m_seq, dst.n_seq_symm = max(ns, 1), src.n_seq_symm
+    return dst
+
+
+def snapshot(g):
+    a, s, i = R.asg_arrays(g)
+    return a.tobytes(), s.tobytes(), i.tobytes()
+
+
+def product_graph_api():
+    L = ma.lib()
+    for name in ("asg_cut_tip", "asg_cut_internal", "asg_cut_biloop", "asg_pop_bubble"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(ma.Asg), C.c_int]
+    L.asg_arc_del_short.restype = C.c_int
+    L.asg_arc_del_short.argtypes = [C.POINTER(ma.Asg), C.c_float]
+    L.ma_ug_gen.restype = C.c_void_p
+    L.ma_ug_gen.argtypes = [C.POINTER(ma.Asg)]
+    L.ma_ug_print.argtypes = [C.c_void_p, C.POINTER(ma.Sdict), C.c_void_p, C.c_void_p]
+    L.ma_sg_print.argtypes = [C.POINTER(ma.Asg), C.POINTER(ma.Sdict), C.c_void_p, C.c_void_p]
+    L.ma_ug_destroy.argtypes = [C.c_void_p]
+    L.sd_put.restype = C.c_int32
+    L.sd_put.argtypes = [C.POINTER(ma.Sdict), C.c_char_p, C.c_uint32]
+    return L
+
+
+def cleaning_script(opt):
+    """the call sequence of reference main.c:160-187 as (function, argument) pairs"""
+    seq = [("asg_cut_tip", opt.max_ext), ("asg_pop_bubble", opt.bub_dist)]
+    for i in range(opt.n_rounds + 1):
+        r = np.float32(opt.min_ovlp_drop_ratio) + (np.float32(opt.max_ovlp_drop_ratio) - np.float32(opt.min_ovlp_drop_ratio)) / np.float32(opt.n_rounds) * np.float32(i)
+        seq.append(("short", float(r)))
+    seq += [("asg_cut_internal", 1), ("asg_cut_biloop", opt.max_ext), ("asg_cut_tip", opt.max_ext), ("asg_pop_bubble", opt.bub_dist),
+            ("short", float(np.float32(opt.final_ovlp_drop_ratio)))]
+    return seq
+
+
+GRAPH_CASES = [
+    ("clean", 1500, 40000, 21, []),
+    ("noisy", 4000, 90000, 22, ["-L", "uniform", "-d", "0.35", "-x", "0.03"]),
+    ("noisy2", 3000, 70000, 23, ["-L", "uniform", "-d", "0.5", "-x", "0.08"]),
+    ("fixed", 2000, 50000, 24, ["-L", "fixed", "-d", "0.2", "-x", "0.02"]),
+]
+
+
+@needs_ref
+@pytest.mark.parametrize("name,reads,lines,seed,extra", GRAPH_CASES, ids=[c[0] for c in GRAPH_CASES])
+def test_cleaners_unitigs_gfa_match_reference(name, reads, lines, seed, extra, tmpdir_s):
+    paf = R.pafgen(os.path.join(tmpdir_s, "h_%s.paf" % name), reads, lines, seed, extra)
+    opt = ma.default_opt()
+    S = ST.ref_stages(paf, opt)
+    LR, LP = R.ref(), product_graph_api()
+    g_ref = S["g"]
+    g_mine = clone_graph(g_ref)
+    n_events = 0
+    for fn, arg in cleaning_script(opt):
+        if fn == "short":
+            r0 = LR.asg_arc_del_short(g_ref, arg)
+            r1 = LP.asg_arc_del_short(C.byref(g_mine), arg)
+            if r0:  # reference main.c:169-172
+                for f2, a2 in (("asg_cut_tip", opt.max_ext), ("asg_pop_bubble", opt.bub_dist)):
+                    assert getattr(LR, f2)(g_ref, a2) == getattr(LP, f2)(C.byref(g_mine), a2)
+        else:
+            r0 = getattr(LR, fn)(g_ref, arg)
+            r1 = getattr(LP, fn)(C.byref(g_mine), arg)
+        assert r0 == r1, (fn, arg, r0, r1)
+        n_events += r0 != 0
+        assert snapshot(g_ref) == snapshot(C.pointer(g_mine)), "graph differs after %s(%r)" % (fn, arg)
+    if name.startswith("noisy"):
+        assert n_events >= 2, "noisy input should exercise the cleaners"
+    # unitigs + GFA text
+    d = LP.sd_init()
+    for i, nm in enumerate(S["names"]):
+        assert LP.sd_put(d, nm.encode(), 0) == i
+    dr = LR.sd_init()
+    for i, nm in enumerate(S["names"]):
+        LR.sd_put(dr, nm.encode(), 0)
+    LR.ma_ug_print = LR.ma_ug_print
+    LR.ma_ug_print.argtypes = [C.c_void_p, C.POINTER(ma.Sdict), C.c_void_p, C.c_void_p]
+    sub = S["cont_sub"]
+    ug_r, ug_p = LR.ma_ug_gen(g_ref), LP.ma_ug_gen(C.byref(g_mine))
+    outs = []
+    for tag, L, ug, dd in (("ref", LR, ug_r, dr), ("mine", LP, ug_p, d)):
+        path = os.path.join(tmpdir_s, "h_%s_%s.gfa" % (name, tag))
+        fp = libc.fopen(path.encode(), b"w")
+        L.ma_ug_print(ug, dd, sub.ctypes.data, fp)
+        libc.fclose(fp)
+        outs.append(open(path, "rb").read())
+    assert outs[0] == outs[1], "GFA text differs (byte for byte, line order included)"
+    assert outs[0].count(b"\nS\t") + outs[0].startswith(b"S\t") >= 1
+    LR.ma_ug_destroy(ug_r); LP.ma_ug_destroy(ug_p)
+    LR.asg_destroy(g_ref)
+    LR.sd_destroy(dr); LP.sd_destroy(d)
+
+
+@needs_ref
+def test_paf_reader_edge_cases(tmpdir_s):
+    """gz input, CRLF, short lines, 10-column lines (stale bl), junk numbers, no trailing newline"""
+    lines = [
+        b"a\t9000\t10\t5000\t+\tb\t9000\t20\t5010\t800\t4990\t255",
+        b"a\t9000\t100\t6000\t-\tc\t9500\t0\t5900\t900\t5900\t255\r",
+        b"short\tline",
+        b"",
+        b"b\t9000\t0\t4000\t+\tc\t9500\t5000\t9000\t700",          # 10 columns: bl keeps the previous value
+        b"c\t9500\t+12\t 4000\t-\td\t8000x\t0\t3988\t600\t3988\t255",  # strtol-isms: sign, blank, trailing junk
+        b"d\t8000\t0\t3000\t+\td\t8000\t10\t3010\t500\t3000\t255",   # self hit
+        b"e\t7000\t0\t2500\t+\ta\t9000\t6500\t9000\t400\t2500\t255\textra\tcols",
+        b"f\t7000\t0\t1500\t+\ta\t9000\t0\t1500\t400\t1500\t255",    # below min_span
+        b"g\t7000\t0\t2500\t+\ta\t9000\t0\t2500\t40\t2500\t255",     # below min_match
+        b"a\t9000\t3000\t8000\t+\tg\t7000\t0\t5000\t900\t5000\t255",  # no trailing newline below
+    ]
+    txt = b"\n".join(lines)
+    paths = [os.path.join(tmpdir_s, "edge.paf"), os.path.join(tmpdir_s, "edge.paf.gz"), os.path.join(tmpdir_s, "edge_nl.paf")]
+    open(paths[0], "wb").write(txt)
+    with gzip.open(paths[1], "wb") as f:
+        f.write(txt)
+    open(paths[2], "wb").write(txt + b"\n")
+    opt = ma.default_opt()
+    LR = R.ref()
+    for p in paths:
+        ing = ma.Ingest(p, opt)
+        d = LR.sd_init()
+        n = C.c_size_t(0)
+        q = LR.ma_hit_read(p.encode(), opt.min_span, opt.min_match, d, C.byref(n), 1, None)
+        ref_hits = R.np_from(q, n.value, ma.HIT_DT)
+        ref_hits["bldel"] &= 0x7FFFFFFF
+        assert n.value == ing.n and n.value > 0
+        assert R.canon(ref_hits).tobytes() == R.canon(ing.hits).tobytes(), p
+        assert [d.contents.seq[i].name.decode() for i in range(d.contents.n_seq)] == ing.names()
+        assert [d.contents.seq[i].len for i in range(d.contents.n_seq)] == list(ing.lens())
+        LR.free_buf(q); LR.sd_destroy(d); ing.close()
+
+
+@needs_ref
+def test_ingest_large_lines_and_chunk_boundaries(tmpdir_s):
+    """a file larger than the 1 MiB read chunk with long read names so that lines straddle chunk boundaries"""
+    paf = R.pafgen(os.path.join(tmpdir_s, "chunk.paf"), 3000, 60000, 31, [])
+    big = os.path.join(tmpdir_s, "chunk_long.paf")
+    with open(paf, "rb") as f, open(big, "wb") as g:
+        for ln in f:
+            g.write(ln.replace(b"r", b"read_with_a_rather_long_name_" * 3))
+    assert os.path.getsize(big) > 3 * (1 << 20)
+    opt = ma.default_opt()
+    ing = ma.Ingest(big, opt)
+    LR = R.ref()
+    d = LR.sd_init()
+    n = C.c_size_t(0)
+    q = LR.ma_hit_read(big.encode(), opt.min_span, opt.min_match, d, C.byref(n), 1, None)
+    ref_hits = R.np_from(q, n.value, ma.HIT_DT)
+    ref_hits["bldel"] &= 0x7FFFFFFF
+    assert n.value == ing.n
+    assert R.canon(ref_hits).tobytes() == R.canon(ing.hits).tobytes()
+    assert [d.contents.seq[i].name.decode() for i in range(d.contents.n_seq)] == ing.names()
+    LR.free_buf(q); LR.sd_destroy(d); ing.close()
+
+
+def test_refsort_emulation_matches_reference_on_ties():
+    """host asg_arc_sort (used for the unitig graph) reproduces the reference's unstable radix order, ties included"""
+    if not R.have_ref():
+        pytest.skip("oracle/_ref not built")
+    LR, LP = R.ref(), ma.lib()
+    LR.asg_arc_sort.argtypes = [C.POINTER(ma.Asg)]
+    LP.asg_arc_sort.argtypes = [C.POINTER(ma.Asg)]
+    rng = np.random.default_rng(5)
+    for n, nu, nl in ((50, 4, 5), (300, 8, 6), (5000, 40, 9), (70000, 300, 30), (20000, 3, 2000)):
+        arcs = np.zeros(n, dtype=ma.ARC_DT)
+        arcs["ul"] = (rng.integers(0, nu, n).astype(np.uint64) << 32) | rng.integers(0, nl, n).astype(np.uint64)
+        arcs["v"] = np.arange(n)  # distinguishes tied records
+        res = []
+        for L in (LR, LP):
+            a = arcs.copy()
+            g = ma.Asg()
+            g.arc, g.n_arc_srt, g.m_arc = a.ctypes.data, n, n
+            L.asg_arc_sort(C.byref(g))
+            res.append(a.tobytes())
+        assert res[0] == res[1], "tie order differs for n=%d" % n

@@ -1,0 +1,34 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, smoke, a bench run and (optionally) rocprofv3 summaries -> gpurun_out/
+# usage: tools/gpu_round.sh [tests|bench|prof|all] ...
+cd "$(dirname "$0")/.." || exit 1
+export PYTHONUNBUFFERED=1 TMPDIR=/tmp
+mkdir -p gpurun_out
+what="${*:-tests}"
+rocminfo 2>/dev/null | grep -m1 -E "gfx9" > gpurun_out/gpu.txt
+for w in $what; do
+case $w in
+tests)
+  timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/tests_parity.log 2>&1; echo "rc=$?" >> gpurun_out/tests_parity.log
+  grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_parity.log | tail -60 ;;
+cli)
+  timeout 1500 python -m pytest tests/test_gpu_cli.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/tests_cli.log 2>&1; echo "rc=$?" >> gpurun_out/tests_cli.log
+  grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_cli.log | tail -60 ;;
+smoke)
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "rc=$?" >> gpurun_out/smoke.log
+  grep -vE "^\[M::" gpurun_out/smoke.log | tail -15 ;;
+benchsmall)
+  timeout 900 python bench.py --reads 20000 --lines 1000000 --steps 3 --warmup 1 > gpurun_out/bench_small.json 2> gpurun_out/bench_small.log; echo "rc=$?" >> gpurun_out/bench_small.log
+  tail -5 gpurun_out/bench_small.log; cat gpurun_out/bench_small.json ;;
+bench)
+  timeout 1500 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.log; echo "rc=$?" >> gpurun_out/bench.log
+  tail -5 gpurun_out/bench.log; cat gpurun_out/bench.json ;;
+benchfixed)
+  timeout 1500 python bench.py --model fixed --no-cpu > gpurun_out/bench_fixed.json 2> gpurun_out/bench_fixed.log; echo "rc=$?" >> gpurun_out/bench_fixed.log
+  tail -3 gpurun_out/bench_fixed.log; cat gpurun_out/bench_fixed.json ;;
+prof)
+  rm -rf gpurun_out/prof; mkdir -p gpurun_out/prof
+  (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof -o r --output-format csv -- python /root/repo/bench.py --steps 5 --warmup 1 --no-cpu --prof-steps 0 > /root/repo/gpurun_out/prof/bench_under_prof.json 2> /root/repo/gpurun_out/prof/bench_under_prof.log); echo "rc=$?"
+  find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" ;;
+esac
+done
