@@ -62,9 +62,8 @@ __global__ __launch_bounds__(256) void k_sg_arcs(HitColsG h, size_t n, const uin
                                                   int max_hang, float int_frac, int min_ovlp, ArcCols a, uint32_t *__restrict__ keep,
                                                   unsigned long long *__restrict__ ctr)
 {
-	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	uint32_t mx = 0;
-	if (i < n) {
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
 		int k = 0;
 		if (!(h.bl[i] & DEAD)) {
 			uint32_t q = h.qid[i], t = h.tn[i], qs = h.qs[i], qe = h.qe[i], ts = h.ts[i], te = h.te[i];
@@ -73,13 +72,12 @@ __global__ __launch_bounds__(256) void k_sg_arcs(HitColsG h, size_t n, const uin
 			int r = mc_hit2arc(q, qs, qe, t, ts, te, rev, (int)slen[q], (int)slen[t], max_hang, int_frac, min_ovlp, &x);
 			if (r >= 0) {
 				if (q == t) { if (qs == ts && qe == te && rev) sdel[q] = 1; } // asm.c:27-31
-				else { a.u[i] = x.u; a.v[i] = x.v; a.len[i] = x.len; a.ol[i] = x.ol; k = 1; mx = x.len; }
+				else { a.u[i] = x.u; a.v[i] = x.v; a.len[i] = x.len; a.ol[i] = x.ol; k = 1; mx = x.len > mx ? x.len : mx; }
 			} else if (r == MC_HT_QCONT) sdel[q] = 1; // asm.c:34
 		}
 		keep[i] = k;
 	}
-	for (int o = 32; o > 0; o >>= 1) { uint32_t y = __shfl_xor(mx, o, 64); mx = y > mx ? y : mx; }
-	if ((threadIdx.x & 63) == 0 && mx) atomicMax(&ctr[CT_MAXLEN], (unsigned long long)mx);
+	blk_max_u64(&ctr[CT_MAXLEN], mx);
 }
 
 // asg.c:57-70 asg_arc_rm predicate: arc survives unless del or an endpoint read is deleted
@@ -206,8 +204,7 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 			if (hm[tr_find(hk, lv[i], hbits)] == (i << 2 | 2u)) aol[st + i] |= ADEL, ++n_red;
 		wv_sync();
 	}
-	n_red = wv_sum_u32(n_red);
-	if (lane == 0 && n_red) atomicAdd(&ctr[CT_NRED], (unsigned long long)n_red);
+	blk_add_u64(&ctr[CT_NRED], n_red);
 }
 
 // second tier: vertices with more than TR_CAP arcs; one block per vertex with a private global mark array
@@ -255,38 +252,35 @@ __global__ __launch_bounds__(256) void k_asg_trans_big(const uint32_t *__restric
 // asg.c:104-121: within one vertex keep the first arc to each target, delete the later ones
 __global__ __launch_bounds__(256) void k_asg_multi(ArcCols a, size_t n, const unsigned long long *__restrict__ idx, unsigned long long *__restrict__ ctr)
 {
-	size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-	int del = 0;
-	if (e < n) {
+	uint32_t cnt = 0;
+	for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
 		uint32_t st = (uint32_t)(idx[a.u[e]] >> 32), v = a.v[e];
+		int del = 0;
 		for (uint32_t j = st; j < e; ++j) if (a.v[j] == v) { del = 1; break; }
-		if (del) a.ol[e] |= ADEL;
+		if (del) a.ol[e] |= ADEL, ++cnt;
 	}
-	wv_count_add(&ctr[CT_NMULTI], del);
+	blk_add_u64(&ctr[CT_NMULTI], cnt);
 }
 
 // asg.c:124-138: u->v survives only if v^1 -> u^1 is present (del bits are not consulted, as in the reference)
 __global__ __launch_bounds__(256) void k_asg_asymm(ArcCols a, size_t n, const unsigned long long *__restrict__ idx, unsigned long long *__restrict__ ctr)
 {
-	size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-	int del = 0;
-	if (e < n) {
+	uint32_t cnt = 0;
+	for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
 		uint32_t v = a.v[e] ^ 1, u = a.u[e] ^ 1;
 		unsigned long long x = idx[v];
 		uint32_t st = (uint32_t)(x >> 32), nv = (uint32_t)x, i;
 		for (i = 0; i < nv; ++i) if (a.v[st + i] == u) break;
-		del = (i == nv);
+		if (i == nv) a.ol[e] |= ADEL, ++cnt; // only the ol column is written; the v column read above is never modified
 	}
-	// all reads of a.v precede the writes below only per thread; a.ol is a different column, so no hazard
-	if (del) a.ol[e] |= ADEL;
-	wv_count_add(&ctr[CT_NASYMM], del);
+	blk_add_u64(&ctr[CT_NASYMM], cnt);
 }
 
 // asg.c:83-101
 __global__ __launch_bounds__(256) void k_asg_short(ArcCols a, const unsigned long long *__restrict__ idx, uint32_t n_vtx, float drop_ratio, unsigned long long *__restrict__ ctr)
 {
-	uint32_t v = blockIdx.x * 256 + threadIdx.x, cnt = 0;
-	if (v < n_vtx) {
+	uint32_t cnt = 0;
+	for (uint32_t v = blockIdx.x * 256 + threadIdx.x; v < n_vtx; v += gridDim.x * 256) {
 		unsigned long long x = idx[v];
 		uint32_t st = (uint32_t)(x >> 32), nv = (uint32_t)x;
 		if (nv >= 2) {
@@ -296,8 +290,7 @@ __global__ __launch_bounds__(256) void k_asg_short(ArcCols a, const unsigned lon
 			for (i = i + 1; i < nv; ++i) a.ol[st + i] |= ADEL, ++cnt;
 		}
 	}
-	cnt = wv_sum_u32(cnt);
-	if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&ctr[CT_NSHORT], (unsigned long long)cnt);
+	blk_add_u64(&ctr[CT_NSHORT], cnt);
 }
 
 // ------------------------------------------------------------------------------------------------ import / export
@@ -391,7 +384,7 @@ extern "C" int mahip_sg_gen(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, co
 	ArcCols a0 = arcs_of(c, 0);
 	if (n) {
 		ProfScope ps(c, "k_sg_arcs", 64.0 * (double)c->n_live); // ma_sg_gen 32 r + 16 look-ups + 16 w
-		hipLaunchKernelGGL(k_sg_arcs, dim3(grid_for(n, 256)), dim3(256), 0, c->st, gcols_of(c), n, (const uint32_t*)P<uint32_t>(c->slen), P<uint8_t>(c->sdel),
+		hipLaunchKernelGGL(k_sg_arcs, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, gcols_of(c), n, (const uint32_t*)P<uint32_t>(c->slen), P<uint8_t>(c->sdel),
 		                   opt->max_hang, opt->int_frac, opt->min_ovlp, a0, P<uint32_t>(c->keep), ctr);
 	}
 	// asg_cleanup: arc_rm (order preserving) ...
@@ -456,7 +449,7 @@ extern "C" int mahip_asg_del_trans(mahip_ctx_t *c, int fuzz, uint32_t *n_reduced
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	if (V && c->n_arc) {
 		ProfScope ps(c, "k_asg_trans", 32.0 * (double)c->n_arc); // 16*(A+I)/A per arc, I ~ A on clean data
-		hipLaunchKernelGGL(k_asg_trans, dim3(grid_for(V, 4, 256 * 12)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
+		hipLaunchKernelGGL(k_asg_trans, dim3(grid_for(V, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
 		                   (const unsigned long long*)P<unsigned long long>(c->idx), (const uint8_t*)P<uint8_t>(c->sdel), V, (uint32_t)fuzz, P<uint32_t>(c->ovf), ctr);
 	}
 	CHK(ctr_fetch(c));
@@ -487,7 +480,7 @@ extern "C" int mahip_asg_symm(mahip_ctx_t *c, uint32_t *n_multi, uint32_t *n_asy
 	CHK(ctr_zero(c));
 	if (c->n_arc) {
 		ProfScope ps(c, "k_asg_multi", 16.0 * (double)c->n_arc);
-		hipLaunchKernelGGL(k_asg_multi, dim3(grid_for(c->n_arc, 256)), dim3(256), 0, c->st, arcs_of(c, c->ag), (size_t)c->n_arc, idx, ctr);
+		hipLaunchKernelGGL(k_asg_multi, dim3(grid_for(c->n_arc, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, arcs_of(c, c->ag), (size_t)c->n_arc, idx, ctr);
 	}
 	CHK(ctr_fetch(c));
 	nm = (uint32_t)c->h_ctr[CT_NMULTI];
@@ -495,7 +488,7 @@ extern "C" int mahip_asg_symm(mahip_ctx_t *c, uint32_t *n_multi, uint32_t *n_asy
 	CHK(ctr_zero(c));
 	if (c->n_arc) {
 		ProfScope ps(c, "k_asg_asymm", 32.0 * (double)c->n_arc);
-		hipLaunchKernelGGL(k_asg_asymm, dim3(grid_for(c->n_arc, 256)), dim3(256), 0, c->st, arcs_of(c, c->ag), (size_t)c->n_arc, idx, ctr);
+		hipLaunchKernelGGL(k_asg_asymm, dim3(grid_for(c->n_arc, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, arcs_of(c, c->ag), (size_t)c->n_arc, idx, ctr);
 	}
 	CHK(ctr_fetch(c));
 	na = (uint32_t)c->h_ctr[CT_NASYMM];
@@ -511,7 +504,7 @@ extern "C" int mahip_asg_del_short(mahip_ctx_t *c, float drop_ratio, uint32_t *n
 	if (!c->graph_ready) { mahip_set_error("mahip_asg_del_short: no graph"); return -1; }
 	uint32_t V = 2 * c->n_seq;
 	CHK(ctr_zero(c));
-	if (V && c->n_arc) hipLaunchKernelGGL(k_asg_short, dim3(grid_for(V, 256)), dim3(256), 0, c->st, arcs_of(c, c->ag), (const unsigned long long*)P<unsigned long long>(c->idx), V, drop_ratio, P<unsigned long long>(c->ctr));
+	if (V && c->n_arc) hipLaunchKernelGGL(k_asg_short, dim3(grid_for(V, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, arcs_of(c, c->ag), (const unsigned long long*)P<unsigned long long>(c->idx), V, drop_ratio, P<unsigned long long>(c->ctr));
 	CHK(ctr_fetch(c));
 	uint32_t ns = (uint32_t)c->h_ctr[CT_NSHORT];
 	if (n_short) *n_short = ns;

@@ -24,23 +24,18 @@ __global__ __launch_bounds__(256) void k_hit_keys(const ma_hit_t *__restrict__ h
                                                    uint32_t *__restrict__ val, unsigned long long *__restrict__ ctr,
                                                    uint32_t q_beg, uint32_t q_end)
 {
-	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	uint32_t mq = 0, ms = 0;
-	int in = 0;
-	if (i < n) {
+	uint32_t mq = 0, ms = 0, cnt = 0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
 		uint64_t k = h[i].qns;
 		uint32_t q = (uint32_t)(k >> 32);
-		in = q >= q_beg && q < q_end;
-		if (in) mq = q, ms = (uint32_t)k; else k = ~0ull;
+		if (q >= q_beg && q < q_end) { mq = q > mq ? q : mq; ms = (uint32_t)k > ms ? (uint32_t)k : ms; ++cnt; }
+		else k = ~0ull;
 		key[i] = k;
 		val[i] = (uint32_t)i;
 	}
-	for (int o = 32; o > 0; o >>= 1) {
-		uint32_t a = __shfl_xor(mq, o, 64), b = __shfl_xor(ms, o, 64);
-		mq = a > mq ? a : mq, ms = b > ms ? b : ms;
-	}
-	if ((threadIdx.x & 63) == 0) { atomicMax(&ctr[CT_MAXQID], (unsigned long long)mq); atomicMax(&ctr[CT_MAXQS], (unsigned long long)ms); }
-	wv_count_add(&ctr[CT_LIVE], in);
+	blk_max_u64(&ctr[CT_MAXQID], mq);
+	blk_max_u64(&ctr[CT_MAXQS], ms);
+	blk_add_u64(&ctr[CT_LIVE], cnt);
 }
 
 struct HitCols { uint32_t *qid, *qs, *qe, *tn, *ts, *te, *ml, *bl; };
@@ -70,15 +65,148 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ ma_hit_sub
-// reference hit.c:109-160.  One wave per query group: events (start<<1, end<<1|1) into LDS, wave bitonic
-// sort, depth sweep by ballot prefix counts, first-longest run with depth >= min_dp by a wave max-reduce.
-#define SUB_CAP 2048 // events per wave held in LDS
+// reference hit.c:109-160: per query read, the first longest interval covered by >= min_dp hits.
+//
+// Tier R (almost every read): ONE WAVE PER READ, everything in registers.  Each lane loads up to ITEMS/2 hits
+// (coalesced column loads), turns them into events (start<<1, end<<1|1), the wave sorts its 64*ITEMS events
+// with a bitonic network whose cross-lane steps are wave shuffles (no LDS round trips, no barriers), then the
+// depth sweep runs as one prefix scan over lanes plus a short in-register walk; the first-longest run is a
+// wave max-reduce on (length, -position).  Reads with more than 512 hits go to tier B.
+// Tier B: one 256-thread block per read, events in LDS (<= 8192) or in global scratch (any size).
+#define EV_PAD 0xffffffffu
+#define SUB_REG_MAX_HITS 512u
+#define SUB_LDS_EVENTS 8192u
 
-template <typename EV, typename UP>
-__device__ __forceinline__ uint64_t sub_sweep(const EV ev, UP up, uint32_t nev, int min_dp, unsigned tid, unsigned stride_is_wave)
+#define MA_CE(a, b) do { uint32_t lo_ = (a) < (b) ? (a) : (b), hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
+
+// ascending sort of the 64*ITEMS values held blocked (element lane*ITEMS + r) across one wave
+template <int ITEMS>
+__device__ __forceinline__ void wave_sort_regs(uint32_t (&x)[ITEMS], unsigned lane)
 {
-	// wave-only sweep over the sorted events; returns best = len<<32 | (~rank)
-	unsigned lane = tid & 63;
+#pragma unroll
+	for (int k = 2; k <= ITEMS; k <<= 1) { // inside a lane
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) { int p = r ^ (k - 1); if (p > r) MA_CE(x[r], x[p]); }
+#pragma unroll
+		for (int j = k >> 2; j > 0; j >>= 1)
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) if ((r & j) == 0) MA_CE(x[r], x[r | j]);
+	}
+#pragma unroll
+	for (int L = 2; L <= 64; L <<= 1) { // merge blocks of L lanes
+		{ // flip step: element e pairs with e ^ (L*ITEMS - 1) = (lane ^ (L-1), ITEMS-1-r)
+			const bool lower = (lane & (L >> 1)) == 0;
+			uint32_t y[ITEMS];
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) y[r] = __shfl_xor(x[ITEMS - 1 - r], L - 1, 64);
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) x[r] = lower ? (x[r] < y[r] ? x[r] : y[r]) : (x[r] < y[r] ? y[r] : x[r]);
+		}
+#pragma unroll
+		for (int m = L >> 2; m > 0; m >>= 1) { // half cleaners across lanes
+			const bool lower = (lane & m) == 0;
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) {
+				uint32_t y = __shfl_xor(x[r], m, 64);
+				x[r] = lower ? (x[r] < y ? x[r] : y) : (x[r] < y ? y : x[r]);
+			}
+		}
+#pragma unroll
+		for (int j = ITEMS >> 1; j > 0; j >>= 1) // half cleaners inside a lane
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) if ((r & j) == 0) MA_CE(x[r], x[r | j]);
+	}
+}
+
+// one read in registers; returns 1 if the read keeps an interval (value identical on all lanes)
+template <int ITEMS>
+__device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q, uint32_t beg, uint32_t end, int min_dp, float min_iden,
+                                                   int end_clip, uint2 *__restrict__ sub, unsigned lane)
+{
+	uint32_t x[ITEMS];
+	int live_any = 0, ev_any = 0;
+#pragma unroll
+	for (int h = 0; h < ITEMS / 2; ++h) {
+		uint32_t i = beg + h * 64 + lane;
+		x[2 * h] = x[2 * h + 1] = EV_PAD;
+		if (i < end) {
+			uint32_t bl = c.bl[i], ml = c.ml[i], qs = c.qs[i], qe = c.qe[i], tn = c.tn[i], es, ee; // independent loads
+			if (!(bl & DEAD)) {
+				live_any = 1;
+				if (mc_sub_ok(q, qs, qe, tn, (int32_t)(ml & 0x7fffffffu), (int32_t)bl, min_iden, end_clip, &es, &ee)) x[2 * h] = es, x[2 * h + 1] = ee, ev_any = 1;
+			}
+		}
+	}
+	if (wv_ballot(live_any) == 0) { if (lane == 0) sub[q] = make_uint2(0, 0); return 0; } // no surviving hit: not a group for the reference
+	if (wv_ballot(ev_any) == 0) { if (lane == 0) sub[q] = make_uint2(DEAD, 0); return 0; } // hit.c:152
+	wave_sort_regs<ITEMS>(x, lane);
+	// depth before this lane's first event
+	int net = 0;
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) if (x[r] != EV_PAD) net += (x[r] & 1) ? -1 : 1;
+	int incl = net;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(incl, o, 64); if (lane >= (unsigned)o) incl += y; }
+	int dp = incl - net;
+	// walk the lane's events: runs opened and closed here are resolved at once; at most one run per lane was
+	// opened in an earlier lane (its closing event is the lane's first down before any local up)
+	const uint32_t NONE = 0xffffffffu;
+	uint32_t cur_up = NONE, last_up = NONE, pend_pos = NONE, pend_idx = 0, best_s = 0;
+	uint64_t best = 0;
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) {
+		uint32_t e = x[r];
+		if (e == EV_PAD) continue;
+		int old = dp;
+		dp += (e & 1) ? -1 : 1;
+		if (old < min_dp && dp >= min_dp) cur_up = last_up = e >> 1;
+		else if (old >= min_dp && dp < min_dp) {
+			if (cur_up != NONE) {
+				uint64_t cand = (uint64_t)((e >> 1) - cur_up) << 32 | (0xffffffffu - (lane * ITEMS + r));
+				if (cand > best) best = cand, best_s = cur_up;
+				cur_up = NONE;
+			} else pend_pos = e >> 1, pend_idx = lane * ITEMS + r;
+		}
+	}
+	uint32_t carry = last_up; // start of the run that is open at the end of each lane: "last defined" scan
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(carry, o, 64); if (lane >= (unsigned)o && carry == NONE) carry = y; }
+	uint32_t before = __shfl_up(carry, 1, 64);
+	if (lane == 0) before = NONE;
+	if (pend_pos != NONE && before != NONE) {
+		uint64_t cand = (uint64_t)(pend_pos - before) << 32 | (0xffffffffu - pend_idx);
+		if (cand > best) best = cand, best_s = before;
+	}
+	uint64_t gbest = wv_max_u64(best);
+	uint32_t len = (uint32_t)(gbest >> 32);
+	if (len == 0) { if (lane == 0) sub[q] = make_uint2(DEAD, 0); return 0; } // strict '>' against an empty best (hit.c:142,146)
+	uint64_t own = wv_ballot(best == gbest);
+	uint32_t s = __shfl(best_s, __ffsll((long long)own) - 1, 64);
+	if (lane == 0) sub[q] = make_uint2((s - (uint32_t)end_clip) & 0x7fffffffu, s + len + (uint32_t)end_clip);
+	return 1;
+}
+
+__global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
+                                                  int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
+                                                  uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr)
+{
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t n_kept = 0;
+	for (uint32_t q = blockIdx.x * 4 + wave; q < n_seq; q += gridDim.x * 4) {
+		uint32_t beg = goff[q], end = goff[q + 1], H = end - beg;
+		if (H == 0) { if (lane == 0) sub[q] = make_uint2(0, 0); continue; } // never a query: calloc'ed zero (hit.c:115)
+		if (H <= 64) n_kept += sub_group_regs<2>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane);
+		else if (H <= 128) n_kept += sub_group_regs<4>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane);
+		else if (H <= 256) n_kept += sub_group_regs<8>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane);
+		else if (H <= SUB_REG_MAX_HITS) n_kept += sub_group_regs<16>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane);
+		else if (lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF], 1ull); ovf[k] = q; } // tier B
+	}
+	blk_add_u64(&ctr[CT_REMAIN], lane == 0 ? n_kept : 0);
+}
+
+// sweep over sorted events held in memory (tier B): ballot prefix counts per 64-event chunk, run starts by rank
+__device__ __forceinline__ uint64_t sub_sweep(const uint32_t *ev, uint32_t *up, uint32_t nev, int min_dp, unsigned lane)
+{
 	const uint64_t lt = wv_lt(lane), le = wv_le(lane);
 	int carry = 0;
 	uint32_t nup = 0, ndown = 0;
@@ -109,88 +237,43 @@ __device__ __forceinline__ uint64_t sub_sweep(const EV ev, UP up, uint32_t nev, 
 	return wv_max_u64(best);
 }
 
-__device__ __forceinline__ void sub_store(uint2 *sub, uint32_t q, uint64_t best, const uint32_t *up, int end_clip, int any_ev_group,
-                                          unsigned long long *ctr)
-{
-	uint32_t len = (uint32_t)(best >> 32);
-	if (len > 0) {
-		uint32_t s = up[0xffffffffu - (uint32_t)best];
-		sub[q] = make_uint2((s - (uint32_t)end_clip) & 0x7fffffffu, s + len + (uint32_t)end_clip);
-		atomicAdd(&ctr[CT_REMAIN], 1ull);
-	} else sub[q] = make_uint2(DEAD, 0);
-}
-
-__global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
-                                                  int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
-                                                  uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr)
-{
-	__shared__ uint32_t s_ev[4][SUB_CAP];
-	__shared__ uint32_t s_up[4][SUB_CAP / 2];
-	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint64_t lt = wv_lt(lane);
-	uint32_t *ev = s_ev[wave], *up = s_up[wave];
-	for (uint32_t q = blockIdx.x * 4 + wave; q < n_seq; q += gridDim.x * 4) {
-		uint32_t beg = goff[q], end = goff[q + 1];
-		if (beg == end) { if (lane == 0) sub[q] = make_uint2(0, 0); continue; } // never a query: calloc'ed zero (hit.c:115)
-		uint32_t nev = 0;
-		int any_live = 0;
-		for (uint32_t b = beg; b < end; b += 64) {
-			uint32_t i = b + lane;
-			int ok = 0, live = 0;
-			uint32_t es = 0, ee = 0;
-			if (i < end) {
-				uint32_t bl = c.bl[i];
-				live = !(bl & DEAD);
-				if (live) {
-					uint32_t ml = c.ml[i];
-					ok = mc_sub_ok(q, c.qs[i], c.qe[i], c.tn[i], (int32_t)(ml & 0x7fffffffu), (int32_t)bl, min_iden, end_clip, &es, &ee);
-				}
-			}
-			uint64_t m = wv_ballot(ok);
-			any_live |= wv_ballot(live) != 0;
-			uint32_t p = nev + 2 * (uint32_t)__popcll(m & lt);
-			if (ok && p + 1 < SUB_CAP) ev[p] = es, ev[p + 1] = ee;
-			nev += 2 * (uint32_t)__popcll(m);
-		}
-		if (!any_live) { if (lane == 0) sub[q] = make_uint2(0, 0); continue; } // no surviving hit: not a group for the reference
-		if (nev > SUB_CAP) { // oversized group: second tier
-			if (lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF], 1ull); ovf[k] = q; }
-			continue;
-		}
-		wv_sync();
-		MA_BITONIC(uint32_t, ev, nev, lane, 64, wv_sync());
-		uint64_t best = sub_sweep(ev, up, nev, min_dp, lane, 1);
-		if (lane == 0) sub_store(sub, q, best, up, end_clip, 1, ctr);
-		wv_sync();
-	}
-}
-
-// second tier: one 256-thread block per oversized group, events and run starts in global scratch
-// (ev at 2*goff[q], up at goff[q]: disjoint per group by construction)
+// tier B: one 256-thread block per oversized read; events (and run starts) in LDS when they fit, else in global
+// scratch (ev at 2*goff[q], up at goff[q]: disjoint per read by construction)
 __global__ __launch_bounds__(256) void k_hit_sub_big(HitCols c, const uint32_t *__restrict__ goff, const uint32_t *__restrict__ ovf, uint32_t n_ovf,
                                                       int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
                                                       uint32_t *__restrict__ gev, uint32_t *__restrict__ gup, unsigned long long *__restrict__ ctr)
 {
-	__shared__ uint32_t s_n;
+	__shared__ uint32_t s_ev[SUB_LDS_EVENTS], s_up[SUB_LDS_EVENTS / 2];
+	__shared__ uint32_t s_n, s_live;
 	for (uint32_t k = blockIdx.x; k < n_ovf; k += gridDim.x) {
 		uint32_t q = ovf[k], beg = goff[q], end = goff[q + 1];
-		uint32_t *ev = gev + 2 * (size_t)beg, *up = gup + beg;
-		if (threadIdx.x == 0) s_n = 0;
+		const bool in_lds = 2 * (end - beg) <= SUB_LDS_EVENTS;
+		uint32_t *ev = in_lds ? s_ev : gev + 2 * (size_t)beg, *up = in_lds ? s_up : gup + beg;
+		if (threadIdx.x == 0) s_n = 0, s_live = 0;
 		__syncthreads();
 		for (uint32_t i = beg + threadIdx.x; i < end; i += 256) {
 			uint32_t bl = c.bl[i], es, ee;
 			if (bl & DEAD) continue;
+			s_live = 1;
 			if (mc_sub_ok(q, c.qs[i], c.qe[i], c.tn[i], (int32_t)(c.ml[i] & 0x7fffffffu), (int32_t)bl, min_iden, end_clip, &es, &ee)) {
-				uint32_t p = atomicAdd(&s_n, 2u); // order irrelevant: sorted next
+				uint32_t p = atomicAdd(&s_n, 2u); // any order: sorted next, equal values are indistinguishable
 				ev[p] = es, ev[p + 1] = ee;
 			}
 		}
 		__syncthreads();
-		uint32_t nev = s_n;
+		uint32_t nev = s_n, live = s_live;
+		if (!live) { if (threadIdx.x == 0) sub[q] = make_uint2(0, 0); __syncthreads(); continue; }
 		MA_BITONIC(uint32_t, ev, nev, threadIdx.x, 256, __syncthreads());
 		if (threadIdx.x < 64) {
-			uint64_t best = sub_sweep(ev, up, nev, min_dp, threadIdx.x, 1);
-			if (threadIdx.x == 0) sub_store(sub, q, best, up, end_clip, 1, ctr);
+			uint64_t best = sub_sweep(ev, up, nev, min_dp, threadIdx.x);
+			if (threadIdx.x == 0) {
+				uint32_t len = (uint32_t)(best >> 32);
+				if (len > 0) {
+					uint32_t s = up[0xffffffffu - (uint32_t)best];
+					sub[q] = make_uint2((s - (uint32_t)end_clip) & 0x7fffffffu, s + len + (uint32_t)end_clip);
+					atomicAdd(&ctr[CT_REMAIN], 1ull);
+				} else sub[q] = make_uint2(DEAD, 0);
+			}
 		}
 		__syncthreads();
 	}
@@ -200,21 +283,21 @@ __global__ __launch_bounds__(256) void k_hit_sub_big(HitCols c, const uint32_t *
 // reference hit.c:162-193, one thread per hit; removed hits only get their dead bit
 __global__ __launch_bounds__(256) void k_hit_cut(HitCols c, size_t n, const uint2 *__restrict__ sub, int min_span, unsigned long long *__restrict__ ctr)
 {
-	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	int keep = 0;
-	if (i < n) {
+	uint32_t n_keep = 0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
 		uint32_t bl = c.bl[i];
-		if (!(bl & DEAD)) {
-			uint2 rq = sub[c.qid[i]], rt = sub[c.tn[i]];
-			if (!(rq.x & DEAD) && !(rt.x & DEAD)) {
-				uint32_t qs = c.qs[i], qe = c.qe[i], ts = c.ts[i], te = c.te[i];
-				keep = mc_cut(&qs, &qe, &ts, &te, c.ml[i] >> 31, (int32_t)rq.x, rq.y, (int32_t)rt.x, rt.y, min_span);
-				if (keep) c.qs[i] = qs, c.qe[i] = qe, c.ts[i] = ts, c.te[i] = te;
-			}
-			if (!keep) c.bl[i] = bl | DEAD;
+		if (bl & DEAD) continue;
+		int keep = 0;
+		uint2 rq = sub[c.qid[i]], rt = sub[c.tn[i]];
+		if (!(rq.x & DEAD) && !(rt.x & DEAD)) {
+			uint32_t qs = c.qs[i], qe = c.qe[i], ts = c.ts[i], te = c.te[i];
+			keep = mc_cut(&qs, &qe, &ts, &te, c.ml[i] >> 31, (int32_t)rq.x, rq.y, (int32_t)rt.x, rt.y, min_span);
+			if (keep) c.qs[i] = qs, c.qe[i] = qe, c.ts[i] = ts, c.te[i] = te;
 		}
+		if (!keep) c.bl[i] = bl | DEAD;
+		n_keep += keep;
 	}
-	wv_count_add(&ctr[CT_LIVE], keep);
+	blk_add_u64(&ctr[CT_LIVE], n_keep);
 }
 
 // ------------------------------------------------------------------------------------------------ ma_hit_flt
@@ -222,39 +305,37 @@ __global__ __launch_bounds__(256) void k_hit_cut(HitCols c, size_t n, const uint
 __global__ __launch_bounds__(256) void k_hit_flt(HitCols c, size_t n, const uint2 *__restrict__ sub, int max_hang, int min_ovlp,
                                                   uint8_t *__restrict__ r_live, unsigned long long *__restrict__ ctr)
 {
-	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	int keep = 0;
+	uint32_t n_keep = 0;
 	uint64_t dp = 0;
-	if (i < n) {
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
 		uint32_t bl = c.bl[i];
-		if (!(bl & DEAD)) {
-			uint32_t q = c.qid[i], t = c.tn[i];
-			uint2 sq = sub[q], st = sub[t];
-			if (!(sq.x & DEAD) && !(st.x & DEAD)) {
-				mc_arc_t a;
-				uint32_t ql = sq.y - (sq.x & 0x7fffffffu), tl = st.y - (st.x & 0x7fffffffu);
-				int r = mc_hit2arc(q, c.qs[i], c.qe[i], t, c.ts[i], c.te[i], c.ml[i] >> 31, (int)ql, (int)tl, max_hang, .5f, min_ovlp, &a);
-				if (r >= 0 || r == MC_HT_QCONT || r == MC_HT_TCONT) {
-					keep = 1;
-					dp = r >= 0 ? (uint32_t)r : r == MC_HT_QCONT ? ql : tl;
-					r_live[q] = 1;
-				}
+		if (bl & DEAD) continue;
+		int keep = 0;
+		uint32_t q = c.qid[i], t = c.tn[i];
+		uint2 sq = sub[q], st = sub[t];
+		if (!(sq.x & DEAD) && !(st.x & DEAD)) {
+			mc_arc_t a;
+			uint32_t ql = sq.y - (sq.x & 0x7fffffffu), tl = st.y - (st.x & 0x7fffffffu);
+			int r = mc_hit2arc(q, c.qs[i], c.qe[i], t, c.ts[i], c.te[i], c.ml[i] >> 31, (int)ql, (int)tl, max_hang, .5f, min_ovlp, &a);
+			if (r >= 0 || r == MC_HT_QCONT || r == MC_HT_TCONT) {
+				keep = 1;
+				dp += r >= 0 ? (uint32_t)r : r == MC_HT_QCONT ? ql : tl;
+				r_live[q] = 1;
 			}
-			if (!keep) c.bl[i] = bl | DEAD;
 		}
+		if (!keep) c.bl[i] = bl | DEAD;
+		n_keep += keep;
 	}
-	wv_count_add(&ctr[CT_LIVE], keep);
-	dp = wv_sum_u64(dp);
-	if ((threadIdx.x & 63) == 0 && dp) atomicAdd(&ctr[CT_TOTDP], (unsigned long long)dp);
+	blk_add_u64(&ctr[CT_LIVE], n_keep);
+	blk_add_u64(&ctr[CT_TOTDP], dp);
 }
 
 __global__ __launch_bounds__(256) void k_flt_totlen(const uint2 *__restrict__ sub, const uint8_t *__restrict__ r_live, uint32_t n_seq, unsigned long long *__restrict__ ctr)
 {
-	uint32_t r = blockIdx.x * 256 + threadIdx.x;
 	uint64_t x = 0;
-	if (r < n_seq && r_live[r]) { uint2 s = sub[r]; x = (uint32_t)(s.y - (s.x & 0x7fffffffu)); }
-	x = wv_sum_u64(x);
-	if ((threadIdx.x & 63) == 0 && x) atomicAdd(&ctr[CT_TOTLEN], (unsigned long long)x);
+	for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n_seq; r += gridDim.x * 256)
+		if (r_live[r]) { uint2 s = sub[r]; x += (uint32_t)(s.y - (s.x & 0x7fffffffu)); }
+	blk_add_u64(&ctr[CT_TOTLEN], x);
 }
 
 // ------------------------------------------------------------------------------------------------ ma_sub_merge
@@ -276,17 +357,17 @@ __global__ __launch_bounds__(256) void k_sub_merge(uint2 *__restrict__ a, const 
 __global__ __launch_bounds__(256) void k_hit_contained(HitCols c, size_t n, const uint2 *__restrict__ sub, int max_hang, float int_frac, int min_ovlp,
                                                         uint8_t *__restrict__ r_cont, uint8_t *__restrict__ r_used)
 {
-	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (i >= n) return;
-	if (c.bl[i] & DEAD) return;
-	uint32_t q = c.qid[i], t = c.tn[i];
-	uint2 sq = sub[q], st = sub[t];
-	mc_arc_t a;
-	int r = mc_hit2arc(q, c.qs[i], c.qe[i], t, c.ts[i], c.te[i], c.ml[i] >> 31, (int)(sq.y - (sq.x & 0x7fffffffu)),
-	                   (int)(st.y - (st.x & 0x7fffffffu)), max_hang, int_frac, min_ovlp, &a);
-	if (r == MC_HT_QCONT) r_cont[q] = 1;
-	else if (r == MC_HT_TCONT) r_cont[t] = 1;
-	r_used[q] = 1; r_used[t] = 1;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+		if (c.bl[i] & DEAD) continue;
+		uint32_t q = c.qid[i], t = c.tn[i];
+		uint2 sq = sub[q], st = sub[t];
+		mc_arc_t a;
+		int r = mc_hit2arc(q, c.qs[i], c.qe[i], t, c.ts[i], c.te[i], c.ml[i] >> 31, (int)(sq.y - (sq.x & 0x7fffffffu)),
+		                   (int)(st.y - (st.x & 0x7fffffffu)), max_hang, int_frac, min_ovlp, &a);
+		if (r == MC_HT_QCONT) r_cont[q] = 1;
+		else if (r == MC_HT_TCONT) r_cont[t] = 1;
+		r_used[q] = 1; r_used[t] = 1;
+	}
 }
 
 __global__ __launch_bounds__(256) void k_read_del(const uint2 *__restrict__ sub, const uint8_t *__restrict__ r_cont, const uint8_t *__restrict__ r_used,
@@ -308,16 +389,15 @@ __global__ __launch_bounds__(256) void k_map_fix(int32_t *__restrict__ map, cons
 
 __global__ __launch_bounds__(256) void k_hit_squeeze(HitCols c, size_t n, const uint8_t *__restrict__ r_del, unsigned long long *__restrict__ ctr)
 {
-	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	int keep = 0;
-	if (i < n) {
+	uint32_t n_keep = 0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
 		uint32_t bl = c.bl[i];
-		if (!(bl & DEAD)) {
-			keep = !r_del[c.qid[i]] && !r_del[c.tn[i]];
-			if (!keep) c.bl[i] = bl | DEAD;
-		}
+		if (bl & DEAD) continue;
+		int keep = !r_del[c.qid[i]] && !r_del[c.tn[i]];
+		if (!keep) c.bl[i] = bl | DEAD;
+		n_keep += keep;
 	}
-	wv_count_add(&ctr[CT_LIVE], keep);
+	blk_add_u64(&ctr[CT_LIVE], n_keep);
 }
 
 // ------------------------------------------------------------------------------------------------ export
@@ -419,7 +499,7 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	{
 		ProfScope ps(c, "k_hit_keys", 20.0 * (double)n); // reads qns (8 B), writes key+val (12 B)
-		hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]), ctr, c->q_beg, c->q_end);
+		hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]), ctr, c->q_beg, c->q_end);
 	}
 	CHK(ctr_fetch(c));
 	size_t n_in = (size_t)c->h_ctr[CT_LIVE];
@@ -462,7 +542,7 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 	uint2 *sub = P<uint2>(c->sub[slot]);
 	if (R) {
 		ProfScope ps(c, "k_hit_sub", 24.0 * (double)c->n_hits + 8.0 * R);
-		hipLaunchKernelGGL(k_hit_sub, dim3(grid_for(R, 4, 256 * 20)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL(k_hit_sub, dim3(grid_for(R, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr);
 	}
 	CHK(ctr_fetch(c));
@@ -488,7 +568,7 @@ extern "C" int mahip_hits_cut(mahip_ctx_t *c, int slot, int min_span, size_t *n_
 	CHK(ctr_zero(c));
 	if (n) {
 		ProfScope ps(c, "k_hit_cut", 80.0 * (double)c->n_live); // 32 r + 2x8 sub look-ups + 32 w per hit
-		hipLaunchKernelGGL(k_hit_cut, dim3(grid_for(n, 256)), dim3(256), 0, c->st, cols_of(c), n, (const uint2*)P<uint2>(c->sub[slot]), min_span, P<unsigned long long>(c->ctr));
+		hipLaunchKernelGGL(k_hit_cut, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, cols_of(c), n, (const uint2*)P<uint2>(c->sub[slot]), min_span, P<unsigned long long>(c->ctr));
 	}
 	CHK(ctr_fetch(c));
 	c->n_live = (size_t)c->h_ctr[CT_LIVE];
@@ -506,10 +586,10 @@ extern "C" int mahip_hits_flt(mahip_ctx_t *c, int slot, int max_hang, int min_ov
 	HIPCHK(hipMemsetAsync(c->r_live.p, 0, R, c->st));
 	if (n) {
 		ProfScope ps(c, "k_hit_flt", 80.0 * (double)c->n_live);
-		hipLaunchKernelGGL(k_hit_flt, dim3(grid_for(n, 256)), dim3(256), 0, c->st, cols_of(c), n, (const uint2*)P<uint2>(c->sub[slot]), max_hang, min_ovlp,
+		hipLaunchKernelGGL(k_hit_flt, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, cols_of(c), n, (const uint2*)P<uint2>(c->sub[slot]), max_hang, min_ovlp,
 		                   P<uint8_t>(c->r_live), P<unsigned long long>(c->ctr));
 	}
-	if (R) hipLaunchKernelGGL(k_flt_totlen, dim3(grid_for(R, 256)), dim3(256), 0, c->st, (const uint2*)P<uint2>(c->sub[slot]), (const uint8_t*)P<uint8_t>(c->r_live), R, P<unsigned long long>(c->ctr));
+	if (R) hipLaunchKernelGGL(k_flt_totlen, dim3(grid_for(R, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint2*)P<uint2>(c->sub[slot]), (const uint8_t*)P<uint8_t>(c->r_live), R, P<unsigned long long>(c->ctr));
 	CHK(ctr_fetch(c));
 	c->n_live = (size_t)c->h_ctr[CT_LIVE];
 	if (n_live) *n_live = c->n_live;
@@ -542,7 +622,7 @@ extern "C" int mahip_hits_contained(mahip_ctx_t *c, const ma_opt_t *opt, const u
 	const uint2 *sub = P<uint2>(c->sub[0]);
 	if (n) {
 		ProfScope ps(c, "k_hit_contained", 48.0 * (double)c->n_live);
-		hipLaunchKernelGGL(k_hit_contained, dim3(grid_for(n, 256)), dim3(256), 0, c->st, h, n, sub, opt->max_hang, opt->int_frac, opt->min_ovlp,
+		hipLaunchKernelGGL(k_hit_contained, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, h, n, sub, opt->max_hang, opt->int_frac, opt->min_ovlp,
 		                   P<uint8_t>(c->r_cont), P<uint8_t>(c->r_used));
 	}
 	uint32_t *d_tot = (uint32_t*)(P<unsigned long long>(c->ctr) + CT_TOTAL);
@@ -554,7 +634,7 @@ extern "C" int mahip_hits_contained(mahip_ctx_t *c, const ma_opt_t *opt, const u
 	}
 	if (n) {
 		ProfScope ps(c, "k_hit_squeeze", 72.0 * (double)c->n_live);
-		hipLaunchKernelGGL(k_hit_squeeze, dim3(grid_for(n, 256)), dim3(256), 0, c->st, h, n, (const uint8_t*)P<uint8_t>(c->r_del), P<unsigned long long>(c->ctr));
+		hipLaunchKernelGGL(k_hit_squeeze, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, h, n, (const uint8_t*)P<uint8_t>(c->r_del), P<unsigned long long>(c->ctr));
 	}
 	CHK(ctr_fetch(c));
 	c->n_live = (size_t)c->h_ctr[CT_LIVE];

@@ -150,6 +150,37 @@ __device__ __forceinline__ void wv_count_add(unsigned long long *ctr, int p)
 	uint64_t m = __ballot(p);
 	if (m && wv_lane() == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(ctr, (unsigned long long)__popcll(m));
 }
+// Block-level reductions into a global counter: ONE atomic per block.  A single counter word sustains only
+// ~88 atomics/us on MI355X, so per-wave atomics from a 20M-element pass cost milliseconds; kernels therefore run
+// as grid-stride loops over <= 2048 blocks, keep private partial results and call these once at the end.
+// Every thread of the block must call (contains __syncthreads); blocks have <= 512 threads.
+__device__ __forceinline__ void blk_add_u64(unsigned long long *ctr, uint64_t x)
+{
+	__shared__ unsigned long long s_part[8];
+	x = wv_sum_u64(x);
+	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = x;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long t = 0;
+		for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) t += s_part[w];
+		if (t) atomicAdd(ctr, t);
+	}
+	__syncthreads();
+}
+__device__ __forceinline__ void blk_max_u64(unsigned long long *ctr, uint64_t x)
+{
+	__shared__ unsigned long long s_part[8];
+	x = wv_max_u64(x);
+	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = x;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long t = 0;
+		for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) t = s_part[w] > t ? s_part[w] : t;
+		if (t) atomicMax(ctr, t);
+	}
+	__syncthreads();
+}
+#define MA_STREAM_BLOCKS 2048u // 256 CUs x 8 blocks of 256 threads: full occupancy for streaming passes
 
 // All-ascending bitonic network on a[0..n) (n need not be a power of two: indices >= n act as +inf).
 // STRIDE threads cooperate (tid in [0,STRIDE)); SYNC() separates the stages.
