@@ -9,8 +9,10 @@ ingest is host work outside the boundary; its rate and the PCIe-inclusive rate a
 
 Workload at N=1: BASELINE.json configs[1] -- synthetic 10M-overlap PAF, 200k reads, lognormal lengths with mean
 8 kb, ~50 lines per read (miniasm_amd/bin/pafgen -r 200000 -n 10000000 -s 1).
-N>1 (launched by torch.distributed.run, one rank per GPU): every rank runs the same pipeline on its own shard
-of reads (weak scaling: 10M overlaps per GPU); value = all ranks' lines / max-over-ranks time.
+N>1 (launched by torch.distributed.run, one rank per GPU): ONE data set of N x 10M overlaps / N x 200k reads, sharded by
+query-read range; every rank runs the hit passes on its shard, sub / flag arrays and the arc blocks are exchanged over
+RCCL (miniasm_amd/sharded.py), rank 0 finishes the graph and writes the GFA.  Weak scaling: per-GPU work is fixed;
+value = global overlaps / max-over-ranks time.
 
 One JSON line on stdout (rank 0).
 """
@@ -123,31 +125,65 @@ def main():
     L.sys_init()
 
     # ---- setup (untimed): synthetic PAF text -> host ingest -> unsorted hit records into HBM
-    seed = args.seed + rank  # one shard of reads per rank (weak scaling)
+    # one global data set of world x (reads, lines); every rank parses it (same dictionary everywhere) and keeps the
+    # hits whose query read falls into its range
+    import numpy as np
+    from miniasm_amd.sharded import Comm, GpuBackend, run_sharded, shard_range
+    g_reads, g_lines = args.reads * world, args.lines * world
     t0 = time.perf_counter()
-    paf = gen_paf(os.path.join(args.workdir, "w_%s_r%d_n%d_s%d.paf" % (args.model, args.reads, args.lines, seed)), args.reads, args.lines, seed, args.gen_extra)
+    paf = os.path.join(args.workdir, "w_%s_r%d_n%d_s%d.paf" % (args.model, g_reads, g_lines, args.seed))
+    if rank == 0:
+        gen_paf(paf, g_reads, g_lines, args.seed, args.gen_extra)
+    if world > 1:
+        dist.barrier()
     t_gen = time.perf_counter() - t0
     opt = ma.default_opt()
     t0 = time.perf_counter()
     ing = ma.Ingest(paf, opt)
     t_ingest = time.perf_counter() - t0
     n_lines = sum(1 for _ in open(paf, "rb"))
-    hits_host = torch.from_numpy(ing.hits.view("u1").reshape(-1))
+    n_seq = ing.n_seq
+    _, q0, q1 = shard_range(n_seq, world, rank)
+    if world > 1:
+        q = (ing.hits["qns"] >> np.uint64(32)).astype(np.int64)
+        my_hits = np.ascontiguousarray(ing.hits[(q >= q0) & (q < q1)])
+        del q
+    else:
+        my_hits = ing.hits.copy()
+    n_my, n_all = len(my_hits), ing.n
+    ing.free_hits()
+    hits_host = torch.from_numpy(my_hits.view("u1").reshape(-1))
     t0 = time.perf_counter()
     hits_dev = hits_host.to("cuda", non_blocking=False)
     torch.cuda.synchronize()
     t_h2d = time.perf_counter() - t0
     if rank == 0:
-        log("workload: %d lines, %d stored hits, %d reads; gen %.1fs ingest %.2fs (%.2f M lines/s) H2D %.3fs (%.1f GB/s)" % (
-            n_lines, ing.n, ing.n_seq, t_gen, t_ingest, n_lines / t_ingest / 1e6, t_h2d, ing.n * 32 / t_h2d / 1e9))
+        log("workload: %d lines, %d stored hits (%d on this rank), %d reads; gen %.1fs ingest %.2fs (%.2f M lines/s) H2D %.3fs (%.1f GB/s)" % (
+            n_lines, n_all, n_my, n_seq, t_gen, t_ingest, n_lines / t_ingest / 1e6, t_h2d, n_my * 32 / max(t_h2d, 1e-9) / 1e9))
 
-    ctx = ma.Ctx(local)
+    if world > 1:  # sharded mode: the context runs on a torch stream so RCCL collectives and kernels share one stream
+        be = GpuBackend.create(local, n_seq)
+        ctx = be.ctx
+    else:
+        ctx, be = ma.Ctx(local), None
     buf, ln = C.c_void_p(0), C.c_size_t(0)
+    L.ma_pipeline_tail_mem.restype = C.c_int
+    L.ma_pipeline_tail_mem.argtypes = [C.c_void_p, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.POINTER(C.c_uint32 * 4),
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    comm = Comm()
 
     def step():
-        ma._chk(L.mahip_hits_adopt(ctx.h, hits_dev.data_ptr(), ing.n, ing.n_seq), "adopt")
-        rc = L.ma_pipeline_device_mem(ctx.h, C.byref(opt), ing.d, b"ug", 100, 0, C.byref(buf), C.byref(ln))
-        assert rc == 0
+        ma._chk(L.mahip_hits_adopt(ctx.h, hits_dev.data_ptr(), n_my, n_seq), "adopt")
+        if world == 1:  # single GPU: the C pipeline end to end
+            rc = L.ma_pipeline_device_mem(ctx.h, C.byref(opt), ing.d, b"ug", 100, 0, C.byref(buf), C.byref(ln))
+            assert rc == 0
+        else:  # sharded: device passes + RCCL exchanges on every rank, graph cleaning + GFA on rank 0
+            stats = run_sharded(be, comm, opt, n_seq)
+            if rank != 0:
+                return 0
+            st = (C.c_uint32 * 4)(1, 1, stats["n_red"], 1)
+            rc = L.ma_pipeline_tail_mem(ctx.h, C.byref(opt), ing.d, b"ug", 100, C.byref(st), C.byref(buf), C.byref(ln))
+            assert rc == 0
         n = ln.value
         L.free_buf(buf)
         return n
@@ -166,13 +202,10 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt, float(n_lines)], dtype=torch.float64, device="cuda")
-        tmax = t.clone()
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, total_lines = float(tmax[0]), float(t[1])
-    else:
-        total_lines = float(n_lines)
+        dt = float(tmax[0])
+    total_lines = float(n_lines)  # the global data set (world x per-GPU lines)
 
     # ---- per-kernel timing with HIP events on the launch stream (separate, instrumented steps)
     roof, kernels = None, []
@@ -208,11 +241,11 @@ def main():
             "value": total_lines * args.steps / dt, "unit": "overlaps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "synthetic %s PAF: %d overlaps, %d reads, mean 8 kb, %.1f stored hits/read, seed %d%s; inputs = unsorted 32-byte hit records resident in HBM; output = GFA text (%d bytes)" % (
-                args.model, n_lines, ing.n_seq, ing.n / max(ing.n_seq, 1), args.seed, " (+rank per GPU)" if world > 1 else "", gfa_len),
-                "per_gpu_overlaps": n_lines, "parallelism": "read-shard x%d" % world},
+            "config": {"workload": "synthetic %s PAF: %d overlaps, %d reads, mean 8 kb, %.1f stored hits/read, seed %d; inputs = unsorted 32-byte hit records resident in HBM%s; output = GFA text (%d bytes)" % (
+                args.model, n_lines, n_seq, n_all / max(n_seq, 1), args.seed, " (sharded by query-read range)" if world > 1 else "", gfa_len),
+                "per_gpu_overlaps": n_lines // world, "parallelism": "read-range shards x%d, RCCL all-gather of sub/flags/arcs" % world if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels[:12],
-            "setup": {"ingest_lines_per_s": n_lines / t_ingest, "h2d_GBs": ing.n * 32 / t_h2d / 1e9, "hbm_bytes_held": ctx.mem_bytes()},
+            "setup": {"ingest_lines_per_s": n_lines / t_ingest, "h2d_GBs": n_my * 32 / max(t_h2d, 1e-9) / 1e9, "hbm_bytes_held": ctx.mem_bytes()},
         }
         print(json.dumps(out), flush=True)
     ing.close()

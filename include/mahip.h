@@ -76,6 +76,37 @@ uint32_t mahip_asg_n_arc(mahip_ctx_t *c);
 /* fills g (arc/seq/idx malloc'ed, is_srt=1) in the squeezed numbering */
 int mahip_asg_download(mahip_ctx_t *c, asg_t *g);
 
+/* ---- building blocks of the sharded multi-GPU mode ---------------------------------------------------
+ * One context per GPU owns the hits whose query id lies in its read range (mahip_set_shard).  Passes that read
+ * another read's sub/flags need the complete read-indexed arrays, so the caller exchanges them between the
+ * split halves below (RCCL all-gather / max all-reduce through torch.distributed in miniasm_amd/sharded.py);
+ * the arcs are exchanged once, before the transitive reduction. */
+#define MAHIP_BUF_SUB0  0   /* uint2 [n_seq] */
+#define MAHIP_BUF_SUB1  1
+#define MAHIP_BUF_RCONT 2   /* u8 [n_seq] contained flags   (hit.c:234-235) */
+#define MAHIP_BUF_RUSED 3   /* u8 [n_seq] touched-by-a-hit  (hit.c:24-36) */
+#define MAHIP_BUF_SDEL  4   /* u8 [n_seq] seq.del           (asm.c:27-34) */
+/* device-to-device copies of elements [first, first+count) out of / into one of the arrays above */
+int mahip_copy_out(mahip_ctx_t *c, int which, void *d_dst, size_t first, size_t count);
+int mahip_copy_in(mahip_ctx_t *c, int which, const void *d_src, size_t first, size_t count);
+/* hit.c:225-256 split at the point where the flags must be complete */
+int mahip_hits_contained_flags(mahip_ctx_t *c, const ma_opt_t *opt);
+int mahip_hits_contained_finish(mahip_ctx_t *c, const uint8_t *seq_del, uint32_t *n_seq_new, size_t *n_live);
+/* asm.c:9-39 split at the point where seq.del must be complete */
+int mahip_sg_flags(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, const uint32_t *seq_len, const uint8_t *seq_del);
+int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc);
+/* local sorted arcs as packed rows {u, v, len, ol|del<<31} (16 B each) */
+int mahip_asg_export_rows(mahip_ctx_t *c, void *d_dst);
+/* replace the graph by the concatenation of n_ranks blocks of rows (block r holds counts[r] rows at d_src + r*stride rows) */
+int mahip_asg_import_rows(mahip_ctx_t *c, const void *d_src, const uint32_t *counts, int n_ranks, size_t stride);
+/* asg.c:148-186 marking for the vertices [v_beg, v_end) only, no cleanup */
+int mahip_asg_del_trans_range(mahip_ctx_t *c, int fuzz, uint32_t v_beg, uint32_t v_end, uint32_t *n_reduced);
+/* the ol|del column of arcs [first, first+count) out of / into the graph */
+int mahip_asg_flags_out(mahip_ctx_t *c, void *d_dst, size_t first, size_t count);
+int mahip_asg_flags_in(mahip_ctx_t *c, const void *d_src, size_t first, size_t count);
+/* asg.c:72-80 asg_cleanup on the current graph */
+int mahip_asg_cleanup(mahip_ctx_t *c, uint32_t *n_arc);
+
 /* ---- instrumentation -------------------------------------------------------------------------------- */
 /* Per-kernel timing with HIP events on the launch stream.  enable=1 brackets every kernel launch with
  * events (adds launch overhead; use for measurement runs only). */

@@ -293,8 +293,12 @@ class Ingest:
         n = C.c_size_t(0)
         p = L.ma_hit_ingest(fn.encode(), opt.min_span, opt.min_match, self.d, C.byref(n), 1 if bi_dir else 0, None)
         self.n = n.value
-        self.hits = np.frombuffer(C.string_at(p, self.n * 32), dtype=HIT_DT).copy() if self.n else np.zeros(0, HIT_DT)
-        L.free_buf(p)
+        self._p = p  # malloc'ed by the library; self.hits is a zero-copy view of it (no second copy of multi-GB arrays)
+        if self.n:
+            raw = (C.c_uint8 * (self.n * 32)).from_address(p)
+            self.hits = np.frombuffer(raw, dtype=HIT_DT)
+        else:
+            self.hits = np.zeros(0, HIT_DT)
         self.n_seq = self.d.contents.n_seq
 
     def names(self):
@@ -305,7 +309,15 @@ class Ingest:
         d = self.d.contents
         return np.array([d.seq[i].len for i in range(d.n_seq)], dtype=np.uint32)
 
+    def free_hits(self):
+        """release the host copy of the hit records (the dictionary stays)"""
+        self.hits = np.zeros(0, HIT_DT)
+        if self._p:
+            lib().free_buf(self._p)
+            self._p = None
+
     def close(self):
+        self.free_hits()
         if self.d:
             lib().sd_destroy(self.d)
             self.d = None

@@ -145,14 +145,14 @@ __device__ __forceinline__ int tr_find(const uint32_t *hk, uint32_t x, uint32_t 
 }
 
 __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ av, const uint32_t *__restrict__ alen, uint32_t *__restrict__ aol,
-                                                    const unsigned long long *__restrict__ idx, const uint8_t *__restrict__ sdel, uint32_t n_vtx,
+                                                    const unsigned long long *__restrict__ idx, const uint8_t *__restrict__ sdel, uint32_t v_beg, uint32_t n_vtx,
                                                     uint32_t fuzz, uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr)
-{
+{ // processes the vertices [v_beg, n_vtx): the whole graph on one GPU, a rank's own read range in the sharded mode
 	__shared__ uint32_t s_v[4][TR_CAP], s_l[4][TR_CAP], s_hk[4][TR_HASH], s_hm[4][TR_HASH];
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t *lv = s_v[wave], *ll = s_l[wave], *hk = s_hk[wave], *hm = s_hm[wave];
 	uint32_t n_red = 0;
-	for (uint32_t v = blockIdx.x * 4 + wave; v < n_vtx; v += gridDim.x * 4) {
+	for (uint32_t v = v_beg + blockIdx.x * 4 + wave; v < n_vtx; v += gridDim.x * 4) {
 		unsigned long long x = idx[v];
 		uint32_t st = (uint32_t)(x >> 32), nv = (uint32_t)x;
 		if (nv == 0) continue;
@@ -363,8 +363,8 @@ static int arc_cleanup(mahip_ctx *c, size_t n_in, int keep_in, int index_mode)
 
 static int bitlen_u64(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
 
-extern "C" int mahip_sg_gen(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, const uint32_t *seq_len, const uint8_t *seq_del, uint32_t *n_arc)
-{
+extern "C" int mahip_sg_flags(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, const uint32_t *seq_len, const uint8_t *seq_del)
+{ // asm.c:14-35: seq.len/seq.del, one candidate arc per hit at the hit's slot, local seq.del side effects
 	HIPCHK(hipSetDevice(c->dev));
 	if (!c->soa_ready) { mahip_set_error("mahip_sg_gen: hits not indexed"); return -1; }
 	size_t n = c->n_hits;
@@ -381,15 +381,21 @@ extern "C" int mahip_sg_gen(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, co
 	if (R) hipLaunchKernelGGL(k_sg_seq, dim3(grid_for(R, 256)), dim3(256), 0, c->st, use_sub ? (const uint2*)P<uint2>(c->sub[0]) : (const uint2*)nullptr,
 	                          c->has_map ? (const uint8_t*)P<uint8_t>(c->r_del) : (const uint8_t*)nullptr, d_len, d_del, R, P<uint32_t>(c->slen), P<uint8_t>(c->sdel));
 	c->ag = 0;
-	ArcCols a0 = arcs_of(c, 0);
 	if (n) {
 		ProfScope ps(c, "k_sg_arcs", 64.0 * (double)c->n_live); // ma_sg_gen 32 r + 16 look-ups + 16 w
 		hipLaunchKernelGGL(k_sg_arcs, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, gcols_of(c), n, (const uint32_t*)P<uint32_t>(c->slen), P<uint8_t>(c->sdel),
-		                   opt->max_hang, opt->int_frac, opt->min_ovlp, a0, P<uint32_t>(c->keep), ctr);
+		                   opt->max_hang, opt->int_frac, opt->min_ovlp, arcs_of(c, 0), P<uint32_t>(c->keep), ctr);
 	}
-	// asg_cleanup: arc_rm (order preserving) ...
-	CHK(arc_cleanup(c, n, 1, -1));
-	// ... sort by (u, len) ...
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
+{ // asg_cleanup (asg.c:72-80) on the candidates: arc_rm (order preserving), sort by (u,len), index
+	HIPCHK(hipSetDevice(c->dev));
+	size_t n = c->n_hits;
+	uint32_t R = c->n_seq;
+	CHK(arc_cleanup(c, n, 1, -1)); // fetches the counters: CT_MAXLEN was set by k_sg_arcs
 	if (c->n_arc > 1) {
 		size_t m = c->n_arc;
 		for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }
@@ -403,10 +409,85 @@ extern "C" int mahip_sg_gen(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, co
 		}
 		c->ag ^= 1;
 	}
-	// ... and index
 	CHK(arc_reindex(c));
 	HIPCHK(hipGetLastError());
 	c->graph_ready = true;
+	if (n_arc) *n_arc = c->n_arc;
+	return 0;
+}
+
+extern "C" int mahip_sg_gen(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, const uint32_t *seq_len, const uint8_t *seq_del, uint32_t *n_arc)
+{
+	CHK(mahip_sg_flags(c, opt, use_sub, seq_len, seq_del));
+	return mahip_sg_finish(c, n_arc);
+}
+
+// ---- sharded mode: arcs as packed rows {u, v, len, ol} ----
+__global__ __launch_bounds__(256) void k_arc_rows_out(ArcCols a, size_t n, uint4 *__restrict__ rows)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) rows[i] = make_uint4(a.u[i], a.v[i], a.len[i], a.ol[i]);
+}
+__global__ __launch_bounds__(256) void k_arc_rows_in(const uint4 *__restrict__ rows, size_t n, size_t dst0, ArcCols a)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) { uint4 r = rows[i]; a.u[dst0 + i] = r.x; a.v[dst0 + i] = r.y; a.len[dst0 + i] = r.z; a.ol[dst0 + i] = r.w; }
+}
+
+extern "C" int mahip_asg_export_rows(mahip_ctx_t *c, void *d_dst)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->graph_ready) { mahip_set_error("mahip_asg_export_rows: no graph"); return -1; }
+	if (c->n_arc) hipLaunchKernelGGL(k_arc_rows_out, dim3(grid_for(c->n_arc, 256)), dim3(256), 0, c->st, arcs_of(c, c->ag), (size_t)c->n_arc, (uint4*)d_dst);
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+extern "C" int mahip_asg_import_rows(mahip_ctx_t *c, const void *d_src, const uint32_t *counts, int n_ranks, size_t stride)
+{ // blocks arrive in rank order = read-range order, each sorted by (u,len): the concatenation is the sorted global list
+	HIPCHK(hipSetDevice(c->dev));
+	size_t tot = 0;
+	for (int r = 0; r < n_ranks; ++r) tot += counts[r];
+	if (tot >= 0x7fffffffull) { mahip_set_error("mahip_asg_import_rows: too many arcs"); return -1; }
+	CHK(reserve_arcs(c, tot));
+	c->ag = 0;
+	ArcCols a = arcs_of(c, 0);
+	size_t off = 0;
+	for (int r = 0; r < n_ranks; ++r) {
+		if (counts[r]) hipLaunchKernelGGL(k_arc_rows_in, dim3(grid_for(counts[r], 256)), dim3(256), 0, c->st, (const uint4*)d_src + (size_t)r * stride, (size_t)counts[r], off, a);
+		off += counts[r];
+	}
+	c->n_arc = (uint32_t)tot;
+	CHK(arc_reindex(c));
+	HIPCHK(hipStreamSynchronize(c->st));
+	c->graph_ready = true;
+	return 0;
+}
+
+extern "C" int mahip_asg_flags_out(mahip_ctx_t *c, void *d_dst, size_t first, size_t count)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (first + count > c->n_arc) { mahip_set_error("mahip_asg_flags_out: bad range"); return -1; }
+	if (count) HIPCHK(hipMemcpyAsync(d_dst, P<uint32_t>(c->aol[c->ag]) + first, count * 4, hipMemcpyDeviceToDevice, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+extern "C" int mahip_asg_flags_in(mahip_ctx_t *c, const void *d_src, size_t first, size_t count)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (first + count > c->n_arc) { mahip_set_error("mahip_asg_flags_in: bad range"); return -1; }
+	if (count) HIPCHK(hipMemcpyAsync(P<uint32_t>(c->aol[c->ag]) + first, d_src, count * 4, hipMemcpyDeviceToDevice, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+extern "C" int mahip_asg_cleanup(mahip_ctx_t *c, uint32_t *n_arc)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->graph_ready) { mahip_set_error("mahip_asg_cleanup: no graph"); return -1; }
+	CHK(ctr_zero(c));
+	CHK(arc_cleanup(c, c->n_arc, 0, 0));
 	if (n_arc) *n_arc = c->n_arc;
 	return 0;
 }
@@ -438,19 +519,20 @@ extern "C" int mahip_asg_upload(mahip_ctx_t *c, const asg_t *g)
 	return 0;
 }
 
-extern "C" int mahip_asg_del_trans(mahip_ctx_t *c, int fuzz, uint32_t *n_reduced)
-{
+extern "C" int mahip_asg_del_trans_range(mahip_ctx_t *c, int fuzz, uint32_t v_beg, uint32_t v_end, uint32_t *n_reduced)
+{ // marking only (asg.c:148-186) for the vertices [v_beg, v_end)
 	HIPCHK(hipSetDevice(c->dev));
 	if (!c->graph_ready) { mahip_set_error("mahip_asg_del_trans: no graph"); return -1; }
 	uint32_t V = 2 * c->n_seq;
+	if (v_end > V) v_end = V;
 	CHK(ctr_zero(c));
 	CHK(dev_reserve(c, c->ovf, ((size_t)V + 1) * 4));
 	ArcCols a = arcs_of(c, c->ag);
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
-	if (V && c->n_arc) {
+	if (v_end > v_beg && c->n_arc) {
 		ProfScope ps(c, "k_asg_trans", 32.0 * (double)c->n_arc); // 16*(A+I)/A per arc, I ~ A on clean data
-		hipLaunchKernelGGL(k_asg_trans, dim3(grid_for(V, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
-		                   (const unsigned long long*)P<unsigned long long>(c->idx), (const uint8_t*)P<uint8_t>(c->sdel), V, (uint32_t)fuzz, P<uint32_t>(c->ovf), ctr);
+		hipLaunchKernelGGL(k_asg_trans, dim3(grid_for(v_end - v_beg, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
+		                   (const unsigned long long*)P<unsigned long long>(c->idx), (const uint8_t*)P<uint8_t>(c->sdel), v_beg, v_end, (uint32_t)fuzz, P<uint32_t>(c->ovf), ctr);
 	}
 	CHK(ctr_fetch(c));
 	uint32_t n_ovf = (uint32_t)c->h_ctr[CT_OVF2];
@@ -464,7 +546,14 @@ extern "C" int mahip_asg_del_trans(mahip_ctx_t *c, int fuzz, uint32_t *n_reduced
 		CHK(ctr_fetch(c));
 	}
 	HIPCHK(hipGetLastError());
-	uint32_t nr = (uint32_t)c->h_ctr[CT_NRED];
+	if (n_reduced) *n_reduced = (uint32_t)c->h_ctr[CT_NRED];
+	return 0;
+}
+
+extern "C" int mahip_asg_del_trans(mahip_ctx_t *c, int fuzz, uint32_t *n_reduced)
+{
+	uint32_t nr = 0;
+	CHK(mahip_asg_del_trans_range(c, fuzz, 0, 2 * c->n_seq, &nr));
 	if (n_reduced) *n_reduced = nr;
 	if (nr) CHK(arc_cleanup(c, c->n_arc, 0, 0)); // asg.c:188-189
 	return 0;

@@ -606,35 +606,45 @@ extern "C" int mahip_sub_merge(mahip_ctx_t *c)
 	return 0;
 }
 
-extern "C" int mahip_hits_contained(mahip_ctx_t *c, const ma_opt_t *opt, const uint8_t *seq_del, uint32_t *n_seq_new, size_t *n_live)
+// Pass 1 of ma_hit_contained on the local hits: r_cont / r_used flags (any read id).  In the sharded mode the two
+// flag arrays are OR-reduced across ranks between _flags and _finish.
+extern "C" int mahip_hits_contained_flags(mahip_ctx_t *c, const ma_opt_t *opt)
 {
 	HIPCHK(hipSetDevice(c->dev));
 	if (!c->soa_ready) { mahip_set_error("mahip_hits_contained: hits not indexed"); return -1; }
 	size_t n = c->n_hits;
 	uint32_t R = c->n_seq;
-	CHK(ctr_zero(c));
-	CHK(dev_reserve(c, c->keep, ((size_t)R + 16) * 4));
 	HIPCHK(hipMemsetAsync(c->r_cont.p, 0, R, c->st));
 	HIPCHK(hipMemsetAsync(c->r_used.p, 0, R, c->st));
-	if (seq_del) HIPCHK(hipMemcpyAsync(c->r_del.p, seq_del, R, hipMemcpyHostToDevice, c->st));
-	else HIPCHK(hipMemsetAsync(c->r_del.p, 0, R, c->st));
-	HitCols h = cols_of(c);
-	const uint2 *sub = P<uint2>(c->sub[0]);
 	if (n) {
 		ProfScope ps(c, "k_hit_contained", 48.0 * (double)c->n_live);
-		hipLaunchKernelGGL(k_hit_contained, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, h, n, sub, opt->max_hang, opt->int_frac, opt->min_ovlp,
-		                   P<uint8_t>(c->r_cont), P<uint8_t>(c->r_used));
+		hipLaunchKernelGGL(k_hit_contained, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, cols_of(c), n, (const uint2*)P<uint2>(c->sub[0]),
+		                   opt->max_hang, opt->int_frac, opt->min_ovlp, P<uint8_t>(c->r_cont), P<uint8_t>(c->r_used));
 	}
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+// Passes 2+3: per-read delete flags, squeeze map (identical on every rank once the flags are complete), local hits dropped
+extern "C" int mahip_hits_contained_finish(mahip_ctx_t *c, const uint8_t *seq_del, uint32_t *n_seq_new, size_t *n_live)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	size_t n = c->n_hits;
+	uint32_t R = c->n_seq;
+	CHK(ctr_zero(c));
+	CHK(dev_reserve(c, c->keep, ((size_t)R + 16) * 4));
+	if (seq_del) HIPCHK(hipMemcpyAsync(c->r_del.p, seq_del, R, hipMemcpyHostToDevice, c->st));
+	else HIPCHK(hipMemsetAsync(c->r_del.p, 0, R, c->st));
 	uint32_t *d_tot = (uint32_t*)(P<unsigned long long>(c->ctr) + CT_TOTAL);
 	if (R) {
-		hipLaunchKernelGGL(k_read_del, dim3(grid_for(R, 256)), dim3(256), 0, c->st, sub, (const uint8_t*)P<uint8_t>(c->r_cont), (const uint8_t*)P<uint8_t>(c->r_used),
-		                   P<uint8_t>(c->r_del), P<uint32_t>(c->keep), R);
+		hipLaunchKernelGGL(k_read_del, dim3(grid_for(R, 256)), dim3(256), 0, c->st, (const uint2*)P<uint2>(c->sub[0]), (const uint8_t*)P<uint8_t>(c->r_cont),
+		                   (const uint8_t*)P<uint8_t>(c->r_used), P<uint8_t>(c->r_del), P<uint32_t>(c->keep), R);
 		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), (uint32_t*)c->map.p, R, d_tot));
 		hipLaunchKernelGGL(k_map_fix, dim3(grid_for(R, 256)), dim3(256), 0, c->st, P<int32_t>(c->map), (const uint8_t*)P<uint8_t>(c->r_del), R);
 	}
 	if (n) {
 		ProfScope ps(c, "k_hit_squeeze", 72.0 * (double)c->n_live);
-		hipLaunchKernelGGL(k_hit_squeeze, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, h, n, (const uint8_t*)P<uint8_t>(c->r_del), P<unsigned long long>(c->ctr));
+		hipLaunchKernelGGL(k_hit_squeeze, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, cols_of(c), n, (const uint8_t*)P<uint8_t>(c->r_del), P<unsigned long long>(c->ctr));
 	}
 	CHK(ctr_fetch(c));
 	c->n_live = (size_t)c->h_ctr[CT_LIVE];
@@ -642,6 +652,47 @@ extern "C" int mahip_hits_contained(mahip_ctx_t *c, const ma_opt_t *opt, const u
 	c->has_map = true;
 	if (n_seq_new) *n_seq_new = c->n_seq_new;
 	if (n_live) *n_live = c->n_live;
+	return 0;
+}
+
+extern "C" int mahip_hits_contained(mahip_ctx_t *c, const ma_opt_t *opt, const uint8_t *seq_del, uint32_t *n_seq_new, size_t *n_live)
+{
+	CHK(mahip_hits_contained_flags(c, opt));
+	return mahip_hits_contained_finish(c, seq_del, n_seq_new, n_live);
+}
+
+// device-to-device access to the read-indexed arrays for the exchanges of the sharded mode (done by the caller over RCCL)
+static DevBuf *xbuf(mahip_ctx *c, int which, size_t *elem)
+{
+	switch (which) {
+	case MAHIP_BUF_SUB0: *elem = 8; return &c->sub[0];
+	case MAHIP_BUF_SUB1: *elem = 8; return &c->sub[1];
+	case MAHIP_BUF_RCONT: *elem = 1; return &c->r_cont;
+	case MAHIP_BUF_RUSED: *elem = 1; return &c->r_used;
+	case MAHIP_BUF_SDEL: *elem = 1; return &c->sdel;
+	default: return nullptr;
+	}
+}
+
+extern "C" int mahip_copy_out(mahip_ctx_t *c, int which, void *d_dst, size_t first, size_t count)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	size_t es;
+	DevBuf *b = xbuf(c, which, &es);
+	if (!b || (first + count) * es > b->cap) { mahip_set_error("mahip_copy_out: bad buffer/range"); return -1; }
+	if (count) HIPCHK(hipMemcpyAsync(d_dst, (char*)b->p + first * es, count * es, hipMemcpyDeviceToDevice, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+extern "C" int mahip_copy_in(mahip_ctx_t *c, int which, const void *d_src, size_t first, size_t count)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	size_t es;
+	DevBuf *b = xbuf(c, which, &es);
+	if (!b || (first + count) * es > b->cap) { mahip_set_error("mahip_copy_in: bad buffer/range"); return -1; }
+	if (count) HIPCHK(hipMemcpyAsync((char*)b->p + first * es, d_src, count * es, hipMemcpyDeviceToDevice, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
 	return 0;
 }
 

@@ -16,6 +16,9 @@ void ma_set_log_path(const char *path);
 
 /* everything after ingest, hits resident in HBM (pipeline.c) */
 int ma_pipeline_device(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, FILE *out);
+/* its two halves: device passes (st[4] = have_sub, squeezed, n_reduced, graph built) and the host part */
+int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, uint32_t st[4]);
+int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, const uint32_t st[4], FILE *out);
 
 /* the process-wide GPU context of the per-symbol entry points; exits with an error if no GPU is usable */
 mahip_ctx_t *ma_gpu(void);

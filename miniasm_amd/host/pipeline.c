@@ -5,8 +5,9 @@
  * sub/cut/merge/contained -> ma_sg_gen -> transitive reduction + symm (all HIP, data stays in HBM) ->
  * download of the small reduced graph -> sequential cleaners, unitigs and GFA text (host).
  *
- * ma_pipeline_device() is the part after ingest; bench.py times exactly that function with the unsorted hit
- * records already sitting in HBM.
+ *   ma_pipeline_device() = ma_pipeline_head() (device passes) + ma_pipeline_tail() (host part); bench.py times
+ *   ma_pipeline_device with the unsorted hit records already in HBM.  In the sharded multi-GPU mode the head is
+ *   replaced by miniasm_amd/sharded.py (same passes + RCCL exchanges) and rank 0 runs the tail.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -43,23 +44,17 @@ static void print_hits(size_t n_hits, const ma_hit_t *hit, const sdict_t *d, con
 	}
 }
 
-/* Everything after ingest.  c holds n unsorted hits (uploaded or adopted) over the reads of d.
- * d is not modified: after containment removal a shallow view of the surviving reads is used for output.
- * flags as in ma_pipeline_run.  Returns the number of input hits processed. */
-int ma_pipeline_device(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, FILE *out)
+/* Device passes up to (and including) transitive reduction + symm.  c holds the unsorted hits (uploaded or
+ * adopted).  st[0] = have_sub, st[1] = squeezed, st[2] = n_reduced, st[3] = graph built. */
+int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, uint32_t st[4])
 {
-	int no_first = flags & 1, no_second = flags & 2, have_sub = 0, squeezed = 0, i;
+	int no_first = flags & 1, no_second = flags & 2, have_sub = 0, squeezed = 0;
 	size_t n_hits = 0, n_rem = 0;
-	uint32_t R = d->n_seq, n_seq_new = R;
+	uint32_t R = d->n_seq, n_seq_new = R, n_red = 0;
 	float cov = 40.0f;
-	sdict_t view; /* surviving reads: names shared with d */
-	ma_sub_t *sub = 0;
 	FILE *lg = MA_LOG;
 
-	memset(&view, 0, sizeof(view));
-	view.n_seq = R; view.seq = d->seq;
 	GPU(mahip_hits_sort(c)); /* hit.c:104 */
-
 	if (!no_first) {
 		fprintf(lg, "[M::%s] ===> Step 2: 1-pass (crude) read selection <===\n", "main");
 		if (stage >= 2) {
@@ -86,45 +81,21 @@ int ma_pipeline_device(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, co
 			have_sub = 1;
 		}
 		if (stage >= 5 && have_sub) {
-			uint8_t *del = (uint8_t*)malloc(R ? R : 1);
-			uint32_t r, k;
 			GPU(mahip_hits_contained(c, opt, 0, &n_seq_new, &n_hits));
-			GPU(mahip_seqdel_download(c, del));
-			view.seq = (sd_seq_t*)malloc((n_seq_new ? n_seq_new : 1) * sizeof(sd_seq_t));
-			for (r = k = 0; r < R; ++r)
-				if (!del[r]) view.seq[k] = d->seq[r], view.seq[k].del = 0, view.seq[k].aux = 0, ++k;
-			view.n_seq = k; squeezed = 1;
-			free(del);
-			if (k != n_seq_new) { fprintf(stderr, "[E::%s] squeeze mismatch: host %u vs device %u\n", __func__, k, n_seq_new); exit(1); }
+			squeezed = 1;
 			if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %d sequences and %ld hits remain after containment removal\n", "ma_hit_contained", sys_timestamp(), n_seq_new, (long)n_hits);
 		}
 	}
-	if (have_sub) {
-		sub = (ma_sub_t*)calloc(R ? R : 1, sizeof(ma_sub_t));
-		GPU(mahip_sub_download(c, 0, sub, squeezed));
-	}
-
-	if (strcmp(outfmt, "bed") == 0) {
-		if (sub) print_subs(&view, sub, out);
-	} else if (strcmp(outfmt, "paf") == 0) {
-		size_t m = mahip_hits_live(c);
-		ma_hit_t *hit = (ma_hit_t*)malloc((m ? m : 1) * sizeof(ma_hit_t));
-		GPU(mahip_hits_download(c, hit, &m));
-		if (sub) print_hits(m, hit, &view, sub, out);
-		free(hit);
-	} else if (strcmp(outfmt, "ug") == 0 || strcmp(outfmt, "sg") == 0) {
-		asg_t *sg = asg_init();
-		ma_ug_t *ug = 0;
-		uint32_t n_arc = 0, n_red = 0, *len = 0;
+	st[0] = have_sub, st[1] = squeezed, st[2] = 0, st[3] = 0;
+	if (strcmp(outfmt, "ug") == 0 || strcmp(outfmt, "sg") == 0) {
+		uint32_t n_arc = 0, *len = 0, r;
 		uint8_t *sdel = 0;
 		fprintf(lg, "[M::%s] ===> Step 4: graph cleaning <===\n", "main");
 		if (!have_sub) {
-			uint32_t r;
 			len = (uint32_t*)malloc((R ? R : 1) * 4);
 			for (r = 0; r < R; ++r) len[r] = d->seq[r].len;
 		}
 		if (!squeezed) {
-			uint32_t r;
 			sdel = (uint8_t*)malloc(R ? R : 1);
 			for (r = 0; r < R; ++r) sdel[r] = d->seq[r].del;
 		}
@@ -142,7 +113,52 @@ int ma_pipeline_device(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, co
 				fprintf(lg, "[M::%s] removed %d asymmetric arcs\n", "asg_arc_del_asymm", n_asymm);
 			}
 		}
+		st[2] = n_red, st[3] = 1;
+	}
+	return 0;
+}
+
+/* Host part: names of the surviving reads, sub, then either a dump (bed/paf) or the reduced graph -> sequential
+ * cleaners (main.c:160-187) -> unitigs -> GFA / string-graph text.  d is not modified: after containment removal
+ * a shallow view of the surviving reads (names shared with d) is used for output. */
+int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, const uint32_t st[4], FILE *out)
+{
+	int have_sub = st[0], squeezed = st[1], i;
+	uint32_t R = d->n_seq, n_red = st[2];
+	sdict_t view;
+	ma_sub_t *sub = 0;
+	FILE *lg = MA_LOG;
+
+	memset(&view, 0, sizeof(view));
+	view.n_seq = R; view.seq = d->seq;
+	if (squeezed) {
+		uint8_t *del = (uint8_t*)malloc(R ? R : 1);
+		uint32_t r, k;
+		GPU(mahip_seqdel_download(c, del));
+		for (r = k = 0; r < R; ++r) k += !del[r];
+		view.seq = (sd_seq_t*)malloc((k ? k : 1) * sizeof(sd_seq_t));
+		for (r = k = 0; r < R; ++r)
+			if (!del[r]) view.seq[k] = d->seq[r], view.seq[k].del = 0, view.seq[k].aux = 0, ++k;
+		view.n_seq = k;
+		free(del);
+	}
+	if (have_sub) {
+		sub = (ma_sub_t*)calloc(R ? R : 1, sizeof(ma_sub_t));
+		GPU(mahip_sub_download(c, 0, sub, squeezed));
+	}
+	if (strcmp(outfmt, "bed") == 0) {
+		if (sub) print_subs(&view, sub, out);
+	} else if (strcmp(outfmt, "paf") == 0) {
+		size_t m = mahip_hits_live(c);
+		ma_hit_t *hit = (ma_hit_t*)malloc((m ? m : 1) * sizeof(ma_hit_t));
+		GPU(mahip_hits_download(c, hit, &m));
+		if (sub) print_hits(m, hit, &view, sub, out);
+		free(hit);
+	} else if (st[3]) {
+		asg_t *sg = asg_init();
+		ma_ug_t *ug = 0;
 		GPU(mahip_asg_download(c, sg)); /* the reduced graph is small: the sequential cleaners run on the host */
+		if (sg->n_seq != view.n_seq) { fprintf(stderr, "[E::%s] squeeze mismatch: host %u vs device %u reads\n", __func__, view.n_seq, sg->n_seq); exit(1); }
 		sg->is_symm = n_red > 0;
 		if (stage >= 7) {
 			fprintf(lg, "[M::%s] ===> Step 4.2: initial tip cutting and bubble popping <===\n", "main");
@@ -186,6 +202,13 @@ int ma_pipeline_device(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, co
 	return 0;
 }
 
+int ma_pipeline_device(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, FILE *out)
+{
+	uint32_t st[4];
+	ma_pipeline_head(c, opt, d, outfmt, stage, flags, st);
+	return ma_pipeline_tail(c, opt, d, outfmt, stage, st, out);
+}
+
 /* same, with the output text returned in a malloc'ed buffer (bench.py / tests) */
 int ma_pipeline_device_mem(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, char **buf, size_t *len)
 {
@@ -193,6 +216,16 @@ int ma_pipeline_device_mem(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d
 	int rc;
 	if (fp == 0) return -1;
 	rc = ma_pipeline_device(c, opt, d, outfmt, stage, flags, fp);
+	fclose(fp);
+	return rc;
+}
+
+int ma_pipeline_tail_mem(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, const uint32_t st[4], char **buf, size_t *len)
+{
+	FILE *fp = open_memstream(buf, len);
+	int rc;
+	if (fp == 0) return -1;
+	rc = ma_pipeline_tail(c, opt, d, outfmt, stage, st, fp);
 	fclose(fp);
 	return rc;
 }

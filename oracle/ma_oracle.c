@@ -168,22 +168,31 @@ void orc_sub_merge(size_t n_sub, orc_sub_t *a, const orc_sub_t *b)
 }
 
 /* ------------------------------------------------------------------ hit.c:225-256 (+ :24-36, sdict.c:69-86) */
+/* first loop of ma_hit_contained + the marking loop of ma_hit_mark_unused, as pure flag computation (no renumbering):
+ * r_cont[x] = read x is contained by the final thresholds, r_used[x] = some hit touches x */
+void orc_contained_flags(const orc_opt_t *opt, const orc_sub_t *sub, size_t n, const orc_hit_t *a, uint8_t *r_cont, uint8_t *r_used)
+{
+	size_t i;
+	orc_arc_t t;
+	for (i = 0; i < n; ++i) {
+		const orc_hit_t *h = &a[i];
+		const orc_sub_t *sq = &sub[h->qns >> 32], *st = &sub[h->tn];
+		int r = orc_hit2arc(h, sq->e - sq->s, st->e - st->s, opt->max_hang, opt->int_frac, opt->min_ovlp, &t);
+		if (r == HT_QCONT) r_cont[h->qns >> 32] = 1;
+		else if (r == HT_TCONT) r_cont[h->tn] = 1;
+		r_used[h->qns >> 32] = r_used[h->tn] = 1;
+	}
+}
+
 size_t orc_hit_contained(const orc_opt_t *opt, uint32_t n_seq, uint8_t *seq_del, orc_sub_t *sub, size_t n, orc_hit_t *a, int32_t *map, uint32_t *n_seq_new)
 {
 	size_t i, m = 0;
 	uint32_t j = 0;
-	uint8_t *used = (uint8_t*)calloc(n_seq ? n_seq : 1, 1);
-	orc_arc_t t;
-	for (i = 0; i < n; ++i) { /* flag contained reads with the final thresholds */
-		orc_hit_t *h = &a[i];
-		orc_sub_t *sq = &sub[h->qns >> 32], *st = &sub[h->tn];
-		int r = orc_hit2arc(h, sq->e - sq->s, st->e - st->s, opt->max_hang, opt->int_frac, opt->min_ovlp, &t);
-		if (r == HT_QCONT) sq->del = 1;
-		else if (r == HT_TCONT) st->del = 1;
-	}
-	for (i = 0; i < n_seq; ++i) if (sub[i].del) seq_del[i] = 1;
-	for (i = 0; i < n; ++i) used[a[i].qns >> 32] = used[a[i].tn] = 1;      /* hit.c:24-36: reads no hit touches go too */
-	for (i = 0; i < n_seq; ++i) if (!used[i]) seq_del[i] = 1;
+	uint8_t *used = (uint8_t*)calloc(n_seq ? n_seq : 1, 1), *cont = (uint8_t*)calloc(n_seq ? n_seq : 1, 1);
+	orc_contained_flags(opt, sub, n, a, cont, used);
+	for (i = 0; i < n_seq; ++i) if (cont[i]) sub[i].del = 1;                    /* hit.c:234-235 write into sub */
+	for (i = 0; i < n_seq; ++i) if (sub[i].del) seq_del[i] = 1;                 /* hit.c:237-238 */
+	for (i = 0; i < n_seq; ++i) if (!used[i]) seq_del[i] = 1;                   /* hit.c:24-36: reads no hit touches go too */
 	for (i = 0; i < n_seq; ++i) map[i] = seq_del[i] ? -1 : (int32_t)j++;        /* sdict.c:75-81 */
 	for (i = 0; i < n_seq; ++i) if (map[i] >= 0) sub[map[i]] = sub[i];
 	for (i = 0; i < n; ++i) {
@@ -193,18 +202,17 @@ size_t orc_hit_contained(const orc_opt_t *opt, uint32_t n_seq, uint8_t *seq_del,
 			a[m++] = a[i];
 		}
 	}
-	free(used);
+	free(used); free(cont);
 	*n_seq_new = j;
 	return m;
 }
 
 /* ------------------------------------------------------------------ asm.c:9-39 (+ asg.c:57-80) */
-size_t orc_sg_gen(const orc_opt_t *opt, uint32_t n_seq, const orc_sub_t *sub, const uint32_t *len_in, const uint8_t *del_in,
-                  size_t n, const orc_hit_t *a, orc_arc_t *arcs, uint32_t *seq_len, uint8_t *seq_del)
+/* asm.c:14-35 without the cleanup: seq arrays, the pushed arcs in push order, seq.del side effects; returns #pushed */
+size_t orc_sg_candidates(const orc_opt_t *opt, uint32_t n_seq, const orc_sub_t *sub, const uint32_t *len_in, const uint8_t *del_in,
+                         size_t n, const orc_hit_t *a, orc_arc_t *arcs, uint32_t *seq_len, uint8_t *seq_del)
 {
-	size_t i, n_arc = 0, m;
-	keypos_t *k;
-	orc_arc_t *tmp;
+	size_t i, n_arc = 0;
 	for (i = 0; i < n_seq; ++i) {
 		if (sub) seq_len[i] = (sub[i].e - sub[i].s) & 0x7fffffffu, seq_del[i] = sub[i].del || (del_in && del_in[i]);
 		else seq_len[i] = len_in[i] & 0x7fffffffu, seq_del[i] = del_in ? del_in[i] : 0;
@@ -224,8 +232,16 @@ size_t orc_sg_gen(const orc_opt_t *opt, uint32_t n_seq, const orc_sub_t *sub, co
 			arcs[n_arc++] = t;
 		} else if (r == HT_QCONT) seq_del[qn] = 1;
 	}
+	return n_arc;
+}
+
+/* asg_cleanup of ma_sg_gen (asm.c:36): arc_rm, then sort by ul with ties in push order */
+size_t orc_sg_finish(size_t n_arc, orc_arc_t *arcs, const uint8_t *seq_del)
+{
+	size_t m;
+	keypos_t *k;
+	orc_arc_t *tmp;
 	n_arc = orc_arc_rm(n_arc, arcs, seq_del);
-	/* sort by ul, ties in push order */
 	k = (keypos_t*)malloc((n_arc ? n_arc : 1) * sizeof(keypos_t));
 	tmp = (orc_arc_t*)malloc((n_arc ? n_arc : 1) * sizeof(orc_arc_t));
 	for (m = 0; m < n_arc; ++m) k[m].key = arcs[m].ul, k[m].pos = m;
@@ -234,6 +250,13 @@ size_t orc_sg_gen(const orc_opt_t *opt, uint32_t n_seq, const orc_sub_t *sub, co
 	memcpy(arcs, tmp, n_arc * sizeof(orc_arc_t));
 	free(k); free(tmp);
 	return n_arc;
+}
+
+size_t orc_sg_gen(const orc_opt_t *opt, uint32_t n_seq, const orc_sub_t *sub, const uint32_t *len_in, const uint8_t *del_in,
+                  size_t n, const orc_hit_t *a, orc_arc_t *arcs, uint32_t *seq_len, uint8_t *seq_del)
+{
+	size_t n_arc = orc_sg_candidates(opt, n_seq, sub, len_in, del_in, n, a, arcs, seq_len, seq_del);
+	return orc_sg_finish(n_arc, arcs, seq_del);
 }
 
 /* ------------------------------------------------------------------ asg.c:27-36 */
@@ -263,11 +286,19 @@ size_t orc_arc_rm(size_t n_arc, orc_arc_t *a, const uint8_t *seq_del)
 /* ------------------------------------------------------------------ asg.c:148-186 */
 uint32_t orc_arc_del_trans(uint32_t n_seq, size_t n_arc, orc_arc_t *a, const uint64_t *idx, const uint8_t *seq_del, int fuzz, uint64_t *n_inner)
 {
+	return orc_arc_del_trans_range(n_seq, n_arc, a, idx, seq_del, fuzz, 0, n_seq * 2, n_inner);
+}
+
+/* the same sweep restricted to the vertices [v_beg, v_end): every vertex only writes its own arcs, so ranges are independent */
+uint32_t orc_arc_del_trans_range(uint32_t n_seq, size_t n_arc, orc_arc_t *a, const uint64_t *idx, const uint8_t *seq_del, int fuzz,
+                                 uint32_t v_beg, uint32_t v_end, uint64_t *n_inner)
+{
 	uint32_t v, n_vtx = n_seq * 2, n_reduced = 0;
 	uint8_t *mark = (uint8_t*)calloc(n_vtx ? n_vtx : 1, 1);
 	uint64_t inner = 0;
 	(void)n_arc;
-	for (v = 0; v < n_vtx; ++v) {
+	if (v_end > n_vtx) v_end = n_vtx;
+	for (v = v_beg; v < v_end; ++v) {
 		uint32_t L, i, nv = ARC_N(idx, v);
 		orc_arc_t *av = ARC_A(a, idx, v);
 		if (nv == 0) continue;

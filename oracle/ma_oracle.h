@@ -46,6 +46,13 @@ size_t orc_hit_contained(const orc_opt_t *opt, uint32_t n_seq, uint8_t *seq_del,
  * arcs come out sorted by (ul, push order) ; returns n_arc */
 size_t orc_sg_gen(const orc_opt_t *opt, uint32_t n_seq, const orc_sub_t *sub, const uint32_t *len_in, const uint8_t *del_in,
                   size_t n, const orc_hit_t *a, orc_arc_t *arcs, uint32_t *seq_len, uint8_t *seq_del);
+/* the pieces of the two passes above, split where the sharded multi-GPU mode exchanges flags (tests/test_dist_gloo.py) */
+void orc_contained_flags(const orc_opt_t *opt, const orc_sub_t *sub, size_t n, const orc_hit_t *a, uint8_t *r_cont, uint8_t *r_used);
+size_t orc_sg_candidates(const orc_opt_t *opt, uint32_t n_seq, const orc_sub_t *sub, const uint32_t *len_in, const uint8_t *del_in,
+                         size_t n, const orc_hit_t *a, orc_arc_t *arcs, uint32_t *seq_len, uint8_t *seq_del);
+size_t orc_sg_finish(size_t n_arc, orc_arc_t *arcs, const uint8_t *seq_del);
+uint32_t orc_arc_del_trans_range(uint32_t n_seq, size_t n_arc, orc_arc_t *a, const uint64_t *idx, const uint8_t *seq_del, int fuzz,
+                                 uint32_t v_beg, uint32_t v_end, uint64_t *n_inner);
 /* asg.c:27-36 ; idx must hold 2*n_seq entries */
 void orc_arc_index(uint32_t n_seq, size_t n_arc, const orc_arc_t *a, uint64_t *idx);
 /* asg.c:57-70 ; returns new n_arc */

@@ -14,6 +14,12 @@ tests)
 cli)
   timeout 1500 python -m pytest tests/test_gpu_cli.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/tests_cli.log 2>&1; echo "rc=$?" >> gpurun_out/tests_cli.log
   grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_cli.log | tail -60 ;;
+sharded)
+  timeout 1500 python -m pytest tests/test_gpu_sharded.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/tests_sharded.log 2>&1; echo "rc=$?" >> gpurun_out/tests_sharded.log
+  grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_sharded.log | tail -40 ;;
+torchrun1)
+  timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --reads 20000 --lines 1000000 --steps 3 --warmup 1 --no-cpu > gpurun_out/bench_torchrun1.json 2> gpurun_out/bench_torchrun1.log; echo "rc=$?"
+  tail -3 gpurun_out/bench_torchrun1.log; cut -c1-400 gpurun_out/bench_torchrun1.json ;;
 smoke)
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "rc=$?" >> gpurun_out/smoke.log
   grep -vE "^\[M::" gpurun_out/smoke.log | tail -15 ;;
