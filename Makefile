@@ -16,7 +16,7 @@ HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall 
 CFLAGS    = -O2 -g -Wall -fPIC -Iinclude -I$(HOST) -I$(CSRC)
 
 HIP_SRC   = scan radix hits graph mahip_api
-HOST_SRC  = timers name_dict paf_reader hits_host graph_host unitig_gfa pipeline
+HOST_SRC  = timers name_dict paf_reader ingest_mt hits_host graph_host unitig_gfa pipeline
 HIP_OBJ   = $(addprefix $(B)/,$(addsuffix .hip.o,$(HIP_SRC)))
 HOST_OBJ  = $(addprefix $(B)/,$(addsuffix .o,$(HOST_SRC)))
 
@@ -39,7 +39,7 @@ $(B)/%.o: $(HOST)/%.c $(HOST)/ma_host.h include/mahip.h include/miniasm_amd.h | 
 	$(CC) $(CFLAGS) -c $< -o $@
 
 $(LIB): $(HIP_OBJ) $(HOST_OBJ) | $(PKG)/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,-Bsymbolic -o $@ $(HIP_OBJ) $(HOST_OBJ) -lz -lm
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,-Bsymbolic -o $@ $(HIP_OBJ) $(HOST_OBJ) -lz -lm -lpthread
 
 $(PKG)/bin/miniasm: $(HOST)/cli.c $(LIB) | $(PKG)/bin
 	$(CC) $(CFLAGS) -o $@ $(HOST)/cli.c -L$(PKG)/lib -lminiasm_amd -Wl,-rpath,'$$ORIGIN/../lib' -lz -lm

@@ -172,8 +172,11 @@ def main():
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     comm = Comm()
 
+    max_qs = ing.max_qs
+
     def step():
         ma._chk(L.mahip_hits_adopt(ctx.h, hits_dev.data_ptr(), n_my, n_seq), "adopt")
+        L.mahip_set_hints(ctx.h, max_qs)
         if world == 1:  # single GPU: the C pipeline end to end
             rc = L.ma_pipeline_device_mem(ctx.h, C.byref(opt), ing.d, b"ug", 100, 0, C.byref(buf), C.byref(ln))
             assert rc == 0

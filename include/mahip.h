@@ -34,6 +34,9 @@ int mahip_hits_adopt(mahip_ctx_t *c, const void *d_hits, size_t n, uint32_t n_se
 /* Multi-GPU: this context owns the hits whose query id lies in [q_beg,q_end); call before sort/index. */
 int mahip_set_shard(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end);
 
+/* optional: an upper bound of the query starts (e.g. the longest read) lets the sort plan its digits without a
+ * device round trip; 0 = unknown */
+int mahip_set_hints(mahip_ctx_t *c, uint32_t max_qs);
 /* hit.c:19-22 ma_hit_sort: LSD radix sort by (query id, query start, input order) -> SoA + group offsets */
 int mahip_hits_sort(mahip_ctx_t *c);
 /* same layout change without sorting (input already grouped by query id: the per-symbol ABI path) */
@@ -55,6 +58,8 @@ int mahip_sub_upload(mahip_ctx_t *c, int slot, const ma_sub_t *sub, size_t n_sub
 int mahip_sub_download(mahip_ctx_t *c, int slot, ma_sub_t *sub, int squeezed); /* squeezed: compacted by the contained map */
 int mahip_seqdel_download(mahip_ctx_t *c, uint8_t *del);                       /* per old read id, after contained */
 int mahip_map_download(mahip_ctx_t *c, int32_t *map);                          /* old -> new id (-1 dropped) */
+uint32_t mahip_n_seq_new(mahip_ctx_t *c);                                      /* reads left after contained (else n_seq) */
+int mahip_survivors_download(mahip_ctx_t *c, uint32_t *old_ids);               /* [n_seq_new] new id -> old id */
 size_t mahip_hits_live(mahip_ctx_t *c);
 /* live hits, compacted in array order, ids renumbered if contained has run; out must hold mahip_hits_live() */
 int mahip_hits_download(mahip_ctx_t *c, ma_hit_t *out, size_t *n);

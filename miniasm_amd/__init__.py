@@ -87,6 +87,7 @@ def lib():
         L.mahip_hits_upload.argtypes = [vp, vp, sz, u32]
         L.mahip_hits_adopt.argtypes = [vp, vp, sz, u32]
         L.mahip_set_shard.argtypes = [vp, u32, u32]
+        L.mahip_set_hints.argtypes = [vp, u32]
         L.mahip_hits_sort.argtypes = [vp]
         L.mahip_hits_index.argtypes = [vp]
         L.mahip_hits_sub.argtypes = [vp, i32, C.c_float, i32, i32, C.POINTER(sz)]
@@ -293,6 +294,8 @@ class Ingest:
         n = C.c_size_t(0)
         p = L.ma_hit_ingest(fn.encode(), opt.min_span, opt.min_match, self.d, C.byref(n), 1 if bi_dir else 0, None)
         self.n = n.value
+        L.ma_ingest_max_qs.restype = C.c_uint32
+        self.max_qs = L.ma_ingest_max_qs()  # exact bound of the query starts: hint for the device sort
         self._p = p  # malloc'ed by the library; self.hits is a zero-copy view of it (no second copy of multi-GB arrays)
         if self.n:
             raw = (C.c_uint8 * (self.n * 32)).from_address(p)

@@ -18,46 +18,70 @@
 #define DEAD 0x80000000u
 
 // ------------------------------------------------------------------------------------------------ sort
-// keys for ma_hit_sort (hit.c:12-22: key = qns), value = input position; max qid / max qs for the digit plan.
-// Hits outside the shard [q_beg,q_end) get the all-ones key and sort to the tail.
+// Sort keys for ma_hit_sort (hit.c:12-22, key = qns = qid<<32 | qs), squeezed to their significant bits:
+//   packed (pk = 1): key = qid << (bs+bi) | qs << bi | input position   (8-byte elements, no value array)
+//   pairs  (pk = 0): key = qid << bs | qs, value = input position        (when the three fields exceed 64 bits)
+// keep[i] = hit belongs to this context's read range (sharded mode).
 __global__ __launch_bounds__(256) void k_hit_keys(const ma_hit_t *__restrict__ h, size_t n, uint64_t *__restrict__ key,
-                                                   uint32_t *__restrict__ val, unsigned long long *__restrict__ ctr,
-                                                   uint32_t q_beg, uint32_t q_end)
+                                                   uint32_t *__restrict__ val, uint32_t *__restrict__ keep, unsigned long long *__restrict__ ctr,
+                                                   uint32_t q_beg, uint32_t q_end, int bs, int bi, int pk)
 {
-	uint32_t mq = 0, ms = 0, cnt = 0;
+	uint32_t cnt = 0;
 	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
 		uint64_t k = h[i].qns;
-		uint32_t q = (uint32_t)(k >> 32);
-		if (q >= q_beg && q < q_end) { mq = q > mq ? q : mq; ms = (uint32_t)k > ms ? (uint32_t)k : ms; ++cnt; }
-		else k = ~0ull;
-		key[i] = k;
-		val[i] = (uint32_t)i;
+		uint32_t q = (uint32_t)(k >> 32), qs = (uint32_t)k;
+		int in = q >= q_beg && q < q_end;
+		cnt += in;
+		if (pk) key[i] = ((uint64_t)q << bs | qs) << bi | i;
+		else key[i] = (uint64_t)q << bs | qs, val[i] = (uint32_t)i;
+		if (keep) keep[i] = in;
+	}
+	blk_add_u64(&ctr[CT_LIVE], cnt);
+}
+
+// largest query id / query start (only when the caller gave no hints: the per-symbol ma_hit_sort)
+__global__ __launch_bounds__(256) void k_hit_bounds(const ma_hit_t *__restrict__ h, size_t n, unsigned long long *__restrict__ ctr)
+{
+	uint32_t mq = 0, ms = 0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+		uint64_t k = h[i].qns;
+		uint32_t q = (uint32_t)(k >> 32), qs = (uint32_t)k;
+		mq = q > mq ? q : mq; ms = qs > ms ? qs : ms;
 	}
 	blk_max_u64(&ctr[CT_MAXQID], mq);
 	blk_max_u64(&ctr[CT_MAXQS], ms);
-	blk_add_u64(&ctr[CT_LIVE], cnt);
+}
+
+__global__ __launch_bounds__(256) void k_key_compact(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, size_t n,
+                                                      const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos,
+                                                      uint64_t *__restrict__ kout, uint32_t *__restrict__ vout)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n && keep[i]) { kout[pos[i]] = kin[i]; if (vin) vout[pos[i]] = vin[i]; }
 }
 
 struct HitCols { uint32_t *qid, *qs, *qe, *tn, *ts, *te, *ml, *bl; };
 
-// AoS (input order) -> SoA (sorted order), one 32-byte record per lane as 2 x dwordx4; group offsets from
-// key boundaries.  perm == nullptr: identity (input already grouped).
-__global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__ h, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ skey,
-                                                     size_t n, uint32_t n_seq, HitCols c, uint32_t *__restrict__ goff)
+// AoS (input order) -> SoA (sorted order): one 32-byte record per lane as 2 x dwordx4 through the permutation held
+// in the sorted keys (low bi bits) or in perm[]; group offsets from the query-id boundaries of the sorted keys.
+// skey == nullptr: identity (input already grouped: the per-symbol path).
+__global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__ h, const uint64_t *__restrict__ skey, const uint32_t *__restrict__ perm,
+                                                     int qshift, int bi, size_t n, uint32_t n_seq, HitCols c, uint32_t *__restrict__ goff)
 {
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (i > n) return;
 	uint32_t q = n_seq, qprev = 0;
 	int first = (i == 0);
 	if (i < n) {
-		size_t j = perm ? perm[i] : i;
+		size_t j = i;
+		if (skey) j = perm ? perm[i] : (size_t)(skey[i] & ((1ull << bi) - 1));
 		const uint4 *p = (const uint4*)(h + j);
 		uint4 a = p[0], b = p[1]; // a = {qs, qid, qe, tn}  b = {ts, te, ml|rev, bl|del}
 		q = a.y;
 		c.qid[i] = a.y; c.qs[i] = a.x; c.qe[i] = a.z; c.tn[i] = a.w;
 		c.ts[i] = b.x; c.te[i] = b.y; c.ml[i] = b.z; c.bl[i] = b.w & ~DEAD;
 	}
-	if (!first) qprev = skey ? (uint32_t)(skey[i - 1] >> 32) : (uint32_t)(h[i - 1].qns >> 32); // sorted keys, or the grouped input itself
+	if (!first) qprev = skey ? (uint32_t)(skey[i - 1] >> qshift) : (uint32_t)(h[i - 1].qns >> 32);
 	// reads qprev+1 .. q start at slot i (reads without hits get empty groups)
 	uint32_t r0 = first ? 0 : qprev + 1;
 	if (q > n_seq) q = n_seq;
@@ -381,10 +405,14 @@ __global__ __launch_bounds__(256) void k_read_del(const uint2 *__restrict__ sub,
 	}
 }
 
-__global__ __launch_bounds__(256) void k_map_fix(int32_t *__restrict__ map, const uint8_t *__restrict__ r_del, uint32_t n_seq)
+// map[r] = -1 for dropped reads; surv[new id] = old id for the survivors (sdict.c:75-81 seen from both sides)
+__global__ __launch_bounds__(256) void k_map_fix(int32_t *__restrict__ map, const uint8_t *__restrict__ r_del, uint32_t n_seq, uint32_t *__restrict__ surv)
 {
 	uint32_t r = blockIdx.x * 256 + threadIdx.x;
-	if (r < n_seq && r_del[r]) map[r] = -1;
+	if (r < n_seq) {
+		if (r_del[r]) map[r] = -1;
+		else surv[map[r]] = r;
+	}
 }
 
 __global__ __launch_bounds__(256) void k_hit_squeeze(HitCols c, size_t n, const uint8_t *__restrict__ r_del, unsigned long long *__restrict__ ctr)
@@ -430,6 +458,8 @@ __global__ __launch_bounds__(256) void k_sub_squeeze(const uint2 *__restrict__ s
 
 // ================================================================================================ host side
 
+static int bitlen(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
+
 static HitCols cols_of(mahip_ctx *c)
 {
 	HitCols h;
@@ -446,6 +476,7 @@ static int reserve_read_arrays(mahip_ctx *c)
 	CHK(dev_reserve(c, c->r_cont, R + 16)); CHK(dev_reserve(c, c->r_used, R + 16));
 	CHK(dev_reserve(c, c->r_del, R + 16)); CHK(dev_reserve(c, c->r_live, R + 16));
 	CHK(dev_reserve(c, c->map, (R + 1) * 4));
+	CHK(dev_reserve(c, c->surv, (R + 1) * 4));
 	return 0;
 }
 
@@ -453,6 +484,7 @@ static int hits_common_setup(mahip_ctx *c, size_t n, uint32_t n_seq)
 {
 	c->n_hits = n; c->n_live = n; c->n_seq = n_seq; c->n_seq_new = n_seq;
 	c->soa_ready = false; c->has_map = false; c->graph_ready = false;
+	c->hint_max_qs = 0; // hints describe one upload: set them again after every upload/adopt
 	CHK(reserve_read_arrays(c));
 	for (int k = 0; k < 8; ++k) CHK(dev_reserve(c, c->col[k], (n + 1) * 4));
 	return 0;
@@ -482,7 +514,12 @@ extern "C" int mahip_set_shard(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end)
 	return 0;
 }
 
-static int bitlen(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
+
+extern "C" int mahip_set_hints(mahip_ctx_t *c, uint32_t max_qs)
+{
+	c->hint_max_qs = max_qs;
+	return 0;
+}
 
 extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 {
@@ -495,23 +532,50 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 		return 0;
 	}
 	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (n + 1) * 8)); CHK(dev_reserve(c, c->val[k], (n + 1) * 4)); }
-	CHK(ctr_zero(c));
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
-	{
-		ProfScope ps(c, "k_hit_keys", 20.0 * (double)n); // reads qns (8 B), writes key+val (12 B)
-		hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]), ctr, c->q_beg, c->q_end);
+	// digit plan: bits of the query start, of the query id, of the record index
+	int bs, bq, bi = bitlen(n - 1);
+	if (c->hint_max_qs && c->n_seq) bs = bitlen(c->hint_max_qs), bq = bitlen(c->n_seq - 1); // no device round trip
+	else {
+		CHK(ctr_zero(c));
+		hipLaunchKernelGGL(k_hit_bounds, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, ctr);
+		CHK(ctr_fetch(c));
+		bs = bitlen(c->h_ctr[CT_MAXQS]); bq = bitlen(c->h_ctr[CT_MAXQID]);
 	}
-	CHK(ctr_fetch(c));
-	size_t n_in = (size_t)c->h_ctr[CT_LIVE];
-	int bq = bitlen(c->h_ctr[CT_MAXQID]), bs = bitlen(c->h_ctr[CT_MAXQS]);
+	if (bi == 0) bi = 1;
+	const int pk = bq + bs + bi <= 64;
+	const bool sharded = c->q_beg > 0 || (c->n_seq && c->q_end < c->n_seq);
 	int gen = 0;
-	if (n_in < n) bq = 32, bs = 32; // out-of-shard hits carry the all-ones key: sort every bit
-	CHK(radix_sort_pairs(c, n, 0, bs, 32, 32 + bq, &gen));
-	// out-of-shard hits sorted to the tail: drop them
-	c->n_hits = c->n_live = n = n_in;
+	if (sharded) { CHK(dev_reserve(c, c->keep, (n + 16) * 4)); CHK(dev_reserve(c, c->pos, (n + 16) * 4)); }
+	CHK(ctr_zero(c));
 	{
-		ProfScope ps(c, "k_hit_gather", 76.0 * (double)n); // perm 4 + key 8 + record 32 + columns 32
-		hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint32_t*)P<uint32_t>(c->val[gen]), (const uint64_t*)P<uint64_t>(c->key[gen]), n, c->n_seq, h, P<uint32_t>(c->goff));
+		ProfScope ps(c, "k_hit_keys", (pk ? 16.0 : 20.0) * (double)n); // reads qns (8 B), writes the key (+ index)
+		hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
+		                   sharded ? P<uint32_t>(c->keep) : (uint32_t*)nullptr, ctr, c->q_beg, c->q_end, bs, bi, pk);
+	}
+	if (sharded) { // this context only keeps the hits whose query read lies in its range
+		CHK(ctr_fetch(c));
+		size_t n_in = (size_t)c->h_ctr[CT_LIVE];
+		if (n_in < n) {
+			CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), n, nullptr));
+			hipLaunchKernelGGL(k_key_compact, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[0]), pk ? (const uint32_t*)nullptr : (const uint32_t*)P<uint32_t>(c->val[0]),
+			                   n, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), P<uint64_t>(c->key[1]), P<uint32_t>(c->val[1]));
+			gen = 1;
+			c->n_hits = n = n_in;
+		}
+	}
+	c->n_live = n;
+	if (n == 0) {
+		HIPCHK(hipMemsetAsync(c->goff.p, 0, ((size_t)c->n_seq + 1) * 4, c->st));
+		c->soa_ready = true;
+		return 0;
+	}
+	if (pk) CHK(radix_sort_keys(c, n, bi, bi + bs + bq, &gen));
+	else CHK(radix_sort_pairs(c, n, 0, bs + bq, 0, 0, &gen));
+	{
+		ProfScope ps(c, "k_hit_gather", (pk ? 72.0 : 76.0) * (double)n); // key 8 (+ index 4) + record 32 + columns 32
+		hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)P<uint64_t>(c->key[gen]),
+		                   pk ? (const uint32_t*)nullptr : (const uint32_t*)P<uint32_t>(c->val[gen]), pk ? bi + bs : bs, bi, n, c->n_seq, h, P<uint32_t>(c->goff));
 	}
 	HIPCHK(hipGetLastError());
 	c->soa_ready = true;
@@ -524,7 +588,7 @@ extern "C" int mahip_hits_index(mahip_ctx_t *c)
 	size_t n = c->n_hits;
 	HitCols h = cols_of(c);
 	ProfScope ps(c, "k_hit_gather", 64.0 * (double)n);
-	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint32_t*)nullptr, (const uint64_t*)nullptr, n, c->n_seq, h, P<uint32_t>(c->goff));
+	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)nullptr, (const uint32_t*)nullptr, 32, 0, n, c->n_seq, h, P<uint32_t>(c->goff));
 	HIPCHK(hipGetLastError());
 	c->soa_ready = true;
 	return 0;
@@ -640,7 +704,7 @@ extern "C" int mahip_hits_contained_finish(mahip_ctx_t *c, const uint8_t *seq_de
 		hipLaunchKernelGGL(k_read_del, dim3(grid_for(R, 256)), dim3(256), 0, c->st, (const uint2*)P<uint2>(c->sub[0]), (const uint8_t*)P<uint8_t>(c->r_cont),
 		                   (const uint8_t*)P<uint8_t>(c->r_used), P<uint8_t>(c->r_del), P<uint32_t>(c->keep), R);
 		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), (uint32_t*)c->map.p, R, d_tot));
-		hipLaunchKernelGGL(k_map_fix, dim3(grid_for(R, 256)), dim3(256), 0, c->st, P<int32_t>(c->map), (const uint8_t*)P<uint8_t>(c->r_del), R);
+		hipLaunchKernelGGL(k_map_fix, dim3(grid_for(R, 256)), dim3(256), 0, c->st, P<int32_t>(c->map), (const uint8_t*)P<uint8_t>(c->r_del), R, P<uint32_t>(c->surv));
 	}
 	if (n) {
 		ProfScope ps(c, "k_hit_squeeze", 72.0 * (double)c->n_live);
@@ -737,6 +801,17 @@ extern "C" int mahip_map_download(mahip_ctx_t *c, int32_t *map)
 }
 
 extern "C" size_t mahip_hits_live(mahip_ctx_t *c) { return c->n_live; }
+
+extern "C" uint32_t mahip_n_seq_new(mahip_ctx_t *c) { return c->has_map ? c->n_seq_new : c->n_seq; }
+
+extern "C" int mahip_survivors_download(mahip_ctx_t *c, uint32_t *old_ids)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->has_map) { mahip_set_error("mahip_survivors_download: no squeeze map"); return -1; }
+	if (c->n_seq_new) HIPCHK(hipMemcpyAsync(old_ids, c->surv.p, (size_t)c->n_seq_new * 4, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}
 
 extern "C" int mahip_hits_download(mahip_ctx_t *c, ma_hit_t *out, size_t *n_out)
 {

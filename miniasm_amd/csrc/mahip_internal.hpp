@@ -36,13 +36,15 @@ struct mahip_ctx {
 	size_t n_live = 0;
 	uint32_t n_seq = 0;       // reads, original numbering
 	uint32_t q_beg = 0, q_end = 0xffffffffu; // shard
+	uint32_t hint_max_qs = 0; // upper bound of the query starts (max read length), 0 = unknown
 	const ma_hit_t *d_aos = nullptr; // input records (adopted or aos_own)
 	DevBuf aos_own;
 	DevBuf col[8];            // qid qs qe tn ts te mlrev bl(dead<<31)
 	DevBuf goff;              // [n_seq+1]
 	DevBuf sub[2];            // uint2 [n_seq]   word0 = s | del<<31, word1 = e
 	DevBuf r_cont, r_used, r_del, r_live; // u8 [n_seq]
-	DevBuf map;               // int32 [n_seq]
+	DevBuf map;               // int32 [n_seq]  old -> new id, -1 dropped
+	DevBuf surv;              // u32 [n_seq_new] new -> old id
 	bool soa_ready = false, has_map = false;
 	uint32_t n_seq_new = 0;
 
@@ -97,6 +99,8 @@ int ctr_fetch(mahip_ctx *c); // D2H + sync into c->h_ctr
 int scan_exclusive_u32(mahip_ctx *c, const uint32_t *in, uint32_t *out, size_t n, uint32_t *d_total);
 // stable LSD radix sort of (u64 key, u32 val) pairs on key bits [lo0,hi0) and [lo1,hi1); result in key[*gen], val[*gen]
 int radix_sort_pairs(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1, int *gen);
+// same for bare u64 keys (a payload such as the record index may ride in the bits below lo): key bits [lo,hi)
+int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen);
 
 static inline unsigned grid_for(size_t n, unsigned per_block, unsigned cap = 0x7fffffffu)
 {
@@ -179,6 +183,27 @@ __device__ __forceinline__ void blk_max_u64(unsigned long long *ctr, uint64_t x)
 		if (t) atomicMax(ctr, t);
 	}
 	__syncthreads();
+}
+// block-wide exclusive scan of one u32 per thread for 256-thread blocks; s_wave: 4 words of LDS scratch
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t x, uint32_t *s_wave, uint32_t *total)
+{
+	unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t incl = x;
+	for (int o = 1; o < 64; o <<= 1) {
+		uint32_t y = __shfl_up(incl, o, 64);
+		if (lane >= (unsigned)o) incl += y;
+	}
+	if (lane == 63) s_wave[wave] = incl;
+	__syncthreads();
+	uint32_t base = 0, tot = 0;
+	for (unsigned w = 0; w < 4; ++w) {
+		uint32_t v = s_wave[w];
+		if (w < wave) base += v;
+		tot += v;
+	}
+	__syncthreads();
+	*total = tot;
+	return base + incl - x;
 }
 #define MA_STREAM_BLOCKS 2048u // 256 CUs x 8 blocks of 256 threads: full occupancy for streaming passes
 

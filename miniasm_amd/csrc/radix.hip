@@ -1,59 +1,74 @@
-// radix.hip -- stable LSD radix sort of (u64 key, u32 value) pairs, 8-bit digits, wave64 ballot ranking.
+// radix.hip -- stable LSD radix sort of 64-bit keys (optionally with a 32-bit value), wave64 ballot ranking.
 //
 // Reproduces WHAT reference hit.c:19-22 (ma_hit_sort -> radix_sort_hit, ksort.h:134-183) and asg.c:22-25
 // (asg_arc_sort) compute -- records ordered by their 64-bit key -- with a TOTAL order: ties keep input
 // order (the reference's in-place American-flag sort leaves ties in a data-dependent order).
-// Only the significant key bits are sorted: two bit ranges [lo0,hi0) and [lo1,hi1), e.g. the bits of the
-// query start and the bits of the query id.
 //
-// Per pass: k_radix_hist (per-tile digit counts, digit-major) -> exclusive scan -> k_radix_scatter
-// (stable multi-split).  HBM-bound: per pass reads keys twice, values once, writes both once.
+// Design for MI355X (HBM-bound):
+//   * only the significant key bits are sorted, in digits of up to 9 bits chosen to minimise the pass count
+//     (hits: 17 bits of start + 18 bits of read id = 4 passes instead of 8 byte-passes over 64 bits);
+//   * when the record index fits below the key bits the index rides in the low bits of the key itself
+//     (8-byte elements, no value array): a pass reads 8 B twice and writes 8 B per record;
+//   * per pass: k_radix_hist (per-tile digit counts, digit-major) -> exclusive scan -> k_radix_scatter;
+//   * tiles of 4096 keys (256 threads x 16): ranks come from wave ballots (stable multi-split), the tile is
+//     reordered through LDS so that consecutive lanes write consecutive addresses of a digit's run.
 #include "mahip_internal.hpp"
 
 #define RS_THREADS 256
-#define RS_ITEMS 8
+#define RS_ITEMS 16
 #define RS_TILE (RS_THREADS * RS_ITEMS)
 #define RS_WAVES (RS_THREADS / 64)
+#define RS_MAXBITS 9
+#define RS_BINS (1 << RS_MAXBITS)
 
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint64_t *__restrict__ key, uint32_t *__restrict__ hist,
                                                             size_t n, unsigned nb, int shift, unsigned mask)
 {
-	__shared__ uint32_t s_cnt[256];
-	s_cnt[threadIdx.x] = 0;
+	__shared__ uint32_t s_cnt[RS_BINS];
+	for (unsigned d = threadIdx.x; d <= mask; d += RS_THREADS) s_cnt[d] = 0;
 	__syncthreads();
 	size_t base = (size_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
 	for (int it = 0; it < RS_ITEMS; ++it) {
 		size_t i = base + (size_t)it * RS_THREADS + threadIdx.x;
 		if (i < n) atomicAdd(&s_cnt[(unsigned)(key[i] >> shift) & mask], 1u);
 	}
 	__syncthreads();
-	hist[(size_t)threadIdx.x * nb + blockIdx.x] = s_cnt[threadIdx.x];
+	for (unsigned d = threadIdx.x; d <= mask; d += RS_THREADS) hist[(size_t)d * nb + blockIdx.x] = s_cnt[d];
 }
 
 // Element order inside a tile is (wave, item, lane): element index = tile + wave*64*ITEMS + item*64 + lane.
+template <bool HAS_VAL>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                                uint64_t *__restrict__ kout, uint32_t *__restrict__ vout,
-                                                               const uint32_t *__restrict__ gofs, size_t n, unsigned nb, int shift, unsigned mask)
+                                                               const uint32_t *__restrict__ gofs, size_t n, unsigned nb, int shift, unsigned mask, int nbits)
 {
-	__shared__ uint32_t s_cnt[RS_WAVES][256];
+	__shared__ uint32_t s_cnt[RS_WAVES][RS_BINS]; // per-wave digit counts, then the wave's first local slot per digit
+	__shared__ uint32_t s_gb[RS_BINS];            // global offset of the digit's run minus its first local slot
+	__shared__ uint32_t s_scan[RS_WAVES];
+	__shared__ uint64_t s_key[RS_TILE];
+	__shared__ uint32_t s_val[HAS_VAL ? RS_TILE : 1];
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint64_t lt = wv_lt(lane);
-	for (int w = 0; w < RS_WAVES; ++w) s_cnt[w][threadIdx.x] = 0;
+	for (unsigned d = threadIdx.x; d < RS_WAVES * RS_BINS; d += RS_THREADS) (&s_cnt[0][0])[d] = 0;
 	__syncthreads();
-	size_t wbase = (size_t)blockIdx.x * RS_TILE + (size_t)wave * 64 * RS_ITEMS;
+	const size_t tile = (size_t)blockIdx.x * RS_TILE, wbase = tile + (size_t)wave * 64 * RS_ITEMS;
+	const unsigned n_tile = (unsigned)(n - tile < RS_TILE ? n - tile : RS_TILE);
 	uint64_t k[RS_ITEMS];
 	uint32_t v[RS_ITEMS], r[RS_ITEMS];
+#pragma unroll
 	for (int it = 0; it < RS_ITEMS; ++it) {
 		size_t i = wbase + (size_t)it * 64 + lane;
 		k[it] = i < n ? kin[i] : 0;
-		v[it] = i < n ? vin[i] : 0;
+		if (HAS_VAL) v[it] = i < n ? vin[i] : 0;
 	}
-	for (int it = 0; it < RS_ITEMS; ++it) {
+#pragma unroll
+	for (int it = 0; it < RS_ITEMS; ++it) { // stable rank inside the wave: lanes with my digit before me + earlier items
 		size_t i = wbase + (size_t)it * 64 + lane;
 		int valid = i < n;
 		unsigned d = (unsigned)(k[it] >> shift) & mask;
 		uint64_t peers = wv_ballot(valid);
-		for (int b = 0; b < 8; ++b) {
+		for (int b = 0; b < nbits; ++b) {
 			uint64_t bal = wv_ballot((d >> b) & 1);
 			peers &= ((d >> b) & 1) ? bal : ~bal;
 		}
@@ -64,51 +79,90 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
 		r[it] = prev + (uint32_t)__popcll(peers & lt);
 	}
 	__syncthreads();
-	{ // per digit: exclusive prefix over the waves + global offset of (digit, tile)
-		unsigned d = threadIdx.x;
-		uint32_t run = gofs[(size_t)d * nb + blockIdx.x];
-		for (int w = 0; w < RS_WAVES; ++w) { uint32_t t = s_cnt[w][d]; s_cnt[w][d] = run; run += t; }
+	{ // thread t owns digits 2t, 2t+1: waves' counts -> exclusive over waves; tile counts -> exclusive over digits
+		unsigned d0 = 2 * threadIdx.x, d1 = d0 + 1;
+		uint32_t c0 = 0, c1 = 0, w0[RS_WAVES], w1[RS_WAVES];
+		for (int w = 0; w < RS_WAVES; ++w) { w0[w] = c0; c0 += s_cnt[w][d0]; w1[w] = c1; c1 += s_cnt[w][d1]; }
+		uint32_t tot, ex = block_excl_scan_256(c0 + c1, s_scan, &tot);
+		for (int w = 0; w < RS_WAVES; ++w) { s_cnt[w][d0] = ex + w0[w]; s_cnt[w][d1] = ex + c0 + w1[w]; }
+		if (d0 <= mask) s_gb[d0] = gofs[(size_t)d0 * nb + blockIdx.x] - ex;
+		if (d1 <= mask) s_gb[d1] = gofs[(size_t)d1 * nb + blockIdx.x] - (ex + c0);
 	}
 	__syncthreads();
-	for (int it = 0; it < RS_ITEMS; ++it) {
+#pragma unroll
+	for (int it = 0; it < RS_ITEMS; ++it) { // tile reordered by digit in LDS
 		size_t i = wbase + (size_t)it * 64 + lane;
 		if (i < n) {
 			unsigned d = (unsigned)(k[it] >> shift) & mask;
 			uint32_t p = s_cnt[wave][d] + r[it];
-			kout[p] = k[it];
-			vout[p] = v[it];
+			s_key[p] = k[it];
+			if (HAS_VAL) s_val[p] = v[it];
+		}
+	}
+	__syncthreads();
+#pragma unroll 4
+	for (int j = 0; j < RS_ITEMS; ++j) { // consecutive lanes -> consecutive slots of a digit's run -> consecutive addresses
+		unsigned p = j * RS_THREADS + threadIdx.x;
+		if (p < n_tile) {
+			uint64_t kk = s_key[p];
+			uint32_t g = s_gb[(unsigned)(kk >> shift) & mask] + p;
+			kout[g] = kk;
+			if (HAS_VAL) vout[g] = s_val[p];
 		}
 	}
 }
 
-int radix_sort_pairs(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1, int *gen)
+// choose digit widths: as few passes as possible, each <= RS_MAXBITS, widths balanced
+static int plan_digits(int lo, int hi, int *shift, int *bits)
 {
-	int g = *gen;
+	int nb = hi - lo, np, i, s = lo;
+	if (nb <= 0) return 0;
+	np = (nb + RS_MAXBITS - 1) / RS_MAXBITS;
+	for (i = 0; i < np; ++i) {
+		int w = (nb - (s - lo) + (np - i) - 1) / (np - i);
+		shift[i] = s; bits[i] = w; s += w;
+	}
+	return np;
+}
+
+// sort key[*gen] (and val[*gen] if has_val) on key bits [lo0,hi0) then [lo1,hi1); result in generation *gen
+static int radix_sort_impl(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1, int *gen, bool has_val)
+{
+	int g = *gen, shift[16], bits[16], np;
 	if (n == 0) return 0;
-	if (n >= 0xffffffffull) { mahip_set_error("radix_sort_pairs: too many records"); return -1; }
+	if (n >= 0xffffffffull) { mahip_set_error("radix sort: too many records"); return -1; }
+	np = plan_digits(lo0, hi0, shift, bits);
+	np += plan_digits(lo1, hi1, shift + np, bits + np);
 	unsigned nb = (unsigned)((n + RS_TILE - 1) / RS_TILE);
-	CHK(dev_reserve(c, c->hist, ((size_t)256 * nb + 8) * 4));
-	for (int range = 0; range < 2; ++range) {
-		int lo = range ? lo1 : lo0, hi = range ? hi1 : hi0;
-		for (int shift = lo; shift < hi; shift += 8) {
-			int bits = hi - shift < 8 ? hi - shift : 8;
-			unsigned mask = (1u << bits) - 1;
-			uint64_t *kin = P<uint64_t>(c->key[g]), *kout = P<uint64_t>(c->key[g ^ 1]);
-			uint32_t *vin = P<uint32_t>(c->val[g]), *vout = P<uint32_t>(c->val[g ^ 1]);
-			uint32_t *hist = P<uint32_t>(c->hist);
-			{
-				ProfScope ps(c, "k_radix_hist", 8.0 * (double)n);
-				hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(RS_THREADS), 0, c->st, kin, hist, n, nb, shift, mask);
-			}
-			CHK(scan_exclusive_u32(c, hist, hist, (size_t)256 * nb, nullptr));
-			{
-				ProfScope ps(c, "k_radix_scatter", 24.0 * (double)n);
-				hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(RS_THREADS), 0, c->st, kin, vin, kout, vout, hist, n, nb, shift, mask);
-			}
-			g ^= 1;
+	CHK(dev_reserve(c, c->hist, ((size_t)RS_BINS * nb + 8) * 4));
+	for (int p = 0; p < np; ++p) {
+		unsigned mask = (1u << bits[p]) - 1;
+		uint64_t *kin = P<uint64_t>(c->key[g]), *kout = P<uint64_t>(c->key[g ^ 1]);
+		uint32_t *vin = P<uint32_t>(c->val[g]), *vout = P<uint32_t>(c->val[g ^ 1]);
+		uint32_t *hist = P<uint32_t>(c->hist);
+		{
+			ProfScope ps(c, "k_radix_hist", 8.0 * (double)n);
+			hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(RS_THREADS), 0, c->st, kin, hist, n, nb, shift[p], mask);
 		}
+		CHK(scan_exclusive_u32(c, hist, hist, (size_t)(mask + 1) * nb, nullptr));
+		{
+			ProfScope ps(c, "k_radix_scatter", (has_val ? 24.0 : 16.0) * (double)n);
+			if (has_val) hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(RS_THREADS), 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p]);
+			else hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nb), dim3(RS_THREADS), 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p]);
+		}
+		g ^= 1;
 	}
 	HIPCHK(hipGetLastError());
 	*gen = g;
 	return 0;
+}
+
+int radix_sort_pairs(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1, int *gen)
+{
+	return radix_sort_impl(c, n, lo0, hi0, lo1, hi1, gen, true);
+}
+
+int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen)
+{
+	return radix_sort_impl(c, n, lo, hi, 0, 0, gen, false);
 }

@@ -88,12 +88,19 @@ sdict_t *ma_hit_no_cont(const char *fn, int min_span, int min_match, int max_han
 	return d;
 }
 
+static uint32_t g_ingest_max_qs; /* largest query start stored by the last ingest: lets the device sort plan its digits */
+uint32_t ma_ingest_max_qs(void) { return g_ingest_max_qs; }
+
 ma_hit_t *ma_hit_ingest(const char *fn, int min_span, int min_match, sdict_t *d, size_t *n, int bi_dir, const sdict_t *excl)
 { /* hit.c:70-103: filter, name -> id in first-appearance order (query before target), store hit + mirrored hit */
-	paf_file_t *fp = paf_open(fn);
+	uint32_t max_qs = 0;
+	paf_file_t *fp;
 	paf_rec_t r;
 	ma_hit_t *a = 0;
 	size_t na = 0, ma = 0, i, tot = 0, tot_len = 0;
+	a = ma_hit_ingest_mt(fn, min_span, min_match, d, &na, bi_dir, excl, &tot, &max_qs); /* plain files: chunk-parallel parse */
+	if (a) goto done;
+	fp = paf_open(fn);
 	if (!fp) {
 		fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn);
 		exit(1);
@@ -114,18 +121,22 @@ ma_hit_t *ma_hit_ingest(const char *fn, int min_span, int min_match, sdict_t *d,
 		p = &a[na++];
 		p->qns = (uint64_t)qid << 32 | r.qs; p->qe = r.qe; p->tn = tid; p->ts = r.ts; p->te = r.te;
 		p->rev = r.rev; p->ml = r.ml; p->bl = r.bl; p->del = 0;
+		if (r.qs > max_qs) max_qs = r.qs;
 		if (bi_dir && qid != tid) {
+			if (r.ts > max_qs) max_qs = r.ts;
 			p = &a[na++];
 			p->qns = (uint64_t)tid << 32 | r.ts; p->qe = r.te; p->tn = qid; p->ts = r.qs; p->te = r.qe;
 			p->rev = r.rev; p->ml = r.ml; p->bl = r.bl; p->del = 0;
 		}
 	}
 	paf_close(fp);
+done:
 	for (i = 0; i < d->n_seq; ++i) tot_len += d->seq[i].len;
 	if (ma_verbose >= 3)
 		fprintf(MA_LOG, "[M::%s::%s] read %ld hits; stored %ld hits and %d sequences (%ld bp)\n", "ma_hit_read", sys_timestamp(), (long)tot, (long)na, d->n_seq, (long)tot_len);
 	if (a == 0) a = (ma_hit_t*)malloc(sizeof(ma_hit_t));
 	*n = na;
+	g_ingest_max_qs = max_qs;
 	return a;
 }
 

@@ -28,6 +28,11 @@ int ma_paf_parse_line(int l, char *s, paf_rec_t *pr);
 
 /* ingest without the sort: reference hit.c:70-101 (everything of ma_hit_read before ma_hit_sort) */
 ma_hit_t *ma_hit_ingest(const char *fn, int min_span, int min_match, sdict_t *d, size_t *n, int bi_dir, const sdict_t *excl);
+/* chunk-parallel variant for plain files (ingest_mt.c); NULL when not eligible (gzip, stdin, small input, one thread) */
+ma_hit_t *ma_hit_ingest_mt(const char *fn, int min_span, int min_match, sdict_t *d, size_t *n, int bi_dir, const sdict_t *excl,
+                           size_t *tot_lines, uint32_t *max_qs);
+int ma_ingest_threads(void); /* MA_THREADS or the number of online cores, capped */
+uint32_t ma_ingest_max_qs(void); /* largest query start stored by the last ma_hit_ingest */
 
 /* literal emulation of the reference's in-place MSD radix sort (ksort.h:134-183) on arcs keyed by ul */
 void ma_refsort_arcs(asg_arc_t *beg, asg_arc_t *end);

@@ -129,23 +129,25 @@ int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 	ma_sub_t *sub = 0;
 	FILE *lg = MA_LOG;
 
+	const int timing = getenv("MA_PIPE_TIMING") != 0;
+	double tt[8] = {0};
+#define TSTAMP(k) do { if (timing) tt[k] = sys_realtime(); } while (0)
+	TSTAMP(0);
 	memset(&view, 0, sizeof(view));
 	view.n_seq = R; view.seq = d->seq;
-	if (squeezed) {
-		uint8_t *del = (uint8_t*)malloc(R ? R : 1);
-		uint32_t r, k;
-		GPU(mahip_seqdel_download(c, del));
-		for (r = k = 0; r < R; ++r) k += !del[r];
-		view.seq = (sd_seq_t*)malloc((k ? k : 1) * sizeof(sd_seq_t));
-		for (r = k = 0; r < R; ++r)
-			if (!del[r]) view.seq[k] = d->seq[r], view.seq[k].del = 0, view.seq[k].aux = 0, ++k;
-		view.n_seq = k;
-		free(del);
+	if (squeezed) { /* O(survivors): the device hands over the list of surviving old ids */
+		uint32_t k, n_new = mahip_n_seq_new(c), *old = (uint32_t*)malloc((n_new ? n_new : 1) * 4);
+		GPU(mahip_survivors_download(c, old));
+		view.seq = (sd_seq_t*)malloc((n_new ? n_new : 1) * sizeof(sd_seq_t));
+		for (k = 0; k < n_new; ++k) view.seq[k] = d->seq[old[k]], view.seq[k].del = 0, view.seq[k].aux = 0;
+		view.n_seq = n_new;
+		free(old);
 	}
 	if (have_sub) {
-		sub = (ma_sub_t*)calloc(R ? R : 1, sizeof(ma_sub_t));
+		sub = (ma_sub_t*)calloc(view.n_seq ? view.n_seq : 1, sizeof(ma_sub_t));
 		GPU(mahip_sub_download(c, 0, sub, squeezed));
 	}
+	TSTAMP(1);
 	if (strcmp(outfmt, "bed") == 0) {
 		if (sub) print_subs(&view, sub, out);
 	} else if (strcmp(outfmt, "paf") == 0) {
@@ -160,6 +162,7 @@ int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 		GPU(mahip_asg_download(c, sg)); /* the reduced graph is small: the sequential cleaners run on the host */
 		if (sg->n_seq != view.n_seq) { fprintf(stderr, "[E::%s] squeeze mismatch: host %u vs device %u reads\n", __func__, view.n_seq, sg->n_seq); exit(1); }
 		sg->is_symm = n_red > 0;
+		TSTAMP(2);
 		if (stage >= 7) {
 			fprintf(lg, "[M::%s] ===> Step 4.2: initial tip cutting and bubble popping <===\n", "main");
 			asg_cut_tip(sg, opt->max_ext);
@@ -189,11 +192,16 @@ int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 				asg_pop_bubble(sg, opt->bub_dist);
 			}
 		}
+		TSTAMP(3);
 		if (strcmp(outfmt, "ug") == 0) {
 			fprintf(lg, "[M::%s] ===> Step 5: generating unitigs <===\n", "main");
 			ug = ma_ug_gen(sg);
+			TSTAMP(4);
 			ma_ug_print(ug, &view, sub, out);
 		} else ma_sg_print(sg, &view, sub, out);
+		TSTAMP(5);
+		if (timing) fprintf(stderr, "[T::tail] names+sub %.3f  graph download %.3f  cleaners %.3f  unitigs %.3f  print %.3f ms (reads %u arcs %u)\n",
+				(tt[1]-tt[0])*1e3, (tt[2]-tt[1])*1e3, (tt[3]-tt[2])*1e3, (tt[4]-tt[3])*1e3, (tt[5]-tt[4])*1e3, sg->n_seq, sg->n_arc);
 		asg_destroy(sg);
 		ma_ug_destroy(ug);
 	}
@@ -205,8 +213,13 @@ int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 int ma_pipeline_device(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, FILE *out)
 {
 	uint32_t st[4];
+	int rc;
+	double t0 = sys_realtime(), t1;
 	ma_pipeline_head(c, opt, d, outfmt, stage, flags, st);
-	return ma_pipeline_tail(c, opt, d, outfmt, stage, st, out);
+	t1 = sys_realtime();
+	rc = ma_pipeline_tail(c, opt, d, outfmt, stage, st, out);
+	if (getenv("MA_PIPE_TIMING")) fprintf(stderr, "[T::pipeline] head %.3f ms  tail %.3f ms\n", (t1 - t0) * 1e3, (sys_realtime() - t1) * 1e3);
+	return rc;
 }
 
 /* same, with the output text returned in a malloc'ed buffer (bench.py / tests) */
@@ -245,6 +258,7 @@ int ma_pipeline_run(const ma_opt_t *opt, const char *fn, const char *outfmt, int
 	hit = ma_hit_ingest(fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), excl);
 	GPU(mahip_set_shard(c, 0, 0xffffffffu));
 	GPU(mahip_hits_upload(c, hit, n_hits, d->n_seq));
+	GPU(mahip_set_hints(c, ma_ingest_max_qs()));
 	GPU(mahip_sync(c));
 	free(hit);
 	ma_pipeline_device(c, opt, d, outfmt, stage, flags, out);

@@ -35,19 +35,56 @@ asg_t *ma_sg_gen(const ma_opt_t *opt, const sdict_t *d, const ma_sub_t *sub, siz
 	return g;
 }
 
-void ma_sg_print(const asg_t *g, const sdict_t *d, const ma_sub_t *sub, FILE *fp)
+/* ---- buffered text output: the writers below produce tens of thousands of short lines; formatting them with
+ * fprintf costs more than every GPU pass together, so lines are assembled in a buffer with hand-rolled integer
+ * formatting and written once.  Byte-for-byte the text the reference's fprintf calls produce. */
+typedef struct { char *s; size_t n, m; FILE *fp; } obuf_t;
+
+static inline void ob_need(obuf_t *o, size_t k)
+{
+	if (o->n + k > o->m) {
+		o->m = (o->n + k) * 2 + 4096;
+		o->s = (char*)realloc(o->s, o->m);
+	}
+}
+static inline void ob_chr(obuf_t *o, char c) { ob_need(o, 1); o->s[o->n++] = c; }
+static inline void ob_mem(obuf_t *o, const char *p, size_t l) { ob_need(o, l); memcpy(o->s + o->n, p, l); o->n += l; }
+static inline void ob_str(obuf_t *o, const char *p) { ob_mem(o, p, strlen(p)); }
+static inline void ob_int(obuf_t *o, int64_t x) /* %d */
+{
+	char t[24]; int k = 0; uint64_t u = x < 0 ? (uint64_t)(-x) : (uint64_t)x;
+	do { t[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+	ob_need(o, (size_t)k + 1);
+	if (x < 0) o->s[o->n++] = '-';
+	while (k) o->s[o->n++] = t[--k];
+}
+static inline void ob_int6(obuf_t *o, uint32_t x) /* %.6d of a non-negative value */
+{
+	char t[24]; int k = 0;
+	do { t[k++] = (char)('0' + x % 10); x /= 10; } while (x);
+	while (k < 6) t[k++] = '0';
+	ob_need(o, (size_t)k);
+	while (k) o->s[o->n++] = t[--k];
+}
+static inline void ob_flush(obuf_t *o) { if (o->n) fwrite(o->s, 1, o->n, o->fp); free(o->s); o->s = 0; o->n = o->m = 0; }
+/* "name:s+1-e" (or just the name without sub) */
+static inline void ob_read(obuf_t *o, const sdict_t *d, const ma_sub_t *sub, uint32_t x)
+{
+	ob_str(o, d->seq[x].name);
+	if (sub) { ob_chr(o, ':'); ob_int(o, (int)sub[x].s + 1); ob_chr(o, '-'); ob_int(o, (int)sub[x].e); }
+}
+
+void ma_sg_print(const asg_t *g, const sdict_t *d, const ma_sub_t *sub, FILE *fp) /* asm.c:41-55 */
 {
 	uint32_t i;
-	for (i = 0; i < g->n_arc; ++i) {
+	obuf_t o = {0, 0, 0, fp};
+	for (i = 0; i < g->n_arc; ++i) { /* "L\t%s:%d-%d\t%c\t%s:%d-%d\t%c\t%d:\tL1:i:%d\n" */
 		const asg_arc_t *p = &g->arc[i];
-		uint32_t q = (uint32_t)(p->ul >> 33), t = p->v >> 1;
-		char so = "+-"[p->ul >> 32 & 1], to = "+-"[p->v & 1];
-		if (sub)
-			fprintf(fp, "L\t%s:%d-%d\t%c\t%s:%d-%d\t%c\t%d:\tL1:i:%d\n", d->seq[q].name, sub[q].s + 1, sub[q].e, so,
-					d->seq[t].name, sub[t].s + 1, sub[t].e, to, p->ol, (uint32_t)p->ul);
-		else
-			fprintf(fp, "L\t%s\t%c\t%s\t%c\t%d:\tL1:i:%d\n", d->seq[q].name, so, d->seq[t].name, to, p->ol, (uint32_t)p->ul);
+		ob_mem(&o, "L\t", 2); ob_read(&o, d, sub, (uint32_t)(p->ul >> 33)); ob_chr(&o, '\t'); ob_chr(&o, "+-"[p->ul >> 32 & 1]); ob_chr(&o, '\t');
+		ob_read(&o, d, sub, p->v >> 1); ob_chr(&o, '\t'); ob_chr(&o, "+-"[p->v & 1]); ob_chr(&o, '\t');
+		ob_int(&o, (int)p->ol); ob_mem(&o, ":\tL1:i:", 7); ob_int(&o, (int)(uint32_t)p->ul); ob_chr(&o, '\n');
 	}
+	ob_flush(&o);
 }
 
 /* ---------------------------------------------------------------------------------------------- unitigs */
@@ -166,46 +203,48 @@ ma_ug_t *ma_ug_gen(asg_t *g) /* asm.c:121-210 */
 	return ug;
 }
 
+static inline void ob_utg(obuf_t *o, uint32_t id1, int circ) { ob_mem(o, "utg", 3); ob_int6(o, id1); ob_chr(o, "lc"[circ]); }
+
 void ma_ug_print(const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, FILE *fp) /* asm.c:77-116 */
 {
 	uint32_t i, j, l;
-	char name[32];
+	obuf_t o = {0, 0, 0, fp};
 	for (i = 0; i < ug->u.n; ++i) { /* S lines, circularising L lines, per-read a lines */
 		const ma_utg_t *p = &ug->u.a[i];
-		sprintf(name, "utg%.6d%c", i + 1, "lc"[p->circ]);
-		fprintf(fp, "S\t%s\t%s\tLN:i:%d\n", name, p->s ? p->s : "*", p->len);
+		ob_mem(&o, "S\t", 2); ob_utg(&o, i + 1, p->circ); ob_chr(&o, '\t'); ob_str(&o, p->s ? p->s : "*"); ob_mem(&o, "\tLN:i:", 6); ob_int(&o, (int)p->len); ob_chr(&o, '\n');
 		if (p->circ) {
-			fprintf(fp, "L\t%s\t+\t%s\t+\t0M\n", name, name);
-			fprintf(fp, "L\t%s\t-\t%s\t-\t0M\n", name, name);
+			for (j = 0; j < 2; ++j) { /* "L\t%s\t+\t%s\t+\t0M\n" and the '-' twin */
+				char c = "+-"[j];
+				ob_mem(&o, "L\t", 2); ob_utg(&o, i + 1, p->circ); ob_chr(&o, '\t'); ob_chr(&o, c); ob_chr(&o, '\t');
+				ob_utg(&o, i + 1, p->circ); ob_chr(&o, '\t'); ob_chr(&o, c); ob_mem(&o, "\t0M\n", 4);
+			}
 		}
-		for (j = l = 0; j < p->n; l += (uint32_t)p->a[j++]) {
-			uint32_t x = (uint32_t)(p->a[j] >> 33);
-			char o = "+-"[p->a[j] >> 32 & 1];
-			if (sub) fprintf(fp, "a\t%s\t%d\t%s:%d-%d\t%c\t%d\n", name, l, d->seq[x].name, sub[x].s + 1, sub[x].e, o, (uint32_t)p->a[j]);
-			else fprintf(fp, "a\t%s\t%d\t%s\t%c\t%d\n", name, l, d->seq[x].name, o, (uint32_t)p->a[j]);
+		for (j = l = 0; j < p->n; l += (uint32_t)p->a[j++]) { /* "a\t%s\t%d\t%s:%d-%d\t%c\t%d\n" */
+			ob_mem(&o, "a\t", 2); ob_utg(&o, i + 1, p->circ); ob_chr(&o, '\t'); ob_int(&o, (int)l); ob_chr(&o, '\t');
+			ob_read(&o, d, sub, (uint32_t)(p->a[j] >> 33)); ob_chr(&o, '\t'); ob_chr(&o, "+-"[p->a[j] >> 32 & 1]); ob_chr(&o, '\t');
+			ob_int(&o, (int)(uint32_t)p->a[j]); ob_chr(&o, '\n');
 		}
 	}
-	for (i = 0; i < ug->g->n_arc; ++i) { /* L lines between unitigs */
+	for (i = 0; i < ug->g->n_arc; ++i) { /* "L\tutg%.6d%c\t%c\tutg%.6d%c\t%c\t%dM\tSD:i:%d\n" */
 		const asg_arc_t *e = &ug->g->arc[i];
 		uint32_t u = (uint32_t)(e->ul >> 32), v = e->v;
-		fprintf(fp, "L\tutg%.6d%c\t%c\tutg%.6d%c\t%c\t%dM\tSD:i:%d\n", (u >> 1) + 1, "lc"[ug->u.a[u >> 1].circ], "+-"[u & 1],
-				(v >> 1) + 1, "lc"[ug->u.a[v >> 1].circ], "+-"[v & 1], e->ol, asg_arc_len(*e));
+		ob_mem(&o, "L\t", 2); ob_utg(&o, (u >> 1) + 1, ug->u.a[u >> 1].circ); ob_chr(&o, '\t'); ob_chr(&o, "+-"[u & 1]); ob_chr(&o, '\t');
+		ob_utg(&o, (v >> 1) + 1, ug->u.a[v >> 1].circ); ob_chr(&o, '\t'); ob_chr(&o, "+-"[v & 1]); ob_chr(&o, '\t');
+		ob_int(&o, (int)e->ol); ob_mem(&o, "M\tSD:i:", 7); ob_int(&o, (int)asg_arc_len(*e)); ob_chr(&o, '\n');
 	}
 	for (i = 0; i < ug->u.n; ++i) { /* x lines: unitig summary */
 		const ma_utg_t *u = &ug->u.a[i];
-		if (u->start == UINT32_MAX) {
-			fprintf(fp, "x\tutg%.6dc\t%d\t%d\n", i + 1, u->len, u->n);
-		} else {
+		if (u->start == UINT32_MAX) { /* "x\tutg%.6dc\t%d\t%d\n" */
+			ob_mem(&o, "x\t", 2); ob_utg(&o, i + 1, 1); ob_chr(&o, '\t'); ob_int(&o, (int)u->len); ob_chr(&o, '\t'); ob_int(&o, (int)u->n); ob_chr(&o, '\n');
+		} else { /* "x\tutg%.6dl\t%d\t%d\t%d\t%d\t%s:%d-%d\t%c\t%s:%d-%d\t%c\n" */
 			uint32_t c0 = asg_arc_n(ug->g, i << 1 | 0), c1 = asg_arc_n(ug->g, i << 1 | 1);
-			uint32_t rs = u->start >> 1, re = u->end >> 1;
-			if (sub)
-				fprintf(fp, "x\tutg%.6dl\t%d\t%d\t%d\t%d\t%s:%d-%d\t%c\t%s:%d-%d\t%c\n", i + 1, u->len, u->n, c1, c0,
-						d->seq[rs].name, sub[rs].s + 1, sub[rs].e, "+-"[u->start & 1], d->seq[re].name, sub[re].s + 1, sub[re].e, "+-"[u->end & 1]);
-			else
-				fprintf(fp, "x\tutg%.6dl\t%d\t%d\t%d\t%d\t%s\t%c\t%s\t%c\n", i + 1, u->len, u->n, c1, c0,
-						d->seq[rs].name, "+-"[u->start & 1], d->seq[re].name, "+-"[u->end & 1]);
+			ob_mem(&o, "x\t", 2); ob_utg(&o, i + 1, 0); ob_chr(&o, '\t'); ob_int(&o, (int)u->len); ob_chr(&o, '\t'); ob_int(&o, (int)u->n); ob_chr(&o, '\t');
+			ob_int(&o, (int)c1); ob_chr(&o, '\t'); ob_int(&o, (int)c0); ob_chr(&o, '\t');
+			ob_read(&o, d, sub, u->start >> 1); ob_chr(&o, '\t'); ob_chr(&o, "+-"[u->start & 1]); ob_chr(&o, '\t');
+			ob_read(&o, d, sub, u->end >> 1); ob_chr(&o, '\t'); ob_chr(&o, "+-"[u->end & 1]); ob_chr(&o, '\n');
 		}
 	}
+	ob_flush(&o);
 }
 
 int ma_ug_seq(ma_ug_t *g, const sdict_t *d, const ma_sub_t *sub, const char *fn)

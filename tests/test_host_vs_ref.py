@@ -113,6 +113,17 @@ def test_cleaners_unitigs_gfa_match_reference(name, reads, lines, seed, extra, t
     LR.ma_ug_print = LR.ma_ug_print
     LR.ma_ug_print.argtypes = [C.c_void_p, C.POINTER(ma.Sdict), C.c_void_p, C.c_void_p]
     sub = S["cont_sub"]
+    LR.ma_sg_print.argtypes = [C.POINTER(ma.Asg), C.POINTER(ma.Sdict), C.c_void_p, C.c_void_p]
+    sg_txt = []
+    for tag, L, gg, dd in (("ref", LR, g_ref, dr), ("mine", LP, C.byref(g_mine), d)):
+        for with_sub in (True, False):
+            path = os.path.join(tmpdir_s, "h_%s_%s_%d.sg" % (name, tag, with_sub))
+            fp = libc.fopen(path.encode(), b"w")
+            L.ma_sg_print(gg, dd, sub.ctypes.data if with_sub else None, fp)
+            libc.fclose(fp)
+            sg_txt.append(open(path, "rb").read())
+    assert sg_txt[0] == sg_txt[2] and sg_txt[1] == sg_txt[3], "string-graph text differs"
+    assert len(sg_txt[0]) > 100
     ug_r, ug_p = LR.ma_ug_gen(g_ref), LP.ma_ug_gen(C.byref(g_mine))
     outs = []
     for tag, L, ug, dd in (("ref", LR, ug_r, dr), ("mine", LP, ug_p, d)):
@@ -209,3 +220,47 @@ def test_refsort_emulation_matches_reference_on_ties():
             L.asg_arc_sort(C.byref(g))
             res.append(a.tobytes())
         assert res[0] == res[1], "tie order differs for n=%d" % n
+
+
+@needs_ref
+def test_parallel_ingest_matches_reference(tmpdir_s, monkeypatch):
+    """chunk-parallel ingest (ingest_mt.c): same ids, same records as the reference's sequential reader, including
+    the `bl` a 10-column line inherits across a chunk cut, CRLF line ends and junk lines"""
+    import random
+    paf = R.pafgen(os.path.join(tmpdir_s, "mt.paf"), 6000, 260000, 33, ["-L", "uniform", "-x", "0.02"])
+    rnd = random.Random(5)
+    big = os.path.join(tmpdir_s, "mt_mod.paf")
+    with open(paf, "rb") as f, open(big, "wb") as g:
+        for ln in f:
+            x = rnd.random()
+            if x < 0.02:
+                ln = b"\t".join(ln.rstrip(b"\n").split(b"\t")[:10]) + b"\n"      # 10 columns: inherits bl
+            elif x < 0.03:
+                ln = ln.rstrip(b"\n") + b"\r\n"
+            elif x < 0.032:
+                ln = b"junk\tline\n"
+            g.write(ln)
+    assert os.path.getsize(big) > (8 << 20)
+    opt = ma.default_opt()
+    LR = R.ref()
+    d = LR.sd_init()
+    n = C.c_size_t(0)
+    q = LR.ma_hit_read(big.encode(), opt.min_span, opt.min_match, d, C.byref(n), 1, None)
+    ref_hits = R.np_from(q, n.value, ma.HIT_DT)
+    ref_hits["bldel"] &= 0x7FFFFFFF
+    ref_names = [d.contents.seq[i].name.decode() for i in range(d.contents.n_seq)]
+    ref_lens = [d.contents.seq[i].len for i in range(d.contents.n_seq)]
+    ref_c = R.canon(ref_hits).tobytes()
+    first = None
+    for th in ("1", "3", "7", "16"):
+        monkeypatch.setenv("MA_THREADS", th)
+        ing = ma.Ingest(big, opt)
+        assert ing.n == n.value, th
+        assert ing.names() == ref_names and list(ing.lens()) == ref_lens, "dictionary differs with %s threads" % th
+        assert R.canon(ing.hits).tobytes() == ref_c, "records differ with %s threads" % th
+        raw = ing.hits.tobytes()
+        if first is None:
+            first = raw
+        assert raw == first, "unsorted record order differs from the sequential path with %s threads" % th
+        ing.close()
+    LR.free_buf(q); LR.sd_destroy(d)
