@@ -23,14 +23,27 @@
 #include <unistd.h>
 #include <pthread.h>
 #include <sys/stat.h>
+#include <sys/mman.h>
 #include "ma_host.h"
+
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+/* Pre-fault the pages of [p, p+bytes) that lie entirely inside it, in the calling thread.  Fresh malloc memory costs
+ * one page fault per 4 KiB on first touch; with the faults interleaved into the emit loop that was 60 % of the
+ * whole ingest.  Populating each thread's slice up front lets the kernel do it in bulk; failure is harmless. */
+static void prefault(void *p, size_t bytes)
+{
+	uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)p + bytes) & ~(uintptr_t)4095;
+	if (e > a) (void)madvise((void*)a, e - a, MADV_POPULATE_WRITE);
+}
 
 /* large arrays are plain malloc (the returned hit array must be ordinary libc heap for the drop-in contract);
  * MADV_HUGEPAGE was tried and was slower on virtualised hosts (direct compaction in the fault path) */
 static void *big_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
 
 #define MT_MIN_BYTES (8u << 20)
-#define MT_MAX_THREADS 16
+#define MT_MAX_THREADS 64
 
 typedef struct { uint32_t q, t, qs, qe, ts, te, mlrev, bl; } lrec_t; /* parsed line with local name ids */
 typedef struct { const char *p; uint32_t l, len; } lname_t;          /* name bytes (in the file buffer), read length */
@@ -106,6 +119,7 @@ static void *phase1(void *arg)
 	c->first_bl_rec = UINT32_MAX;
 	c->m_rec = (c->end - c->beg) / 48 + 1024; /* PAF lines are rarely shorter than this: avoids regrowing in the common case */
 	c->rec = (lrec_t*)big_alloc(c->m_rec * sizeof(lrec_t));
+	prefault(c->rec, c->m_rec * sizeof(lrec_t));
 	while (p < end) {
 		const char *nl = (const char*)memchr(p, '\n', (size_t)(end - p)), *le = nl ? nl : end, *f[12];
 		uint32_t fl[12], nf = 0, ql, qs, qe, tl, ts, te, ml, rev;
@@ -155,6 +169,7 @@ static void *phase3(void *arg)
 	ma_hit_t *o = c->out + c->out_off;
 	size_t i;
 	uint32_t mx = 0;
+	prefault(o, c->n_out * sizeof(ma_hit_t));
 	for (i = 0; i < c->n_rec; ++i) {
 		const lrec_t *r = &c->rec[i];
 		uint32_t qid = c->l2g[r->q], tid = c->l2g[r->t];
@@ -178,6 +193,7 @@ static void *reader(void *arg)
 {
 	rd_t *r = (rd_t*)arg;
 	size_t off = r->beg;
+	prefault(r->buf + r->beg, r->end - r->beg);
 	while (off < r->end) {
 		ssize_t k = pread(r->fd, r->buf + off, r->end - off, (off_t)off);
 		if (k <= 0) break;
@@ -190,6 +206,7 @@ int ma_ingest_threads(void)
 {
 	const char *s = getenv("MA_THREADS");
 	long n = s ? atol(s) : sysconf(_SC_NPROCESSORS_ONLN);
+	if (!s && n > 16) n = 16; /* the sequential id-merge grows with the chunk count: 16 is the measured sweet spot (EPYC 9575F) */
 	if (n < 1) n = 1;
 	if (n > MT_MAX_THREADS) n = MT_MAX_THREADS;
 	return (int)n;
