@@ -54,6 +54,15 @@ int mahip_sub_merge(mahip_ctx_t *c);
  * seq_del: optional host array [n_seq] of reads already flagged d->seq[i].del. */
 int mahip_hits_contained(mahip_ctx_t *c, const ma_opt_t *opt, const uint8_t *seq_del, uint32_t *n_seq_new, size_t *n_live);
 
+/* Fused forms used by the resident pipeline (same results, fewer sweeps over the hits):
+ *   cutflt_sub    : hit.c:162-216 (ma_hit_cut against cut_slot, then ma_hit_flt) applied inside the coverage pass that
+ *                   computes out_slot (hit.c:109-160) -- the hits are already in registers there;
+ *   cut_contained : the second ma_hit_cut (against cut_slot) + the flag pass and the squeeze MAP of ma_hit_contained
+ *                   (against slot 0); the squeeze of the hit array itself is postponed to ma_sg_gen / hits_download. */
+int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span, int max_hang, int min_ovlp, int min_dp, float min_iden, int end_clip,
+                          int out_slot, size_t *n_cut, size_t *n_flt, float *cov, size_t *n_remained);
+int mahip_hits_cut_contained(mahip_ctx_t *c, int cut_slot, int min_span, const ma_opt_t *opt, size_t *n_cut, uint32_t *n_seq_new);
+
 int mahip_sub_upload(mahip_ctx_t *c, int slot, const ma_sub_t *sub, size_t n_sub);
 int mahip_sub_download(mahip_ctx_t *c, int slot, ma_sub_t *sub, int squeezed); /* squeezed: compacted by the contained map */
 int mahip_seqdel_download(mahip_ctx_t *c, uint8_t *del);                       /* per old read id, after contained */

@@ -60,12 +60,13 @@ __global__ __launch_bounds__(256) void k_sg_seq(const uint2 *__restrict__ sub, c
 // asm.c:18-35 per hit: candidate arc at the hit's own slot (push order = hit order), seq.del side effects
 __global__ __launch_bounds__(256) void k_sg_arcs(HitColsG h, size_t n, const uint32_t *__restrict__ slen, uint8_t *__restrict__ sdel,
                                                   int max_hang, float int_frac, int min_ovlp, ArcCols a, uint32_t *__restrict__ keep,
-                                                  unsigned long long *__restrict__ ctr)
-{
-	uint32_t mx = 0;
+                                                  unsigned long long *__restrict__ ctr, const uint8_t *__restrict__ lazy_del)
+{ // lazy_del != nullptr: the squeeze of ma_hit_contained was postponed; hits with a dropped endpoint are skipped here
+	uint32_t mx = 0, n_live = 0;
 	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
 		int k = 0;
-		if (!(h.bl[i] & DEAD)) {
+		if (!(h.bl[i] & DEAD) && !(lazy_del && (lazy_del[h.qid[i]] || lazy_del[h.tn[i]]))) {
+			++n_live;
 			uint32_t q = h.qid[i], t = h.tn[i], qs = h.qs[i], qe = h.qe[i], ts = h.ts[i], te = h.te[i];
 			int rev = h.ml[i] >> 31;
 			mc_arc_t x;
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256) void k_sg_arcs(HitColsG h, size_t n, const uin
 		keep[i] = k;
 	}
 	blk_max_u64(&ctr[CT_MAXLEN], mx);
+	blk_add_u64(&ctr[CT_LIVE], n_live);
 }
 
 // asg.c:57-70 asg_arc_rm predicate: arc survives unless del or an endpoint read is deleted
@@ -384,7 +386,8 @@ extern "C" int mahip_sg_flags(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, 
 	if (n) {
 		ProfScope ps(c, "k_sg_arcs", 64.0 * (double)c->n_live); // ma_sg_gen 32 r + 16 look-ups + 16 w
 		hipLaunchKernelGGL(k_sg_arcs, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, gcols_of(c), n, (const uint32_t*)P<uint32_t>(c->slen), P<uint8_t>(c->sdel),
-		                   opt->max_hang, opt->int_frac, opt->min_ovlp, arcs_of(c, 0), P<uint32_t>(c->keep), ctr);
+		                   opt->max_hang, opt->int_frac, opt->min_ovlp, arcs_of(c, 0), P<uint32_t>(c->keep), ctr,
+		                   c->lazy_squeeze ? (const uint8_t*)P<uint8_t>(c->r_del) : (const uint8_t*)nullptr);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -395,7 +398,8 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 	HIPCHK(hipSetDevice(c->dev));
 	size_t n = c->n_hits;
 	uint32_t R = c->n_seq;
-	CHK(arc_cleanup(c, n, 1, -1)); // fetches the counters: CT_MAXLEN was set by k_sg_arcs
+	CHK(arc_cleanup(c, n, 1, -1)); // fetches the counters: CT_MAXLEN / CT_LIVE were set by k_sg_arcs
+	c->n_live = (size_t)c->h_ctr[CT_LIVE];
 	if (c->n_arc > 1) {
 		size_t m = c->n_arc;
 		for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }

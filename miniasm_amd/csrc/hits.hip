@@ -142,20 +142,55 @@ __device__ __forceinline__ void wave_sort_regs(uint32_t (&x)[ITEMS], unsigned la
 	}
 }
 
+// Optional fusion (resident pipeline): while a hit sits in registers on its way into the coverage events of the
+// SECOND pass, first apply ma_hit_cut against the first-pass intervals (hit.c:162-193) and ma_hit_flt
+// (hit.c:195-216) -- the two streaming passes the reference runs between its two ma_hit_sub calls.
+struct SubFuse {
+	const uint2 *cut_sub; // intervals to cut against (and to classify with)
+	int min_span, max_hang, min_ovlp;
+	uint8_t *r_live;      // query groups that keep a hit after the filter (for the coverage estimate)
+};
+struct SubAcc { uint32_t n_cut, n_flt; uint64_t dp; }; // per-lane partial counters of the fused passes
+
+// cut + filter of one live hit held in registers; returns 0 if the hit dies (its dead bit is written), else 1
+__device__ __forceinline__ int fuse_cut_flt(const HitCols &c, uint32_t i, const SubFuse &f, uint32_t q, uint2 rq, uint32_t tn,
+                                            uint32_t &qs, uint32_t &qe, uint32_t ml, uint32_t bl, SubAcc &acc)
+{
+	uint2 rt = f.cut_sub[tn];
+	uint32_t ts = c.ts[i], te = c.te[i];
+	int keep = 0;
+	if (!(rq.x & DEAD) && !(rt.x & DEAD) && mc_cut(&qs, &qe, &ts, &te, ml >> 31, (int32_t)rq.x, rq.y, (int32_t)rt.x, rt.y, f.min_span)) {
+		mc_arc_t a;
+		uint32_t ql = rq.y - (rq.x & 0x7fffffffu), tl = rt.y - (rt.x & 0x7fffffffu);
+		++acc.n_cut;
+		int r = mc_hit2arc(q, qs, qe, tn, ts, te, ml >> 31, (int)ql, (int)tl, f.max_hang, .5f, f.min_ovlp, &a);
+		if (r >= 0 || r == MC_HT_QCONT || r == MC_HT_TCONT) {
+			keep = 1; ++acc.n_flt;
+			acc.dp += r >= 0 ? (uint32_t)r : r == MC_HT_QCONT ? ql : tl;
+			f.r_live[q] = 1;
+			c.qs[i] = qs; c.qe[i] = qe; c.ts[i] = ts; c.te[i] = te;
+		}
+	}
+	if (!keep) c.bl[i] = bl | DEAD;
+	return keep;
+}
+
 // one read in registers; returns 1 if the read keeps an interval (value identical on all lanes)
-template <int ITEMS>
+template <int ITEMS, bool FUSE>
 __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q, uint32_t beg, uint32_t end, int min_dp, float min_iden,
-                                                   int end_clip, uint2 *__restrict__ sub, unsigned lane)
+                                                   int end_clip, uint2 *__restrict__ sub, unsigned lane, const SubFuse &f, SubAcc &acc)
 {
 	uint32_t x[ITEMS];
 	int live_any = 0, ev_any = 0;
+	uint2 rq = make_uint2(0, 0);
+	if (FUSE) rq = f.cut_sub[q];
 #pragma unroll
 	for (int h = 0; h < ITEMS / 2; ++h) {
 		uint32_t i = beg + h * 64 + lane;
 		x[2 * h] = x[2 * h + 1] = EV_PAD;
 		if (i < end) {
 			uint32_t bl = c.bl[i], ml = c.ml[i], qs = c.qs[i], qe = c.qe[i], tn = c.tn[i], es, ee; // independent loads
-			if (!(bl & DEAD)) {
+			if (!(bl & DEAD) && (!FUSE || fuse_cut_flt(c, i, f, q, rq, tn, qs, qe, ml, bl, acc))) {
 				live_any = 1;
 				if (mc_sub_ok(q, qs, qe, tn, (int32_t)(ml & 0x7fffffffu), (int32_t)bl, min_iden, end_clip, &es, &ee)) x[2 * h] = es, x[2 * h + 1] = ee, ev_any = 1;
 			}
@@ -210,22 +245,25 @@ __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q,
 	return 1;
 }
 
+template <bool FUSE>
 __global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
                                                   int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
-                                                  uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr)
+                                                  uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr, SubFuse f)
 {
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t n_kept = 0;
+	SubAcc acc = {0, 0, 0};
 	for (uint32_t q = blockIdx.x * 4 + wave; q < n_seq; q += gridDim.x * 4) {
 		uint32_t beg = goff[q], end = goff[q + 1], H = end - beg;
 		if (H == 0) { if (lane == 0) sub[q] = make_uint2(0, 0); continue; } // never a query: calloc'ed zero (hit.c:115)
-		if (H <= 64) n_kept += sub_group_regs<2>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane);
-		else if (H <= 128) n_kept += sub_group_regs<4>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane);
-		else if (H <= 256) n_kept += sub_group_regs<8>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane);
-		else if (H <= SUB_REG_MAX_HITS) n_kept += sub_group_regs<16>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane);
+		if (H <= 64) n_kept += sub_group_regs<2, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc);
+		else if (H <= 128) n_kept += sub_group_regs<4, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc);
+		else if (H <= 256) n_kept += sub_group_regs<8, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc);
+		else if (H <= SUB_REG_MAX_HITS) n_kept += sub_group_regs<16, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc);
 		else if (lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF], 1ull); ovf[k] = q; } // tier B
 	}
 	blk_add_u64(&ctr[CT_REMAIN], lane == 0 ? n_kept : 0);
+	if (FUSE) { blk_add_u64(&ctr[CT_CUT], acc.n_cut); blk_add_u64(&ctr[CT_LIVE], acc.n_flt); blk_add_u64(&ctr[CT_TOTDP], acc.dp); }
 }
 
 // sweep over sorted events held in memory (tier B): ballot prefix counts per 64-event chunk, run starts by rank
@@ -263,23 +301,29 @@ __device__ __forceinline__ uint64_t sub_sweep(const uint32_t *ev, uint32_t *up, 
 
 // tier B: one 256-thread block per oversized read; events (and run starts) in LDS when they fit, else in global
 // scratch (ev at 2*goff[q], up at goff[q]: disjoint per read by construction)
+template <bool FUSE>
 __global__ __launch_bounds__(256) void k_hit_sub_big(HitCols c, const uint32_t *__restrict__ goff, const uint32_t *__restrict__ ovf, uint32_t n_ovf,
                                                       int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
-                                                      uint32_t *__restrict__ gev, uint32_t *__restrict__ gup, unsigned long long *__restrict__ ctr)
+                                                      uint32_t *__restrict__ gev, uint32_t *__restrict__ gup, unsigned long long *__restrict__ ctr, SubFuse f)
 {
 	__shared__ uint32_t s_ev[SUB_LDS_EVENTS], s_up[SUB_LDS_EVENTS / 2];
 	__shared__ uint32_t s_n, s_live;
+	SubAcc acc = {0, 0, 0};
 	for (uint32_t k = blockIdx.x; k < n_ovf; k += gridDim.x) {
 		uint32_t q = ovf[k], beg = goff[q], end = goff[q + 1];
 		const bool in_lds = 2 * (end - beg) <= SUB_LDS_EVENTS;
 		uint32_t *ev = in_lds ? s_ev : gev + 2 * (size_t)beg, *up = in_lds ? s_up : gup + beg;
 		if (threadIdx.x == 0) s_n = 0, s_live = 0;
 		__syncthreads();
+		uint2 rq = make_uint2(0, 0);
+		if (FUSE) rq = f.cut_sub[q];
 		for (uint32_t i = beg + threadIdx.x; i < end; i += 256) {
 			uint32_t bl = c.bl[i], es, ee;
 			if (bl & DEAD) continue;
+			uint32_t qs = c.qs[i], qe = c.qe[i], tn = c.tn[i], ml = c.ml[i];
+			if (FUSE && !fuse_cut_flt(c, i, f, q, rq, tn, qs, qe, ml, bl, acc)) continue;
 			s_live = 1;
-			if (mc_sub_ok(q, c.qs[i], c.qe[i], c.tn[i], (int32_t)(c.ml[i] & 0x7fffffffu), (int32_t)bl, min_iden, end_clip, &es, &ee)) {
+			if (mc_sub_ok(q, qs, qe, tn, (int32_t)(ml & 0x7fffffffu), (int32_t)bl, min_iden, end_clip, &es, &ee)) {
 				uint32_t p = atomicAdd(&s_n, 2u); // any order: sorted next, equal values are indistinguishable
 				ev[p] = es, ev[p + 1] = ee;
 			}
@@ -301,6 +345,7 @@ __global__ __launch_bounds__(256) void k_hit_sub_big(HitCols c, const uint32_t *
 		}
 		__syncthreads();
 	}
+	if (FUSE) { blk_add_u64(&ctr[CT_CUT], acc.n_cut); blk_add_u64(&ctr[CT_LIVE], acc.n_flt); blk_add_u64(&ctr[CT_TOTDP], acc.dp); }
 }
 
 // ------------------------------------------------------------------------------------------------ ma_hit_cut
@@ -394,6 +439,33 @@ __global__ __launch_bounds__(256) void k_hit_contained(HitCols c, size_t n, cons
 	}
 }
 
+// resident pipeline: the second ma_hit_cut (against cut_sub) and the flag pass of ma_hit_contained (against the merged
+// intervals cls_sub) in one sweep over the hits
+__global__ __launch_bounds__(256) void k_hit_cut_contained(HitCols c, size_t n, const uint2 *__restrict__ cut_sub, int min_span,
+                                                            const uint2 *__restrict__ cls_sub, int max_hang, float int_frac, int min_ovlp,
+                                                            uint8_t *__restrict__ r_cont, uint8_t *__restrict__ r_used, unsigned long long *__restrict__ ctr)
+{
+	uint32_t n_keep = 0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+		uint32_t bl = c.bl[i];
+		if (bl & DEAD) continue;
+		uint32_t q = c.qid[i], t = c.tn[i], ml = c.ml[i];
+		uint2 rq = cut_sub[q], rt = cut_sub[t];
+		uint32_t qs = c.qs[i], qe = c.qe[i], ts = c.ts[i], te = c.te[i];
+		if (!(rq.x & DEAD) && !(rt.x & DEAD) && mc_cut(&qs, &qe, &ts, &te, ml >> 31, (int32_t)rq.x, rq.y, (int32_t)rt.x, rt.y, min_span)) {
+			uint2 sq = cls_sub[q], st = cls_sub[t];
+			mc_arc_t a;
+			c.qs[i] = qs; c.qe[i] = qe; c.ts[i] = ts; c.te[i] = te;
+			++n_keep;
+			int r = mc_hit2arc(q, qs, qe, t, ts, te, ml >> 31, (int)(sq.y - (sq.x & 0x7fffffffu)), (int)(st.y - (st.x & 0x7fffffffu)), max_hang, int_frac, min_ovlp, &a);
+			if (r == MC_HT_QCONT) r_cont[q] = 1;
+			else if (r == MC_HT_TCONT) r_cont[t] = 1;
+			r_used[q] = 1; r_used[t] = 1;
+		} else c.bl[i] = bl | DEAD;
+	}
+	blk_add_u64(&ctr[CT_LIVE], n_keep);
+}
+
 __global__ __launch_bounds__(256) void k_read_del(const uint2 *__restrict__ sub, const uint8_t *__restrict__ r_cont, const uint8_t *__restrict__ r_used,
                                                    uint8_t *__restrict__ r_del, uint32_t *__restrict__ keep, uint32_t n_seq)
 {
@@ -485,6 +557,7 @@ static int hits_common_setup(mahip_ctx *c, size_t n, uint32_t n_seq)
 	c->n_hits = n; c->n_live = n; c->n_seq = n_seq; c->n_seq_new = n_seq;
 	c->soa_ready = false; c->has_map = false; c->graph_ready = false;
 	c->hint_max_qs = 0; // hints describe one upload: set them again after every upload/adopt
+	c->lazy_squeeze = false;
 	CHK(reserve_read_arrays(c));
 	for (int k = 0; k < 8; ++k) CHK(dev_reserve(c, c->col[k], (n + 1) * 4));
 	return 0;
@@ -604,10 +677,11 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 	CHK(dev_reserve(c, c->ovf, ((size_t)R + 1) * 4));
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	uint2 *sub = P<uint2>(c->sub[slot]);
+	SubFuse nofuse = {nullptr, 0, 0, 0, nullptr};
 	if (R) {
 		ProfScope ps(c, "k_hit_sub", 24.0 * (double)c->n_hits + 8.0 * R);
-		hipLaunchKernelGGL(k_hit_sub, dim3(grid_for(R, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr);
+		hipLaunchKernelGGL(k_hit_sub<false>, dim3(grid_for(R, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		                   sub, P<uint32_t>(c->ovf), ctr, nofuse);
 	}
 	CHK(ctr_fetch(c));
 	uint32_t n_ovf = (uint32_t)c->h_ctr[CT_OVF];
@@ -615,12 +689,88 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 		CHK(dev_reserve(c, c->big0, (2 * c->n_hits + 8) * 4));
 		CHK(dev_reserve(c, c->big1, (c->n_hits + 8) * 4));
 		ProfScope ps(c, "k_hit_sub_big", 0);
-		hipLaunchKernelGGL(k_hit_sub_big, dim3(n_ovf < 1024 ? n_ovf : 1024), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), (const uint32_t*)P<uint32_t>(c->ovf), n_ovf,
-		                   min_dp, min_iden, end_clip, sub, P<uint32_t>(c->big0), P<uint32_t>(c->big1), ctr);
+		hipLaunchKernelGGL(k_hit_sub_big<false>, dim3(n_ovf < 1024 ? n_ovf : 1024), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), (const uint32_t*)P<uint32_t>(c->ovf), n_ovf,
+		                   min_dp, min_iden, end_clip, sub, P<uint32_t>(c->big0), P<uint32_t>(c->big1), ctr, nofuse);
 		CHK(ctr_fetch(c));
 	}
 	HIPCHK(hipGetLastError());
 	if (n_remained) *n_remained = (size_t)c->h_ctr[CT_REMAIN];
+	return 0;
+}
+
+// resident pipeline: hit.c:162-216 (cut against cut_slot, then flt) folded into the coverage pass that writes out_slot
+extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span, int max_hang, int min_ovlp, int min_dp, float min_iden, int end_clip,
+                                     int out_slot, size_t *n_cut, size_t *n_flt, float *cov, size_t *n_remained)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->soa_ready) { mahip_set_error("mahip_hits_cutflt_sub: hits not indexed"); return -1; }
+	HitCols h = cols_of(c);
+	uint32_t R = c->n_seq;
+	CHK(ctr_zero(c));
+	CHK(dev_reserve(c, c->ovf, ((size_t)R + 1) * 4));
+	HIPCHK(hipMemsetAsync(c->r_live.p, 0, R, c->st));
+	unsigned long long *ctr = P<unsigned long long>(c->ctr);
+	uint2 *sub = P<uint2>(c->sub[out_slot]);
+	SubFuse f = {(const uint2*)P<uint2>(c->sub[cut_slot]), min_span, max_hang, min_ovlp, P<uint8_t>(c->r_live)};
+	if (R) {
+		ProfScope ps(c, "k_hit_sub<cut+flt>", (80.0 + 80.0 + 48.0) * (double)c->n_hits + 8.0 * R); // cut 80 + flt 80 + sub 48 B per hit
+		hipLaunchKernelGGL(k_hit_sub<true>, dim3(grid_for(R, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		                   sub, P<uint32_t>(c->ovf), ctr, f);
+	}
+	CHK(ctr_fetch(c));
+	uint32_t n_ovf = (uint32_t)c->h_ctr[CT_OVF];
+	if (n_ovf) {
+		CHK(dev_reserve(c, c->big0, (2 * c->n_hits + 8) * 4));
+		CHK(dev_reserve(c, c->big1, (c->n_hits + 8) * 4));
+		ProfScope ps(c, "k_hit_sub_big", 0);
+		hipLaunchKernelGGL(k_hit_sub_big<true>, dim3(n_ovf < 1024 ? n_ovf : 1024), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), (const uint32_t*)P<uint32_t>(c->ovf), n_ovf,
+		                   min_dp, min_iden, end_clip, sub, P<uint32_t>(c->big0), P<uint32_t>(c->big1), ctr, f);
+	}
+	if (R) hipLaunchKernelGGL(k_flt_totlen, dim3(grid_for(R, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, f.cut_sub, (const uint8_t*)P<uint8_t>(c->r_live), R, ctr);
+	CHK(ctr_fetch(c));
+	HIPCHK(hipGetLastError());
+	c->n_live = (size_t)c->h_ctr[CT_LIVE];
+	if (n_cut) *n_cut = (size_t)c->h_ctr[CT_CUT];
+	if (n_flt) *n_flt = c->n_live;
+	if (cov) *cov = (float)((double)c->h_ctr[CT_TOTDP] / (double)c->h_ctr[CT_TOTLEN]);
+	if (n_remained) *n_remained = (size_t)c->h_ctr[CT_REMAIN];
+	return 0;
+}
+
+// resident pipeline: second ma_hit_cut (against cut_slot) + the flag pass of ma_hit_contained (against slot 0) in one sweep;
+// the squeeze of the hits is left to ma_sg_gen's pass (lazy), which is the next reader of the hits
+extern "C" int mahip_hits_cut_contained(mahip_ctx_t *c, int cut_slot, int min_span, const ma_opt_t *opt, size_t *n_cut, uint32_t *n_seq_new)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->soa_ready) { mahip_set_error("mahip_hits_cut_contained: hits not indexed"); return -1; }
+	size_t n = c->n_hits;
+	uint32_t R = c->n_seq;
+	CHK(ctr_zero(c));
+	CHK(dev_reserve(c, c->keep, ((size_t)R + 16) * 4));
+	HIPCHK(hipMemsetAsync(c->r_cont.p, 0, R, c->st));
+	HIPCHK(hipMemsetAsync(c->r_used.p, 0, R, c->st));
+	HIPCHK(hipMemsetAsync(c->r_del.p, 0, R, c->st));
+	unsigned long long *ctr = P<unsigned long long>(c->ctr);
+	if (n) {
+		ProfScope ps(c, "k_hit_cut_contained", (80.0 + 48.0) * (double)c->n_live);
+		hipLaunchKernelGGL(k_hit_cut_contained, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, cols_of(c), n, (const uint2*)P<uint2>(c->sub[cut_slot]), min_span,
+		                   (const uint2*)P<uint2>(c->sub[0]), opt->max_hang, opt->int_frac, opt->min_ovlp, P<uint8_t>(c->r_cont), P<uint8_t>(c->r_used), ctr);
+	}
+	uint32_t *d_tot = (uint32_t*)(ctr + CT_TOTAL);
+	if (R) {
+		hipLaunchKernelGGL(k_read_del, dim3(grid_for(R, 256)), dim3(256), 0, c->st, (const uint2*)P<uint2>(c->sub[0]), (const uint8_t*)P<uint8_t>(c->r_cont),
+		                   (const uint8_t*)P<uint8_t>(c->r_used), P<uint8_t>(c->r_del), P<uint32_t>(c->keep), R);
+		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), (uint32_t*)c->map.p, R, d_tot));
+		hipLaunchKernelGGL(k_map_fix, dim3(grid_for(R, 256)), dim3(256), 0, c->st, P<int32_t>(c->map), (const uint8_t*)P<uint8_t>(c->r_del), R, P<uint32_t>(c->surv));
+	}
+	CHK(ctr_fetch(c));
+	HIPCHK(hipGetLastError());
+	c->n_live = (size_t)c->h_ctr[CT_LIVE];
+	c->n_seq_new = R ? (uint32_t)(c->h_ctr[CT_TOTAL] & 0xffffffffu) : 0;
+	c->has_map = true;
+	c->lazy_squeeze = true; // hits of dropped reads still carry no dead bit: readers must consult r_del
+	if (n_cut) *n_cut = c->n_live;
+	if (n_seq_new) *n_seq_new = c->n_seq_new;
 	return 0;
 }
 
@@ -714,6 +864,7 @@ extern "C" int mahip_hits_contained_finish(mahip_ctx_t *c, const uint8_t *seq_de
 	c->n_live = (size_t)c->h_ctr[CT_LIVE];
 	c->n_seq_new = R ? (uint32_t)(c->h_ctr[CT_TOTAL] & 0xffffffffu) : 0;
 	c->has_map = true;
+	c->lazy_squeeze = false;
 	if (n_seq_new) *n_seq_new = c->n_seq_new;
 	if (n_live) *n_live = c->n_live;
 	return 0;
@@ -818,6 +969,13 @@ extern "C" int mahip_hits_download(mahip_ctx_t *c, ma_hit_t *out, size_t *n_out)
 	HIPCHK(hipSetDevice(c->dev));
 	if (!c->soa_ready) { mahip_set_error("mahip_hits_download: hits not indexed"); return -1; }
 	size_t n = c->n_hits;
+	if (c->lazy_squeeze && n) { // the resident pipeline postponed the squeeze of the hits: do it now
+		CHK(ctr_zero(c));
+		hipLaunchKernelGGL(k_hit_squeeze, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, cols_of(c), n, (const uint8_t*)P<uint8_t>(c->r_del), P<unsigned long long>(c->ctr));
+		CHK(ctr_fetch(c));
+		c->n_live = (size_t)c->h_ctr[CT_LIVE];
+		c->lazy_squeeze = false;
+	}
 	if (n_out) *n_out = c->n_live;
 	if (n == 0 || c->n_live == 0) return 0;
 	HitCols h = cols_of(c);

@@ -45,7 +45,7 @@ struct mahip_ctx {
 	DevBuf r_cont, r_used, r_del, r_live; // u8 [n_seq]
 	DevBuf map;               // int32 [n_seq]  old -> new id, -1 dropped
 	DevBuf surv;              // u32 [n_seq_new] new -> old id
-	bool soa_ready = false, has_map = false;
+	bool soa_ready = false, has_map = false, lazy_squeeze = false;
 	uint32_t n_seq_new = 0;
 
 	// ---- arcs (dense SoA, two generations for compaction) ----
@@ -90,7 +90,7 @@ struct ProfScope {
 template <typename T> static inline T *P(DevBuf &b) { return (T*)b.p; }
 
 // counters (indices into ctx->ctr)
-enum { CT_LIVE = 0, CT_REMAIN, CT_TOTDP, CT_TOTLEN, CT_OVF, CT_NRED, CT_NMULTI, CT_NASYMM, CT_NSHORT, CT_MAXQID, CT_MAXQS, CT_TOTAL, CT_OVF2, CT_MAXLEN, CT_N };
+enum { CT_LIVE = 0, CT_REMAIN, CT_TOTDP, CT_TOTLEN, CT_OVF, CT_NRED, CT_NMULTI, CT_NASYMM, CT_NSHORT, CT_MAXQID, CT_MAXQS, CT_TOTAL, CT_OVF2, CT_MAXLEN, CT_CUT, CT_N };
 int ctr_zero(mahip_ctx *c);
 int ctr_fetch(mahip_ctx *c); // D2H + sync into c->h_ctr
 

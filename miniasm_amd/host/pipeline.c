@@ -54,7 +54,32 @@ int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 	float cov = 40.0f;
 	FILE *lg = MA_LOG;
 
+	const int graph_out = strcmp(outfmt, "ug") == 0 || strcmp(outfmt, "sg") == 0;
+	const int fused = !no_first && !no_second && stage >= 5 && graph_out && !getenv("MA_NO_FUSE");
+	size_t n_cont_hits = 0;
+
 	GPU(mahip_hits_sort(c)); /* hit.c:104 */
+	if (fused) {
+		/* Same passes, same log lines, fewer sweeps over the hits: the first ma_hit_cut + ma_hit_flt ride inside the second
+		 * coverage pass, the second ma_hit_cut rides with the flag pass of ma_hit_contained, and the squeeze of the hit
+		 * array is left to the pass that reads the hits next (ma_sg_gen). */
+		size_t n_cut = 0, n_flt = 0, n_rem2 = 0;
+		fprintf(lg, "[M::%s] ===> Step 2: 1-pass (crude) read selection <===\n", "main");
+		GPU(mahip_hits_sub(c, opt->min_dp, opt->min_iden, 0, 0, &n_rem));
+		if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)n_rem);
+		GPU(mahip_hits_cutflt_sub(c, 0, opt->min_span, (int)(opt->max_hang * 1.5), (int)(opt->min_ovlp * .5), opt->min_dp, opt->min_iden, opt->min_span / 2,
+		                          1, &n_cut, &n_flt, &cov, &n_rem2));
+		if (ma_verbose >= 3) {
+			fprintf(lg, "[M::%s::%s] %ld hits remain after cut\n", "ma_hit_cut", sys_timestamp(), (long)n_cut);
+			fprintf(lg, "[M::%s::%s] %ld hits remain after filtering; crude coverage after filtering: %.2f\n", "ma_hit_flt", sys_timestamp(), (long)n_flt, cov);
+		}
+		fprintf(lg, "[M::%s] ===> Step 3: 2-pass (fine) read selection <===\n", "main");
+		if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)n_rem2);
+		GPU(mahip_sub_merge(c)); /* only reads the two interval arrays: may run before the second cut */
+		GPU(mahip_hits_cut_contained(c, 1, opt->min_span, opt, &n_hits, &n_seq_new));
+		if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld hits remain after cut\n", "ma_hit_cut", sys_timestamp(), (long)n_hits);
+		have_sub = squeezed = 1;
+	} else {
 	if (!no_first) {
 		fprintf(lg, "[M::%s] ===> Step 2: 1-pass (crude) read selection <===\n", "main");
 		if (stage >= 2) {
@@ -86,11 +111,12 @@ int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 			if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %d sequences and %ld hits remain after containment removal\n", "ma_hit_contained", sys_timestamp(), n_seq_new, (long)n_hits);
 		}
 	}
+	}
 	st[0] = have_sub, st[1] = squeezed, st[2] = 0, st[3] = 0;
 	if (strcmp(outfmt, "ug") == 0 || strcmp(outfmt, "sg") == 0) {
 		uint32_t n_arc = 0, *len = 0, r;
 		uint8_t *sdel = 0;
-		fprintf(lg, "[M::%s] ===> Step 4: graph cleaning <===\n", "main");
+		if (!fused) fprintf(lg, "[M::%s] ===> Step 4: graph cleaning <===\n", "main");
 		if (!have_sub) {
 			len = (uint32_t*)malloc((R ? R : 1) * 4);
 			for (r = 0; r < R; ++r) len[r] = d->seq[r].len;
@@ -101,6 +127,11 @@ int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 		}
 		GPU(mahip_sg_gen(c, opt, have_sub, len, sdel, &n_arc));
 		free(len); free(sdel);
+		if (fused) { /* the hit count after the (postponed) squeeze is known now; keep the reference's line order */
+			n_cont_hits = mahip_hits_live(c);
+			if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %d sequences and %ld hits remain after containment removal\n", "ma_hit_contained", sys_timestamp(), n_seq_new, (long)n_cont_hits);
+			fprintf(lg, "[M::%s] ===> Step 4: graph cleaning <===\n", "main");
+		}
 		fprintf(lg, "[M::%s] read %d arcs\n", "ma_sg_gen", n_arc);
 		if (stage >= 6) {
 			fprintf(lg, "[M::%s] ===> Step 4.1: transitive reduction <===\n", "main");
