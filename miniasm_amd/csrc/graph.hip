@@ -146,26 +146,42 @@ __device__ __forceinline__ int tr_find(const uint32_t *hk, uint32_t x, uint32_t 
 	}
 }
 
+// One wave per vertex.  Two instantiations split the vertices by out-degree so that the common case (<= 128 arcs)
+// runs with a small LDS footprint at full occupancy: SMALL handles 1..128 arcs and also prefetches the CSR entries of
+// all neighbours (one coalesced gather instead of one dependent load per expansion); !SMALL handles 129..TR_CAP arcs
+// and sends larger vertices to the block-per-vertex tier.
+//
+// The reference walks v's arcs in order and expands neighbour i only if mark[target_i] is still 1 (asg.c:168).  Marks
+// only ever go 1 -> 2, so "the next arc to expand" is simply the lowest not-yet-passed arc whose target is still
+// marked 1 NOW: each lane watches the mark of its own arc and a ballot finds that arc -- the serial walk shrinks from
+// one step per arc to one step per expansion (about one per vertex on clean data).
+template <int CAP, int HASH, bool SMALL>
 __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ av, const uint32_t *__restrict__ alen, uint32_t *__restrict__ aol,
                                                     const unsigned long long *__restrict__ idx, const uint8_t *__restrict__ sdel, uint32_t v_beg, uint32_t n_vtx,
                                                     uint32_t fuzz, uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr)
 { // processes the vertices [v_beg, n_vtx): the whole graph on one GPU, a rank's own read range in the sharded mode
-	__shared__ uint32_t s_v[4][TR_CAP], s_l[4][TR_CAP], s_hk[4][TR_HASH], s_hm[4][TR_HASH];
+	__shared__ uint32_t s_v[4][CAP], s_l[4][CAP], s_slot[4][CAP], s_hk[4][HASH], s_hm[4][HASH];
+	__shared__ uint32_t s_ws[4][SMALL ? CAP : 1], s_nw[4][SMALL ? CAP : 1];
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	uint32_t *lv = s_v[wave], *ll = s_l[wave], *hk = s_hk[wave], *hm = s_hm[wave];
+	uint32_t *lv = s_v[wave], *ll = s_l[wave], *slot = s_slot[wave], *hk = s_hk[wave], *hm = s_hm[wave];
 	uint32_t n_red = 0;
 	for (uint32_t v = v_beg + blockIdx.x * 4 + wave; v < n_vtx; v += gridDim.x * 4) {
 		unsigned long long x = idx[v];
 		uint32_t st = (uint32_t)(x >> 32), nv = (uint32_t)x;
 		if (nv == 0) continue;
+		if (SMALL ? nv > (uint32_t)CAP : nv <= 128u) continue; // the other instantiation's vertices
 		if (sdel[v >> 1]) { // asg.c:158-161
 			for (uint32_t i = lane; i < nv; i += 64) aol[st + i] |= ADEL, ++n_red;
 			continue;
 		}
-		if (nv > TR_CAP) { if (lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF2], 1ull); ovf[k] = v; } continue; }
+		if (nv > (uint32_t)CAP) { if (lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF2], 1ull); ovf[k] = v; } continue; }
 		uint32_t hbits = 6; while ((1u << hbits) < 2 * nv) ++hbits;
 		uint32_t hsize = 1u << hbits, hmask = hsize - 1;
-		for (uint32_t i = lane; i < nv; i += 64) lv[i] = av[st + i], ll[i] = alen[st + i];
+		for (uint32_t i = lane; i < nv; i += 64) {
+			uint32_t w = av[st + i];
+			lv[i] = w, ll[i] = alen[st + i];
+			if (SMALL) { unsigned long long xw = idx[w]; s_ws[wave][i] = (uint32_t)(xw >> 32); s_nw[wave][i] = (uint32_t)xw; }
+		}
 		// hm[slot] = (index of the FIRST arc to this target) << 2 | mark
 		for (uint32_t s = lane; s < hsize; s += 64) hk[s] = TR_EMPTY, hm[s] = 0xffffffffu;
 		wv_sync();
@@ -173,37 +189,45 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 			uint32_t key = lv[i], s = tr_hash(key, hbits);
 			for (;;) {
 				uint32_t old = atomicCAS(&hk[s], TR_EMPTY, key);
-				if (old == TR_EMPTY || old == key) { atomicMin(&hm[s], i << 2 | 1u); break; }
+				if (old == TR_EMPTY || old == key) { atomicMin(&hm[s], i << 2 | 1u); slot[i] = s; break; }
 				s = (s + 1) & hmask;
 			}
 		}
 		wv_sync();
-		uint32_t L = ll[nv - 1] + fuzz; // asg.c:163
-		for (uint32_t i = 0; i < nv; ++i) { // sequential over v's arcs: the skip below is order dependent (asg.c:168)
-			uint32_t w = lv[i], li = ll[i];
-			int sw = tr_find(hk, w, hbits);
-			if ((hm[sw] & 3u) != 1) continue;
-			unsigned long long xw = idx[w];
-			uint32_t ws = (uint32_t)(xw >> 32), nw = (uint32_t)xw;
-			for (uint32_t j0 = 0; j0 < nw; j0 += 64) { // lanes over w's arcs; sorted by len => the loop of asg.c:169 is a prefix
-				uint32_t j = j0 + lane;
-				int ok = j < nw;
-				uint32_t lx = ok ? alen[ws + j] : 0;
-				int cond = ok && lx + li <= L;
-				uint64_t fail = wv_ballot(ok && !cond);
-				if (fail) cond = cond && lane < (unsigned)(__ffsll((long long)fail) - 1);
-				if (cond) {
-					int sx = tr_find(hk, av[ws + j], hbits);
-					if (sx >= 0) hm[sx] = (hm[sx] & ~3u) | 2u; // every writer stores the same word
+		const uint32_t L = ll[nv - 1] + fuzz; // asg.c:163
+		for (uint32_t base = 0; base < nv; base += 64) {
+			const uint32_t i = base + lane;
+			const uint32_t myslot = i < nv ? slot[i] : 0;
+			uint64_t passed = 0; // lanes of this chunk the walk has gone past
+			for (;;) {
+				uint64_t cand = wv_ballot(i < nv && (hm[myslot] & 3u) == 1u) & ~passed;
+				if (!cand) break;
+				const unsigned l0 = (unsigned)(__ffsll((long long)cand) - 1);
+				passed |= l0 == 63 ? ~0ull : ((2ull << l0) - 1ull);
+				const uint32_t i0 = base + l0, li = ll[i0];
+				uint32_t ws, nw;
+				if (SMALL) ws = s_ws[wave][i0], nw = s_nw[wave][i0];
+				else { unsigned long long xw = idx[lv[i0]]; ws = (uint32_t)(xw >> 32); nw = (uint32_t)xw; }
+				for (uint32_t j0 = 0; j0 < nw; j0 += 64) { // lanes over w's arcs; sorted by len => the loop of asg.c:169 is a prefix
+					uint32_t j = j0 + lane;
+					int ok = j < nw;
+					uint32_t lx = ok ? alen[ws + j] : 0;
+					int cond = ok && lx + li <= L;
+					uint64_t fail = wv_ballot(ok && !cond);
+					if (fail) cond = cond && lane < (unsigned)(__ffsll((long long)fail) - 1);
+					if (cond) {
+						int sx = tr_find(hk, av[ws + j], hbits);
+						if (sx >= 0) hm[sx] = (hm[sx] & ~3u) | 2u; // every writer stores the same word
+					}
+					if (fail) break;
 				}
-				if (fail) break;
+				wv_sync();
 			}
-			wv_sync();
 		}
 		// asg.c:181-184: the sweep resets mark[target] at the first arc to a target, so of several arcs to one
 		// reduced target (multi-arcs are still present here) only the first is deleted
 		for (uint32_t i = lane; i < nv; i += 64)
-			if (hm[tr_find(hk, lv[i], hbits)] == (i << 2 | 2u)) aol[st + i] |= ADEL, ++n_red;
+			if (hm[slot[i]] == (i << 2 | 2u)) aol[st + i] |= ADEL, ++n_red;
 		wv_sync();
 	}
 	blk_add_u64(&ctr[CT_NRED], n_red);
@@ -535,7 +559,9 @@ extern "C" int mahip_asg_del_trans_range(mahip_ctx_t *c, int fuzz, uint32_t v_be
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	if (v_end > v_beg && c->n_arc) {
 		ProfScope ps(c, "k_asg_trans", 32.0 * (double)c->n_arc); // 16*(A+I)/A per arc, I ~ A on clean data
-		hipLaunchKernelGGL(k_asg_trans, dim3(grid_for(v_end - v_beg, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
+		hipLaunchKernelGGL((k_asg_trans<128, 256, true>), dim3(grid_for(v_end - v_beg, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
+		                   (const unsigned long long*)P<unsigned long long>(c->idx), (const uint8_t*)P<uint8_t>(c->sdel), v_beg, v_end, (uint32_t)fuzz, P<uint32_t>(c->ovf), ctr);
+		hipLaunchKernelGGL((k_asg_trans<TR_CAP, TR_HASH, false>), dim3(grid_for(v_end - v_beg, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
 		                   (const unsigned long long*)P<unsigned long long>(c->idx), (const uint8_t*)P<uint8_t>(c->sdel), v_beg, v_end, (uint32_t)fuzz, P<uint32_t>(c->ovf), ctr);
 	}
 	CHK(ctr_fetch(c));
