@@ -84,6 +84,26 @@ def cpu_baseline(args, workdir):
             "sample": "%d-line sample; oracle/ma_oracle.c (sort .. transitive reduction only, no cleaners/GFA), 1 thread" % n_lines}
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC run of this same workload (profiles/, made by
+    `tools/gpu_round.sh pmc`: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM
+    section prescribes for gfx950 -- the doubling reproduces the known 640 MB read of k_hit_keys exactly).  PMC counters
+    cannot be read from inside this process, so the figure is only attached when the workload is the profiled one."""
+    if (args.model, args.reads, args.lines) != ("lognormal", 200000, 10000000):
+        return None
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_cfg2.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    base = kernel.split("<")[0]
+    hits = [v for k, v in d.items() if k.split("<")[0].replace("void ", "") == base]
+    if not hits:
+        return None
+    tot = sum((v["fetch_bytes_x2"] + v["write_bytes"]) * v["launches"] for v in hits) / max(sum(v["launches"] for v in hits), 1)
+    return round(tot)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,7 +248,7 @@ def main():
         dom = next((k for k in kernels if k["alg_GBs"]), None)
         if dom:
             roof = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["alg_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(dom["alg_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(dom["alg_GBs"] / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom["name"], args),
                     "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"]}
 
     cpu = None

@@ -156,7 +156,7 @@ asg_t *ma_sg_gen(const ma_opt_t *opt, const sdict_t *d, const ma_sub_t *sub, siz
                  const ma_hit_t *hit);                                                                         /* :70 ; HIP */
 void ma_sg_print(const asg_t *g, const sdict_t *d, const ma_sub_t *sub, FILE *fp);                             /* :71 */
 ma_ug_t *ma_ug_gen(asg_t *g);                                                                                  /* :72 */
-int ma_ug_seq(ma_ug_t *g, const sdict_t *d, const ma_sub_t *sub, const char *fn);                              /* :73 ; not on the PAF->GFA path: returns -1 */
+int ma_ug_seq(ma_ug_t *g, const sdict_t *d, const ma_sub_t *sub, const char *fn);                              /* :73 ; host: FASTA/FASTQ (gz) -> unitig strings */
 void ma_ug_print(const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, FILE *fp);                          /* :74 */
 void ma_ug_destroy(ma_ug_t *ug);                                                                               /* :75 */
 /* non-header externals of the reference's hit.c (hit.c:19,24) */

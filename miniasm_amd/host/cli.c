@@ -88,7 +88,7 @@ int main(int argc, char *argv[])
 	if (argc == optind) { usage(&opt, outfmt); return 1; }
 
 	sys_init();
-	if (fn_reads) ma_ug_seq(0, 0, 0, fn_reads); /* prints the "not part of this build" note */
+	ma_set_reads_file(fn_reads); /* -f: unitig sequences are stitched from this file before the GFA is written */
 	ma_pipeline_run(&opt, argv[optind], outfmt, stage, flags, stdout);
 
 	fprintf(stderr, "[M::%s] Version: %s (%s)\n", __func__, MA_VERSION, MA_BUILD);

@@ -13,12 +13,16 @@ extern "C" {
 extern FILE *ma_log_fp;
 #define MA_LOG (ma_log_fp ? ma_log_fp : stderr)
 void ma_set_log_path(const char *path);
+void ma_set_reads_file(const char *fn); /* reads FASTA/FASTQ for unitig sequences (-f), NULL = none */
 
 /* everything after ingest, hits resident in HBM (pipeline.c) */
 int ma_pipeline_device(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, FILE *out);
 /* its two halves: device passes (st[4] = have_sub, squeezed, n_reduced, graph built) and the host part */
 int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, uint32_t st[4]);
 int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, const uint32_t st[4], FILE *out);
+
+void ma_sd_reindex(sdict_t *d);    /* build the name index from seq[] (for dictionaries assembled by hand) */
+void ma_sd_drop_index(sdict_t *d);
 
 /* the process-wide GPU context of the per-symbol entry points; exits with an error if no GPU is usable */
 mahip_ctx_t *ma_gpu(void);

@@ -120,3 +120,21 @@ int32_t *sd_squeeze(sdict_t *d)
 	d->h = ix;
 	return map;
 }
+
+/* (re)build / drop the name index of a dictionary whose seq[] was filled by hand (the shallow survivor view of pipeline.c) */
+void ma_sd_reindex(sdict_t *d)
+{
+	uint32_t i, n_slot = 1024;
+	sd_index_t *ix;
+	ix_free((sd_index_t*)d->h);
+	while (n_slot < 2 * (uint64_t)d->n_seq + 16) n_slot <<= 1;
+	ix = ix_new(n_slot);
+	for (i = 0; i < d->n_seq; ++i) ix_insert_raw(ix, sd_hash_str(d->seq[i].name), i);
+	d->h = ix;
+}
+
+void ma_sd_drop_index(sdict_t *d)
+{
+	ix_free((sd_index_t*)d->h);
+	d->h = 0;
+}

@@ -18,6 +18,8 @@
 #define GPU(call) do { if ((call) != 0) ma_gpu_fail(__func__); } while (0)
 
 FILE *ma_log_fp = 0;
+static const char *g_reads_fn = 0;
+void ma_set_reads_file(const char *fn) { g_reads_fn = fn; } /* -f of the CLI (reference main.c:193) */
 
 void ma_set_log_path(const char *path)
 {
@@ -227,6 +229,11 @@ int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 		if (strcmp(outfmt, "ug") == 0) {
 			fprintf(lg, "[M::%s] ===> Step 5: generating unitigs <===\n", "main");
 			ug = ma_ug_gen(sg);
+			if (g_reads_fn) { /* main.c:193; the survivor view needs a name index of its own for sd_get */
+				if (squeezed) ma_sd_reindex(&view);
+				ma_ug_seq(ug, squeezed ? &view : d, sub, g_reads_fn);
+				if (squeezed) ma_sd_drop_index(&view);
+			}
 			TSTAMP(4);
 			ma_ug_print(ug, &view, sub, out);
 		} else ma_sg_print(sg, &view, sub, out);

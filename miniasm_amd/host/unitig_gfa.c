@@ -247,9 +247,132 @@ void ma_ug_print(const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, FILE 
 	ob_flush(&o);
 }
 
+/* ---------------------------------------------------------------------------------------------- unitig sequences
+ * reference asm.c:216-290 (ma_ug_seq): every read placed on a unitig contributes the first `len` bases of its kept
+ * interval (forward) or the reverse complement of its last `len` bases (reverse).  FASTA/FASTQ, plain or gzip, read
+ * with the record rules of the reference's reader (kseq.h:172-247): a record starts at a line beginning with '>' or
+ * '@', the name ends at the first white space, sequence lines run until a line starting with '>', '@' or '+', a '+'
+ * line is followed by as many quality characters as there are bases. */
+#include <zlib.h>
+#include <ctype.h>
+#include <assert.h>
+
+typedef struct { gzFile fp; unsigned char *buf; int beg, end, eof; } fq_stream_t;
+#define FQ_BUF (1 << 18)
+
+static inline int fq_getc(fq_stream_t *f)
+{
+	if (f->beg >= f->end) {
+		if (f->eof) return -1;
+		f->beg = 0; f->end = gzread(f->fp, f->buf, FQ_BUF);
+		if (f->end < FQ_BUF) f->eof = 1;
+		if (f->end <= 0) { f->end = 0; return -1; }
+	}
+	return f->buf[f->beg++];
+}
+
+typedef struct { char *s; size_t l, m; } fq_str_t;
+static inline void fq_push(fq_str_t *t, int c)
+{
+	if (t->l + 2 > t->m) { t->m = t->m ? t->m << 1 : 256; t->s = (char*)realloc(t->s, t->m); }
+	t->s[t->l++] = (char)c; t->s[t->l] = 0;
+}
+/* append the rest of the current line (without the line end, CR dropped like kseq.h:146 when the line is longer than 1) */
+static int fq_line(fq_stream_t *f, fq_str_t *t)
+{
+	int c;
+	size_t l0 = t->l;
+	while ((c = fq_getc(f)) != -1 && c != '\n') fq_push(t, c);
+	if (t->l - l0 > 1 && t->s[t->l - 1] == '\r') t->s[--t->l] = 0;
+	return c;
+}
+
+/* next record: name and sequence (qualities are skipped); *last is the look-ahead marker; returns <0 at end */
+static int fq_read(fq_stream_t *f, int *last, fq_str_t *name, fq_str_t *seq)
+{
+	int c;
+	if (*last == 0) {
+		while ((c = fq_getc(f)) != -1 && c != '>' && c != '@');
+		if (c == -1) return -1;
+		*last = c;
+	}
+	name->l = seq->l = 0;
+	if (name->s) name->s[0] = 0;
+	while ((c = fq_getc(f)) != -1 && !isspace(c)) fq_push(name, c); /* name up to the first white space */
+	if (c == -1 && name->l == 0) return -1;
+	if (c != '\n' && c != -1) while ((c = fq_getc(f)) != -1 && c != '\n'); /* comment */
+	if (seq->s == 0) { seq->m = 256; seq->s = (char*)malloc(seq->m); }
+	seq->s[0] = 0;
+	while ((c = fq_getc(f)) != -1 && c != '>' && c != '+' && c != '@') {
+		if (c == '\n') continue; /* empty line */
+		fq_push(seq, c);
+		fq_line(f, seq);
+	}
+	if (c == '>' || c == '@') *last = c; else *last = 0;
+	if (c == '+') { /* FASTQ: skip the '+' line and as many quality characters as there are bases */
+		size_t ql = 0;
+		while ((c = fq_getc(f)) != -1 && c != '\n');
+		while (ql < seq->l && (c = fq_getc(f)) != -1) if (c != '\n' && c != '\r') ++ql; else if (c == '\r') { /* CR inside qualities: kseq keeps line semantics */ }
+		*last = 0;
+	}
+	return (int)seq->l;
+}
+
+/* complement of a base letter (IUPAC codes included), identity elsewhere; same mapping as the reference's table
+ * (asm.c:225-234), including its one oddity: 0x60 maps to 0x40 */
+static inline int base_comp(int c)
+{
+	static const char from[] = "ABCDGHKMRTUVYabcdghkmrtuvy", to[] = "TVGHCDMKYAABRtvghcdmkyaabr";
+	const char *p;
+	if (c == 0x60) return 0x40;
+	if (c <= 0 || c >= 128) return c;
+	p = strchr(from, c);
+	return p ? to[p - from] : c;
+}
+
+typedef struct { uint32_t utg:31, ori:1, start, len; } utg_place_t;
+
 int ma_ug_seq(ma_ug_t *g, const sdict_t *d, const ma_sub_t *sub, const char *fn)
-{ /* reference asm.c:216-290: unitig sequences from the reads file; not on the PAF->GFA hot path */
-	(void)g; (void)d; (void)sub;
-	fprintf(stderr, "[W::%s] unitig sequence stitching (-f %s) is not part of this build; S lines carry '*'\n", __func__, fn ? fn : "-");
-	return -1;
+{
+	fq_stream_t f;
+	fq_str_t name = {0, 0, 0}, seq = {0, 0, 0};
+	utg_place_t *pl;
+	uint32_t i, j;
+	int last = 0;
+	memset(&f, 0, sizeof(f));
+	f.fp = fn && strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(fileno(stdin), "r");
+	if (f.fp == 0) return -1;
+	f.buf = (unsigned char*)malloc(FQ_BUF);
+	pl = (utg_place_t*)calloc(d->n_seq ? d->n_seq : 1, sizeof(utg_place_t));
+	for (i = 0; i < g->u.n; ++i) { /* where every read lands */
+		ma_utg_t *u = &g->u.a[i];
+		uint32_t l = 0;
+		u->s = (char*)calloc(1, (size_t)u->len + 1);
+		memset(u->s, 'N', u->len);
+		for (j = 0; j < u->n; ++j) {
+			utg_place_t *t = &pl[u->a[j] >> 33];
+			assert(t->len == 0);
+			t->utg = i, t->ori = u->a[j] >> 32 & 1;
+			t->start = l, t->len = (uint32_t)u->a[j];
+			l += t->len;
+		}
+	}
+	while (fq_read(&f, &last, &name, &seq) >= 0) {
+		int32_t id = name.s ? sd_get(d, name.s) : -1;
+		const utg_place_t *t;
+		char *us, *rs = seq.s;
+		size_t rl = seq.l;
+		if (id < 0 || pl[id].len == 0) continue;
+		t = &pl[id];
+		us = g->u.a[t->utg].s + t->start;
+		if (sub) {
+			assert(sub[id].e - sub[id].s <= rl);
+			rs += sub[id].s; rl = sub[id].e - sub[id].s;
+		}
+		if (!t->ori) for (i = 0; i < t->len; ++i) us[i] = rs[i];
+		else for (i = 0; i < t->len; ++i) { int c = (uint8_t)rs[rl - 1 - i]; us[i] = c >= 128 ? 'N' : (char)base_comp(c); }
+	}
+	free(pl); free(name.s); free(seq.s); free(f.buf);
+	gzclose(f.fp);
+	return 0;
 }

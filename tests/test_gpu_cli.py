@@ -88,3 +88,24 @@ def test_cli_gz_and_stdin(tmpdir_s):
     assert out == base
     r = subprocess.run([ma.CLI_PATH, "-"], stdin=open(paf, "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0 and r.stdout == base
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+def test_cli_unitig_sequences_with_reads_file(tmpdir_s):
+    """-f reads.fa: unitig sequences stitched from the reads (reference main.c:193, asm.c:216-290)"""
+    import random
+    paf = _gen(tmpdir_s, "noisy")
+    lens = {}
+    for ln in open(paf, "rb"):
+        f = ln.split(b"\t")
+        lens.setdefault(f[0], int(f[1]))
+        lens.setdefault(f[5], int(f[6]))
+    rnd = random.Random(11)
+    fa = os.path.join(tmpdir_s, "cli_reads.fa")
+    with open(fa, "w") as out:
+        for nm, n in lens.items():
+            out.write(">%s\n%s\n" % (nm.decode(), "".join(rnd.choice("ACGT") for _ in range(n))))
+    ref_out, ref_log = R.run_cli(R.REF_BIN, ["-f", fa], paf)
+    assert b"\tLN:i:" in ref_out and not ref_out.split(b"\n")[0].split(b"\t")[2].startswith(b"*")
+    _same(ma.CLI_PATH, ["-f", fa], paf, ref_out, ref_log, "cli -f")
+    _same(R.DROPIN_BIN, ["-f", fa], paf, ref_out, ref_log, "dropin -f")

@@ -264,3 +264,58 @@ def test_parallel_ingest_matches_reference(tmpdir_s, monkeypatch):
         assert raw == first, "unsorted record order differs from the sequential path with %s threads" % th
         ing.close()
     LR.free_buf(q); LR.sd_destroy(d)
+
+
+@needs_ref
+def test_unitig_sequences_match_reference(tmpdir_s):
+    """ma_ug_seq (-f): FASTA and FASTQ (gz, multi-line, CRLF, lower case, IUPAC, reads not in the graph)"""
+    import random
+    paf = R.pafgen(os.path.join(tmpdir_s, "seq.paf"), 1500, 40000, 27, ["-L", "uniform", "-d", "0.3", "-x", "0.03"])
+    opt = ma.default_opt()
+    S = ST.ref_stages(paf, opt)
+    LR, LP = R.ref(), product_graph_api()
+    for L in (LR, LP):
+        L.ma_ug_seq.restype = C.c_int
+        L.ma_ug_seq.argtypes = [C.c_void_p, C.POINTER(ma.Sdict), C.c_void_p, C.c_char_p]
+        L.ma_ug_print.argtypes = [C.c_void_p, C.POINTER(ma.Sdict), C.c_void_p, C.c_void_p]
+    # read lengths: every surviving read needs at least sub.e bases
+    rnd = random.Random(3)
+    need = {nm: int(s["e"]) for nm, s in zip(S["names"], S["cont_sub"])}
+    alphabet = "ACGTacgtNnRYKMSWBDHV"
+    fa, fq = os.path.join(tmpdir_s, "reads.fa"), os.path.join(tmpdir_s, "reads.fq.gz")
+    recs = [("ghost1", "ACGT" * 10)]
+    for nm, n in need.items():
+        recs.append((nm, "".join(rnd.choice(alphabet) for _ in range(n + rnd.randrange(0, 50)))))
+    recs.append(("ghost2", "TTTT"))
+    with open(fa, "w") as f:
+        for k, (nm, sq) in enumerate(recs):
+            f.write(">%s some comment\n" % nm)
+            w = 60 if k % 3 else 10 ** 9
+            eol = "\r\n" if k % 5 == 0 else "\n"
+            for i in range(0, len(sq), w):
+                f.write(sq[i:i + w] + eol)
+    with gzip.open(fq, "wt") as f:
+        for nm, sq in recs:
+            f.write("@%s\n%s\n+\n%s\n" % (nm, sq, "I" * len(sq)))
+    sub = S["cont_sub"]
+    for reads in (fa, fq):
+        texts = []
+        for L in (LR, LP):
+            g = clone_graph(S["g"])
+            d = L.sd_init()
+            for i, nm in enumerate(S["names"]):
+                L.sd_put(d, nm.encode(), 0)
+            ug = L.ma_ug_gen(C.byref(g))
+            assert L.ma_ug_seq(ug, d, sub.ctypes.data, reads.encode()) == 0
+            path = os.path.join(tmpdir_s, "seq_%d.gfa" % len(texts))
+            fp = libc.fopen(path.encode(), b"w")
+            L.ma_ug_print(ug, d, sub.ctypes.data, fp)
+            libc.fclose(fp)
+            texts.append(open(path, "rb").read())
+            L.ma_ug_destroy(ug); L.sd_destroy(d)
+            for p in (g.arc, g.seq, g.idx):
+                libc.free(C.c_void_p(p))
+        assert texts[0] == texts[1], "unitig sequences differ (%s)" % reads
+        first = texts[0].split(b"\n")[0].split(b"\t")
+        assert first[0] == b"S" and first[2] != b"*" and len(first[2]) > 1000
+    LR.asg_destroy(S["g"])
