@@ -424,6 +424,7 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 	uint32_t R = c->n_seq;
 	CHK(arc_cleanup(c, n, 1, -1)); // fetches the counters: CT_MAXLEN / CT_LIVE were set by k_sg_arcs
 	c->n_live = (size_t)c->h_ctr[CT_LIVE];
+	if (c->prof) prof_patch_last(c, "k_sg_arcs", 64.0 * (double)c->n_live); // units = hits left after containment (64 B each)
 	if (c->n_arc > 1) {
 		size_t m = c->n_arc;
 		for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }

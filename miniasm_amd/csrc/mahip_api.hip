@@ -128,6 +128,14 @@ void prof_end(mahip_ctx *c)
 	(void)hipEventRecord(c->pev[k].b, c->st);
 }
 
+// correct the algorithmic byte count of the most recent launch recorded under `name` (when the number of units a
+// kernel really processed is only known after a later counter fetch)
+void prof_patch_last(mahip_ctx *c, const char *name, double alg_bytes)
+{
+	for (size_t k = c->pev.size(); k-- > 0;)
+		if (strcmp(c->pev[k].name, name) == 0) { c->pev[k].alg_bytes = alg_bytes; return; }
+}
+
 int prof_collect(mahip_ctx *c)
 {
 	HIPCHK(hipStreamSynchronize(c->st));

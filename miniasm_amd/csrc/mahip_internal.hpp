@@ -80,6 +80,7 @@ void dev_free(mahip_ctx *c, DevBuf &b);
 void prof_begin(mahip_ctx *c, const char *name, double alg_bytes);
 void prof_end(mahip_ctx *c);
 int prof_collect(mahip_ctx *c);
+void prof_patch_last(mahip_ctx *c, const char *name, double alg_bytes);
 
 struct ProfScope {
 	mahip_ctx *c;
