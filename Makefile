@@ -16,7 +16,7 @@ HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall 
 CFLAGS    = -O2 -g -Wall -fPIC -Iinclude -I$(HOST) -I$(CSRC)
 
 HIP_SRC   = scan radix hits graph mahip_api
-HOST_SRC  = timers name_dict paf_reader ingest_mt hits_host graph_host unitig_gfa pipeline
+HOST_SRC  = timers name_dict paf_reader ingest_mt hits_host graph_host refsort unitig_gfa pipeline
 HIP_OBJ   = $(addprefix $(B)/,$(addsuffix .hip.o,$(HIP_SRC)))
 HOST_OBJ  = $(addprefix $(B)/,$(addsuffix .o,$(HOST_SRC)))
 

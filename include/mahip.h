@@ -37,6 +37,12 @@ int mahip_set_shard(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end);
 /* optional: an upper bound of the query starts (e.g. the longest read) lets the sort plan its digits without a
  * device round trip; 0 = unknown */
 int mahip_set_hints(mahip_ctx_t *c, uint32_t max_qs);
+/* Tie order.  0 (default): stable device sorts, total order (key, input position).  1: records with equal keys are
+ * left in the order the reference's unstable in-place radix sort (ksort.h:134-183, used at hit.c:21 and asg.c:24)
+ * leaves them; that order is a sequential function of the whole input, so it is computed on the host from the
+ * keys (8 B/record down, 4 B/record up) and the device only gathers.  Initial value: MA_EXACT_TIES in the environment.
+ * Not available together with mahip_set_shard ranges. */
+int mahip_set_exact_ties(mahip_ctx_t *c, int on);
 /* hit.c:19-22 ma_hit_sort: LSD radix sort by (query id, query start, input order) -> SoA + group offsets */
 int mahip_hits_sort(mahip_ctx_t *c);
 /* same layout change without sorting (input already grouped by query id: the per-symbol ABI path) */

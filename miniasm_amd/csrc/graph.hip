@@ -431,7 +431,8 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 		ArcCols in = arcs_of(c, c->ag), out = arcs_of(c, c->ag ^ 1);
 		hipLaunchKernelGGL(k_arc_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
 		int gen = 0;
-		CHK(radix_sort_pairs(c, m, 0, bitlen_u64(c->h_ctr[CT_MAXLEN]), 32, 32 + bitlen_u64(2ull * R), &gen));
+		if (c->exact_ties) { CHK(reference_order(c, P<uint64_t>(c->key[0]), m, P<uint32_t>(c->val[1]))); gen = 1; } // asg.c:24 with its tie order
+		else CHK(radix_sort_pairs(c, m, 0, bitlen_u64(c->h_ctr[CT_MAXLEN]), 32, 32 + bitlen_u64(2ull * R), &gen));
 		{
 			ProfScope ps(c, "k_arc_permute", 36.0 * (double)m);
 			hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, (const uint32_t*)P<uint32_t>(c->val[gen]), out);

@@ -74,14 +74,15 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 	int first = (i == 0);
 	if (i < n) {
 		size_t j = i;
-		if (skey) j = perm ? perm[i] : (size_t)(skey[i] & ((1ull << bi) - 1));
+		if (perm) j = perm[i];
+		else if (skey) j = (size_t)(skey[i] & ((1ull << bi) - 1));
 		const uint4 *p = (const uint4*)(h + j);
 		uint4 a = p[0], b = p[1]; // a = {qs, qid, qe, tn}  b = {ts, te, ml|rev, bl|del}
 		q = a.y;
 		c.qid[i] = a.y; c.qs[i] = a.x; c.qe[i] = a.z; c.tn[i] = a.w;
 		c.ts[i] = b.x; c.te[i] = b.y; c.ml[i] = b.z; c.bl[i] = b.w & ~DEAD;
 	}
-	if (!first) qprev = skey ? (uint32_t)(skey[i - 1] >> qshift) : (uint32_t)(h[i - 1].qns >> 32);
+	if (!first) qprev = skey ? (uint32_t)(skey[i - 1] >> qshift) : (uint32_t)(h[perm ? perm[i - 1] : i - 1].qns >> 32);
 	// reads qprev+1 .. q start at slot i (reads without hits get empty groups)
 	uint32_t r0 = first ? 0 : qprev + 1;
 	if (q > n_seq) q = n_seq;
@@ -600,6 +601,12 @@ extern "C" int mahip_set_hints(mahip_ctx_t *c, uint32_t max_qs)
 	return 0;
 }
 
+extern "C" int mahip_set_exact_ties(mahip_ctx_t *c, int on)
+{
+	c->exact_ties = on != 0;
+	return 0;
+}
+
 extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 {
 	HIPCHK(hipSetDevice(c->dev));
@@ -612,6 +619,19 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	}
 	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (n + 1) * 8)); CHK(dev_reserve(c, c->val[k], (n + 1) * 4)); }
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
+	if (c->exact_ties) { // the reference's own (unstable) order: keys = qns as they are, permutation from the host
+		if (c->q_beg > 0 || (c->n_seq && c->q_end < c->n_seq)) { mahip_set_error("mahip_hits_sort: exact-tie mode is not available on a shard"); return -1; }
+		CHK(ctr_zero(c));
+		hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
+		                   (uint32_t*)nullptr, ctr, 0u, 0xffffffffu, 32, 0, 0); // key = qid<<32 | qs
+		CHK(reference_order(c, P<uint64_t>(c->key[0]), n, P<uint32_t>(c->val[1])));
+		c->n_live = n;
+		ProfScope ps(c, "k_hit_gather", 68.0 * (double)n);
+		hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)nullptr, (const uint32_t*)P<uint32_t>(c->val[1]), 32, 0, n, c->n_seq, h, P<uint32_t>(c->goff));
+		HIPCHK(hipGetLastError());
+		c->soa_ready = true;
+		return 0;
+	}
 	// digit plan: bits of the query start, of the query id, of the record index
 	int bs, bq, bi = bitlen(n - 1);
 	if (c->hint_max_qs && c->n_seq) bs = bitlen(c->hint_max_qs), bq = bitlen(c->n_seq - 1); // no device round trip

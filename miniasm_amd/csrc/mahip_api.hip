@@ -72,6 +72,7 @@ extern "C" mahip_ctx_t *mahip_create(int device, void *stream)
 	if (dev_reserve(c, c->ctr, 64 * 8) != 0) { delete c; return nullptr; }
 	if (hipHostMalloc((void**)&c->h_ctr, 64 * 8, hipHostMallocDefault) != hipSuccess) { mahip_set_error("mahip_create: hipHostMalloc failed"); delete c; return nullptr; }
 	memset(c->h_ctr, 0, 64 * 8);
+	{ const char *s = getenv("MA_EXACT_TIES"); c->exact_ties = s && atoi(s) != 0; }
 	return c;
 }
 

@@ -46,6 +46,7 @@ struct mahip_ctx {
 	DevBuf map;               // int32 [n_seq]  old -> new id, -1 dropped
 	DevBuf surv;              // u32 [n_seq_new] new -> old id
 	bool soa_ready = false, has_map = false, lazy_squeeze = false;
+	bool exact_ties = false; // order records with equal sort keys exactly as the reference's unstable sort does (host-computed permutation)
 	uint32_t n_seq_new = 0;
 
 	// ---- arcs (dense SoA, two generations for compaction) ----
@@ -102,6 +103,8 @@ int scan_exclusive_u32(mahip_ctx *c, const uint32_t *in, uint32_t *out, size_t n
 int radix_sort_pairs(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1, int *gen);
 // same for bare u64 keys (a payload such as the record index may ride in the bits below lo): key bits [lo,hi)
 int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen);
+// exact-tie mode: the permutation the reference's sort applies to d_keys[0..n) (input order), written to d_perm
+int reference_order(mahip_ctx *c, const uint64_t *d_keys, size_t n, uint32_t *d_perm);
 
 static inline unsigned grid_for(size_t n, unsigned per_block, unsigned cap = 0x7fffffffu)
 {

@@ -166,3 +166,23 @@ int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen)
 {
 	return radix_sort_impl(c, n, lo, hi, 0, 0, gen, false);
 }
+
+// ---- exact-tie mode (include/mahip.h: mahip_set_exact_ties) ----
+// The order the reference's in-place MSD radix sort gives to equal keys is a sequential function of the whole
+// input; the host computes it from the keys (host/refsort.c) and the device gathers through the permutation.
+extern "C" int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm);
+
+int reference_order(mahip_ctx *c, const uint64_t *d_keys, size_t n, uint32_t *d_perm)
+{
+	if (n == 0) return 0;
+	uint64_t *hk = (uint64_t*)malloc(n * 8);
+	uint32_t *hp = (uint32_t*)malloc(n * 4);
+	if (!hk || !hp) { free(hk); free(hp); mahip_set_error("reference_order: out of host memory"); return -1; }
+	int rc = 0;
+	if (hipMemcpyAsync(hk, d_keys, n * 8, hipMemcpyDeviceToHost, c->st) != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess) rc = -1;
+	if (rc == 0 && ma_refsort_perm(hk, n, hp) != 0) rc = -1;
+	if (rc == 0 && (hipMemcpyAsync(d_perm, hp, n * 4, hipMemcpyHostToDevice, c->st) != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess)) rc = -1;
+	free(hk); free(hp);
+	if (rc) mahip_set_error("reference_order: copy or host sort failed");
+	return rc;
+}

@@ -40,6 +40,10 @@ uint32_t ma_ingest_max_qs(void); /* largest query start stored by the last ma_hi
 
 /* literal emulation of the reference's in-place MSD radix sort (ksort.h:134-183) on arcs keyed by ul */
 void ma_refsort_arcs(asg_arc_t *beg, asg_arc_t *end);
+/* the same procedure on (key, input index) pairs, sub-buckets on worker threads (refsort.c): exact-tie mode */
+typedef struct { uint64_t key; uint32_t idx, pad; } ma_ki_t;
+void ma_refsort_ki(ma_ki_t *a, size_t n, int n_threads);
+int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm); /* perm[i] = input position of the i-th record in reference order */
 
 #ifdef __cplusplus
 }

@@ -109,3 +109,37 @@ def test_cli_unitig_sequences_with_reads_file(tmpdir_s):
     assert b"\tLN:i:" in ref_out and not ref_out.split(b"\n")[0].split(b"\t")[2].startswith(b"*")
     _same(ma.CLI_PATH, ["-f", fa], paf, ref_out, ref_log, "cli -f")
     _same(R.DROPIN_BIN, ["-f", fa], paf, ref_out, ref_log, "dropin -f")
+
+
+TIE_INPUTS = {  # coordinates on a grid (pafgen -q): hundreds of equal (qid,qs) hit keys and (u,len) arc keys
+    "grid16": dict(reads=3000, lines=80000, seed=5, extra=["-q", "16", "-L", "uniform", "-d", "0.3", "-x", "0.03"]),
+    "grid200": dict(reads=3000, lines=80000, seed=6, extra=["-q", "200", "-L", "uniform", "-d", "0.3", "-x", "0.03"]),
+    "grid400_lognormal": dict(reads=4000, lines=120000, seed=7, extra=["-q", "400", "-d", "0.2"]),
+    "grid50_fixed": dict(reads=2500, lines=70000, seed=8, extra=["-q", "50", "-L", "fixed", "-d", "0.1"]),
+}
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name", list(TIE_INPUTS))
+def test_exact_tie_mode_is_byte_identical(name, tmpdir_s, monkeypatch):
+    """MA_EXACT_TIES=1 (mahip_set_exact_ties): on inputs full of equal sort keys every dump equals the reference's
+    BYTE FOR BYTE -- no line-order normalisation: hit order, arc order and everything downstream of them"""
+    monkeypatch.setenv("MA_EXACT_TIES", "1")
+    cfg = TIE_INPUTS[name]
+    paf = R.pafgen(os.path.join(tmpdir_s, "tie_%s.paf" % name), cfg["reads"], cfg["lines"], cfg["seed"], cfg["extra"])
+    ref_sg, _ = R.run_cli(R.REF_BIN, ["-p", "sg", "-S5"], paf)
+    assert R.arc_tie_groups(ref_sg) >= 5, "input is supposed to be tie-rich"
+    for args in DUMPS:
+        ref_out, ref_log = R.run_cli(R.REF_BIN, args, paf)
+        out, log = R.run_cli(ma.CLI_PATH, args, paf)
+        assert out == ref_out, "cli[%s] %s: bytes differ from the reference" % (name, " ".join(args))
+        assert [x for x in R.counters(log) if not x.startswith("main: Version")] == R.counters(ref_log)
+    for args in (["-p", "paf"], ["-p", "sg", "-S5"], ["-p", "ug"]):
+        ref_out, _ = R.run_cli(R.REF_BIN, args, paf)
+        out, _ = R.run_cli(R.DROPIN_BIN, args, paf)
+        assert out == ref_out, "dropin[%s] %s: bytes differ from the reference" % (name, " ".join(args))
+    # unfused resident pipeline as well
+    monkeypatch.setenv("MA_NO_FUSE", "1")
+    ref_out, _ = R.run_cli(R.REF_BIN, ["-p", "ug"], paf)
+    out, _ = R.run_cli(ma.CLI_PATH, ["-p", "ug"], paf)
+    assert out == ref_out

@@ -223,6 +223,45 @@ def test_refsort_emulation_matches_reference_on_ties():
 
 
 @needs_ref
+@pytest.mark.parametrize("threads", ["1", "8"])
+def test_refsort_perm_matches_reference_sort(threads, monkeypatch):
+    """exact-tie mode: the permutation computed from the keys alone (host/refsort.c, sub-buckets on threads) is the
+    one the reference's radix_sort_hit (hit.c:13,21) / asg_arc_sort (asg.c:9,24) apply to the records"""
+    monkeypatch.setenv("MA_THREADS", threads)
+    LR, LP = R.ref(), ma.lib()
+    LP.ma_refsort_perm.restype = C.c_int
+    LP.ma_refsort_perm.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    LR.radix_sort_hit.argtypes = [C.c_void_p, C.c_void_p]
+    LR.radix_sort_hit.restype = None
+    rng = np.random.default_rng(17)
+    # (n, reads, distinct starts): from the insertion-sort-only case to multi-level buckets with heavy ties
+    for n, nq, ns in ((1, 1, 1), (64, 3, 4), (65, 3, 4), (1000, 1, 1), (3000, 7, 40), (200000, 300, 50), (700000, 70000, 3), (900000, 300000, 100000)):
+        hits = np.zeros(n, dtype=ma.HIT_DT)
+        hits["qns"] = (rng.integers(0, nq, n).astype(np.uint64) << 32) | (rng.integers(0, ns, n).astype(np.uint64) * 977 % 70001)
+        hits["tn"] = np.arange(n)  # distinguishes tied records
+        perm = np.zeros(n, dtype=np.uint32)
+        keys = np.ascontiguousarray(hits["qns"])
+        assert LP.ma_refsort_perm(keys.ctypes.data, n, perm.ctypes.data) == 0
+        ref = hits.copy()
+        LR.radix_sort_hit(ref.ctypes.data, ref.ctypes.data + n * 32)
+        assert (np.diff(ref["qns"].astype(np.int64)) >= 0).all()
+        assert hits[perm].tobytes() == ref.tobytes(), "hit order differs for n=%d" % n
+    LR.asg_arc_sort.argtypes = [C.POINTER(ma.Asg)]
+    for n, nu, nl in ((300, 8, 6), (400000, 5000, 12), (600000, 400000, 3)):
+        arcs = np.zeros(n, dtype=ma.ARC_DT)
+        arcs["ul"] = (rng.integers(0, nu, n).astype(np.uint64) << 32) | rng.integers(0, nl, n).astype(np.uint64)
+        arcs["v"] = np.arange(n)
+        perm = np.zeros(n, dtype=np.uint32)
+        keys = np.ascontiguousarray(arcs["ul"])
+        assert LP.ma_refsort_perm(keys.ctypes.data, n, perm.ctypes.data) == 0
+        ref = arcs.copy()
+        g = ma.Asg()
+        g.arc, g.n_arc_srt, g.m_arc = ref.ctypes.data, n, n
+        LR.asg_arc_sort(C.byref(g))
+        assert arcs[perm].tobytes() == ref.tobytes(), "arc order differs for n=%d" % n
+
+
+@needs_ref
 def test_parallel_ingest_matches_reference(tmpdir_s, monkeypatch):
     """chunk-parallel ingest (ingest_mt.c): same ids, same records as the reference's sequential reader, including
     the `bl` a 10-column line inherits across a chunk cut, CRLF line ends and junk lines"""

@@ -32,6 +32,9 @@ bench)
 benchfixed)
   timeout 1500 python bench.py --model fixed --no-cpu > gpurun_out/bench_fixed.json 2> gpurun_out/bench_fixed.log; echo "rc=$?" >> gpurun_out/bench_fixed.log
   tail -3 gpurun_out/bench_fixed.log; cat gpurun_out/bench_fixed.json ;;
+benchexact)
+  MA_EXACT_TIES=1 timeout 1500 python bench.py --no-cpu --steps 3 --warmup 1 --prof-steps 0 > gpurun_out/bench_exact.json 2> gpurun_out/bench_exact.log; echo "rc=$?" >> gpurun_out/bench_exact.log
+  tail -3 gpurun_out/bench_exact.log; cat gpurun_out/bench_exact.json ;;
 prof)
   rm -rf gpurun_out/prof; mkdir -p gpurun_out/prof
   (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof -o r --output-format csv -- python /root/repo/bench.py --steps 5 --warmup 1 --no-cpu --prof-steps 0 > /root/repo/gpurun_out/prof/bench_under_prof.json 2> /root/repo/gpurun_out/prof/bench_under_prof.log); echo "rc=$?"

@@ -62,7 +62,7 @@ static inline char *put_u32(char *p, uint32_t x)
 }
 
 typedef struct {
-	uint32_t n_reads, len_min, len_max, min_ovlp;
+	uint32_t n_reads, len_min, len_max, min_ovlp, quantum;
 	uint64_t n_lines, seed;
 	int model; /* 0 lognormal, 1 fixed, 2 uniform */
 	double mean, sigma, dropout, false_frac, lowid_frac;
@@ -150,7 +150,7 @@ int main(int argc, char *argv[])
 	memset(&o, 0, sizeof(o));
 	o.n_reads = 2000; o.n_lines = 50000; o.seed = 1; o.model = 0; o.mean = 8000.; o.sigma = .5;
 	o.len_min = 2500; o.len_max = 60000; o.min_ovlp = 2000;
-	while ((c = getopt(argc, argv, "r:n:s:L:m:S:d:x:i:o:gl:M:O:")) >= 0) {
+	while ((c = getopt(argc, argv, "r:n:s:L:m:S:d:x:i:o:gl:M:O:q:")) >= 0) {
 		if (c == 'r') o.n_reads = atol(optarg);
 		else if (c == 'n') o.n_lines = atoll(optarg);
 		else if (c == 's') o.seed = atoll(optarg);
@@ -165,6 +165,7 @@ int main(int argc, char *argv[])
 		else if (c == 'l') o.len_min = atol(optarg);
 		else if (c == 'M') o.len_max = atol(optarg);
 		else if (c == 'O') o.min_ovlp = atol(optarg);
+		else if (c == 'q') o.quantum = atol(optarg); /* coordinates on a grid: many equal sort keys (tie-order tests) */
 	}
 	if (o.n_reads < 2) { fprintf(stderr, "pafgen: need >= 2 reads\n"); return 1; }
 	sm_state = o.seed * 0x2545F4914F6CDD1DULL + 12345;
@@ -199,10 +200,17 @@ int main(int argc, char *argv[])
 	}
 	G = hi;
 	place(r, u, o.n_reads, G, o.len_max);
+	if (o.quantum > 1) { /* tie-rich variant: starts and lengths on a grid, no de-duplication */
+		for (i = 0; i < o.n_reads; ++i) {
+			r[i].start = r[i].start / o.quantum * o.quantum;
+			r[i].len = r[i].len / o.quantum * o.quantum;
+			if (r[i].len < o.quantum) r[i].len = o.quantum;
+		}
+	}
 	/* make starts pairwise distinct, then ends pairwise distinct (shrink a read by 1 bp on collision) */
-	for (i = 1; i < o.n_reads; ++i)
+	for (i = 1; i < o.n_reads && o.quantum <= 1; ++i)
 		if (r[i].start <= r[i-1].start) r[i].start = r[i-1].start + 1;
-	{
+	if (o.quantum <= 1) {
 		uint64_t *e = (uint64_t*)malloc(sizeof(uint64_t) * o.n_reads);
 		int changed = 1, iter = 0;
 		while (changed && iter++ < 64) {
