@@ -22,7 +22,7 @@
 #include "ma_host.h"
 
 #define RS_SMALL 64           /* RS_MIN_SIZE ksort.h:132 */
-#define TASK_MIN (1u << 15)   /* buckets smaller than this are finished by the thread that made them */
+#define TASK_MIN (1u << 11)   /* buckets smaller than this are finished by the thread that made them */
 
 static void ki_insertion(ma_ki_t *a, size_t n) /* ksort.h:142-152: stable insertion sort on the whole key */
 {
@@ -64,14 +64,16 @@ static void ki_level(rs_pool_t *pool, ma_ki_t *a, size_t n, int shift)
 {
 	size_t head[256], tail[256], start[257], i;
 	int k;
-	{ /* a level on which the digit does not vary leaves the range untouched and recurses into the same range (n > 64 here) */
+	/* A level on which the digit does not vary leaves the range untouched and recurses into the same range (n > 64
+	 * here).  One sweep gives the varying bits and, optimistically, the histogram of the current digit. */
+	for (;;) {
 		uint64_t diff = 0, k0 = a[0].key;
-		for (i = 1; i < n; ++i) diff |= a[i].key ^ k0;
+		memset(tail, 0, sizeof(tail));
+		for (i = 0; i < n; ++i) diff |= a[i].key ^ k0, ++tail[a[i].key >> shift & 0xff];
 		if (diff == 0) return; /* all keys equal: every remaining level is the identity */
+		if ((diff >> shift & 0xff) != 0) break;
 		while (shift > 0 && (diff >> shift & 0xff) == 0) shift -= 8;
 	}
-	memset(tail, 0, sizeof(tail));
-	for (i = 0; i < n; ++i) ++tail[a[i].key >> shift & 0xff];
 	start[0] = 0;
 	for (k = 0; k < 256; ++k) start[k + 1] = start[k] + tail[k], head[k] = start[k], tail[k] = start[k + 1];
 	for (k = 0; k < 256;) {
@@ -126,7 +128,7 @@ static void *pool_worker(void *arg)
 void ma_refsort_ki(ma_ki_t *a, size_t n, int n_threads)
 {
 	if (n <= RS_SMALL) { ki_insertion(a, n); return; } /* ksort.h:182 */
-	if (n_threads <= 1 || n < 4 * (size_t)TASK_MIN) { ki_level(0, a, n, 56); return; }
+	if (n_threads <= 1 || n < (1u << 17)) { ki_level(0, a, n, 56); return; }
 	{
 		rs_pool_t p;
 		pthread_t *th;
@@ -147,16 +149,43 @@ void ma_refsort_ki(ma_ki_t *a, size_t n, int n_threads)
 }
 
 /* perm[i] = input position of the record the reference's sort leaves at position i */
+typedef struct { const uint64_t *keys; ma_ki_t *a; uint32_t *perm; size_t beg, end; int phase; } fill_t;
+
+static void *fill_worker(void *arg)
+{
+	fill_t *f = (fill_t*)arg;
+	size_t i;
+	if (f->phase == 0) for (i = f->beg; i < f->end; ++i) f->a[i].key = f->keys[i], f->a[i].idx = (uint32_t)i, f->a[i].pad = 0;
+	else for (i = f->beg; i < f->end; ++i) f->perm[i] = f->a[i].idx;
+	return 0;
+}
+
+static void fill_run(const uint64_t *keys, ma_ki_t *a, uint32_t *perm, size_t n, int phase, int n_threads)
+{
+	fill_t f[64];
+	pthread_t th[64];
+	int t;
+	if (n_threads > 64) n_threads = 64;
+	if (n < (1u << 20) || n_threads < 2) n_threads = 1;
+	for (t = 0; t < n_threads; ++t) {
+		f[t].keys = keys, f[t].a = a, f[t].perm = perm, f[t].phase = phase;
+		f[t].beg = n / n_threads * t, f[t].end = t == n_threads - 1 ? n : n / n_threads * (t + 1);
+	}
+	if (n_threads == 1) { fill_worker(&f[0]); return; }
+	for (t = 0; t < n_threads; ++t) pthread_create(&th[t], 0, fill_worker, &f[t]);
+	for (t = 0; t < n_threads; ++t) pthread_join(th[t], 0);
+}
+
 int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm)
 {
 	ma_ki_t *a;
-	size_t i;
+	const int nt = ma_ingest_threads();
 	if (n == 0) return 0;
 	a = (ma_ki_t*)malloc(n * sizeof(ma_ki_t));
 	if (a == 0) return -1;
-	for (i = 0; i < n; ++i) a[i].key = keys[i], a[i].idx = (uint32_t)i, a[i].pad = 0;
-	ma_refsort_ki(a, n, ma_ingest_threads());
-	for (i = 0; i < n; ++i) perm[i] = a[i].idx;
+	fill_run(keys, a, perm, n, 0, nt);
+	ma_refsort_ki(a, n, nt);
+	fill_run(keys, a, perm, n, 1, nt);
 	free(a);
 	return 0;
 }
