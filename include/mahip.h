@@ -34,9 +34,34 @@ int mahip_hits_adopt(mahip_ctx_t *c, const void *d_hits, size_t n, uint32_t n_se
 /* Multi-GPU: this context owns the hits whose query id lies in [q_beg,q_end); call before sort/index. */
 int mahip_set_shard(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end);
 
+/* ---- PAF text ingest on the device (replaces paf.c:34-67 paf_parse/paf_read + sdict.c:27-45 sd_put + hit.c:70-101, the part of
+ * ma_hit_read before the sort).  Load the whole (decompressed) text, parse: afterwards the context holds the unsorted hit
+ * records exactly as the reference has them before ma_hit_sort (as after mahip_hits_upload) and the read-name dictionary
+ * with the reference's ids (dense, in order of first appearance, first length wins).  No `excl` dictionary (-R) here:
+ * that option keeps the host reader. */
+typedef struct {
+	uint64_t n_lines;         /* text lines */
+	uint64_t n_records;       /* lines with >= 10 columns = what the reference logs as "read %ld hits" (hit.c:102) */
+	uint64_t n_stored_lines;  /* lines passing the span/match filter (hit.c:85) */
+	uint64_t n_hits;          /* records stored (mirrored hits included) */
+	uint64_t name_bytes;      /* bytes mahip_paf_names() writes (names NUL-terminated, back to back, in id order) */
+	uint32_t n_seq, max_qs;   /* reads in the dictionary; upper bound of the stored query starts */
+} mahip_paf_info_t;
+int mahip_paf_load_mem(mahip_ctx_t *c, const void *text, size_t nbytes);   /* text in host memory */
+int mahip_paf_load_fd(mahip_ctx_t *c, int fd, size_t nbytes);              /* bytes [0,nbytes) of an open plain file, read straight into pinned staging */
+int mahip_paf_parse(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, mahip_paf_info_t *info);
+int mahip_paf_names(mahip_ctx_t *c, char *names, uint32_t *lens);          /* names[name_bytes], lens[n_seq] = first-seen read lengths */
+int mahip_paf_release(mahip_ctx_t *c);
+int mahip_hits_raw_download(mahip_ctx_t *c, ma_hit_t *out);                 /* the unsorted records held by the context (n_hits of them) */                                     /* free the text and the per-line columns */
+
 /* optional: an upper bound of the query starts (e.g. the longest read) lets the sort plan its digits without a
  * device round trip; 0 = unknown */
 int mahip_set_hints(mahip_ctx_t *c, uint32_t max_qs);
+/* Bulk copies between pageable host memory and device memory at PCIe speed: worker threads stage slices through
+ * pinned slots while their DMAs run (a plain hipMemcpy of pageable memory is staged by one runtime thread).
+ * Synchronous; ordered after the work already queued on the context's stream.  MA_XFER_THREADS sets the workers. */
+int mahip_memcpy_h2d(mahip_ctx_t *c, void *d_dst, const void *h_src, size_t bytes);
+int mahip_memcpy_d2h(mahip_ctx_t *c, void *h_dst, const void *d_src, size_t bytes);
 /* Tie order.  0 (default): stable device sorts, total order (key, input position).  1: records with equal keys are
  * left in the order the reference's unstable in-place radix sort (ksort.h:134-183, used at hit.c:21 and asg.c:24)
  * leaves them; that order is a sequential function of the whole input, so it is computed on the host from the

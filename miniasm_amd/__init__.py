@@ -88,6 +88,9 @@ def lib():
         L.mahip_hits_adopt.argtypes = [vp, vp, sz, u32]
         L.mahip_set_shard.argtypes = [vp, u32, u32]
         L.mahip_set_hints.argtypes = [vp, u32]
+        L.mahip_set_exact_ties.argtypes = [vp, i32]
+        L.mahip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+        L.mahip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
         L.mahip_hits_sort.argtypes = [vp]
         L.mahip_hits_index.argtypes = [vp]
         L.mahip_hits_sub.argtypes = [vp, i32, C.c_float, i32, i32, C.POINTER(sz)]
@@ -321,6 +324,40 @@ class Ingest:
 
     def close(self):
         self.free_hits()
+        if self.d:
+            lib().sd_destroy(self.d)
+            self.d = None
+
+
+class GpuIngest:
+    """Device-side ingest (csrc/paf.hip through host/ingest_gpu.c): the records stay in `ctx`; the dictionary comes back.
+    Same attributes as Ingest; `hits` downloads the unsorted records (tests)."""
+
+    def __init__(self, ctx, fn, opt=None, bi_dir=True):
+        L = lib()
+        opt = opt or default_opt()
+        self.ctx = ctx
+        self.d = L.sd_init()
+        n = C.c_size_t(0)
+        L.ma_hit_ingest_gpu.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(Sdict), C.POINTER(C.c_size_t), C.c_int]
+        rc = L.ma_hit_ingest_gpu(ctx.h, fn.encode(), opt.min_span, opt.min_match, self.d, C.byref(n), 1 if bi_dir else 0)
+        if rc != 0:
+            raise OSError("cannot open %s" % fn)
+        self.n = n.value
+        self.n_seq = self.d.contents.n_seq
+
+    @property
+    def hits(self):
+        out = np.zeros(self.n, dtype=HIT_DT)
+        L = lib()
+        L.mahip_hits_raw_download.argtypes = [C.c_void_p, C.c_void_p]
+        _chk(L.mahip_hits_raw_download(self.ctx.h, out.ctypes.data), "hits_raw_download")
+        return out
+
+    names = Ingest.names
+    lens = Ingest.lens
+
+    def close(self):
         if self.d:
             lib().sd_destroy(self.d)
             self.d = None

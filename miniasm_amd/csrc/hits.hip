@@ -575,7 +575,7 @@ extern "C" int mahip_hits_upload(mahip_ctx_t *c, const ma_hit_t *h, size_t n, ui
 	HIPCHK(hipSetDevice(c->dev));
 	CHK(hits_common_setup(c, n, n_seq));
 	CHK(dev_reserve(c, c->aos_own, (n + 1) * sizeof(ma_hit_t)));
-	if (n) HIPCHK(hipMemcpyAsync(c->aos_own.p, h, n * sizeof(ma_hit_t), hipMemcpyHostToDevice, c->st));
+	CHK(xfer_copy(c, c->aos_own.p, (void*)h, n * sizeof(ma_hit_t), 1));
 	c->d_aos = (const ma_hit_t*)c->aos_own.p;
 	return 0;
 }
@@ -586,6 +586,15 @@ extern "C" int mahip_hits_adopt(mahip_ctx_t *c, const void *d_hits, size_t n, ui
 	CHK(hits_common_setup(c, n, n_seq));
 	c->d_aos = (const ma_hit_t*)d_hits;
 	return 0;
+}
+
+// the unsorted records as they sit in the context (after an upload / adopt / device-side parse), for tests
+extern "C" int mahip_hits_raw_download(mahip_ctx_t *c, ma_hit_t *out)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (c->n_hits == 0) return 0;
+	if (!c->d_aos) { mahip_set_error("mahip_hits_raw_download: no records"); return -1; }
+	return xfer_copy(c, (void*)c->d_aos, out, c->n_hits * sizeof(ma_hit_t), 0);
 }
 
 extern "C" int mahip_set_shard(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end)
@@ -1016,7 +1025,6 @@ extern "C" int mahip_hits_download(mahip_ctx_t *c, ma_hit_t *out, size_t *n_out)
 	CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), n, nullptr));
 	hipLaunchKernelGGL(k_hit_export, dim3(grid_for(n, 256)), dim3(256), 0, c->st, h, n, (const uint32_t*)P<uint32_t>(c->pos),
 	                   c->has_map ? (const int32_t*)P<int32_t>(c->map) : (const int32_t*)nullptr, (ma_hit_t*)c->key[0].p);
-	HIPCHK(hipMemcpyAsync(out, c->key[0].p, c->n_live * sizeof(ma_hit_t), hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipStreamSynchronize(c->st));
+	CHK(xfer_copy(c, c->key[0].p, out, c->n_live * sizeof(ma_hit_t), 0));
 	return 0;
 }

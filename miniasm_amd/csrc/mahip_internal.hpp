@@ -68,6 +68,8 @@ struct mahip_ctx {
 	DevBuf big0, big1;        // lazily allocated global scratch for oversized groups
 	DevBuf marks;             // trans-reduce tier-2 mark arrays
 	uint64_t *h_ctr = nullptr; // pinned host mirror of ctr
+	void *xfer = nullptr;      // staged-copy worker pool (xfer.hip)
+	void *paf = nullptr;       // text-ingest buffers (paf.hip)
 
 	// ---- profiling ----
 	bool prof = false;
@@ -105,6 +107,11 @@ int radix_sort_pairs(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1,
 int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen);
 // exact-tie mode: the permutation the reference's sort applies to d_keys[0..n) (input order), written to d_perm
 int reference_order(mahip_ctx *c, const uint64_t *d_keys, size_t n, uint32_t *d_perm);
+// bulk pageable<->device copy through per-thread pinned slots (xfer.hip); returns after the copy is complete
+int xfer_copy(mahip_ctx *c, void *dev_ptr, void *host_ptr, size_t bytes, int to_device);
+void xfer_pool_free(mahip_ctx *c);
+int xfer_from_fd(mahip_ctx *c, void *dev_ptr, int fd, size_t bytes);
+void paf_free(mahip_ctx *c);
 
 static inline unsigned grid_for(size_t n, unsigned per_block, unsigned cap = 0x7fffffffu)
 {

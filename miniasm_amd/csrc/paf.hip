@@ -1,0 +1,537 @@
+// paf.hip -- PAF text -> hit records + read-name dictionary on the device.
+//
+// Reproduces, bit for bit, what the reference's reader and ma_hit_read produce before the sort
+// (paf.c:34-67 paf_parse/paf_read, kseq.h line semantics, sdict.c:27-45 sd_put, hit.c:70-101):
+//   * a record is a line split on TABs; a trailing CR is dropped when the line is longer than one char;
+//     lines with fewer than 10 columns are skipped; with exactly 10 columns `bl` keeps the value of the last
+//     line that had an 11th column (0 before any);
+//   * numeric columns follow strtol (leading blanks, sign, junk after the digits, saturation at LONG_MAX/MIN)
+//     and are truncated to 32 bits (ml, bl to 31); rev = first char of column 5 is '-';
+//   * a line is stored when both spans >= min_span and ml >= min_match (hit.c:85); its query name, then its target
+//     name, enter the dictionary: ids are dense in order of FIRST APPEARANCE, the first length seen wins;
+//   * every stored line yields the hit and, with bi_dir and qid != tid, the mirrored hit right after it.
+// The sequential parts of the reference become data-parallel as follows: line starts = positions after '\n'
+// (count, scan, scatter); first-appearance ids = hash-table insert with an atomic MIN of the occurrence number
+// (2*line + column) per distinct name, then a sort of the distinct names by that minimum; the stale `bl` = a
+// compaction of the lines that have one plus a prefix count; record slots = prefix sum of 1-or-2 per line.
+// All HBM-bound byte/integer work: text is read once (through LDS tiles), per-line columns are 61 B.
+#include "mahip_internal.hpp"
+
+#define PAF_TILE 4096u            // bytes per block in the newline passes (256 threads x 16 B)
+#define PAF_LDS_BYTES 49152u      // text of 256 consecutive lines is staged in LDS when it fits
+#define PAF_PROBE_LIMIT 2048u
+#define PAF_EMPTY 0xffffffffffffffffull
+
+// counter slots used by this file (aliases into ctx->ctr)
+#define PC_LINES CT_TOTAL
+#define PC_VALID CT_LIVE
+#define PC_PASS CT_REMAIN
+#define PC_NOBL CT_OVF
+#define PC_MAXQS CT_MAXQS
+#define PC_OVERFLOW CT_OVF2
+#define PC_HITS CT_NRED
+
+struct PafBufs {
+	DevBuf text, lstart, tile;
+	DevBuf flags, num[8], tnoff, qlen, tlen, hq, ht, qslot, tslot;
+	DevBuf tab, tmin, slot_id, blv, scal;
+	DevBuf name_off, name_len, name_pos, seq_len, names;
+	size_t nbytes = 0, name_bytes = 0;
+	uint32_t n_seq = 0;
+	bool loaded = false;
+};
+
+struct PafCols {
+	uint8_t *flags;            // bit0 valid (>= 10 columns), bit1 stored, bit2 has column 11, bit3 rev
+	uint32_t *ql, *qs, *qe, *tl, *ts, *te, *ml, *bl;
+	uint32_t *tnoff, *qlen, *tlen; // target-name offset inside the line, name lengths (up to the first NUL)
+	uint64_t *hq, *ht;
+	uint32_t *qslot, *tslot;   // hash-table slot of the two names, later their ids
+};
+
+static PafBufs *paf_of(mahip_ctx *c)
+{
+	if (!c->paf) c->paf = new PafBufs();
+	return (PafBufs*)c->paf;
+}
+
+void paf_free(mahip_ctx *c)
+{
+	PafBufs *b = (PafBufs*)c->paf;
+	if (!b) return;
+	DevBuf *all[] = { &b->text, &b->lstart, &b->tile, &b->flags, &b->tnoff, &b->qlen, &b->tlen, &b->hq, &b->ht, &b->qslot, &b->tslot, &b->tab, &b->tmin,
+		&b->slot_id, &b->blv, &b->scal, &b->name_off, &b->name_len, &b->name_pos, &b->seq_len, &b->names };
+	for (DevBuf *d : all) dev_free(c, *d);
+	for (int k = 0; k < 8; ++k) dev_free(c, b->num[k]);
+	delete b;
+	c->paf = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ line starts
+
+__device__ __forceinline__ uint32_t nl_mask(uint32_t v) // 0x80 in every byte of v that equals '\n'
+{
+	v ^= 0x0A0A0A0Au;
+	uint32_t t = (v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+	return ~(t | v | 0x7F7F7F7Fu);
+}
+
+__device__ __forceinline__ uint4 load16(const unsigned char *__restrict__ text, size_t off, size_t n)
+{
+	if (off + 16 <= n) return *(const uint4*)(text + off);
+	uint32_t w[4] = { 0, 0, 0, 0 };
+	for (int k = 0; k < 16; ++k) if (off + k < n) w[k >> 2] |= (uint32_t)text[off + k] << (8 * (k & 3));
+	return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__global__ __launch_bounds__(256) void k_paf_nl_count(const unsigned char *__restrict__ text, size_t n, uint32_t *__restrict__ tile_cnt)
+{
+	__shared__ uint32_t s_w[4];
+	size_t off = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+	uint32_t cnt = 0;
+	if (off < n) {
+		uint4 v = load16(text, off, n);
+		cnt = __popc(nl_mask(v.x)) + __popc(nl_mask(v.y)) + __popc(nl_mask(v.z)) + __popc(nl_mask(v.w));
+	}
+	cnt = wv_sum_u32(cnt);
+	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
+	__syncthreads();
+	if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// lstart[k+1] = byte after the k-th newline; lstart[0] = 0; an unterminated last line gets the sentinel n+1
+__global__ __launch_bounds__(256) void k_paf_nl_pos(const unsigned char *__restrict__ text, size_t n, const uint32_t *__restrict__ tile_off,
+                                                     const uint32_t *__restrict__ d_total, uint64_t *__restrict__ lstart, unsigned long long *__restrict__ ctr)
+{
+	__shared__ uint32_t s_w[4];
+	size_t off = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+	uint32_t m[4] = { 0, 0, 0, 0 }, cnt = 0, tot;
+	if (off < n) {
+		uint4 v = load16(text, off, n);
+		m[0] = nl_mask(v.x); m[1] = nl_mask(v.y); m[2] = nl_mask(v.z); m[3] = nl_mask(v.w);
+		cnt = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
+	}
+	uint32_t k = tile_off[blockIdx.x] + block_excl_scan_256(cnt, s_w, &tot);
+	for (int w = 0; w < 4; ++w)
+		for (uint32_t x = m[w]; x; x &= x - 1) {
+			int byte = (__ffs(x) - 1) >> 3;
+			lstart[++k] = off + (size_t)(w * 4 + byte) + 1;
+		}
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		uint32_t nl = *d_total;
+		int open = n > 0 && text[n - 1] != '\n';
+		lstart[0] = 0;
+		if (open) lstart[(size_t)nl + 1] = (uint64_t)n + 1;
+		ctr[PC_LINES] = (unsigned long long)nl + (unsigned long long)open;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ per-line parse
+
+#define FNV_OFF 0xcbf29ce484222325ull
+#define FNV_PRIME 0x100000001b3ull
+
+__global__ __launch_bounds__(256) void k_paf_parse(const unsigned char *__restrict__ text, size_t n, const uint64_t *__restrict__ lstart, uint32_t L,
+                                                    int min_span, int min_match, PafCols o, uint32_t *__restrict__ f_hasbl, unsigned long long *__restrict__ ctr)
+{
+	extern __shared__ unsigned char s_text[];
+	const uint32_t i0 = blockIdx.x * 256u, i1 = i0 + 256u < L ? i0 + 256u : L;
+	const uint64_t b0 = lstart[i0], e1 = lstart[i1] - 1; // bytes of these lines: [b0, e1)
+	const uint64_t a0 = b0 & ~(uint64_t)15;
+	const bool in_lds = e1 - a0 <= PAF_LDS_BYTES;
+	if (in_lds) {
+		for (uint64_t x = (uint64_t)threadIdx.x * 16; a0 + x < e1; x += 256 * 16) *(uint4*)(s_text + x) = load16(text, a0 + x, n);
+		__syncthreads();
+	}
+	const uint32_t i = i0 + threadIdx.x;
+	uint32_t valid = 0, pass = 0, nobl = 0;
+	uint64_t mq = 0;
+	if (i < i1) {
+		const uint64_t ls = lstart[i];
+		uint32_t l = (uint32_t)(lstart[i + 1] - 1 - ls);
+		const unsigned char *p = in_lds ? (const unsigned char*)s_text + (ls - a0) : text + ls;
+		if (l > 1 && p[l - 1] == '\r') --l;
+		uint32_t t = 0, fstart = 0, nlen = 0, nstate = 0;
+		bool neg = false, ovf = false, nstop = false, rev = false;
+		uint64_t acc = 0, h = FNV_OFF;
+		uint32_t ql = 0, qs = 0, qe = 0, tl = 0, ts = 0, te = 0, ml = 0, bl = 0, tnoff = 0, qlen = 0, tlen = 0;
+		uint64_t hq = 0, ht = 0;
+		for (uint32_t pos = 0; pos <= l; ++pos) {
+			const unsigned ch = pos < l ? p[pos] : '\t';
+			if (ch != '\t') {
+				if (t == 0 || t == 5) { // name: bytes up to the first NUL (the reference handles names as C strings)
+					if (!nstop) { if (ch == 0) nstop = true; else h = (h ^ ch) * FNV_PRIME, ++nlen; }
+				} else if (t == 4) {
+					if (pos == fstart) rev = ch == '-';
+				} else if (t <= 10) { // strtol, base 10
+					const unsigned d = ch - '0';
+					if (nstate == 0) {
+						if (ch == ' ' || (ch >= 0x0b && ch <= 0x0d)) { /* leading blanks */ }
+						else if (ch == '+') nstate = 1;
+						else if (ch == '-') neg = true, nstate = 1;
+						else if (d < 10u) nstate = 1, acc = d;
+						else nstate = 2;
+					} else if (nstate == 1) {
+						if (d < 10u) {
+							const uint64_t lim = neg ? 0x8000000000000000ull : 0x7fffffffffffffffull;
+							if (ovf || acc > (lim - d) / 10) ovf = true; else acc = acc * 10 + d;
+						} else nstate = 2;
+					}
+				}
+				continue;
+			}
+			// end of column t
+			const uint32_t val = ovf ? (neg ? 0u : 0xffffffffu) : (uint32_t)(neg ? (uint64_t)0 - acc : acc);
+			switch (t) {
+			case 0: hq = h; qlen = nlen; break;
+			case 1: ql = val; break;
+			case 2: qs = val; break;
+			case 3: qe = val; break;
+			case 5: ht = h; tlen = nlen; tnoff = fstart; break;
+			case 6: tl = val; break;
+			case 7: ts = val; break;
+			case 8: te = val; break;
+			case 9: ml = val & 0x7fffffffu; break;
+			case 10: bl = val; break;
+			default: break;
+			}
+			++t; fstart = pos + 1;
+			nstate = 0; neg = false; ovf = false; acc = 0; h = FNV_OFF; nlen = 0; nstop = false;
+		}
+		valid = t >= 10;
+		const uint32_t hasbl = t >= 11;
+		pass = valid && !(qe - qs < (uint32_t)min_span || te - ts < (uint32_t)min_span || (int)ml < min_match); // hit.c:85
+		nobl = valid && !hasbl;
+		o.flags[i] = (uint8_t)(valid | pass << 1 | hasbl << 2 | (uint32_t)rev << 3);
+		f_hasbl[i] = hasbl;
+		o.ql[i] = ql; o.qs[i] = qs; o.qe[i] = qe; o.tl[i] = tl; o.ts[i] = ts; o.te[i] = te; o.ml[i] = ml; o.bl[i] = bl;
+		o.tnoff[i] = tnoff; o.qlen[i] = qlen; o.tlen[i] = tlen; o.hq[i] = hq; o.ht[i] = ht;
+		if (pass) mq = qs > ts ? qs : ts;
+	}
+	blk_add_u64(&ctr[PC_VALID], valid);
+	blk_add_u64(&ctr[PC_PASS], pass);
+	blk_add_u64(&ctr[PC_NOBL], nobl);
+	blk_max_u64(&ctr[PC_MAXQS], mq);
+}
+
+// the `bl` a 10-column line inherits: value of the nearest earlier line with an 11th column (paf.c leaves the field alone)
+__global__ __launch_bounds__(256) void k_paf_bl_compact(const uint32_t *__restrict__ f_hasbl, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ bl, uint32_t L, uint32_t *__restrict__ blv)
+{
+	uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < L && f_hasbl[i]) blv[pos[i]] = bl[i];
+}
+__global__ __launch_bounds__(256) void k_paf_bl_fill(const uint32_t *__restrict__ f_hasbl, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ blv, uint32_t L, uint32_t *__restrict__ bl)
+{
+	uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < L && !f_hasbl[i]) bl[i] = pos[i] ? blv[pos[i] - 1] : 0u;
+}
+
+// ------------------------------------------------------------------------------------------------ name dictionary
+
+__device__ __forceinline__ bool name_eq(const unsigned char *__restrict__ a, const unsigned char *__restrict__ b, uint32_t len)
+{
+	for (uint32_t k = 0; k < len; ++k) if (a[k] != b[k]) return false;
+	return true;
+}
+
+// One thread per stored line: query name, then target name.  Slot word = tag(32) | occurrence of the name's first
+// inserter; tmin[slot] = smallest occurrence (2*line + column) of the name = its first appearance in the file.
+__global__ __launch_bounds__(256) void k_dict_insert(const unsigned char *__restrict__ text, const uint64_t *__restrict__ lstart, uint32_t L, PafCols o,
+                                                      unsigned long long *__restrict__ tab, uint32_t *__restrict__ tmin, uint32_t mask, unsigned long long *__restrict__ ctr)
+{
+	uint32_t fail = 0;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < L; i += gridDim.x * 256u) {
+		if (!(o.flags[i] & 2)) continue;
+		const uint64_t ls = lstart[i];
+		for (uint32_t col = 0; col < 2; ++col) {
+			const uint64_t h = col ? o.ht[i] : o.hq[i];
+			const uint32_t len = col ? o.tlen[i] : o.qlen[i], occ = i * 2u + col;
+			const unsigned char *nm = text + ls + (col ? o.tnoff[i] : 0u);
+			const uint32_t tag = (uint32_t)(h >> 32);
+			uint32_t s = (uint32_t)h & mask, slot = 0xffffffffu;
+			for (uint32_t probe = 0; probe < PAF_PROBE_LIMIT; ++probe, s = (s + 1) & mask) {
+				unsigned long long e = tab[s];
+				if (e == PAF_EMPTY) {
+					e = atomicCAS(&tab[s], PAF_EMPTY, (unsigned long long)tag << 32 | occ);
+					if (e == PAF_EMPTY) { atomicMin(&tmin[s], occ); slot = s; break; }
+				}
+				if ((uint32_t)(e >> 32) == tag) {
+					const uint32_t r = (uint32_t)e, rl = r >> 1;
+					const uint32_t rlen = (r & 1) ? o.tlen[rl] : o.qlen[rl];
+					if (rlen == len && name_eq(nm, text + lstart[rl] + ((r & 1) ? o.tnoff[rl] : 0u), len)) {
+						if (tmin[s] > occ) atomicMin(&tmin[s], occ);
+						slot = s; break;
+					}
+				}
+			}
+			if (slot == 0xffffffffu) fail = 1;
+			if (col) o.tslot[i] = slot; else o.qslot[i] = slot;
+		}
+	}
+	blk_add_u64(&ctr[PC_OVERFLOW], fail);
+}
+
+__global__ __launch_bounds__(256) void k_dict_flag(const unsigned long long *__restrict__ tab, uint32_t cap, uint32_t *__restrict__ keep)
+{
+	uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s < cap) keep[s] = tab[s] != PAF_EMPTY;
+}
+__global__ __launch_bounds__(256) void k_dict_collect(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ tmin, uint32_t cap,
+                                                       uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+	uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s < cap && keep[s]) { key[pos[s]] = tmin[s]; val[pos[s]] = s; }
+}
+// names sorted by first appearance: rank = id (sdict.c:27-45); first-seen length, where the name's bytes are
+__global__ __launch_bounds__(256) void k_dict_assign(const uint64_t *__restrict__ key, const uint32_t *__restrict__ val, uint32_t R, const uint64_t *__restrict__ lstart, PafCols o,
+                                                      uint32_t *__restrict__ slot_id, uint32_t *__restrict__ seq_len, uint64_t *__restrict__ name_off, uint32_t *__restrict__ name_len,
+                                                      uint32_t *__restrict__ keep)
+{
+	uint32_t j = blockIdx.x * 256u + threadIdx.x;
+	if (j >= R) return;
+	const uint32_t occ = (uint32_t)key[j], line = occ >> 1, col = occ & 1;
+	slot_id[val[j]] = j;
+	seq_len[j] = col ? o.tl[line] : o.ql[line];
+	name_off[j] = lstart[line] + (col ? o.tnoff[line] : 0u);
+	const uint32_t len = col ? o.tlen[line] : o.qlen[line];
+	name_len[j] = len;
+	keep[j] = len + 1;
+}
+__global__ __launch_bounds__(256) void k_dict_names(const unsigned char *__restrict__ text, const uint64_t *__restrict__ name_off, const uint32_t *__restrict__ name_len,
+                                                     const uint32_t *__restrict__ name_pos, uint32_t R, char *__restrict__ out)
+{
+	uint32_t j = blockIdx.x * 256u + threadIdx.x;
+	if (j >= R) return;
+	const unsigned char *s = text + name_off[j];
+	char *d = out + name_pos[j];
+	const uint32_t len = name_len[j];
+	for (uint32_t k = 0; k < len; ++k) d[k] = (char)s[k];
+	d[len] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ records
+
+__global__ __launch_bounds__(256) void k_paf_ids(PafCols o, const uint32_t *__restrict__ slot_id, uint32_t L, int bi_dir, uint32_t *__restrict__ keep)
+{
+	uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= L) return;
+	uint32_t cnt = 0;
+	if (o.flags[i] & 2) {
+		const uint32_t qid = slot_id[o.qslot[i]], tid = slot_id[o.tslot[i]];
+		o.qslot[i] = qid; o.tslot[i] = tid;
+		cnt = 1 + (bi_dir && qid != tid); // hit.c:87-98
+	}
+	keep[i] = cnt;
+}
+
+__global__ __launch_bounds__(256) void k_paf_emit(PafCols o, const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, uint32_t L, uint4 *__restrict__ rec)
+{
+	uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= L || keep[i] == 0) return;
+	const uint32_t qid = o.qslot[i], tid = o.tslot[i];
+	const uint32_t mlrev = o.ml[i] | (uint32_t)(o.flags[i] >> 3 & 1) << 31, bl = o.bl[i] & 0x7fffffffu;
+	const size_t k = (size_t)pos[i] * 2;
+	rec[k] = make_uint4(o.qs[i], qid, o.qe[i], tid);       // qns = qid<<32 | qs ; qe ; tn
+	rec[k + 1] = make_uint4(o.ts[i], o.te[i], mlrev, bl);   // ts ; te ; ml|rev ; bl|del=0
+	if (keep[i] == 2) {
+		rec[k + 2] = make_uint4(o.ts[i], tid, o.te[i], qid);
+		rec[k + 3] = make_uint4(o.qs[i], o.qe[i], mlrev, bl);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ host entries
+
+static int paf_reserve_text(mahip_ctx *c, size_t nbytes)
+{
+	PafBufs *b = paf_of(c);
+	CHK(dev_reserve(c, b->text, nbytes + 64));
+	b->nbytes = nbytes;
+	b->loaded = false;
+	return 0;
+}
+
+extern "C" int mahip_paf_load_mem(mahip_ctx_t *c, const void *text, size_t nbytes)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	CHK(paf_reserve_text(c, nbytes));
+	CHK(xfer_copy(c, paf_of(c)->text.p, (void*)text, nbytes, 1));
+	paf_of(c)->loaded = true;
+	return 0;
+}
+
+extern "C" int mahip_paf_load_fd(mahip_ctx_t *c, int fd, size_t nbytes)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	CHK(paf_reserve_text(c, nbytes));
+	CHK(xfer_from_fd(c, paf_of(c)->text.p, fd, nbytes));
+	paf_of(c)->loaded = true;
+	return 0;
+}
+
+static uint32_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p > 0x80000000ull ? 0x80000000u : (uint32_t)p; }
+static int bits_of(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
+
+extern "C" int mahip_paf_parse(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, mahip_paf_info_t *info)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	PafBufs *b = paf_of(c);
+	if (!b->loaded) { mahip_set_error("mahip_paf_parse: no text loaded"); return -1; }
+	const size_t n = b->nbytes;
+	const unsigned char *text = P<unsigned char>(b->text);
+	unsigned long long *ctr = P<unsigned long long>(c->ctr);
+	memset(info, 0, sizeof(*info));
+	b->n_seq = 0; b->name_bytes = 0;
+
+	// ---- line starts
+	const size_t n_tiles = (n + PAF_TILE - 1) / PAF_TILE;
+	if (n_tiles > 0x7fffffffull) { mahip_set_error("mahip_paf_parse: text too large"); return -1; }
+	CHK(dev_reserve(c, b->tile, (n_tiles + 8) * 4));
+	CHK(dev_reserve(c, b->scal, 64));
+	CHK(ctr_zero(c));
+	uint32_t L = 0;
+	if (n) {
+		{
+			ProfScope ps(c, "k_paf_nl_count", (double)n);
+			hipLaunchKernelGGL(k_paf_nl_count, dim3((unsigned)n_tiles), dim3(256), 0, c->st, text, n, P<uint32_t>(b->tile));
+		}
+		CHK(scan_exclusive_u32(c, P<uint32_t>(b->tile), P<uint32_t>(b->tile), n_tiles, P<uint32_t>(b->scal)));
+		uint32_t n_nl = 0;
+		HIPCHK(hipMemcpyAsync(&n_nl, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));
+		if ((uint64_t)n_nl + 1 >= 0x7fffffffull) { mahip_set_error("mahip_paf_parse: more than 2^31 lines"); return -1; }
+		CHK(dev_reserve(c, b->lstart, ((size_t)n_nl + 4) * 8));
+		{
+			ProfScope ps(c, "k_paf_nl_pos", (double)n + 8.0 * (double)n_nl);
+			hipLaunchKernelGGL(k_paf_nl_pos, dim3((unsigned)n_tiles), dim3(256), 0, c->st, text, n, (const uint32_t*)P<uint32_t>(b->tile), (const uint32_t*)P<uint32_t>(b->scal), P<uint64_t>(b->lstart), ctr);
+		}
+		int open_line = 0;
+		{ // same decision as the kernel's, from the host's view of the counts: L = newlines + unterminated tail
+			unsigned char last = 0;
+			HIPCHK(hipMemcpyAsync(&last, text + n - 1, 1, hipMemcpyDeviceToHost, c->st));
+			HIPCHK(hipStreamSynchronize(c->st));
+			open_line = last != '\n';
+		}
+		L = n_nl + (uint32_t)open_line;
+		if (!open_line) { // terminated text: line L-1 ends at the last newline; lstart[L] was written by the scatter
+		}
+	}
+	PafCols o;
+	{
+		const size_t Lr = (size_t)L + 4;
+		CHK(dev_reserve(c, b->flags, Lr));
+		for (int k = 0; k < 8; ++k) CHK(dev_reserve(c, b->num[k], Lr * 4));
+		CHK(dev_reserve(c, b->tnoff, Lr * 4)); CHK(dev_reserve(c, b->qlen, Lr * 4)); CHK(dev_reserve(c, b->tlen, Lr * 4));
+		CHK(dev_reserve(c, b->hq, Lr * 8)); CHK(dev_reserve(c, b->ht, Lr * 8));
+		CHK(dev_reserve(c, b->qslot, Lr * 4)); CHK(dev_reserve(c, b->tslot, Lr * 4));
+		o.flags = P<uint8_t>(b->flags);
+		o.ql = P<uint32_t>(b->num[0]); o.qs = P<uint32_t>(b->num[1]); o.qe = P<uint32_t>(b->num[2]); o.tl = P<uint32_t>(b->num[3]);
+		o.ts = P<uint32_t>(b->num[4]); o.te = P<uint32_t>(b->num[5]); o.ml = P<uint32_t>(b->num[6]); o.bl = P<uint32_t>(b->num[7]);
+		o.tnoff = P<uint32_t>(b->tnoff); o.qlen = P<uint32_t>(b->qlen); o.tlen = P<uint32_t>(b->tlen);
+		o.hq = P<uint64_t>(b->hq); o.ht = P<uint64_t>(b->ht); o.qslot = P<uint32_t>(b->qslot); o.tslot = P<uint32_t>(b->tslot);
+	}
+	size_t n_valid = 0, n_pass = 0, n_nobl = 0;
+	uint32_t max_qs = 0;
+	if (L) {
+		CHK(dev_reserve(c, c->keep, ((size_t)L + 16) * 4)); CHK(dev_reserve(c, c->pos, ((size_t)L + 16) * 4));
+		{
+			ProfScope ps(c, "k_paf_parse", (double)n + 61.0 * (double)L);
+			hipLaunchKernelGGL(k_paf_parse, dim3(grid_for(L, 256)), dim3(256), PAF_LDS_BYTES + 32, c->st, text, n, (const uint64_t*)P<uint64_t>(b->lstart), L, min_span, min_match, o, P<uint32_t>(c->keep), ctr);
+		}
+		CHK(ctr_fetch(c));
+		n_valid = (size_t)c->h_ctr[PC_VALID]; n_pass = (size_t)c->h_ctr[PC_PASS]; n_nobl = (size_t)c->h_ctr[PC_NOBL];
+		max_qs = (uint32_t)c->h_ctr[PC_MAXQS];
+		if (n_nobl) { // stale bl: rare (PAF writers emit 12+ columns)
+			CHK(dev_reserve(c, b->blv, ((size_t)L + 4) * 4));
+			CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), L, nullptr));
+			hipLaunchKernelGGL(k_paf_bl_compact, dim3(grid_for(L, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (const uint32_t*)o.bl, L, P<uint32_t>(b->blv));
+			hipLaunchKernelGGL(k_paf_bl_fill, dim3(grid_for(L, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (const uint32_t*)P<uint32_t>(b->blv), L, o.bl);
+		}
+	}
+
+	// ---- dictionary: distinct names, ids in order of first appearance
+	uint32_t R = 0;
+	if (n_pass) {
+		uint32_t cap = pow2_at_least(n_pass / 2 + 65536);
+		for (int attempt = 0;; ++attempt) {
+			CHK(dev_reserve(c, b->tab, (size_t)cap * 8)); CHK(dev_reserve(c, b->tmin, (size_t)cap * 4)); CHK(dev_reserve(c, b->slot_id, (size_t)cap * 4));
+			HIPCHK(hipMemsetAsync(b->tab.p, 0xff, (size_t)cap * 8, c->st));
+			HIPCHK(hipMemsetAsync(b->tmin.p, 0xff, (size_t)cap * 4, c->st));
+			CHK(ctr_zero(c));
+			{
+				ProfScope ps(c, "k_dict_insert", 2.0 * 40.0 * (double)n_pass);
+				hipLaunchKernelGGL(k_dict_insert, dim3(grid_for(L, 256, 8192)), dim3(256), 0, c->st, text, (const uint64_t*)P<uint64_t>(b->lstart), L, o,
+				                   P<unsigned long long>(b->tab), P<uint32_t>(b->tmin), cap - 1, ctr);
+			}
+			CHK(ctr_fetch(c));
+			if (c->h_ctr[PC_OVERFLOW] == 0) break;
+			if (attempt >= 1 || cap >= 0x80000000u) { mahip_set_error("mahip_paf_parse: name table overflow"); return -1; }
+			cap = pow2_at_least(4 * (uint64_t)n_pass + 65536); // at most 2 names per stored line: load <= 1/2
+		}
+		CHK(dev_reserve(c, c->keep, ((size_t)cap + 16) * 4)); CHK(dev_reserve(c, c->pos, ((size_t)cap + 16) * 4));
+		hipLaunchKernelGGL(k_dict_flag, dim3(grid_for(cap, 256)), dim3(256), 0, c->st, (const unsigned long long*)P<unsigned long long>(b->tab), cap, P<uint32_t>(c->keep));
+		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), cap, P<uint32_t>(b->scal)));
+		HIPCHK(hipMemcpyAsync(&R, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));
+		for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], ((size_t)R + 1) * 8)); CHK(dev_reserve(c, c->val[k], ((size_t)R + 1) * 4)); }
+		hipLaunchKernelGGL(k_dict_collect, dim3(grid_for(cap, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (const uint32_t*)P<uint32_t>(b->tmin), cap,
+		                   P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
+		int gen = 0;
+		CHK(radix_sort_pairs(c, R, 0, bits_of(2ull * L), 0, 0, &gen));
+		CHK(dev_reserve(c, b->seq_len, ((size_t)R + 4) * 4)); CHK(dev_reserve(c, b->name_off, ((size_t)R + 4) * 8));
+		CHK(dev_reserve(c, b->name_len, ((size_t)R + 4) * 4)); CHK(dev_reserve(c, b->name_pos, ((size_t)R + 4) * 4));
+		hipLaunchKernelGGL(k_dict_assign, dim3(grid_for(R, 256)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[gen]), (const uint32_t*)P<uint32_t>(c->val[gen]), R,
+		                   (const uint64_t*)P<uint64_t>(b->lstart), o, P<uint32_t>(b->slot_id), P<uint32_t>(b->seq_len), P<uint64_t>(b->name_off), P<uint32_t>(b->name_len), P<uint32_t>(c->keep));
+		uint32_t nb = 0;
+		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(b->name_pos), R, P<uint32_t>(b->scal)));
+		HIPCHK(hipMemcpyAsync(&nb, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));
+		CHK(dev_reserve(c, b->names, (size_t)nb + 16));
+		hipLaunchKernelGGL(k_dict_names, dim3(grid_for(R, 256)), dim3(256), 0, c->st, text, (const uint64_t*)P<uint64_t>(b->name_off), (const uint32_t*)P<uint32_t>(b->name_len),
+		                   (const uint32_t*)P<uint32_t>(b->name_pos), R, P<char>(b->names));
+		b->name_bytes = nb;
+	}
+	b->n_seq = R;
+
+	// ---- records: hit (+ mirrored hit) per stored line, in line order
+	size_t n_hits = 0;
+	if (n_pass) {
+		CHK(dev_reserve(c, c->keep, ((size_t)L + 16) * 4)); CHK(dev_reserve(c, c->pos, ((size_t)L + 16) * 4));
+		hipLaunchKernelGGL(k_paf_ids, dim3(grid_for(L, 256)), dim3(256), 0, c->st, o, (const uint32_t*)P<uint32_t>(b->slot_id), L, bi_dir, P<uint32_t>(c->keep));
+		uint32_t nh = 0;
+		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), L, P<uint32_t>(b->scal)));
+		HIPCHK(hipMemcpyAsync(&nh, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));
+		n_hits = nh;
+	}
+	CHK(mahip_hits_adopt(c, nullptr, n_hits, R)); // resets the per-upload state and sizes the read arrays
+	CHK(dev_reserve(c, c->aos_own, (n_hits + 1) * sizeof(ma_hit_t)));
+	c->d_aos = (const ma_hit_t*)c->aos_own.p;
+	if (n_hits) {
+		ProfScope ps(c, "k_paf_emit", 45.0 * (double)n_pass + 32.0 * (double)n_hits);
+		hipLaunchKernelGGL(k_paf_emit, dim3(grid_for(L, 256)), dim3(256), 0, c->st, o, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), L, (uint4*)c->aos_own.p);
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(c->st));
+	c->hint_max_qs = max_qs;
+	info->n_records = n_valid; info->n_stored_lines = n_pass; info->n_hits = n_hits; info->n_seq = R; info->max_qs = max_qs; info->name_bytes = b->name_bytes; info->n_lines = L;
+	return 0;
+}
+
+extern "C" int mahip_paf_names(mahip_ctx_t *c, char *names, uint32_t *lens)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	PafBufs *b = paf_of(c);
+	if (b->n_seq == 0) return 0;
+	if (names) CHK(xfer_copy(c, b->names.p, names, b->name_bytes, 0));
+	if (lens) CHK(xfer_copy(c, b->seq_len.p, lens, (size_t)b->n_seq * 4, 0));
+	return 0;
+}
+
+// the text and the per-line columns are only needed until the records and the names are out
+extern "C" int mahip_paf_release(mahip_ctx_t *c)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	HIPCHK(hipStreamSynchronize(c->st));
+	paf_free(c);
+	return 0;
+}

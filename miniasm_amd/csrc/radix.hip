@@ -179,9 +179,9 @@ int reference_order(mahip_ctx *c, const uint64_t *d_keys, size_t n, uint32_t *d_
 	uint32_t *hp = (uint32_t*)malloc(n * 4);
 	if (!hk || !hp) { free(hk); free(hp); mahip_set_error("reference_order: out of host memory"); return -1; }
 	int rc = 0;
-	if (hipMemcpyAsync(hk, d_keys, n * 8, hipMemcpyDeviceToHost, c->st) != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess) rc = -1;
+	if (xfer_copy(c, (void*)d_keys, hk, n * 8, 0) != 0) rc = -1;
 	if (rc == 0 && ma_refsort_perm(hk, n, hp) != 0) rc = -1;
-	if (rc == 0 && (hipMemcpyAsync(d_perm, hp, n * 4, hipMemcpyHostToDevice, c->st) != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess)) rc = -1;
+	if (rc == 0 && xfer_copy(c, d_perm, hp, n * 4, 1) != 0) rc = -1;
 	free(hk); free(hp);
 	if (rc) mahip_set_error("reference_order: copy or host sort failed");
 	return rc;

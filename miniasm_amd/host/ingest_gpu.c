@@ -1,0 +1,107 @@
+/* ingest_gpu.c -- the text part of ma_hit_read (reference hit.c:70-101, paf.c, sdict.c) on the device.
+ *
+ * The host only moves bytes: a plain file goes from the page cache straight into pinned staging slots and on to
+ * HBM (mahip_paf_load_fd); gzip / stdin input is inflated into memory first (zlib, as the reference does through
+ * gzread) and uploaded.  Lines, columns, numbers, the span/match filter, the name dictionary with the reference's
+ * first-appearance ids and the (mirrored) hit records are all produced by csrc/paf.hip; what comes back is the
+ * dictionary (names + first-seen lengths, R entries) and, only for the per-symbol ABI, the records.
+ * Not used with an exclusion dictionary (-R): that pass and its lookups stay on the host reader.
+ * MA_HOST_PARSE=1 forces the host reader (ingest_mt.c / paf_reader.c); both are pinned to the same records and ids.
+ */
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+#include "ma_host.h"
+
+#define GPU(call) do { if ((call) != 0) ma_gpu_fail(__func__); } while (0)
+
+static char *slurp_gz(gzFile fp, size_t *len)
+{
+	size_t n = 0, m = 64u << 20;
+	char *buf = (char*)malloc(m);
+	for (;;) {
+		int got;
+		if (m - n < (16u << 20)) { m += m >> 1; buf = (char*)realloc(buf, m); }
+		got = gzread(fp, buf + n, (unsigned)((m - n) < (1u << 30) ? (m - n) : (1u << 30)));
+		if (got <= 0) break;
+		n += (size_t)got;
+	}
+	*len = n;
+	return buf;
+}
+
+int ma_gpu_parse_enabled(void)
+{
+	const char *s = getenv("MA_HOST_PARSE");
+	return !(s && atoi(s) != 0);
+}
+
+/* returns 0 and leaves the unsorted records in the context (as after mahip_hits_upload); -1 = could not open */
+int ma_hit_ingest_gpu(mahip_ctx_t *c, const char *fn, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir)
+{
+	const int timing = getenv("MA_PIPE_TIMING") != 0;
+	double t0 = sys_realtime(), t1, t2, t3;
+	mahip_paf_info_t info;
+	int fd = -1, is_plain = 0;
+	struct stat st;
+	size_t i, tot_len = 0;
+
+	if (fn && strcmp(fn, "-") != 0) {
+		unsigned char magic[2] = { 0, 0 };
+		fd = open(fn, O_RDONLY);
+		if (fd < 0) return -1;
+		if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+			ssize_t r = pread(fd, magic, 2, 0);
+			is_plain = !(r == 2 && magic[0] == 0x1f && magic[1] == 0x8b);
+		}
+	}
+	if (is_plain) {
+		GPU(mahip_paf_load_fd(c, fd, (size_t)st.st_size));
+		close(fd);
+	} else {
+		gzFile fp = fd >= 0 ? gzdopen(fd, "r") : gzdopen(fileno(stdin), "r");
+		size_t len = 0;
+		char *buf;
+		if (fp == 0) { if (fd >= 0) close(fd); return -1; }
+		gzbuffer(fp, 1u << 20);
+		buf = slurp_gz(fp, &len);
+		gzclose(fp);
+		GPU(mahip_paf_load_mem(c, buf, len));
+		free(buf);
+	}
+	t1 = sys_realtime();
+	GPU(mahip_set_shard(c, 0, 0xffffffffu));
+	GPU(mahip_paf_parse(c, min_span, min_match, bi_dir, &info));
+	t2 = sys_realtime();
+	/* the dictionary: names and first-seen lengths in id order */
+	{
+		char *names = (char*)malloc(info.name_bytes ? info.name_bytes : 1), *p;
+		uint32_t *lens = (uint32_t*)malloc(((size_t)info.n_seq + 1) * 4);
+		GPU(mahip_paf_names(c, names, lens));
+		for (i = 0; i < d->n_seq; ++i) free(d->seq[i].name);
+		d->n_seq = d->m_seq = info.n_seq;
+		d->seq = (sd_seq_t*)realloc(d->seq, ((size_t)info.n_seq + 1) * sizeof(sd_seq_t));
+		for (i = 0, p = names; i < info.n_seq; ++i) {
+			size_t l = strlen(p);
+			sd_seq_t *q = &d->seq[i];
+			q->name = (char*)malloc(l + 1);
+			memcpy(q->name, p, l + 1);
+			q->len = lens[i]; q->aux = 0; q->del = 0;
+			tot_len += lens[i];
+			p += l + 1;
+		}
+		ma_sd_drop_index(d); /* rebuilt on the first sd_get/sd_put (sd_squeeze builds its own) */
+		free(names); free(lens);
+	}
+	GPU(mahip_paf_release(c));
+	t3 = sys_realtime();
+	if (ma_verbose >= 3)
+		fprintf(MA_LOG, "[M::%s::%s] read %ld hits; stored %ld hits and %d sequences (%ld bp)\n", "ma_hit_read", sys_timestamp(), (long)info.n_records, (long)info.n_hits, d->n_seq, (long)tot_len);
+	if (timing) fprintf(stderr, "[T::ingest_gpu] load %.3f  parse %.3f  dictionary+release %.3f s (%.0f MB text, %lu lines)\n", t1 - t0, t2 - t1, t3 - t2, 0.0, (unsigned long)info.n_lines);
+	*n_hits = (size_t)info.n_hits;
+	return 0;
+}

@@ -35,6 +35,9 @@ ma_hit_t *ma_hit_ingest(const char *fn, int min_span, int min_match, sdict_t *d,
 /* chunk-parallel variant for plain files (ingest_mt.c); NULL when not eligible (gzip, stdin, small input, one thread) */
 ma_hit_t *ma_hit_ingest_mt(const char *fn, int min_span, int min_match, sdict_t *d, size_t *n, int bi_dir, const sdict_t *excl,
                            size_t *tot_lines, uint32_t *max_qs);
+/* the same on the device (ingest_gpu.c + csrc/paf.hip): records stay in the context; 0 ok, -1 cannot open */
+int ma_hit_ingest_gpu(mahip_ctx_t *c, const char *fn, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir);
+int ma_gpu_parse_enabled(void); /* 0 when MA_HOST_PARSE=1 */
 int ma_ingest_threads(void); /* MA_THREADS or the number of online cores, capped */
 uint32_t ma_ingest_max_qs(void); /* largest query start stored by the last ma_hit_ingest */
 

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "miniasm_amd.h"
+#include "ma_host.h"
 
 typedef struct {
 	uint32_t n_slot, n_used; /* n_slot is a power of two */
@@ -78,6 +79,7 @@ int32_t sd_get(const sdict_t *d, const char *name)
 {
 	const sd_index_t *ix = (const sd_index_t*)d->h;
 	uint32_t h = sd_hash_str(name), m, s;
+	if (ix == 0 && d->n_seq) { ma_sd_reindex((sdict_t*)d); ix = (const sd_index_t*)d->h; } /* index dropped by a bulk fill: build on first use */
 	if (ix == 0) return -1;
 	m = ix->n_slot - 1;
 	for (s = h & m; ix->id[s]; s = (s + 1) & m)
@@ -88,8 +90,10 @@ int32_t sd_get(const sdict_t *d, const char *name)
 int32_t sd_put(sdict_t *d, const char *name, uint32_t len)
 {
 	sd_index_t *ix = (sd_index_t*)d->h;
-	uint32_t h = sd_hash_str(name), m = ix->n_slot - 1, s;
+	uint32_t h = sd_hash_str(name), m, s;
 	sd_seq_t *q;
+	if (ix == 0) { ma_sd_reindex(d); ix = (sd_index_t*)d->h; }
+	m = ix->n_slot - 1;
 	for (s = h & m; ix->id[s]; s = (s + 1) & m)
 		if (ix->hv[s] == h && strcmp(d->seq[ix->id[s] - 1].name, name) == 0) return (int32_t)(ix->id[s] - 1);
 	if (d->n_seq == d->m_seq) {

@@ -12,6 +12,7 @@
 #define _GNU_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include <string.h>
 #include "ma_host.h"
 
@@ -281,10 +282,17 @@ int ma_pipeline_tail_mem(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, 
 	return rc;
 }
 
+static void *gpu_warmup(void *arg) { (void)arg; (void)ma_gpu(); return 0; }
+static void *free_bg(void *p) { free(p); return 0; }
+
 int ma_pipeline_run(const ma_opt_t *opt, const char *fn, const char *outfmt, int stage, int flags, FILE *out)
 {
 	sdict_t *d = sd_init(), *excl = 0;
-	mahip_ctx_t *c = ma_gpu(); /* fail before parsing gigabytes of text if there is no GPU */
+	mahip_ctx_t *c;
+	pthread_t th_gpu, th_free;
+	/* the GPU context comes up (HIP runtime, code objects: 0.1-0.3 s) while the host parses; a machine without a GPU
+	 * still fails before any result is produced */
+	const int gpu_bg = pthread_create(&th_gpu, 0, gpu_warmup, 0) == 0;
 	ma_hit_t *hit;
 	size_t n_hits = 0;
 	FILE *lg = MA_LOG;
@@ -293,12 +301,29 @@ int ma_pipeline_run(const ma_opt_t *opt, const char *fn, const char *outfmt, int
 		excl = ma_hit_no_cont(fn, opt->min_span, opt->min_match, opt->max_hang, opt->int_frac);
 	}
 	fprintf(lg, "[M::%s] ===> Step 1: reading read mappings <===\n", "main");
-	hit = ma_hit_ingest(fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), excl);
-	GPU(mahip_set_shard(c, 0, 0xffffffffu));
-	GPU(mahip_hits_upload(c, hit, n_hits, d->n_seq));
-	GPU(mahip_set_hints(c, ma_ingest_max_qs()));
-	GPU(mahip_sync(c));
-	free(hit);
+	if (excl == 0 && ma_gpu_parse_enabled()) { /* text -> records + dictionary on the device (csrc/paf.hip) */
+		if (gpu_bg) pthread_join(th_gpu, 0);
+		c = ma_gpu();
+		if (ma_hit_ingest_gpu(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4)) != 0) {
+			fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn);
+			exit(1);
+		}
+	} else {
+		const int timing = getenv("MA_PIPE_TIMING") != 0;
+		double t0 = sys_realtime(), t1, t2;
+		hit = ma_hit_ingest(fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), excl);
+		if (gpu_bg) pthread_join(th_gpu, 0);
+		c = ma_gpu();
+		t1 = sys_realtime();
+		GPU(mahip_set_shard(c, 0, 0xffffffffu));
+		GPU(mahip_hits_upload(c, hit, n_hits, d->n_seq));
+		GPU(mahip_set_hints(c, ma_ingest_max_qs()));
+		GPU(mahip_sync(c));
+		t2 = sys_realtime();
+		if (pthread_create(&th_free, 0, free_bg, hit) == 0) pthread_detach(th_free); /* returning 640 MB to the OS takes 60 ms: off the critical path */
+		else free(hit);
+		if (timing) fprintf(stderr, "[T::pipeline] ingest %.3f s  upload %.3f s (%.1f GB/s)\n", t1 - t0, t2 - t1, (double)n_hits * 32 / (t2 - t1 + 1e-12) / 1e9);
+	}
 	ma_pipeline_device(c, opt, d, outfmt, stage, flags, out);
 	sd_destroy(d);
 	if (excl) sd_destroy(excl);

@@ -1,0 +1,130 @@
+"""Device-side PAF ingest (csrc/paf.hip: lines, columns, strtol numbers, filter, name dictionary with first-appearance
+ids, mirrored records) against the host reader -- which tests/test_host_vs_ref.py pins to the reference's paf.c /
+sdict.c / hit.c:70-101 on the CPU -- and against the reference library itself: same records in the same order, same
+names, same ids, same first-seen lengths, same counters."""
+import ctypes as C
+import gzip
+import os
+import random
+
+import numpy as np
+import pytest
+
+import miniasm_amd as ma
+import refapi as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_as_host(ctx, path, opt=None, bi_dir=True):
+    host = ma.Ingest(path, opt, bi_dir)
+    dev = ma.GpuIngest(ctx, path, opt, bi_dir)
+    assert dev.n == host.n and dev.n_seq == host.n_seq, (dev.n, host.n, dev.n_seq, host.n_seq)
+    assert dev.names() == host.names()
+    assert list(dev.lens()) == list(host.lens())
+    assert dev.hits.tobytes() == host.hits.tobytes(), "records differ (or their order)"
+    host.close(); dev.close()
+    return dev.n
+
+
+def _adversarial(path, seed=5):
+    """every reader quirk the reference has: CRLF, 10-column lines (stale bl), short/junk/empty lines, signs, blanks,
+    junk after digits, numbers that overflow 32 and 64 bits, 13+ columns, a NUL inside a name, names that are prefixes of
+    each other, self hits, no newline at the end"""
+    rnd = random.Random(seed)
+    names = ["r%d" % i for i in range(300)] + ["r1", "r10", "r100", "r1000", "x", "xx", "x" * 300, "read with space", "r\x001"]
+    lines = []
+    for k in range(40000):
+        q, t = rnd.choice(names), rnd.choice(names)
+        ql, tl = rnd.randint(3000, 20000), rnd.randint(3000, 20000)
+        qs = rnd.randint(0, ql // 2); qe = rnd.randint(qs, ql)
+        ts = rnd.randint(0, tl // 2); te = rnd.randint(ts, tl)
+        ml = rnd.randint(0, 3000); bl = rnd.randint(ml, ml + 5000)
+        f = [q, str(ql), str(qs), str(qe), rnd.choice("+-"), t, str(tl), str(ts), str(te), str(ml), str(bl), "255"]
+        x = rnd.random()
+        if x < 0.03: f = f[:10]                                   # stale bl
+        elif x < 0.05: f = f[:rnd.randint(1, 9)]                   # skipped
+        elif x < 0.06: f = []                                      # empty line
+        elif x < 0.08: f[2] = " " + f[2]; f[3] = "+" + f[3]        # strtol blanks and sign
+        elif x < 0.09: f[7] = "-" + f[7]                           # negative -> wraps
+        elif x < 0.10: f[9] = f[9] + "abc"                         # junk after digits
+        elif x < 0.105: f[1] = "99999999999"                       # > 32 bits: truncated
+        elif x < 0.11: f[6] = "99999999999999999999999"            # > 64 bits: saturates
+        elif x < 0.115: f[10] = "-99999999999999999999999"
+        elif x < 0.12: f[4] = ""                                   # empty strand column
+        elif x < 0.13: f += ["tp:A:P", "cm:i:5"]
+        elif x < 0.135: f[8] = "x12"                               # no digits -> 0
+        ln = "\t".join(f)
+        if rnd.random() < 0.05: ln += "\r"
+        lines.append(ln)
+    with open(path, "wb") as g:
+        g.write("\n".join(lines).encode("latin-1"))                # no trailing newline
+    return path
+
+
+def test_ingest_clean_inputs(tmpdir_s):
+    ctx = ma.Ctx(0)
+    for reads, lines, seed, extra in ((3000, 80000, 41, []), (20000, 1000000, 3, ["-L", "uniform", "-d", "0.2"]), (50, 200, 9, [])):
+        paf = R.pafgen(os.path.join(tmpdir_s, "gi_%d.paf" % seed), reads, lines, seed, extra)
+        assert _same_as_host(ctx, paf) > 0
+        _same_as_host(ctx, paf, bi_dir=False)
+    ctx.close()
+
+
+def test_ingest_adversarial_text(tmpdir_s):
+    ctx = ma.Ctx(0)
+    paf = _adversarial(os.path.join(tmpdir_s, "gi_adv.paf"))
+    n = _same_as_host(ctx, paf)
+    assert n > 1000
+    opt = ma.default_opt(); opt.min_span = 500; opt.min_match = 10
+    _same_as_host(ctx, paf, opt)
+    # with a trailing newline, with only junk, empty, one line
+    data = open(paf, "rb").read()
+    for k, blob in enumerate((data + b"\n", b"junk\tline\nmore junk\n", b"", b"\n\n\n", data.split(b"\n")[0], data.split(b"\n")[0] + b"\n")):
+        p = os.path.join(tmpdir_s, "gi_edge%d.paf" % k)
+        open(p, "wb").write(blob)
+        _same_as_host(ctx, p, opt)
+    ctx.close()
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+def test_ingest_matches_reference_library(tmpdir_s):
+    """straight against the reference's ma_hit_read (sorted there, so compare canonicalised records) and its dictionary"""
+    ctx = ma.Ctx(0)
+    paf = _adversarial(os.path.join(tmpdir_s, "gi_adv2.paf"), seed=11)
+    opt = ma.default_opt(); opt.min_span = 500; opt.min_match = 10
+    LR = R.ref()
+    d = LR.sd_init()
+    n = C.c_size_t(0)
+    q = LR.ma_hit_read(paf.encode(), opt.min_span, opt.min_match, d, C.byref(n), 1, None)
+    ref_hits = R.np_from(q, n.value, ma.HIT_DT)
+    ref_hits["bldel"] &= 0x7FFFFFFF
+    dev = ma.GpuIngest(ctx, paf, opt)
+    assert dev.n == n.value
+    assert dev.names() == [d.contents.seq[i].name.decode("latin-1") for i in range(d.contents.n_seq)] or \
+        [x.encode() for x in dev.names()] == [d.contents.seq[i].name for i in range(d.contents.n_seq)]
+    assert list(dev.lens()) == [d.contents.seq[i].len for i in range(d.contents.n_seq)]
+    assert R.canon(dev.hits).tobytes() == R.canon(ref_hits).tobytes()
+    dev.close(); ctx.close()
+
+
+def test_ingest_gz_and_cli_paths_agree(tmpdir_s, monkeypatch):
+    """gzip input goes through the inflate-then-upload branch; the CLI output with the device parser equals the one with
+    the host reader for every dump"""
+    paf = R.pafgen(os.path.join(tmpdir_s, "gi_cli.paf"), 4000, 90000, 63, ["-L", "uniform", "-d", "0.35", "-x", "0.03"])
+    gz = paf + ".gz"
+    with open(paf, "rb") as f, gzip.open(gz, "wb") as g:
+        g.write(f.read())
+    ctx = ma.Ctx(0)
+    a = ma.GpuIngest(ctx, paf); b = ma.GpuIngest(ctx, gz)
+    assert a.n == b.n and a.names() == b.names()
+    a.close(); b.close(); ctx.close()
+    for args in (["-p", "bed"], ["-p", "paf"], ["-p", "sg", "-S5"], ["-p", "ug"], ["-b"], ["-1", "-2", "-p", "sg"]):
+        monkeypatch.setenv("MA_HOST_PARSE", "1")
+        host_out, host_log = R.run_cli(ma.CLI_PATH, args, paf)
+        monkeypatch.delenv("MA_HOST_PARSE")
+        dev_out, dev_log = R.run_cli(ma.CLI_PATH, args, paf)
+        assert dev_out == host_out, args
+        assert R.counters(dev_log) == R.counters(host_log), args
+    r_out, _ = R.run_cli(ma.CLI_PATH, ["-p", "ug"], gz)
+    assert r_out == R.run_cli(ma.CLI_PATH, ["-p", "ug"], paf)[0]

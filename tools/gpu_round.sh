@@ -14,6 +14,9 @@ tests)
 cli)
   timeout 1500 python -m pytest tests/test_gpu_cli.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/tests_cli.log 2>&1; echo "rc=$?" >> gpurun_out/tests_cli.log
   grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_cli.log | tail -60 ;;
+ingest)
+  timeout 1500 python -m pytest tests/test_gpu_ingest.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/tests_ingest.log 2>&1; echo "rc=$?" >> gpurun_out/tests_ingest.log
+  grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_ingest.log | tail -60 ;;
 sharded)
   timeout 1500 python -m pytest tests/test_gpu_sharded.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/tests_sharded.log 2>&1; echo "rc=$?" >> gpurun_out/tests_sharded.log
   grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_sharded.log | tail -40 ;;
