@@ -91,6 +91,10 @@ def lib():
         L.mahip_set_exact_ties.argtypes = [vp, i32]
         L.mahip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
         L.mahip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+        L.mahip_paf_release.argtypes = [vp]
+        L.mahip_paf_load_fd.argtypes = [vp, i32, sz]
+        L.mahip_paf_load_mem.argtypes = [vp, vp, sz]
+        L.mahip_hits_raw_download.argtypes = [vp, vp]
         L.mahip_hits_sort.argtypes = [vp]
         L.mahip_hits_index.argtypes = [vp]
         L.mahip_hits_sub.argtypes = [vp, i32, C.c_float, i32, i32, C.POINTER(sz)]

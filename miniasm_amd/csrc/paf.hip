@@ -16,6 +16,7 @@
 // compaction of the lines that have one plus a prefix count; record slots = prefix sum of 1-or-2 per line.
 // All HBM-bound byte/integer work: text is read once (through LDS tiles), per-line columns are 61 B.
 #include "mahip_internal.hpp"
+#include <time.h>
 
 #define PAF_TILE 4096u            // bytes per block in the newline passes (256 threads x 16 B)
 #define PAF_LDS_BYTES 49152u      // text of 256 consecutive lines is staged in LDS when it fits
@@ -344,7 +345,14 @@ __global__ __launch_bounds__(256) void k_paf_emit(PafCols o, const uint32_t *__r
 static int paf_reserve_text(mahip_ctx *c, size_t nbytes)
 {
 	PafBufs *b = paf_of(c);
+	const bool timing = getenv("MA_PIPE_TIMING") != nullptr;
+	struct timespec ts0, ts1;
+	if (timing) clock_gettime(CLOCK_MONOTONIC, &ts0);
 	CHK(dev_reserve(c, b->text, nbytes + 64));
+	if (timing) {
+		clock_gettime(CLOCK_MONOTONIC, &ts1);
+		fprintf(stderr, "[T::paf] hipMalloc of the text buffer: %.3f s\n", (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec));
+	}
 	b->nbytes = nbytes;
 	b->loaded = false;
 	return 0;

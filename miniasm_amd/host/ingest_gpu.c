@@ -40,40 +40,14 @@ int ma_gpu_parse_enabled(void)
 	return !(s && atoi(s) != 0);
 }
 
-/* returns 0 and leaves the unsorted records in the context (as after mahip_hits_upload); -1 = could not open */
-int ma_hit_ingest_gpu(mahip_ctx_t *c, const char *fn, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir)
+/* parse the text already loaded into the context (mahip_paf_load_*): records stay on the device, the dictionary is
+ * rebuilt in d (which must be empty or a previous result of this function); release = free the text afterwards */
+int ma_hit_ingest_loaded(mahip_ctx_t *c, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir, int release)
 {
 	const int timing = getenv("MA_PIPE_TIMING") != 0;
-	double t0 = sys_realtime(), t1, t2, t3;
+	double t1 = sys_realtime(), t2, t3;
 	mahip_paf_info_t info;
-	int fd = -1, is_plain = 0;
-	struct stat st;
 	size_t i, tot_len = 0;
-
-	if (fn && strcmp(fn, "-") != 0) {
-		unsigned char magic[2] = { 0, 0 };
-		fd = open(fn, O_RDONLY);
-		if (fd < 0) return -1;
-		if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
-			ssize_t r = pread(fd, magic, 2, 0);
-			is_plain = !(r == 2 && magic[0] == 0x1f && magic[1] == 0x8b);
-		}
-	}
-	if (is_plain) {
-		GPU(mahip_paf_load_fd(c, fd, (size_t)st.st_size));
-		close(fd);
-	} else {
-		gzFile fp = fd >= 0 ? gzdopen(fd, "r") : gzdopen(fileno(stdin), "r");
-		size_t len = 0;
-		char *buf;
-		if (fp == 0) { if (fd >= 0) close(fd); return -1; }
-		gzbuffer(fp, 1u << 20);
-		buf = slurp_gz(fp, &len);
-		gzclose(fp);
-		GPU(mahip_paf_load_mem(c, buf, len));
-		free(buf);
-	}
-	t1 = sys_realtime();
 	GPU(mahip_set_shard(c, 0, 0xffffffffu));
 	GPU(mahip_paf_parse(c, min_span, min_match, bi_dir, &info));
 	t2 = sys_realtime();
@@ -97,11 +71,52 @@ int ma_hit_ingest_gpu(mahip_ctx_t *c, const char *fn, int min_span, int min_matc
 		ma_sd_drop_index(d); /* rebuilt on the first sd_get/sd_put (sd_squeeze builds its own) */
 		free(names); free(lens);
 	}
-	GPU(mahip_paf_release(c));
+	if (release) GPU(mahip_paf_release(c));
 	t3 = sys_realtime();
 	if (ma_verbose >= 3)
 		fprintf(MA_LOG, "[M::%s::%s] read %ld hits; stored %ld hits and %d sequences (%ld bp)\n", "ma_hit_read", sys_timestamp(), (long)info.n_records, (long)info.n_hits, d->n_seq, (long)tot_len);
-	if (timing) fprintf(stderr, "[T::ingest_gpu] load %.3f  parse %.3f  dictionary+release %.3f s (%.0f MB text, %lu lines)\n", t1 - t0, t2 - t1, t3 - t2, 0.0, (unsigned long)info.n_lines);
+	if (timing) fprintf(stderr, "[T::ingest_gpu] parse %.3f  dictionary%s %.3f s (%lu lines)\n", t2 - t1, release ? "+release" : "", t3 - t2, (unsigned long)info.n_lines);
 	*n_hits = (size_t)info.n_hits;
 	return 0;
+}
+
+/* file -> HBM; 0 ok, -1 = could not open */
+int ma_paf_load_file(mahip_ctx_t *c, const char *fn)
+{
+	int fd = -1, is_plain = 0;
+	struct stat st;
+	if (fn && strcmp(fn, "-") != 0) {
+		unsigned char magic[2] = { 0, 0 };
+		fd = open(fn, O_RDONLY);
+		if (fd < 0) return -1;
+		if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+			ssize_t r = pread(fd, magic, 2, 0);
+			is_plain = !(r == 2 && magic[0] == 0x1f && magic[1] == 0x8b);
+		}
+	}
+	if (is_plain) {
+		GPU(mahip_paf_load_fd(c, fd, (size_t)st.st_size));
+		close(fd);
+	} else {
+		gzFile fp = fd >= 0 ? gzdopen(fd, "r") : gzdopen(fileno(stdin), "r");
+		size_t len = 0;
+		char *buf;
+		if (fp == 0) { if (fd >= 0) close(fd); return -1; }
+		gzbuffer(fp, 1u << 20);
+		buf = slurp_gz(fp, &len);
+		gzclose(fp);
+		GPU(mahip_paf_load_mem(c, buf, len));
+		free(buf);
+	}
+	return 0;
+}
+
+/* returns 0 and leaves the unsorted records in the context (as after mahip_hits_upload); -1 = could not open */
+int ma_hit_ingest_gpu(mahip_ctx_t *c, const char *fn, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir)
+{
+	const int timing = getenv("MA_PIPE_TIMING") != 0;
+	double t0 = sys_realtime();
+	if (ma_paf_load_file(c, fn) != 0) return -1;
+	if (timing) fprintf(stderr, "[T::ingest_gpu] load %.3f s\n", sys_realtime() - t0);
+	return ma_hit_ingest_loaded(c, min_span, min_match, d, n_hits, bi_dir, 1);
 }
