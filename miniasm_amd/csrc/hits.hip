@@ -98,11 +98,35 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 // depth sweep runs as one prefix scan over lanes plus a short in-register walk; the first-longest run is a
 // wave max-reduce on (length, -position).  Reads with more than 512 hits go to tier B.
 // Tier B: one 256-thread block per read, events in LDS (<= 8192) or in global scratch (any size).
+// grid of the coverage kernels (blocks of 4 waves, one read per wave at a time); env MA_SUB_BLOCKS for experiments
+static unsigned sub_blocks() { static unsigned v = 0; if (!v) { const char *e = getenv("MA_SUB_BLOCKS"); v = e ? (unsigned)atoi(e) : 2 * MA_STREAM_BLOCKS; /* 2 x the resident capacity: the dispatcher evens out the tail (measured 2048: 0.51, 4096: 0.46, 8192: 0.45 ms; more blocks = more end-of-block atomics) */ if (v < 1) v = 1; } return v; }
+#define MA_SUB_BLOCKS sub_blocks()
 #define EV_PAD 0xffffffffu
 #define SUB_REG_MAX_HITS 512u
 #define SUB_LDS_EVENTS 8192u
 
 #define MA_CE(a, b) do { uint32_t lo_ = (a) < (b) ? (a) : (b), hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
+
+// Value of lane (lane ^ M) for a compile-time M.  Exchanges inside a row of 16 lanes are DPP modifiers of a VALU move
+// (quad_perm, row_half_mirror, row_mirror, row_ror, banked row_shl/shr): no LDS crossbar round trip, no s_waitcnt.
+// Only the exchanges across rows (16, 31, 63) go through ds_bpermute.
+__device__ __forceinline__ uint32_t lane_xor(uint32_t x, int m)
+{
+	const int v = (int)x;
+	switch (m) {
+	case 1: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+	case 2: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+	case 3: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x1B, 0xf, 0xf, true);  // quad_perm [3,2,1,0]
+	case 7: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true); // row_half_mirror
+	case 15: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true); // row_mirror
+	case 8: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true);  // row_ror:8
+	case 4: { // banks with lane bit 2 clear read lane+4 (row_shl:4), the others lane-4 (row_shr:4)
+		int t = __builtin_amdgcn_mov_dpp(v, 0x104, 0xf, 0x5, true);
+		return (uint32_t)__builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xa, false);
+	}
+	default: return __shfl_xor(x, m, 64);
+	}
+}
 
 // ascending sort of the 64*ITEMS values held blocked (element lane*ITEMS + r) across one wave
 template <int ITEMS>
@@ -123,17 +147,17 @@ __device__ __forceinline__ void wave_sort_regs(uint32_t (&x)[ITEMS], unsigned la
 			const bool lower = (lane & (L >> 1)) == 0;
 			uint32_t y[ITEMS];
 #pragma unroll
-			for (int r = 0; r < ITEMS; ++r) y[r] = __shfl_xor(x[ITEMS - 1 - r], L - 1, 64);
+			for (int r = 0; r < ITEMS; ++r) y[r] = lane_xor(x[ITEMS - 1 - r], L - 1);
 #pragma unroll
-			for (int r = 0; r < ITEMS; ++r) x[r] = lower ? (x[r] < y[r] ? x[r] : y[r]) : (x[r] < y[r] ? y[r] : x[r]);
+			for (int r = 0; r < ITEMS; ++r) x[r] = ((x[r] < y[r]) != lower) ? y[r] : x[r]; // lower half keeps the min, upper the max
 		}
 #pragma unroll
 		for (int m = L >> 2; m > 0; m >>= 1) { // half cleaners across lanes
 			const bool lower = (lane & m) == 0;
 #pragma unroll
 			for (int r = 0; r < ITEMS; ++r) {
-				uint32_t y = __shfl_xor(x[r], m, 64);
-				x[r] = lower ? (x[r] < y ? x[r] : y) : (x[r] < y ? y : x[r]);
+				uint32_t y = lane_xor(x[r], m);
+				x[r] = ((x[r] < y) != lower) ? y : x[r];
 			}
 		}
 #pragma unroll
@@ -715,9 +739,9 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 	SubFuse nofuse = {nullptr, 0, 0, 0, nullptr};
 	if (R) {
 		ProfScope ps(c, "k_hit_sub", 24.0 * (double)c->n_hits + 8.0 * R);
-		hipLaunchKernelGGL((k_hit_sub<false, true>), dim3(grid_for(R, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse);
-		hipLaunchKernelGGL((k_hit_sub<false, false>), dim3(grid_for(R, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, false>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse);
 	}
 	CHK(ctr_fetch(c));
@@ -751,9 +775,9 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
 	SubFuse f = {(const uint2*)P<uint2>(c->sub[cut_slot]), min_span, max_hang, min_ovlp, P<uint8_t>(c->r_live)};
 	if (R) {
 		ProfScope ps(c, "k_hit_sub<cut+flt>", (80.0 + 80.0 + 48.0) * (double)c->n_hits + 8.0 * R); // cut 80 + flt 80 + sub 48 B per hit
-		hipLaunchKernelGGL((k_hit_sub<true, true>), dim3(grid_for(R, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<true, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, f);
-		hipLaunchKernelGGL((k_hit_sub<true, false>), dim3(grid_for(R, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<true, false>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, f);
 	}
 	CHK(ctr_fetch(c));

@@ -5,6 +5,7 @@
  */
 #include <stdio.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include <string.h>
 #include "ma_host.h"
 
@@ -205,46 +206,111 @@ ma_ug_t *ma_ug_gen(asg_t *g) /* asm.c:121-210 */
 
 static inline void ob_utg(obuf_t *o, uint32_t id1, int circ) { ob_mem(o, "utg", 3); ob_int6(o, id1); ob_chr(o, "lc"[circ]); }
 
-void ma_ug_print(const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, FILE *fp) /* asm.c:77-116 */
+/* The three blocks of a unitig GFA (asm.c:77-116).  Formatting is bound by cache misses on names and intervals of reads
+ * scattered over the dictionary, so big outputs are formatted by several threads, each into its own buffer over a
+ * contiguous range of unitigs / links, and written in order: the text is the sequential one byte for byte. */
+static void fmt_units(obuf_t *o, const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, uint32_t lo, uint32_t hi)
 {
 	uint32_t i, j, l;
-	obuf_t o = {0, 0, 0, fp};
-	for (i = 0; i < ug->u.n; ++i) { /* S lines, circularising L lines, per-read a lines */
+	for (i = lo; i < hi; ++i) { /* S lines, circularising L lines, per-read a lines */
 		const ma_utg_t *p = &ug->u.a[i];
-		ob_mem(&o, "S\t", 2); ob_utg(&o, i + 1, p->circ); ob_chr(&o, '\t'); ob_str(&o, p->s ? p->s : "*"); ob_mem(&o, "\tLN:i:", 6); ob_int(&o, (int)p->len); ob_chr(&o, '\n');
+		ob_mem(o, "S\t", 2); ob_utg(o, i + 1, p->circ); ob_chr(o, '\t'); ob_str(o, p->s ? p->s : "*"); ob_mem(o, "\tLN:i:", 6); ob_int(o, (int)p->len); ob_chr(o, '\n');
 		if (p->circ) {
 			for (j = 0; j < 2; ++j) { /* "L\t%s\t+\t%s\t+\t0M\n" and the '-' twin */
 				char c = "+-"[j];
-				ob_mem(&o, "L\t", 2); ob_utg(&o, i + 1, p->circ); ob_chr(&o, '\t'); ob_chr(&o, c); ob_chr(&o, '\t');
-				ob_utg(&o, i + 1, p->circ); ob_chr(&o, '\t'); ob_chr(&o, c); ob_mem(&o, "\t0M\n", 4);
+				ob_mem(o, "L\t", 2); ob_utg(o, i + 1, p->circ); ob_chr(o, '\t'); ob_chr(o, c); ob_chr(o, '\t');
+				ob_utg(o, i + 1, p->circ); ob_chr(o, '\t'); ob_chr(o, c); ob_mem(o, "\t0M\n", 4);
 			}
 		}
 		for (j = l = 0; j < p->n; l += (uint32_t)p->a[j++]) { /* "a\t%s\t%d\t%s:%d-%d\t%c\t%d\n" */
-			ob_mem(&o, "a\t", 2); ob_utg(&o, i + 1, p->circ); ob_chr(&o, '\t'); ob_int(&o, (int)l); ob_chr(&o, '\t');
-			ob_read(&o, d, sub, (uint32_t)(p->a[j] >> 33)); ob_chr(&o, '\t'); ob_chr(&o, "+-"[p->a[j] >> 32 & 1]); ob_chr(&o, '\t');
-			ob_int(&o, (int)(uint32_t)p->a[j]); ob_chr(&o, '\n');
+			if (j + 4 < p->n) __builtin_prefetch(&d->seq[p->a[j + 4] >> 33]);
+			if (j + 2 < p->n) __builtin_prefetch(d->seq[p->a[j + 2] >> 33].name);
+			ob_mem(o, "a\t", 2); ob_utg(o, i + 1, p->circ); ob_chr(o, '\t'); ob_int(o, (int)l); ob_chr(o, '\t');
+			ob_read(o, d, sub, (uint32_t)(p->a[j] >> 33)); ob_chr(o, '\t'); ob_chr(o, "+-"[p->a[j] >> 32 & 1]); ob_chr(o, '\t');
+			ob_int(o, (int)(uint32_t)p->a[j]); ob_chr(o, '\n');
 		}
 	}
-	for (i = 0; i < ug->g->n_arc; ++i) { /* "L\tutg%.6d%c\t%c\tutg%.6d%c\t%c\t%dM\tSD:i:%d\n" */
+}
+
+static void fmt_links(obuf_t *o, const ma_ug_t *ug, uint32_t lo, uint32_t hi)
+{
+	uint32_t i;
+	for (i = lo; i < hi; ++i) { /* "L\tutg%.6d%c\t%c\tutg%.6d%c\t%c\t%dM\tSD:i:%d\n" */
 		const asg_arc_t *e = &ug->g->arc[i];
 		uint32_t u = (uint32_t)(e->ul >> 32), v = e->v;
-		ob_mem(&o, "L\t", 2); ob_utg(&o, (u >> 1) + 1, ug->u.a[u >> 1].circ); ob_chr(&o, '\t'); ob_chr(&o, "+-"[u & 1]); ob_chr(&o, '\t');
-		ob_utg(&o, (v >> 1) + 1, ug->u.a[v >> 1].circ); ob_chr(&o, '\t'); ob_chr(&o, "+-"[v & 1]); ob_chr(&o, '\t');
-		ob_int(&o, (int)e->ol); ob_mem(&o, "M\tSD:i:", 7); ob_int(&o, (int)asg_arc_len(*e)); ob_chr(&o, '\n');
+		ob_mem(o, "L\t", 2); ob_utg(o, (u >> 1) + 1, ug->u.a[u >> 1].circ); ob_chr(o, '\t'); ob_chr(o, "+-"[u & 1]); ob_chr(o, '\t');
+		ob_utg(o, (v >> 1) + 1, ug->u.a[v >> 1].circ); ob_chr(o, '\t'); ob_chr(o, "+-"[v & 1]); ob_chr(o, '\t');
+		ob_int(o, (int)e->ol); ob_mem(o, "M\tSD:i:", 7); ob_int(o, (int)asg_arc_len(*e)); ob_chr(o, '\n');
 	}
-	for (i = 0; i < ug->u.n; ++i) { /* x lines: unitig summary */
+}
+
+static void fmt_summary(obuf_t *o, const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, uint32_t lo, uint32_t hi)
+{
+	uint32_t i;
+	for (i = lo; i < hi; ++i) { /* x lines: unitig summary */
 		const ma_utg_t *u = &ug->u.a[i];
 		if (u->start == UINT32_MAX) { /* "x\tutg%.6dc\t%d\t%d\n" */
-			ob_mem(&o, "x\t", 2); ob_utg(&o, i + 1, 1); ob_chr(&o, '\t'); ob_int(&o, (int)u->len); ob_chr(&o, '\t'); ob_int(&o, (int)u->n); ob_chr(&o, '\n');
+			ob_mem(o, "x\t", 2); ob_utg(o, i + 1, 1); ob_chr(o, '\t'); ob_int(o, (int)u->len); ob_chr(o, '\t'); ob_int(o, (int)u->n); ob_chr(o, '\n');
 		} else { /* "x\tutg%.6dl\t%d\t%d\t%d\t%d\t%s:%d-%d\t%c\t%s:%d-%d\t%c\n" */
 			uint32_t c0 = asg_arc_n(ug->g, i << 1 | 0), c1 = asg_arc_n(ug->g, i << 1 | 1);
-			ob_mem(&o, "x\t", 2); ob_utg(&o, i + 1, 0); ob_chr(&o, '\t'); ob_int(&o, (int)u->len); ob_chr(&o, '\t'); ob_int(&o, (int)u->n); ob_chr(&o, '\t');
-			ob_int(&o, (int)c1); ob_chr(&o, '\t'); ob_int(&o, (int)c0); ob_chr(&o, '\t');
-			ob_read(&o, d, sub, u->start >> 1); ob_chr(&o, '\t'); ob_chr(&o, "+-"[u->start & 1]); ob_chr(&o, '\t');
-			ob_read(&o, d, sub, u->end >> 1); ob_chr(&o, '\t'); ob_chr(&o, "+-"[u->end & 1]); ob_chr(&o, '\n');
+			ob_mem(o, "x\t", 2); ob_utg(o, i + 1, 0); ob_chr(o, '\t'); ob_int(o, (int)u->len); ob_chr(o, '\t'); ob_int(o, (int)u->n); ob_chr(o, '\t');
+			ob_int(o, (int)c1); ob_chr(o, '\t'); ob_int(o, (int)c0); ob_chr(o, '\t');
+			ob_read(o, d, sub, u->start >> 1); ob_chr(o, '\t'); ob_chr(o, "+-"[u->start & 1]); ob_chr(o, '\t');
+			ob_read(o, d, sub, u->end >> 1); ob_chr(o, '\t'); ob_chr(o, "+-"[u->end & 1]); ob_chr(o, '\n');
 		}
 	}
-	ob_flush(&o);
+}
+
+typedef struct { const ma_ug_t *ug; const sdict_t *d; const ma_sub_t *sub; uint32_t u_lo, u_hi, l_lo, l_hi; obuf_t units, links, summary; } fmt_job_t;
+
+static void *fmt_worker(void *arg)
+{
+	fmt_job_t *j = (fmt_job_t*)arg;
+	fmt_units(&j->units, j->ug, j->d, j->sub, j->u_lo, j->u_hi);
+	fmt_links(&j->links, j->ug, j->l_lo, j->l_hi);
+	fmt_summary(&j->summary, j->ug, j->d, j->sub, j->u_lo, j->u_hi);
+	return 0;
+}
+
+#define FMT_MAX_THREADS 16
+void ma_ug_print(const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, FILE *fp) /* asm.c:77-116 */
+{
+	const uint32_t nu = (uint32_t)ug->u.n, nl = ug->g->n_arc;
+	uint64_t tot = 0, acc = 0;
+	uint32_t i;
+	int T, t, k;
+	fmt_job_t job[FMT_MAX_THREADS];
+	pthread_t th[FMT_MAX_THREADS];
+	int started[FMT_MAX_THREADS];
+	for (i = 0; i < nu; ++i) tot += ug->u.a[i].n + 2;
+	{
+		const char *e = getenv("MA_FMT_GRAIN"); /* lines per thread at least: about 0.3 ms of formatting */
+		long grain = e ? atol(e) : 6000;
+		T = (int)(tot / (uint64_t)(grain > 0 ? grain : 1));
+	}
+	k = ma_ingest_threads();
+	if (T > k) T = k;
+	if (T > FMT_MAX_THREADS) T = FMT_MAX_THREADS;
+	if (T < 1) T = 1;
+	memset(job, 0, sizeof(job));
+	for (t = 0, i = 0; t < T; ++t) { /* unitig ranges of about equal read count, link ranges of equal size */
+		uint64_t want = tot * (uint64_t)(t + 1) / (uint64_t)T;
+		job[t].ug = ug; job[t].d = d; job[t].sub = sub;
+		job[t].u_lo = i;
+		while (i < nu && (acc < want || t == T - 1)) acc += ug->u.a[i++].n + 2;
+		job[t].u_hi = i;
+		job[t].l_lo = (uint32_t)((uint64_t)nl * (uint64_t)t / (uint64_t)T);
+		job[t].l_hi = (uint32_t)((uint64_t)nl * (uint64_t)(t + 1) / (uint64_t)T);
+	}
+	for (t = 1; t < T; ++t) {
+		started[t] = pthread_create(&th[t], 0, fmt_worker, &job[t]) == 0;
+		if (!started[t]) fmt_worker(&job[t]);
+	}
+	fmt_worker(&job[0]);
+	for (t = 1; t < T; ++t) if (started[t]) pthread_join(th[t], 0);
+	for (t = 0; t < T; ++t) { job[t].units.fp = fp; ob_flush(&job[t].units); }
+	for (t = 0; t < T; ++t) { job[t].links.fp = fp; ob_flush(&job[t].links); }
+	for (t = 0; t < T; ++t) { job[t].summary.fp = fp; ob_flush(&job[t].summary); }
 }
 
 /* ---------------------------------------------------------------------------------------------- unitig sequences

@@ -35,6 +35,15 @@ bench)
 benchfixed)
   timeout 1500 python bench.py --model fixed --no-cpu > gpurun_out/bench_fixed.json 2> gpurun_out/bench_fixed.log; echo "rc=$?" >> gpurun_out/bench_fixed.log
   tail -3 gpurun_out/bench_fixed.log; cat gpurun_out/bench_fixed.json ;;
+sq)
+  # instruction-mix / occupancy counters of the coverage kernels (two passes: the SQ block has 8 counter slots)
+  i=0
+  for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE"; do
+    i=$((i+1)); rm -rf gpurun_out/sq_$i; mkdir -p gpurun_out/sq_$i
+    (cd /tmp && timeout 900 rocprofv3 --pmc $set --kernel-trace -d /root/repo/gpurun_out/sq_$i -o r --output-format csv -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu --no-text --prof-steps 0 > /root/repo/gpurun_out/sq_$i/bench.json 2> /root/repo/gpurun_out/sq_$i/bench.log); echo "sq set $i rc=$?"
+  done
+  python tools/pmc_generic.py gpurun_out/sq_1 gpurun_out/sq_2 gpurun_out/sq_3 --filter k_hit_sub > gpurun_out/sq_summary.txt 2>&1; cat gpurun_out/sq_summary.txt | head -80
+  find gpurun_out/sq_1 gpurun_out/sq_2 gpurun_out/sq_3 -name "*.csv" -size +8M -delete ;;
 benchexact)
   MA_EXACT_TIES=1 timeout 1500 python bench.py --no-cpu --steps 3 --warmup 1 --prof-steps 0 > gpurun_out/bench_exact.json 2> gpurun_out/bench_exact.log; echo "rc=$?" >> gpurun_out/bench_exact.log
   tail -3 gpurun_out/bench_exact.log; cat gpurun_out/bench_exact.json ;;
