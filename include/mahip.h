@@ -93,6 +93,9 @@ int mahip_hits_contained(mahip_ctx_t *c, const ma_opt_t *opt, const uint8_t *seq
 int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span, int max_hang, int min_ovlp, int min_dp, float min_iden, int end_clip,
                           int out_slot, size_t *n_cut, size_t *n_flt, float *cov, size_t *n_remained);
 int mahip_hits_cut_contained(mahip_ctx_t *c, int cut_slot, int min_span, const ma_opt_t *opt, size_t *n_cut, uint32_t *n_seq_new);
+/* its two halves for the sharded mode: the r_cont / r_used flags are max-all-reduced across ranks in between */
+int mahip_hits_cut_contained_flags(mahip_ctx_t *c, int cut_slot, int min_span, const ma_opt_t *opt);
+int mahip_hits_cut_contained_finish(mahip_ctx_t *c, size_t *n_cut, uint32_t *n_seq_new);
 
 int mahip_sub_upload(mahip_ctx_t *c, int slot, const ma_sub_t *sub, size_t n_sub);
 int mahip_sub_download(mahip_ctx_t *c, int slot, ma_sub_t *sub, int squeezed); /* squeezed: compacted by the contained map */

@@ -802,23 +802,33 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
 
 // resident pipeline: second ma_hit_cut (against cut_slot) + the flag pass of ma_hit_contained (against slot 0) in one sweep;
 // the squeeze of the hits is left to ma_sg_gen's pass (lazy), which is the next reader of the hits
-extern "C" int mahip_hits_cut_contained(mahip_ctx_t *c, int cut_slot, int min_span, const ma_opt_t *opt, size_t *n_cut, uint32_t *n_seq_new)
+// sharded mode runs it in two halves with the flag exchange (max-all-reduce of r_cont / r_used) in between
+extern "C" int mahip_hits_cut_contained_flags(mahip_ctx_t *c, int cut_slot, int min_span, const ma_opt_t *opt)
 {
 	HIPCHK(hipSetDevice(c->dev));
 	if (!c->soa_ready) { mahip_set_error("mahip_hits_cut_contained: hits not indexed"); return -1; }
 	size_t n = c->n_hits;
 	uint32_t R = c->n_seq;
 	CHK(ctr_zero(c));
-	CHK(dev_reserve(c, c->keep, ((size_t)R + 16) * 4));
 	HIPCHK(hipMemsetAsync(c->r_cont.p, 0, R, c->st));
 	HIPCHK(hipMemsetAsync(c->r_used.p, 0, R, c->st));
-	HIPCHK(hipMemsetAsync(c->r_del.p, 0, R, c->st));
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	if (n) {
 		ProfScope ps(c, "k_hit_cut_contained", (80.0 + 48.0) * (double)c->n_live);
 		hipLaunchKernelGGL(k_hit_cut_contained, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, cols_of(c), n, (const uint2*)P<uint2>(c->sub[cut_slot]), min_span,
 		                   (const uint2*)P<uint2>(c->sub[0]), opt->max_hang, opt->int_frac, opt->min_ovlp, P<uint8_t>(c->r_cont), P<uint8_t>(c->r_used), ctr);
 	}
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int mahip_hits_cut_contained_finish(mahip_ctx_t *c, size_t *n_cut, uint32_t *n_seq_new)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	uint32_t R = c->n_seq;
+	CHK(dev_reserve(c, c->keep, ((size_t)R + 16) * 4));
+	HIPCHK(hipMemsetAsync(c->r_del.p, 0, R, c->st));
+	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	uint32_t *d_tot = (uint32_t*)(ctr + CT_TOTAL);
 	if (R) {
 		hipLaunchKernelGGL(k_read_del, dim3(grid_for(R, 256)), dim3(256), 0, c->st, (const uint2*)P<uint2>(c->sub[0]), (const uint8_t*)P<uint8_t>(c->r_cont),
@@ -835,6 +845,12 @@ extern "C" int mahip_hits_cut_contained(mahip_ctx_t *c, int cut_slot, int min_sp
 	if (n_cut) *n_cut = c->n_live;
 	if (n_seq_new) *n_seq_new = c->n_seq_new;
 	return 0;
+}
+
+extern "C" int mahip_hits_cut_contained(mahip_ctx_t *c, int cut_slot, int min_span, const ma_opt_t *opt, size_t *n_cut, uint32_t *n_seq_new)
+{
+	CHK(mahip_hits_cut_contained_flags(c, cut_slot, min_span, opt));
+	return mahip_hits_cut_contained_finish(c, n_cut, n_seq_new);
 }
 
 extern "C" int mahip_hits_cut(mahip_ctx_t *c, int slot, int min_span, size_t *n_live)

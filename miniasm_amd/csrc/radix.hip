@@ -28,10 +28,21 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint64_t *__res
 	for (unsigned d = threadIdx.x; d <= mask; d += RS_THREADS) s_cnt[d] = 0;
 	__syncthreads();
 	size_t base = (size_t)blockIdx.x * RS_TILE;
-#pragma unroll 4
-	for (int it = 0; it < RS_ITEMS; ++it) {
-		size_t i = base + (size_t)it * RS_THREADS + threadIdx.x;
-		if (i < n) atomicAdd(&s_cnt[(unsigned)(key[i] >> shift) & mask], 1u);
+	if (base + RS_TILE <= n) { // full tile: two keys per 16-byte load, all loads in flight before the first LDS atomic
+		const ulonglong2 *p = (const ulonglong2*)(key + base);
+		ulonglong2 kk[RS_ITEMS / 2];
+#pragma unroll
+		for (int it = 0; it < RS_ITEMS / 2; ++it) kk[it] = p[it * RS_THREADS + threadIdx.x];
+#pragma unroll
+		for (int it = 0; it < RS_ITEMS / 2; ++it) {
+			atomicAdd(&s_cnt[(unsigned)(kk[it].x >> shift) & mask], 1u);
+			atomicAdd(&s_cnt[(unsigned)(kk[it].y >> shift) & mask], 1u);
+		}
+	} else {
+		for (int it = 0; it < RS_ITEMS; ++it) {
+			size_t i = base + (size_t)it * RS_THREADS + threadIdx.x;
+			if (i < n) atomicAdd(&s_cnt[(unsigned)(key[i] >> shift) & mask], 1u);
+		}
 	}
 	__syncthreads();
 	for (unsigned d = threadIdx.x; d <= mask; d += RS_THREADS) hist[(size_t)d * nb + blockIdx.x] = s_cnt[d];

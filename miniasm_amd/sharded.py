@@ -4,8 +4,8 @@ through torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
 The sequence below is the whole distributed algorithm:
 
     rank g owns reads [g*C, (g+1)*C), C = ceil(R / N), and every hit whose QUERY is one of them
-    sort | sub1 | all-gather sub | cut, flt | sub2 | all-gather sub2 | cut, merge
-    contained flags | max-all-reduce(r_cont), max-all-reduce(r_used) | squeeze (map identical on all ranks)
+    sort | sub1 | all-gather sub | [cut + flt + sub2 in one kernel] | all-gather sub2 | merge
+    [cut + contained flags in one kernel] | max-all-reduce(r_cont), max-all-reduce(r_used) | squeeze map (identical on all ranks)
     sg candidate arcs | max-all-reduce(seq.del) | local rm + sort            (rank order = global (u,len) order)
     ALL-GATHER OF THE ARC BLOCKS  ->  every rank holds the whole sorted graph + CSR index
     transitive reduction of the rank's own vertices | all-gather of the del flags | rank 0: cleanup, symm, download
@@ -56,6 +56,14 @@ class Comm:
     def sum_int(self, x, device):
         return sum(self.all_gather_int(x, device))
 
+    def sum_ints(self, xs, device):
+        """element-wise sum of a short list of integers over the ranks: one collective, one host sync"""
+        if self.world == 1:
+            return [int(x) for x in xs]
+        t = torch.tensor([int(x) for x in xs], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return [int(v) for v in t.tolist()]
+
 
 class GpuBackend:
     """the passes on one MI355X through the C ABI; buffers are cuda uint8 tensors.
@@ -94,6 +102,9 @@ class GpuBackend:
         L.mahip_asg_flags_out.argtypes = [vp, vp, sz, sz]
         L.mahip_asg_flags_in.argtypes = [vp, vp, sz, sz]
         L.mahip_asg_cleanup.argtypes = [vp, C.POINTER(u32)]
+        L.mahip_hits_cutflt_sub.argtypes = [vp, i32, i32, i32, i32, i32, C.c_float, i32, i32, C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_float), C.POINTER(sz)]
+        L.mahip_hits_cut_contained_flags.argtypes = [vp, i32, i32, C.POINTER(ma.MaOpt)]
+        L.mahip_hits_cut_contained_finish.argtypes = [vp, C.POINTER(sz), C.POINTER(u32)]
 
     def _chk(self, rc, what):
         self.ma._chk(rc, what)
@@ -118,6 +129,25 @@ class GpuBackend:
 
     def merge(self):
         self.ctx.sub_merge()
+
+    def cutflt_sub(self, opt):
+        """first cut (against slot 0) + filter + second coverage pass (into slot 1) in one kernel; returns reads kept"""
+        n_cut, n_flt, n_rem, cov = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_float(0)
+        self._chk(self.L.mahip_hits_cutflt_sub(self.h, 0, opt.min_span, int(opt.max_hang * 1.5), int(opt.min_ovlp * .5), opt.min_dp, opt.min_iden,
+                                               opt.min_span // 2, 1, C.byref(n_cut), C.byref(n_flt), C.byref(cov), C.byref(n_rem)), "cutflt_sub")
+        return n_rem.value
+
+    def cut_contained_flags(self, opt):
+        """second cut (against slot 1) + containment flags (against the merged slot 0) in one kernel"""
+        self._chk(self.L.mahip_hits_cut_contained_flags(self.h, 1, opt.min_span, C.byref(opt)), "cut_contained_flags")
+
+    def cut_contained_finish(self):
+        n, r = C.c_size_t(0), C.c_uint32(0)
+        self._chk(self.L.mahip_hits_cut_contained_finish(self.h, C.byref(n), C.byref(r)), "cut_contained_finish")
+        return r.value
+
+    def hits_live(self):
+        return int(self.L.mahip_hits_live(self.h))
 
     def copy_out(self, which, dst, first, count):
         self._chk(self.L.mahip_copy_out(self.h, which, dst.data_ptr(), first, count), "copy_out")
@@ -208,22 +238,20 @@ def _run_sharded(be, comm, opt, n_seq):
         comm.all_reduce_max_bytes(t)
         be.copy_in(which, t, 0, n_seq)
 
-    stats["n_rem1"] = comm.sum_int(be.sub(opt, 0, 0), dev)
+    # counters are kept local and summed once at the end: every blocking exchange of a scalar costs a host sync
+    loc_rem1 = be.sub(opt, 0, 0)
     exchange_sub(BUF_SUB0)
-    be.cut(opt, 0)
-    be.flt(opt, 0)
-    stats["n_rem2"] = comm.sum_int(be.sub(opt, 1, opt.min_span // 2), dev)
+    loc_rem2 = be.cutflt_sub(opt)          # hit.c:162-216 + second ma_hit_sub: needs the complete first-pass intervals
     exchange_sub(BUF_SUB1)
-    be.cut(opt, 1)
-    be.merge()
-    be.contained_flags(opt)
+    be.merge()                             # on the complete arrays, identical on every rank
+    be.cut_contained_flags(opt)            # second cut + hit.c:225-245 flags for the local hits
     exchange_flags(BUF_RCONT)
     exchange_flags(BUF_RUSED)
-    n_seq_new, n_live = be.contained_finish()
-    stats["n_seq_new"], stats["n_hits"] = n_seq_new, comm.sum_int(n_live, dev)
+    stats["n_seq_new"] = be.cut_contained_finish()
     be.sg_flags(opt)
     exchange_flags(BUF_SDEL)
     n_loc = be.sg_finish()
+    loc_hits = be.hits_live()
     if N > 1:  # the arc all-gather: blocks padded to the largest block
         counts = comm.all_gather_int(n_loc, dev)
         stride = max(max(counts), 1)
@@ -245,7 +273,8 @@ def _run_sharded(be, comm, opt, n_seq):
             if r != g and counts[r]:
                 be.flags_in(allfl, r * stride * 4, off, counts[r])
             off += counts[r]
-    stats["n_red"] = comm.sum_int(n_red, dev)
+    loc_rem1, loc_rem2, loc_hits, n_red = comm.sum_ints([loc_rem1, loc_rem2, loc_hits, n_red], dev)
+    stats["n_rem1"], stats["n_rem2"], stats["n_hits"], stats["n_red"] = loc_rem1, loc_rem2, loc_hits, n_red
     stats["n_multi"] = stats["n_asymm"] = 0
     if g == 0 and stats["n_red"]:
         be.cleanup()

@@ -95,6 +95,22 @@ class OracleBackend:
         self.hits = self.hits[(self.r_del[q] == 0) & (self.r_del[t] == 0)].copy()
         return int(keep.sum()), len(self.hits)
 
+    # the fused entries of the product (one kernel each there) as compositions of the oracle's passes
+    def cutflt_sub(self, opt):
+        self.cut(opt, 0)
+        self.flt(opt, 0)
+        return self.sub(opt, 1, opt.min_span // 2)
+
+    def cut_contained_flags(self, opt):  # the orchestration has merged the intervals already: cut against slot 1, classify against slot 0
+        self.cut(opt, 1)
+        self.contained_flags(opt)
+
+    def cut_contained_finish(self):
+        return self.contained_finish()[0]
+
+    def hits_live(self):
+        return len(self.hits)
+
     def sg_flags(self, opt):
         n = len(self.hits)
         self.cand = np.zeros(max(n, 1), ARC_DT)

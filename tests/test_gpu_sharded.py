@@ -50,6 +50,10 @@ class ThreadComm:
     def sum_int(self, x, device):
         return sum(self.all_gather_int(x, device))
 
+    def sum_ints(self, xs, device):
+        parts = self._exchange([int(x) for x in xs])
+        return [sum(p[k] for p in parts) for k in range(len(xs))]
+
 
 def _run_virtual_ranks(world, hits, n_seq, opt, ing):
     shared = _Shared(world)
