@@ -164,6 +164,8 @@ int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 	FILE *lg = MA_LOG;
 
 	const int timing = getenv("MA_PIPE_TIMING") != 0;
+	double ct_acc[5] = {0, 0, 0, 0, 0}; /* per-cleaner wall time (MA_PIPE_TIMING) */
+#define CT(k, call) __extension__ ({ double t0_ = sys_realtime(); int r_ = (call); ct_acc[k] += sys_realtime() - t0_; r_; })
 	double tt[8] = {0};
 #define TSTAMP(k) do { if (timing) tt[k] = sys_realtime(); } while (0)
 	TSTAMP(0);
@@ -199,33 +201,34 @@ int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 		TSTAMP(2);
 		if (stage >= 7) {
 			fprintf(lg, "[M::%s] ===> Step 4.2: initial tip cutting and bubble popping <===\n", "main");
-			asg_cut_tip(sg, opt->max_ext);
-			asg_pop_bubble(sg, opt->bub_dist);
+			CT(0, asg_cut_tip(sg, opt->max_ext));
+			CT(1, asg_pop_bubble(sg, opt->bub_dist));
 		}
 		if (stage >= 9) {
 			fprintf(lg, "[M::%s] ===> Step 4.3: cutting short overlaps (%d rounds in total) <===\n", "main", opt->n_rounds + 1);
 			for (i = 0; i <= opt->n_rounds; ++i) {
 				float r = opt->min_ovlp_drop_ratio + (opt->max_ovlp_drop_ratio - opt->min_ovlp_drop_ratio) / opt->n_rounds * i;
-				if (asg_arc_del_short(sg, r) != 0) {
-					asg_cut_tip(sg, opt->max_ext);
-					asg_pop_bubble(sg, opt->bub_dist);
+				if (CT(2, asg_arc_del_short(sg, r)) != 0) {
+					CT(0, asg_cut_tip(sg, opt->max_ext));
+					CT(1, asg_pop_bubble(sg, opt->bub_dist));
 				}
 			}
 		}
 		if (stage >= 10) {
 			fprintf(lg, "[M::%s] ===> Step 4.4: removing short internal sequences and bi-loops <===\n", "main");
-			asg_cut_internal(sg, 1);
-			asg_cut_biloop(sg, opt->max_ext);
-			asg_cut_tip(sg, opt->max_ext);
-			asg_pop_bubble(sg, opt->bub_dist);
+			CT(3, asg_cut_internal(sg, 1));
+			CT(4, asg_cut_biloop(sg, opt->max_ext));
+			CT(0, asg_cut_tip(sg, opt->max_ext));
+			CT(1, asg_pop_bubble(sg, opt->bub_dist));
 		}
 		if (stage >= 11) {
 			fprintf(lg, "[M::%s] ===> Step 4.5: aggressively cutting short overlaps <===\n", "main");
-			if (asg_arc_del_short(sg, opt->final_ovlp_drop_ratio) != 0) {
-				asg_cut_tip(sg, opt->max_ext);
-				asg_pop_bubble(sg, opt->bub_dist);
+			if (CT(2, asg_arc_del_short(sg, opt->final_ovlp_drop_ratio)) != 0) {
+				CT(0, asg_cut_tip(sg, opt->max_ext));
+				CT(1, asg_pop_bubble(sg, opt->bub_dist));
 			}
 		}
+		if (timing) fprintf(stderr, "[T::cleaners] cut_tip %.2f  pop_bubble %.2f  del_short(+cleanup+symm) %.2f  cut_internal %.2f  cut_biloop %.2f ms\n", ct_acc[0] * 1e3, ct_acc[1] * 1e3, ct_acc[2] * 1e3, ct_acc[3] * 1e3, ct_acc[4] * 1e3);
 		TSTAMP(3);
 		if (strcmp(outfmt, "ug") == 0) {
 			fprintf(lg, "[M::%s] ===> Step 5: generating unitigs <===\n", "main");

@@ -79,8 +79,14 @@ GRAPH_CASES = [
 
 
 @needs_ref
+@pytest.mark.parametrize("threads", [None, "5"], ids=["sequential", "speculative-5-threads"])
 @pytest.mark.parametrize("name,reads,lines,seed,extra", GRAPH_CASES, ids=[c[0] for c in GRAPH_CASES])
-def test_cleaners_unitigs_gfa_match_reference(name, reads, lines, seed, extra, tmpdir_s):
+def test_cleaners_unitigs_gfa_match_reference(name, reads, lines, seed, extra, threads, tmpdir_s, monkeypatch):
+    """threads != None forces the speculative multi-threaded sweeps (graph_host.c) on these small graphs: the graph must
+    still equal the reference's after EVERY cleaner call"""
+    if threads:
+        monkeypatch.setenv("MA_CLEAN_PAR_MIN", "0")
+        monkeypatch.setenv("MA_THREADS", threads)
     paf = R.pafgen(os.path.join(tmpdir_s, "h_%s.paf" % name), reads, lines, seed, extra)
     opt = ma.default_opt()
     S = ST.ref_stages(paf, opt)
