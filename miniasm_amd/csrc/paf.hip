@@ -132,14 +132,79 @@ __global__ __launch_bounds__(256) void k_paf_nl_pos(const unsigned char *__restr
 #define FNV_OFF 0xcbf29ce484222325ull
 #define FNV_PRIME 0x100000001b3ull
 
-__global__ __launch_bounds__(256) void k_paf_parse(const unsigned char *__restrict__ text, size_t n, const uint64_t *__restrict__ lstart, uint32_t L,
-                                                    int min_span, int min_match, PafCols o, uint32_t *__restrict__ f_hasbl, unsigned long long *__restrict__ ctr)
+// strtol(base 10) of the bytes [beg, end) of a column, truncated to 32 bits (paf.c:41-52 through the (uint32_t) casts)
+template <typename PTR>
+__device__ __forceinline__ uint32_t paf_num(PTR p, uint32_t beg, uint32_t end)
 {
-	extern __shared__ unsigned char s_text[];
+	uint32_t pos = beg, nd = 0;
+	unsigned ch = 0;
+	for (; pos < end; ++pos) { ch = p[pos]; if (!(ch == ' ' || (ch >= 0x0bu && ch <= 0x0du))) break; } // leading blanks (TAB / LF cannot occur inside a column)
+	bool neg = false, ovf = false;
+	if (pos < end && (ch == '+' || ch == '-')) { neg = ch == '-'; ++pos; }
+	uint64_t acc = 0;
+	for (; pos < end; ++pos, ++nd) {
+		const unsigned d = (unsigned)p[pos] - '0';
+		if (d >= 10u) break; // junk (or a NUL) ends the number
+		if (nd < 18) acc = acc * 10 + d; // 18 digits cannot overflow 63 bits
+		else {
+			const uint64_t lim = neg ? 0x8000000000000000ull : 0x7fffffffffffffffull;
+			if (ovf || acc > (lim - d) / 10) ovf = true; else acc = acc * 10 + d;
+		}
+	}
+	return ovf ? (neg ? 0u : 0xffffffffu) : (uint32_t)(neg ? (uint64_t)0 - acc : acc); // LONG_MIN -> 0, LONG_MAX -> 0xffffffff
+}
+
+// FNV-1a of a name column up to its first NUL (the reference handles names as C strings); *len = bytes hashed
+template <typename PTR>
+__device__ __forceinline__ uint64_t paf_name(PTR p, uint32_t beg, uint32_t end, uint32_t *len)
+{
+	uint64_t h = FNV_OFF;
+	uint32_t pos = beg;
+	for (; pos < end; ++pos) { const unsigned ch = p[pos]; if (ch == 0) break; h = (h ^ ch) * FNV_PRIME; }
+	*len = pos - beg;
+	return h;
+}
+
+struct PafLine { uint32_t valid, hasbl, rev, ql, qs, qe, tl, ts, te, ml, bl, tnoff, qlen, tlen; uint64_t hq, ht; };
+
+// One line: first the column starts (one pass over the bytes, starts kept in LDS), then each column with straight-line
+// code -- every lane is in the same routine at the same time, only the trip counts differ.
+template <typename PTR>
+__device__ __forceinline__ void paf_line(PTR p, uint32_t l, uint32_t *fs /* LDS, 12 entries, stride 1 */, PafLine &o)
+{
+	if (l > 1 && p[l - 1] == '\r') --l;
+	uint32_t t = 0;
+	fs[0] = 0;
+	for (uint32_t pos = 0; pos < l; ++pos)
+		if (p[pos] == '\t') { ++t; if (t < 12) fs[t] = pos + 1; }
+	++t; // columns
+	if (t < 12) fs[t] = l + 1; // end sentinel: column k is [fs[k], fs[k+1] - 1)
+	o.valid = t >= 10; o.hasbl = t >= 11;
+	o.rev = 0; o.ql = o.qs = o.qe = o.tl = o.ts = o.te = o.ml = o.bl = o.tnoff = o.qlen = o.tlen = 0; o.hq = o.ht = 0;
+	if (!o.valid) return; // the reference fills the columns it finds and drops the record: nothing of it is ever used
+	o.hq = paf_name(p, fs[0], fs[1] - 1, &o.qlen);
+	o.ql = paf_num(p, fs[1], fs[2] - 1);
+	o.qs = paf_num(p, fs[2], fs[3] - 1);
+	o.qe = paf_num(p, fs[3], fs[4] - 1);
+	o.rev = fs[4] < fs[5] - 1 && p[fs[4]] == '-';
+	o.tnoff = fs[5];
+	o.ht = paf_name(p, fs[5], fs[6] - 1, &o.tlen);
+	o.tl = paf_num(p, fs[6], fs[7] - 1);
+	o.ts = paf_num(p, fs[7], fs[8] - 1);
+	o.te = paf_num(p, fs[8], fs[9] - 1);
+	o.ml = paf_num(p, fs[9], fs[10] - 1) & 0x7fffffffu;
+	if (o.hasbl) o.bl = paf_num(p, fs[10], fs[11] - 1);
+}
+
+__global__ __launch_bounds__(256) void k_paf_parse(const unsigned char *__restrict__ text, size_t n, const uint64_t *__restrict__ lstart, uint32_t L,
+                                                    int min_span, int min_match, PafCols o, uint32_t *__restrict__ f_hasbl, unsigned long long *__restrict__ ctr, uint32_t lds_bytes)
+{
+	extern __shared__ unsigned char s_text[]; // lds_bytes (+ slack): sized by the host from the mean line length, so that several blocks fit a CU
+	__shared__ uint32_t s_fs[256 * 12];
 	const uint32_t i0 = blockIdx.x * 256u, i1 = i0 + 256u < L ? i0 + 256u : L;
 	const uint64_t b0 = lstart[i0], e1 = lstart[i1] - 1; // bytes of these lines: [b0, e1)
 	const uint64_t a0 = b0 & ~(uint64_t)15;
-	const bool in_lds = e1 - a0 <= PAF_LDS_BYTES;
+	const bool in_lds = e1 - a0 <= lds_bytes;
 	if (in_lds) {
 		for (uint64_t x = (uint64_t)threadIdx.x * 16; a0 + x < e1; x += 256 * 16) *(uint4*)(s_text + x) = load16(text, a0 + x, n);
 		__syncthreads();
@@ -149,65 +214,19 @@ __global__ __launch_bounds__(256) void k_paf_parse(const unsigned char *__restri
 	uint64_t mq = 0;
 	if (i < i1) {
 		const uint64_t ls = lstart[i];
-		uint32_t l = (uint32_t)(lstart[i + 1] - 1 - ls);
-		const unsigned char *p = in_lds ? (const unsigned char*)s_text + (ls - a0) : text + ls;
-		if (l > 1 && p[l - 1] == '\r') --l;
-		uint32_t t = 0, fstart = 0, nlen = 0, nstate = 0;
-		bool neg = false, ovf = false, nstop = false, rev = false;
-		uint64_t acc = 0, h = FNV_OFF;
-		uint32_t ql = 0, qs = 0, qe = 0, tl = 0, ts = 0, te = 0, ml = 0, bl = 0, tnoff = 0, qlen = 0, tlen = 0;
-		uint64_t hq = 0, ht = 0;
-		for (uint32_t pos = 0; pos <= l; ++pos) {
-			const unsigned ch = pos < l ? p[pos] : '\t';
-			if (ch != '\t') {
-				if (t == 0 || t == 5) { // name: bytes up to the first NUL (the reference handles names as C strings)
-					if (!nstop) { if (ch == 0) nstop = true; else h = (h ^ ch) * FNV_PRIME, ++nlen; }
-				} else if (t == 4) {
-					if (pos == fstart) rev = ch == '-';
-				} else if (t <= 10) { // strtol, base 10
-					const unsigned d = ch - '0';
-					if (nstate == 0) {
-						if (ch == ' ' || (ch >= 0x0b && ch <= 0x0d)) { /* leading blanks */ }
-						else if (ch == '+') nstate = 1;
-						else if (ch == '-') neg = true, nstate = 1;
-						else if (d < 10u) nstate = 1, acc = d;
-						else nstate = 2;
-					} else if (nstate == 1) {
-						if (d < 10u) {
-							const uint64_t lim = neg ? 0x8000000000000000ull : 0x7fffffffffffffffull;
-							if (ovf || acc > (lim - d) / 10) ovf = true; else acc = acc * 10 + d;
-						} else nstate = 2;
-					}
-				}
-				continue;
-			}
-			// end of column t
-			const uint32_t val = ovf ? (neg ? 0u : 0xffffffffu) : (uint32_t)(neg ? (uint64_t)0 - acc : acc);
-			switch (t) {
-			case 0: hq = h; qlen = nlen; break;
-			case 1: ql = val; break;
-			case 2: qs = val; break;
-			case 3: qe = val; break;
-			case 5: ht = h; tlen = nlen; tnoff = fstart; break;
-			case 6: tl = val; break;
-			case 7: ts = val; break;
-			case 8: te = val; break;
-			case 9: ml = val & 0x7fffffffu; break;
-			case 10: bl = val; break;
-			default: break;
-			}
-			++t; fstart = pos + 1;
-			nstate = 0; neg = false; ovf = false; acc = 0; h = FNV_OFF; nlen = 0; nstop = false;
-		}
-		valid = t >= 10;
-		const uint32_t hasbl = t >= 11;
-		pass = valid && !(qe - qs < (uint32_t)min_span || te - ts < (uint32_t)min_span || (int)ml < min_match); // hit.c:85
-		nobl = valid && !hasbl;
-		o.flags[i] = (uint8_t)(valid | pass << 1 | hasbl << 2 | (uint32_t)rev << 3);
-		f_hasbl[i] = hasbl;
-		o.ql[i] = ql; o.qs[i] = qs; o.qe[i] = qe; o.tl[i] = tl; o.ts[i] = ts; o.te[i] = te; o.ml[i] = ml; o.bl[i] = bl;
-		o.tnoff[i] = tnoff; o.qlen[i] = qlen; o.tlen[i] = tlen; o.hq[i] = hq; o.ht[i] = ht;
-		if (pass) mq = qs > ts ? qs : ts;
+		const uint32_t l = (uint32_t)(lstart[i + 1] - 1 - ls);
+		PafLine r;
+		uint32_t *fs = s_fs + threadIdx.x * 12;
+		if (in_lds) paf_line((const unsigned char*)(s_text + (ls - a0)), l, fs, r); // LDS byte reads
+		else paf_line(text + ls, l, fs, r);                                              // oversized lines: straight from global memory
+		valid = r.valid;
+		pass = valid && !(r.qe - r.qs < (uint32_t)min_span || r.te - r.ts < (uint32_t)min_span || (int)r.ml < min_match); // hit.c:85
+		nobl = valid && !r.hasbl;
+		o.flags[i] = (uint8_t)(valid | pass << 1 | r.hasbl << 2 | r.rev << 3);
+		f_hasbl[i] = r.hasbl;
+		o.ql[i] = r.ql; o.qs[i] = r.qs; o.qe[i] = r.qe; o.tl[i] = r.tl; o.ts[i] = r.ts; o.te[i] = r.te; o.ml[i] = r.ml; o.bl[i] = r.bl;
+		o.tnoff[i] = r.tnoff; o.qlen[i] = r.qlen; o.tlen[i] = r.tlen; o.hq[i] = r.hq; o.ht[i] = r.ht;
+		if (pass) mq = r.qs > r.ts ? r.qs : r.ts;
 	}
 	blk_add_u64(&ctr[PC_VALID], valid);
 	blk_add_u64(&ctr[PC_PASS], pass);
@@ -443,7 +462,12 @@ extern "C" int mahip_paf_parse(mahip_ctx_t *c, int min_span, int min_match, int 
 		CHK(dev_reserve(c, c->keep, ((size_t)L + 16) * 4)); CHK(dev_reserve(c, c->pos, ((size_t)L + 16) * 4));
 		{
 			ProfScope ps(c, "k_paf_parse", (double)n + 61.0 * (double)L);
-			hipLaunchKernelGGL(k_paf_parse, dim3(grid_for(L, 256)), dim3(256), PAF_LDS_BYTES + 32, c->st, text, n, (const uint64_t*)P<uint64_t>(b->lstart), L, min_span, min_match, o, P<uint32_t>(c->keep), ctr);
+			// LDS tile: 1.5 x the mean text of 256 lines, in 4 KiB steps (blocks whose lines are longer read global memory)
+			uint32_t lds_bytes = (uint32_t)((double)n / (double)L * 256.0 * 1.5);
+			lds_bytes = (lds_bytes + 4095u) & ~4095u;
+			if (lds_bytes < 8192u) lds_bytes = 8192u;
+			if (lds_bytes > PAF_LDS_BYTES) lds_bytes = PAF_LDS_BYTES;
+			hipLaunchKernelGGL(k_paf_parse, dim3(grid_for(L, 256)), dim3(256), lds_bytes + 32, c->st, text, n, (const uint64_t*)P<uint64_t>(b->lstart), L, min_span, min_match, o, P<uint32_t>(c->keep), ctr, lds_bytes);
 		}
 		CHK(ctr_fetch(c));
 		n_valid = (size_t)c->h_ctr[PC_VALID]; n_pass = (size_t)c->h_ctr[PC_PASS]; n_nobl = (size_t)c->h_ctr[PC_NOBL];

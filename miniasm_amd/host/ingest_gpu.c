@@ -51,25 +51,14 @@ int ma_hit_ingest_loaded(mahip_ctx_t *c, int min_span, int min_match, sdict_t *d
 	GPU(mahip_set_shard(c, 0, 0xffffffffu));
 	GPU(mahip_paf_parse(c, min_span, min_match, bi_dir, &info));
 	t2 = sys_realtime();
-	/* the dictionary: names and first-seen lengths in id order */
+	/* the dictionary: names (one block, adopted as the dictionary's arena: no per-name allocation) and first-seen lengths */
 	{
-		char *names = (char*)malloc(info.name_bytes ? info.name_bytes : 1), *p;
+		char *names = (char*)malloc(info.name_bytes ? info.name_bytes : 1);
 		uint32_t *lens = (uint32_t*)malloc(((size_t)info.n_seq + 1) * 4);
 		GPU(mahip_paf_names(c, names, lens));
-		for (i = 0; i < d->n_seq; ++i) free(d->seq[i].name);
-		d->n_seq = d->m_seq = info.n_seq;
-		d->seq = (sd_seq_t*)realloc(d->seq, ((size_t)info.n_seq + 1) * sizeof(sd_seq_t));
-		for (i = 0, p = names; i < info.n_seq; ++i) {
-			size_t l = strlen(p);
-			sd_seq_t *q = &d->seq[i];
-			q->name = (char*)malloc(l + 1);
-			memcpy(q->name, p, l + 1);
-			q->len = lens[i]; q->aux = 0; q->del = 0;
-			tot_len += lens[i];
-			p += l + 1;
-		}
-		ma_sd_drop_index(d); /* rebuilt on the first sd_get/sd_put (sd_squeeze builds its own) */
-		free(names); free(lens);
+		ma_sd_fill(d, names, info.name_bytes, info.n_seq, lens);
+		for (i = 0; i < info.n_seq; ++i) tot_len += lens[i];
+		free(lens);
 	}
 	if (release) GPU(mahip_paf_release(c));
 	t3 = sys_realtime();

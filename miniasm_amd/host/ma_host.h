@@ -23,6 +23,7 @@ int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 
 void ma_sd_reindex(sdict_t *d);    /* build the name index from seq[] (for dictionaries assembled by hand) */
 void ma_sd_drop_index(sdict_t *d);
+void ma_sd_fill(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, const uint32_t *lens); /* bulk fill; the dictionary owns arena */
 
 /* the process-wide GPU context of the per-symbol entry points; exits with an error if no GPU is usable */
 mahip_ctx_t *ma_gpu(void);

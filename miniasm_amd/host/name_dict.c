@@ -12,10 +12,14 @@
 #include "ma_host.h"
 
 typedef struct {
-	uint32_t n_slot, n_used; /* n_slot is a power of two */
+	uint32_t n_slot, n_used; /* n_slot is a power of two; 0 = index not built (bulk-filled dictionary: built on first use) */
 	uint32_t *id;            /* id+1, 0 = empty */
 	uint32_t *hv;            /* cached hash */
+	char *arena;             /* names of a bulk fill live in ONE block (device-side ingest): freed as a whole */
+	size_t arena_len;
 } sd_index_t;
+
+static inline int in_arena(const sd_index_t *ix, const char *p) { return ix && ix->arena && p >= ix->arena && p < ix->arena + ix->arena_len; }
 
 static inline uint32_t sd_hash_str(const char *s)
 {
@@ -36,7 +40,7 @@ static sd_index_t *ix_new(uint32_t n_slot)
 static void ix_free(sd_index_t *ix)
 {
 	if (!ix) return;
-	free(ix->id); free(ix->hv); free(ix);
+	free(ix->id); free(ix->hv); free(ix->arena); free(ix);
 }
 
 static void ix_insert_raw(sd_index_t *ix, uint32_t h, uint32_t id)
@@ -69,18 +73,71 @@ void sd_destroy(sdict_t *d)
 {
 	uint32_t i;
 	if (d == 0) return;
+	for (i = 0; i < d->n_seq; ++i)
+		if (!in_arena((sd_index_t*)d->h, d->seq[i].name)) free(d->seq[i].name);
 	ix_free((sd_index_t*)d->h);
-	for (i = 0; i < d->n_seq; ++i) free(d->seq[i].name);
 	free(d->seq);
 	free(d);
+}
+
+static void ix_table(sd_index_t *ix, uint32_t n_slot) /* (re)allocate an empty table; 0 = no table */
+{
+	free(ix->id); free(ix->hv);
+	ix->id = 0; ix->hv = 0; ix->n_slot = n_slot; ix->n_used = 0;
+	if (n_slot) {
+		ix->id = (uint32_t*)calloc(n_slot, 4);
+		ix->hv = (uint32_t*)malloc((size_t)n_slot * 4);
+	}
+}
+
+/* (re)build the name index from seq[] (dictionaries filled in bulk, the shallow survivor view of pipeline.c) */
+void ma_sd_reindex(sdict_t *d)
+{
+	uint32_t i, n_slot = 1024;
+	sd_index_t *ix = (sd_index_t*)d->h;
+	if (ix == 0) { ix = (sd_index_t*)calloc(1, sizeof(sd_index_t)); d->h = ix; }
+	while (n_slot < 2 * (uint64_t)d->n_seq + 16) n_slot <<= 1;
+	ix_table(ix, n_slot);
+	for (i = 0; i < d->n_seq; ++i) ix_insert_raw(ix, sd_hash_str(d->seq[i].name), i);
+}
+
+/* forget the index (it is rebuilt on the first sd_get / sd_put); the name arena, if any, stays */
+void ma_sd_drop_index(sdict_t *d)
+{
+	sd_index_t *ix = (sd_index_t*)d->h;
+	if (ix == 0) return;
+	if (ix->arena) ix_table(ix, 0);
+	else { ix_free(ix); d->h = 0; }
+}
+
+/* bulk fill (device-side ingest): `arena` holds n_seq NUL-terminated names back to back and becomes the dictionary's
+ * property; lens[i] = first-seen length.  Replaces whatever the dictionary held. */
+void ma_sd_fill(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, const uint32_t *lens)
+{
+	uint32_t i;
+	char *p = arena;
+	sd_index_t *ix = (sd_index_t*)d->h;
+	for (i = 0; i < d->n_seq; ++i)
+		if (!in_arena(ix, d->seq[i].name)) free(d->seq[i].name);
+	if (ix == 0) { ix = (sd_index_t*)calloc(1, sizeof(sd_index_t)); d->h = ix; }
+	free(ix->arena);
+	ix->arena = arena; ix->arena_len = arena_len;
+	ix_table(ix, 0);
+	d->n_seq = d->m_seq = n_seq;
+	d->seq = (sd_seq_t*)realloc(d->seq, ((size_t)n_seq + 1) * sizeof(sd_seq_t));
+	for (i = 0; i < n_seq; ++i) {
+		sd_seq_t *q = &d->seq[i];
+		q->name = p; q->len = lens[i]; q->aux = 0; q->del = 0;
+		p += strlen(p) + 1;
+	}
 }
 
 int32_t sd_get(const sdict_t *d, const char *name)
 {
 	const sd_index_t *ix = (const sd_index_t*)d->h;
 	uint32_t h = sd_hash_str(name), m, s;
-	if (ix == 0 && d->n_seq) { ma_sd_reindex((sdict_t*)d); ix = (const sd_index_t*)d->h; } /* index dropped by a bulk fill: build on first use */
-	if (ix == 0) return -1;
+	if ((ix == 0 || ix->n_slot == 0) && d->n_seq) { ma_sd_reindex((sdict_t*)d); ix = (const sd_index_t*)d->h; } /* built on first use */
+	if (ix == 0 || ix->n_slot == 0) return -1;
 	m = ix->n_slot - 1;
 	for (s = h & m; ix->id[s]; s = (s + 1) & m)
 		if (ix->hv[s] == h && strcmp(d->seq[ix->id[s] - 1].name, name) == 0) return (int32_t)(ix->id[s] - 1);
@@ -92,7 +149,7 @@ int32_t sd_put(sdict_t *d, const char *name, uint32_t len)
 	sd_index_t *ix = (sd_index_t*)d->h;
 	uint32_t h = sd_hash_str(name), m, s;
 	sd_seq_t *q;
-	if (ix == 0) { ma_sd_reindex(d); ix = (sd_index_t*)d->h; }
+	if (ix == 0 || ix->n_slot == 0) { ma_sd_reindex(d); ix = (sd_index_t*)d->h; }
 	m = ix->n_slot - 1;
 	for (s = h & m; ix->id[s]; s = (s + 1) & m)
 		if (ix->hv[s] == h && strcmp(d->seq[ix->id[s] - 1].name, name) == 0) return (int32_t)(ix->id[s] - 1);
@@ -110,35 +167,13 @@ int32_t sd_put(sdict_t *d, const char *name, uint32_t len)
 int32_t *sd_squeeze(sdict_t *d)
 {
 	int32_t *map = (int32_t*)calloc(d->n_seq ? d->n_seq : 1, 4);
-	uint32_t i, j, n_slot = 1024;
-	sd_index_t *ix;
-	ix_free((sd_index_t*)d->h);
+	uint32_t i, j;
+	sd_index_t *ix = (sd_index_t*)d->h;
 	for (i = j = 0; i < d->n_seq; ++i) {
-		if (d->seq[i].del) { free(d->seq[i].name); map[i] = -1; }
+		if (d->seq[i].del) { if (!in_arena(ix, d->seq[i].name)) free(d->seq[i].name); map[i] = -1; }
 		else { d->seq[j] = d->seq[i]; map[i] = (int32_t)j++; }
 	}
 	d->n_seq = j;
-	while (n_slot < 2 * (uint64_t)j + 16) n_slot <<= 1;
-	ix = ix_new(n_slot);
-	for (i = 0; i < j; ++i) ix_insert_raw(ix, sd_hash_str(d->seq[i].name), i);
-	d->h = ix;
+	ma_sd_reindex(d);
 	return map;
-}
-
-/* (re)build / drop the name index of a dictionary whose seq[] was filled by hand (the shallow survivor view of pipeline.c) */
-void ma_sd_reindex(sdict_t *d)
-{
-	uint32_t i, n_slot = 1024;
-	sd_index_t *ix;
-	ix_free((sd_index_t*)d->h);
-	while (n_slot < 2 * (uint64_t)d->n_seq + 16) n_slot <<= 1;
-	ix = ix_new(n_slot);
-	for (i = 0; i < d->n_seq; ++i) ix_insert_raw(ix, sd_hash_str(d->seq[i].name), i);
-	d->h = ix;
-}
-
-void ma_sd_drop_index(sdict_t *d)
-{
-	ix_free((sd_index_t*)d->h);
-	d->h = 0;
 }
