@@ -32,6 +32,13 @@ void ma_gpu_fail(const char *where)
 	exit(1);
 }
 
+/* orderly teardown before the HIP runtime's own exit handlers run (a process that ends with a live stream and pinned
+ * buffers was seen to crash in the runtime's teardown about once in 200 runs) */
+static void ma_gpu_shutdown(void)
+{
+	if (g_ctx) { mahip_destroy(g_ctx); g_ctx = 0; }
+}
+
 mahip_ctx_t *ma_gpu(void)
 {
 	if (g_ctx == 0) {
@@ -39,6 +46,7 @@ mahip_ctx_t *ma_gpu(void)
 		if (s == 0) s = getenv("LOCAL_RANK");
 		g_ctx = mahip_create(s ? atoi(s) : 0, 0);
 		if (g_ctx == 0) ma_gpu_fail("ma_gpu");
+		atexit(ma_gpu_shutdown);
 	}
 	return g_ctx;
 }
