@@ -143,3 +143,27 @@ def test_exact_tie_mode_is_byte_identical(name, tmpdir_s, monkeypatch):
     ref_out, _ = R.run_cli(R.REF_BIN, ["-p", "ug"], paf)
     out, _ = R.run_cli(ma.CLI_PATH, ["-p", "ug"], paf)
     assert out == ref_out
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+def test_cli_degenerate_inputs(tmpdir_s, monkeypatch):
+    """empty file, junk only, one line, everything filtered out, reads that all contain each other: same (mostly empty) output,
+    same counters and exit status as the reference, with the device parser and with the host reader"""
+    tiny = R.pafgen(os.path.join(tmpdir_s, "deg_tiny.paf"), 50, 200, 9, [])
+    first = open(tiny, "rb").readline()
+    cases = {"empty": b"", "junk": b"junk\tline\nmore\n\n\n", "one": first, "one_nonl": first.rstrip(b"\n"),
+             "dup": first * 5, "tiny": open(tiny, "rb").read()}
+    for name, blob in cases.items():
+        p = os.path.join(tmpdir_s, "deg_%s.paf" % name)
+        open(p, "wb").write(blob)
+        for args in (["-p", "ug"], ["-p", "sg"], ["-p", "paf"], ["-p", "bed"], ["-s", "100000"], ["-m", "1000000", "-p", "paf"]):
+            ref_out, ref_log = R.run_cli(R.REF_BIN, args, p)
+            for host_parse in (False, True):
+                if host_parse:
+                    monkeypatch.setenv("MA_HOST_PARSE", "1")
+                else:
+                    monkeypatch.delenv("MA_HOST_PARSE", raising=False)
+                _same(ma.CLI_PATH, args, p, ref_out, ref_log, "cli[%s,%s]" % (name, "host" if host_parse else "device"))
+            monkeypatch.delenv("MA_HOST_PARSE", raising=False)
+        ref_out, ref_log = R.run_cli(R.REF_BIN, ["-p", "ug"], p)
+        _same(R.DROPIN_BIN, ["-p", "ug"], p, ref_out, ref_log, "dropin[%s]" % name)
