@@ -57,32 +57,86 @@ __global__ __launch_bounds__(256) void k_sg_seq(const uint2 *__restrict__ sub, c
 	slen[r] = len; sdel[r] = (uint8_t)del;
 }
 
-// asm.c:18-35 per hit: candidate arc at the hit's own slot (push order = hit order), seq.del side effects
+// asm.c:18-35 per hit.  The arcs a read pair yields are few next to the hit slots (after containment 99 % of the slots are
+// dead), so nothing is materialised per slot: pass A only applies the seq.del side effects (asm.c:27-34) and takes the
+// maxima; once seq.del is final (after the exchange in the sharded mode) pass B counts the surviving arcs per tile of
+// SG_TILE consecutive hits and pass C -- after a scan of the tile counts -- recomputes them and writes them densely,
+// in hit order (= the reference's push order).  Three sweeps over the dead bits instead of 16 B of arc per slot.
+#define SG_TILE 2048u
+
+__device__ __forceinline__ int sg_candidate(const HitColsG &h, size_t i, const uint32_t *__restrict__ slen, int max_hang, float int_frac, int min_ovlp,
+                                            const uint8_t *__restrict__ lazy_del, mc_arc_t *x, uint32_t *q_, uint32_t *t_, int *self_rc)
+{ // <0: dead slot; else mc_hit2arc's verdict (r >= 0: arc in *x), *self_rc: the palindromic self hit of asm.c:27-30
+	if (h.bl[i] & DEAD) return -100;
+	uint32_t q = h.qid[i], t = h.tn[i];
+	if (lazy_del && (lazy_del[q] || lazy_del[t])) return -100;
+	uint32_t qs = h.qs[i], qe = h.qe[i], ts = h.ts[i], te = h.te[i];
+	int rev = h.ml[i] >> 31;
+	*q_ = q; *t_ = t;
+	*self_rc = q == t && qs == ts && qe == te && rev;
+	return mc_hit2arc(q, qs, qe, t, ts, te, rev, (int)slen[q], (int)slen[t], max_hang, int_frac, min_ovlp, x);
+}
+
 __global__ __launch_bounds__(256) void k_sg_arcs(HitColsG h, size_t n, const uint32_t *__restrict__ slen, uint8_t *__restrict__ sdel,
-                                                  int max_hang, float int_frac, int min_ovlp, ArcCols a, uint32_t *__restrict__ keep,
-                                                  unsigned long long *__restrict__ ctr, const uint8_t *__restrict__ lazy_del)
-{ // lazy_del != nullptr: the squeeze of ma_hit_contained was postponed; hits with a dropped endpoint are skipped here
+                                                  int max_hang, float int_frac, int min_ovlp, unsigned long long *__restrict__ ctr, const uint8_t *__restrict__ lazy_del,
+                                                  unsigned long long *__restrict__ cmask)
+{ // pass A.  lazy_del != nullptr: the squeeze of ma_hit_contained was postponed; hits with a dropped endpoint are skipped here.
+  // cmask: one bit per hit slot = "yields an arc" (before the endpoint test), so that passes B and C need not look at dead slots
 	uint32_t mx = 0, n_live = 0;
-	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-		int k = 0;
-		if (!(h.bl[i] & DEAD) && !(lazy_del && (lazy_del[h.qid[i]] || lazy_del[h.tn[i]]))) {
-			++n_live;
-			uint32_t q = h.qid[i], t = h.tn[i], qs = h.qs[i], qe = h.qe[i], ts = h.ts[i], te = h.te[i];
-			int rev = h.ml[i] >> 31;
+	for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+		const size_t i = base + threadIdx.x;
+		int cand = 0;
+		if (i < n) {
 			mc_arc_t x;
-			int r = mc_hit2arc(q, qs, qe, t, ts, te, rev, (int)slen[q], (int)slen[t], max_hang, int_frac, min_ovlp, &x);
-			if (r >= 0) {
-				if (q == t) { if (qs == ts && qe == te && rev) sdel[q] = 1; } // asm.c:27-31
-				else { a.u[i] = x.u; a.v[i] = x.v; a.len[i] = x.len; a.ol[i] = x.ol; k = 1; mx = x.len > mx ? x.len : mx; }
-			} else if (r == MC_HT_QCONT) sdel[q] = 1; // asm.c:34
+			uint32_t q = 0, t = 0;
+			int self_rc = 0, r = sg_candidate(h, i, slen, max_hang, int_frac, min_ovlp, lazy_del, &x, &q, &t, &self_rc);
+			if (r != -100) {
+				++n_live;
+				if (r >= 0) {
+					if (q == t) { if (self_rc) sdel[q] = 1; } // asm.c:27-31
+					else cand = 1, mx = x.len > mx ? x.len : mx;
+				} else if (r == MC_HT_QCONT) sdel[q] = 1; // asm.c:34
+			}
 		}
-		keep[i] = k;
+		const unsigned long long m = wv_ballot(cand);
+		if ((threadIdx.x & 63) == 0) cmask[i >> 6] = m;
 	}
 	blk_max_u64(&ctr[CT_MAXLEN], mx);
 	blk_add_u64(&ctr[CT_LIVE], n_live);
 }
 
-// asg.c:57-70 asg_arc_rm predicate: arc survives unless del or an endpoint read is deleted
+// passes B (out.u == nullptr: count per tile) and C (write): tile b = hits [b*SG_TILE, (b+1)*SG_TILE), row j of a tile = 256 consecutive hits
+__global__ __launch_bounds__(256) void k_sg_emit(HitColsG h, size_t n, const uint32_t *__restrict__ slen, const uint8_t *__restrict__ sdel,
+                                                  int max_hang, float int_frac, int min_ovlp, const unsigned long long *__restrict__ cmask,
+                                                  uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off, ArcCols out)
+{
+	__shared__ uint32_t s_w[4];
+	const size_t base = (size_t)blockIdx.x * SG_TILE;
+	uint32_t run = out.u ? tile_off[blockIdx.x] : 0, total = 0;
+	for (uint32_t j = 0; j < SG_TILE / 256; ++j) {
+		const size_t i = base + (size_t)j * 256 + threadIdx.x;
+		mc_arc_t x;
+		int keep = 0;
+		if (i < n && (cmask[i >> 6] >> (i & 63) & 1)) { // an arc-yielding slot: recompute the arc (a handful per tile)
+			uint32_t q = 0, t = 0;
+			int self_rc = 0;
+			sg_candidate(h, i, slen, max_hang, int_frac, min_ovlp, nullptr, &x, &q, &t, &self_rc);
+			keep = !sdel[q] && !sdel[t]; // asg_arc_rm on the fresh arcs (asg.c:57-70): endpoints must be alive
+		}
+		if (out.u) { // dense slot = arcs of earlier tiles + earlier rows + earlier lanes of this row
+			uint32_t tot, ex = block_excl_scan_256((uint32_t)keep, s_w, &tot);
+			if (keep) { uint32_t p = run + ex; out.u[p] = x.u; out.v[p] = x.v; out.len[p] = x.len; out.ol[p] = x.ol; }
+			run += tot;
+		} else total += (uint32_t)keep;
+	}
+	if (!out.u) {
+		total = wv_sum_u32(total);
+		if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = total;
+		__syncthreads();
+		if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+	}
+}
+
 __global__ __launch_bounds__(256) void k_arc_keep(ArcCols a, size_t n, const uint8_t *__restrict__ sdel, uint32_t *__restrict__ keep, int use_keep_in)
 {
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -395,8 +449,8 @@ extern "C" int mahip_sg_flags(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, 
 	if (!c->soa_ready) { mahip_set_error("mahip_sg_gen: hits not indexed"); return -1; }
 	size_t n = c->n_hits;
 	uint32_t R = c->n_seq;
-	CHK(reserve_arcs(c, n));
 	CHK(dev_reserve(c, c->slen, ((size_t)R + 4) * 4)); CHK(dev_reserve(c, c->sdel, (size_t)R + 16));
+	c->sg_max_hang = opt->max_hang; c->sg_int_frac = opt->int_frac; c->sg_min_ovlp = opt->min_ovlp;
 	CHK(ctr_zero(c));
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	// host-side per-read arrays (per-symbol path) go through the scratch buffers
@@ -407,11 +461,12 @@ extern "C" int mahip_sg_flags(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, 
 	if (R) hipLaunchKernelGGL(k_sg_seq, dim3(grid_for(R, 256)), dim3(256), 0, c->st, use_sub ? (const uint2*)P<uint2>(c->sub[0]) : (const uint2*)nullptr,
 	                          c->has_map ? (const uint8_t*)P<uint8_t>(c->r_del) : (const uint8_t*)nullptr, d_len, d_del, R, P<uint32_t>(c->slen), P<uint8_t>(c->sdel));
 	c->ag = 0;
+	if (n) CHK(dev_reserve(c, c->sgmask, (n / 64 + 8) * 8)); // candidate bit per hit slot
 	if (n) {
 		ProfScope ps(c, "k_sg_arcs", 64.0 * (double)c->n_live); // ma_sg_gen 32 r + 16 look-ups + 16 w
 		hipLaunchKernelGGL(k_sg_arcs, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, gcols_of(c), n, (const uint32_t*)P<uint32_t>(c->slen), P<uint8_t>(c->sdel),
-		                   opt->max_hang, opt->int_frac, opt->min_ovlp, arcs_of(c, 0), P<uint32_t>(c->keep), ctr,
-		                   c->lazy_squeeze ? (const uint8_t*)P<uint8_t>(c->r_del) : (const uint8_t*)nullptr);
+		                   opt->max_hang, opt->int_frac, opt->min_ovlp, ctr,
+		                   c->lazy_squeeze ? (const uint8_t*)P<uint8_t>(c->r_del) : (const uint8_t*)nullptr, P<unsigned long long>(c->sgmask));
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
@@ -422,9 +477,31 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 	HIPCHK(hipSetDevice(c->dev));
 	size_t n = c->n_hits;
 	uint32_t R = c->n_seq;
-	CHK(arc_cleanup(c, n, 1, -1)); // fetches the counters: CT_MAXLEN / CT_LIVE were set by k_sg_arcs
+	CHK(ctr_fetch(c)); // CT_MAXLEN / CT_LIVE of pass A
 	c->n_live = (size_t)c->h_ctr[CT_LIVE];
 	if (c->prof) prof_patch_last(c, "k_sg_arcs", 64.0 * (double)c->n_live); // units = hits left after containment (64 B each)
+	c->n_arc = 0; c->ag = 0;
+	if (n) {
+		const size_t n_tiles = (n + SG_TILE - 1) / SG_TILE;
+		const unsigned long long *lazy = (const unsigned long long*)P<unsigned long long>(c->sgmask); // pass A's candidate bits
+		uint32_t *d_tot = (uint32_t*)(P<unsigned long long>(c->ctr) + CT_TOTAL);
+		ArcCols none = { nullptr, nullptr, nullptr, nullptr };
+		CHK(dev_reserve(c, c->keep, (n + 16) * 4)); CHK(dev_reserve(c, c->pos, (n + 16) * 4)); // also what reserve_arcs(n_arc <= n) asks for: no reallocation between the passes
+		{
+			ProfScope ps(c, "k_sg_emit", 4.0 * (double)n + 64.0 * (double)c->n_live);
+			hipLaunchKernelGGL(k_sg_emit, dim3((unsigned)n_tiles), dim3(256), 0, c->st, gcols_of(c), n, (const uint32_t*)P<uint32_t>(c->slen), (const uint8_t*)P<uint8_t>(c->sdel),
+			                   c->sg_max_hang, c->sg_int_frac, c->sg_min_ovlp, lazy, P<uint32_t>(c->keep), (const uint32_t*)nullptr, none);
+		}
+		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), n_tiles, d_tot));
+		CHK(ctr_fetch(c));
+		c->n_arc = (uint32_t)(c->h_ctr[CT_TOTAL] & 0xffffffffu);
+		CHK(reserve_arcs(c, c->n_arc));
+		if (c->n_arc) {
+			ProfScope ps(c, "k_sg_emit", 4.0 * (double)n + 64.0 * (double)c->n_live + 16.0 * (double)c->n_arc);
+			hipLaunchKernelGGL(k_sg_emit, dim3((unsigned)n_tiles), dim3(256), 0, c->st, gcols_of(c), n, (const uint32_t*)P<uint32_t>(c->slen), (const uint8_t*)P<uint8_t>(c->sdel),
+			                   c->sg_max_hang, c->sg_int_frac, c->sg_min_ovlp, lazy, (uint32_t*)nullptr, (const uint32_t*)P<uint32_t>(c->pos), arcs_of(c, 0));
+		}
+	} else CHK(reserve_arcs(c, 0));
 	if (c->n_arc > 1) {
 		size_t m = c->n_arc;
 		for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }

@@ -46,6 +46,7 @@ struct mahip_ctx {
 	DevBuf map;               // int32 [n_seq]  old -> new id, -1 dropped
 	DevBuf surv;              // u32 [n_seq_new] new -> old id
 	bool soa_ready = false, has_map = false, lazy_squeeze = false;
+	int sg_max_hang = 0, sg_min_ovlp = 0; float sg_int_frac = 0; // classifier options of the last mahip_sg_flags (pass B/C recompute the arcs)
 	bool exact_ties = false; // order records with equal sort keys exactly as the reference's unstable sort does (host-computed permutation)
 	uint32_t n_seq_new = 0;
 
@@ -67,6 +68,7 @@ struct mahip_ctx {
 	DevBuf ovf;               // overflow lists
 	DevBuf big0, big1;        // lazily allocated global scratch for oversized groups
 	DevBuf marks;             // trans-reduce tier-2 mark arrays
+	DevBuf sgmask;            // ma_sg_gen: one candidate bit per hit slot
 	uint64_t *h_ctr = nullptr; // pinned host mirror of ctr
 	void *xfer = nullptr;      // staged-copy worker pool (xfer.hip)
 	void *paf = nullptr;       // text-ingest buffers (paf.hip)

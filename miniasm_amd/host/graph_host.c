@@ -71,8 +71,10 @@ static int clean_par_at(const asg_t *g, long dflt_min_vtx)
 	return ma_clean_threads() > 1 && (long)g->n_seq * 2 >= min_vtx;
 }
 /* measured on the MI355X host (2 x EPYC 9575F), 440 k vertices: bubble probes, short-overlap / symmetry filters and the
- * arc compaction gain 30-40 % from 8 threads, the end classification of the tip / internal / bi-loop sweeps does not */
-static int clean_par(const asg_t *g) { return clean_par_at(g, 200000); }
+ * arc compaction gain 30-40 % from 8 threads on a noisy graph, the end classification of the tip / internal / bi-loop sweeps
+ * does not; on a clean graph of that size (few sources, few deletions) the threads only cost their start-up: the default
+ * thresholds keep the speculative sweeps for cfg5-class graphs */
+static int clean_par(const asg_t *g) { return clean_par_at(g, 1000000); }
 static int clean_par_ends(const asg_t *g) { return clean_par_at(g, 4000000); }
 
 typedef struct { uint8_t *map; size_t n; } dirty_t; /* per read: state (seq.del or an arc's del on either strand) changed since the snapshot */
@@ -813,6 +815,12 @@ static uint64_t pop_bubble_par(asg_t *g, int max_dist, bub_buf_t *b0)
 	cand = (uint32_t*)malloc(((size_t)n_vtx + 1) * 4);
 	for (v = 0; v < n_vtx; ++v) /* sources at entry; deletions only ever remove sources */
 		if (asg_arc_n(g, v) >= 2 && !g->seq[v >> 1].del) cand[nc++] = v;
+	if (nc < 100000 && !getenv("MA_CLEAN_PAR_MIN")) { /* few sources: not worth a thread pool */
+		for (k = 0; k < nc; ++k)
+			if (bub_is_source(g, cand[k])) n_pop += bub_pop1(g, cand[k], max_dist, b0, 1);
+		free(cand);
+		return n_pop;
+	}
 	memset(&p, 0, sizeof(p));
 	p.g = g; p.max_dist = max_dist; p.cand = cand;
 	p.spec = (bub_spec_t*)malloc((size_t)BUB_BLOCK_MAX * sizeof(bub_spec_t));

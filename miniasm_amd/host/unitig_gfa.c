@@ -209,20 +209,28 @@ static inline void ob_utg(obuf_t *o, uint32_t id1, int circ) { ob_mem(o, "utg", 
 /* The three blocks of a unitig GFA (asm.c:77-116).  Formatting is bound by cache misses on names and intervals of reads
  * scattered over the dictionary, so big outputs are formatted by several threads, each into its own buffer over a
  * contiguous range of unitigs / links, and written in order: the text is the sequential one byte for byte. */
-static void fmt_units(obuf_t *o, const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, uint32_t lo, uint32_t hi)
+/* a segment = reads [j0, j1) of unitig u, l0 = offset of read j0 on the unitig; the segment with j0 == 0 also carries the
+ * S line (and the circularising L lines): long unitigs are cut into several segments so that they can be formatted in parallel */
+typedef struct { uint32_t u, j0, j1, l0; } fmt_seg_t;
+
+static void fmt_units(obuf_t *o, const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, const fmt_seg_t *seg, size_t lo, size_t hi)
 {
-	uint32_t i, j, l;
-	for (i = lo; i < hi; ++i) { /* S lines, circularising L lines, per-read a lines */
+	size_t k;
+	uint32_t j, l;
+	for (k = lo; k < hi; ++k) {
+		const uint32_t i = seg[k].u;
 		const ma_utg_t *p = &ug->u.a[i];
-		ob_mem(o, "S\t", 2); ob_utg(o, i + 1, p->circ); ob_chr(o, '\t'); ob_str(o, p->s ? p->s : "*"); ob_mem(o, "\tLN:i:", 6); ob_int(o, (int)p->len); ob_chr(o, '\n');
-		if (p->circ) {
-			for (j = 0; j < 2; ++j) { /* "L\t%s\t+\t%s\t+\t0M\n" and the '-' twin */
-				char c = "+-"[j];
-				ob_mem(o, "L\t", 2); ob_utg(o, i + 1, p->circ); ob_chr(o, '\t'); ob_chr(o, c); ob_chr(o, '\t');
-				ob_utg(o, i + 1, p->circ); ob_chr(o, '\t'); ob_chr(o, c); ob_mem(o, "\t0M\n", 4);
+		if (seg[k].j0 == 0) { /* S line, circularising L lines */
+			ob_mem(o, "S\t", 2); ob_utg(o, i + 1, p->circ); ob_chr(o, '\t'); ob_str(o, p->s ? p->s : "*"); ob_mem(o, "\tLN:i:", 6); ob_int(o, (int)p->len); ob_chr(o, '\n');
+			if (p->circ) {
+				for (j = 0; j < 2; ++j) { /* "L\t%s\t+\t%s\t+\t0M\n" and the '-' twin */
+					char c = "+-"[j];
+					ob_mem(o, "L\t", 2); ob_utg(o, i + 1, p->circ); ob_chr(o, '\t'); ob_chr(o, c); ob_chr(o, '\t');
+					ob_utg(o, i + 1, p->circ); ob_chr(o, '\t'); ob_chr(o, c); ob_mem(o, "\t0M\n", 4);
+				}
 			}
 		}
-		for (j = l = 0; j < p->n; l += (uint32_t)p->a[j++]) { /* "a\t%s\t%d\t%s:%d-%d\t%c\t%d\n" */
+		for (j = seg[k].j0, l = seg[k].l0; j < seg[k].j1; l += (uint32_t)p->a[j++]) { /* "a\t%s\t%d\t%s:%d-%d\t%c\t%d\n" */
 			if (j + 4 < p->n) __builtin_prefetch(&d->seq[p->a[j + 4] >> 33]);
 			if (j + 2 < p->n) __builtin_prefetch(d->seq[p->a[j + 2] >> 33].name);
 			ob_mem(o, "a\t", 2); ob_utg(o, i + 1, p->circ); ob_chr(o, '\t'); ob_int(o, (int)l); ob_chr(o, '\t');
@@ -261,28 +269,44 @@ static void fmt_summary(obuf_t *o, const ma_ug_t *ug, const sdict_t *d, const ma
 	}
 }
 
-typedef struct { const ma_ug_t *ug; const sdict_t *d; const ma_sub_t *sub; uint32_t u_lo, u_hi, l_lo, l_hi; obuf_t units, links, summary; } fmt_job_t;
+typedef struct { const ma_ug_t *ug; const sdict_t *d; const ma_sub_t *sub; const fmt_seg_t *seg; size_t s_lo, s_hi; uint32_t u_lo, u_hi, l_lo, l_hi; obuf_t units, links, summary; } fmt_job_t;
 
 static void *fmt_worker(void *arg)
 {
 	fmt_job_t *j = (fmt_job_t*)arg;
-	fmt_units(&j->units, j->ug, j->d, j->sub, j->u_lo, j->u_hi);
+	fmt_units(&j->units, j->ug, j->d, j->sub, j->seg, j->s_lo, j->s_hi);
 	fmt_links(&j->links, j->ug, j->l_lo, j->l_hi);
 	fmt_summary(&j->summary, j->ug, j->d, j->sub, j->u_lo, j->u_hi);
 	return 0;
 }
 
 #define FMT_MAX_THREADS 16
+#define FMT_SEG_READS 2048u
 void ma_ug_print(const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, FILE *fp) /* asm.c:77-116 */
 {
 	const uint32_t nu = (uint32_t)ug->u.n, nl = ug->g->n_arc;
 	uint64_t tot = 0, acc = 0;
-	uint32_t i;
+	uint32_t i, j, l;
+	size_t n_seg = 0, m_seg = (size_t)nu + 16, si;
 	int T, t, k;
+	fmt_seg_t *seg = (fmt_seg_t*)malloc(m_seg * sizeof(fmt_seg_t));
+	const char *e_seg = getenv("MA_FMT_SEG"); /* reads per segment (tests shrink it to cut short unitigs too) */
+	const uint32_t seg_reads = e_seg && atol(e_seg) > 0 ? (uint32_t)atol(e_seg) : FMT_SEG_READS;
 	fmt_job_t job[FMT_MAX_THREADS];
 	pthread_t th[FMT_MAX_THREADS];
 	int started[FMT_MAX_THREADS];
-	for (i = 0; i < nu; ++i) tot += ug->u.a[i].n + 2;
+	for (i = 0; i < nu; ++i) { /* segments in output order */
+		const ma_utg_t *p = &ug->u.a[i];
+		tot += p->n + 2;
+		j = 0; l = 0;
+		do {
+			uint32_t j1 = p->n - j > seg_reads ? j + seg_reads : p->n, x;
+			if (n_seg == m_seg) { m_seg <<= 1; seg = (fmt_seg_t*)realloc(seg, m_seg * sizeof(fmt_seg_t)); }
+			seg[n_seg].u = i; seg[n_seg].j0 = j; seg[n_seg].j1 = j1; seg[n_seg].l0 = l; ++n_seg;
+			for (x = j; x < j1; ++x) l += (uint32_t)p->a[x];
+			j = j1;
+		} while (j < p->n);
+	}
 	{
 		const char *e = getenv("MA_FMT_GRAIN"); /* lines per thread at least: about 0.3 ms of formatting */
 		long grain = e ? atol(e) : 6000;
@@ -293,24 +317,32 @@ void ma_ug_print(const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, FILE 
 	if (T > FMT_MAX_THREADS) T = FMT_MAX_THREADS;
 	if (T < 1) T = 1;
 	memset(job, 0, sizeof(job));
-	for (t = 0, i = 0; t < T; ++t) { /* unitig ranges of about equal read count, link ranges of equal size */
+	for (t = 0, si = 0; t < T; ++t) { /* segment ranges of about equal read count; summary lines by unitig range, links by equal share */
 		uint64_t want = tot * (uint64_t)(t + 1) / (uint64_t)T;
-		job[t].ug = ug; job[t].d = d; job[t].sub = sub;
-		job[t].u_lo = i;
-		while (i < nu && (acc < want || t == T - 1)) acc += ug->u.a[i++].n + 2;
-		job[t].u_hi = i;
+		job[t].ug = ug; job[t].d = d; job[t].sub = sub; job[t].seg = seg;
+		job[t].s_lo = si;
+		while (si < n_seg && (acc < want || t == T - 1)) { acc += (seg[si].j1 - seg[si].j0) + (seg[si].j0 == 0 ? 2 : 0); ++si; }
+		job[t].s_hi = si;
+		job[t].u_lo = (uint32_t)((uint64_t)nu * (uint64_t)t / (uint64_t)T);
+		job[t].u_hi = (uint32_t)((uint64_t)nu * (uint64_t)(t + 1) / (uint64_t)T);
 		job[t].l_lo = (uint32_t)((uint64_t)nl * (uint64_t)t / (uint64_t)T);
 		job[t].l_hi = (uint32_t)((uint64_t)nl * (uint64_t)(t + 1) / (uint64_t)T);
 	}
+	const int timing = getenv("MA_PIPE_TIMING") != 0;
+	const double t_begin = timing ? sys_realtime() : 0;
+	double t_fmt;
 	for (t = 1; t < T; ++t) {
 		started[t] = pthread_create(&th[t], 0, fmt_worker, &job[t]) == 0;
 		if (!started[t]) fmt_worker(&job[t]);
 	}
 	fmt_worker(&job[0]);
 	for (t = 1; t < T; ++t) if (started[t]) pthread_join(th[t], 0);
+	t_fmt = timing ? sys_realtime() : 0;
 	for (t = 0; t < T; ++t) { job[t].units.fp = fp; ob_flush(&job[t].units); }
 	for (t = 0; t < T; ++t) { job[t].links.fp = fp; ob_flush(&job[t].links); }
 	for (t = 0; t < T; ++t) { job[t].summary.fp = fp; ob_flush(&job[t].summary); }
+	free(seg);
+	if (timing) fprintf(stderr, "[T::ug_print] %d threads: format %.3f ms, write %.3f ms\n", T, (t_fmt - t_begin) * 1e3, (sys_realtime() - t_fmt) * 1e3);
 }
 
 /* ---------------------------------------------------------------------------------------------- unitig sequences

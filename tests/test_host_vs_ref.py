@@ -140,8 +140,8 @@ def test_cleaners_unitigs_gfa_match_reference(name, reads, lines, seed, extra, t
         outs.append(open(path, "rb").read())
     assert outs[0] == outs[1], "GFA text differs (byte for byte, line order included)"
     assert outs[0].count(b"\nS\t") + outs[0].startswith(b"S\t") >= 1
-    for grain, threads in (("40", "7"), ("3", "16"), ("100000", "4")):  # the writer formats big outputs on several threads: same bytes
-        os.environ["MA_FMT_GRAIN"], os.environ["MA_THREADS"] = grain, threads
+    for grain, threads, seg in (("40", "7", "5"), ("3", "16", "1"), ("100000", "4", "3"), ("10", "3", "100000")):  # the writer formats big outputs on several threads, long unitigs in pieces: same bytes
+        os.environ["MA_FMT_GRAIN"], os.environ["MA_THREADS"], os.environ["MA_FMT_SEG"] = grain, threads, seg
         try:
             path = os.path.join(tmpdir_s, "h_%s_mt.gfa" % name)
             fp = libc.fopen(path.encode(), b"w")
@@ -149,7 +149,7 @@ def test_cleaners_unitigs_gfa_match_reference(name, reads, lines, seed, extra, t
             libc.fclose(fp)
             assert open(path, "rb").read() == outs[0], "multi-threaded GFA text differs (grain %s)" % grain
         finally:
-            del os.environ["MA_FMT_GRAIN"], os.environ["MA_THREADS"]
+            del os.environ["MA_FMT_GRAIN"], os.environ["MA_THREADS"], os.environ["MA_FMT_SEG"]
     LR.ma_ug_destroy(ug_r); LP.ma_ug_destroy(ug_p)
     LR.asg_destroy(g_ref)
     LR.sd_destroy(dr); LP.sd_destroy(d)
