@@ -128,3 +128,30 @@ def test_ingest_gz_and_cli_paths_agree(tmpdir_s, monkeypatch):
         assert R.counters(dev_log) == R.counters(host_log), args
     r_out, _ = R.run_cli(ma.CLI_PATH, ["-p", "ug"], gz)
     assert r_out == R.run_cli(ma.CLI_PATH, ["-p", "ug"], paf)[0]
+
+
+def test_ingest_fuzz_against_host_reader(tmpdir_s):
+    """random ASCII soup with the separators, signs, blanks, CR and NUL over-represented: whatever the host reader (pinned to
+    the reference on the CPU) makes of it, the device parser must make the same of it"""
+    rnd = random.Random(2024)
+    alphabet = "0123456789" * 6 + "\t" * 14 + "\n" * 3 + "+- \r\x00\x0b\x0cabcxyzACGT:_.|" + "\t\t"
+    ctx = ma.Ctx(0)
+    opt = ma.default_opt(); opt.min_span = 0; opt.min_match = 0
+    total = 0
+    for k in range(12):
+        n = rnd.choice((0, 1, 7, 300, 5000, 60000, 400000))
+        txt = "".join(rnd.choice(alphabet) for _ in range(n))
+        if k % 3 == 0:  # sprinkle well-formed lines so that the dictionary and the mirrored records are exercised too
+            good = ["r%d\t9000\t%d\t%d\t%s\tr%d\t8000\t%d\t%d\t%d\t%d\t255" % (rnd.randint(0, 40), a, a + rnd.randint(0, 5000), rnd.choice("+-"), rnd.randint(0, 40), b,
+                                                                         b + rnd.randint(0, 5000), rnd.randint(0, 900), rnd.randint(0, 4000))
+                    for a, b in ((rnd.randint(0, 3000), rnd.randint(0, 3000)) for _ in range(400))]
+            parts = txt.split("\n")
+            for g in good:
+                parts.insert(rnd.randint(0, len(parts)), g)
+            txt = "\n".join(parts)
+        p = os.path.join(tmpdir_s, "gi_fuzz%d.paf" % k)
+        open(p, "wb").write(txt.encode("ascii"))
+        total += _same_as_host(ctx, p, opt)
+        total += _same_as_host(ctx, p, opt, bi_dir=False)
+    assert total > 1000
+    ctx.close()

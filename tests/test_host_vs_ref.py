@@ -374,3 +374,37 @@ def test_unitig_sequences_match_reference(tmpdir_s):
         first = texts[0].split(b"\n")[0].split(b"\t")
         assert first[0] == b"S" and first[2] != b"*" and len(first[2]) > 1000
     LR.asg_destroy(S["g"])
+
+
+@needs_ref
+def test_host_reader_fuzz_matches_reference(tmpdir_s):
+    """random ASCII soup (separators, signs, blanks, CR, NUL over-represented) through the reference's ma_hit_read and through
+    the host reader: same dictionary, same records.  (The device parser is fuzzed against the host reader in test_gpu_ingest.)"""
+    import random
+    rnd = random.Random(77)
+    alphabet = "0123456789" * 6 + "\t" * 14 + "\n" * 3 + "+- \r\x00\x0b\x0cabcxyzACGT:_.|" + "\t\t"
+    opt = ma.default_opt(); opt.min_span = 0; opt.min_match = 0
+    LR = R.ref()
+    for k in range(10):
+        n = rnd.choice((0, 7, 300, 5000, 60000, 300000))
+        txt = "".join(rnd.choice(alphabet) for _ in range(n))
+        good = ["r%d\t9000\t%d\t%d\t%s\tr%d\t8000\t%d\t%d\t%d\t%d\t255" % (rnd.randint(0, 40), a, a + rnd.randint(0, 5000), rnd.choice("+-"), rnd.randint(0, 40), b,
+                                                                     b + rnd.randint(0, 5000), rnd.randint(0, 900), rnd.randint(0, 4000))
+                for a, b in ((rnd.randint(0, 3000), rnd.randint(0, 3000)) for _ in range(200))]
+        parts = txt.split("\n")
+        for g in good[1:]:
+            parts.insert(rnd.randint(0, len(parts)), g)
+        txt = good[0] + "\n" + "\n".join(parts)  # a full first line: the reference's `bl` is uninitialised before the first 11-column line
+        p = os.path.join(tmpdir_s, "fz%d.paf" % k)
+        open(p, "wb").write(txt.encode("ascii"))
+        d = LR.sd_init()
+        cnt = C.c_size_t(0)
+        q = LR.ma_hit_read(p.encode(), opt.min_span, opt.min_match, d, C.byref(cnt), 1, None)
+        ref_hits = R.np_from(q, cnt.value, ma.HIT_DT)
+        ref_hits["bldel"] &= 0x7FFFFFFF
+        ing = ma.Ingest(p, opt)
+        assert ing.n == cnt.value, k
+        assert [x.encode() for x in ing.names()] == [d.contents.seq[i].name for i in range(d.contents.n_seq)], k
+        assert list(ing.lens()) == [d.contents.seq[i].len for i in range(d.contents.n_seq)], k
+        assert R.canon(ing.hits).tobytes() == R.canon(ref_hits).tobytes(), k
+        LR.free_buf(q); LR.sd_destroy(d); ing.close()
