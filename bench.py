@@ -129,9 +129,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook: exercise the multi-process path on a box with ONE GPU (all ranks on device 0, collectives over gloo);
+    # never set by the driver -- the real thing is one rank per GPU over RCCL
+    one_gpu_debug = os.environ.get("MA_BENCH_ONE_GPU_DEBUG") == "1"
+    if one_gpu_debug:
+        local = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if one_gpu_debug:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local)
@@ -205,6 +213,9 @@ def main():
     max_qs = ing.max_qs
 
     def step():
+        if os.environ.get("MA_DEBUG_COMM") == "1":
+            log2 = lambda *a: print("[bench %d]" % rank, *a, file=sys.stderr, flush=True)
+            log2("step: adopt", n_my, n_seq)
         ma._chk(L.mahip_hits_adopt(ctx.h, hits_dev.data_ptr(), n_my, n_seq), "adopt")
         L.mahip_set_hints(ctx.h, max_qs)
         if world == 1:  # single GPU: the C pipeline end to end
@@ -235,7 +246,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu_debug else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
     total_lines = float(n_lines)  # the global data set (world x per-GPU lines)
@@ -245,8 +256,10 @@ def main():
     if rank == 0:
         ctx.prof_enable(True)
         ctx.prof_reset()
-        for _ in range(args.prof_steps):
-            step()
+    for _ in range(args.prof_steps):  # a step is collective in the sharded mode: EVERY rank runs it, rank 0 is the one instrumented
+        step()
+    fence()
+    if rank == 0:
         recs = ctx.prof_get()
         ctx.prof_enable(False)
         tot_ms = sum(r["total_ms"] for r in recs) or 1.0

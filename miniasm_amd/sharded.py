@@ -15,12 +15,15 @@ very same orchestration code over gloo with a test double built on the oracle (t
 All exchange buffers are flat uint8 torch tensors on the backend's device.
 """
 import ctypes as C
+import os
+import sys
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
 BUF_SUB0, BUF_SUB1, BUF_RCONT, BUF_RUSED, BUF_SDEL = 0, 1, 2, 3, 4
+_DEBUG = os.environ.get("MA_DEBUG_COMM") == "1"
 
 
 class Comm:
@@ -31,24 +34,35 @@ class Comm:
         self.rank = dist.get_rank() if self.on else 0
         self.world = dist.get_world_size() if self.on else 1
         self.group = group
+        # gloo (CPU tests, the one-GPU debug hook of bench.py) moves device buffers through the host; RCCL works on them in place
+        self.via_host = self.on and dist.get_backend(group) == "gloo"
+
+    def _stage(self, t):
+        return t.cpu() if self.via_host and t.is_cuda else t
 
     def all_gather_bytes(self, local):
         """local: uint8 [n] -> uint8 [world*n] (rank-major)"""
         if self.world == 1:
             return local
-        out = torch.empty(self.world * local.numel(), dtype=torch.uint8, device=local.device)
-        dist.all_gather_into_tensor(out, local, group=self.group)
-        return out
+        src = self._stage(local)
+        out = torch.empty(self.world * src.numel(), dtype=torch.uint8, device=src.device)
+        if _DEBUG:
+            print("[comm %d] all_gather %d bytes on %s" % (self.rank, src.numel(), src.device), file=sys.stderr, flush=True)
+        dist.all_gather_into_tensor(out, src, group=self.group)
+        return out.to(local.device) if out.device != local.device else out
 
     def all_reduce_max_bytes(self, t):
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            h = self._stage(t)
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+            if h is not t:
+                t.copy_(h)
         return t
 
     def all_gather_int(self, x, device):
         if self.world == 1:
             return [int(x)]
-        t = torch.zeros(self.world, dtype=torch.int64, device=device)
+        t = torch.zeros(self.world, dtype=torch.int64, device="cpu" if self.via_host else device)
         t[self.rank] = int(x)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return [int(v) for v in t.tolist()]
@@ -60,7 +74,7 @@ class Comm:
         """element-wise sum of a short list of integers over the ranks: one collective, one host sync"""
         if self.world == 1:
             return [int(x) for x in xs]
-        t = torch.tensor([int(x) for x in xs], dtype=torch.int64, device=device)
+        t = torch.tensor([int(x) for x in xs], dtype=torch.int64, device="cpu" if self.via_host else device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return [int(v) for v in t.tolist()]
 

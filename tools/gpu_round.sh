@@ -23,6 +23,10 @@ sharded)
 torchrun1)
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --reads 20000 --lines 1000000 --steps 3 --warmup 1 --no-cpu > gpurun_out/bench_torchrun1.json 2> gpurun_out/bench_torchrun1.log; echo "rc=$?"
   tail -3 gpurun_out/bench_torchrun1.log; cut -c1-400 gpurun_out/bench_torchrun1.json ;;
+torchrun2debug)
+  # 2 processes on the one GPU of this box, gloo collectives: the multi-process control flow of bench.py end to end
+  MA_BENCH_ONE_GPU_DEBUG=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --reads 20000 --lines 1000000 --steps 3 --warmup 1 > gpurun_out/bench_torchrun2.json 2> gpurun_out/bench_torchrun2.log; echo "rc=$?"
+  tail -5 gpurun_out/bench_torchrun2.log; cut -c1-600 gpurun_out/bench_torchrun2.json ;;
 smoke)
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "rc=$?" >> gpurun_out/smoke.log
   grep -vE "^\[M::" gpurun_out/smoke.log | tail -15 ;;
