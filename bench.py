@@ -52,7 +52,13 @@ def cpu_baseline(args, workdir):
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "miniasm_ref")
     reads, lines = args.reads // args.cpu_div, args.lines // args.cpu_div
     paf = gen_paf(os.path.join(workdir, "cpu_r%d_n%d_s%d.paf" % (reads, lines, args.seed + 1000)), reads, lines, args.seed + 1000, args.gen_extra)
-    n_lines = sum(1 for _ in open(paf, "rb"))
+    n_lines = 0
+    with open(paf, "rb") as f:  # pafgen writes one overlap per line, newline-terminated
+        while True:
+            blk = f.read(64 << 20)
+            if not blk:
+                break
+            n_lines += blk.count(b"\n")
     if os.path.exists(ref_bin):
         best = None
         for _ in range(args.cpu_runs):
@@ -170,7 +176,13 @@ def main():
     t0 = time.perf_counter()
     ing = ma.Ingest(paf, opt)
     t_ingest = time.perf_counter() - t0
-    n_lines = sum(1 for _ in open(paf, "rb"))
+    n_lines = 0
+    with open(paf, "rb") as f:  # pafgen writes one overlap per line, newline-terminated
+        while True:
+            blk = f.read(64 << 20)
+            if not blk:
+                break
+            n_lines += blk.count(b"\n")
     n_seq = ing.n_seq
     _, q0, q1 = shard_range(n_seq, world, rank)
     if world > 1:
