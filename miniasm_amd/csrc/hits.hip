@@ -178,11 +178,9 @@ struct SubFuse {
 struct SubAcc { uint32_t n_cut, n_flt; uint64_t dp; }; // per-lane partial counters of the fused passes
 
 // cut + filter of one live hit held in registers; returns 0 if the hit dies (its dead bit is written), else 1
-__device__ __forceinline__ int fuse_cut_flt(const HitCols &c, uint32_t i, const SubFuse &f, uint32_t q, uint2 rq, uint32_t tn,
-                                            uint32_t &qs, uint32_t &qe, uint32_t ml, uint32_t bl, SubAcc &acc)
-{
-	uint2 rt = f.cut_sub[tn];
-	uint32_t ts = c.ts[i], te = c.te[i];
+__device__ __forceinline__ int fuse_cut_flt_v(const HitCols &c, uint32_t i, const SubFuse &f, uint32_t q, uint2 rq, uint32_t tn,
+                                              uint32_t &qs, uint32_t &qe, uint32_t ml, uint32_t bl, SubAcc &acc, uint2 rt, uint32_t ts, uint32_t te)
+{ // rt = the target's interval, ts/te = the hit's target columns: fetched by the caller (ahead of time in the SMALL kernels)
 	int keep = 0;
 	if (!(rq.x & DEAD) && !(rt.x & DEAD) && mc_cut(&qs, &qe, &ts, &te, ml >> 31, (int32_t)rq.x, rq.y, (int32_t)rt.x, rt.y, f.min_span)) {
 		mc_arc_t a;
@@ -199,23 +197,58 @@ __device__ __forceinline__ int fuse_cut_flt(const HitCols &c, uint32_t i, const 
 	if (!keep) c.bl[i] = bl | DEAD;
 	return keep;
 }
+__device__ __forceinline__ int fuse_cut_flt(const HitCols &c, uint32_t i, const SubFuse &f, uint32_t q, uint2 rq, uint32_t tn,
+                                            uint32_t &qs, uint32_t &qe, uint32_t ml, uint32_t bl, SubAcc &acc)
+{
+	return fuse_cut_flt_v(c, i, f, q, rq, tn, qs, qe, ml, bl, acc, f.cut_sub[tn], c.ts[i], c.te[i]);
+}
 
-// one read in registers; returns 1 if the read keeps an interval (value identical on all lanes)
+// the columns of up to 128 hits of one read, two slots per lane (hits lane and lane + 64), loaded ahead of their use: the
+// SMALL kernels fetch the next read's hits before they work on the current one (the work is a long dependent chain per read,
+// and 8 waves per SIMD do not hide an HBM round trip per read on their own)
+struct SubPre { uint32_t beg, end; uint32_t bl[2], ml[2], qs[2], qe[2], tn[2], ts[2], te[2]; uint2 rt[2], rq; }; // ts/te, rt/rq: fused passes only
+
+template <bool FUSE>
+__device__ __forceinline__ void sub_preload(const HitCols &c, const uint32_t *__restrict__ goff, uint32_t q, unsigned lane, SubPre &p)
+{
+	p.beg = goff[q]; p.end = goff[q + 1];
+	const uint32_t H = p.end - p.beg;
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const uint32_t i = p.beg + h * 64 + lane;
+		p.bl[h] = DEAD; p.ml[h] = p.qs[h] = p.qe[h] = p.tn[h] = p.ts[h] = p.te[h] = 0;
+		if (H <= 128u && i < p.end) {
+			p.bl[h] = c.bl[i]; p.ml[h] = c.ml[i]; p.qs[h] = c.qs[i]; p.qe[h] = c.qe[i]; p.tn[h] = c.tn[i];
+			if (FUSE) { p.ts[h] = c.ts[i]; p.te[h] = c.te[i]; }
+		}
+	}
+}
+
+// one read in registers; returns 1 if the read keeps an interval (value identical on all lanes).  pre != nullptr: the
+// columns of the (at most 128) hits are already in registers
 template <int ITEMS, bool FUSE>
 __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q, uint32_t beg, uint32_t end, int min_dp, float min_iden,
-                                                   int end_clip, uint2 *__restrict__ sub, unsigned lane, const SubFuse &f, SubAcc &acc)
+                                                   int end_clip, uint2 *__restrict__ sub, unsigned lane, const SubFuse &f, SubAcc &acc, const SubPre *pre = nullptr)
 {
 	uint32_t x[ITEMS];
 	int live_any = 0, ev_any = 0;
 	uint2 rq = make_uint2(0, 0);
-	if (FUSE) rq = f.cut_sub[q];
+	if (FUSE) rq = pre ? pre->rq : f.cut_sub[q];
 #pragma unroll
 	for (int h = 0; h < ITEMS / 2; ++h) {
 		uint32_t i = beg + h * 64 + lane;
 		x[2 * h] = x[2 * h + 1] = EV_PAD;
 		if (i < end) {
-			uint32_t bl = c.bl[i], ml = c.ml[i], qs = c.qs[i], qe = c.qe[i], tn = c.tn[i], es, ee; // independent loads
-			if (!(bl & DEAD) && (!FUSE || fuse_cut_flt(c, i, f, q, rq, tn, qs, qe, ml, bl, acc))) {
+			uint32_t bl, ml, qs, qe, tn, es, ee;
+			int alive;
+			if (pre && h < 2) {
+				bl = pre->bl[h]; ml = pre->ml[h]; qs = pre->qs[h]; qe = pre->qe[h]; tn = pre->tn[h];
+				alive = !(bl & DEAD) && (!FUSE || fuse_cut_flt_v(c, i, f, q, rq, tn, qs, qe, ml, bl, acc, pre->rt[h], pre->ts[h], pre->te[h]));
+			} else {
+				bl = c.bl[i]; ml = c.ml[i]; qs = c.qs[i]; qe = c.qe[i]; tn = c.tn[i]; // independent loads
+				alive = !(bl & DEAD) && (!FUSE || fuse_cut_flt(c, i, f, q, rq, tn, qs, qe, ml, bl, acc));
+			}
+			if (alive) {
 				live_any = 1;
 				if (mc_sub_ok(q, qs, qe, tn, (int32_t)(ml & 0x7fffffffu), (int32_t)bl, min_iden, end_clip, &es, &ee)) x[2 * h] = es, x[2 * h + 1] = ee, ev_any = 1;
 			}
@@ -280,13 +313,29 @@ __global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__re
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t n_kept = 0;
 	SubAcc acc = {0, 0, 0};
+	if (SMALL) { // software pipeline: the hits of the wave's next read are in flight while the current read is processed
+		const uint32_t stride = gridDim.x * 4;
+		uint32_t q = blockIdx.x * 4 + wave;
+		SubPre cur, nxt;
+		if (q < n_seq) sub_preload<FUSE>(c, goff, q, lane, cur);
+		while (q < n_seq) {
+			const uint32_t qn = q + stride;
+			if (FUSE) { // this read's interval gathers first, the next read's columns behind them: the waits below are in issue order
+				cur.rq = f.cut_sub[q];
+#pragma unroll
+				for (int h = 0; h < 2; ++h) cur.rt[h] = (cur.bl[h] & DEAD) ? make_uint2(DEAD, 0) : f.cut_sub[cur.tn[h]];
+			}
+			if (qn < n_seq) sub_preload<FUSE>(c, goff, qn, lane, nxt);
+			const uint32_t beg = cur.beg, end = cur.end, H = end - beg;
+			if (H == 0) { if (lane == 0) sub[q] = make_uint2(0, 0); } // never a query: calloc'ed zero (hit.c:115)
+			else if (H <= 64) n_kept += sub_group_regs<2, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc, &cur);
+			else if (H <= 128) n_kept += sub_group_regs<4, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc, &cur);
+			cur = nxt; q = qn;
+		}
+	} else
 	for (uint32_t q = blockIdx.x * 4 + wave; q < n_seq; q += gridDim.x * 4) {
 		uint32_t beg = goff[q], end = goff[q + 1], H = end - beg;
-		if (SMALL) {
-			if (H == 0) { if (lane == 0) sub[q] = make_uint2(0, 0); continue; } // never a query: calloc'ed zero (hit.c:115)
-			if (H <= 64) n_kept += sub_group_regs<2, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc);
-			else if (H <= 128) n_kept += sub_group_regs<4, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc);
-		} else {
+		{
 			if (H <= 128) continue;
 			if (H <= 256) n_kept += sub_group_regs<8, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc);
 			else if (H <= SUB_REG_MAX_HITS) n_kept += sub_group_regs<16, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc);
