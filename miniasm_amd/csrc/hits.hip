@@ -303,9 +303,10 @@ __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q,
 	return 1;
 }
 
-// Two instantiations per fusion mode share the work by read size: SMALL handles reads with <= 128 hits (4 events per
-// lane, few registers -> high occupancy, which this latency-bound code needs), !SMALL the rest (up to 16 events per lane).
-template <bool FUSE, bool SMALL>
+// Three instantiations per fusion mode share the work by read size, so that each runs at the occupancy its register
+// need allows: CLS 0 = reads with <= 128 hits (4 events per lane, 8 waves/SIMD, software-pipelined loads), CLS 1 = 129..256
+// hits (16 events per lane), CLS 2 = 257..512 hits (32 events per lane); larger reads go to the block kernel (tier B).
+template <bool FUSE, int CLS>
 __global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
                                                   int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
                                                   uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr, SubFuse f)
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__re
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t n_kept = 0;
 	SubAcc acc = {0, 0, 0};
-	if (SMALL) { // software pipeline: the hits of the wave's next read are in flight while the current read is processed
+	if (CLS == 0) { // software pipeline: the hits of the wave's next read are in flight while the current read is processed
 		const uint32_t stride = gridDim.x * 4;
 		uint32_t q = blockIdx.x * 4 + wave;
 		SubPre cur, nxt;
@@ -335,11 +336,11 @@ __global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__re
 	} else
 	for (uint32_t q = blockIdx.x * 4 + wave; q < n_seq; q += gridDim.x * 4) {
 		uint32_t beg = goff[q], end = goff[q + 1], H = end - beg;
-		{
-			if (H <= 128) continue;
-			if (H <= 256) n_kept += sub_group_regs<8, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc);
-			else if (H <= SUB_REG_MAX_HITS) n_kept += sub_group_regs<16, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc);
-			else if (lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF], 1ull); ovf[k] = q; } // tier B
+		if (CLS == 1) {
+			if (H > 128 && H <= 256) n_kept += sub_group_regs<8, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc);
+		} else {
+			if (H > 256 && H <= SUB_REG_MAX_HITS) n_kept += sub_group_regs<16, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc);
+			else if (H > SUB_REG_MAX_HITS && lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF], 1ull); ovf[k] = q; } // tier B
 		}
 	}
 	blk_add_u64(&ctr[CT_REMAIN], lane == 0 ? n_kept : 0);
@@ -788,9 +789,11 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 	SubFuse nofuse = {nullptr, 0, 0, 0, nullptr};
 	if (R) {
 		ProfScope ps(c, "k_hit_sub", 24.0 * (double)c->n_hits + 8.0 * R);
-		hipLaunchKernelGGL((k_hit_sub<false, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse);
-		hipLaunchKernelGGL((k_hit_sub<false, false>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		                   sub, P<uint32_t>(c->ovf), ctr, nofuse);
+		hipLaunchKernelGGL((k_hit_sub<false, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse);
 	}
 	CHK(ctr_fetch(c));
@@ -824,9 +827,11 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
 	SubFuse f = {(const uint2*)P<uint2>(c->sub[cut_slot]), min_span, max_hang, min_ovlp, P<uint8_t>(c->r_live)};
 	if (R) {
 		ProfScope ps(c, "k_hit_sub<cut+flt>", (80.0 + 80.0 + 48.0) * (double)c->n_hits + 8.0 * R); // cut 80 + flt 80 + sub 48 B per hit
-		hipLaunchKernelGGL((k_hit_sub<true, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<true, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, f);
-		hipLaunchKernelGGL((k_hit_sub<true, false>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<true, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		                   sub, P<uint32_t>(c->ovf), ctr, f);
+		hipLaunchKernelGGL((k_hit_sub<true, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, f);
 	}
 	CHK(ctr_fetch(c));
