@@ -102,11 +102,18 @@ def pmc_traffic(kernel, args):
         d = json.load(open(path))
     except Exception:
         return None
+    names = {k.replace("void ", ""): v for k, v in d.items()}
+    per_launch = lambda v: v["fetch_bytes_x2"] + v["write_bytes"]
+    # a timed scope of the coverage passes = one launch of each size-class kernel: their bytes add up
+    scope = {"k_hit_sub<cut+flt>": "k_hit_sub<true,", "k_hit_sub": "k_hit_sub<false,"}.get(kernel)
+    if scope:
+        parts = [v for k, v in names.items() if k.startswith(scope)]
+        return round(sum(per_launch(v) for v in parts)) if parts else None
     base = kernel.split("<")[0]
-    hits = [v for k, v in d.items() if k.split("<")[0].replace("void ", "") == base]
+    hits = [v for k, v in names.items() if k.split("<")[0] == base]
     if not hits:
         return None
-    tot = sum((v["fetch_bytes_x2"] + v["write_bytes"]) * v["launches"] for v in hits) / max(sum(v["launches"] for v in hits), 1)
+    tot = sum(per_launch(v) * v["launches"] for v in hits) / max(sum(v["launches"] for v in hits), 1)
     return round(tot)
 
 
