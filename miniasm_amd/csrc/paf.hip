@@ -364,6 +364,10 @@ __global__ __launch_bounds__(256) void k_paf_emit(PafCols o, const uint32_t *__r
 static int paf_reserve_text(mahip_ctx *c, size_t nbytes)
 {
 	PafBufs *b = paf_of(c);
+	{ // a cap on the text the device stage accepts (tests use it to exercise the caller's fall-back to the host reader)
+		const char *e = getenv("MA_PAF_MAX_BYTES");
+		if (e && nbytes > (size_t)atoll(e)) { mahip_set_error("text of %zu bytes exceeds MA_PAF_MAX_BYTES", nbytes); return -1; }
+	}
 	const bool timing = getenv("MA_PIPE_TIMING") != nullptr;
 	struct timespec ts0, ts1;
 	if (timing) clock_gettime(CLOCK_MONOTONIC, &ts0);

@@ -165,16 +165,19 @@ ma_hit_t *ma_hit_read(const char *fn, int min_span, int min_match, sdict_t *d, s
 	if (excl == 0 && d->n_seq == 0 && ma_gpu_parse_enabled()) { /* text -> sorted records on the device, one download */
 		mahip_ctx_t *c = ma_gpu();
 		size_t m = 0;
-		if (ma_hit_ingest_gpu(c, fn, min_span, min_match, d, n, bi_dir) != 0) {
+		int rc = strcmp(fn, "-") != 0 ? ma_hit_ingest_gpu(c, fn, min_span, min_match, d, n, bi_dir) : -2;
+		if (rc == -1) {
 			fprintf(stderr, "[E::%s] could not open PAF file %s\n", __func__, fn);
 			exit(1);
 		}
-		a = (ma_hit_t*)malloc((*n ? *n : 1) * sizeof(ma_hit_t));
-		if (*n) {
-			GPU(mahip_hits_sort(c));
-			GPU(mahip_hits_download(c, a, &m));
-		}
-		return a;
+		if (rc == 0) {
+			a = (ma_hit_t*)malloc((*n ? *n : 1) * sizeof(ma_hit_t));
+			if (*n) {
+				GPU(mahip_hits_sort(c));
+				GPU(mahip_hits_download(c, a, &m));
+			}
+			return a;
+		} /* -2: stdin, or the text stage does not fit the device: host reader */
 	}
 	a = ma_hit_ingest(fn, min_span, min_match, d, n, bi_dir, excl);
 	ma_hit_sort(*n, a);

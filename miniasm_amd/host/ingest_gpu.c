@@ -18,6 +18,9 @@
 #include "ma_host.h"
 
 #define GPU(call) do { if ((call) != 0) ma_gpu_fail(__func__); } while (0)
+/* the text stage may simply not fit (text + 61 B of columns per line + the records): report -2 and let the caller fall
+ * back to the host reader, which streams the file and only needs the records on the device */
+#define GPU_SOFT(call) do { if ((call) != 0) { fprintf(stderr, "[W::%s] device-side parse not possible (%s); using the host reader\n", __func__, mahip_strerror()); mahip_paf_release(c); return -2; } } while (0)
 
 static char *slurp_gz(gzFile fp, size_t *len)
 {
@@ -49,7 +52,7 @@ int ma_hit_ingest_loaded(mahip_ctx_t *c, int min_span, int min_match, sdict_t *d
 	mahip_paf_info_t info;
 	size_t i, tot_len = 0;
 	GPU(mahip_set_shard(c, 0, 0xffffffffu));
-	GPU(mahip_paf_parse(c, min_span, min_match, bi_dir, &info));
+	GPU_SOFT(mahip_paf_parse(c, min_span, min_match, bi_dir, &info));
 	t2 = sys_realtime();
 	/* the dictionary: names (one block, adopted as the dictionary's arena: no per-name allocation) and first-seen lengths */
 	{
@@ -84,7 +87,7 @@ int ma_paf_load_file(mahip_ctx_t *c, const char *fn)
 		}
 	}
 	if (is_plain) {
-		GPU(mahip_paf_load_fd(c, fd, (size_t)st.st_size));
+		if (mahip_paf_load_fd(c, fd, (size_t)st.st_size) != 0) { close(fd); fprintf(stderr, "[W::%s] device-side parse not possible (%s); using the host reader\n", __func__, mahip_strerror()); mahip_paf_release(c); return -2; }
 		close(fd);
 	} else {
 		gzFile fp = fd >= 0 ? gzdopen(fd, "r") : gzdopen(fileno(stdin), "r");
@@ -94,18 +97,22 @@ int ma_paf_load_file(mahip_ctx_t *c, const char *fn)
 		gzbuffer(fp, 1u << 20);
 		buf = slurp_gz(fp, &len);
 		gzclose(fp);
-		GPU(mahip_paf_load_mem(c, buf, len));
+		if (mahip_paf_load_mem(c, buf, len) != 0) { free(buf); fprintf(stderr, "[W::%s] device-side parse not possible (%s); using the host reader\n", __func__, mahip_strerror()); mahip_paf_release(c); return -2; }
 		free(buf);
 	}
 	return 0;
 }
 
-/* returns 0 and leaves the unsorted records in the context (as after mahip_hits_upload); -1 = could not open */
+/* returns 0 and leaves the unsorted records in the context (as after mahip_hits_upload); -1 = could not open;
+ * -2 = the device-side stage could not run (memory): nothing was consumed, the caller may use the host reader */
 int ma_hit_ingest_gpu(mahip_ctx_t *c, const char *fn, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir)
 {
 	const int timing = getenv("MA_PIPE_TIMING") != 0;
 	double t0 = sys_realtime();
-	if (ma_paf_load_file(c, fn) != 0) return -1;
+	{
+		int rc = ma_paf_load_file(c, fn);
+		if (rc != 0) return rc; /* -1 cannot open, -2 does not fit */
+	}
 	if (timing) fprintf(stderr, "[T::ingest_gpu] load %.3f s\n", sys_realtime() - t0);
 	return ma_hit_ingest_loaded(c, min_span, min_match, d, n_hits, bi_dir, 1);
 }

@@ -295,7 +295,7 @@ int ma_pipeline_run(const ma_opt_t *opt, const char *fn, const char *outfmt, int
 	pthread_t th_gpu, th_free;
 	/* the GPU context comes up (HIP runtime, code objects: 0.1-0.3 s) while the host parses; a machine without a GPU
 	 * still fails before any result is produced */
-	const int gpu_bg = pthread_create(&th_gpu, 0, gpu_warmup, 0) == 0;
+	int gpu_bg = pthread_create(&th_gpu, 0, gpu_warmup, 0) == 0;
 	ma_hit_t *hit;
 	size_t n_hits = 0;
 	FILE *lg = MA_LOG;
@@ -304,14 +304,19 @@ int ma_pipeline_run(const ma_opt_t *opt, const char *fn, const char *outfmt, int
 		excl = ma_hit_no_cont(fn, opt->min_span, opt->min_match, opt->max_hang, opt->int_frac);
 	}
 	fprintf(lg, "[M::%s] ===> Step 1: reading read mappings <===\n", "main");
-	if (excl == 0 && ma_gpu_parse_enabled()) { /* text -> records + dictionary on the device (csrc/paf.hip) */
-		if (gpu_bg) pthread_join(th_gpu, 0);
+	int on_device = 0;
+	if (excl == 0 && ma_gpu_parse_enabled() && strcmp(fn, "-") != 0) { /* text -> records + dictionary on the device (csrc/paf.hip) */
+		int rc;
+		if (gpu_bg) pthread_join(th_gpu, 0), gpu_bg = 0;
 		c = ma_gpu();
-		if (ma_hit_ingest_gpu(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4)) != 0) {
+		rc = ma_hit_ingest_gpu(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4));
+		if (rc == -1) {
 			fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn);
 			exit(1);
 		}
-	} else {
+		on_device = rc == 0; /* -2: does not fit -> host reader below */
+	}
+	if (!on_device) { /* -R, MA_HOST_PARSE=1, stdin (a stream cannot be re-read after a failed device attempt), or a text too big for the device stage */
 		const int timing = getenv("MA_PIPE_TIMING") != 0;
 		double t0 = sys_realtime(), t1, t2;
 		hit = ma_hit_ingest(fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), excl);

@@ -155,3 +155,16 @@ def test_ingest_fuzz_against_host_reader(tmpdir_s):
         total += _same_as_host(ctx, p, opt, bi_dir=False)
     assert total > 1000
     ctx.close()
+
+
+def test_cli_falls_back_to_host_reader_when_text_stage_does_not_fit(tmpdir_s, monkeypatch):
+    """a text the device stage refuses (here: an artificial cap) is parsed by the host reader instead: same output, a warning"""
+    import subprocess
+    paf = R.pafgen(os.path.join(tmpdir_s, "gi_fb.paf"), 3000, 80000, 41, [])
+    base, _ = R.run_cli(ma.CLI_PATH, ["-p", "ug"], paf)
+    monkeypatch.setenv("MA_PAF_MAX_BYTES", "1000")
+    out, log = R.run_cli(ma.CLI_PATH, ["-p", "ug"], paf)
+    assert out == base and "using the host reader" in log
+    r = subprocess.run([R.DROPIN_BIN, "-p", "ug", paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE) if R.have_ref() else None
+    if r is not None:
+        assert r.returncode == 0 and r.stdout == base and b"using the host reader" in r.stderr
