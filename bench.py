@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--workdir", default=os.environ.get("MA_BENCH_DIR", "/tmp/ma_bench"))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-text", action="store_true", help="skip the text-resident leg (device-side parse)")
+    ap.add_argument("--no-overlap", action="store_true", help="run each pass's host tail before the next pass's device part starts")
     ap.add_argument("--cpu-div", type=int, default=5, help="CPU baseline sample = workload / this")
     ap.add_argument("--cpu-runs", type=int, default=2)
     ap.add_argument("--prof-steps", type=int, default=3)
@@ -231,39 +232,82 @@ def main():
 
     max_qs = ing.max_qs
 
+    # Passes are pipelined over the stream of batches: the device part of pass k+1 starts as soon as pass k's reduced graph
+    # has been fetched (ma_pipeline_tail_fetch = the last use of the device for a batch), while pass k's host part (sequential
+    # cleaners, unitigs, GFA text: ma_pipeline_tail_finish) runs on a worker thread.  All K outputs are complete before the
+    # closing fence.  --no-overlap runs head and tail back to back.
+    import queue
+    import threading
+    L.ma_pipeline_head.restype = C.c_int
+    L.ma_pipeline_head.argtypes = [C.c_void_p, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint32 * 4)]
+    L.ma_pipeline_tail_fetch.restype = C.c_void_p
+    L.ma_pipeline_tail_fetch.argtypes = [C.c_void_p, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.POINTER(C.c_uint32 * 4)]
+    L.ma_pipeline_tail_finish_mem.restype = C.c_int
+    L.ma_pipeline_tail_finish_mem.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    overlap = not args.no_overlap
+    tail_out = {"n": 0, "rc": 0}
+
+    def finish(job):
+        b, l = C.c_void_p(0), C.c_size_t(0)
+        rc = L.ma_pipeline_tail_finish_mem(job, C.byref(b), C.byref(l))
+        tail_out["n"], tail_out["rc"] = l.value, tail_out["rc"] or rc
+        L.free_buf(b)
+
+    tailq = queue.Queue(maxsize=1)  # one batch may wait while another is being finished
+
+    def tail_worker():
+        while True:
+            job = tailq.get()
+            if job is not None:
+                finish(job)
+            tailq.task_done()
+            if job is None:
+                return
+
+    worker = None
+    if overlap and rank == 0:
+        worker = threading.Thread(target=tail_worker, daemon=True)
+        worker.start()
+
     def step():
         if os.environ.get("MA_DEBUG_COMM") == "1":
             log2 = lambda *a: print("[bench %d]" % rank, *a, file=sys.stderr, flush=True)
             log2("step: adopt", n_my, n_seq)
         ma._chk(L.mahip_hits_adopt(ctx.h, hits_dev.data_ptr(), n_my, n_seq), "adopt")
         L.mahip_set_hints(ctx.h, max_qs)
-        if world == 1:  # single GPU: the C pipeline end to end
-            rc = L.ma_pipeline_device_mem(ctx.h, C.byref(opt), ing.d, b"ug", 100, 0, C.byref(buf), C.byref(ln))
-            assert rc == 0
+        st = (C.c_uint32 * 4)(0, 0, 0, 0)
+        if world == 1:  # single GPU: the C pipeline's device half
+            assert L.ma_pipeline_head(ctx.h, C.byref(opt), ing.d, b"ug", 100, 0, C.byref(st)) == 0
         else:  # sharded: device passes + RCCL exchanges on every rank, graph cleaning + GFA on rank 0
             stats = run_sharded(be, comm, opt, n_seq)
             if rank != 0:
                 return 0
             st = (C.c_uint32 * 4)(1, 1, stats["n_red"], 1)
-            rc = L.ma_pipeline_tail_mem(ctx.h, C.byref(opt), ing.d, b"ug", 100, C.byref(st), C.byref(buf), C.byref(ln))
-            assert rc == 0
-        n = ln.value
-        L.free_buf(buf)
-        return n
+        job = L.ma_pipeline_tail_fetch(ctx.h, C.byref(opt), ing.d, b"ug", 100, C.byref(st))
+        assert job
+        if worker:
+            tailq.put(job)
+        else:
+            finish(job)
+        return tail_out["n"]
 
     def fence():
+        if worker:
+            tailq.join()  # every host tail handed over so far is complete
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        assert tail_out["rc"] == 0
 
     for _ in range(args.warmup):
-        gfa_len = step()
+        step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        gfa_len = step()
+        step()
     fence()
     dt = time.perf_counter() - t0
+    gfa_len = tail_out["n"]
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu_debug else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -343,7 +387,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "synthetic %s PAF: %d overlaps, %d reads, mean 8 kb, %.1f stored hits/read, seed %d; inputs = unsorted 32-byte hit records resident in HBM%s; output = GFA text (%d bytes)" % (
                 args.model, n_lines, n_seq, n_all / max(n_seq, 1), args.seed, " (sharded by query-read range)" if world > 1 else "", gfa_len),
-                "per_gpu_overlaps": n_lines // world, "parallelism": "read-range shards x%d, RCCL all-gather of sub/flags/arcs" % world if world > 1 else "single GPU"},
+                "per_gpu_overlaps": n_lines // world,
+                "pipelining": "host tail of pass k (cleaners, unitigs, GFA text) overlaps the device part of pass k+1; all K outputs complete inside the timed region" if overlap else "none (--no-overlap)",
+                "parallelism": "read-range shards x%d, RCCL all-gather of sub/flags/arcs" % world if world > 1 else "single GPU"},
             "roofline": roof, "cpu_baseline": cpu, "from_text": from_text, "kernels": kernels[:12],
             "setup": {"ingest_lines_per_s": n_lines / t_ingest, "h2d_GBs": n_my * 32 / max(t_h2d, 1e-9) / 1e9, "hbm_bytes_held": ctx.mem_bytes()},
         }

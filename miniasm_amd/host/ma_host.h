@@ -20,6 +20,12 @@ int ma_pipeline_device(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, co
 /* its two halves: device passes (st[4] = have_sub, squeezed, n_reduced, graph built) and the host part */
 int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, uint32_t st[4]);
 int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, const uint32_t st[4], FILE *out);
+/* the tail's two halves: fetch = the last use of the device for this input; finish = host only (may run on another thread
+ * while the device already works on the next input), frees the job */
+typedef struct ma_tail_job ma_tail_job_t;
+ma_tail_job_t *ma_pipeline_tail_fetch(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, const uint32_t st[4]);
+int ma_pipeline_tail_finish(ma_tail_job_t *job, FILE *out);
+int ma_pipeline_tail_finish_mem(ma_tail_job_t *job, char **buf, size_t *len);
 
 void ma_sd_reindex(sdict_t *d);    /* build the name index from seq[] (for dictionaries assembled by hand) */
 void ma_sd_drop_index(sdict_t *d);

@@ -152,52 +152,83 @@ int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 	return 0;
 }
 
-/* Host part: names of the surviving reads, sub, then either a dump (bed/paf) or the reduced graph -> sequential
- * cleaners (main.c:160-187) -> unitigs -> GFA / string-graph text.  d is not modified: after containment removal
- * a shallow view of the surviving reads (names shared with d) is used for output. */
-int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, const uint32_t st[4], FILE *out)
-{
-	int have_sub = st[0], squeezed = st[1], i;
-	uint32_t R = d->n_seq, n_red = st[2];
+/* The tail in two halves.  ma_pipeline_tail_fetch() brings to the host what the rest needs -- the surviving reads (a shallow
+ * view of d: names shared), their kept intervals, and either the hits (paf dump) or the reduced graph -- and is the last
+ * thing that touches the device: a caller that processes a stream of inputs can start the next one's device passes right
+ * after it.  ma_pipeline_tail_finish() is pure host work: sequential cleaners (main.c:160-187) -> unitigs -> GFA /
+ * string-graph text (or the bed / paf dump); it frees the job.  d is not modified. */
+struct ma_tail_job {
+	ma_opt_t opt;
+	const sdict_t *d;
+	char outfmt[8];
+	int stage, have_sub, squeezed, have_graph;
+	uint32_t n_red;
 	sdict_t view;
-	ma_sub_t *sub = 0;
-	FILE *lg = MA_LOG;
+	ma_sub_t *sub;
+	size_t n_hit;
+	ma_hit_t *hit;
+	asg_t *sg;
+	double t_fetch[3];
+};
 
+ma_tail_job_t *ma_pipeline_tail_fetch(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, const uint32_t st[4])
+{
+	ma_tail_job_t *j = (ma_tail_job_t*)calloc(1, sizeof(ma_tail_job_t));
+	const uint32_t R = d->n_seq;
+	j->opt = *opt; j->d = d; j->stage = stage;
+	strncpy(j->outfmt, outfmt, sizeof(j->outfmt) - 1);
+	j->have_sub = st[0]; j->squeezed = st[1]; j->n_red = st[2]; j->have_graph = st[3];
+	j->t_fetch[0] = sys_realtime();
+	j->view.n_seq = R; j->view.seq = d->seq;
+	if (j->squeezed) { /* O(survivors): the device hands over the list of surviving old ids */
+		uint32_t k, n_new = mahip_n_seq_new(c), *old = (uint32_t*)malloc((n_new ? n_new : 1) * 4);
+		GPU(mahip_survivors_download(c, old));
+		j->view.seq = (sd_seq_t*)malloc((n_new ? n_new : 1) * sizeof(sd_seq_t));
+		for (k = 0; k < n_new; ++k) j->view.seq[k] = d->seq[old[k]], j->view.seq[k].del = 0, j->view.seq[k].aux = 0;
+		j->view.n_seq = n_new;
+		free(old);
+	}
+	if (j->have_sub) {
+		j->sub = (ma_sub_t*)calloc(j->view.n_seq ? j->view.n_seq : 1, sizeof(ma_sub_t));
+		GPU(mahip_sub_download(c, 0, j->sub, j->squeezed));
+	}
+	j->t_fetch[1] = sys_realtime();
+	if (strcmp(outfmt, "paf") == 0) {
+		j->n_hit = mahip_hits_live(c);
+		j->hit = (ma_hit_t*)malloc((j->n_hit ? j->n_hit : 1) * sizeof(ma_hit_t));
+		GPU(mahip_hits_download(c, j->hit, &j->n_hit));
+	} else if (strcmp(outfmt, "bed") != 0 && j->have_graph) {
+		j->sg = asg_init();
+		GPU(mahip_asg_download(c, j->sg)); /* the reduced graph is small: the sequential cleaners run on the host */
+		if (j->sg->n_seq != j->view.n_seq) { fprintf(stderr, "[E::%s] squeeze mismatch: host %u vs device %u reads\n", __func__, j->view.n_seq, j->sg->n_seq); exit(1); }
+		j->sg->is_symm = j->n_red > 0;
+	}
+	j->t_fetch[2] = sys_realtime();
+	return j;
+}
+
+int ma_pipeline_tail_finish(ma_tail_job_t *j, FILE *out)
+{
+	const ma_opt_t *opt = &j->opt;
+	const sdict_t *d = j->d;
+	const char *outfmt = j->outfmt;
+	const int stage = j->stage, squeezed = j->squeezed;
+	sdict_t *view = &j->view;
+	ma_sub_t *sub = j->sub;
+	FILE *lg = MA_LOG;
+	int i;
 	const int timing = getenv("MA_PIPE_TIMING") != 0;
 	double ct_acc[5] = {0, 0, 0, 0, 0}; /* per-cleaner wall time (MA_PIPE_TIMING) */
 #define CT(k, call) __extension__ ({ double t0_ = sys_realtime(); int r_ = (call); ct_acc[k] += sys_realtime() - t0_; r_; })
 	double tt[8] = {0};
 #define TSTAMP(k) do { if (timing) tt[k] = sys_realtime(); } while (0)
-	TSTAMP(0);
-	memset(&view, 0, sizeof(view));
-	view.n_seq = R; view.seq = d->seq;
-	if (squeezed) { /* O(survivors): the device hands over the list of surviving old ids */
-		uint32_t k, n_new = mahip_n_seq_new(c), *old = (uint32_t*)malloc((n_new ? n_new : 1) * 4);
-		GPU(mahip_survivors_download(c, old));
-		view.seq = (sd_seq_t*)malloc((n_new ? n_new : 1) * sizeof(sd_seq_t));
-		for (k = 0; k < n_new; ++k) view.seq[k] = d->seq[old[k]], view.seq[k].del = 0, view.seq[k].aux = 0;
-		view.n_seq = n_new;
-		free(old);
-	}
-	if (have_sub) {
-		sub = (ma_sub_t*)calloc(view.n_seq ? view.n_seq : 1, sizeof(ma_sub_t));
-		GPU(mahip_sub_download(c, 0, sub, squeezed));
-	}
-	TSTAMP(1);
 	if (strcmp(outfmt, "bed") == 0) {
-		if (sub) print_subs(&view, sub, out);
+		if (sub) print_subs(view, sub, out);
 	} else if (strcmp(outfmt, "paf") == 0) {
-		size_t m = mahip_hits_live(c);
-		ma_hit_t *hit = (ma_hit_t*)malloc((m ? m : 1) * sizeof(ma_hit_t));
-		GPU(mahip_hits_download(c, hit, &m));
-		if (sub) print_hits(m, hit, &view, sub, out);
-		free(hit);
-	} else if (st[3]) {
-		asg_t *sg = asg_init();
+		if (sub) print_hits(j->n_hit, j->hit, view, sub, out);
+	} else if (j->sg) {
+		asg_t *sg = j->sg;
 		ma_ug_t *ug = 0;
-		GPU(mahip_asg_download(c, sg)); /* the reduced graph is small: the sequential cleaners run on the host */
-		if (sg->n_seq != view.n_seq) { fprintf(stderr, "[E::%s] squeeze mismatch: host %u vs device %u reads\n", __func__, view.n_seq, sg->n_seq); exit(1); }
-		sg->is_symm = n_red > 0;
 		TSTAMP(2);
 		if (stage >= 7) {
 			fprintf(lg, "[M::%s] ===> Step 4.2: initial tip cutting and bubble popping <===\n", "main");
@@ -234,22 +265,41 @@ int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 			fprintf(lg, "[M::%s] ===> Step 5: generating unitigs <===\n", "main");
 			ug = ma_ug_gen(sg);
 			if (g_reads_fn) { /* main.c:193; the survivor view needs a name index of its own for sd_get */
-				if (squeezed) ma_sd_reindex(&view);
-				ma_ug_seq(ug, squeezed ? &view : d, sub, g_reads_fn);
-				if (squeezed) ma_sd_drop_index(&view);
+				if (squeezed) ma_sd_reindex(view);
+				ma_ug_seq(ug, squeezed ? view : d, sub, g_reads_fn);
+				if (squeezed) ma_sd_drop_index(view);
 			}
 			TSTAMP(4);
-			ma_ug_print(ug, &view, sub, out);
-		} else ma_sg_print(sg, &view, sub, out);
+			ma_ug_print(ug, view, sub, out);
+		} else { TSTAMP(4); ma_sg_print(sg, view, sub, out); }
 		TSTAMP(5);
 		if (timing) fprintf(stderr, "[T::tail] names+sub %.3f  graph download %.3f  cleaners %.3f  unitigs %.3f  print %.3f ms (reads %u arcs %u)\n",
-				(tt[1]-tt[0])*1e3, (tt[2]-tt[1])*1e3, (tt[3]-tt[2])*1e3, (tt[4]-tt[3])*1e3, (tt[5]-tt[4])*1e3, sg->n_seq, sg->n_arc);
-		asg_destroy(sg);
+				(j->t_fetch[1]-j->t_fetch[0])*1e3, (j->t_fetch[2]-j->t_fetch[1])*1e3, (tt[3]-tt[2])*1e3, (tt[4]-tt[3])*1e3, (tt[5]-tt[4])*1e3, sg->n_seq, sg->n_arc);
 		ma_ug_destroy(ug);
 	}
-	free(sub);
-	if (squeezed) free(view.seq);
+#undef CT
+#undef TSTAMP
+	asg_destroy(j->sg);
+	free(j->hit);
+	free(j->sub);
+	if (squeezed) free(j->view.seq);
+	free(j);
 	return 0;
+}
+
+int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, const uint32_t st[4], FILE *out)
+{
+	return ma_pipeline_tail_finish(ma_pipeline_tail_fetch(c, opt, d, outfmt, stage, st), out);
+}
+
+int ma_pipeline_tail_finish_mem(ma_tail_job_t *j, char **buf, size_t *len)
+{
+	FILE *fp = open_memstream(buf, len);
+	int rc;
+	if (fp == 0) return -1;
+	rc = ma_pipeline_tail_finish(j, fp);
+	fclose(fp);
+	return rc;
 }
 
 int ma_pipeline_device(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, FILE *out)
