@@ -294,12 +294,11 @@ __global__ __launch_bounds__(256) void k_asg_trans_big(const uint32_t *__restric
                                                         const uint32_t *__restrict__ ovf, uint32_t n_ovf, uint8_t *__restrict__ marks, unsigned long long *__restrict__ ctr)
 {
 	uint8_t *mark = marks + (size_t)blockIdx.x * n_vtx;
-	__shared__ uint32_t s_red, s_go;
+	__shared__ uint32_t s_go;
 	for (uint32_t k = blockIdx.x; k < n_ovf; k += gridDim.x) {
 		uint32_t v = ovf[k];
 		unsigned long long x = idx[v];
 		uint32_t st = (uint32_t)(x >> 32), nv = (uint32_t)x;
-		if (threadIdx.x == 0) s_red = 0;
 		for (uint32_t i = threadIdx.x; i < nv; i += 256) mark[av[st + i]] = 1;
 		__syncthreads();
 		uint32_t L = alen[st + nv - 1] + fuzz;

@@ -207,7 +207,7 @@ void asg_arc_sort(asg_t *g) { ma_refsort_arcs(g->arc, g->arc + g->n_arc); } /* a
 
 uint64_t *asg_arc_index_core(size_t max_seq, size_t n, const asg_arc_t *a) /* asg.c:27-36 */
 {
-	uint64_t *idx = (uint64_t*)calloc(max_seq * 2 ? max_seq * 2 : 1, 8);
+	uint64_t *idx = (uint64_t*)calloc(max_seq ? max_seq * 2 : 1, 8);
 	size_t i, first = 0;
 	for (i = 1; i <= n; ++i)
 		if (i == n || a[i].ul >> 32 != a[i-1].ul >> 32) {
