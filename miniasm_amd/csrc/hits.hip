@@ -39,6 +39,28 @@ __global__ __launch_bounds__(256) void k_hit_keys(const ma_hit_t *__restrict__ h
 	blk_add_u64(&ctr[CT_LIVE], cnt);
 }
 
+// The same for the packed layout of an unsharded context, one block per radix tile: the block also counts the first sort
+// digit of its keys, which is exactly the per-tile histogram the first radix pass needs (saves one sweep over the keys).
+__global__ __launch_bounds__(256) void k_hit_keys_tiled(const ma_hit_t *__restrict__ h, size_t n, uint64_t *__restrict__ key, int bs, int bi,
+                                                         uint32_t *__restrict__ hist, unsigned nb, unsigned tile, int shift, unsigned mask)
+{
+	__shared__ uint32_t s_cnt[512];
+	for (unsigned d = threadIdx.x; d <= mask; d += 256) s_cnt[d] = 0;
+	__syncthreads();
+	const size_t base = (size_t)blockIdx.x * tile;
+	for (unsigned it = 0; it < tile / 256; ++it) {
+		const size_t i = base + (size_t)it * 256 + threadIdx.x;
+		if (i < n) {
+			const uint64_t k = h[i].qns;
+			const uint64_t kk = ((uint64_t)(uint32_t)(k >> 32) << bs | (uint32_t)k) << bi | i;
+			key[i] = kk;
+			atomicAdd(&s_cnt[(unsigned)(kk >> shift) & mask], 1u);
+		}
+	}
+	__syncthreads();
+	for (unsigned d = threadIdx.x; d <= mask; d += 256) hist[(size_t)d * nb + blockIdx.x] = s_cnt[d];
+}
+
 // largest query id / query start (only when the caller gave no hints: the per-symbol ma_hit_sort)
 __global__ __launch_bounds__(256) void k_hit_bounds(const ma_hit_t *__restrict__ h, size_t n, unsigned long long *__restrict__ ctr)
 {
@@ -730,7 +752,19 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	int gen = 0;
 	if (sharded) { CHK(dev_reserve(c, c->keep, (n + 16) * 4)); CHK(dev_reserve(c, c->pos, (n + 16) * 4)); }
 	CHK(ctr_zero(c));
-	{
+	bool first_hist = false;
+	if (pk && !sharded) { // keys + the first pass's per-tile histogram in one sweep
+		int sh0, bt0; unsigned tile;
+		radix_first_digit(bi, bi + bs + bq, &sh0, &bt0, &tile);
+		if (bt0 > 0 && bt0 <= 9) {
+			const unsigned nb = (unsigned)((n + tile - 1) / tile);
+			CHK(radix_reserve_hist(c, n));
+			ProfScope ps(c, "k_hit_keys", 16.0 * (double)n);
+			hipLaunchKernelGGL(k_hit_keys_tiled, dim3(nb), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), bs, bi, P<uint32_t>(c->hist), nb, tile, sh0, (1u << bt0) - 1);
+			first_hist = true;
+		}
+	}
+	if (!first_hist) {
 		ProfScope ps(c, "k_hit_keys", (pk ? 16.0 : 20.0) * (double)n); // reads qns (8 B), writes the key (+ index)
 		hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
 		                   sharded ? P<uint32_t>(c->keep) : (uint32_t*)nullptr, ctr, c->q_beg, c->q_end, bs, bi, pk);
@@ -752,7 +786,7 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 		c->soa_ready = true;
 		return 0;
 	}
-	if (pk) CHK(radix_sort_keys(c, n, bi, bi + bs + bq, &gen));
+	if (pk) CHK(radix_sort_keys(c, n, bi, bi + bs + bq, &gen, first_hist));
 	else CHK(radix_sort_pairs(c, n, 0, bs + bq, 0, 0, &gen));
 	{
 		ProfScope ps(c, "k_hit_gather", (pk ? 72.0 : 76.0) * (double)n); // key 8 (+ index 4) + record 32 + columns 32

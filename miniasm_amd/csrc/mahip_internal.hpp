@@ -106,7 +106,9 @@ int scan_exclusive_u32(mahip_ctx *c, const uint32_t *in, uint32_t *out, size_t n
 // stable LSD radix sort of (u64 key, u32 val) pairs on key bits [lo0,hi0) and [lo1,hi1); result in key[*gen], val[*gen]
 int radix_sort_pairs(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1, int *gen);
 // same for bare u64 keys (a payload such as the record index may ride in the bits below lo): key bits [lo,hi)
-int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen);
+int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen, bool first_hist_ready = false);
+void radix_first_digit(int lo, int hi, int *shift, int *bits, unsigned *tile);
+int radix_reserve_hist(mahip_ctx *c, size_t n);
 // exact-tie mode: the permutation the reference's sort applies to d_keys[0..n) (input order), written to d_perm
 int reference_order(mahip_ctx *c, const uint64_t *d_keys, size_t n, uint32_t *d_perm);
 // bulk pageable<->device copy through per-thread pinned slots (xfer.hip); returns after the copy is complete

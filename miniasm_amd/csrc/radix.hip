@@ -137,7 +137,16 @@ static int plan_digits(int lo, int hi, int *shift, int *bits)
 }
 
 // sort key[*gen] (and val[*gen] if has_val) on key bits [lo0,hi0) then [lo1,hi1); result in generation *gen
-static int radix_sort_impl(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1, int *gen, bool has_val)
+// the first digit of a key sort on bits [lo,hi) and the histogram layout (digit-major, one column per RS_TILE keys), for a
+// producer of the keys that counts the first digit on the fly (k_hit_keys_tiled) and so saves the first histogram pass
+void radix_first_digit(int lo, int hi, int *shift, int *bits, unsigned *tile)
+{
+	int sh[16], bt[16];
+	*shift = lo; *bits = 0; *tile = RS_TILE;
+	if (plan_digits(lo, hi, sh, bt) > 0) *shift = sh[0], *bits = bt[0];
+}
+
+static int radix_sort_impl(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1, int *gen, bool has_val, bool first_hist_ready = false)
 {
 	int g = *gen, shift[16], bits[16], np;
 	if (n == 0) return 0;
@@ -151,7 +160,7 @@ static int radix_sort_impl(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, in
 		uint64_t *kin = P<uint64_t>(c->key[g]), *kout = P<uint64_t>(c->key[g ^ 1]);
 		uint32_t *vin = P<uint32_t>(c->val[g]), *vout = P<uint32_t>(c->val[g ^ 1]);
 		uint32_t *hist = P<uint32_t>(c->hist);
-		{
+		if (!(p == 0 && first_hist_ready)) {
 			ProfScope ps(c, "k_radix_hist", 8.0 * (double)n);
 			hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(RS_THREADS), 0, c->st, kin, hist, n, nb, shift[p], mask);
 		}
@@ -173,9 +182,15 @@ int radix_sort_pairs(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1,
 	return radix_sort_impl(c, n, lo0, hi0, lo1, hi1, gen, true);
 }
 
-int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen)
+int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen, bool first_hist_ready)
 {
-	return radix_sort_impl(c, n, lo, hi, 0, 0, gen, false);
+	return radix_sort_impl(c, n, lo, hi, 0, 0, gen, false, first_hist_ready);
+}
+
+int radix_reserve_hist(mahip_ctx *c, size_t n)
+{
+	unsigned nb = (unsigned)((n + RS_TILE - 1) / RS_TILE);
+	return dev_reserve(c, c->hist, ((size_t)RS_BINS * nb + 8) * 4);
 }
 
 // ---- exact-tie mode (include/mahip.h: mahip_set_exact_ties) ----
