@@ -61,7 +61,11 @@ int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 	const int fused = !no_first && !no_second && stage >= 5 && graph_out && !getenv("MA_NO_FUSE");
 	size_t n_cont_hits = 0;
 
+	const int ht = getenv("MA_PIPE_TIMING") && atoi(getenv("MA_PIPE_TIMING")) >= 2; /* per-pass wall time (adds a device sync per pass) */
+	double ht0 = sys_realtime();
+#define HT(label) do { if (ht) { mahip_sync(c); fprintf(stderr, "[T::head] %-28s %8.3f ms\n", label, (sys_realtime() - ht0) * 1e3); ht0 = sys_realtime(); } } while (0)
 	GPU(mahip_hits_sort(c)); /* hit.c:104 */
+	HT("sort");
 	if (fused) {
 		/* Same passes, same log lines, fewer sweeps over the hits: the first ma_hit_cut + ma_hit_flt ride inside the second
 		 * coverage pass, the second ma_hit_cut rides with the flag pass of ma_hit_contained, and the squeeze of the hit
@@ -69,9 +73,11 @@ int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 		size_t n_cut = 0, n_flt = 0, n_rem2 = 0;
 		fprintf(lg, "[M::%s] ===> Step 2: 1-pass (crude) read selection <===\n", "main");
 		GPU(mahip_hits_sub(c, opt->min_dp, opt->min_iden, 0, 0, &n_rem));
+		HT("sub #1");
 		if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)n_rem);
 		GPU(mahip_hits_cutflt_sub(c, 0, opt->min_span, (int)(opt->max_hang * 1.5), (int)(opt->min_ovlp * .5), opt->min_dp, opt->min_iden, opt->min_span / 2,
 		                          1, &n_cut, &n_flt, &cov, &n_rem2));
+		HT("cut+flt+sub #2");
 		if (ma_verbose >= 3) {
 			fprintf(lg, "[M::%s::%s] %ld hits remain after cut\n", "ma_hit_cut", sys_timestamp(), (long)n_cut);
 			fprintf(lg, "[M::%s::%s] %ld hits remain after filtering; crude coverage after filtering: %.2f\n", "ma_hit_flt", sys_timestamp(), (long)n_flt, cov);
@@ -80,6 +86,7 @@ int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 		if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)n_rem2);
 		GPU(mahip_sub_merge(c)); /* only reads the two interval arrays: may run before the second cut */
 		GPU(mahip_hits_cut_contained(c, 1, opt->min_span, opt, &n_hits, &n_seq_new));
+		HT("merge + cut + contained");
 		if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld hits remain after cut\n", "ma_hit_cut", sys_timestamp(), (long)n_hits);
 		have_sub = squeezed = 1;
 	} else {
@@ -129,6 +136,7 @@ int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 			for (r = 0; r < R; ++r) sdel[r] = d->seq[r].del;
 		}
 		GPU(mahip_sg_gen(c, opt, have_sub, len, sdel, &n_arc));
+		HT("sg_gen");
 		free(len); free(sdel);
 		if (fused) { /* the hit count after the (postponed) squeeze is known now; keep the reference's line order */
 			n_cont_hits = mahip_hits_live(c);
@@ -139,10 +147,12 @@ int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 		if (stage >= 6) {
 			fprintf(lg, "[M::%s] ===> Step 4.1: transitive reduction <===\n", "main");
 			GPU(mahip_asg_del_trans(c, opt->gap_fuzz, &n_red));
+			HT("del_trans");
 			fprintf(lg, "[M::%s] transitively reduced %d arcs\n", "asg_arc_del_trans", n_red);
 			if (n_red) {
 				uint32_t n_multi = 0, n_asymm = 0;
 				GPU(mahip_asg_symm(c, &n_multi, &n_asymm));
+				HT("symm");
 				fprintf(lg, "[M::%s] removed %d multi-arcs\n", "asg_arc_del_multi", n_multi);
 				fprintf(lg, "[M::%s] removed %d asymmetric arcs\n", "asg_arc_del_asymm", n_asymm);
 			}
