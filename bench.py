@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--workdir", default=os.environ.get("MA_BENCH_DIR", "/tmp/ma_bench"))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-text", action="store_true", help="skip the text-resident leg (device-side parse)")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-tie leg")
     ap.add_argument("--no-overlap", action="store_true", help="run each pass's host tail before the next pass's device part starts")
     ap.add_argument("--cpu-div", type=int, default=5, help="CPU baseline sample = workload / this")
     ap.add_argument("--cpu-runs", type=int, default=2)
@@ -372,6 +373,34 @@ def main():
         except Exception as e:
             log("from_text leg failed:", e)
 
+    # ---- the same job with the reference's order of equal sort keys (guaranteed byte-identical output on ANY input: the tie
+    # order is a sequential function of the whole input, computed on the host from the keys)
+    exact = None
+    if rank == 0 and world == 1 and not args.no_exact:
+        try:
+            L.mahip_set_exact_ties(ctx.h, 1)
+
+            def exact_step():
+                ma._chk(L.mahip_hits_adopt(ctx.h, hits_dev.data_ptr(), n_my, n_seq), "adopt")
+                L.mahip_set_hints(ctx.h, max_qs)
+                assert L.ma_pipeline_device_mem(ctx.h, C.byref(opt), ing.d, b"ug", 100, 0, C.byref(buf), C.byref(ln)) == 0
+                n = ln.value
+                L.free_buf(buf)
+                return n
+            n_ex = exact_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                n_ex = exact_step()
+            torch.cuda.synchronize()
+            dte = (time.perf_counter() - t0) / 2
+            exact = {"value": total_lines / dte, "unit": "overlaps/s", "ms_per_step": dte * 1e3, "gfa_bytes": n_ex,
+                     "note": "MA_EXACT_TIES=1: host emulation of the reference's unstable radix sort for the hit and arc orders (8 B/hit down, 4 B/hit up)"}
+        except Exception as e:
+            log("exact-tie leg failed:", e)
+        finally:
+            L.mahip_set_exact_ties(ctx.h, 0)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
@@ -390,7 +419,7 @@ def main():
                 "per_gpu_overlaps": n_lines // world,
                 "pipelining": "host tail of pass k (cleaners, unitigs, GFA text) overlaps the device part of pass k+1; all K outputs complete inside the timed region" if overlap else "none (--no-overlap)",
                 "parallelism": "read-range shards x%d, RCCL all-gather of sub/flags/arcs" % world if world > 1 else "single GPU"},
-            "roofline": roof, "cpu_baseline": cpu, "from_text": from_text, "kernels": kernels[:12],
+            "roofline": roof, "cpu_baseline": cpu, "from_text": from_text, "exact_ties": exact, "kernels": kernels[:12],
             "setup": {"ingest_lines_per_s": n_lines / t_ingest, "h2d_GBs": n_my * 32 / max(t_h2d, 1e-9) / 1e9, "hbm_bytes_held": ctx.mem_bytes()},
         }
         print(json.dumps(out), flush=True)
