@@ -259,9 +259,14 @@ def main():
     def tail_worker():
         while True:
             job = tailq.get()
-            if job is not None:
-                finish(job)
-            tailq.task_done()
+            try:
+                if job is not None:
+                    finish(job)
+            except Exception as e:  # never leave the fence waiting on a dead worker
+                tail_out["rc"] = tail_out["rc"] or -1
+                log("host tail failed:", e)
+            finally:
+                tailq.task_done()
             if job is None:
                 return
 
