@@ -1063,7 +1063,7 @@ extern "C" int mahip_copy_out(mahip_ctx_t *c, int which, void *d_dst, size_t fir
 	DevBuf *b = xbuf(c, which, &es);
 	if (!b || (first + count) * es > b->cap) { mahip_set_error("mahip_copy_out: bad buffer/range"); return -1; }
 	if (count) HIPCHK(hipMemcpyAsync(d_dst, (char*)b->p + first * es, count * es, hipMemcpyDeviceToDevice, c->st));
-	HIPCHK(hipStreamSynchronize(c->st));
+	if (c->own_stream) HIPCHK(hipStreamSynchronize(c->st)); // a caller-owned stream orders the exchange itself (sharded mode: the collectives are queued on it)
 	return 0;
 }
 
@@ -1074,7 +1074,7 @@ extern "C" int mahip_copy_in(mahip_ctx_t *c, int which, const void *d_src, size_
 	DevBuf *b = xbuf(c, which, &es);
 	if (!b || (first + count) * es > b->cap) { mahip_set_error("mahip_copy_in: bad buffer/range"); return -1; }
 	if (count) HIPCHK(hipMemcpyAsync((char*)b->p + first * es, d_src, count * es, hipMemcpyDeviceToDevice, c->st));
-	HIPCHK(hipStreamSynchronize(c->st));
+	if (c->own_stream) HIPCHK(hipStreamSynchronize(c->st)); // a caller-owned stream orders the exchange itself (sharded mode: the collectives are queued on it)
 	return 0;
 }
 

@@ -124,7 +124,20 @@ class GpuBackend:
         self.ma._chk(rc, what)
 
     def new_bytes(self, n):
-        return torch.zeros(max(int(n), 1), dtype=torch.uint8, device=self.device)
+        """exchange buffer of n bytes; buffers are kept and reused (every use is ordered on the backend's stream)"""
+        n = max(int(n), 1)
+        pool = self.__dict__.setdefault("_pool", {})
+        k = pool.get("next", 0)
+        pool["next"] = k + 1
+        t = pool.get(k)
+        if t is None or t.numel() < n:
+            t = torch.empty(n, dtype=torch.uint8, device=self.device)
+            pool[k] = t
+        return t[:n]
+
+    def begin_pass(self):
+        """a new pass may reuse the exchange buffers of the previous one, in the same order"""
+        self.__dict__.setdefault("_pool", {})["next"] = 0
 
     def set_shard(self, q0, q1):
         self._chk(self.L.mahip_set_shard(self.h, q0, q1), "set_shard")
@@ -233,6 +246,8 @@ def _run_sharded(be, comm, opt, n_seq):
     Cn, q0, q1 = shard_range(n_seq, N, g)
     dev = be.device
     stats = {}
+    if hasattr(be, "begin_pass"):
+        be.begin_pass()
     be.set_shard(q0, q1)
     be.sort()
 
@@ -244,13 +259,15 @@ def _run_sharded(be, comm, opt, n_seq):
         full = comm.all_gather_bytes(loc)
         be.copy_in(slot, full, 0, n_seq)
 
-    def exchange_flags(which):  # OR of 0/1 byte flags = max-all-reduce
+    def exchange_flags(*which):  # OR of 0/1 byte flags = max-all-reduce; several flag arrays share one collective
         if N == 1:
             return
-        t = be.new_bytes(n_seq)
-        be.copy_out(which, t, 0, n_seq)
+        t = be.new_bytes(n_seq * len(which))
+        for k, w in enumerate(which):
+            be.copy_out(w, t[k * n_seq:(k + 1) * n_seq], 0, n_seq)
         comm.all_reduce_max_bytes(t)
-        be.copy_in(which, t, 0, n_seq)
+        for k, w in enumerate(which):
+            be.copy_in(w, t[k * n_seq:(k + 1) * n_seq], 0, n_seq)
 
     # counters are kept local and summed once at the end: every blocking exchange of a scalar costs a host sync
     loc_rem1 = be.sub(opt, 0, 0)
@@ -259,8 +276,7 @@ def _run_sharded(be, comm, opt, n_seq):
     exchange_sub(BUF_SUB1)
     be.merge()                             # on the complete arrays, identical on every rank
     be.cut_contained_flags(opt)            # second cut + hit.c:225-245 flags for the local hits
-    exchange_flags(BUF_RCONT)
-    exchange_flags(BUF_RUSED)
+    exchange_flags(BUF_RCONT, BUF_RUSED)
     stats["n_seq_new"] = be.cut_contained_finish()
     be.sg_flags(opt)
     exchange_flags(BUF_SDEL)
