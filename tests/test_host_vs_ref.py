@@ -408,3 +408,44 @@ def test_host_reader_fuzz_matches_reference(tmpdir_s):
         assert list(ing.lens()) == [d.contents.seq[i].len for i in range(d.contents.n_seq)], k
         assert R.canon(ing.hits).tobytes() == R.canon(ref_hits).tobytes(), k
         LR.free_buf(q); LR.sd_destroy(d); ing.close()
+
+
+def test_dictionary_bulk_fill_arena_semantics():
+    """ma_sd_fill (what the device-side ingest uses): names live in one block owned by the dictionary; the index is built on
+    first use; sd_put adds ordinary names next to the arena ones; sd_squeeze and sd_destroy free each kind correctly"""
+    L = ma.lib()
+    L.ma_sd_fill.argtypes = [C.POINTER(ma.Sdict), C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+    L.ma_sd_fill.restype = None
+    L.sd_get.restype = C.c_int32
+    L.sd_get.argtypes = [C.POINTER(ma.Sdict), C.c_char_p]
+    L.sd_put.restype = C.c_int32
+    L.sd_put.argtypes = [C.POINTER(ma.Sdict), C.c_char_p, C.c_uint32]
+    L.sd_squeeze.restype = C.c_void_p
+    L.sd_squeeze.argtypes = [C.POINTER(ma.Sdict)]
+    names = [("read%d" % i).encode() for i in range(5000)]
+    blob = b"\0".join(names) + b"\0"
+    arena = libc.malloc(len(blob))
+    C.memmove(arena, blob, len(blob))
+    lens = np.arange(5000, dtype=np.uint32) + 100
+    for refill in (False, True):
+        d = L.sd_init()
+        assert L.sd_put(d, b"old_name", 7) == 0  # a dictionary that already holds something is replaced by the fill
+        if refill:  # fill twice: the first arena must be released by the second fill
+            a0 = libc.malloc(len(blob)); C.memmove(a0, blob, len(blob))
+            L.ma_sd_fill(d, a0, len(blob), 5000, lens.ctypes.data)
+        a1 = libc.malloc(len(blob)); C.memmove(a1, blob, len(blob))
+        L.ma_sd_fill(d, a1, len(blob), 5000, lens.ctypes.data)
+        assert d.contents.n_seq == 5000 and d.contents.seq[4999].name == b"read4999" and d.contents.seq[17].len == 117
+        assert L.sd_get(d, b"read1234") == 1234 and L.sd_get(d, b"old_name") == -1 and L.sd_get(d, b"nope") == -1
+        assert L.sd_put(d, b"read42", 1) == 42            # known name: first length wins
+        assert d.contents.seq[42].len == 142
+        assert L.sd_put(d, b"late_comer", 9) == 5000       # strdup'ed next to the arena names
+        for i in range(0, 5001, 2):
+            d.contents.seq[i].auxdel |= 0x80000000         # drop every other read (and the late comer)
+        m = L.sd_squeeze(d)
+        mp = np.frombuffer(C.string_at(m, 5001 * 4), dtype=np.int32)
+        L.free_buf(m)
+        assert d.contents.n_seq == 2500 and mp[1] == 0 and mp[0] == -1 and mp[4999] == 2499 and mp[5000] == -1
+        assert L.sd_get(d, b"read4999") == 2499 and L.sd_get(d, b"read4998") == -1 and L.sd_get(d, b"late_comer") == -1
+        L.sd_destroy(d)
+    libc.free(C.c_void_p(arena))
