@@ -276,9 +276,6 @@ def main():
         worker.start()
 
     def step():
-        if os.environ.get("MA_DEBUG_COMM") == "1":
-            log2 = lambda *a: print("[bench %d]" % rank, *a, file=sys.stderr, flush=True)
-            log2("step: adopt", n_my, n_seq)
         ma._chk(L.mahip_hits_adopt(ctx.h, hits_dev.data_ptr(), n_my, n_seq), "adopt")
         L.mahip_set_hints(ctx.h, max_qs)
         st = (C.c_uint32 * 4)(0, 0, 0, 0)
