@@ -3,21 +3,23 @@
 
 Metric (BASELINE.json): PAF overlaps (input lines) processed per second through
     hit sort -> coverage/cut/filter x2 -> containment -> string graph -> transitive reduction + symm
-    -> (host) tip/bubble/short-overlap cleaning -> unitigs -> GFA text,
-with the parsed, unsorted 32-byte hit records already resident in HBM when the timed region starts (the text
-ingest is host work outside the boundary; its rate and the PCIe-inclusive rate are reported in DESIGN.md).
+    -> tip/bubble/short-overlap cleaning -> unitigs -> GFA text,
+with the parsed, unsorted 32-byte hit records already resident in HBM when the timed region starts.
 
-Workload at N=1: BASELINE.json configs[1] -- synthetic 10M-overlap PAF, 200k reads, lognormal lengths with mean
-8 kb, ~50 lines per read (miniasm_amd/bin/pafgen -r 200000 -n 10000000 -s 1).
-N>1 (launched by torch.distributed.run, one rank per GPU): ONE data set of N x 10M overlaps / N x 200k reads, sharded by
-query-read range; every rank runs the hit passes on its shard, sub / flag arrays and the arc blocks are exchanged over
-RCCL (miniasm_amd/sharded.py), rank 0 finishes the graph and writes the GFA.  Weak scaling: per-GPU work is fixed;
-value = global overlaps / max-over-ranks time.
+Workload: BASELINE.json configs[3] -- synthetic 100M-overlap PAF, 2M reads, lognormal lengths with mean 8 kb
+(miniasm_amd/bin/pafgen -r 2000000 -n 100000000 -s 2): the configuration north_star's 1-GPU target is stated on.  The same
+data set is used at every N (strong scaling): at N>1 (launched by torch.distributed.run, one rank per GPU) the hits are
+sharded by query-read range, sub / flag arrays and the arc blocks are exchanged over RCCL, rank 0 finishes the graph.
+
+In the same run (rank 0, N=1): the unmodified reference miniasm on the SAME file (cpu_baseline, and its GFA is compared with
+ours: gfa_identical), the CLI end to end (process start -> GFA on disk), the text-resident variant (device-side parse inside
+the step), BASELINE configs[1] (10M overlaps) and a tie-rich input as secondary legs.
 
 One JSON line on stdout (rank 0).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import re
@@ -45,76 +47,115 @@ def gen_paf(path, reads, lines, seed, extra=()):
     return path
 
 
-def cpu_baseline(args, workdir):
-    """single-thread reference miniasm (oracle/_ref/miniasm_ref, unmodified) on a bounded sample of the same
-    workload law, timed on this box's host cores; the post-ingest part (sort -> GFA) is what `value` measures."""
-    import miniasm_amd as ma
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "miniasm_ref")
-    reads, lines = args.reads // args.cpu_div, args.lines // args.cpu_div
-    paf = gen_paf(os.path.join(workdir, "cpu_r%d_n%d_s%d.paf" % (reads, lines, args.seed + 1000)), reads, lines, args.seed + 1000, args.gen_extra)
-    n_lines = 0
-    with open(paf, "rb") as f:  # pafgen writes one overlap per line, newline-terminated
+def count_lines(path):
+    n = 0
+    with open(path, "rb") as f:  # pafgen writes one overlap per line, newline-terminated
         while True:
             blk = f.read(64 << 20)
             if not blk:
                 break
-            n_lines += blk.count(b"\n")
-    if os.path.exists(ref_bin):
-        best = None
-        for _ in range(args.cpu_runs):
-            t0 = time.perf_counter()
-            r = subprocess.run([ref_bin, paf], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
-            wall = time.perf_counter() - t0
-            m = re.search(r"\[M::ma_hit_read::([0-9.]+)\*", r.stderr)
-            tot = re.search(r"Real time: ([0-9.]+) sec", r.stderr)
-            if r.returncode != 0 or not m or not tot:
-                return None
-            t_parse, t_all = float(m.group(1)), float(tot.group(1))
-            cur = (t_all - t_parse, t_all, wall)
-            if best is None or cur[0] < best[0]:
-                best = cur
-        return {"value": n_lines / best[0], "unit": "overlaps/s", "cores": 1, "kind": "reference",
-                "sample": "%d-line / %d-read sample of the same generator law; unmodified reference miniasm 0.3-r179 (gcc -O2), 1 thread, best of %d; "
-                          "post-ingest part (its own stamps: total %.3f s - parse %.3f s); end-to-end incl. text parse %.0f overlaps/s" % (
-                              n_lines, reads, args.cpu_runs, best[1], best[1] - best[0], n_lines / best[1])}
-    # fallback: the C restatement (covers sort -> transitive reduction only)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import stages as ST
-    opt = ma.default_opt()
-    ing = ma.Ingest(paf, opt)
-    t0 = time.perf_counter()
-    ST.orc_stages(ing.hits, ing.n_seq, opt)
-    dt = time.perf_counter() - t0
-    ing.close()
-    return {"value": n_lines / dt, "unit": "overlaps/s", "cores": 1, "kind": "port",
-            "sample": "%d-line sample; oracle/ma_oracle.c (sort .. transitive reduction only, no cleaners/GFA), 1 thread" % n_lines}
+            n += blk.count(b"\n")
+    return n
 
 
-def pmc_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC run of this same workload (profiles/, made by
-    `tools/gpu_round.sh pmc`: FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM
-    section prescribes for gfx950 -- the doubling reproduces the known 640 MB read of k_hit_keys exactly).  PMC counters
-    cannot be read from inside this process, so the figure is only attached when the workload is the profiled one."""
-    if (args.model, args.reads, args.lines) != ("lognormal", 200000, 10000000):
+def md5_pair(data):
+    """(md5 of the bytes, md5 of the LC_ALL=C sorted lines)"""
+    raw = hashlib.md5(data).hexdigest()
+    lines = data.split(b"\n")
+    lines.sort()
+    return raw, hashlib.md5(b"\n".join(lines)).hexdigest()
+
+
+def run_reference(paf, out_path, runs=1):
+    """the unmodified reference (oracle/_ref/miniasm_ref, gcc -O2, 1 thread) on `paf`; returns timings + the GFA's digests"""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "miniasm_ref")
+    if not os.path.exists(ref_bin):
         return None
-    path = os.path.join(ROOT, "profiles", "pmc_traffic_cfg2.json")
+    best = None
+    for _ in range(runs):
+        with open(out_path, "wb") as fo:
+            t0 = time.perf_counter()
+            r = subprocess.run(["taskset", "-c", "0", ref_bin, paf], stdout=fo, stderr=subprocess.PIPE, text=True)
+            wall = time.perf_counter() - t0
+        m = re.search(r"\[M::ma_hit_read::([0-9.]+)\*", r.stderr)
+        tot = re.search(r"Real time: ([0-9.]+) sec", r.stderr)
+        if r.returncode != 0 or not m or not tot:
+            log("reference run failed:", r.stderr[-500:])
+            return None
+        cur = {"t_parse": float(m.group(1)), "t_all": float(tot.group(1)), "wall": wall}
+        if best is None or cur["t_all"] - cur["t_parse"] < best["t_all"] - best["t_parse"]:
+            best = cur
+    with open(out_path, "rb") as f:
+        best["md5"], best["md5_sorted"] = md5_pair(f.read())
+    return best
+
+
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC run of this same command (profiles/, made by
+    `tools/gpu_round.sh pmc`: FETCH_SIZE and WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md's HBM section
+    prescribes).  PMC counters cannot be read from inside this process: the figure is attached only when the workload is
+    the profiled one, and is labelled with its source."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic_%s.json" % workload)
     try:
         d = json.load(open(path))
     except Exception:
-        return None
+        return None, None
     names = {k.replace("void ", ""): v for k, v in d.items()}
     per_launch = lambda v: v["fetch_bytes_x2"] + v["write_bytes"]
-    # a timed scope of the coverage passes = one launch of each size-class kernel: their bytes add up
     scope = {"k_hit_sub<cut+flt>": "k_hit_sub<true,", "k_hit_sub": "k_hit_sub<false,"}.get(kernel)
-    if scope:
+    if scope:  # a timed scope of the coverage passes = one launch of each size-class kernel: their bytes add up
         parts = [v for k, v in names.items() if k.startswith(scope)]
-        return round(sum(per_launch(v) for v in parts)) if parts else None
+        return (round(sum(per_launch(v) for v in parts)) if parts else None), os.path.relpath(path, ROOT)
     base = kernel.split("<")[0]
     hits = [v for k, v in names.items() if k.split("<")[0] == base]
     if not hits:
-        return None
+        return None, None
     tot = sum(per_launch(v) * v["launches"] for v in hits) / max(sum(v["launches"] for v in hits), 1)
-    return round(tot)
+    return round(tot), os.path.relpath(path, ROOT)
+
+
+class Workload:
+    """one PAF file brought to the state the timed region starts from: text parsed on the device, the unsorted records of this
+    rank's read range in a torch buffer, the dictionary on the host"""
+
+    def __init__(self, ma, L, ctx, paf, opt, world, rank, keep_text=False):
+        import torch
+        from miniasm_amd.sharded import shard_range
+        self.paf, self.n_lines = paf, count_lines(paf)
+        L.ma_paf_load_file.argtypes = [C.c_void_p, C.c_char_p]
+        L.ma_hit_ingest_loaded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(ma.Sdict), C.POINTER(C.c_size_t), C.c_int, C.c_int]
+        L.mahip_hits_raw_extract.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_size_t)]
+        t0 = time.perf_counter()
+        if L.ma_paf_load_file(ctx.h, paf.encode()) != 0:
+            raise RuntimeError("cannot load %s into HBM" % paf)
+        L.mahip_sync(ctx.h)
+        self.t_load = time.perf_counter() - t0
+        self.d = L.sd_init()
+        nh = C.c_size_t(0)
+        t0 = time.perf_counter()
+        if L.ma_hit_ingest_loaded(ctx.h, opt.min_span, opt.min_match, self.d, C.byref(nh), 1, 0 if keep_text else 1) != 0:
+            raise RuntimeError("device-side parse failed: " + L.mahip_strerror().decode())
+        self.t_parse = time.perf_counter() - t0
+        self.n_all, self.n_seq = nh.value, self.d.contents.n_seq
+        L.mahip_paf_max_qs.restype = C.c_uint32
+        L.mahip_paf_max_qs.argtypes = [C.c_void_p]
+        self.max_qs = L.mahip_paf_max_qs(ctx.h)
+        _, q0, q1 = shard_range(self.n_seq, world, rank)
+        if world == 1:
+            q0, q1 = 0, 0xffffffff
+        n_my = C.c_size_t(0)
+        ma._chk(L.mahip_hits_raw_extract(ctx.h, q0, q1, None, C.byref(n_my)), "raw_extract")
+        self.n_my = n_my.value
+        self.hits_dev = torch.empty(max(self.n_my, 1) * 32, dtype=torch.uint8, device="cuda")
+        ma._chk(L.mahip_hits_raw_extract(ctx.h, q0, q1, C.c_void_p(self.hits_dev.data_ptr()), C.byref(n_my)), "raw_extract")
+        L.mahip_sync(ctx.h)
+        self.size = os.path.getsize(paf)
+
+    def close(self, L):
+        if self.d:
+            L.sd_destroy(self.d)
+            self.d = None
+        self.hits_dev = None
 
 
 def main():
@@ -122,20 +163,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=200000)
-    ap.add_argument("--lines", type=int, default=10000000)
-    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=2000000)
+    ap.add_argument("--lines", type=int, default=100000000)
+    ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--model", default="lognormal", choices=["lognormal", "fixed", "uniform"])
     ap.add_argument("--workdir", default=os.environ.get("MA_BENCH_DIR", "/tmp/ma_bench"))
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-text", action="store_true", help="skip the text-resident leg (device-side parse)")
-    ap.add_argument("--no-exact", action="store_true", help="skip the exact-tie leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the reference run (no cpu_baseline, no gfa_identical)")
+    ap.add_argument("--no-text", action="store_true", help="skip the text-resident leg (device-side parse inside the step)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (cfg2, tie-rich input, CLI end to end)")
     ap.add_argument("--no-overlap", action="store_true", help="run each pass's host tail before the next pass's device part starts")
-    ap.add_argument("--cpu-div", type=int, default=5, help="CPU baseline sample = workload / this")
-    ap.add_argument("--cpu-runs", type=int, default=2)
     ap.add_argument("--prof-steps", type=int, default=3)
     args = ap.parse_args()
     args.gen_extra = [] if args.model == "lognormal" else ["-L", args.model]
+    cfg_name = {(2000000, 100000000, 2, "lognormal"): "cfg4", (200000, 10000000, 1, "lognormal"): "cfg2"}.get((args.reads, args.lines, args.seed, args.model), "custom")
 
     import torch
     import torch.distributed as dist
@@ -168,154 +208,137 @@ def main():
     L.ma_set_log_path(b"/dev/null")
     L.sys_init()
 
-    # ---- setup (untimed): synthetic PAF text -> host ingest -> unsorted hit records into HBM
-    # one global data set of world x (reads, lines); every rank parses it (same dictionary everywhere) and keeps the
-    # hits whose query read falls into its range
-    import numpy as np
-    from miniasm_amd.sharded import Comm, GpuBackend, run_sharded, shard_range
-    g_reads, g_lines = args.reads * world, args.lines * world
+    from miniasm_amd.sharded import Comm, GpuBackend, run_sharded
     t0 = time.perf_counter()
-    paf = os.path.join(args.workdir, "w_%s_r%d_n%d_s%d.paf" % (args.model, g_reads, g_lines, args.seed))
+    paf = os.path.join(args.workdir, "w_%s_r%d_n%d_s%d.paf" % (args.model, args.reads, args.lines, args.seed))
     if rank == 0:
-        gen_paf(paf, g_reads, g_lines, args.seed, args.gen_extra)
+        gen_paf(paf, args.reads, args.lines, args.seed, args.gen_extra)
     if world > 1:
         dist.barrier()
     t_gen = time.perf_counter() - t0
     opt = ma.default_opt()
-    t0 = time.perf_counter()
-    ing = ma.Ingest(paf, opt)
-    t_ingest = time.perf_counter() - t0
-    n_lines = 0
-    with open(paf, "rb") as f:  # pafgen writes one overlap per line, newline-terminated
-        while True:
-            blk = f.read(64 << 20)
-            if not blk:
-                break
-            n_lines += blk.count(b"\n")
-    n_seq = ing.n_seq
-    _, q0, q1 = shard_range(n_seq, world, rank)
-    if world > 1:
-        q = (ing.hits["qns"] >> np.uint64(32)).astype(np.int64)
-        my_hits = np.ascontiguousarray(ing.hits[(q >= q0) & (q < q1)])
-        del q
-    else:
-        my_hits = ing.hits.copy()
-    n_my, n_all = len(my_hits), ing.n
-    ing.free_hits()
-    hits_host = torch.from_numpy(my_hits.view("u1").reshape(-1))
-    t0 = time.perf_counter()
-    hits_dev = torch.empty(hits_host.numel(), dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
-    t_h2d = 1e-9
-    if hits_host.numel():  # staged multi-threaded upload of the pageable records (include/mahip.h: mahip_memcpy_h2d)
-        xc = ma.Ctx(local)  # the first queue of a process costs ~0.15 s: not part of the copy
-        t0 = time.perf_counter()
-        rc = ma.lib().mahip_memcpy_h2d(xc.h, C.c_void_p(hits_dev.data_ptr()), C.c_void_p(hits_host.data_ptr()), C.c_size_t(hits_host.numel()))
-        t_h2d = time.perf_counter() - t0
-        if rc != 0:
-            raise RuntimeError("mahip_memcpy_h2d: " + ma.lib().mahip_strerror().decode())
-        xc.close()
-    torch.cuda.synchronize()
-    if rank == 0:
-        log("workload: %d lines, %d stored hits (%d on this rank), %d reads; gen %.1fs ingest %.2fs (%.2f M lines/s) H2D %.3fs (%.1f GB/s)" % (
-            n_lines, n_all, n_my, n_seq, t_gen, t_ingest, n_lines / t_ingest / 1e6, t_h2d, n_my * 32 / max(t_h2d, 1e-9) / 1e9))
 
     if world > 1:  # sharded mode: the context runs on a torch stream so RCCL collectives and kernels share one stream
-        be = GpuBackend.create(local, n_seq)
+        be = GpuBackend.create(local, 0)
         ctx = be.ctx
     else:
         ctx, be = ma.Ctx(local), None
-    buf, ln = C.c_void_p(0), C.c_size_t(0)
-    L.ma_pipeline_tail_mem.restype = C.c_int
-    L.ma_pipeline_tail_mem.argtypes = [C.c_void_p, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.POINTER(C.c_uint32 * 4),
-                                       C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
-    comm = Comm()
+    want_text = rank == 0 and world == 1 and not args.no_text
+    W = Workload(ma, L, ctx, paf, opt, world, rank, keep_text=want_text)
+    if be is not None:
+        be.n_seq = W.n_seq
+    if rank == 0:
+        log("workload %s: %d lines (%.2f GB text), %d stored hits (%d on this rank), %d reads; gen %.1fs, file->HBM %.3fs (%.1f GB/s), parse+dictionary %.3fs" % (
+            cfg_name, W.n_lines, W.size / 1e9, W.n_all, W.n_my, W.n_seq, t_gen, W.t_load, W.size / W.t_load / 1e9, W.t_parse))
 
-    max_qs = ing.max_qs
+    vp = C.c_void_p
+    L.ma_pipeline_head.restype = C.c_int
+    L.ma_pipeline_head.argtypes = [vp, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint32 * 4)]
+    L.ma_pipeline_tail_fetch.restype = vp
+    L.ma_pipeline_tail_fetch.argtypes = [vp, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.POINTER(C.c_uint32 * 4)]
+    L.ma_pipeline_tail_finish_mem.restype = C.c_int
+    L.ma_pipeline_tail_finish_mem.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    comm = Comm()
+    overlap = not args.no_overlap
 
     # Passes are pipelined over the stream of batches: the device part of pass k+1 starts as soon as pass k's reduced graph
-    # has been fetched (ma_pipeline_tail_fetch = the last use of the device for a batch), while pass k's host part (sequential
-    # cleaners, unitigs, GFA text: ma_pipeline_tail_finish) runs on a worker thread.  All K outputs are complete before the
+    # has been fetched (ma_pipeline_tail_fetch = the last use of the device for a batch), while pass k's host part (graph
+    # cleaning, unitigs, GFA text: ma_pipeline_tail_finish) runs on a worker thread.  All K outputs are complete before the
     # closing fence.  --no-overlap runs head and tail back to back.
     import queue
     import threading
-    L.ma_pipeline_head.restype = C.c_int
-    L.ma_pipeline_head.argtypes = [C.c_void_p, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint32 * 4)]
-    L.ma_pipeline_tail_fetch.restype = C.c_void_p
-    L.ma_pipeline_tail_fetch.argtypes = [C.c_void_p, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.POINTER(C.c_uint32 * 4)]
-    L.ma_pipeline_tail_finish_mem.restype = C.c_int
-    L.ma_pipeline_tail_finish_mem.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
-    overlap = not args.no_overlap
-    tail_out = {"n": 0, "rc": 0}
 
-    def finish(job):
-        b, l = C.c_void_p(0), C.c_size_t(0)
-        rc = L.ma_pipeline_tail_finish_mem(job, C.byref(b), C.byref(l))
-        tail_out["n"], tail_out["rc"] = l.value, tail_out["rc"] or rc
-        L.free_buf(b)
+    class Runner:
+        """the timed step over one workload"""
 
-    tailq = queue.Queue(maxsize=1)  # one batch may wait while another is being finished
+        def __init__(self, W):
+            self.W = W
+            self.out = {"n": 0, "rc": 0, "buf": None}
+            self.q = queue.Queue(maxsize=1)  # one batch may wait while another is being finished
+            self.worker = None
+            if overlap and rank == 0:
+                self.worker = threading.Thread(target=self._work, daemon=True)
+                self.worker.start()
 
-    def tail_worker():
-        while True:
-            job = tailq.get()
-            try:
-                if job is not None:
-                    finish(job)
-            except Exception as e:  # never leave the fence waiting on a dead worker
-                tail_out["rc"] = tail_out["rc"] or -1
-                log("host tail failed:", e)
-            finally:
-                tailq.task_done()
-            if job is None:
-                return
+        def _finish(self, job):
+            b, l = vp(0), C.c_size_t(0)
+            rc = L.ma_pipeline_tail_finish_mem(job, C.byref(b), C.byref(l))
+            if self.out["buf"]:
+                L.free_buf(self.out["buf"])
+            self.out["n"], self.out["rc"], self.out["buf"] = l.value, self.out["rc"] or rc, b  # the last output is kept for the parity check
 
-    worker = None
-    if overlap and rank == 0:
-        worker = threading.Thread(target=tail_worker, daemon=True)
-        worker.start()
+        def _work(self):
+            while True:
+                job = self.q.get()
+                try:
+                    if job is not None:
+                        self._finish(job)
+                except Exception as e:  # never leave the fence waiting on a dead worker
+                    self.out["rc"] = self.out["rc"] or -1
+                    log("host tail failed:", e)
+                finally:
+                    self.q.task_done()
+                if job is None:
+                    return
 
-    def step():
-        ma._chk(L.mahip_hits_adopt(ctx.h, hits_dev.data_ptr(), n_my, n_seq), "adopt")
-        L.mahip_set_hints(ctx.h, max_qs)
-        st = (C.c_uint32 * 4)(0, 0, 0, 0)
-        if world == 1:  # single GPU: the C pipeline's device half
-            assert L.ma_pipeline_head(ctx.h, C.byref(opt), ing.d, b"ug", 100, 0, C.byref(st)) == 0
-        else:  # sharded: device passes + RCCL exchanges on every rank, graph cleaning + GFA on rank 0
-            stats = run_sharded(be, comm, opt, n_seq)
-            if rank != 0:
-                return 0
-            st = (C.c_uint32 * 4)(1, 1, stats["n_red"], 1)
-        job = L.ma_pipeline_tail_fetch(ctx.h, C.byref(opt), ing.d, b"ug", 100, C.byref(st))
-        assert job
-        if worker:
-            tailq.put(job)
-        else:
-            finish(job)
-        return tail_out["n"]
+        def step(self):
+            W = self.W
+            ma._chk(L.mahip_hits_adopt(ctx.h, W.hits_dev.data_ptr(), W.n_my, W.n_seq), "adopt")
+            L.mahip_set_hints(ctx.h, W.max_qs)
+            st = (C.c_uint32 * 4)(0, 0, 0, 0)
+            if world == 1:  # single GPU: the C pipeline's device half
+                assert L.ma_pipeline_head(ctx.h, C.byref(opt), W.d, b"ug", 100, 0, C.byref(st)) == 0
+            else:  # sharded: device passes + RCCL exchanges on every rank, graph cleaning + GFA on rank 0
+                stats = run_sharded(be, comm, opt, W.n_seq)
+                if rank != 0:
+                    return
+                st = (C.c_uint32 * 4)(1, 1, stats["n_red"], 1)
+            job = L.ma_pipeline_tail_fetch(ctx.h, C.byref(opt), W.d, b"ug", 100, C.byref(st))
+            assert job
+            if self.worker:
+                self.q.put(job)
+            else:
+                self._finish(job)
 
-    def fence():
-        if worker:
-            tailq.join()  # every host tail handed over so far is complete
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        assert tail_out["rc"] == 0
+        def fence(self):
+            if self.worker:
+                self.q.join()  # every host tail handed over so far is complete
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            assert self.out["rc"] == 0
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    gfa_len = tail_out["n"]
+        def timed(self, warmup, steps):
+            for _ in range(warmup):
+                self.step()
+            self.fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            self.fence()
+            return time.perf_counter() - t0
+
+        def output(self):
+            return C.string_at(self.out["buf"], self.out["n"]) if self.out["buf"] else b""
+
+        def close(self):
+            if self.worker:
+                self.q.put(None)
+                self.worker.join()
+                self.worker = None
+            if self.out["buf"]:
+                L.free_buf(self.out["buf"])
+                self.out["buf"] = None
+
+    run = Runner(W)
+    dt = run.timed(args.warmup, args.steps)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu_debug else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
-    total_lines = float(n_lines)  # the global data set (world x per-GPU lines)
+    total_lines = float(W.n_lines)
+    gfa = run.output() if rank == 0 else b""
+    tie = ctx.tie_stats() if rank == 0 else None
 
     # ---- per-kernel timing with HIP events on the launch stream (separate, instrumented steps)
     roof, kernels = None, []
@@ -323,32 +346,34 @@ def main():
         ctx.prof_enable(True)
         ctx.prof_reset()
     for _ in range(args.prof_steps):  # a step is collective in the sharded mode: EVERY rank runs it, rank 0 is the one instrumented
-        step()
-    fence()
+        run.step()
+    run.fence()
     if rank == 0:
         recs = ctx.prof_get()
         ctx.prof_enable(False)
         tot_ms = sum(r["total_ms"] for r in recs) or 1.0
         for r in sorted(recs, key=lambda r: -r["total_ms"]):
             per = r["total_ms"] / max(r["launches"], 1)
-            kernels.append({"name": r["name"], "launches_per_step": r["launches"] / args.prof_steps, "avg_ms": round(per, 5),
+            kernels.append({"name": r["name"], "launches_per_step": r["launches"] / max(args.prof_steps, 1), "avg_ms": round(per, 5),
                             "share": round(r["total_ms"] / tot_ms, 4),
                             "alg_GBs": round(r["alg_bytes"] / max(r["launches"], 1) / (per * 1e-3) / 1e9, 1) if per > 0 and r["alg_bytes"] > 0 else None})
         dom = next((k for k in kernels if k["alg_GBs"]), None)
         if dom:
+            traffic, src = pmc_traffic(dom["name"], cfg_name)
             roof = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["alg_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(dom["alg_GBs"] / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom["name"], args),
-                    "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"]}
+                    "frac": round(dom["alg_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": src and "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)" % src,
+                    # the same kernel priced by the bytes it really moved: a fused kernel cannot exceed 1 here
+                    "frac_counter": round(traffic / (dom["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
+                    "note": "achieved = SURVEY 8(d) algorithmic bytes of the reference passes this kernel replaces / HIP-event launch time"}
+    run.close()
 
     # ---- the same job started one stage earlier: PAF TEXT resident in HBM -> device-side parse + dictionary -> ... -> GFA
     from_text = None
-    if rank == 0 and world == 1 and not args.no_text:
+    buf, ln = vp(0), C.c_size_t(0)
+    if want_text:
         try:
-            L.ma_paf_load_file.argtypes = [C.c_void_p, C.c_char_p]
-            L.ma_hit_ingest_loaded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(ma.Sdict), C.POINTER(C.c_size_t), C.c_int, C.c_int]
-            t0 = time.perf_counter()
-            assert L.ma_paf_load_file(ctx.h, paf.encode()) == 0
-            t_load = time.perf_counter() - t0
             d2 = L.sd_init()
             nh = C.c_size_t(0)
 
@@ -358,74 +383,106 @@ def main():
                 n = ln.value
                 L.free_buf(buf)
                 return n
-            for _ in range(args.warmup):
-                n_txt = text_step()
+            n_txt = text_step()
             torch.cuda.synchronize()
+            k = max(2, args.steps // 2)
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(k):
                 n_txt = text_step()
             torch.cuda.synchronize()
             dtt = time.perf_counter() - t0
-            assert n_txt == gfa_len and nh.value == n_all, (n_txt, gfa_len, nh.value, n_all)
-            from_text = {"value": total_lines * args.steps / dtt, "unit": "overlaps/s", "ms_per_step": dtt / args.steps * 1e3,
-                         "input": "PAF text resident in HBM (%d bytes); each step parses it on the device, rebuilds the name dictionary on the host, runs the pipeline and writes the GFA" % os.path.getsize(paf),
-                         "file_to_hbm_s": t_load, "file_to_hbm_GBs": os.path.getsize(paf) / t_load / 1e9}
+            assert n_txt == len(gfa) and nh.value == W.n_all, (n_txt, len(gfa), nh.value, W.n_all)
+            from_text = {"value": total_lines * k / dtt, "unit": "overlaps/s", "ms_per_step": dtt / k * 1e3,
+                         "input": "PAF text resident in HBM (%d bytes); each step parses it on the device, rebuilds the name dictionary on the host, runs the pipeline and writes the GFA" % W.size,
+                         "file_to_hbm_s": W.t_load, "file_to_hbm_GBs": W.size / W.t_load / 1e9}
             L.mahip_paf_release(ctx.h)
             L.sd_destroy(d2)
         except Exception as e:
             log("from_text leg failed:", e)
 
-    # ---- the same job with the reference's order of equal sort keys (guaranteed byte-identical output on ANY input: the tie
-    # order is a sequential function of the whole input, computed on the host from the keys)
-    exact = None
-    if rank == 0 and world == 1 and not args.no_exact:
-        try:
-            L.mahip_set_exact_ties(ctx.h, 1)
+    # ---- secondary legs (rank 0, one GPU)
+    legs = {}
+    if rank == 0 and world == 1 and not args.no_legs:
+        def leg(name, reads, lines, seed, extra, steps, with_ref):
+            try:
+                p = gen_paf(os.path.join(args.workdir, "leg_%s_r%d_n%d_s%d.paf" % (name, reads, lines, seed)), reads, lines, seed, extra)
+                w = Workload(ma, L, ctx, p, opt, 1, 0)
+                r = Runner(w)
+                t = r.timed(1, steps)
+                out = r.output()
+                ti = ctx.tie_stats()
+                res = {"value": w.n_lines * steps / t, "unit": "overlaps/s", "ms_per_step": t / steps * 1e3, "overlaps": w.n_lines, "reads": w.n_seq,
+                       "gfa_bytes": len(out), "tie_groups": ti["arc_tie_groups"],
+                       "tie_path": "arc walk%s" % (" + hit walk" if ti["hit_walk"] else "") if ti["arc_walk"] else "stable order (no arc ties)"}
+                if with_ref:
+                    ref = run_reference(p, os.path.join(args.workdir, "leg_%s.ref.gfa" % name))
+                    if ref:
+                        res["gfa_identical"] = md5_pair(out)[0] == ref["md5"]
+                        res["cpu_overlaps_per_s"] = w.n_lines / (ref["t_all"] - ref["t_parse"])
+                r.close()
+                w.close(L)
+                legs[name] = res
+            except Exception as e:
+                log("leg %s failed:" % name, e)
+        if cfg_name != "cfg2":
+            leg("cfg2", 200000, 10000000, 1, [], 10, False)  # BASELINE configs[1]
+        # coordinates on a 16-bp grid, 30 % dropout, 3 % false overlaps: thousands of equal (u,len) arc keys -- the default
+        # mode finds them by census and reproduces the reference's (unstable-sort) order
+        leg("tie_rich", 250000, 5000000, 5, ["-q", "16", "-L", "uniform", "-d", "0.3", "-x", "0.03"], 3, not args.no_cpu)
 
-            def exact_step():
-                ma._chk(L.mahip_hits_adopt(ctx.h, hits_dev.data_ptr(), n_my, n_seq), "adopt")
-                L.mahip_set_hints(ctx.h, max_qs)
-                assert L.ma_pipeline_device_mem(ctx.h, C.byref(opt), ing.d, b"ug", 100, 0, C.byref(buf), C.byref(ln)) == 0
-                n = ln.value
-                L.free_buf(buf)
-                return n
-            n_ex = exact_step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(2):
-                n_ex = exact_step()
-            torch.cuda.synchronize()
-            dte = (time.perf_counter() - t0) / 2
-            exact = {"value": total_lines / dte, "unit": "overlaps/s", "ms_per_step": dte * 1e3, "gfa_bytes": n_ex,
-                     "note": "MA_EXACT_TIES=1: host emulation of the reference's unstable radix sort for the hit and arc orders (8 B/hit down, 4 B/hit up)"}
-        except Exception as e:
-            log("exact-tie leg failed:", e)
-        finally:
-            L.mahip_set_exact_ties(ctx.h, 0)
-
-    cpu = None
+    # ---- the reference on the same file: CPU baseline + the GFA every output above is compared with
+    cpu, parity, e2e = None, None, None
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
-            cpu = cpu_baseline(args, args.workdir)
+            ref = run_reference(paf, os.path.join(args.workdir, "ref_%s.gfa" % cfg_name))
+            if ref:
+                mine = md5_pair(gfa)
+                parity = {"gfa_identical": mine[0] == ref["md5"], "gfa_identical_sorted": mine[1] == ref["md5_sorted"], "gfa_md5": mine[0], "ref_md5": ref["md5"]}
+                cpu = {"value": W.n_lines / (ref["t_all"] - ref["t_parse"]), "unit": "overlaps/s", "cores": 1, "kind": "reference",
+                       "sample": "the SAME file (%d lines, %d reads); unmodified reference miniasm 0.3-r179 (gcc -O2), 1 thread pinned with taskset -c 0, 1 run; "
+                                 "value = post-ingest part (its own stamps: total %.3f s - parse %.3f s), the part `value` measures; end to end incl. text parse: %.0f overlaps/s (%.1f s wall)" % (
+                                     W.n_lines, W.n_seq, ref["t_all"], ref["t_parse"], W.n_lines / ref["t_all"], ref["wall"]),
+                       "end_to_end_s": ref["wall"]}
         except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
             log("cpu baseline failed:", e)
+    if rank == 0 and world == 1 and not args.no_legs:
+        try:  # the command line, process start -> GFA on disk (north_star's ">= 10x reference wall-clock" is about this)
+            outp = os.path.join(args.workdir, "cli_%s.gfa" % cfg_name)
+            best = None
+            for _ in range(2):
+                with open(outp, "wb") as fo:
+                    t0 = time.perf_counter()
+                    r = subprocess.run([ma.CLI_PATH, paf], stdout=fo, stderr=subprocess.PIPE)
+                    wall = time.perf_counter() - t0
+                assert r.returncode == 0, r.stderr[-300:]
+                best = wall if best is None else min(best, wall)
+            cli_md5 = md5_pair(open(outp, "rb").read())[0]
+            e2e = {"value": W.n_lines / best, "unit": "overlaps/s", "wall_s": best, "what": "miniasm_amd/bin/miniasm <file> > out.gfa: process start to GFA on disk, warm page cache, best of 2",
+                   "gfa_identical": (cli_md5 == parity["ref_md5"]) if parity else None,
+                   "vs_reference_wall": (cpu["end_to_end_s"] / best) if cpu else None}
+        except Exception as e:
+            log("e2e leg failed:", e)
 
     if rank == 0:
         out = {
             "metric": "PAF overlaps processed/sec (hit-filter->trans-reduce->GFA)",
             "value": total_lines * args.steps / dt, "unit": "overlaps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "synthetic %s PAF: %d overlaps, %d reads, mean 8 kb, %.1f stored hits/read, seed %d; inputs = unsorted 32-byte hit records resident in HBM%s; output = GFA text (%d bytes)" % (
-                args.model, n_lines, n_seq, n_all / max(n_seq, 1), args.seed, " (sharded by query-read range)" if world > 1 else "", gfa_len),
-                "per_gpu_overlaps": n_lines // world,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "%s: synthetic %s PAF (pafgen seed %d), %d overlaps, %d reads, mean 8 kb, %.1f stored hits/read; inputs = unsorted 32-byte hit records resident in HBM%s; output = GFA text (%d bytes)" % (
+                "BASELINE configs[3]" if cfg_name == "cfg4" else "BASELINE configs[1]" if cfg_name == "cfg2" else cfg_name,
+                args.model, args.seed, W.n_lines, W.n_seq, W.n_all / max(W.n_seq, 1), " (sharded by query-read range)" if world > 1 else "", len(gfa)),
+                "global_overlaps": W.n_lines, "per_gpu_hits": W.n_my,
                 "pipelining": "host tail of pass k (cleaners, unitigs, GFA text) overlaps the device part of pass k+1; all K outputs complete inside the timed region" if overlap else "none (--no-overlap)",
                 "parallelism": "read-range shards x%d, RCCL all-gather of sub/flags/arcs" % world if world > 1 else "single GPU"},
-            "roofline": roof, "cpu_baseline": cpu, "from_text": from_text, "exact_ties": exact, "kernels": kernels[:12],
-            "setup": {"ingest_lines_per_s": n_lines / t_ingest, "h2d_GBs": n_my * 32 / max(t_h2d, 1e-9) / 1e9, "hbm_bytes_held": ctx.mem_bytes()},
+            "gfa_identical": parity["gfa_identical"] if parity else None, "parity": parity,
+            "tie_groups": tie["arc_tie_groups"] if tie else None,
+            "tie_path": None if not tie else ("arc walk%s" % (" + hit walk" if tie["hit_walk"] else "") if tie["arc_walk"] else "unrepaired" if tie["unrepaired"] else "stable order (census: no arc ties => provably the reference's order)"),
+            "roofline": roof, "cpu_baseline": cpu, "e2e": e2e, "from_text": from_text, "legs": legs, "kernels": kernels[:14],
+            "setup": {"gen_s": t_gen, "file_to_hbm_s": W.t_load, "file_to_hbm_GBs": W.size / W.t_load / 1e9, "parse_dictionary_s": W.t_parse, "hbm_bytes_held": ctx.mem_bytes()},
         }
         print(json.dumps(out), flush=True)
-    ing.close()
+    W.close(L)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

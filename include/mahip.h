@@ -51,8 +51,12 @@ int mahip_paf_load_mem(mahip_ctx_t *c, const void *text, size_t nbytes);   /* te
 int mahip_paf_load_fd(mahip_ctx_t *c, int fd, size_t nbytes);              /* bytes [0,nbytes) of an open plain file, read straight into pinned staging */
 int mahip_paf_parse(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, mahip_paf_info_t *info);
 int mahip_paf_names(mahip_ctx_t *c, char *names, uint32_t *lens);          /* names[name_bytes], lens[n_seq] = first-seen read lengths */
-int mahip_paf_release(mahip_ctx_t *c);
-int mahip_hits_raw_download(mahip_ctx_t *c, ma_hit_t *out);                 /* the unsorted records held by the context (n_hits of them) */                                     /* free the text and the per-line columns */
+int mahip_paf_release(mahip_ctx_t *c);                                      /* free the text and the per-line columns */
+uint32_t mahip_paf_max_qs(mahip_ctx_t *c);                                  /* info.max_qs of the last parse (a sort hint for later mahip_hits_adopt calls) */
+int mahip_hits_raw_download(mahip_ctx_t *c, ma_hit_t *out);                 /* the unsorted records held by the context (n_hits of them) */
+/* device-to-device: the unsorted records whose query id lies in [q_beg,q_end), in input order, into d_dst (NULL: only count
+ * them); *n_out = their number.  Lets a caller keep the records of one read-range shard (bench.py, multi-GPU set-up). */
+int mahip_hits_raw_extract(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end, void *d_dst, size_t *n_out);
 
 /* optional: an upper bound of the query starts (e.g. the longest read) lets the sort plan its digits without a
  * device round trip; 0 = unknown */
@@ -62,12 +66,27 @@ int mahip_set_hints(mahip_ctx_t *c, uint32_t max_qs);
  * Synchronous; ordered after the work already queued on the context's stream.  MA_XFER_THREADS sets the workers. */
 int mahip_memcpy_h2d(mahip_ctx_t *c, void *d_dst, const void *h_src, size_t bytes);
 int mahip_memcpy_d2h(mahip_ctx_t *c, void *h_dst, const void *d_src, size_t bytes);
-/* Tie order.  0 (default): stable device sorts, total order (key, input position).  1: records with equal keys are
- * left in the order the reference's unstable in-place radix sort (ksort.h:134-183, used at hit.c:21 and asg.c:24)
- * leaves them; that order is a sequential function of the whole input, so it is computed on the host from the
- * keys (8 B/record down, 4 B/record up) and the device only gathers.  Initial value: MA_EXACT_TIES in the environment.
- * Not available together with mahip_set_shard ranges. */
-int mahip_set_exact_ties(mahip_ctx_t *c, int on);
+/* Tie order.  The reference's two sorts (ksort.h:134-183, used at hit.c:21 and asg.c:24) are an in-place MSD radix sort that
+ * leaves records with equal keys in an order that is a sequential function of the whole input; the device sorts are stable.
+ * The difference is only observable through arcs with equal (u,len) keys, so:
+ *   mode 2 (default, "auto"): after the arc sort a census counts (u,len) tie groups.  None: the stable order is provably the
+ *           reference's result (whatever the order of tied hits was).  Some: the reference's order is reproduced -- a host walk
+ *           over the arc keys (squeezed ids, as the reference sorts them) and, only when two arcs were pushed from hits with
+ *           equal (qid,qs), over the hit keys too; the device re-gathers.  Hit dumps (mahip_hits_download) are put in the
+ *           reference's order when tied hits exist.
+ *   mode 1: the same repair, unconditionally.      mode 0: never (stable total order (key, input position)).
+ * Initial value: MA_EXACT_TIES in the environment (unset = 2).  On a shard (mahip_set_shard) the repair is not available:
+ * mode 1 fails there, mode 2 reports the census (mahip_tie_stats) and leaves the stable order. */
+int mahip_set_exact_ties(mahip_ctx_t *c, int mode);
+typedef struct {
+	uint64_t arc_tie_groups;   /* groups of >= 2 arcs with equal (u,len) after the last ma_sg_gen */
+	uint64_t arc_tie_arcs;     /* arcs in such groups */
+	uint64_t push_conflicts;   /* consecutive pushed arcs whose hits had equal (qid,qs): the hit order matters */
+	uint64_t hit_ties;         /* hits with the same (qid,qs) as their predecessor (only counted when needed, else 0) */
+	int arc_walk, hit_walk;    /* 1 if the reference's arc / hit order was computed on the host for the last graph */
+	int unrepaired;            /* 1 if tie groups exist and the stable order was kept (mode 0, or a shard) */
+} mahip_tie_info_t;
+int mahip_tie_stats(mahip_ctx_t *c, mahip_tie_info_t *out);
 /* hit.c:19-22 ma_hit_sort: LSD radix sort by (query id, query start, input order) -> SoA + group offsets */
 int mahip_hits_sort(mahip_ctx_t *c);
 /* same layout change without sorting (input already grouped by query id: the per-symbol ABI path) */

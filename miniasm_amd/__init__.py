@@ -53,6 +53,11 @@ class Asg(C.Structure):  # asg.h:17-23
         return self.n_seq_symm & 0x7FFFFFFF
 
 
+class TieInfo(C.Structure):  # include/mahip.h: mahip_tie_info_t
+    _fields_ = [("arc_tie_groups", C.c_uint64), ("arc_tie_arcs", C.c_uint64), ("push_conflicts", C.c_uint64), ("hit_ties", C.c_uint64),
+                ("arc_walk", C.c_int), ("hit_walk", C.c_int), ("unrepaired", C.c_int)]
+
+
 class ProfRec(C.Structure):
     _fields_ = [("name", C.c_char_p), ("launches", C.c_uint64), ("total_ms", C.c_double), ("alg_bytes", C.c_double)]
 
@@ -89,6 +94,7 @@ def lib():
         L.mahip_set_shard.argtypes = [vp, u32, u32]
         L.mahip_set_hints.argtypes = [vp, u32]
         L.mahip_set_exact_ties.argtypes = [vp, i32]
+        L.mahip_tie_stats.argtypes = [vp, C.POINTER(TieInfo)]
         L.mahip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
         L.mahip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
         L.mahip_paf_release.argtypes = [vp]
@@ -171,6 +177,14 @@ class Ctx:
             self.close()
         except Exception:
             pass
+
+    def set_exact_ties(self, mode):
+        lib().mahip_set_exact_ties(self.h, mode)
+
+    def tie_stats(self):
+        t = TieInfo()
+        lib().mahip_tie_stats(self.h, C.byref(t))
+        return {k: getattr(t, k) for k, _ in TieInfo._fields_}
 
     # ---- hits
     def hits_upload(self, hits, n_seq):

@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256) void k_sg_arcs(HitColsG h, size_t n, const uin
 // passes B (out.u == nullptr: count per tile) and C (write): tile b = hits [b*SG_TILE, (b+1)*SG_TILE), row j of a tile = 256 consecutive hits
 __global__ __launch_bounds__(256) void k_sg_emit(HitColsG h, size_t n, const uint32_t *__restrict__ slen, const uint8_t *__restrict__ sdel,
                                                   int max_hang, float int_frac, int min_ovlp, const unsigned long long *__restrict__ cmask,
-                                                  uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off, ArcCols out)
-{
+                                                  uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off, ArcCols out, uint32_t *__restrict__ aslot)
+{ // aslot (optional, pass C): the hit slot each pushed arc comes from (tie-order repair)
 	__shared__ uint32_t s_w[4];
 	const size_t base = (size_t)blockIdx.x * SG_TILE;
 	uint32_t run = out.u ? tile_off[blockIdx.x] : 0, total = 0;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_sg_emit(HitColsG h, size_t n, const uin
 		}
 		if (out.u) { // dense slot = arcs of earlier tiles + earlier rows + earlier lanes of this row
 			uint32_t tot, ex = block_excl_scan_256((uint32_t)keep, s_w, &tot);
-			if (keep) { uint32_t p = run + ex; out.u[p] = x.u; out.v[p] = x.v; out.len[p] = x.len; out.ol[p] = x.ol; }
+			if (keep) { uint32_t p = run + ex; out.u[p] = x.u; out.v[p] = x.v; out.len[p] = x.len; out.ol[p] = x.ol; if (aslot) aslot[p] = (uint32_t)i; }
 			run += tot;
 		} else total += (uint32_t)keep;
 	}
@@ -167,6 +167,46 @@ __global__ __launch_bounds__(256) void k_arc_permute(ArcCols in, size_t n, const
 	if (i < n) {
 		uint32_t j = perm[i];
 		out.u[i] = in.u[j]; out.v[i] = in.v[j]; out.len[i] = in.len[j]; out.ol[i] = in.ol[j];
+	}
+}
+
+// ---- tie order of asg_arc_sort (asg.c:22-25) ----
+// census over the stably sorted keys: groups of >= 2 equal (u,len) keys and their members
+__global__ __launch_bounds__(256) void k_arc_tie_census(const uint64_t *__restrict__ skey, size_t n, unsigned long long *__restrict__ ctr)
+{
+	uint32_t groups = 0, members = 0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+		const uint64_t k = skey[i];
+		const int eq_prev = i > 0 && skey[i - 1] == k, eq_next = i + 1 < n && skey[i + 1] == k;
+		groups += eq_next && !eq_prev;
+		members += eq_prev || eq_next;
+	}
+	blk_add_u64(&ctr[ST_ARC_TIE_GROUPS], groups);
+	blk_add_u64(&ctr[ST_ARC_TIE_ARCS], members);
+}
+// consecutive pushed arcs whose hits had the same ORIGINAL (qid,qs) key: only then does the order of tied hits reach the arcs
+__global__ __launch_bounds__(256) void k_arc_push_conflicts(const uint32_t *__restrict__ aslot, size_t n, const ma_hit_t *__restrict__ h, const uint32_t *__restrict__ sidx,
+                                                             unsigned long long *__restrict__ ctr)
+{
+	uint32_t cnt = 0;
+	for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x + 1; p < n; p += (size_t)gridDim.x * 256)
+		cnt += h[sidx[aslot[p]]].qns == h[sidx[aslot[p - 1]]].qns;
+	blk_add_u64(&ctr[ST_PUSH_CONFLICTS], cnt);
+}
+// sort key of a pushed arc in the reference's hit order
+__global__ __launch_bounds__(256) void k_arc_push_keys(const uint32_t *__restrict__ aslot, const uint32_t *__restrict__ hrank, size_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) { key[i] = hrank[aslot[i]]; val[i] = (uint32_t)i; }
+}
+// the keys the reference sorts: ul = u<<32 | len with the SQUEEZED read ids (ma_sg_gen runs after ma_hit_contained renumbered the reads)
+__global__ __launch_bounds__(256) void k_arc_keys_ref(ArcCols a, size_t n, const int32_t *__restrict__ map, uint64_t *__restrict__ key)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) {
+		uint32_t u = a.u[i];
+		if (map) u = (uint32_t)map[u >> 1] << 1 | (u & 1);
+		key[i] = (uint64_t)u << 32 | a.len[i];
 	}
 }
 
@@ -480,6 +520,9 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 	c->n_live = (size_t)c->h_ctr[CT_LIVE];
 	if (c->prof) prof_patch_last(c, "k_sg_arcs", 64.0 * (double)c->n_live); // units = hits left after containment (64 B each)
 	c->n_arc = 0; c->ag = 0;
+	const bool sharded = c->q_beg > 0 || (c->n_seq && c->q_end < c->n_seq);
+	const bool want_slots = c->tie_mode != 0 && c->sorted_here && c->sidx.p != nullptr && !sharded; // the hit order can be repaired
+	{ const uint64_t keep_hit_ties = c->tie.hit_ties; const int keep_walk = c->hrank_ready; memset(&c->tie, 0, sizeof(c->tie)); c->tie.hit_ties = keep_hit_ties; c->tie.hit_walk = keep_walk; }
 	if (n) {
 		const size_t n_tiles = (n + SG_TILE - 1) / SG_TILE;
 		const unsigned long long *lazy = (const unsigned long long*)P<unsigned long long>(c->sgmask); // pass A's candidate bits
@@ -489,29 +532,75 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 		{
 			ProfScope ps(c, "k_sg_emit", 4.0 * (double)n + 64.0 * (double)c->n_live);
 			hipLaunchKernelGGL(k_sg_emit, dim3((unsigned)n_tiles), dim3(256), 0, c->st, gcols_of(c), n, (const uint32_t*)P<uint32_t>(c->slen), (const uint8_t*)P<uint8_t>(c->sdel),
-			                   c->sg_max_hang, c->sg_int_frac, c->sg_min_ovlp, lazy, P<uint32_t>(c->keep), (const uint32_t*)nullptr, none);
+			                   c->sg_max_hang, c->sg_int_frac, c->sg_min_ovlp, lazy, P<uint32_t>(c->keep), (const uint32_t*)nullptr, none, (uint32_t*)nullptr);
 		}
 		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), n_tiles, d_tot));
 		CHK(ctr_fetch(c));
 		c->n_arc = (uint32_t)(c->h_ctr[CT_TOTAL] & 0xffffffffu);
 		CHK(reserve_arcs(c, c->n_arc));
+		if (want_slots) CHK(dev_reserve(c, c->aslot, ((size_t)c->n_arc + 4) * 4));
 		if (c->n_arc) {
 			ProfScope ps(c, "k_sg_emit", 4.0 * (double)n + 64.0 * (double)c->n_live + 16.0 * (double)c->n_arc);
 			hipLaunchKernelGGL(k_sg_emit, dim3((unsigned)n_tiles), dim3(256), 0, c->st, gcols_of(c), n, (const uint32_t*)P<uint32_t>(c->slen), (const uint8_t*)P<uint8_t>(c->sdel),
-			                   c->sg_max_hang, c->sg_int_frac, c->sg_min_ovlp, lazy, (uint32_t*)nullptr, (const uint32_t*)P<uint32_t>(c->pos), arcs_of(c, 0));
+			                   c->sg_max_hang, c->sg_int_frac, c->sg_min_ovlp, lazy, (uint32_t*)nullptr, (const uint32_t*)P<uint32_t>(c->pos), arcs_of(c, 0),
+			                   want_slots ? P<uint32_t>(c->aslot) : (uint32_t*)nullptr);
 		}
 	} else CHK(reserve_arcs(c, 0));
 	if (c->n_arc > 1) {
 		size_t m = c->n_arc;
 		for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }
 		ArcCols in = arcs_of(c, c->ag), out = arcs_of(c, c->ag ^ 1);
-		hipLaunchKernelGGL(k_arc_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
-		int gen = 0;
-		if (c->exact_ties) { CHK(reference_order(c, P<uint64_t>(c->key[0]), m, P<uint32_t>(c->val[1]))); gen = 1; } // asg.c:24 with its tie order
-		else CHK(radix_sort_pairs(c, m, 0, bitlen_u64(c->h_ctr[CT_MAXLEN]), 32, 32 + bitlen_u64(2ull * R), &gen));
-		{
-			ProfScope ps(c, "k_arc_permute", 36.0 * (double)m);
-			hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, (const uint32_t*)P<uint32_t>(c->val[gen]), out);
+		unsigned long long *ctr = P<unsigned long long>(c->ctr);
+		const int32_t *map = c->has_map ? (const int32_t*)P<int32_t>(c->map) : (const int32_t*)nullptr;
+		int gen = 0, need_walk = c->tie_mode == 1;
+		if (c->tie_mode != 1) { // stable sort (asg.c:24 up to the order of equal keys), then the census
+			hipLaunchKernelGGL(k_arc_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
+			CHK(radix_sort_pairs(c, m, 0, bitlen_u64(c->h_ctr[CT_MAXLEN]), 32, 32 + bitlen_u64(2ull * R), &gen));
+			{
+				ProfScope ps(c, "k_arc_permute", 36.0 * (double)m);
+				hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, (const uint32_t*)P<uint32_t>(c->val[gen]), out);
+			}
+			if (c->tie_mode == 2) {
+				HIPCHK(hipMemsetAsync(ctr + CT_STICKY, 0, (64 - CT_STICKY) * 8, c->st));
+				ProfScope ps(c, "k_arc_tie_census", 8.0 * (double)m);
+				hipLaunchKernelGGL(k_arc_tie_census, dim3(grid_for(m, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[gen]), m, ctr);
+				CHK(ctr_fetch(c));
+				c->tie.arc_tie_groups = c->h_ctr[ST_ARC_TIE_GROUPS]; c->tie.arc_tie_arcs = c->h_ctr[ST_ARC_TIE_ARCS];
+				need_walk = c->tie.arc_tie_groups > 0;
+				if (need_walk && sharded) need_walk = 0, c->tie.unrepaired = 1; // the order is a function of the whole graph: reported, not repaired, on a shard
+			}
+		} else if (sharded) { mahip_set_error("mahip_sg_gen: exact tie order (mode 1) is not available on a shard"); return -1; }
+		if (need_walk) {
+			// (1) the push order: arcs leave ma_sg_gen in hit order (asm.c:18-35), and the reference's hit order differs from the stable
+			//     one inside runs of equal (qid,qs).  Only if two arcs come from one such run does that reach the arcs.
+			int fix_push = 0;
+			if (want_slots) {
+				HIPCHK(hipMemsetAsync(ctr + ST_PUSH_CONFLICTS, 0, 8, c->st));
+				hipLaunchKernelGGL(k_arc_push_conflicts, dim3(grid_for(m, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->aslot), m, c->d_aos,
+				                   (const uint32_t*)P<uint32_t>(c->sidx), ctr);
+				CHK(ctr_fetch(c));
+				c->tie.push_conflicts = c->h_ctr[ST_PUSH_CONFLICTS];
+				fix_push = c->tie.push_conflicts > 0;
+			}
+			if (fix_push) {
+				CHK(hits_reference_rank(c)); // uses key[]/val[] as scratch
+				for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }
+				hipLaunchKernelGGL(k_arc_push_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->aslot), (const uint32_t*)P<uint32_t>(c->hrank), m,
+				                   P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
+				int g2 = 0;
+				CHK(radix_sort_pairs(c, m, 0, bitlen_u64(c->n_hits), 0, 0, &g2));
+				hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, (const uint32_t*)P<uint32_t>(c->val[g2]), out);
+				c->ag ^= 1; // `out` now holds the arcs in the reference's push order
+				in = arcs_of(c, c->ag); out = arcs_of(c, c->ag ^ 1);
+			}
+			// (2) the reference's sort of that sequence (ksort.h:134-183 on ul with squeezed ids): permutation from the host walk
+			hipLaunchKernelGGL(k_arc_keys_ref, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, map, P<uint64_t>(c->key[0]));
+			CHK(reference_order(c, P<uint64_t>(c->key[0]), m, P<uint32_t>(c->val[1])));
+			{
+				ProfScope ps(c, "k_arc_permute", 36.0 * (double)m);
+				hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, (const uint32_t*)P<uint32_t>(c->val[1]), out);
+			}
+			c->tie.arc_walk = 1;
 		}
 		c->ag ^= 1;
 	}

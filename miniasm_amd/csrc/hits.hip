@@ -88,8 +88,8 @@ struct HitCols { uint32_t *qid, *qs, *qe, *tn, *ts, *te, *ml, *bl; };
 // in the sorted keys (low bi bits) or in perm[]; group offsets from the query-id boundaries of the sorted keys.
 // skey == nullptr: identity (input already grouped: the per-symbol path).
 __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__ h, const uint64_t *__restrict__ skey, const uint32_t *__restrict__ perm,
-                                                     int qshift, int bi, size_t n, uint32_t n_seq, HitCols c, uint32_t *__restrict__ goff)
-{
+                                                     int qshift, int bi, size_t n, uint32_t n_seq, HitCols c, uint32_t *__restrict__ goff, uint32_t *__restrict__ sidx)
+{ // sidx (optional): input position of the record in every sorted slot -- what the tie-order repair needs to find a slot's original key
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (i > n) return;
 	uint32_t q = n_seq, qprev = 0;
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 		const uint4 *p = (const uint4*)(h + j);
 		uint4 a = p[0], b = p[1]; // a = {qs, qid, qe, tn}  b = {ts, te, ml|rev, bl|del}
 		q = a.y;
+		if (sidx) sidx[i] = (uint32_t)j;
 		c.qid[i] = a.y; c.qs[i] = a.x; c.qe[i] = a.z; c.tn[i] = a.w;
 		c.ts[i] = b.x; c.te[i] = b.y; c.ml[i] = b.z; c.bl[i] = b.w & ~DEAD;
 	}
@@ -604,15 +605,16 @@ __global__ __launch_bounds__(256) void k_hit_squeeze(HitCols c, size_t n, const 
 }
 
 // ------------------------------------------------------------------------------------------------ export
-__global__ __launch_bounds__(256) void k_hit_keepflags(const uint32_t *__restrict__ bl, size_t n, uint32_t *__restrict__ keep)
+// rank (optional): position of slot i in the order the records are exported in (the reference's order of tied hits)
+__global__ __launch_bounds__(256) void k_hit_keepflags(const uint32_t *__restrict__ bl, size_t n, uint32_t *__restrict__ keep, const uint32_t *__restrict__ rank)
 {
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (i < n) keep[i] = !(bl[i] & DEAD);
+	if (i < n) keep[rank ? rank[i] : i] = !(bl[i] & DEAD);
 }
 
 // live hits -> dense AoS in array order, ids renumbered through map (if any)
 __global__ __launch_bounds__(256) void k_hit_export(HitCols c, size_t n, const uint32_t *__restrict__ pos, const int32_t *__restrict__ map,
-                                                     ma_hit_t *__restrict__ out)
+                                                     ma_hit_t *__restrict__ out, const uint32_t *__restrict__ rank)
 {
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= n) return;
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(256) void k_hit_export(HitCols c, size_t n, const u
 	if (bl & DEAD) return;
 	uint32_t q = c.qid[i], t = c.tn[i];
 	if (map) q = (uint32_t)map[q], t = (uint32_t)map[t];
-	uint4 *o = (uint4*)(out + pos[i]);
+	uint4 *o = (uint4*)(out + pos[rank ? rank[i] : i]);
 	o[0] = make_uint4(c.qs[i], q, c.qe[i], t);
 	o[1] = make_uint4(c.ts[i], c.te[i], c.ml[i], bl);
 }
@@ -661,6 +663,8 @@ static int hits_common_setup(mahip_ctx *c, size_t n, uint32_t n_seq)
 	c->soa_ready = false; c->has_map = false; c->graph_ready = false;
 	c->hint_max_qs = 0; // hints describe one upload: set them again after every upload/adopt
 	c->lazy_squeeze = false;
+	c->sorted_here = false; c->hrank_ready = false;
+	memset(&c->tie, 0, sizeof(c->tie));
 	CHK(reserve_read_arrays(c));
 	for (int k = 0; k < 8; ++k) CHK(dev_reserve(c, c->col[k], (n + 1) * 4));
 	return 0;
@@ -693,6 +697,35 @@ extern "C" int mahip_hits_raw_download(mahip_ctx_t *c, ma_hit_t *out)
 	return xfer_copy(c, (void*)c->d_aos, out, c->n_hits * sizeof(ma_hit_t), 0);
 }
 
+__global__ __launch_bounds__(256) void k_rec_keep(const ma_hit_t *__restrict__ h, size_t n, uint32_t q_beg, uint32_t q_end, uint32_t *__restrict__ keep)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) { uint32_t q = (uint32_t)(h[i].qns >> 32); keep[i] = q >= q_beg && q < q_end; }
+}
+__global__ __launch_bounds__(256) void k_rec_compact(const ma_hit_t *__restrict__ h, size_t n, const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, ma_hit_t *__restrict__ out)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n && keep[i]) { const uint4 *p = (const uint4*)(h + i); uint4 *o = (uint4*)(out + pos[i]); o[0] = p[0]; o[1] = p[1]; }
+}
+
+extern "C" int mahip_hits_raw_extract(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end, void *d_dst, size_t *n_out)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	const size_t n = c->n_hits;
+	if (n_out) *n_out = 0;
+	if (n == 0) return 0;
+	if (!c->d_aos) { mahip_set_error("mahip_hits_raw_extract: no records"); return -1; }
+	CHK(dev_reserve(c, c->keep, (n + 16) * 4)); CHK(dev_reserve(c, c->pos, (n + 16) * 4));
+	uint32_t *d_tot = (uint32_t*)(P<unsigned long long>(c->ctr) + CT_TOTAL);
+	hipLaunchKernelGGL(k_rec_keep, dim3(grid_for(n, 256)), dim3(256), 0, c->st, c->d_aos, n, q_beg, q_end, P<uint32_t>(c->keep));
+	CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), n, d_tot));
+	if (d_dst) hipLaunchKernelGGL(k_rec_compact, dim3(grid_for(n, 256)), dim3(256), 0, c->st, c->d_aos, n, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (ma_hit_t*)d_dst);
+	CHK(ctr_fetch(c));
+	HIPCHK(hipGetLastError());
+	if (n_out) *n_out = (size_t)(c->h_ctr[CT_TOTAL] & 0xffffffffu);
+	return 0;
+}
+
 extern "C" int mahip_set_shard(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end)
 {
 	c->q_beg = q_beg; c->q_end = q_end;
@@ -706,9 +739,59 @@ extern "C" int mahip_set_hints(mahip_ctx_t *c, uint32_t max_qs)
 	return 0;
 }
 
-extern "C" int mahip_set_exact_ties(mahip_ctx_t *c, int on)
+extern "C" int mahip_set_exact_ties(mahip_ctx_t *c, int mode)
 {
-	c->exact_ties = on != 0;
+	c->tie_mode = mode < 0 || mode > 2 ? 2 : mode;
+	return 0;
+}
+
+extern "C" int mahip_tie_stats(mahip_ctx_t *c, mahip_tie_info_t *out)
+{
+	if (out) *out = c->tie;
+	return 0;
+}
+
+static inline bool ctx_sharded(const mahip_ctx *c) { return c->q_beg > 0 || (c->n_seq && c->q_end < c->n_seq); }
+
+// ---- the reference's order of hits with equal (qid, qs) ----
+// A slot's ORIGINAL key is the qns of its input record (cuts rewrite the qs column, never the input records).
+__global__ __launch_bounds__(256) void k_hit_tie_count(const ma_hit_t *__restrict__ h, const uint32_t *__restrict__ sidx, size_t n, unsigned long long *__restrict__ ctr)
+{
+	uint32_t cnt = 0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + 1; i < n; i += (size_t)gridDim.x * 256)
+		cnt += h[sidx[i]].qns == h[sidx[i - 1]].qns;
+	blk_add_u64(&ctr[ST_HIT_TIES], cnt);
+}
+__global__ __launch_bounds__(256) void k_perm_invert(const uint32_t *__restrict__ perm, size_t n, uint32_t *__restrict__ inv)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) inv[perm[i]] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void k_hit_rank(const uint32_t *__restrict__ sidx, const uint32_t *__restrict__ inv, size_t n, uint32_t *__restrict__ hrank)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) hrank[i] = inv[sidx[i]];
+}
+
+// c->hrank[slot] = position of the slot's record in the order the reference's ma_hit_sort (hit.c:19-22) leaves the input in.
+// Both orders are sorted by key, so hrank is the identity outside runs of equal keys.
+int hits_reference_rank(mahip_ctx *c)
+{
+	if (c->hrank_ready) return 0;
+	const size_t n = c->n_hits;
+	if (!c->sorted_here || !c->sidx.p || !c->d_aos) { mahip_set_error("hits_reference_rank: the hits were not sorted by this context"); return -1; }
+	if (ctx_sharded(c)) { mahip_set_error("hits_reference_rank: the reference's tie order is a function of the whole input; not available on a shard"); return -1; }
+	CHK(dev_reserve(c, c->hrank, (n + 1) * 4));
+	if (n == 0) { c->hrank_ready = true; return 0; }
+	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (n + 1) * 8)); CHK(dev_reserve(c, c->val[k], (n + 1) * 4)); }
+	hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
+	                   (uint32_t*)nullptr, P<unsigned long long>(c->ctr), 0u, 0xffffffffu, 32, 0, 0); // key = qid<<32 | qs, input order
+	CHK(reference_order(c, P<uint64_t>(c->key[0]), n, P<uint32_t>(c->val[1])));
+	hipLaunchKernelGGL(k_perm_invert, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->val[1]), n, P<uint32_t>(c->val[0]));
+	hipLaunchKernelGGL(k_hit_rank, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->sidx), (const uint32_t*)P<uint32_t>(c->val[0]), n, P<uint32_t>(c->hrank));
+	HIPCHK(hipGetLastError());
+	c->hrank_ready = true;
+	c->tie.hit_walk = 1;
 	return 0;
 }
 
@@ -724,19 +807,9 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	}
 	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (n + 1) * 8)); CHK(dev_reserve(c, c->val[k], (n + 1) * 4)); }
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
-	if (c->exact_ties) { // the reference's own (unstable) order: keys = qns as they are, permutation from the host
-		if (c->q_beg > 0 || (c->n_seq && c->q_end < c->n_seq)) { mahip_set_error("mahip_hits_sort: exact-tie mode is not available on a shard"); return -1; }
-		CHK(ctr_zero(c));
-		hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
-		                   (uint32_t*)nullptr, ctr, 0u, 0xffffffffu, 32, 0, 0); // key = qid<<32 | qs
-		CHK(reference_order(c, P<uint64_t>(c->key[0]), n, P<uint32_t>(c->val[1])));
-		c->n_live = n;
-		ProfScope ps(c, "k_hit_gather", 68.0 * (double)n);
-		hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)nullptr, (const uint32_t*)P<uint32_t>(c->val[1]), 32, 0, n, c->n_seq, h, P<uint32_t>(c->goff));
-		HIPCHK(hipGetLastError());
-		c->soa_ready = true;
-		return 0;
-	}
+	const bool want_sidx = c->tie_mode != 0;
+	if (want_sidx) CHK(dev_reserve(c, c->sidx, (n + 1) * 4));
+	c->sorted_here = true; c->hrank_ready = false;
 	// digit plan: bits of the query start, of the query id, of the record index
 	int bs, bq, bi = bitlen(n - 1);
 	if (c->hint_max_qs && c->n_seq) bs = bitlen(c->hint_max_qs), bq = bitlen(c->n_seq - 1); // no device round trip
@@ -791,7 +864,8 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	{
 		ProfScope ps(c, "k_hit_gather", (pk ? 72.0 : 76.0) * (double)n); // key 8 (+ index 4) + record 32 + columns 32
 		hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)P<uint64_t>(c->key[gen]),
-		                   pk ? (const uint32_t*)nullptr : (const uint32_t*)P<uint32_t>(c->val[gen]), pk ? bi + bs : bs, bi, n, c->n_seq, h, P<uint32_t>(c->goff));
+		                   pk ? (const uint32_t*)nullptr : (const uint32_t*)P<uint32_t>(c->val[gen]), pk ? bi + bs : bs, bi, n, c->n_seq, h, P<uint32_t>(c->goff),
+		                   want_sidx ? P<uint32_t>(c->sidx) : (uint32_t*)nullptr);
 	}
 	HIPCHK(hipGetLastError());
 	c->soa_ready = true;
@@ -804,9 +878,10 @@ extern "C" int mahip_hits_index(mahip_ctx_t *c)
 	size_t n = c->n_hits;
 	HitCols h = cols_of(c);
 	ProfScope ps(c, "k_hit_gather", 64.0 * (double)n);
-	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)nullptr, (const uint32_t*)nullptr, 32, 0, n, c->n_seq, h, P<uint32_t>(c->goff));
+	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)nullptr, (const uint32_t*)nullptr, 32, 0, n, c->n_seq, h, P<uint32_t>(c->goff), (uint32_t*)nullptr);
 	HIPCHK(hipGetLastError());
 	c->soa_ready = true;
+	c->sorted_here = false; c->hrank_ready = false; // the caller's order is final (per-symbol path: already the reference's)
 	return 0;
 }
 
@@ -1146,13 +1221,28 @@ extern "C" int mahip_hits_download(mahip_ctx_t *c, ma_hit_t *out, size_t *n_out)
 	if (n_out) *n_out = c->n_live;
 	if (n == 0 || c->n_live == 0) return 0;
 	HitCols h = cols_of(c);
+	// the order of hits with equal (qid,qs) is visible in a hit dump: reproduce the reference's when there are any
+	const uint32_t *rank = nullptr;
+	if (c->tie_mode != 0 && c->sorted_here && c->sidx.p) {
+		if (!c->hrank_ready) {
+			HIPCHK(hipMemsetAsync(P<unsigned long long>(c->ctr) + ST_HIT_TIES, 0, 8, c->st));
+			hipLaunchKernelGGL(k_hit_tie_count, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, (const uint32_t*)P<uint32_t>(c->sidx), n, P<unsigned long long>(c->ctr));
+			CHK(ctr_fetch(c));
+			c->tie.hit_ties = c->h_ctr[ST_HIT_TIES];
+			if (c->tie.hit_ties) {
+				if (ctx_sharded(c)) { if (c->tie_mode == 1) { mahip_set_error("mahip_hits_download: exact tie order is not available on a shard"); return -1; } c->tie.unrepaired = 1; }
+				else CHK(hits_reference_rank(c));
+			}
+		}
+		if (c->hrank_ready) rank = P<uint32_t>(c->hrank);
+	}
 	CHK(dev_reserve(c, c->keep, (n + 16) * 4));
 	CHK(dev_reserve(c, c->pos, (n + 16) * 4));
 	CHK(dev_reserve(c, c->key[0], (c->n_live + 1) * sizeof(ma_hit_t))); // staging for the dense AoS
-	hipLaunchKernelGGL(k_hit_keepflags, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint32_t*)h.bl, n, P<uint32_t>(c->keep));
+	hipLaunchKernelGGL(k_hit_keepflags, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint32_t*)h.bl, n, P<uint32_t>(c->keep), rank);
 	CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), n, nullptr));
 	hipLaunchKernelGGL(k_hit_export, dim3(grid_for(n, 256)), dim3(256), 0, c->st, h, n, (const uint32_t*)P<uint32_t>(c->pos),
-	                   c->has_map ? (const int32_t*)P<int32_t>(c->map) : (const int32_t*)nullptr, (ma_hit_t*)c->key[0].p);
+	                   c->has_map ? (const int32_t*)P<int32_t>(c->map) : (const int32_t*)nullptr, (ma_hit_t*)c->key[0].p, rank);
 	CHK(xfer_copy(c, c->key[0].p, out, c->n_live * sizeof(ma_hit_t), 0));
 	return 0;
 }

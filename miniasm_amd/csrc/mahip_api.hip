@@ -41,7 +41,7 @@ void dev_free(mahip_ctx *c, DevBuf &b)
 
 int ctr_zero(mahip_ctx *c)
 {
-	HIPCHK(hipMemsetAsync(c->ctr.p, 0, 64 * 8, c->st));
+	HIPCHK(hipMemsetAsync(c->ctr.p, 0, CT_STICKY * 8, c->st));
 	return 0;
 }
 
@@ -72,7 +72,8 @@ extern "C" mahip_ctx_t *mahip_create(int device, void *stream)
 	if (dev_reserve(c, c->ctr, 64 * 8) != 0) { delete c; return nullptr; }
 	if (hipHostMalloc((void**)&c->h_ctr, 64 * 8, hipHostMallocDefault) != hipSuccess) { mahip_set_error("mahip_create: hipHostMalloc failed"); delete c; return nullptr; }
 	memset(c->h_ctr, 0, 64 * 8);
-	{ const char *s = getenv("MA_EXACT_TIES"); c->exact_ties = s && atoi(s) != 0; }
+	if (hipMemsetAsync(c->ctr.p, 0, 64 * 8, c->st) != hipSuccess) { mahip_set_error("mahip_create: memset failed"); delete c; return nullptr; }
+	{ const char *s = getenv("MA_EXACT_TIES"); c->tie_mode = s == 0 || *s == 0 ? 2 : atoi(s) != 0 ? 1 : 0; } // unset: automatic
 	return c;
 }
 
@@ -85,7 +86,7 @@ extern "C" void mahip_destroy(mahip_ctx_t *c)
 	DevBuf *all[] = { &c->aos_own, &c->goff, &c->sub[0], &c->sub[1], &c->r_cont, &c->r_used, &c->r_del, &c->r_live, &c->map, &c->surv,
 		&c->au[0], &c->au[1], &c->av[0], &c->av[1], &c->alen[0], &c->alen[1], &c->aol[0], &c->aol[1], &c->idx, &c->sdel, &c->slen,
 		&c->keep, &c->pos, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->hist, &c->scan_tmp[0], &c->scan_tmp[1], &c->scan_tmp[2],
-		&c->ctr, &c->ovf, &c->big0, &c->big1, &c->marks, &c->sgmask };
+		&c->ctr, &c->ovf, &c->big0, &c->big1, &c->marks, &c->sgmask, &c->sidx, &c->hrank, &c->aslot };
 	for (DevBuf *b : all) dev_free(c, *b);
 	for (int k = 0; k < 8; ++k) dev_free(c, c->col[k]);
 	paf_free(c);

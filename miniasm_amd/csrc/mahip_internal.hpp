@@ -37,6 +37,7 @@ struct mahip_ctx {
 	uint32_t n_seq = 0;       // reads, original numbering
 	uint32_t q_beg = 0, q_end = 0xffffffffu; // shard
 	uint32_t hint_max_qs = 0; // upper bound of the query starts (max read length), 0 = unknown
+	uint32_t paf_max_qs = 0;  // the same as found by the last mahip_paf_parse (hints are reset by every upload/adopt)
 	const ma_hit_t *d_aos = nullptr; // input records (adopted or aos_own)
 	DevBuf aos_own;
 	DevBuf col[8];            // qid qs qe tn ts te mlrev bl(dead<<31)
@@ -47,7 +48,16 @@ struct mahip_ctx {
 	DevBuf surv;              // u32 [n_seq_new] new -> old id
 	bool soa_ready = false, has_map = false, lazy_squeeze = false;
 	int sg_max_hang = 0, sg_min_ovlp = 0; float sg_int_frac = 0; // classifier options of the last mahip_sg_flags (pass B/C recompute the arcs)
-	bool exact_ties = false; // order records with equal sort keys exactly as the reference's unstable sort does (host-computed permutation)
+	// ---- tie order.  The device sorts are stable; the reference's are not.  tie_mode 2 (default): after the arc
+	// sort a census counts (u,len) tie groups; none => the stable order IS the reference's result; some => the reference's order is
+	// reproduced (host walk over the keys) for the arcs and, when two arcs were pushed from hits with equal (qid,qs), for the hits.
+	// tie_mode 1: always reproduce it.  tie_mode 0: never (documented total order).
+	int tie_mode = 2;
+	DevBuf sidx;              // u32 [n_hits] input position of the record in each sorted slot
+	DevBuf hrank;             // u32 [n_hits] position of each sorted slot in the reference's order (identity outside tie runs)
+	DevBuf aslot;             // u32 [n_arc]  hit slot every pushed arc came from
+	bool sorted_here = false, hrank_ready = false; // hits sorted by mahip_hits_sort (d_aos = the unsorted input) / hrank valid
+	mahip_tie_info_t tie = {0, 0, 0, 0, 0, 0, 0};
 	uint32_t n_seq_new = 0;
 
 	// ---- arcs (dense SoA, two generations for compaction) ----
@@ -97,6 +107,8 @@ template <typename T> static inline T *P(DevBuf &b) { return (T*)b.p; }
 
 // counters (indices into ctx->ctr)
 enum { CT_LIVE = 0, CT_REMAIN, CT_TOTDP, CT_TOTLEN, CT_OVF, CT_NRED, CT_NMULTI, CT_NASYMM, CT_NSHORT, CT_MAXQID, CT_MAXQS, CT_TOTAL, CT_OVF2, CT_MAXLEN, CT_CUT, CT_N };
+// slots [CT_STICKY, 64) are not touched by ctr_zero: the tie census keeps its results there until they are read
+enum { CT_STICKY = 48, ST_ARC_TIE_GROUPS = 48, ST_ARC_TIE_ARCS, ST_PUSH_CONFLICTS, ST_HIT_TIES };
 int ctr_zero(mahip_ctx *c);
 int ctr_fetch(mahip_ctx *c); // D2H + sync into c->h_ctr
 
@@ -109,8 +121,10 @@ int radix_sort_pairs(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1,
 int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen, bool first_hist_ready = false);
 void radix_first_digit(int lo, int hi, int *shift, int *bits, unsigned *tile);
 int radix_reserve_hist(mahip_ctx *c, size_t n);
-// exact-tie mode: the permutation the reference's sort applies to d_keys[0..n) (input order), written to d_perm
+// the permutation the reference's (unstable) sort applies to d_keys[0..n) (input order), written to d_perm
 int reference_order(mahip_ctx *c, const uint64_t *d_keys, size_t n, uint32_t *d_perm);
+// position of every sorted hit slot in the reference's order -> c->hrank (hits.hip)
+int hits_reference_rank(mahip_ctx *c);
 // bulk pageable<->device copy through per-thread pinned slots (xfer.hip); returns after the copy is complete
 int xfer_copy(mahip_ctx *c, void *dev_ptr, void *host_ptr, size_t bytes, int to_device);
 void xfer_pool_free(mahip_ctx *c);

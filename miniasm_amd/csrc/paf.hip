@@ -548,7 +548,7 @@ extern "C" int mahip_paf_parse(mahip_ctx_t *c, int min_span, int min_match, int 
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipStreamSynchronize(c->st));
-	c->hint_max_qs = max_qs;
+	c->hint_max_qs = c->paf_max_qs = max_qs;
 	info->n_records = n_valid; info->n_stored_lines = n_pass; info->n_hits = n_hits; info->n_seq = R; info->max_qs = max_qs; info->name_bytes = b->name_bytes; info->n_lines = L;
 	return 0;
 }
@@ -571,3 +571,5 @@ extern "C" int mahip_paf_release(mahip_ctx_t *c)
 	paf_free(c);
 	return 0;
 }
+
+extern "C" uint32_t mahip_paf_max_qs(mahip_ctx_t *c) { return c->paf_max_qs; }

@@ -137,6 +137,12 @@ int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 		}
 		GPU(mahip_sg_gen(c, opt, have_sub, len, sdel, &n_arc));
 		HT("sg_gen");
+		if (getenv("MA_PIPE_TIMING")) { /* what the tie census found and what was done about it */
+			mahip_tie_info_t ti;
+			mahip_tie_stats(c, &ti);
+			fprintf(stderr, "[T::ties] %llu arc tie groups (%llu arcs), %llu push conflicts -> arc walk %d, hit walk %d%s\n", (unsigned long long)ti.arc_tie_groups,
+			        (unsigned long long)ti.arc_tie_arcs, (unsigned long long)ti.push_conflicts, ti.arc_walk, ti.hit_walk, ti.unrepaired ? " (NOT repaired: stable order kept)" : "");
+		}
 		free(len); free(sdel);
 		if (fused) { /* the hit count after the (postponed) squeeze is known now; keep the reference's line order */
 			n_cont_hits = mahip_hits_live(c);
@@ -170,7 +176,7 @@ int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 struct ma_tail_job {
 	ma_opt_t opt;
 	const sdict_t *d;
-	char outfmt[8];
+	char outfmt[16];
 	int stage, have_sub, squeezed, have_graph;
 	uint32_t n_red;
 	sdict_t view;
@@ -186,7 +192,7 @@ ma_tail_job_t *ma_pipeline_tail_fetch(mahip_ctx_t *c, const ma_opt_t *opt, const
 	ma_tail_job_t *j = (ma_tail_job_t*)calloc(1, sizeof(ma_tail_job_t));
 	const uint32_t R = d->n_seq;
 	j->opt = *opt; j->d = d; j->stage = stage;
-	strncpy(j->outfmt, outfmt, sizeof(j->outfmt) - 1);
+	if (strlen(outfmt) < sizeof(j->outfmt)) strcpy(j->outfmt, outfmt); /* a longer -p value names no output mode: the empty string matches none either */
 	j->have_sub = st[0]; j->squeezed = st[1]; j->n_red = st[2]; j->have_graph = st[3];
 	j->t_fetch[0] = sys_realtime();
 	j->view.n_seq = R; j->view.seq = d->seq;

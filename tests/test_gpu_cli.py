@@ -116,15 +116,21 @@ TIE_INPUTS = {  # coordinates on a grid (pafgen -q): hundreds of equal (qid,qs) 
     "grid200": dict(reads=3000, lines=80000, seed=6, extra=["-q", "200", "-L", "uniform", "-d", "0.3", "-x", "0.03"]),
     "grid400_lognormal": dict(reads=4000, lines=120000, seed=7, extra=["-q", "400", "-d", "0.2"]),
     "grid50_fixed": dict(reads=2500, lines=70000, seed=8, extra=["-q", "50", "-L", "fixed", "-d", "0.1"]),
+    "grid400_deep": dict(reads=30000, lines=1500000, seed=9, extra=["-q", "400", "-d", "0.2", "-x", "0.03"]),  # 97 % of the reads contained (squeezed-id keys matter)
 }
 
 
 @pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("mode", ["default", "forced"])
 @pytest.mark.parametrize("name", list(TIE_INPUTS))
-def test_exact_tie_mode_is_byte_identical(name, tmpdir_s, monkeypatch):
-    """MA_EXACT_TIES=1 (mahip_set_exact_ties): on inputs full of equal sort keys every dump equals the reference's
-    BYTE FOR BYTE -- no line-order normalisation: hit order, arc order and everything downstream of them"""
-    monkeypatch.setenv("MA_EXACT_TIES", "1")
+def test_tie_rich_input_is_byte_identical(name, mode, tmpdir_s, monkeypatch):
+    """On inputs full of equal sort keys every dump equals the reference's BYTE FOR BYTE -- no line-order normalisation: hit
+    order, arc order and everything downstream of them.  "default": nothing set -- the tie census after the arc sort finds
+    the tie groups and the reference's order is reproduced automatically; "forced": MA_EXACT_TIES=1 (mahip_set_exact_ties 1)"""
+    if mode == "forced":
+        monkeypatch.setenv("MA_EXACT_TIES", "1")
+    else:
+        monkeypatch.delenv("MA_EXACT_TIES", raising=False)
     cfg = TIE_INPUTS[name]
     paf = R.pafgen(os.path.join(tmpdir_s, "tie_%s.paf" % name), cfg["reads"], cfg["lines"], cfg["seed"], cfg["extra"])
     ref_sg, _ = R.run_cli(R.REF_BIN, ["-p", "sg", "-S5"], paf)
@@ -143,6 +149,36 @@ def test_exact_tie_mode_is_byte_identical(name, tmpdir_s, monkeypatch):
     ref_out, _ = R.run_cli(R.REF_BIN, ["-p", "ug"], paf)
     out, _ = R.run_cli(ma.CLI_PATH, ["-p", "ug"], paf)
     assert out == ref_out
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+def test_tie_census_and_walks_are_reported(tmpdir_s):
+    """the C ABI reports what the automatic mode found and did (mahip_tie_stats): tie groups -> arc walk (and the hit walk
+    only when two arcs were pushed from hits with equal keys); a tie-free input -> nothing to do"""
+    opt = ma.default_opt()
+    for name, cfg, want_ties in (("grid16", TIE_INPUTS["grid16"], True), ("lognormal", INPUTS["lognormal"], False)):
+        paf = R.pafgen(os.path.join(tmpdir_s, "ts_%s.paf" % name), cfg["reads"], cfg["lines"], cfg["seed"], cfg["extra"])
+        ing = ma.Ingest(paf, opt)
+        ctx = ma.Ctx(0)
+        ctx.set_exact_ties(2)
+        ctx.hits_upload(ing.hits, ing.n_seq)
+        gfa = ma.run_resident(ctx, opt, ing, "ug")
+        st = ctx.tie_stats()
+        ref_gfa, _ = R.run_cli(R.REF_BIN, [], paf)
+        assert gfa == ref_gfa
+        if want_ties:
+            assert st["arc_tie_groups"] >= 5 and st["arc_tie_arcs"] >= 2 * st["arc_tie_groups"] and st["arc_walk"] == 1 and st["unrepaired"] == 0
+            assert st["hit_walk"] == (1 if st["push_conflicts"] else 0)
+        else:
+            assert st["arc_tie_groups"] == 0 and st["arc_walk"] == 0 and st["hit_walk"] == 0
+        # mode 0 keeps the stable order and says so
+        ctx.set_exact_ties(0)
+        ctx.hits_upload(ing.hits, ing.n_seq)
+        ma.run_resident(ctx, opt, ing, "ug")
+        st0 = ctx.tie_stats()
+        assert st0["arc_walk"] == 0 and st0["hit_walk"] == 0
+        ing.close()
+        ctx.close()
 
 
 @pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")

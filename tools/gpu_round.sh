@@ -11,6 +11,9 @@ case $w in
 tests)
   timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/tests_parity.log 2>&1; echo "rc=$?" >> gpurun_out/tests_parity.log
   grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_parity.log | tail -60 ;;
+ties)
+  timeout 1500 python -m pytest tests/test_gpu_cli.py -m gpu -q --tb=short -p no:cacheprovider -k "tie" > gpurun_out/tests_ties.log 2>&1; echo "rc=$?" >> gpurun_out/tests_ties.log
+  grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_ties.log | tail -60 ;;
 cli)
   timeout 1500 python -m pytest tests/test_gpu_cli.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/tests_cli.log 2>&1; echo "rc=$?" >> gpurun_out/tests_cli.log
   grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_cli.log | tail -60 ;;
@@ -34,8 +37,11 @@ benchsmall)
   timeout 900 python bench.py --reads 20000 --lines 1000000 --steps 3 --warmup 1 > gpurun_out/bench_small.json 2> gpurun_out/bench_small.log; echo "rc=$?" >> gpurun_out/bench_small.log
   tail -5 gpurun_out/bench_small.log; cat gpurun_out/bench_small.json ;;
 bench)
-  timeout 1500 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.log; echo "rc=$?" >> gpurun_out/bench.log
-  tail -5 gpurun_out/bench.log; cat gpurun_out/bench.json ;;
+  /usr/bin/time -v timeout 1700 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.log; echo "rc=$?" >> gpurun_out/bench.log
+  grep -E "^\[bench\]|rc=|Elapsed|Maximum resident" gpurun_out/bench.log | tail -12; cat gpurun_out/bench.json ;;
+benchcfg2)
+  timeout 900 python bench.py --reads 200000 --lines 10000000 --seed 1 --no-legs > gpurun_out/bench_cfg2.json 2> gpurun_out/bench_cfg2.log; echo "rc=$?" >> gpurun_out/bench_cfg2.log
+  grep -E "^\[bench\]|rc=" gpurun_out/bench_cfg2.log | tail -8; cat gpurun_out/bench_cfg2.json ;;
 benchfixed)
   timeout 1500 python bench.py --model fixed --no-cpu > gpurun_out/bench_fixed.json 2> gpurun_out/bench_fixed.log; echo "rc=$?" >> gpurun_out/bench_fixed.log
   tail -3 gpurun_out/bench_fixed.log; cat gpurun_out/bench_fixed.json ;;
