@@ -129,8 +129,10 @@ def orc_stages(hits, n_seq, opt, upto="trans"):
 
 
 # --------------------------------------------------------------------------------------------- HIP
-def gpu_stages(ctx, hits, n_seq, opt, upto="trans"):
+def gpu_stages(ctx, hits, n_seq, opt, upto="trans", tie_mode=0):
+    """tie_mode 0: the stable total order (what the oracle computes); 2: the default -- the reference's order of equal keys"""
     S = {"n_seq": n_seq}
+    ctx.set_exact_ties(tie_mode)
     ctx.hits_upload(hits, n_seq)
     ctx.sort()
     S["sorted"] = ctx.hits_download()
@@ -158,6 +160,8 @@ def gpu_stages(ctx, hits, n_seq, opt, upto="trans"):
         if S["n_red"]:
             ctx.symm()
         S["tr_arcs"], S["tr_seq"], S["tr_idx"] = ctx.asg_download()
+    S["tie"] = ctx.tie_stats()
+    ctx.set_exact_ties(2)
     return S
 
 

@@ -1,7 +1,8 @@
 """GPU parity tests proper: every HIP pass, called through the C ABI (include/mahip.h), against the C oracle
-(bit-exact, order included: both use the total order) and against the unmodified reference library (records
-compared as multisets because the reference's sort leaves ties in a data-dependent order; the graph compared
-exactly on arc-tie-free inputs).  Run with `pytest -m gpu` on an MI355X."""
+(bit-exact, order included: tie mode 0 = the stable total order the oracle computes) and, in the default tie mode,
+against the unmodified reference library -- bit-exact INCLUDING the order of hits and arcs with equal sort keys on
+every input (the synthetic inputs are full of equal (qid,qs) hit keys: every hit that covers the query's first base).
+Run with `pytest -m gpu` on an MI355X."""
 import ctypes as C
 import os
 
@@ -41,13 +42,18 @@ def test_stages_match_oracle_and_reference(name, reads, lines, seed, extra, tmpd
         assert idx.tobytes() == gpu["tr_idx"].tobytes(), "CSR index differs"
     if R.have_ref():
         ref = ST.ref_stages(paf, opt)
-        ST.compare(ref, gpu, "reference vs gpu [%s]" % name, exact_order=False, graph=False)
+        ST.compare(ref, gpu, "reference vs gpu, stable order [%s]" % name, exact_order=False, graph=False)
         assert R.canon(ref["sg_arcs"]).tobytes() == R.canon(gpu["sg_arcs"]).tobytes()
+        # the default tie mode: every stage equals the reference's array, order included
+        auto = ST.gpu_stages(gpu_ctx, ing.hits, ing.n_seq, opt, tie_mode=2)
+        ST.compare(ref, auto, "reference vs gpu, default tie mode [%s]" % name, exact_order=True, graph=True)
+        assert ref["tr_idx"].tobytes() == auto["tr_idx"].tobytes()
         keys = ref["sg_arcs"]["ul"]
-        if len(np.unique(keys)) == len(keys):  # no (u,len) ties: the reference order is unique
-            assert ref["sg_arcs"].tobytes() == gpu["sg_arcs"].tobytes()
-            assert ref["tr_arcs"].tobytes() == gpu["tr_arcs"].tobytes()
-            assert ref["tr_idx"].tobytes() == gpu["tr_idx"].tobytes()
+        if len(np.unique(keys)) == len(keys):  # no (u,len) ties: nothing to repair, and the census must say so
+            assert auto["tie"]["arc_tie_groups"] == 0 and auto["tie"]["arc_walk"] == 0
+            assert ref["sg_arcs"].tobytes() == gpu["sg_arcs"].tobytes() and ref["tr_arcs"].tobytes() == gpu["tr_arcs"].tobytes()
+        else:
+            assert auto["tie"]["arc_tie_groups"] > 0 and auto["tie"]["arc_walk"] == 1
         R.ref().asg_destroy(ref["g"])
     ing.close()
 
@@ -60,12 +66,24 @@ def test_sort_random_keys_and_ties(gpu_ctx):
         h["qns"] = (rng.integers(0, nq, n).astype(np.uint64) << 32) | rng.integers(0, ns, n).astype(np.uint64)
         h["qe"] = np.arange(n)  # distinguishes tied records: stability is observable
         h["tn"] = rng.integers(0, nq, n)
+        gpu_ctx.set_exact_ties(0)  # the stable total order (key, input position)
         gpu_ctx.hits_upload(h, int(nq))
         gpu_ctx.sort()
         got = gpu_ctx.hits_download()
         exp = h.copy()
         R.orc().orc_hit_sort(n, exp.ctypes.data)
         assert got.tobytes() == exp.tobytes(), "sort differs for n=%d" % n
+        gpu_ctx.set_exact_ties(2)  # default: ties as the reference's in-place radix sort leaves them (hit.c:19-22)
+        if R.have_ref():
+            gpu_ctx.hits_upload(h, int(nq))
+            gpu_ctx.sort()
+            got = gpu_ctx.hits_download()
+            LR = R.ref()
+            LR.radix_sort_hit.argtypes = [C.c_void_p, C.c_void_p]
+            LR.radix_sort_hit.restype = None
+            exp = h.copy()
+            LR.radix_sort_hit(exp.ctypes.data, exp.ctypes.data + n * 32)
+            assert got.tobytes() == exp.tobytes(), "reference tie order differs for n=%d" % n
 
 
 def test_empty_and_degenerate_inputs(gpu_ctx):

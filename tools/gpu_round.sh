@@ -37,8 +37,8 @@ benchsmall)
   timeout 900 python bench.py --reads 20000 --lines 1000000 --steps 3 --warmup 1 > gpurun_out/bench_small.json 2> gpurun_out/bench_small.log; echo "rc=$?" >> gpurun_out/bench_small.log
   tail -5 gpurun_out/bench_small.log; cat gpurun_out/bench_small.json ;;
 bench)
-  /usr/bin/time -v timeout 1700 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.log; echo "rc=$?" >> gpurun_out/bench.log
-  grep -E "^\[bench\]|rc=|Elapsed|Maximum resident" gpurun_out/bench.log | tail -12; cat gpurun_out/bench.json ;;
+  timeout 1700 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.log; echo "rc=$?" >> gpurun_out/bench.log
+  grep -E "^\[bench\]|rc=" gpurun_out/bench.log | tail -12; cat gpurun_out/bench.json ;;
 benchcfg2)
   timeout 900 python bench.py --reads 200000 --lines 10000000 --seed 1 --no-legs > gpurun_out/bench_cfg2.json 2> gpurun_out/bench_cfg2.log; echo "rc=$?" >> gpurun_out/bench_cfg2.log
   grep -E "^\[bench\]|rc=" gpurun_out/bench_cfg2.log | tail -8; cat gpurun_out/bench_cfg2.json ;;
