@@ -15,14 +15,14 @@ B         = build/obj
 HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function -Iinclude -I$(CSRC)
 CFLAGS    = -O2 -g -Wall -fPIC -Iinclude -I$(HOST) -I$(CSRC)
 
-HIP_SRC   = scan radix hits graph paf mahip_api xfer
+HIP_SRC   = scan radix hits graph clean ug paf mahip_api xfer
 HOST_SRC  = timers name_dict paf_reader ingest_mt ingest_gpu hits_host graph_host refsort unitig_gfa pipeline
 HIP_OBJ   = $(addprefix $(B)/,$(addsuffix .hip.o,$(HIP_SRC)))
 HOST_OBJ  = $(addprefix $(B)/,$(addsuffix .o,$(HOST_SRC)))
 
 LIB       = $(PKG)/lib/libminiasm_amd.so
 BIN       = $(PKG)/bin/miniasm $(PKG)/bin/pafgen
-CORE_TEST = $(PKG)/lib/libma_core_host.so
+CORE_TEST = $(PKG)/lib/libma_core_host.so $(PKG)/lib/libclean_host.so
 
 .PHONY: all lib oracle dropin clean
 all: lib $(BIN) $(CORE_TEST) oracle dropin
@@ -32,7 +32,7 @@ lib: $(LIB)
 $(B) $(PKG)/lib $(PKG)/bin:
 	mkdir -p $@
 
-$(B)/%.hip.o: $(CSRC)/%.hip $(CSRC)/mahip_internal.hpp $(CSRC)/ma_core.h include/mahip.h include/miniasm_amd.h | $(B)
+$(B)/%.hip.o: $(CSRC)/%.hip $(CSRC)/mahip_internal.hpp $(CSRC)/ma_core.h $(CSRC)/clean_core.h $(CSRC)/ug_core.h include/mahip.h include/miniasm_amd.h | $(B)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(B)/%.o: $(HOST)/%.c $(HOST)/ma_host.h include/mahip.h include/miniasm_amd.h | $(B)
@@ -48,8 +48,12 @@ $(PKG)/bin/pafgen: tools/pafgen.c | $(PKG)/bin
 	$(CC) -O2 -Wall -o $@ tools/pafgen.c -lm
 
 # ma_core.h compiled for the host: lets the CPU tests check the per-hit arithmetic against the reference
-$(CORE_TEST): tests/core_host.c $(CSRC)/ma_core.h | $(PKG)/lib
+$(PKG)/lib/libma_core_host.so: tests/core_host.c $(CSRC)/ma_core.h | $(PKG)/lib
 	$(CC) -O2 -g -Wall -fPIC -ffp-contract=off -shared -I$(CSRC) -o $@ tests/core_host.c
+
+# clean_core.h / ug_core.h compiled for the host: the cleaners' fixpoint and the unitig construction run on the CPU in the tests
+$(PKG)/lib/libclean_host.so: tests/clean_host.cpp $(CSRC)/clean_core.h $(CSRC)/ug_core.h | $(PKG)/lib
+	g++ -O2 -g -Wall -fPIC -shared -std=c++17 -I$(CSRC) -o $@ tests/clean_host.cpp
 
 oracle:
 	$(MAKE) -C oracle all

@@ -95,10 +95,15 @@ def pmc_traffic(kernel, workload):
     `tools/gpu_round.sh pmc`: FETCH_SIZE and WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md's HBM section
     prescribes).  PMC counters cannot be read from inside this process: the figure is attached only when the workload is
     the profiled one, and is labelled with its source."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic_%s.json" % workload)
-    try:
-        d = json.load(open(path))
-    except Exception:
+    d = None
+    for rnd in ("r02", "r01"):  # the newest profile of this workload
+        path = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, workload))
+        try:
+            d = json.load(open(path))
+            break
+        except Exception:
+            pass
+    if d is None:
         return None, None
     names = {k.replace("void ", ""): v for k, v in d.items()}
     per_launch = lambda v: v["fetch_bytes_x2"] + v["write_bytes"]

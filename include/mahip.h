@@ -137,8 +137,26 @@ int mahip_asg_upload(mahip_ctx_t *c, const asg_t *g);
 int mahip_asg_del_trans(mahip_ctx_t *c, int fuzz, uint32_t *n_reduced);
 /* asg.c:104-145 asg_arc_del_multi / asg_arc_del_asymm, each followed by asg_cleanup when it removed arcs */
 int mahip_asg_symm(mahip_ctx_t *c, uint32_t *n_multi, uint32_t *n_asymm);
+int mahip_asg_del_multi(mahip_ctx_t *c, uint32_t *n_multi);   /* asg.c:104-121 */
+int mahip_asg_del_asymm(mahip_ctx_t *c, uint32_t *n_asymm);   /* asg.c:124-138 */
 /* asg.c:83-101 asg_arc_del_short marking + cleanup (symm separate) */
 int mahip_asg_del_short(mahip_ctx_t *c, float drop_ratio, uint32_t *n_short);
+/* Renumber the device graph to the squeezed read ids (sdict.c:69-86 applied to the graph, as the reference has it from ma_sg_gen
+ * on): a relabelling -- arc order and CSR positions are unchanged -- after which the cleaners and the unitig pass sweep the
+ * surviving reads only.  No-op when no squeeze map is pending. */
+int mahip_asg_squeeze(mahip_ctx_t *c);
+/* The order-dependent cleaners (asg.c:238-433) as a device fixpoint over versioned state (csrc/clean_core.h); each includes the
+ * asg_cleanup the reference runs when something was cut.  Results equal the reference's sequential sweeps exactly. */
+int mahip_asg_cut_tip(mahip_ctx_t *c, int max_ext, uint32_t *n_cut);                       /* asg.c:238-254 */
+int mahip_asg_cut_internal(mahip_ctx_t *c, int max_ext, uint32_t *n_cut);                  /* asg.c:256-272 */
+int mahip_asg_cut_biloop(mahip_ctx_t *c, int max_ext, uint32_t *n_cut);                    /* asg.c:274-306 */
+int mahip_asg_pop_bubble(mahip_ctx_t *c, int max_dist, uint32_t *n_pop, uint32_t *n_tips); /* asg.c:412-433 (the graph must be symmetric) */
+/* asm.c:121-210 ma_ug_gen on the device (csrc/ug.hip): unitigs of the current graph.  Counts: unitigs, reads on them, arcs
+ * between unitig ends.  mahip_ug_download: per unitig {reads, length, start, end} (start == end == 0xffffffff: circular) and the
+ * offset of its members; members = vertex << 32 | length to the next read; uarcs = the unitig arcs in push order (the
+ * reference sorts them with its own sort afterwards, asm.c:208). */
+int mahip_ug_gen(mahip_ctx_t *c, uint32_t *n_utg, uint32_t *n_members, uint32_t *n_uarc);
+int mahip_ug_download(mahip_ctx_t *c, uint32_t *u_n, uint32_t *u_len, uint32_t *u_start, uint32_t *u_end, uint32_t *u_off, uint64_t *members, asg_arc_t *uarcs);
 uint32_t mahip_asg_n_arc(mahip_ctx_t *c);
 /* fills g (arc/seq/idx malloc'ed, is_srt=1) in the squeezed numbering */
 int mahip_asg_download(mahip_ctx_t *c, asg_t *g);

@@ -1,0 +1,226 @@
+// clean.hip -- the order-dependent graph cleaners (reference asg.c:238-433: asg_cut_tip, asg_cut_internal, asg_cut_biloop,
+// asg_pop_bubble) on the device, as a fixpoint over versioned state (see clean_core.h for the method and the proof sketch).
+//
+//   one iteration = k_clean_rule / k_clean_bubble : every vertex evaluated against the stamps of the previous iteration,
+//                                                   the stamps of this iteration rebuilt with atomicMin
+//                 + k_clean_diff                  : did any stamp change?
+//   after the fixpoint: k_clean_apply writes the stamps into the base flags, asg_cleanup (asg.c:72-80) compacts.
+//
+// Work units: one thread per vertex for the three short-unitig rules (a rule reads a handful of arc lists); one thread per
+// bubble source with a private open-addressing table in HBM scratch (probes touch a handful of vertices; the table grows and
+// the iteration is repeated if a probe ever fills it).  Integer work, latency-bound on dependent list reads: the reduced graph
+// is small next to the hit arrays, what matters is that nothing leaves the device and that the sweep costs a few launches
+// instead of one host step per vertex.
+#include "mahip_internal.hpp"
+#include "clean_core.h"
+
+int graph_cleanup(mahip_ctx *c); // graph.hip: asg_cleanup on the current graph
+uint32_t graph_nseq(const mahip_ctx *c);
+
+enum { CLEAN_TIP = 0, CLEAN_INTERNAL = 1, CLEAN_BILOOP = 2 };
+
+template <int RULE>
+__global__ __launch_bounds__(256) void k_clean_rule(cl_view_t g, cl_stamps_t s, int max_ext, unsigned long long *__restrict__ ctr)
+{
+	uint32_t cnt = 0;
+	for (uint32_t v = blockIdx.x * 256 + threadIdx.x; v < g.n_vtx; v += gridDim.x * 256) {
+		if (RULE == CLEAN_TIP) cnt += cl_rule_tip(&g, s, v, max_ext);
+		else if (RULE == CLEAN_INTERNAL) cnt += cl_rule_internal(&g, s, v, max_ext);
+		else cnt += cl_rule_biloop(&g, s, v, max_ext);
+	}
+	blk_add_u64(&ctr[CT_LIVE], cnt);
+}
+
+// vertices that can be a bubble source at all: at least two arcs in the index (asg.c:366)
+__global__ __launch_bounds__(256) void k_bubble_cand(const unsigned long long *__restrict__ idx, uint32_t n_vtx, uint32_t *__restrict__ keep)
+{
+	uint32_t v = blockIdx.x * 256 + threadIdx.x;
+	if (v < n_vtx) keep[v] = (uint32_t)idx[v] >= 2;
+}
+__global__ __launch_bounds__(256) void k_bubble_list(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, uint32_t n_vtx, uint32_t *__restrict__ list)
+{
+	uint32_t v = blockIdx.x * 256 + threadIdx.x;
+	if (v < n_vtx && keep[v]) list[pos[v]] = v;
+}
+
+__global__ __launch_bounds__(64) void k_clean_bubble(cl_view_t g, cl_stamps_t s, const uint32_t *__restrict__ src, uint32_t n_src, uint32_t max_dist,
+                                                      cl_binfo_t *__restrict__ tabs, uint32_t *__restrict__ aux, uint32_t cap, unsigned long long *__restrict__ ctr)
+{
+	const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
+	cl_bscratch_t b;
+	b.tab = tabs + (size_t)tid * cap; b.used = aux + (size_t)tid * 2 * cap; b.stack = b.used + cap; b.cap = cap; b.n_used = 0;
+	uint32_t pops = 0, tips = 0, ovf = 0;
+	for (uint32_t k = tid; k < n_src; k += gridDim.x * 64) {
+		const uint32_t v0 = src[k];
+		uint32_t sink = 0, nt = 0;
+		int r = cl_bubble_probe(&g, v0, max_dist, &b, &sink, &nt);
+		if (r > 0) { cl_bubble_stamp(&g, s, v0, sink, &b); ++pops; tips += nt; }
+		else if (r < 0) ovf = 1;
+	}
+	if (pops) atomicAdd(&ctr[CT_LIVE], (unsigned long long)pops); // pops are rare: a handful of atomics per launch
+	if (tips) atomicAdd(&ctr[CT_REMAIN], (unsigned long long)tips);
+	if (ovf) atomicAdd(&ctr[CT_OVF], 1ull);
+}
+
+__global__ __launch_bounds__(256) void k_table_init(cl_binfo_t *__restrict__ tabs, size_t n)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) tabs[i].key = CL_NONE;
+}
+
+__global__ __launch_bounds__(256) void k_clean_diff(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, size_t n, unsigned long long *__restrict__ ctr)
+{
+	uint32_t d = 0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d += a[i] != b[i];
+	blk_add_u64(&ctr[CT_TOTDP], d);
+}
+
+// the fixpoint's stamps into the base flags: seq.del for stamped reads, the del bit for stamped arcs
+__global__ __launch_bounds__(256) void k_clean_apply(const uint32_t *__restrict__ rst, uint32_t n_read, uint8_t *__restrict__ sdel,
+                                                      const uint32_t *__restrict__ ast, size_t n_arc, uint32_t *__restrict__ aol)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n_read && rst[i] != CL_NONE) sdel[i] = 1;
+	if (i < n_arc && ast[i] != CL_NONE) aol[i] |= CL_ADEL;
+}
+
+struct CleanBufs { DevBuf rst[2], ast[2], src, tabs, aux; uint32_t cap = 0; unsigned threads = 0; };
+
+static CleanBufs *clean_bufs(mahip_ctx *c)
+{
+	if (!c->clean) c->clean = new CleanBufs();
+	return (CleanBufs*)c->clean;
+}
+
+void clean_free(mahip_ctx *c)
+{
+	CleanBufs *b = (CleanBufs*)c->clean;
+	if (!b) return;
+	DevBuf *all[] = { &b->rst[0], &b->rst[1], &b->ast[0], &b->ast[1], &b->src, &b->tabs, &b->aux };
+	for (DevBuf *x : all) dev_free(c, *x);
+	delete b;
+	c->clean = nullptr;
+}
+
+// mode 0..2: the short-unitig rules with param = max_ext; mode 3: bubbles with param = max_dist.
+// *cnt = actions of the sweep (tips cut / internal sequences / bi-loops / bubbles), *cnt2 = tips trimmed by bubble pops.
+static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_t *cnt2, int *n_iter)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->graph_ready) { mahip_set_error("graph cleaner: no graph"); return -1; }
+	CleanBufs *b = clean_bufs(c);
+	const uint32_t R = graph_nseq(c), V = 2 * R;
+	const size_t A = c->n_arc;
+	*cnt = *cnt2 = 0; if (n_iter) *n_iter = 0;
+	if (V == 0 || A == 0) return 0;
+	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, b->rst[k], ((size_t)R + 4) * 4)); CHK(dev_reserve(c, b->ast[k], (A + 4) * 4)); }
+	unsigned long long *ctr = P<unsigned long long>(c->ctr);
+	uint32_t n_src = 0;
+	if (mode == 3) { // source list: vertices with >= 2 arcs, in vertex order
+		CHK(dev_reserve(c, c->keep, ((size_t)V + 16) * 4)); CHK(dev_reserve(c, c->pos, ((size_t)V + 16) * 4));
+		CHK(dev_reserve(c, b->src, ((size_t)V + 4) * 4));
+		uint32_t *d_tot = (uint32_t*)(ctr + CT_TOTAL);
+		hipLaunchKernelGGL(k_bubble_cand, dim3(grid_for(V, 256)), dim3(256), 0, c->st, (const unsigned long long*)P<unsigned long long>(c->idx), V, P<uint32_t>(c->keep));
+		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), V, d_tot));
+		hipLaunchKernelGGL(k_bubble_list, dim3(grid_for(V, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), V, P<uint32_t>(b->src));
+		CHK(ctr_fetch(c));
+		n_src = (uint32_t)(c->h_ctr[CT_TOTAL] & 0xffffffffu);
+		if (n_src == 0) return 0;
+		if (b->cap == 0) b->cap = 64;
+	}
+	cl_view_t g;
+	const int ag = c->ag;
+	g.av = P<uint32_t>(c->av[ag]); g.alen = P<uint32_t>(c->alen[ag]); g.aol = P<uint32_t>(c->aol[ag]);
+	g.idx = P<unsigned long long>(c->idx); g.sdel = P<uint8_t>(c->sdel); g.n_vtx = V;
+	int cur = 0;
+	HIPCHK(hipMemsetAsync(b->rst[0].p, 0xff, (size_t)R * 4, c->st));
+	HIPCHK(hipMemsetAsync(b->ast[0].p, 0xff, A * 4, c->st));
+	for (int it = 0;; ++it) {
+		if (it > 100000) { mahip_set_error("graph cleaner: no fixpoint"); return -1; }
+		cl_stamps_t s; s.rst = P<uint32_t>(b->rst[cur ^ 1]); s.ast = P<uint32_t>(b->ast[cur ^ 1]);
+		g.rst = P<uint32_t>(b->rst[cur]); g.ast = P<uint32_t>(b->ast[cur]);
+		HIPCHK(hipMemsetAsync(s.rst, 0xff, (size_t)R * 4, c->st));
+		HIPCHK(hipMemsetAsync(s.ast, 0xff, A * 4, c->st));
+		CHK(ctr_zero(c));
+		if (mode == 3) {
+			const unsigned want = n_src < 65536u ? (n_src + 63) / 64 * 64 : 65536u;
+			if (b->threads < want || b->tabs.cap < (size_t)want * b->cap * sizeof(cl_binfo_t)) {
+				b->threads = want;
+				CHK(dev_reserve(c, b->tabs, (size_t)want * b->cap * sizeof(cl_binfo_t)));
+				CHK(dev_reserve(c, b->aux, (size_t)want * b->cap * 2 * 4));
+			}
+			// probes leave their table empty; (re)initialise when it was (re)allocated or after an overflow
+			hipLaunchKernelGGL(k_table_init, dim3(grid_for((size_t)want * b->cap, 256)), dim3(256), 0, c->st, (cl_binfo_t*)b->tabs.p, (size_t)want * b->cap);
+			ProfScope ps(c, "k_clean_bubble", 0);
+			hipLaunchKernelGGL(k_clean_bubble, dim3(want / 64), dim3(64), 0, c->st, g, s, (const uint32_t*)P<uint32_t>(b->src), n_src, (uint32_t)param,
+			                   (cl_binfo_t*)b->tabs.p, P<uint32_t>(b->aux), b->cap, ctr);
+		} else {
+			ProfScope ps(c, "k_clean_rule", 0);
+			const unsigned grid = grid_for(V, 256, MA_STREAM_BLOCKS);
+			if (mode == CLEAN_TIP) hipLaunchKernelGGL(k_clean_rule<CLEAN_TIP>, dim3(grid), dim3(256), 0, c->st, g, s, param, ctr);
+			else if (mode == CLEAN_INTERNAL) hipLaunchKernelGGL(k_clean_rule<CLEAN_INTERNAL>, dim3(grid), dim3(256), 0, c->st, g, s, param, ctr);
+			else hipLaunchKernelGGL(k_clean_rule<CLEAN_BILOOP>, dim3(grid), dim3(256), 0, c->st, g, s, param, ctr);
+		}
+		hipLaunchKernelGGL(k_clean_diff, dim3(grid_for(R, 256, 1024)), dim3(256), 0, c->st, g.rst, (const uint32_t*)s.rst, (size_t)R, ctr);
+		hipLaunchKernelGGL(k_clean_diff, dim3(grid_for(A, 256, 1024)), dim3(256), 0, c->st, g.ast, (const uint32_t*)s.ast, A, ctr);
+		CHK(ctr_fetch(c));
+		HIPCHK(hipGetLastError());
+		if (c->h_ctr[CT_OVF]) { // a probe filled its table: bigger tables, same iteration again
+			if (b->cap >= (1u << 20)) { mahip_set_error("asg_pop_bubble: a probe visits more than %u vertices", b->cap); return -1; }
+			b->cap <<= 2; b->threads = 0;
+			continue;
+		}
+		cur ^= 1;
+		if (n_iter) *n_iter = it + 1;
+		if (c->h_ctr[CT_TOTDP] == 0) { *cnt = (uint32_t)c->h_ctr[CT_LIVE]; *cnt2 = (uint32_t)c->h_ctr[CT_REMAIN]; break; }
+	}
+	if (*cnt) {
+		const size_t m = A > R ? A : R;
+		hipLaunchKernelGGL(k_clean_apply, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(b->rst[cur]), R, P<uint8_t>(c->sdel),
+		                   (const uint32_t*)P<uint32_t>(b->ast[cur]), A, P<uint32_t>(c->aol[ag]));
+		CHK(ctr_zero(c));
+		CHK(graph_cleanup(c)); // asg.c:251, 269, 303, 430: asg_cleanup when something was cut
+	}
+	return 0;
+}
+
+static void clean_timing(const char *what, int n_iter, uint32_t cnt)
+{
+	static int on = -1;
+	if (on < 0) on = getenv("MA_PIPE_TIMING") && atoi(getenv("MA_PIPE_TIMING")) >= 2;
+	if (on) fprintf(stderr, "[T::clean] %-14s %2d iterations, %u actions\n", what, n_iter, cnt);
+}
+
+extern "C" int mahip_asg_cut_tip(mahip_ctx_t *c, int max_ext, uint32_t *n_cut)
+{
+	uint32_t a = 0, b = 0; int it = 0;
+	CHK(clean_sweep(c, CLEAN_TIP, max_ext, &a, &b, &it));
+	clean_timing("cut_tip", it, a);
+	if (n_cut) *n_cut = a;
+	return 0;
+}
+extern "C" int mahip_asg_cut_internal(mahip_ctx_t *c, int max_ext, uint32_t *n_cut)
+{
+	uint32_t a = 0, b = 0; int it = 0;
+	CHK(clean_sweep(c, CLEAN_INTERNAL, max_ext, &a, &b, &it));
+	clean_timing("cut_internal", it, a);
+	if (n_cut) *n_cut = a;
+	return 0;
+}
+extern "C" int mahip_asg_cut_biloop(mahip_ctx_t *c, int max_ext, uint32_t *n_cut)
+{
+	uint32_t a = 0, b = 0; int it = 0;
+	CHK(clean_sweep(c, CLEAN_BILOOP, max_ext, &a, &b, &it));
+	clean_timing("cut_biloop", it, a);
+	if (n_cut) *n_cut = a;
+	return 0;
+}
+extern "C" int mahip_asg_pop_bubble(mahip_ctx_t *c, int max_dist, uint32_t *n_pop, uint32_t *n_tips)
+{
+	uint32_t a = 0, b = 0; int it = 0;
+	CHK(clean_sweep(c, 3, max_dist, &a, &b, &it));
+	clean_timing("pop_bubble", it, a);
+	if (n_pop) *n_pop = a;
+	if (n_tips) *n_tips = b;
+	return 0;
+}

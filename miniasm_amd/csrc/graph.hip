@@ -444,9 +444,13 @@ __global__ __launch_bounds__(256) void k_seq_to_aos(const uint32_t *__restrict__
 
 // ================================================================================================ host side
 
+// reads of the graph / the map that still has to be applied when it leaves the device
+uint32_t graph_nseq(const mahip_ctx *c) { return c->gsq ? c->n_seq_new : c->n_seq; }
+static const int32_t *graph_map(mahip_ctx *c) { return c->has_map && !c->gsq ? (const int32_t*)P<int32_t>(c->map) : (const int32_t*)nullptr; }
+
 static int arc_reindex(mahip_ctx *c)
 {
-	size_t V = 2 * (size_t)c->n_seq;
+	size_t V = 2 * (size_t)graph_nseq(c);
 	CHK(dev_reserve(c, c->idx, (V + 2) * 8));
 	HIPCHK(hipMemsetAsync(c->idx.p, 0, V * 8, c->st));
 	if (c->n_arc) {
@@ -490,6 +494,7 @@ extern "C" int mahip_sg_flags(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, 
 	uint32_t R = c->n_seq;
 	CHK(dev_reserve(c, c->slen, ((size_t)R + 4) * 4)); CHK(dev_reserve(c, c->sdel, (size_t)R + 16));
 	c->sg_max_hang = opt->max_hang; c->sg_int_frac = opt->int_frac; c->sg_min_ovlp = opt->min_ovlp;
+	c->gsq = false;
 	CHK(ctr_zero(c));
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	// host-side per-read arrays (per-symbol path) go through the scratch buffers
@@ -645,7 +650,7 @@ extern "C" int mahip_asg_import_rows(mahip_ctx_t *c, const void *d_src, const ui
 	for (int r = 0; r < n_ranks; ++r) tot += counts[r];
 	if (tot >= 0x7fffffffull) { mahip_set_error("mahip_asg_import_rows: too many arcs"); return -1; }
 	CHK(reserve_arcs(c, tot));
-	c->ag = 0;
+	c->ag = 0; c->gsq = false;
 	ArcCols a = arcs_of(c, 0);
 	size_t off = 0;
 	for (int r = 0; r < n_ranks; ++r) {
@@ -677,6 +682,53 @@ extern "C" int mahip_asg_flags_in(mahip_ctx_t *c, const void *d_src, size_t firs
 	return 0;
 }
 
+int graph_cleanup(mahip_ctx *c) { return arc_cleanup(c, c->n_arc, 0, 0); }
+
+// ---- the graph in the squeezed numbering (sdict.c:69-86 applied to the graph, as the reference has it from ma_sg_gen on) ----
+__global__ __launch_bounds__(256) void k_arc_squeeze_ids(uint32_t *__restrict__ au, uint32_t *__restrict__ av, size_t n, const int32_t *__restrict__ map)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) {
+		uint32_t u = au[i], v = av[i];
+		au[i] = (uint32_t)map[u >> 1] << 1 | (u & 1); av[i] = (uint32_t)map[v >> 1] << 1 | (v & 1);
+	}
+}
+__global__ __launch_bounds__(256) void k_seq_squeeze(const uint32_t *__restrict__ slen, const uint8_t *__restrict__ sdel, const unsigned long long *__restrict__ idx,
+                                                      const int32_t *__restrict__ map, uint32_t n_seq, uint32_t *__restrict__ slen2, uint8_t *__restrict__ sdel2, unsigned long long *__restrict__ idx2)
+{
+	uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	if (r >= n_seq) return;
+	int32_t m = map[r];
+	if (m < 0) return;
+	slen2[m] = slen[r]; sdel2[m] = sdel[r];
+	idx2[2 * (size_t)m] = idx[2 * (size_t)r]; idx2[2 * (size_t)m + 1] = idx[2 * (size_t)r + 1];
+}
+
+// Renumber the device graph to the squeezed read ids.  After ma_sg_gen only surviving reads carry arcs, so this is a relabelling:
+// arc order, CSR positions and every later result are unchanged; the cleaners and the unitig pass then sweep n_seq_new reads
+// instead of n_seq.
+extern "C" int mahip_asg_squeeze(mahip_ctx_t *c)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->graph_ready) { mahip_set_error("mahip_asg_squeeze: no graph"); return -1; }
+	if (!c->has_map || c->gsq) return 0;
+	const uint32_t R = c->n_seq, Rn = c->n_seq_new;
+	const int32_t *map = (const int32_t*)P<int32_t>(c->map);
+	CHK(dev_reserve(c, c->big0, ((size_t)Rn + 4) * 4)); CHK(dev_reserve(c, c->big1, (size_t)Rn + 16));
+	CHK(dev_reserve(c, c->pos, (2 * (size_t)Rn + 2) * 8));
+	if (c->n_arc) hipLaunchKernelGGL(k_arc_squeeze_ids, dim3(grid_for(c->n_arc, 256)), dim3(256), 0, c->st, P<uint32_t>(c->au[c->ag]), P<uint32_t>(c->av[c->ag]), (size_t)c->n_arc, map);
+	if (R) hipLaunchKernelGGL(k_seq_squeeze, dim3(grid_for(R, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->slen), (const uint8_t*)P<uint8_t>(c->sdel),
+	                          (const unsigned long long*)P<unsigned long long>(c->idx), map, R, P<uint32_t>(c->big0), P<uint8_t>(c->big1), P<unsigned long long>(c->pos));
+	if (Rn) {
+		HIPCHK(hipMemcpyAsync(c->slen.p, c->big0.p, (size_t)Rn * 4, hipMemcpyDeviceToDevice, c->st));
+		HIPCHK(hipMemcpyAsync(c->sdel.p, c->big1.p, (size_t)Rn, hipMemcpyDeviceToDevice, c->st));
+		HIPCHK(hipMemcpyAsync(c->idx.p, c->pos.p, 2 * (size_t)Rn * 8, hipMemcpyDeviceToDevice, c->st));
+	}
+	HIPCHK(hipGetLastError());
+	c->gsq = true;
+	return 0;
+}
+
 extern "C" int mahip_asg_cleanup(mahip_ctx_t *c, uint32_t *n_arc)
 {
 	HIPCHK(hipSetDevice(c->dev));
@@ -692,7 +744,7 @@ extern "C" int mahip_asg_upload(mahip_ctx_t *c, const asg_t *g)
 	HIPCHK(hipSetDevice(c->dev));
 	size_t n = g->n_arc;
 	uint32_t R = g->n_seq;
-	c->n_seq = R; c->n_seq_new = R; c->has_map = false; c->soa_ready = false;
+	c->n_seq = R; c->n_seq_new = R; c->has_map = false; c->soa_ready = false; c->gsq = false;
 	CHK(reserve_arcs(c, n));
 	CHK(dev_reserve(c, c->slen, ((size_t)R + 4) * 4)); CHK(dev_reserve(c, c->sdel, (size_t)R + 16));
 	CHK(dev_reserve(c, c->idx, (2 * (size_t)R + 2) * 8));
@@ -718,7 +770,7 @@ extern "C" int mahip_asg_del_trans_range(mahip_ctx_t *c, int fuzz, uint32_t v_be
 { // marking only (asg.c:148-186) for the vertices [v_beg, v_end)
 	HIPCHK(hipSetDevice(c->dev));
 	if (!c->graph_ready) { mahip_set_error("mahip_asg_del_trans: no graph"); return -1; }
-	uint32_t V = 2 * c->n_seq;
+	uint32_t V = 2 * graph_nseq(c);
 	if (v_end > V) v_end = V;
 	CHK(ctr_zero(c));
 	CHK(dev_reserve(c, c->ovf, ((size_t)V + 1) * 4));
@@ -750,45 +802,59 @@ extern "C" int mahip_asg_del_trans_range(mahip_ctx_t *c, int fuzz, uint32_t v_be
 extern "C" int mahip_asg_del_trans(mahip_ctx_t *c, int fuzz, uint32_t *n_reduced)
 {
 	uint32_t nr = 0;
-	CHK(mahip_asg_del_trans_range(c, fuzz, 0, 2 * c->n_seq, &nr));
+	CHK(mahip_asg_del_trans_range(c, fuzz, 0, 2 * graph_nseq(c), &nr));
 	if (n_reduced) *n_reduced = nr;
 	if (nr) CHK(arc_cleanup(c, c->n_arc, 0, 0)); // asg.c:188-189
 	return 0;
 }
 
-extern "C" int mahip_asg_symm(mahip_ctx_t *c, uint32_t *n_multi, uint32_t *n_asymm)
+// asg.c:104-121 asg_arc_del_multi (+ asg_cleanup when it removed arcs)
+extern "C" int mahip_asg_del_multi(mahip_ctx_t *c, uint32_t *n_multi)
 {
 	HIPCHK(hipSetDevice(c->dev));
-	if (!c->graph_ready) { mahip_set_error("mahip_asg_symm: no graph"); return -1; }
-	unsigned long long *ctr = P<unsigned long long>(c->ctr);
-	const unsigned long long *idx = P<unsigned long long>(c->idx);
-	uint32_t nm = 0, na = 0;
+	if (!c->graph_ready) { mahip_set_error("mahip_asg_del_multi: no graph"); return -1; }
 	CHK(ctr_zero(c));
 	if (c->n_arc) {
 		ProfScope ps(c, "k_asg_multi", 16.0 * (double)c->n_arc);
-		hipLaunchKernelGGL(k_asg_multi, dim3(grid_for(c->n_arc, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, arcs_of(c, c->ag), (size_t)c->n_arc, idx, ctr);
+		hipLaunchKernelGGL(k_asg_multi, dim3(grid_for(c->n_arc, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, arcs_of(c, c->ag), (size_t)c->n_arc,
+		                   (const unsigned long long*)P<unsigned long long>(c->idx), P<unsigned long long>(c->ctr));
 	}
 	CHK(ctr_fetch(c));
-	nm = (uint32_t)c->h_ctr[CT_NMULTI];
+	const uint32_t nm = (uint32_t)c->h_ctr[CT_NMULTI];
 	if (nm) CHK(arc_cleanup(c, c->n_arc, 0, 0));
+	if (n_multi) *n_multi = nm;
+	return 0;
+}
+
+// asg.c:124-138 asg_arc_del_asymm (+ asg_cleanup when it removed arcs)
+extern "C" int mahip_asg_del_asymm(mahip_ctx_t *c, uint32_t *n_asymm)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->graph_ready) { mahip_set_error("mahip_asg_del_asymm: no graph"); return -1; }
 	CHK(ctr_zero(c));
 	if (c->n_arc) {
 		ProfScope ps(c, "k_asg_asymm", 32.0 * (double)c->n_arc);
-		hipLaunchKernelGGL(k_asg_asymm, dim3(grid_for(c->n_arc, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, arcs_of(c, c->ag), (size_t)c->n_arc, idx, ctr);
+		hipLaunchKernelGGL(k_asg_asymm, dim3(grid_for(c->n_arc, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, arcs_of(c, c->ag), (size_t)c->n_arc,
+		                   (const unsigned long long*)P<unsigned long long>(c->idx), P<unsigned long long>(c->ctr));
 	}
 	CHK(ctr_fetch(c));
-	na = (uint32_t)c->h_ctr[CT_NASYMM];
+	const uint32_t na = (uint32_t)c->h_ctr[CT_NASYMM];
 	if (na) CHK(arc_cleanup(c, c->n_arc, 0, 0));
-	if (n_multi) *n_multi = nm;
 	if (n_asymm) *n_asymm = na;
 	return 0;
+}
+
+extern "C" int mahip_asg_symm(mahip_ctx_t *c, uint32_t *n_multi, uint32_t *n_asymm)
+{
+	CHK(mahip_asg_del_multi(c, n_multi));
+	return mahip_asg_del_asymm(c, n_asymm);
 }
 
 extern "C" int mahip_asg_del_short(mahip_ctx_t *c, float drop_ratio, uint32_t *n_short)
 {
 	HIPCHK(hipSetDevice(c->dev));
 	if (!c->graph_ready) { mahip_set_error("mahip_asg_del_short: no graph"); return -1; }
-	uint32_t V = 2 * c->n_seq;
+	uint32_t V = 2 * graph_nseq(c);
 	CHK(ctr_zero(c));
 	if (V && c->n_arc) hipLaunchKernelGGL(k_asg_short, dim3(grid_for(V, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, arcs_of(c, c->ag), (const unsigned long long*)P<unsigned long long>(c->idx), V, drop_ratio, P<unsigned long long>(c->ctr));
 	CHK(ctr_fetch(c));
@@ -805,8 +871,8 @@ extern "C" int mahip_asg_download(mahip_ctx_t *c, asg_t *g)
 	HIPCHK(hipSetDevice(c->dev));
 	if (!c->graph_ready) { mahip_set_error("mahip_asg_download: no graph"); return -1; }
 	size_t n = c->n_arc;
-	uint32_t R = c->n_seq, Rn = c->has_map ? c->n_seq_new : R;
-	const int32_t *map = c->has_map ? (const int32_t*)P<int32_t>(c->map) : (const int32_t*)nullptr;
+	uint32_t R = graph_nseq(c), Rn = c->has_map ? c->n_seq_new : R;
+	const int32_t *map = graph_map(c);
 	size_t off_seq = (n + 1) * 16, off_idx = off_seq + (((size_t)Rn + 4) * 4 + 15) / 16 * 16;
 	CHK(dev_reserve(c, c->key[0], off_idx + (2 * (size_t)Rn + 2) * 8));
 	char *stg = (char*)c->key[0].p;

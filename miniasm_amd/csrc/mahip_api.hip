@@ -90,6 +90,8 @@ extern "C" void mahip_destroy(mahip_ctx_t *c)
 	for (DevBuf *b : all) dev_free(c, *b);
 	for (int k = 0; k < 8; ++k) dev_free(c, c->col[k]);
 	paf_free(c);
+	clean_free(c);
+	ug_free(c);
 	xfer_pool_free(c);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	if (c->own_stream) (void)hipStreamDestroy(c->st);

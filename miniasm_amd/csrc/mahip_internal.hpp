@@ -68,6 +68,9 @@ struct mahip_ctx {
 	DevBuf sdel;              // u8 [n_seq] seq.del
 	DevBuf slen;              // u32 [n_seq] seq.len
 	bool graph_ready = false;
+	bool gsq = false;         // the graph has been renumbered to the squeezed read ids (mahip_asg_squeeze): it has n_seq_new reads, no map applies
+	void *clean = nullptr;    // scratch of the graph cleaners (clean.hip)
+	void *ug = nullptr;       // unitig arrays (ug.hip)
 
 	// ---- scratch ----
 	DevBuf keep, pos;         // u32 flags / scanned positions
@@ -130,6 +133,8 @@ int xfer_copy(mahip_ctx *c, void *dev_ptr, void *host_ptr, size_t bytes, int to_
 void xfer_pool_free(mahip_ctx *c);
 int xfer_from_fd(mahip_ctx *c, void *dev_ptr, int fd, size_t bytes);
 void paf_free(mahip_ctx *c);
+void clean_free(mahip_ctx *c);
+void ug_free(mahip_ctx *c);
 
 static inline unsigned grid_for(size_t n, unsigned per_block, unsigned cap = 0x7fffffffu)
 {

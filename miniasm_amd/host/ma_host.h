@@ -27,6 +27,7 @@ ma_tail_job_t *ma_pipeline_tail_fetch(mahip_ctx_t *c, const ma_opt_t *opt, const
 int ma_pipeline_tail_finish(ma_tail_job_t *job, FILE *out);
 int ma_pipeline_tail_finish_mem(ma_tail_job_t *job, char **buf, size_t *len);
 
+ma_ug_t *ma_ug_from_device(mahip_ctx_t *c); /* unitigs of the graph resident in c (unitig_gfa.c over csrc/ug.hip) */
 void ma_sd_reindex(sdict_t *d);    /* build the name index from seq[] (for dictionaries assembled by hand) */
 void ma_sd_drop_index(sdict_t *d);
 void ma_sd_fill(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, const uint32_t *lens); /* bulk fill; the dictionary owns arena */

