@@ -11,6 +11,14 @@ case $w in
 tests)
   timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/tests_parity.log 2>&1; echo "rc=$?" >> gpurun_out/tests_parity.log
   grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_parity.log | tail -60 ;;
+all_tests)
+  timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/tests_all.log 2>&1; echo "rc=$?" >> gpurun_out/tests_all.log
+  grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_all.log | tail -40 ;;
+graphapi)
+  timeout 1500 python -m pytest tests/test_gpu_graph_api.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/tests_graphapi.log 2>&1; echo "rc=$?" >> gpurun_out/tests_graphapi.log
+  grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_graphapi.log | tail -40 ;;
+bignoisy)
+  MA_PIPE_TIMING=2 bash tools/e2e_big.sh 1000000 50000000 3 "-L uniform -d 0.35 -x 0.03" ref | tail -70 ;;
 ties)
   timeout 1500 python -m pytest tests/test_gpu_cli.py -m gpu -q --tb=short -p no:cacheprovider -k "tie" > gpurun_out/tests_ties.log 2>&1; echo "rc=$?" >> gpurun_out/tests_ties.log
   grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_ties.log | tail -60 ;;
