@@ -15,8 +15,8 @@ B         = build/obj
 HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function -Iinclude -I$(CSRC)
 CFLAGS    = -O2 -g -Wall -fPIC -Iinclude -I$(HOST) -I$(CSRC)
 
-HIP_SRC   = scan radix hits graph clean ug paf mahip_api xfer
-HOST_SRC  = timers name_dict paf_reader ingest_mt ingest_gpu hits_host graph_host refsort unitig_gfa pipeline
+HIP_SRC   = scan radix hits graph clean ug comm paf mahip_api xfer
+HOST_SRC  = timers name_dict paf_reader ingest_mt ingest_gpu hits_host graph_host refsort unitig_gfa pipeline sharded
 HIP_OBJ   = $(addprefix $(B)/,$(addsuffix .hip.o,$(HIP_SRC)))
 HOST_OBJ  = $(addprefix $(B)/,$(addsuffix .o,$(HOST_SRC)))
 
@@ -39,7 +39,7 @@ $(B)/%.o: $(HOST)/%.c $(HOST)/ma_host.h include/mahip.h include/miniasm_amd.h | 
 	$(CC) $(CFLAGS) -c $< -o $@
 
 $(LIB): $(HIP_OBJ) $(HOST_OBJ) | $(PKG)/lib
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,-Bsymbolic -o $@ $(HIP_OBJ) $(HOST_OBJ) -lz -lm -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,-Bsymbolic -o $@ $(HIP_OBJ) $(HOST_OBJ) -lz -lm -lpthread -ldl -lrt
 
 $(PKG)/bin/miniasm: $(HOST)/cli.c $(LIB) | $(PKG)/bin
 	$(CC) $(CFLAGS) -o $@ $(HOST)/cli.c -L$(PKG)/lib -lminiasm_amd -Wl,-rpath,'$$ORIGIN/../lib' -lz -lm

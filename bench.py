@@ -196,10 +196,9 @@ def main():
         local = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if one_gpu_debug:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        # torch.distributed is the control plane only (rendezvous of the RCCL id, barriers, the max over ranks of the time):
+        # the data plane is RCCL called from C on the context's stream (csrc/comm.hip, host/sharded.c)
+        dist.init_process_group(backend="gloo")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local)
@@ -213,7 +212,6 @@ def main():
     L.ma_set_log_path(b"/dev/null")
     L.sys_init()
 
-    from miniasm_amd.sharded import Comm, GpuBackend, run_sharded
     t0 = time.perf_counter()
     paf = os.path.join(args.workdir, "w_%s_r%d_n%d_s%d.paf" % (args.model, args.reads, args.lines, args.seed))
     if rank == 0:
@@ -223,15 +221,22 @@ def main():
     t_gen = time.perf_counter() - t0
     opt = ma.default_opt()
 
-    if world > 1:  # sharded mode: the context runs on a torch stream so RCCL collectives and kernels share one stream
-        be = GpuBackend.create(local, 0)
-        ctx = be.ctx
-    else:
-        ctx, be = ma.Ctx(local), None
+    ctx = ma.Ctx(local)
+    if world > 1:  # one communicator per rank: rank 0 makes the RCCL id, the control plane hands it round
+        L.mahip_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+        L.mahip_comm_init_shm.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+        if one_gpu_debug:
+            ma._chk(L.mahip_comm_init_shm(ctx.h, b"miniasm_amd_bench_%s" % os.environ.get("MASTER_PORT", "0").encode(), rank, world), "comm_init_shm")
+        else:
+            box = [None]
+            if rank == 0:
+                idb = C.create_string_buffer(128)
+                ma._chk(L.mahip_comm_unique_id(idb), "comm_unique_id")
+                box[0] = idb.raw
+            dist.broadcast_object_list(box, src=0)
+            ma._chk(L.mahip_comm_init(ctx.h, box[0], rank, world), "comm_init")
     want_text = rank == 0 and world == 1 and not args.no_text
     W = Workload(ma, L, ctx, paf, opt, world, rank, keep_text=want_text)
-    if be is not None:
-        be.n_seq = W.n_seq
     if rank == 0:
         log("workload %s: %d lines (%.2f GB text), %d stored hits (%d on this rank), %d reads; gen %.1fs, file->HBM %.3fs (%.1f GB/s), parse+dictionary %.3fs" % (
             cfg_name, W.n_lines, W.size / 1e9, W.n_all, W.n_my, W.n_seq, t_gen, W.t_load, W.size / W.t_load / 1e9, W.t_parse))
@@ -243,7 +248,12 @@ def main():
     L.ma_pipeline_tail_fetch.argtypes = [vp, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.POINTER(C.c_uint32 * 4)]
     L.ma_pipeline_tail_finish_mem.restype = C.c_int
     L.ma_pipeline_tail_finish_mem.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
-    comm = Comm()
+
+    class ShardStats(C.Structure):  # host/ma_host.h: ma_shard_stats_t
+        _fields_ = [("n_rem1", C.c_uint64), ("n_rem2", C.c_uint64), ("n_hits", C.c_uint64), ("n_seq_new", C.c_uint32), ("n_arc", C.c_uint32), ("n_loc_arc", C.c_uint32),
+                    ("n_red", C.c_uint32), ("n_multi", C.c_uint32), ("n_asymm", C.c_uint32), ("tie_groups", C.c_uint64)]
+    L.ma_pipeline_head_sharded.restype = C.c_int
+    L.ma_pipeline_head_sharded.argtypes = [vp, C.POINTER(ma.MaOpt), C.c_uint32, C.POINTER(ShardStats)]
     overlap = not args.no_overlap
 
     # Passes are pipelined over the stream of batches: the device part of pass k+1 starts as soon as pass k's reduced graph
@@ -293,11 +303,12 @@ def main():
             st = (C.c_uint32 * 4)(0, 0, 0, 0)
             if world == 1:  # single GPU: the C pipeline's device half
                 assert L.ma_pipeline_head(ctx.h, C.byref(opt), W.d, b"ug", 100, 0, C.byref(st)) == 0
-            else:  # sharded: device passes + RCCL exchanges on every rank, graph cleaning + GFA on rank 0
-                stats = run_sharded(be, comm, opt, W.n_seq)
+            else:  # sharded: device passes + RCCL exchanges on every rank (host/sharded.c), graph cleaning + unitigs + GFA on rank 0
+                stats = ShardStats()
+                assert L.ma_pipeline_head_sharded(ctx.h, C.byref(opt), W.n_seq, C.byref(stats)) == 0
                 if rank != 0:
                     return
-                st = (C.c_uint32 * 4)(1, 1, stats["n_red"], 1)
+                st = (C.c_uint32 * 4)(1, 1, stats.n_red, 1)
             job = L.ma_pipeline_tail_fetch(ctx.h, C.byref(opt), W.d, b"ug", 100, C.byref(st))
             assert job
             if self.worker:
@@ -338,7 +349,7 @@ def main():
     run = Runner(W)
     dt = run.timed(args.warmup, args.steps)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu_debug else "cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
     total_lines = float(W.n_lines)
@@ -479,7 +490,7 @@ def main():
                 args.model, args.seed, W.n_lines, W.n_seq, W.n_all / max(W.n_seq, 1), " (sharded by query-read range)" if world > 1 else "", len(gfa)),
                 "global_overlaps": W.n_lines, "per_gpu_hits": W.n_my,
                 "pipelining": "host tail of pass k (cleaners, unitigs, GFA text) overlaps the device part of pass k+1; all K outputs complete inside the timed region" if overlap else "none (--no-overlap)",
-                "parallelism": "read-range shards x%d, RCCL all-gather of sub/flags/arcs" % world if world > 1 else "single GPU"},
+                "parallelism": "read-range shards x%d, RCCL all-gather of sub/flags/arcs from C (host/sharded.c)" % world if world > 1 else "single GPU"},
             "gfa_identical": parity["gfa_identical"] if parity else None, "parity": parity,
             "tie_groups": tie["arc_tie_groups"] if tie else None,
             "tie_path": None if not tie else ("arc walk%s" % (" + hit walk" if tie["hit_walk"] else "") if tie["arc_walk"] else "unrepaired" if tie["unrepaired"] else "stable order (census: no arc ties => provably the reference's order)"),

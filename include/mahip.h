@@ -192,6 +192,21 @@ int mahip_asg_flags_in(mahip_ctx_t *c, const void *d_src, size_t first, size_t c
 /* asg.c:72-80 asg_cleanup on the current graph */
 int mahip_asg_cleanup(mahip_ctx_t *c, uint32_t *n_arc);
 
+/* ---- collectives of the sharded mode (csrc/comm.hip), queued on the context's stream ----------------------------------
+ * RCCL (librccl opened at run time): rank 0 makes an id, everybody calls mahip_comm_init with it.  mahip_comm_init_shm is a
+ * host-staged test double over POSIX shared memory for boxes with a single GPU (N processes on one device). */
+int mahip_comm_unique_id(void *id128);
+int mahip_comm_init(mahip_ctx_t *c, const void *id128, int rank, int world);
+int mahip_comm_init_shm(mahip_ctx_t *c, const char *name, int rank, int world);
+void mahip_comm_destroy(mahip_ctx_t *c);
+int mahip_comm_rank(mahip_ctx_t *c);
+int mahip_comm_world(mahip_ctx_t *c);
+int mahip_comm_all_gather(mahip_ctx_t *c, const void *d_send, void *d_recv, size_t bytes_per_rank);  /* d_recv: world x bytes, rank-major */
+int mahip_comm_all_reduce_max_u8(mahip_ctx_t *c, void *d_buf, size_t n);                               /* OR of 0/1 flag bytes */
+int mahip_comm_all_reduce_sum_u64(mahip_ctx_t *c, uint64_t *h_vals, size_t n);                         /* <= 32 host counters */
+int mahip_comm_barrier(mahip_ctx_t *c);
+int mahip_xbuf(mahip_ctx_t *c, int slot, size_t bytes, void **d_ptr);                                  /* exchange buffers (slot 0 / 1) */
+
 /* ---- instrumentation -------------------------------------------------------------------------------- */
 /* Per-kernel timing with HIP events on the launch stream.  enable=1 brackets every kernel launch with
  * events (adds launch overhead; use for measurement runs only). */

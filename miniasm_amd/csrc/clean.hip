@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_clean_apply(const uint32_t *__restrict_
 	if (i < n_arc && ast[i] != CL_NONE) aol[i] |= CL_ADEL;
 }
 
-struct CleanBufs { DevBuf rst[2], ast[2], src, tabs, aux; uint32_t cap = 0; unsigned threads = 0; };
+struct CleanBufs { DevBuf st[2], src, tabs, aux; uint32_t cap = 0; unsigned threads = 0; }; // st[k]: read stamps [R rounded up] then arc stamps [A]
 
 static CleanBufs *clean_bufs(mahip_ctx *c)
 {
@@ -96,7 +96,7 @@ void clean_free(mahip_ctx *c)
 {
 	CleanBufs *b = (CleanBufs*)c->clean;
 	if (!b) return;
-	DevBuf *all[] = { &b->rst[0], &b->rst[1], &b->ast[0], &b->ast[1], &b->src, &b->tabs, &b->aux };
+	DevBuf *all[] = { &b->st[0], &b->st[1], &b->src, &b->tabs, &b->aux };
 	for (DevBuf *x : all) dev_free(c, *x);
 	delete b;
 	c->clean = nullptr;
@@ -112,11 +112,13 @@ static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_
 	const uint32_t R = graph_nseq(c), V = 2 * R;
 	const size_t A = c->n_arc;
 	*cnt = *cnt2 = 0; if (n_iter) *n_iter = 0;
-	if (V == 0 || A == 0) return 0;
-	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, b->rst[k], ((size_t)R + 4) * 4)); CHK(dev_reserve(c, b->ast[k], (A + 4) * 4)); }
+	if (V == 0) return 0; // (no arcs at all is still a graph: every read without arcs is a tip, asg.c:238-254)
+	const size_t Rp = ((size_t)R + 63) & ~(size_t)63, W = Rp + A; // words per stamp set
+	for (int k = 0; k < 2; ++k) CHK(dev_reserve(c, b->st[k], (W + 4) * 4));
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	uint32_t n_src = 0;
 	if (mode == 3) { // source list: vertices with >= 2 arcs, in vertex order
+		if (A == 0) return 0;
 		CHK(dev_reserve(c, c->keep, ((size_t)V + 16) * 4)); CHK(dev_reserve(c, c->pos, ((size_t)V + 16) * 4));
 		CHK(dev_reserve(c, b->src, ((size_t)V + 4) * 4));
 		uint32_t *d_tot = (uint32_t*)(ctr + CT_TOTAL);
@@ -133,14 +135,13 @@ static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_
 	g.av = P<uint32_t>(c->av[ag]); g.alen = P<uint32_t>(c->alen[ag]); g.aol = P<uint32_t>(c->aol[ag]);
 	g.idx = P<unsigned long long>(c->idx); g.sdel = P<uint8_t>(c->sdel); g.n_vtx = V;
 	int cur = 0;
-	HIPCHK(hipMemsetAsync(b->rst[0].p, 0xff, (size_t)R * 4, c->st));
-	HIPCHK(hipMemsetAsync(b->ast[0].p, 0xff, A * 4, c->st));
+	bool tables_ready = false;
 	for (int it = 0;; ++it) {
 		if (it > 100000) { mahip_set_error("graph cleaner: no fixpoint"); return -1; }
-		cl_stamps_t s; s.rst = P<uint32_t>(b->rst[cur ^ 1]); s.ast = P<uint32_t>(b->ast[cur ^ 1]);
-		g.rst = P<uint32_t>(b->rst[cur]); g.ast = P<uint32_t>(b->ast[cur]);
-		HIPCHK(hipMemsetAsync(s.rst, 0xff, (size_t)R * 4, c->st));
-		HIPCHK(hipMemsetAsync(s.ast, 0xff, A * 4, c->st));
+		cl_stamps_t s; s.rst = P<uint32_t>(b->st[cur ^ 1]); s.ast = s.rst + Rp;
+		g.rst = P<uint32_t>(b->st[cur]); g.ast = g.rst + Rp;
+		g.no_stamps = it == 0; // the first sweep sees the base graph: the old stamp set is neither initialised nor read
+		HIPCHK(hipMemsetAsync(s.rst, 0xff, W * 4, c->st));
 		CHK(ctr_zero(c));
 		if (mode == 3) {
 			const unsigned want = n_src < 65536u ? (n_src + 63) / 64 * 64 : 65536u;
@@ -148,9 +149,12 @@ static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_
 				b->threads = want;
 				CHK(dev_reserve(c, b->tabs, (size_t)want * b->cap * sizeof(cl_binfo_t)));
 				CHK(dev_reserve(c, b->aux, (size_t)want * b->cap * 2 * 4));
+				tables_ready = false;
 			}
-			// probes leave their table empty; (re)initialise when it was (re)allocated or after an overflow
-			hipLaunchKernelGGL(k_table_init, dim3(grid_for((size_t)want * b->cap, 256)), dim3(256), 0, c->st, (cl_binfo_t*)b->tabs.p, (size_t)want * b->cap);
+			if (!tables_ready) { // probes leave their table empty: initialise once per (re)allocation and after an overflow
+				hipLaunchKernelGGL(k_table_init, dim3(grid_for((size_t)b->threads * b->cap, 256)), dim3(256), 0, c->st, (cl_binfo_t*)b->tabs.p, (size_t)b->threads * b->cap);
+				tables_ready = true;
+			}
 			ProfScope ps(c, "k_clean_bubble", 0);
 			hipLaunchKernelGGL(k_clean_bubble, dim3(want / 64), dim3(64), 0, c->st, g, s, (const uint32_t*)P<uint32_t>(b->src), n_src, (uint32_t)param,
 			                   (cl_binfo_t*)b->tabs.p, P<uint32_t>(b->aux), b->cap, ctr);
@@ -161,23 +165,24 @@ static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_
 			else if (mode == CLEAN_INTERNAL) hipLaunchKernelGGL(k_clean_rule<CLEAN_INTERNAL>, dim3(grid), dim3(256), 0, c->st, g, s, param, ctr);
 			else hipLaunchKernelGGL(k_clean_rule<CLEAN_BILOOP>, dim3(grid), dim3(256), 0, c->st, g, s, param, ctr);
 		}
-		hipLaunchKernelGGL(k_clean_diff, dim3(grid_for(R, 256, 1024)), dim3(256), 0, c->st, g.rst, (const uint32_t*)s.rst, (size_t)R, ctr);
-		hipLaunchKernelGGL(k_clean_diff, dim3(grid_for(A, 256, 1024)), dim3(256), 0, c->st, g.ast, (const uint32_t*)s.ast, A, ctr);
+		if (it > 0) hipLaunchKernelGGL(k_clean_diff, dim3(grid_for(W, 256, 1024)), dim3(256), 0, c->st, g.rst, (const uint32_t*)s.rst, W, ctr);
 		CHK(ctr_fetch(c));
 		HIPCHK(hipGetLastError());
 		if (c->h_ctr[CT_OVF]) { // a probe filled its table: bigger tables, same iteration again
 			if (b->cap >= (1u << 20)) { mahip_set_error("asg_pop_bubble: a probe visits more than %u vertices", b->cap); return -1; }
-			b->cap <<= 2; b->threads = 0;
+			b->cap <<= 2; b->threads = 0; tables_ready = false;
+			--it;
 			continue;
 		}
 		cur ^= 1;
 		if (n_iter) *n_iter = it + 1;
-		if (c->h_ctr[CT_TOTDP] == 0) { *cnt = (uint32_t)c->h_ctr[CT_LIVE]; *cnt2 = (uint32_t)c->h_ctr[CT_REMAIN]; break; }
+		// fixpoint: the stamps did not change.  After the first sweep: no action means no stamp (an action may also be a no-op: counted, asg.c:296-302)
+		if (it == 0 ? c->h_ctr[CT_LIVE] == 0 : c->h_ctr[CT_TOTDP] == 0) { *cnt = (uint32_t)c->h_ctr[CT_LIVE]; *cnt2 = (uint32_t)c->h_ctr[CT_REMAIN]; break; }
 	}
 	if (*cnt) {
 		const size_t m = A > R ? A : R;
-		hipLaunchKernelGGL(k_clean_apply, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(b->rst[cur]), R, P<uint8_t>(c->sdel),
-		                   (const uint32_t*)P<uint32_t>(b->ast[cur]), A, P<uint32_t>(c->aol[ag]));
+		const uint32_t *fin = P<uint32_t>(b->st[cur]);
+		hipLaunchKernelGGL(k_clean_apply, dim3(grid_for(m, 256)), dim3(256), 0, c->st, fin, R, P<uint8_t>(c->sdel), fin + Rp, A, P<uint32_t>(c->aol[ag]));
 		CHK(ctr_zero(c));
 		CHK(graph_cleanup(c)); // asg.c:251, 269, 303, 430: asg_cleanup when something was cut
 	}

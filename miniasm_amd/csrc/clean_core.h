@@ -45,12 +45,13 @@ typedef struct {
 	const uint8_t *sdel;               /* per read: seq.del (base flag) */
 	const uint32_t *rst, *ast;         /* stamps of the previous iteration, per read / per arc */
 	uint32_t n_vtx;
+	uint32_t no_stamps;                /* first iteration: there are no stamps yet (rst / ast are not read) */
 } cl_view_t;
 
 typedef struct { uint32_t *rst, *ast; } cl_stamps_t; /* stamps being built by this iteration */
 
-CL_HD int cl_arc_dead(const cl_view_t *g, uint32_t e, uint32_t me) { return (g->aol[e] >> 31) || g->ast[e] < me; }
-CL_HD int cl_seq_dead(const cl_view_t *g, uint32_t r, uint32_t me) { return g->sdel[r] || g->rst[r] < me; }
+CL_HD int cl_arc_dead(const cl_view_t *g, uint32_t e, uint32_t me) { return (g->aol[e] >> 31) || (!g->no_stamps && g->ast[e] < me); }
+CL_HD int cl_seq_dead(const cl_view_t *g, uint32_t r, uint32_t me) { return g->sdel[r] || (!g->no_stamps && g->rst[r] < me); }
 CL_HD uint32_t cl_first(const cl_view_t *g, uint32_t v) { return (uint32_t)(g->idx[v] >> 32); }
 CL_HD uint32_t cl_count(const cl_view_t *g, uint32_t v) { return (uint32_t)g->idx[v]; }
 

@@ -1,0 +1,204 @@
+// comm.hip -- the collectives of the sharded multi-GPU mode, called from C on the context's stream.
+//
+//   RCCL  : one process per GPU, ncclAllGather / ncclAllReduce over xGMI queued on the context's stream (no host sync between a
+//           collective and the kernels around it).  librccl is opened at run time (dlopen): a single-GPU user never loads it, and a
+//           process that already carries a copy (PyTorch ships one) is not handed a second one at link time.
+//   shm   : the same three operations staged through a POSIX shared-memory segment by the host -- a test double for boxes with
+//           ONE GPU (RCCL refuses two ranks on one device): N processes, one context each on the same device, exercise the
+//           orchestration code (host/sharded.c) end to end.  Never the production path.
+#include "mahip_internal.hpp"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+struct RcclApi {
+	void *dl = nullptr;
+	ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+	ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+	const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi g_rccl;
+
+static int rccl_load(void)
+{
+	if (g_rccl.dl) return 0;
+	const char *names[] = { getenv("MA_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+	for (const char *n : names) {
+		if (!n || !*n) continue;
+		g_rccl.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+		if (g_rccl.dl) break;
+	}
+	if (!g_rccl.dl) { mahip_set_error("cannot open librccl (%s); set MA_RCCL_LIB", dlerror()); return -1; }
+#define SYM(field, name) do { *(void**)&g_rccl.field = dlsym(g_rccl.dl, name); if (!g_rccl.field) { mahip_set_error("librccl has no %s", name); g_rccl.dl = nullptr; return -1; } } while (0)
+	SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+	SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+	return 0;
+}
+
+#define NCCLCHK(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { mahip_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, g_rccl.GetErrorString(r_)); return -1; } } while (0)
+
+// ---- shared-memory test double ----
+struct ShmHeader { volatile unsigned arrive, sense; unsigned world; size_t slot; };
+#define SHM_SLOT_BYTES ((size_t)1 << 30) // per rank, sparse: pages exist only where a collective wrote
+
+struct Comm {
+	int kind = 0, rank = 0, world = 1; // kind 1 = RCCL, 2 = shm
+	ncclComm_t nccl = nullptr;
+	ShmHeader *hdr = nullptr;
+	char *slots = nullptr;
+	size_t map_bytes = 0;
+	unsigned my_sense = 0;
+	char name[128] = "";
+};
+
+static void shm_barrier(Comm *m)
+{
+	ShmHeader *h = m->hdr;
+	m->my_sense ^= 1;
+	if (__atomic_add_fetch(&h->arrive, 1, __ATOMIC_ACQ_REL) == (unsigned)m->world) {
+		__atomic_store_n(&h->arrive, 0, __ATOMIC_RELAXED);
+		__atomic_store_n(&h->sense, m->my_sense, __ATOMIC_RELEASE);
+	} else while (__atomic_load_n(&h->sense, __ATOMIC_ACQUIRE) != m->my_sense) sched_yield();
+}
+
+extern "C" int mahip_comm_unique_id(void *id128)
+{
+	CHK(rccl_load());
+	ncclUniqueId id;
+	NCCLCHK(g_rccl.GetUniqueId(&id));
+	memcpy(id128, &id, sizeof(id));
+	return 0;
+}
+
+extern "C" void mahip_comm_destroy(mahip_ctx_t *c)
+{
+	Comm *m = (Comm*)c->comm;
+	if (!m) return;
+	if (m->kind == 1 && m->nccl) (void)g_rccl.CommDestroy(m->nccl);
+	if (m->kind == 2 && m->hdr) { munmap((void*)m->hdr, m->map_bytes); if (m->rank == 0) shm_unlink(m->name); }
+	delete m;
+	c->comm = nullptr;
+}
+
+extern "C" int mahip_comm_init(mahip_ctx_t *c, const void *id128, int rank, int world)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	CHK(rccl_load());
+	mahip_comm_destroy(c);
+	Comm *m = new Comm();
+	m->kind = 1; m->rank = rank; m->world = world;
+	ncclUniqueId id;
+	memcpy(&id, id128, sizeof(id));
+	ncclResult_t r = g_rccl.CommInitRank(&m->nccl, world, id, rank);
+	if (r != ncclSuccess) { mahip_set_error("ncclCommInitRank(rank %d of %d on device %d): %s", rank, world, c->dev, g_rccl.GetErrorString(r)); delete m; return -1; }
+	c->comm = m;
+	return 0;
+}
+
+extern "C" int mahip_comm_init_shm(mahip_ctx_t *c, const char *name, int rank, int world)
+{
+	mahip_comm_destroy(c);
+	Comm *m = new Comm();
+	m->kind = 2; m->rank = rank; m->world = world;
+	snprintf(m->name, sizeof(m->name), "/%s", name);
+	m->map_bytes = 4096 + (size_t)world * SHM_SLOT_BYTES;
+	int fd = -1;
+	for (int tries = 0; tries < 20000 && fd < 0; ++tries) { // rank 0 creates, the others wait for it
+		fd = rank == 0 ? shm_open(m->name, O_CREAT | O_RDWR, 0600) : shm_open(m->name, O_RDWR, 0600);
+		if (fd < 0) usleep(1000);
+	}
+	if (fd < 0) { mahip_set_error("mahip_comm_init_shm: shm_open(%s) failed", m->name); delete m; return -1; }
+	if (rank == 0 && ftruncate(fd, (off_t)m->map_bytes) != 0) { close(fd); mahip_set_error("mahip_comm_init_shm: ftruncate failed"); delete m; return -1; }
+	if (rank != 0) for (int tries = 0; tries < 20000; ++tries) { off_t sz = lseek(fd, 0, SEEK_END); if ((size_t)sz >= m->map_bytes) break; usleep(1000); }
+	void *p = mmap(nullptr, m->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+	close(fd);
+	if (p == MAP_FAILED) { mahip_set_error("mahip_comm_init_shm: mmap failed"); delete m; return -1; }
+	m->hdr = (ShmHeader*)p; m->slots = (char*)p + 4096;
+	if (rank == 0) { m->hdr->arrive = 0; m->hdr->sense = 0; m->hdr->slot = SHM_SLOT_BYTES; __atomic_store_n(&m->hdr->world, (unsigned)world, __ATOMIC_RELEASE); }
+	else while (__atomic_load_n(&m->hdr->world, __ATOMIC_ACQUIRE) != (unsigned)world) sched_yield();
+	c->comm = m;
+	shm_barrier(m);
+	return 0;
+}
+
+extern "C" int mahip_comm_rank(mahip_ctx_t *c) { return c->comm ? ((Comm*)c->comm)->rank : 0; }
+extern "C" int mahip_comm_world(mahip_ctx_t *c) { return c->comm ? ((Comm*)c->comm)->world : 1; }
+
+// every rank contributes `bytes` from d_send; d_recv receives world * bytes, rank-major
+extern "C" int mahip_comm_all_gather(mahip_ctx_t *c, const void *d_send, void *d_recv, size_t bytes)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	Comm *m = (Comm*)c->comm;
+	if (!m || m->world == 1) { if (bytes && d_recv != d_send) HIPCHK(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, c->st)); return 0; }
+	if (bytes == 0) return 0;
+	if (m->kind == 1) { NCCLCHK(g_rccl.AllGather(d_send, d_recv, bytes, ncclUint8, m->nccl, c->st)); return 0; }
+	if (bytes > SHM_SLOT_BYTES) { mahip_set_error("shm all-gather: %zu bytes per rank exceed the slot", bytes); return -1; }
+	HIPCHK(hipMemcpyAsync(m->slots + (size_t)m->rank * SHM_SLOT_BYTES, d_send, bytes, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	shm_barrier(m);
+	for (int r = 0; r < m->world; ++r) HIPCHK(hipMemcpyAsync((char*)d_recv + (size_t)r * bytes, m->slots + (size_t)r * SHM_SLOT_BYTES, bytes, hipMemcpyHostToDevice, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	shm_barrier(m);
+	return 0;
+}
+
+// element-wise maximum of n bytes over the ranks, in place (the OR of 0/1 flag arrays)
+extern "C" int mahip_comm_all_reduce_max_u8(mahip_ctx_t *c, void *d_buf, size_t n)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	Comm *m = (Comm*)c->comm;
+	if (!m || m->world == 1 || n == 0) return 0;
+	if (m->kind == 1) { NCCLCHK(g_rccl.AllReduce(d_buf, d_buf, n, ncclUint8, ncclMax, m->nccl, c->st)); return 0; }
+	if (n > SHM_SLOT_BYTES) { mahip_set_error("shm all-reduce: %zu bytes exceed the slot", n); return -1; }
+	uint8_t *mine = (uint8_t*)(m->slots + (size_t)m->rank * SHM_SLOT_BYTES);
+	HIPCHK(hipMemcpyAsync(mine, d_buf, n, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	shm_barrier(m);
+	uint8_t *acc = (uint8_t*)malloc(n);
+	memcpy(acc, m->slots, n);
+	for (int r = 1; r < m->world; ++r) { const uint8_t *s = (const uint8_t*)(m->slots + (size_t)r * SHM_SLOT_BYTES); for (size_t i = 0; i < n; ++i) acc[i] = s[i] > acc[i] ? s[i] : acc[i]; }
+	shm_barrier(m);
+	HIPCHK(hipMemcpyAsync(d_buf, acc, n, hipMemcpyHostToDevice, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	free(acc);
+	return 0;
+}
+
+// element-wise sum of n u64 counters over the ranks, host values in and out (one device round trip)
+extern "C" int mahip_comm_all_reduce_sum_u64(mahip_ctx_t *c, uint64_t *h_vals, size_t n)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	Comm *m = (Comm*)c->comm;
+	if (!m || m->world == 1 || n == 0) return 0;
+	if (n > 32) { mahip_set_error("mahip_comm_all_reduce_sum_u64: at most 32 counters"); return -1; }
+	if (m->kind == 1) {
+		unsigned long long *d = P<unsigned long long>(c->ctr) + 16; // scratch words of the counter block (not sticky, not in use between passes)
+		HIPCHK(hipMemcpyAsync(d, h_vals, n * 8, hipMemcpyHostToDevice, c->st));
+		NCCLCHK(g_rccl.AllReduce(d, d, n, ncclUint64, ncclSum, m->nccl, c->st));
+		HIPCHK(hipMemcpyAsync(h_vals, d, n * 8, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));
+		return 0;
+	}
+	memcpy(m->slots + (size_t)m->rank * SHM_SLOT_BYTES, h_vals, n * 8);
+	shm_barrier(m);
+	uint64_t acc[32];
+	memset(acc, 0, sizeof(acc));
+	for (int r = 0; r < m->world; ++r) { const uint64_t *s = (const uint64_t*)(m->slots + (size_t)r * SHM_SLOT_BYTES); for (size_t i = 0; i < n; ++i) acc[i] += s[i]; }
+	shm_barrier(m);
+	memcpy(h_vals, acc, n * 8);
+	return 0;
+}
+
+extern "C" int mahip_comm_barrier(mahip_ctx_t *c)
+{
+	uint64_t x = 1;
+	return mahip_comm_all_reduce_sum_u64(c, &x, 1);
+}

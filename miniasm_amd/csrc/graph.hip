@@ -659,6 +659,18 @@ extern "C" int mahip_asg_import_rows(mahip_ctx_t *c, const void *d_src, const ui
 	}
 	c->n_arc = (uint32_t)tot;
 	CHK(arc_reindex(c));
+	memset(&c->tie, 0, sizeof(c->tie));
+	if (c->tie_mode != 0 && tot > 1) { // every rank now holds the whole sorted graph: the tie census of the single-GPU path, reported (the repair
+		// needs the global push order and the global hit order: not available on shards)
+		unsigned long long *ctr = P<unsigned long long>(c->ctr);
+		CHK(dev_reserve(c, c->key[0], (tot + 1) * 8)); CHK(dev_reserve(c, c->val[0], (tot + 1) * 4));
+		hipLaunchKernelGGL(k_arc_keys, dim3(grid_for(tot, 256)), dim3(256), 0, c->st, a, tot, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
+		HIPCHK(hipMemsetAsync(ctr + CT_STICKY, 0, (64 - CT_STICKY) * 8, c->st));
+		hipLaunchKernelGGL(k_arc_tie_census, dim3(grid_for(tot, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[0]), tot, ctr);
+		CHK(ctr_fetch(c));
+		c->tie.arc_tie_groups = c->h_ctr[ST_ARC_TIE_GROUPS]; c->tie.arc_tie_arcs = c->h_ctr[ST_ARC_TIE_ARCS];
+		c->tie.unrepaired = c->tie.arc_tie_groups > 0;
+	}
 	if (c->own_stream) HIPCHK(hipStreamSynchronize(c->st)); // a caller-owned stream orders the exchange itself (sharded mode: the collectives are queued on it)
 	c->graph_ready = true;
 	return 0;

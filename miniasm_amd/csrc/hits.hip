@@ -19,12 +19,14 @@
 
 // ------------------------------------------------------------------------------------------------ sort
 // Sort keys for ma_hit_sort (hit.c:12-22, key = qns = qid<<32 | qs), squeezed to their significant bits:
-//   packed (pk = 1): key = qid << (bs+bi) | qs << bi | input position   (8-byte elements, no value array)
+//   packed (pk = 1): key = qid << (bs+bi) | qs << bi | input position >> drop   (8-byte elements, no value array).  drop > 0 when the
+//                    three fields are a few bits too wide for 64: the low bits of the position are left out and the gather picks the
+//                    record among the 2^drop neighbours of the position (one or two cache lines it reads anyway), see k_hit_gather
 //   pairs  (pk = 0): key = qid << bs | qs, value = input position        (when the three fields exceed 64 bits)
 // keep[i] = hit belongs to this context's read range (sharded mode).
 __global__ __launch_bounds__(256) void k_hit_keys(const ma_hit_t *__restrict__ h, size_t n, uint64_t *__restrict__ key,
                                                    uint32_t *__restrict__ val, uint32_t *__restrict__ keep, unsigned long long *__restrict__ ctr,
-                                                   uint32_t q_beg, uint32_t q_end, int bs, int bi, int pk)
+                                                   uint32_t q_beg, uint32_t q_end, int bs, int bi, int pk, int drop)
 {
 	uint32_t cnt = 0;
 	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(256) void k_hit_keys(const ma_hit_t *__restrict__ h
 		uint32_t q = (uint32_t)(k >> 32), qs = (uint32_t)k;
 		int in = q >= q_beg && q < q_end;
 		cnt += in;
-		if (pk) key[i] = ((uint64_t)q << bs | qs) << bi | i;
+		if (pk) key[i] = ((uint64_t)q << bs | qs) << bi | (i >> drop);
 		else key[i] = (uint64_t)q << bs | qs, val[i] = (uint32_t)i;
 		if (keep) keep[i] = in;
 	}
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void k_hit_keys(const ma_hit_t *__restrict__ h
 
 // The same for the packed layout of an unsharded context, one block per radix tile: the block also counts the first sort
 // digit of its keys, which is exactly the per-tile histogram the first radix pass needs (saves one sweep over the keys).
-__global__ __launch_bounds__(256) void k_hit_keys_tiled(const ma_hit_t *__restrict__ h, size_t n, uint64_t *__restrict__ key, int bs, int bi,
+__global__ __launch_bounds__(256) void k_hit_keys_tiled(const ma_hit_t *__restrict__ h, size_t n, uint64_t *__restrict__ key, int bs, int bi, int drop,
                                                          uint32_t *__restrict__ hist, unsigned nb, unsigned tile, int shift, unsigned mask)
 {
 	__shared__ uint32_t s_cnt[512];
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void k_hit_keys_tiled(const ma_hit_t *__restri
 		const size_t i = base + (size_t)it * 256 + threadIdx.x;
 		if (i < n) {
 			const uint64_t k = h[i].qns;
-			const uint64_t kk = ((uint64_t)(uint32_t)(k >> 32) << bs | (uint32_t)k) << bi | i;
+			const uint64_t kk = ((uint64_t)(uint32_t)(k >> 32) << bs | (uint32_t)k) << bi | (i >> drop);
 			key[i] = kk;
 			atomicAdd(&s_cnt[(unsigned)(kk >> shift) & mask], 1u);
 		}
@@ -88,8 +90,11 @@ struct HitCols { uint32_t *qid, *qs, *qe, *tn, *ts, *te, *ml, *bl; };
 // in the sorted keys (low bi bits) or in perm[]; group offsets from the query-id boundaries of the sorted keys.
 // skey == nullptr: identity (input already grouped: the per-symbol path).
 __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__ h, const uint64_t *__restrict__ skey, const uint32_t *__restrict__ perm,
-                                                     int qshift, int bi, size_t n, uint32_t n_seq, HitCols c, uint32_t *__restrict__ goff, uint32_t *__restrict__ sidx)
+                                                     int qshift, int bi, size_t n, uint32_t n_seq, HitCols c, uint32_t *__restrict__ goff, uint32_t *__restrict__ sidx,
+                                                     int drop, int bs, size_t n_in)
 { // sidx (optional): input position of the record in every sorted slot -- what the tie-order repair needs to find a slot's original key
+  // drop > 0: the key holds (input position >> drop); the record is the r-th one among the 2^drop candidates whose (qid,qs) equals the key's,
+  // r = this slot's rank inside its run of equal keys (the sort is stable and candidates of one run are in input order)
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (i > n) return;
 	uint32_t q = n_seq, qprev = 0;
@@ -97,7 +102,20 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 	if (i < n) {
 		size_t j = i;
 		if (perm) j = perm[i];
-		else if (skey) j = (size_t)(skey[i] & ((1ull << bi) - 1));
+		else if (skey) {
+			const uint64_t K = skey[i];
+			j = (size_t)(K & ((1ull << bi) - 1)) << drop;
+			if (drop) {
+				const uint32_t span = 1u << drop;
+				const uint64_t want = K >> bi;
+				uint32_t r = 0, seen = 0;
+				while (r + 1 < span && i > r && skey[i - 1 - r] == K) ++r;
+				for (uint32_t t = 0; t < span && j + t < n_in; ++t) {
+					const uint64_t x = h[j + t].qns;
+					if ((((x >> 32) << bs) | (uint32_t)x) == want) { if (seen == r) { j += t; break; } ++seen; }
+				}
+			}
+		}
 		const uint4 *p = (const uint4*)(h + j);
 		uint4 a = p[0], b = p[1]; // a = {qs, qid, qe, tn}  b = {ts, te, ml|rev, bl|del}
 		q = a.y;
@@ -785,7 +803,7 @@ int hits_reference_rank(mahip_ctx *c)
 	if (n == 0) { c->hrank_ready = true; return 0; }
 	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (n + 1) * 8)); CHK(dev_reserve(c, c->val[k], (n + 1) * 4)); }
 	hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
-	                   (uint32_t*)nullptr, P<unsigned long long>(c->ctr), 0u, 0xffffffffu, 32, 0, 0); // key = qid<<32 | qs, input order
+	                   (uint32_t*)nullptr, P<unsigned long long>(c->ctr), 0u, 0xffffffffu, 32, 0, 0, 0); // key = qid<<32 | qs, input order
 	CHK(reference_order(c, P<uint64_t>(c->key[0]), n, P<uint32_t>(c->val[1])));
 	hipLaunchKernelGGL(k_perm_invert, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->val[1]), n, P<uint32_t>(c->val[0]));
 	hipLaunchKernelGGL(k_hit_rank, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->sidx), (const uint32_t*)P<uint32_t>(c->val[0]), n, P<uint32_t>(c->hrank));
@@ -820,7 +838,12 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 		bs = bitlen(c->h_ctr[CT_MAXQS]); bq = bitlen(c->h_ctr[CT_MAXQID]);
 	}
 	if (bi == 0) bi = 1;
-	const int pk = bq + bs + bi <= 64;
+	int drop = bq + bs + bi - 64; // bits the packed key is too wide by
+	if (drop < 0) drop = 0;
+	const int pk = drop <= 3 && bi > drop;
+	if (!pk) drop = 0;
+	const size_t n_in = n;
+	bi -= drop;
 	const bool sharded = c->q_beg > 0 || (c->n_seq && c->q_end < c->n_seq);
 	int gen = 0;
 	if (sharded) { CHK(dev_reserve(c, c->keep, (n + 16) * 4)); CHK(dev_reserve(c, c->pos, (n + 16) * 4)); }
@@ -833,14 +856,14 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 			const unsigned nb = (unsigned)((n + tile - 1) / tile);
 			CHK(radix_reserve_hist(c, n));
 			ProfScope ps(c, "k_hit_keys", 16.0 * (double)n);
-			hipLaunchKernelGGL(k_hit_keys_tiled, dim3(nb), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), bs, bi, P<uint32_t>(c->hist), nb, tile, sh0, (1u << bt0) - 1);
+			hipLaunchKernelGGL(k_hit_keys_tiled, dim3(nb), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), bs, bi, drop, P<uint32_t>(c->hist), nb, tile, sh0, (1u << bt0) - 1);
 			first_hist = true;
 		}
 	}
 	if (!first_hist) {
 		ProfScope ps(c, "k_hit_keys", (pk ? 16.0 : 20.0) * (double)n); // reads qns (8 B), writes the key (+ index)
 		hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
-		                   sharded ? P<uint32_t>(c->keep) : (uint32_t*)nullptr, ctr, c->q_beg, c->q_end, bs, bi, pk);
+		                   sharded ? P<uint32_t>(c->keep) : (uint32_t*)nullptr, ctr, c->q_beg, c->q_end, bs, bi, pk, drop);
 	}
 	if (sharded) { // this context only keeps the hits whose query read lies in its range
 		CHK(ctr_fetch(c));
@@ -865,7 +888,7 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 		ProfScope ps(c, "k_hit_gather", (pk ? 72.0 : 76.0) * (double)n); // key 8 (+ index 4) + record 32 + columns 32
 		hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)P<uint64_t>(c->key[gen]),
 		                   pk ? (const uint32_t*)nullptr : (const uint32_t*)P<uint32_t>(c->val[gen]), pk ? bi + bs : bs, bi, n, c->n_seq, h, P<uint32_t>(c->goff),
-		                   want_sidx ? P<uint32_t>(c->sidx) : (uint32_t*)nullptr);
+		                   want_sidx ? P<uint32_t>(c->sidx) : (uint32_t*)nullptr, drop, bs, n_in);
 	}
 	HIPCHK(hipGetLastError());
 	c->soa_ready = true;
@@ -878,7 +901,7 @@ extern "C" int mahip_hits_index(mahip_ctx_t *c)
 	size_t n = c->n_hits;
 	HitCols h = cols_of(c);
 	ProfScope ps(c, "k_hit_gather", 64.0 * (double)n);
-	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)nullptr, (const uint32_t*)nullptr, 32, 0, n, c->n_seq, h, P<uint32_t>(c->goff), (uint32_t*)nullptr);
+	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)nullptr, (const uint32_t*)nullptr, 32, 0, n, c->n_seq, h, P<uint32_t>(c->goff), (uint32_t*)nullptr, 0, 0, n);
 	HIPCHK(hipGetLastError());
 	c->soa_ready = true;
 	c->sorted_here = false; c->hrank_ready = false; // the caller's order is final (per-symbol path: already the reference's)

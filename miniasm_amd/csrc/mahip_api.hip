@@ -86,9 +86,10 @@ extern "C" void mahip_destroy(mahip_ctx_t *c)
 	DevBuf *all[] = { &c->aos_own, &c->goff, &c->sub[0], &c->sub[1], &c->r_cont, &c->r_used, &c->r_del, &c->r_live, &c->map, &c->surv,
 		&c->au[0], &c->au[1], &c->av[0], &c->av[1], &c->alen[0], &c->alen[1], &c->aol[0], &c->aol[1], &c->idx, &c->sdel, &c->slen,
 		&c->keep, &c->pos, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->hist, &c->scan_tmp[0], &c->scan_tmp[1], &c->scan_tmp[2],
-		&c->ctr, &c->ovf, &c->big0, &c->big1, &c->marks, &c->sgmask, &c->sidx, &c->hrank, &c->aslot };
+		&c->ctr, &c->ovf, &c->big0, &c->big1, &c->marks, &c->sgmask, &c->sidx, &c->hrank, &c->aslot, &c->xb[0], &c->xb[1] };
 	for (DevBuf *b : all) dev_free(c, *b);
 	for (int k = 0; k < 8; ++k) dev_free(c, c->col[k]);
+	mahip_comm_destroy(c);
 	paf_free(c);
 	clean_free(c);
 	ug_free(c);
@@ -96,6 +97,16 @@ extern "C" void mahip_destroy(mahip_ctx_t *c)
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	if (c->own_stream) (void)hipStreamDestroy(c->st);
 	delete c;
+}
+
+// exchange buffer `slot` (0/1) of at least `bytes` bytes (sharded mode: send / receive side of a collective)
+extern "C" int mahip_xbuf(mahip_ctx_t *c, int slot, size_t bytes, void **d_ptr)
+{
+	if (slot < 0 || slot > 1) { mahip_set_error("mahip_xbuf: bad slot"); return -1; }
+	HIPCHK(hipSetDevice(c->dev));
+	CHK(dev_reserve(c, c->xb[slot], bytes + 256));
+	*d_ptr = c->xb[slot].p;
+	return 0;
 }
 
 extern "C" int mahip_sync(mahip_ctx_t *c)

@@ -69,6 +69,8 @@ struct mahip_ctx {
 	DevBuf slen;              // u32 [n_seq] seq.len
 	bool graph_ready = false;
 	bool gsq = false;         // the graph has been renumbered to the squeezed read ids (mahip_asg_squeeze): it has n_seq_new reads, no map applies
+	void *comm = nullptr;     // communicator of the sharded mode (comm.hip)
+	DevBuf xb[2];             // exchange buffers of the sharded mode
 	void *clean = nullptr;    // scratch of the graph cleaners (clean.hip)
 	void *ug = nullptr;       // unitig arrays (ug.hip)
 

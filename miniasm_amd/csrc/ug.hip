@@ -64,11 +64,35 @@ __global__ __launch_bounds__(256) void k_ug_arc_emit(ug_t a, size_t n, const uin
 
 static int bitlen32(uint32_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
 
+// small graphs: all rounds of one ranking pass in ONE block (a launch per round would cost more than the round); the arrays stay in L2
+#define UG_SMALL_V 65536u
+__global__ __launch_bounds__(1024) void k_ug_rank_small(ug_t a, int rounds, uint32_t *ptr0, uint32_t *ptr1, uint32_t *mn0, uint32_t *mn1, uint32_t *dist0, uint32_t *dist1)
+{
+	const uint32_t V = a.n_vtx;
+	for (uint32_t w = threadIdx.x; w < V; w += 1024) ugk_jump_init(&a, w, ptr0, mn0, dist0);
+	__syncthreads();
+	for (int k = 0; k < rounds; ++k) {
+		const uint32_t *pi = k & 1 ? ptr1 : ptr0, *mi = mn0 ? (k & 1 ? mn1 : mn0) : nullptr, *di = dist0 ? (k & 1 ? dist1 : dist0) : nullptr;
+		uint32_t *po = k & 1 ? ptr0 : ptr1, *mo = mn0 ? (k & 1 ? mn0 : mn1) : nullptr, *dd = dist0 ? (k & 1 ? dist0 : dist1) : nullptr;
+		for (uint32_t w = threadIdx.x; w < V; w += 1024) ugk_jump(w, pi, mi, di, po, mo, dd);
+		__threadfence_block();
+		__syncthreads();
+	}
+}
+
 // ranking of every member along prv: afterwards ptr = chain head (or a cycle vertex), mn = minimum over the stretch skipped, dist = links to the head
 static int ug_rank(mahip_ctx *c, UgBufs *b, const ug_t &a, bool want_mn, bool want_dist, int *gen_out)
 {
 	const uint32_t V = a.n_vtx;
 	int g = 0;
+	if (V <= UG_SMALL_V) {
+		const int rounds = bitlen32(V) + 1;
+		hipLaunchKernelGGL(k_ug_rank_small, dim3(1), dim3(1024), 0, c->st, a, rounds, P<uint32_t>(b->ptr[0]), P<uint32_t>(b->ptr[1]),
+		                   want_mn ? P<uint32_t>(b->mn[0]) : (uint32_t*)nullptr, want_mn ? P<uint32_t>(b->mn[1]) : (uint32_t*)nullptr,
+		                   want_dist ? P<uint32_t>(b->dist[0]) : (uint32_t*)nullptr, want_dist ? P<uint32_t>(b->dist[1]) : (uint32_t*)nullptr);
+		*gen_out = rounds & 1;
+		return 0;
+	}
 	hipLaunchKernelGGL(k_ug_jump_init, dim3(grid_for(V, 256)), dim3(256), 0, c->st, a, P<uint32_t>(b->ptr[0]),
 	                   want_mn ? P<uint32_t>(b->mn[0]) : (uint32_t*)nullptr, want_dist ? P<uint32_t>(b->dist[0]) : (uint32_t*)nullptr);
 	for (int k = bitlen32(V) + 1; k > 0; --k, g ^= 1)

@@ -89,7 +89,12 @@ int main(int argc, char *argv[])
 
 	sys_init();
 	ma_set_reads_file(fn_reads); /* -f: unitig sequences are stitched from this file before the GFA is written */
-	ma_pipeline_run(&opt, argv[optind], outfmt, stage, flags, stdout);
+	{
+		const char *g = getenv("MA_GPUS"); /* N > 1: one process per GPU, read-range shards, RCCL exchanges (host/sharded.c) */
+		const int world = g ? atoi(g) : 1;
+		if (world > 1) ma_pipeline_run_sharded(&opt, argv[optind], outfmt, stage, flags, stdout, world);
+		else ma_pipeline_run(&opt, argv[optind], outfmt, stage, flags, stdout);
+	}
 
 	fprintf(stderr, "[M::%s] Version: %s (%s)\n", __func__, MA_VERSION, MA_BUILD);
 	fprintf(stderr, "[M::%s] CMD:", __func__);

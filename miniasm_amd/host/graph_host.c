@@ -257,7 +257,7 @@ int asg_extend(const asg_t *g, uint32_t v, int max_ext, asg64_v *a)
 	int kind;
 	for (i = 0; i < g->n_arc; ++i) av[i] = g->arc[i].v, alen[i] = (uint32_t)g->arc[i].ul, aol[i] = g->arc[i].ol | (uint32_t)g->arc[i].del << 31, ast[i] = CL_NONE;
 	for (i = 0; i < R; ++i) sdel[i] = g->seq[i].del, rst[i] = CL_NONE;
-	w.av = av; w.alen = alen; w.aol = aol; w.idx = (const unsigned long long*)g->idx; w.sdel = sdel; w.rst = rst; w.ast = ast; w.n_vtx = 2 * R;
+	w.av = av; w.alen = alen; w.aol = aol; w.idx = (const unsigned long long*)g->idx; w.sdel = sdel; w.rst = rst; w.ast = ast; w.n_vtx = 2 * R; w.no_stamps = 1;
 #define EXT_PUSH(x) do { if (a->n == a->m) { a->m = a->m ? a->m << 1 : 2; a->a = (uint64_t*)realloc(a->a, a->m * 8); } a->a[a->n] = (x); ++a->n; } while (0)
 	a->n = 0;
 	EXT_PUSH((uint64_t)v);

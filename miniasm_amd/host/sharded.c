@@ -1,0 +1,210 @@
+/* sharded.c -- the hot path on N GPUs, one process per GPU, orchestrated from C.
+ *
+ * Rank g owns the reads [g*C, (g+1)*C), C = ceil(R/N), and every hit whose QUERY is one of them; all hit passes are local to a
+ * query group except the look-ups of the target's interval / flags and the neighbour look-ups of the reduction, so the
+ * exchange points are few and sit between the same fused kernels the single-GPU pipeline uses:
+ *
+ *   sort | sub #1 | ALL-GATHER sub | cut + flt + sub #2 | ALL-GATHER sub | merge | cut + containment flags
+ *   | MAX-ALL-REDUCE (contained, used) | squeeze map (identical on all ranks) | ma_sg_gen flags | MAX-ALL-REDUCE seq.del
+ *   | local arcs, sorted | ALL-GATHER OF THE ARC BLOCKS (rank order = global (u,len) order) -> every rank holds graph + CSR
+ *   | transitive reduction of the own vertices | ALL-GATHER of the del flags | rank 0: cleanup, symm
+ *
+ * The collectives are RCCL calls queued on the context's stream (csrc/comm.hip); nothing but the few per-pass counters and
+ * the arc-block sizes comes back to the host in between.  The same sequence is kept as an executable specification in
+ * miniasm_amd/sharded.py (driven over gloo with an oracle-backed stand-in in tests/test_dist_gloo.py).
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <sys/wait.h>
+#include "ma_host.h"
+
+#define GPU(call) do { if ((call) != 0) ma_gpu_fail(__func__); } while (0)
+
+static void shard_range(uint32_t n_seq, int world, int rank, uint32_t *per, uint32_t *q0, uint32_t *q1)
+{
+	uint32_t c = world > 0 ? (uint32_t)(((uint64_t)n_seq + world - 1) / world) : n_seq;
+	uint64_t b = (uint64_t)rank * c, e = b + c;
+	*per = c;
+	*q0 = (uint32_t)(b < n_seq ? b : n_seq);
+	*q1 = (uint32_t)(e < n_seq ? e : n_seq);
+}
+
+/* all-gather of the owned slices of one of the read-indexed arrays (element size es): afterwards every rank holds all n_seq entries */
+static void exchange_slices(mahip_ctx_t *c, int which, size_t es, uint32_t n_seq, uint32_t per, uint32_t q0, uint32_t q1, int world)
+{
+	void *loc, *all;
+	if (world == 1) return;
+	GPU(mahip_xbuf(c, 0, (size_t)per * es, &loc));
+	GPU(mahip_xbuf(c, 1, (size_t)per * es * world, &all));
+	GPU(mahip_copy_out(c, which, loc, q0, q1 - q0));
+	GPU(mahip_comm_all_gather(c, loc, all, (size_t)per * es));
+	GPU(mahip_copy_in(c, which, all, 0, n_seq));
+}
+
+/* OR of 0/1 byte flag arrays over the ranks = one max-all-reduce over their concatenation */
+static void exchange_flags(mahip_ctx_t *c, uint32_t n_seq, int world, int n_which, const int *which)
+{
+	char *t;
+	int k;
+	if (world == 1) return;
+	GPU(mahip_xbuf(c, 0, (size_t)n_seq * n_which, (void**)&t));
+	for (k = 0; k < n_which; ++k) GPU(mahip_copy_out(c, which[k], t + (size_t)k * n_seq, 0, n_seq));
+	GPU(mahip_comm_all_reduce_max_u8(c, t, (size_t)n_seq * n_which));
+	for (k = 0; k < n_which; ++k) GPU(mahip_copy_in(c, which[k], t + (size_t)k * n_seq, 0, n_seq));
+}
+
+/* The device passes of one input on this rank's shard, up to the reduced graph.  c holds the unsorted hits of (at least) this
+ * rank's read range and a communicator (mahip_comm_init*).  Afterwards rank 0's context holds the reduced, symmetrised graph. */
+int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq, ma_shard_stats_t *st)
+{
+	const int world = mahip_comm_world(c), rank = mahip_comm_rank(c);
+	uint32_t per, q0, q1, n_loc = 0, n_red = 0, n_seq_new = 0, i;
+	size_t n_rem1 = 0, n_rem2 = 0, n_cut = 0, n_flt = 0, n_hits = 0;
+	float cov = 0;
+	uint64_t cnt[64], sums[4];
+	uint32_t *counts = (uint32_t*)calloc((size_t)world + 1, 4);
+	size_t stride = 1, first = 0, tot = 0;
+	memset(st, 0, sizeof(*st));
+	shard_range(n_seq, world, rank, &per, &q0, &q1);
+	GPU(mahip_set_shard(c, world > 1 ? q0 : 0, world > 1 ? q1 : 0xffffffffu));
+	GPU(mahip_hits_sort(c));
+	GPU(mahip_hits_sub(c, opt->min_dp, opt->min_iden, 0, 0, &n_rem1));
+	exchange_slices(c, MAHIP_BUF_SUB0, 8, n_seq, per, q0, q1, world);
+	GPU(mahip_hits_cutflt_sub(c, 0, opt->min_span, (int)(opt->max_hang * 1.5), (int)(opt->min_ovlp * .5), opt->min_dp, opt->min_iden, opt->min_span / 2,
+	                          1, &n_cut, &n_flt, &cov, &n_rem2)); /* hit.c:162-216 + the second ma_hit_sub: needs the complete first-pass intervals */
+	exchange_slices(c, MAHIP_BUF_SUB1, 8, n_seq, per, q0, q1, world);
+	GPU(mahip_sub_merge(c)); /* on the complete arrays: identical on every rank */
+	GPU(mahip_hits_cut_contained_flags(c, 1, opt->min_span, opt));
+	{ const int w[2] = { MAHIP_BUF_RCONT, MAHIP_BUF_RUSED }; exchange_flags(c, n_seq, world, 2, w); }
+	GPU(mahip_hits_cut_contained_finish(c, &n_cut, &n_seq_new));
+	GPU(mahip_sg_flags(c, opt, 1, 0, 0));
+	{ const int w[1] = { MAHIP_BUF_SDEL }; exchange_flags(c, n_seq, world, 1, w); }
+	GPU(mahip_sg_finish(c, &n_loc));
+	n_hits = mahip_hits_live(c);
+	/* the arc all-gather: block sizes first (one counter per rank), then the blocks padded to the largest */
+	memset(cnt, 0, sizeof(cnt));
+	if (world > 32) { fprintf(stderr, "[E::%s] at most 32 ranks\n", __func__); exit(1); }
+	cnt[rank] = n_loc;
+	GPU(mahip_comm_all_reduce_sum_u64(c, cnt, (size_t)world));
+	for (i = 0; i < (uint32_t)world; ++i) { counts[i] = (uint32_t)cnt[i]; if (cnt[i] > stride) stride = cnt[i]; if ((int)i < rank) first += cnt[i]; tot += cnt[i]; }
+	if (world > 1) {
+		void *rows, *all;
+		GPU(mahip_xbuf(c, 0, stride * 16, &rows));
+		GPU(mahip_xbuf(c, 1, stride * 16 * world, &all));
+		GPU(mahip_asg_export_rows(c, rows));
+		GPU(mahip_comm_all_gather(c, rows, all, stride * 16));
+		GPU(mahip_asg_import_rows(c, all, counts, world, stride));
+	}
+	{ mahip_tie_info_t ti; mahip_tie_stats(c, &ti); st->tie_groups = ti.arc_tie_groups; }
+	GPU(mahip_asg_del_trans_range(c, opt->gap_fuzz, 2 * q0, world > 1 ? 2 * q1 : 2 * n_seq, &n_red));
+	if (world > 1) { /* the del flags of the own block -> everyone (only rank 0 needs them; kept symmetric) */
+		char *fl, *all;
+		size_t off = 0;
+		GPU(mahip_xbuf(c, 0, stride * 4, (void**)&fl));
+		GPU(mahip_xbuf(c, 1, stride * 4 * world, (void**)&all));
+		GPU(mahip_asg_flags_out(c, fl, first, n_loc));
+		GPU(mahip_comm_all_gather(c, fl, all, stride * 4));
+		for (i = 0; i < (uint32_t)world; ++i) {
+			if ((int)i != rank && counts[i]) GPU(mahip_asg_flags_in(c, all + (size_t)i * stride * 4, off, counts[i]));
+			off += counts[i];
+		}
+	}
+	sums[0] = n_rem1; sums[1] = n_rem2; sums[2] = n_hits; sums[3] = n_red;
+	GPU(mahip_comm_all_reduce_sum_u64(c, sums, 4)); /* the per-pass counters: one reduction at the end */
+	st->n_rem1 = sums[0]; st->n_rem2 = sums[1]; st->n_hits = sums[2]; st->n_red = (uint32_t)sums[3];
+	st->n_seq_new = n_seq_new; st->n_arc = (uint32_t)tot; st->n_loc_arc = n_loc;
+	if (rank == 0 && st->n_red) {
+		uint32_t n_arc = 0;
+		GPU(mahip_asg_cleanup(c, &n_arc));
+		GPU(mahip_asg_symm(c, &st->n_multi, &st->n_asymm));
+	}
+	free(counts);
+	return 0;
+}
+
+/* ---- the command line on N GPUs: MA_GPUS=N miniasm in.paf > out.gfa ------------------------------------------------------
+ * The parent is rank 0; it forks N-1 children BEFORE any HIP call and hands them the RCCL id through pipes.  Every rank loads
+ * and parses the whole text on its own GPU (its own PCIe link; the device parser makes this cheaper than routing records:
+ * DESIGN section 6) and keeps the hits of its read range; rank 0 cleans the graph and writes the output, the others leave
+ * after the last collective.  MA_COMM=shm selects the host-staged test double (all ranks on MA_GPU_DEVICE / device 0). */
+int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *outfmt, int stage, int flags, FILE *out, int world)
+{
+	const char *kind = getenv("MA_COMM");
+	const int use_shm = kind && strcmp(kind, "shm") == 0;
+	int rank = 0, r, (*pipes)[2] = (int(*)[2])calloc((size_t)world, sizeof(int[2]));
+	pid_t *kids = (pid_t*)calloc((size_t)world, sizeof(pid_t));
+	char id[128], shm_name[64];
+	mahip_ctx_t *c;
+	sdict_t *d = sd_init();
+	size_t n_hits = 0;
+	ma_shard_stats_t st;
+	uint32_t pst[4];
+	FILE *lg;
+	memset(id, 0, sizeof(id));
+	snprintf(shm_name, sizeof(shm_name), "miniasm_amd_%d", (int)getpid());
+	if (flags & 8) { fprintf(stderr, "[E::%s] -R is not available with MA_GPUS > 1\n", __func__); exit(1); }
+	fflush(stdout); fflush(stderr);
+	for (r = 1; r < world; ++r) {
+		if (pipe(pipes[r]) != 0) { perror("pipe"); exit(1); }
+		kids[r] = fork();
+		if (kids[r] < 0) { perror("fork"); exit(1); }
+		if (kids[r] == 0) { rank = r; close(pipes[r][1]); break; }
+		close(pipes[r][0]);
+	}
+	if (rank == 0) {
+		if (!use_shm) GPU(mahip_comm_unique_id(id));
+		for (r = 1; r < world; ++r) { if (write(pipes[r][1], id, sizeof(id)) != (ssize_t)sizeof(id)) { perror("write"); exit(1); } close(pipes[r][1]); }
+	} else {
+		if (read(pipes[rank][0], id, sizeof(id)) != (ssize_t)sizeof(id)) { fprintf(stderr, "[E::%s] rank %d: no id from rank 0\n", __func__, rank); _exit(1); }
+		close(pipes[rank][0]);
+		ma_set_log_path("/dev/null"); /* one copy of the log lines: rank 0's */
+	}
+	{
+		char dev[16];
+		const char *base = getenv("MA_GPU_DEVICE");
+		snprintf(dev, sizeof(dev), "%d", use_shm ? (base ? atoi(base) : 0) : (base ? atoi(base) : 0) + rank);
+		setenv("MA_GPU_DEVICE", dev, 1);
+	}
+	c = ma_gpu();
+	if (use_shm) GPU(mahip_comm_init_shm(c, shm_name, rank, world));
+	else GPU(mahip_comm_init(c, id, rank, world));
+	lg = MA_LOG;
+	fprintf(lg, "[M::%s] ===> Step 1: reading read mappings <===\n", "main");
+	r = ma_hit_ingest_gpu(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4));
+	if (r == -1) { fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn); exit(1); }
+	if (r != 0) { fprintf(stderr, "[E::%s] the text does not fit the device stage; MA_GPUS > 1 needs the device parser\n", __func__); exit(1); }
+	ma_pipeline_head_sharded(c, opt, d->n_seq, &st);
+	if (rank == 0) {
+		fprintf(lg, "[M::%s] ===> Step 2: 1-pass (crude) read selection <===\n", "main");
+		if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)st.n_rem1);
+		fprintf(lg, "[M::%s] ===> Step 3: 2-pass (fine) read selection <===\n", "main");
+		if (ma_verbose >= 3) {
+			fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)st.n_rem2);
+			fprintf(lg, "[M::%s::%s] %d sequences and %ld hits remain after containment removal\n", "ma_hit_contained", sys_timestamp(), st.n_seq_new, (long)st.n_hits);
+		}
+		fprintf(lg, "[M::%s] ===> Step 4: graph cleaning <===\n", "main");
+		fprintf(lg, "[M::%s] read %d arcs\n", "ma_sg_gen", st.n_arc);
+		if (st.tie_groups && world > 1)
+			fprintf(stderr, "[W::%s] %llu groups of arcs with equal (u,len) keys: the reference leaves such arcs in an order that depends on the whole input; "
+			        "it is reproduced on one GPU, not on shards -- the output may differ from the reference's inside those groups\n", __func__, (unsigned long long)st.tie_groups);
+		fprintf(lg, "[M::%s] ===> Step 4.1: transitive reduction <===\n", "main");
+		fprintf(lg, "[M::%s] transitively reduced %d arcs\n", "asg_arc_del_trans", st.n_red);
+		if (st.n_red) {
+			fprintf(lg, "[M::%s] removed %d multi-arcs\n", "asg_arc_del_multi", st.n_multi);
+			fprintf(lg, "[M::%s] removed %d asymmetric arcs\n", "asg_arc_del_asymm", st.n_asymm);
+		}
+		pst[0] = 1; pst[1] = 1; pst[2] = st.n_red; pst[3] = 1;
+		if (strcmp(outfmt, "ug") != 0 && strcmp(outfmt, "sg") != 0) { fprintf(stderr, "[E::%s] MA_GPUS > 1 produces -p ug or -p sg\n", __func__); exit(1); }
+		ma_pipeline_tail(c, opt, d, outfmt, stage, pst, out);
+	}
+	GPU(mahip_comm_barrier(c));
+	mahip_comm_destroy(c);
+	sd_destroy(d);
+	if (rank != 0) exit(0); /* orderly: the context's atexit teardown runs */
+	for (r = 1; r < world; ++r) { int status = 0; waitpid(kids[r], &status, 0); if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) fprintf(stderr, "[W::%s] rank %d ended abnormally\n", __func__, r); }
+	free(pipes); free(kids);
+	return 0;
+}

@@ -37,7 +37,7 @@ extern "C" int clh_sweep(int mode, int param, uint32_t n_seq, uint32_t n_arc, ar
 	std::vector<uint32_t> rst[2], ast[2];
 	for (int k = 0; k < 2; ++k) rst[k].assign(n_seq + 1, CL_NONE), ast[k].assign(n_arc + 1, CL_NONE);
 	cl_view_t g;
-	g.av = G.av.data(); g.alen = G.alen.data(); g.aol = G.aol.data(); g.idx = G.idx.data(); g.sdel = G.sdel.data(); g.n_vtx = V;
+	g.av = G.av.data(); g.alen = G.alen.data(); g.aol = G.aol.data(); g.idx = G.idx.data(); g.sdel = G.sdel.data(); g.n_vtx = V; g.no_stamps = 0;
 	uint32_t cap = bubble_cap ? bubble_cap : 64;
 	int cur = 0;
 	*cnt = *cnt2 = 0; *iters = 0;
@@ -45,7 +45,7 @@ extern "C" int clh_sweep(int mode, int param, uint32_t n_seq, uint32_t n_arc, ar
 		std::fill(rst[cur ^ 1].begin(), rst[cur ^ 1].end(), CL_NONE);
 		std::fill(ast[cur ^ 1].begin(), ast[cur ^ 1].end(), CL_NONE);
 		cl_stamps_t s; s.rst = rst[cur ^ 1].data(); s.ast = ast[cur ^ 1].data();
-		g.rst = rst[cur].data(); g.ast = ast[cur].data();
+		g.rst = rst[cur].data(); g.ast = ast[cur].data(); g.no_stamps = it == 0; // as the device does: the first sweep does not read stamps
 		uint32_t acts = 0, tips = 0, ovf = 0;
 		if (mode == 3) {
 			std::vector<cl_binfo_t> tab(cap);

@@ -86,6 +86,44 @@ def test_sort_random_keys_and_ties(gpu_ctx):
             assert got.tobytes() == exp.tobytes(), "reference tie order differs for n=%d" % n
 
 
+def test_sort_with_keys_wider_than_64_bits(gpu_ctx):
+    """query id, query start and input position together need 65..67 bits: the packed key drops the low position bits and the gather
+    picks the record among the 2^drop neighbours (rank inside the run of equal keys); beyond that the (key, value) pair sort takes over"""
+    rng = np.random.default_rng(10)
+    LR = R.ref() if R.have_ref() else None
+    for n, qvals, svals in ((100000, [0, 5, (1 << 24) - 1], [0, 7, (1 << 24) - 1]),            # 17 + 24 + 24 = 65 bits, three distinct values each: huge tie runs
+                            (300001, None, None),                                              # 19 + 24 + 23 = 66 bits, random keys
+                            (300001, [1, (1 << 24) - 2], [3, (1 << 23) + 1]),                  # 66 bits, tie runs of ~75000
+                            (70000, [0, (1 << 26) - 1], None)):                                # 17 + 26 + 24 = 67 bits
+        h = np.zeros(n, dtype=ma.HIT_DT)
+        q = rng.choice(np.array(qvals, dtype=np.uint64), n) if qvals else rng.integers(0, 1 << 24, n).astype(np.uint64)
+        s = rng.choice(np.array(svals, dtype=np.uint64), n) if svals else rng.integers(0, 1 << (24 if n == 70000 else 23), n).astype(np.uint64)
+        if not svals:
+            s[0] = (1 << (24 if n == 70000 else 23)) - 1
+        if not qvals:
+            q[0] = (1 << 24) - 1
+        h["qns"] = (q << np.uint64(32)) | s
+        h["qe"] = np.arange(n)
+        h["tn"] = rng.integers(0, 1000, n)
+        nq = int(q.max()) + 1
+        for mode in (0, 2):
+            gpu_ctx.set_exact_ties(mode)
+            gpu_ctx.hits_upload(h, nq)
+            gpu_ctx.sort()
+            got = gpu_ctx.hits_download()
+            exp = h.copy()
+            if mode == 0:
+                R.orc().orc_hit_sort(n, exp.ctypes.data)
+            elif LR is not None:
+                LR.radix_sort_hit.argtypes = [C.c_void_p, C.c_void_p]
+                LR.radix_sort_hit.restype = None
+                LR.radix_sort_hit(exp.ctypes.data, exp.ctypes.data + n * 32)
+            else:
+                continue
+            assert got.tobytes() == exp.tobytes(), "wide-key sort differs (n=%d, tie mode %d)" % (n, mode)
+    gpu_ctx.set_exact_ties(2)
+
+
 def test_empty_and_degenerate_inputs(gpu_ctx):
     opt = ma.default_opt()
     # no hits at all

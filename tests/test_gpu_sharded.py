@@ -119,3 +119,60 @@ def test_virtual_ranks_match_single_gpu_and_oracle(world, case, tmpdir_s):
     ctx.close()
     ma.lib().ma_set_log_path(b"")
     ing.close()
+
+
+# ---- the product path: orchestration in C (host/sharded.c), collectives from C (csrc/comm.hip) ----
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", ["lognormal", "noisy", "fixed"])
+def test_cli_on_n_ranks_matches_one_gpu_and_reference(world, case, tmpdir_s):
+    """MA_GPUS=N miniasm: one process per rank, read-range shards, the C orchestration end to end.  This box has one GPU, where RCCL
+    refuses several ranks, so the collectives run through the host-staged shared-memory double (MA_COMM=shm); everything else --
+    shard bookkeeping, exchange points, buffer layout, rank-0 tail -- is the production code."""
+    import subprocess
+    extra = {"lognormal": [], "noisy": ["-L", "uniform", "-d", "0.35", "-x", "0.03"], "fixed": ["-L", "fixed"]}[case]
+    paf = R.pafgen(os.path.join(tmpdir_s, "shc_%s.paf" % case), 3001, 80000, 81, extra)
+    one, _ = R.run_cli(ma.CLI_PATH, [], paf)
+    env = dict(os.environ, MA_GPUS=str(world), MA_COMM="shm")
+    r = subprocess.run([ma.CLI_PATH, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout == one, "N-rank GFA differs from the single-GPU GFA"
+    ref_sg, _ = R.run_cli(R.REF_BIN, ["-p", "sg", "-S5"], paf)
+    if R.arc_tie_groups(ref_sg) == 0:
+        ref, _ = R.run_cli(R.REF_BIN, [], paf)
+        assert r.stdout == ref
+    r = subprocess.run([ma.CLI_PATH, "-p", "sg", paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert r.returncode == 0 and r.stdout == R.run_cli(ma.CLI_PATH, ["-p", "sg"], paf)[0]
+
+
+@pytest.mark.skipif(ma.lib().mahip_device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_cli_on_two_gpus_over_rccl(tmpdir_s):
+    import subprocess
+    paf = R.pafgen(os.path.join(tmpdir_s, "shc_rccl.paf"), 6000, 200000, 83, ["-L", "uniform", "-d", "0.3", "-x", "0.03"])
+    one, _ = R.run_cli(ma.CLI_PATH, [], paf)
+    env = dict(os.environ, MA_GPUS="2")
+    env.pop("MA_COMM", None)
+    r = subprocess.run([ma.CLI_PATH, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout == one
+
+
+def test_rccl_loads_and_initialises_a_one_rank_communicator():
+    """librccl is opened at run time (dlopen); a one-rank communicator comes up on this GPU and the collectives degenerate to copies"""
+    L = ma.lib()
+    L.mahip_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    L.mahip_comm_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mahip_comm_destroy.argtypes = [C.c_void_p]
+    L.mahip_comm_world.argtypes = [C.c_void_p]
+    ctx = ma.Ctx(0)
+    idb = C.create_string_buffer(128)
+    ma._chk(L.mahip_comm_unique_id(idb), "comm_unique_id")
+    ma._chk(L.mahip_comm_init(ctx.h, idb.raw, 0, 1), "comm_init")
+    assert L.mahip_comm_world(ctx.h) == 1
+    a = torch.arange(1000, dtype=torch.uint8, device="cuda")
+    b = torch.zeros(1000, dtype=torch.uint8, device="cuda")
+    ma._chk(L.mahip_comm_all_gather(ctx.h, a.data_ptr(), b.data_ptr(), 1000), "all_gather")
+    ma._chk(L.mahip_sync(ctx.h), "sync")
+    assert torch.equal(a, b)
+    L.mahip_comm_destroy(ctx.h)
+    ctx.close()
