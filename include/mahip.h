@@ -37,8 +37,7 @@ int mahip_set_shard(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end);
 /* ---- PAF text ingest on the device (replaces paf.c:34-67 paf_parse/paf_read + sdict.c:27-45 sd_put + hit.c:70-101, the part of
  * ma_hit_read before the sort).  Load the whole (decompressed) text, parse: afterwards the context holds the unsorted hit
  * records exactly as the reference has them before ma_hit_sort (as after mahip_hits_upload) and the read-name dictionary
- * with the reference's ids (dense, in order of first appearance, first length wins).  No `excl` dictionary (-R) here:
- * that option keeps the host reader. */
+ * with the reference's ids (dense, in order of first appearance, first length wins). */
 typedef struct {
 	uint64_t n_lines;         /* text lines */
 	uint64_t n_records;       /* lines with >= 10 columns = what the reference logs as "read %ld hits" (hit.c:102) */
@@ -46,10 +45,14 @@ typedef struct {
 	uint64_t n_hits;          /* records stored (mirrored hits included) */
 	uint64_t name_bytes;      /* bytes mahip_paf_names() writes (names NUL-terminated, back to back, in id order) */
 	uint32_t n_seq, max_qs;   /* reads in the dictionary; upper bound of the stored query starts */
+	uint32_t n_excl;          /* -R: reads excluded as clearly contained (what the reference logs as "dropped %d contained reads", hit.c:66) */
 } mahip_paf_info_t;
 int mahip_paf_load_mem(mahip_ctx_t *c, const void *text, size_t nbytes);   /* text in host memory */
 int mahip_paf_load_fd(mahip_ctx_t *c, int fd, size_t nbytes);              /* bytes [0,nbytes) of an open plain file, read straight into pinned staging */
 int mahip_paf_parse(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, mahip_paf_info_t *info);
+/* the same with the -R pre-filter folded in (hit.c:38-68 ma_hit_no_cont + the exclusion test of hit.c:86): names of reads that some line shows
+ * to be clearly contained are excluded before ids are given out; lines touching them are dropped */
+int mahip_paf_parse_excl(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, int no_cont, int max_hang, float int_frac, mahip_paf_info_t *info);
 int mahip_paf_names(mahip_ctx_t *c, char *names, uint32_t *lens);          /* names[name_bytes], lens[n_seq] = first-seen read lengths */
 int mahip_paf_release(mahip_ctx_t *c);                                      /* free the text and the per-line columns */
 uint32_t mahip_paf_max_qs(mahip_ctx_t *c);                                  /* info.max_qs of the last parse (a sort hint for later mahip_hits_adopt calls) */

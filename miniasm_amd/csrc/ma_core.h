@@ -99,4 +99,19 @@ MA_HD int mc_sub_ok(uint32_t qid, uint32_t qs, uint32_t qe, uint32_t tn, int32_t
 	return 0;
 }
 
+/* ma_hit_no_cont's per-line verdict (hit.c:52-64; the -R pre-filter): 0 nothing, 1 the TARGET read is clearly contained, 2 the QUERY
+ * read is.  The columns are the reader's uint32_t fields; l5 / l3 are ints built from uint32 arithmetic as in the reference. */
+MA_HD int mc_no_cont(uint32_t ql, uint32_t qs, uint32_t qe, uint32_t tl, uint32_t ts, uint32_t te, int rev, int max_hang, float int_frac)
+{
+	const int l5 = (int)(rev ? tl - te : ts), l3 = (int)(rev ? ts : tl - te);
+	if (ql >> 1 > tl) {
+		if (l5 > max_hang >> 2 || l3 > max_hang >> 2 || (float)(te - ts) < (float)tl * int_frac) return 0;
+		if ((int)qs - l5 > max_hang << 1 && (int)(ql - qe) - l3 > max_hang << 1) return 1;
+	} else if (ql < tl >> 1) {
+		if (qs > (uint32_t)(max_hang >> 2) || ql - qe > (uint32_t)(max_hang >> 2) || (float)(qe - qs) < (float)ql * int_frac) return 0;
+		if (l5 - (int)qs > max_hang << 1 && l3 - (int)(ql - qe) > max_hang << 1) return 2;
+	}
+	return 0;
+}
+
 #endif

@@ -35,7 +35,7 @@
 struct PafBufs {
 	DevBuf text, lstart, tile;
 	DevBuf flags, num[8], tnoff, qlen, tlen, hq, ht, qslot, tslot;
-	DevBuf tab, tmin, slot_id, blv, scal;
+	DevBuf tab, tmin, slot_id, blv, scal, excl;
 	DevBuf name_off, name_len, name_pos, seq_len, names;
 	size_t nbytes = 0, name_bytes = 0;
 	uint32_t n_seq = 0;
@@ -61,7 +61,7 @@ void paf_free(mahip_ctx *c)
 	PafBufs *b = (PafBufs*)c->paf;
 	if (!b) return;
 	DevBuf *all[] = { &b->text, &b->lstart, &b->tile, &b->flags, &b->tnoff, &b->qlen, &b->tlen, &b->hq, &b->ht, &b->qslot, &b->tslot, &b->tab, &b->tmin,
-		&b->slot_id, &b->blv, &b->scal, &b->name_off, &b->name_len, &b->name_pos, &b->seq_len, &b->names };
+		&b->slot_id, &b->blv, &b->scal, &b->excl, &b->name_off, &b->name_len, &b->name_pos, &b->seq_len, &b->names };
 	for (DevBuf *d : all) dev_free(c, *d);
 	for (int k = 0; k < 8; ++k) dev_free(c, b->num[k]);
 	delete b;
@@ -291,10 +291,42 @@ __global__ __launch_bounds__(256) void k_dict_insert(const unsigned char *__rest
 	blk_add_u64(&ctr[PC_OVERFLOW], fail);
 }
 
-__global__ __launch_bounds__(256) void k_dict_flag(const unsigned long long *__restrict__ tab, uint32_t cap, uint32_t *__restrict__ keep)
+// ---- -R (ma_hit_no_cont, hit.c:38-68) on the parsed columns: reads that are clearly contained are excluded BEFORE ids are given out
+// (hit.c:86), so the exclusion is a property of NAMES: a line's verdict flags the name's table slot, lines that touch a flagged name are
+// dropped, and first appearances are taken over the lines that are left.
+__global__ __launch_bounds__(256) void k_paf_nocont(PafCols o, uint32_t L, int max_hang, float int_frac, uint8_t *__restrict__ excl)
+{
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < L; i += gridDim.x * 256u) {
+		if (!(o.flags[i] & 2)) continue;
+		const int v = mc_no_cont(o.ql[i], o.qs[i], o.qe[i], o.tl[i], o.ts[i], o.te[i], o.flags[i] >> 3 & 1, max_hang, int_frac);
+		if (v == 1) excl[o.tslot[i]] = 1;
+		else if (v == 2) excl[o.qslot[i]] = 1;
+	}
+}
+__global__ __launch_bounds__(256) void k_paf_refilter(PafCols o, uint32_t L, const uint8_t *__restrict__ excl, uint32_t *__restrict__ tmin, unsigned long long *__restrict__ ctr)
+{
+	uint32_t pass = 0;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < L; i += gridDim.x * 256u) {
+		if (!(o.flags[i] & 2)) continue;
+		const uint32_t qs = o.qslot[i], ts = o.tslot[i];
+		if (excl[qs] || excl[ts]) { o.flags[i] &= (uint8_t)~2u; continue; }
+		atomicMin(&tmin[qs], i * 2u); atomicMin(&tmin[ts], i * 2u + 1u);
+		++pass;
+	}
+	blk_add_u64(&ctr[PC_PASS], pass);
+}
+__global__ __launch_bounds__(256) void k_excl_count(const uint8_t *__restrict__ excl, uint32_t cap, unsigned long long *__restrict__ ctr)
+{
+	uint32_t n = 0;
+	for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < cap; s += gridDim.x * 256u) n += excl[s];
+	blk_add_u64(&ctr[PC_VALID], n);
+}
+
+// a name gets an id if some STORED line carries it (with -R a name may sit in the table without such a line)
+__global__ __launch_bounds__(256) void k_dict_flag(const unsigned long long *__restrict__ tab, const uint32_t *__restrict__ tmin, uint32_t cap, uint32_t *__restrict__ keep)
 {
 	uint32_t s = blockIdx.x * 256u + threadIdx.x;
-	if (s < cap) keep[s] = tab[s] != PAF_EMPTY;
+	if (s < cap) keep[s] = tab[s] != PAF_EMPTY && tmin[s] != 0xffffffffu;
 }
 __global__ __launch_bounds__(256) void k_dict_collect(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ tmin, uint32_t cap,
                                                        uint64_t *__restrict__ key, uint32_t *__restrict__ val)
@@ -404,6 +436,11 @@ static int bits_of(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
 
 extern "C" int mahip_paf_parse(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, mahip_paf_info_t *info)
 {
+	return mahip_paf_parse_excl(c, min_span, min_match, bi_dir, 0, 0, 0.f, info);
+}
+
+extern "C" int mahip_paf_parse_excl(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, int no_cont, int max_hang, float int_frac, mahip_paf_info_t *info)
+{
 	HIPCHK(hipSetDevice(c->dev));
 	PafBufs *b = paf_of(c);
 	if (!b->loaded) { mahip_set_error("mahip_paf_parse: no text loaded"); return -1; }
@@ -503,8 +540,20 @@ extern "C" int mahip_paf_parse(mahip_ctx_t *c, int min_span, int min_match, int 
 			if (attempt >= 1 || cap >= 0x80000000u) { mahip_set_error("mahip_paf_parse: name table overflow"); return -1; }
 			cap = pow2_at_least(4 * (uint64_t)n_pass + 65536); // at most 2 names per stored line: load <= 1/2
 		}
+		if (no_cont) { // hit.c:38-68 + hit.c:86
+			CHK(dev_reserve(c, b->excl, (size_t)cap + 16));
+			HIPCHK(hipMemsetAsync(b->excl.p, 0, cap, c->st));
+			hipLaunchKernelGGL(k_paf_nocont, dim3(grid_for(L, 256, 8192)), dim3(256), 0, c->st, o, L, max_hang, int_frac, P<uint8_t>(b->excl));
+			HIPCHK(hipMemsetAsync(b->tmin.p, 0xff, (size_t)cap * 4, c->st));
+			CHK(ctr_zero(c));
+			hipLaunchKernelGGL(k_paf_refilter, dim3(grid_for(L, 256, 8192)), dim3(256), 0, c->st, o, L, (const uint8_t*)P<uint8_t>(b->excl), P<uint32_t>(b->tmin), ctr);
+			hipLaunchKernelGGL(k_excl_count, dim3(grid_for(cap, 256, 2048)), dim3(256), 0, c->st, (const uint8_t*)P<uint8_t>(b->excl), cap, ctr);
+			CHK(ctr_fetch(c));
+			n_pass = (size_t)c->h_ctr[PC_PASS];
+			info->n_excl = (uint32_t)c->h_ctr[PC_VALID];
+		}
 		CHK(dev_reserve(c, c->keep, ((size_t)cap + 16) * 4)); CHK(dev_reserve(c, c->pos, ((size_t)cap + 16) * 4));
-		hipLaunchKernelGGL(k_dict_flag, dim3(grid_for(cap, 256)), dim3(256), 0, c->st, (const unsigned long long*)P<unsigned long long>(b->tab), cap, P<uint32_t>(c->keep));
+		hipLaunchKernelGGL(k_dict_flag, dim3(grid_for(cap, 256)), dim3(256), 0, c->st, (const unsigned long long*)P<unsigned long long>(b->tab), (const uint32_t*)P<uint32_t>(b->tmin), cap, P<uint32_t>(c->keep));
 		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), cap, P<uint32_t>(b->scal)));
 		HIPCHK(hipMemcpyAsync(&R, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(hipStreamSynchronize(c->st));

@@ -48,6 +48,14 @@ __global__ __launch_bounds__(256) void k_ug_link(ug_t a) { uint32_t w = blockIdx
 __global__ __launch_bounds__(256) void k_ug_jump_init(ug_t a, uint32_t *ptr, uint32_t *mn, uint32_t *dist) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_jump_init(&a, w, ptr, mn, dist); }
 __global__ __launch_bounds__(256) void k_ug_jump(uint32_t n_vtx, const uint32_t *ptr, const uint32_t *mn, const uint32_t *dist, uint32_t *ptr2, uint32_t *mn2, uint32_t *dist2)
 { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < n_vtx) ugk_jump(w, ptr, mn, dist, ptr2, mn2, dist2); }
+// does any member sit on a chain without a head (a cycle)?  Cycles are rare: the cut and the second ranking only run when one exists
+__global__ __launch_bounds__(256) void k_ug_cycle_check(ug_t a, const uint32_t *ptr, unsigned long long *ctr)
+{
+	uint32_t w = blockIdx.x * 256 + threadIdx.x;
+	int cyc = 0;
+	if (w < a.n_vtx) { const uint32_t p = a.prv[w]; cyc = p < UG_OUT && a.prv[ptr[w]] != UG_NONE; }
+	if (__ballot(cyc) && (threadIdx.x & 63) == 0) atomicAdd(&ctr[CT_OVF], 1ull);
+}
 __global__ __launch_bounds__(256) void k_ug_heads(ug_t a, uint8_t *is_head) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) is_head[w] = a.prv[w] == UG_NONE; }
 __global__ __launch_bounds__(256) void k_ug_cut(ug_t a, const uint32_t *ptr, const uint32_t *mn, const uint8_t *is_head) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_cut(&a, w, ptr, mn, is_head); }
 __global__ __launch_bounds__(256) void k_ug_chain(ug_t a, const uint32_t *ptr) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_chain(&a, w, ptr); }
@@ -64,35 +72,11 @@ __global__ __launch_bounds__(256) void k_ug_arc_emit(ug_t a, size_t n, const uin
 
 static int bitlen32(uint32_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
 
-// small graphs: all rounds of one ranking pass in ONE block (a launch per round would cost more than the round); the arrays stay in L2
-#define UG_SMALL_V 65536u
-__global__ __launch_bounds__(1024) void k_ug_rank_small(ug_t a, int rounds, uint32_t *ptr0, uint32_t *ptr1, uint32_t *mn0, uint32_t *mn1, uint32_t *dist0, uint32_t *dist1)
-{
-	const uint32_t V = a.n_vtx;
-	for (uint32_t w = threadIdx.x; w < V; w += 1024) ugk_jump_init(&a, w, ptr0, mn0, dist0);
-	__syncthreads();
-	for (int k = 0; k < rounds; ++k) {
-		const uint32_t *pi = k & 1 ? ptr1 : ptr0, *mi = mn0 ? (k & 1 ? mn1 : mn0) : nullptr, *di = dist0 ? (k & 1 ? dist1 : dist0) : nullptr;
-		uint32_t *po = k & 1 ? ptr0 : ptr1, *mo = mn0 ? (k & 1 ? mn0 : mn1) : nullptr, *dd = dist0 ? (k & 1 ? dist0 : dist1) : nullptr;
-		for (uint32_t w = threadIdx.x; w < V; w += 1024) ugk_jump(w, pi, mi, di, po, mo, dd);
-		__threadfence_block();
-		__syncthreads();
-	}
-}
-
 // ranking of every member along prv: afterwards ptr = chain head (or a cycle vertex), mn = minimum over the stretch skipped, dist = links to the head
 static int ug_rank(mahip_ctx *c, UgBufs *b, const ug_t &a, bool want_mn, bool want_dist, int *gen_out)
 {
 	const uint32_t V = a.n_vtx;
 	int g = 0;
-	if (V <= UG_SMALL_V) {
-		const int rounds = bitlen32(V) + 1;
-		hipLaunchKernelGGL(k_ug_rank_small, dim3(1), dim3(1024), 0, c->st, a, rounds, P<uint32_t>(b->ptr[0]), P<uint32_t>(b->ptr[1]),
-		                   want_mn ? P<uint32_t>(b->mn[0]) : (uint32_t*)nullptr, want_mn ? P<uint32_t>(b->mn[1]) : (uint32_t*)nullptr,
-		                   want_dist ? P<uint32_t>(b->dist[0]) : (uint32_t*)nullptr, want_dist ? P<uint32_t>(b->dist[1]) : (uint32_t*)nullptr);
-		*gen_out = rounds & 1;
-		return 0;
-	}
 	hipLaunchKernelGGL(k_ug_jump_init, dim3(grid_for(V, 256)), dim3(256), 0, c->st, a, P<uint32_t>(b->ptr[0]),
 	                   want_mn ? P<uint32_t>(b->mn[0]) : (uint32_t*)nullptr, want_dist ? P<uint32_t>(b->dist[0]) : (uint32_t*)nullptr);
 	for (int k = bitlen32(V) + 1; k > 0; --k, g ^= 1)
@@ -134,10 +118,16 @@ extern "C" int mahip_ug_gen(mahip_ctx_t *c, uint32_t *n_utg, uint32_t *n_members
 	ProfScope ps(c, "ug_gen", 0);
 	hipLaunchKernelGGL(k_ug_link, dim3(gv), dim3(256), 0, c->st, a);
 	int g = 0;
-	CHK(ug_rank(c, b, a, true, false, &g));         // pass 1: find the cycles and their smallest vertices
-	hipLaunchKernelGGL(k_ug_heads, dim3(gv), dim3(256), 0, c->st, a, P<uint8_t>(b->ishead));
-	hipLaunchKernelGGL(k_ug_cut, dim3(gv), dim3(256), 0, c->st, a, (const uint32_t*)P<uint32_t>(b->ptr[g]), (const uint32_t*)P<uint32_t>(b->mn[g]), (const uint8_t*)P<uint8_t>(b->ishead));
-	CHK(ug_rank(c, b, a, false, true, &g));         // pass 2: every member now has a head: head and offset
+	HIPCHK(hipMemsetAsync(b->circ.p, 0, (size_t)V, c->st));
+	CHK(ctr_zero(c));
+	CHK(ug_rank(c, b, a, true, true, &g));          // head, offset and the minimum over each chain in one ranking pass
+	hipLaunchKernelGGL(k_ug_cycle_check, dim3(gv), dim3(256), 0, c->st, a, (const uint32_t*)P<uint32_t>(b->ptr[g]), ctr);
+	CHK(ctr_fetch(c));
+	if (c->h_ctr[CT_OVF]) { // some chain has no head: cut every cycle in front of its smallest vertex, rank again
+		hipLaunchKernelGGL(k_ug_heads, dim3(gv), dim3(256), 0, c->st, a, P<uint8_t>(b->ishead));
+		hipLaunchKernelGGL(k_ug_cut, dim3(gv), dim3(256), 0, c->st, a, (const uint32_t*)P<uint32_t>(b->ptr[g]), (const uint32_t*)P<uint32_t>(b->mn[g]), (const uint8_t*)P<uint8_t>(b->ishead));
+		CHK(ug_rank(c, b, a, false, true, &g));
+	}
 	const uint32_t *ptr = P<uint32_t>(b->ptr[g]), *dist = P<uint32_t>(b->dist[g]);
 	HIPCHK(hipMemsetAsync(b->cm.p, 0xff, (size_t)V * 4, c->st));
 	HIPCHK(hipMemsetAsync(b->tail.p, 0xff, (size_t)V * 4, c->st));

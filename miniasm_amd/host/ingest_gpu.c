@@ -5,7 +5,7 @@
  * gzread) and uploaded.  Lines, columns, numbers, the span/match filter, the name dictionary with the reference's
  * first-appearance ids and the (mirrored) hit records are all produced by csrc/paf.hip; what comes back is the
  * dictionary (names + first-seen lengths, R entries) and, only for the per-symbol ABI, the records.
- * Not used with an exclusion dictionary (-R): that pass and its lookups stay on the host reader.
+ * The -R pre-filter (ma_hit_no_cont, hit.c:38-68) rides in the same parse: the exclusion is a flag per name.
  * MA_HOST_PARSE=1 forces the host reader (ingest_mt.c / paf_reader.c); both are pinned to the same records and ids.
  */
 #include <fcntl.h>
@@ -47,12 +47,22 @@ int ma_gpu_parse_enabled(void)
  * rebuilt in d (which must be empty or a previous result of this function); release = free the text afterwards */
 int ma_hit_ingest_loaded(mahip_ctx_t *c, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir, int release)
 {
+	return ma_hit_ingest_loaded_excl(c, min_span, min_match, d, n_hits, bi_dir, release, 0, 0, 0.f);
+}
+
+/* no_cont: -R, the reference's Step 0 (hit.c:38-68) folded into the same parse; prints its log line first */
+int ma_hit_ingest_loaded_excl(mahip_ctx_t *c, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir, int release, int no_cont, int max_hang, float int_frac)
+{
 	const int timing = getenv("MA_PIPE_TIMING") != 0;
 	double t1 = sys_realtime(), t2, t3;
 	mahip_paf_info_t info;
 	size_t i, tot_len = 0;
 	GPU(mahip_set_shard(c, 0, 0xffffffffu));
-	GPU_SOFT(mahip_paf_parse(c, min_span, min_match, bi_dir, &info));
+	GPU_SOFT(mahip_paf_parse_excl(c, min_span, min_match, bi_dir, no_cont, max_hang, int_frac, &info));
+	if (no_cont) {
+		if (ma_verbose >= 3) fprintf(MA_LOG, "[M::%s::%s] dropped %d contained reads\n", "ma_hit_no_cont", sys_timestamp(), info.n_excl);
+		fprintf(MA_LOG, "[M::%s] ===> Step 1: reading read mappings <===\n", "main");
+	}
 	t2 = sys_realtime();
 	/* the dictionary: names (one block, adopted as the dictionary's arena: no per-name allocation) and first-seen lengths */
 	{
@@ -107,6 +117,11 @@ int ma_paf_load_file(mahip_ctx_t *c, const char *fn)
  * -2 = the device-side stage could not run (memory): nothing was consumed, the caller may use the host reader */
 int ma_hit_ingest_gpu(mahip_ctx_t *c, const char *fn, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir)
 {
+	return ma_hit_ingest_gpu_excl(c, fn, min_span, min_match, d, n_hits, bi_dir, 0, 0, 0.f);
+}
+
+int ma_hit_ingest_gpu_excl(mahip_ctx_t *c, const char *fn, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir, int no_cont, int max_hang, float int_frac)
+{
 	const int timing = getenv("MA_PIPE_TIMING") != 0;
 	double t0 = sys_realtime();
 	{
@@ -114,5 +129,5 @@ int ma_hit_ingest_gpu(mahip_ctx_t *c, const char *fn, int min_span, int min_matc
 		if (rc != 0) return rc; /* -1 cannot open, -2 does not fit */
 	}
 	if (timing) fprintf(stderr, "[T::ingest_gpu] load %.3f s\n", sys_realtime() - t0);
-	return ma_hit_ingest_loaded(c, min_span, min_match, d, n_hits, bi_dir, 1);
+	return ma_hit_ingest_loaded_excl(c, min_span, min_match, d, n_hits, bi_dir, 1, no_cont, max_hang, int_frac);
 }

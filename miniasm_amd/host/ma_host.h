@@ -49,6 +49,8 @@ ma_hit_t *ma_hit_ingest_mt(const char *fn, int min_span, int min_match, sdict_t 
                            size_t *tot_lines, uint32_t *max_qs);
 /* the same on the device (ingest_gpu.c + csrc/paf.hip): records stay in the context; 0 ok, -1 cannot open */
 int ma_hit_ingest_gpu(mahip_ctx_t *c, const char *fn, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir);
+int ma_hit_ingest_gpu_excl(mahip_ctx_t *c, const char *fn, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir, int no_cont, int max_hang, float int_frac);
+int ma_hit_ingest_loaded_excl(mahip_ctx_t *c, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir, int release, int no_cont, int max_hang, float int_frac);
 int ma_paf_load_file(mahip_ctx_t *c, const char *fn); /* plain / gzip / "-": text into HBM */
 int ma_hit_ingest_loaded(mahip_ctx_t *c, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir, int release);
 int ma_gpu_parse_enabled(void); /* 0 when MA_HOST_PARSE=1 */

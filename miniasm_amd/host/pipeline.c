@@ -400,24 +400,26 @@ int ma_pipeline_run(const ma_opt_t *opt, const char *fn, const char *outfmt, int
 	ma_hit_t *hit;
 	size_t n_hits = 0;
 	FILE *lg = MA_LOG;
-	if (flags & 8) {
-		fprintf(lg, "[M::%s] ===> Step 0: removing contained reads <===\n", "main");
-		excl = ma_hit_no_cont(fn, opt->min_span, opt->min_match, opt->max_hang, opt->int_frac);
-	}
-	fprintf(lg, "[M::%s] ===> Step 1: reading read mappings <===\n", "main");
+	const int dev_parse = ma_gpu_parse_enabled() && strcmp(fn, "-") != 0;
 	int on_device = 0;
-	if (excl == 0 && ma_gpu_parse_enabled() && strcmp(fn, "-") != 0) { /* text -> records + dictionary on the device (csrc/paf.hip) */
+	if (flags & 8) fprintf(lg, "[M::%s] ===> Step 0: removing contained reads <===\n", "main");
+	if (dev_parse) { /* text -> records + dictionary on the device (csrc/paf.hip); with -R the pre-filter rides in the same parse */
 		int rc;
 		if (gpu_bg) pthread_join(th_gpu, 0), gpu_bg = 0;
 		c = ma_gpu();
-		rc = ma_hit_ingest_gpu(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4));
+		if (!(flags & 8)) fprintf(lg, "[M::%s] ===> Step 1: reading read mappings <===\n", "main");
+		rc = ma_hit_ingest_gpu_excl(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), (flags & 8) != 0, opt->max_hang, opt->int_frac);
 		if (rc == -1) {
-			fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn);
+			fprintf(stderr, "[E::%s] could not open PAF file %s\n", (flags & 8) ? "ma_hit_no_cont" : "ma_hit_read", fn);
 			exit(1);
 		}
 		on_device = rc == 0; /* -2: does not fit -> host reader below */
 	}
-	if (!on_device) { /* -R, MA_HOST_PARSE=1, stdin (a stream cannot be re-read after a failed device attempt), or a text too big for the device stage */
+	if (!on_device) {
+		if (flags & 8) excl = ma_hit_no_cont(fn, opt->min_span, opt->min_match, opt->max_hang, opt->int_frac);
+		if (!dev_parse || (flags & 8)) fprintf(lg, "[M::%s] ===> Step 1: reading read mappings <===\n", "main");
+	}
+	if (!on_device) { /* MA_HOST_PARSE=1, stdin (a stream cannot be re-read after a failed device attempt), or a text too big for the device stage */
 		const int timing = getenv("MA_PIPE_TIMING") != 0;
 		double t0 = sys_realtime(), t1, t2;
 		hit = ma_hit_ingest(fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), excl);

@@ -145,7 +145,6 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 	FILE *lg;
 	memset(id, 0, sizeof(id));
 	snprintf(shm_name, sizeof(shm_name), "miniasm_amd_%d", (int)getpid());
-	if (flags & 8) { fprintf(stderr, "[E::%s] -R is not available with MA_GPUS > 1\n", __func__); exit(1); }
 	fflush(stdout); fflush(stderr);
 	for (r = 1; r < world; ++r) {
 		if (pipe(pipes[r]) != 0) { perror("pipe"); exit(1); }
@@ -172,8 +171,8 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 	if (use_shm) GPU(mahip_comm_init_shm(c, shm_name, rank, world));
 	else GPU(mahip_comm_init(c, id, rank, world));
 	lg = MA_LOG;
-	fprintf(lg, "[M::%s] ===> Step 1: reading read mappings <===\n", "main");
-	r = ma_hit_ingest_gpu(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4));
+	fprintf(lg, "[M::%s] ===> Step %d: %s <===\n", "main", (flags & 8) ? 0 : 1, (flags & 8) ? "removing contained reads" : "reading read mappings");
+	r = ma_hit_ingest_gpu_excl(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), (flags & 8) != 0, opt->max_hang, opt->int_frac);
 	if (r == -1) { fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn); exit(1); }
 	if (r != 0) { fprintf(stderr, "[E::%s] the text does not fit the device stage; MA_GPUS > 1 needs the device parser\n", __func__); exit(1); }
 	ma_pipeline_head_sharded(c, opt, d->n_seq, &st);

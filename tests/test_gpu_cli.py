@@ -22,7 +22,7 @@ INPUTS = {  # name -> pafgen arguments (all arc-tie-free: checked when the golde
     "noisy": dict(reads=4000, lines=90000, seed=63, extra=["-L", "uniform", "-d", "0.35", "-x", "0.03"]),
 }
 
-EXTRA_ARGS = [["-1"], ["-2", "-p", "sg"], ["-b"], ["-R"], ["-c", "2", "-s", "1500", "-h", "500", "-I", "0.7", "-g", "500", "-e", "3", "-d", "30000"],
+EXTRA_ARGS = [["-1"], ["-2", "-p", "sg"], ["-b"], ["-R"], ["-R", "-p", "paf"], ["-R", "-h", "4000", "-p", "bed"], ["-c", "2", "-s", "1500", "-h", "500", "-I", "0.7", "-g", "500", "-e", "3", "-d", "30000"],
               ["-n", "4", "-r", "0.8,0.4", "-F", "0.9"], ["-o", "1000", "-m", "200", "-i", "0.1"], ["-1", "-2", "-p", "sg"]]
 
 
@@ -52,13 +52,24 @@ def test_cli_and_dropin_match_reference_binary(name, tmpdir_s):
 
 
 @pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
-def test_cli_options_match_reference_binary(tmpdir_s):
+def test_cli_options_match_reference_binary(tmpdir_s, monkeypatch):
     paf = _gen(tmpdir_s, "noisy")
     for args in EXTRA_ARGS:
         ref_out, ref_log = R.run_cli(R.REF_BIN, args, paf)
-        if "-p" in args and "sg" in args and R.arc_tie_groups(ref_out):
-            continue
         _same(ma.CLI_PATH, args, paf, ref_out, ref_log, "cli-opts")
+    # -R (ma_hit_no_cont, hit.c:38-68): through the device parser (default) and through the host reader; on an input where the
+    # pre-filter really drops reads (length spread: short reads clearly inside long ones)
+    paf2 = R.pafgen(os.path.join(tmpdir_s, "cli_R.paf"), 3000, 90000, 64, ["-d", "0.1"])
+    for args in (["-R"], ["-R", "-p", "paf", "-S2"], ["-R", "-p", "bed"]):
+        ref_out, ref_log = R.run_cli(R.REF_BIN, args, paf2)
+        assert "dropped 0 contained reads" not in ref_log, "this input is supposed to trigger the -R pre-filter"
+        for host in (False, True):
+            if host:
+                monkeypatch.setenv("MA_HOST_PARSE", "1")
+            else:
+                monkeypatch.delenv("MA_HOST_PARSE", raising=False)
+            _same(ma.CLI_PATH, args, paf2, ref_out, ref_log, "cli -R (%s parser)" % ("host" if host else "device"))
+        monkeypatch.delenv("MA_HOST_PARSE", raising=False)
 
 
 def test_cli_matches_golden_digests(tmpdir_s):
@@ -203,3 +214,30 @@ def test_cli_degenerate_inputs(tmpdir_s, monkeypatch):
             monkeypatch.delenv("MA_HOST_PARSE", raising=False)
         ref_out, ref_log = R.run_cli(R.REF_BIN, ["-p", "ug"], p)
         _same(R.DROPIN_BIN, ["-p", "ug"], p, ref_out, ref_log, "dropin[%s]" % name)
+
+
+# ---- BASELINE-scale inputs (configs[1]: 10 M overlaps / 200 k reads): lognormal (containment-heavy), fixed-length (20 M arcs: the
+# graph kernels see real work), noisy (tips, bubbles, short overlaps: the device cleaners at scale) -- against the reference binary
+BIG_INPUTS = {
+    "cfg2_lognormal": dict(reads=200000, lines=10000000, seed=1, extra=[]),
+    "cfg2_fixed": dict(reads=200000, lines=10000000, seed=11, extra=["-L", "fixed"]),
+    "cfg2_noisy": dict(reads=400000, lines=10000000, seed=12, extra=["-L", "uniform", "-d", "0.35", "-x", "0.03"]),
+}
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name", list(BIG_INPUTS))
+def test_cli_matches_reference_at_baseline_scale(name, tmpdir_s):
+    import hashlib
+    import subprocess
+    cfg = BIG_INPUTS[name]
+    paf = R.pafgen(os.path.join(tmpdir_s, "big_%s.paf" % name), cfg["reads"], cfg["lines"], cfg["seed"], cfg["extra"])
+    for args in (["-p", "sg", "-S6"], ["-p", "ug"]):
+        digests = []
+        for binary in (R.REF_BIN, ma.CLI_PATH):
+            r = subprocess.run([binary] + args + [paf], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=1200)
+            assert r.returncode == 0
+            digests.append((hashlib.md5(r.stdout).hexdigest(), len(r.stdout)))
+        assert digests[0] == digests[1], "%s %s: bytes differ from the reference (raw md5, no normalisation)" % (name, " ".join(args))
+        assert digests[0][1] > 1000
+    os.remove(paf)

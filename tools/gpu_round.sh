@@ -67,13 +67,13 @@ benchexact)
   tail -3 gpurun_out/bench_exact.log; cat gpurun_out/bench_exact.json ;;
 prof)
   rm -rf gpurun_out/prof; mkdir -p gpurun_out/prof
-  (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof -o r --output-format csv -- python /root/repo/bench.py --steps 5 --warmup 1 --no-cpu --prof-steps 0 > /root/repo/gpurun_out/prof/bench_under_prof.json 2> /root/repo/gpurun_out/prof/bench_under_prof.log); echo "rc=$?"
+  (cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof -o r --output-format csv -- python /root/repo/bench.py --steps 5 --warmup 1 --no-cpu --no-legs --no-text --prof-steps 0 > /root/repo/gpurun_out/prof/bench_under_prof.json 2> /root/repo/gpurun_out/prof/bench_under_prof.log); echo "rc=$?"
   find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" ;;
 pmc)
   # HBM traffic counters, one counter per run (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2: they do not fit one pass)
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc_$ctr; mkdir -p gpurun_out/pmc_$ctr
-    (cd /tmp && timeout 1500 rocprofv3 --pmc $ctr --kernel-trace -d /root/repo/gpurun_out/pmc_$ctr -o r --output-format csv -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu --prof-steps 0 > /root/repo/gpurun_out/pmc_$ctr/bench.json 2> /root/repo/gpurun_out/pmc_$ctr/bench.log); echo "pmc $ctr rc=$?"
+    (cd /tmp && timeout 1500 rocprofv3 --pmc $ctr --kernel-trace -d /root/repo/gpurun_out/pmc_$ctr -o r --output-format csv -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu --no-legs --no-text --prof-steps 0 > /root/repo/gpurun_out/pmc_$ctr/bench.json 2> /root/repo/gpurun_out/pmc_$ctr/bench.log); echo "pmc $ctr rc=$?"
     find gpurun_out/pmc_$ctr -name "*.csv" | head -5
   done
   python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_summary.json 2> gpurun_out/pmc_summary.log; tail -3 gpurun_out/pmc_summary.log; head -c 3000 gpurun_out/pmc_summary.json ;;
