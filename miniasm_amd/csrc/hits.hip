@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_hit_keys(const ma_hit_t *__restrict__ h
 __global__ __launch_bounds__(256) void k_hit_keys_tiled(const ma_hit_t *__restrict__ h, size_t n, uint64_t *__restrict__ key, int bs, int bi, int drop,
                                                          uint32_t *__restrict__ hist, unsigned nb, unsigned tile, int shift, unsigned mask)
 {
-	__shared__ uint32_t s_cnt[512];
+	__shared__ uint32_t s_cnt[1024]; // up to 10-bit digits (radix.hip: RS_MAXBITS)
 	for (unsigned d = threadIdx.x; d <= mask; d += 256) s_cnt[d] = 0;
 	__syncthreads();
 	const size_t base = (size_t)blockIdx.x * tile;
@@ -101,23 +101,36 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 	int first = (i == 0);
 	if (i < n) {
 		size_t j = i;
+		uint4 a, b;
+		bool have = false;
 		if (perm) j = perm[i];
 		else if (skey) {
 			const uint64_t K = skey[i];
 			j = (size_t)(K & ((1ull << bi) - 1)) << drop;
-			if (drop) {
+			if (drop) { // all candidates are fetched at once (they share one or two cache lines): no dependent second round trip
 				const uint32_t span = 1u << drop;
 				const uint64_t want = K >> bi;
-				uint32_t r = 0, seen = 0;
+				uint32_t r = 0, seen = 0, pick = 0;
+				uint4 ca[8];
 				while (r + 1 < span && i > r && skey[i - 1 - r] == K) ++r;
-				for (uint32_t t = 0; t < span && j + t < n_in; ++t) {
-					const uint64_t x = h[j + t].qns;
-					if ((((x >> 32) << bs) | (uint32_t)x) == want) { if (seen == r) { j += t; break; } ++seen; }
-				}
+#pragma unroll
+				for (uint32_t t = 0; t < 8; ++t) if (t < span && j + t < n_in) ca[t] = ((const uint4*)(h + j + t))[0];
+				uint4 cb0 = ((const uint4*)(h + j))[1], cb1 = span > 1 && j + 1 < n_in ? ((const uint4*)(h + j + 1))[1] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+				for (uint32_t t = 0; t < 8; ++t)
+					if (t < span && j + t < n_in) {
+						const uint64_t kk = ((uint64_t)ca[t].y << bs) | ca[t].x; // a = {qs, qid, qe, tn}
+						if (kk == want) { if (seen == r) pick = t; ++seen; }
+					}
+				a = ca[0];
+#pragma unroll
+				for (uint32_t t = 1; t < 8; ++t) if (t == pick) a = ca[t];
+				b = pick == 0 ? cb0 : pick == 1 ? cb1 : ((const uint4*)(h + j + pick))[1];
+				j += pick;
+				have = true;
 			}
 		}
-		const uint4 *p = (const uint4*)(h + j);
-		uint4 a = p[0], b = p[1]; // a = {qs, qid, qe, tn}  b = {ts, te, ml|rev, bl|del}
+		if (!have) { const uint4 *p = (const uint4*)(h + j); a = p[0]; b = p[1]; } // a = {qs, qid, qe, tn}  b = {ts, te, ml|rev, bl|del}
 		q = a.y;
 		if (sidx) sidx[i] = (uint32_t)j;
 		c.qid[i] = a.y; c.qs[i] = a.x; c.qe[i] = a.z; c.tn[i] = a.w;
@@ -852,7 +865,7 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	if (pk && !sharded) { // keys + the first pass's per-tile histogram in one sweep
 		int sh0, bt0; unsigned tile;
 		radix_first_digit(bi, bi + bs + bq, &sh0, &bt0, &tile);
-		if (bt0 > 0 && bt0 <= 9) {
+		if (bt0 > 0 && bt0 <= 10) {
 			const unsigned nb = (unsigned)((n + tile - 1) / tile);
 			CHK(radix_reserve_hist(c, n));
 			ProfScope ps(c, "k_hit_keys", 16.0 * (double)n);

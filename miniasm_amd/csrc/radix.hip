@@ -6,7 +6,7 @@
 //
 // Design for MI355X (HBM-bound):
 //   * only the significant key bits are sorted, in digits of up to 9 bits chosen to minimise the pass count
-//     (hits: 17 bits of start + 18 bits of read id = 4 passes instead of 8 byte-passes over 64 bits);
+//     (hits: 16 bits of start + 18..21 bits of read id = 4 passes of <= 10 bits instead of 8 byte-passes over 64 bits);
 //   * when the record index fits below the key bits the index rides in the low bits of the key itself
 //     (8-byte elements, no value array): a pass reads 8 B twice and writes 8 B per record;
 //   * per pass: k_radix_hist (per-tile digit counts, digit-major) -> exclusive scan -> k_radix_scatter;
@@ -18,7 +18,7 @@
 #define RS_ITEMS 16
 #define RS_TILE (RS_THREADS * RS_ITEMS)
 #define RS_WAVES (RS_THREADS / 64)
-#define RS_MAXBITS 9
+#define RS_MAXBITS 10
 #define RS_BINS (1 << RS_MAXBITS)
 
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint64_t *__restrict__ key, uint32_t *__restrict__ hist,
@@ -90,14 +90,23 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
 		r[it] = prev + (uint32_t)__popcll(peers & lt);
 	}
 	__syncthreads();
-	{ // thread t owns digits 2t, 2t+1: waves' counts -> exclusive over waves; tile counts -> exclusive over digits
-		unsigned d0 = 2 * threadIdx.x, d1 = d0 + 1;
-		uint32_t c0 = 0, c1 = 0, w0[RS_WAVES], w1[RS_WAVES];
-		for (int w = 0; w < RS_WAVES; ++w) { w0[w] = c0; c0 += s_cnt[w][d0]; w1[w] = c1; c1 += s_cnt[w][d1]; }
-		uint32_t tot, ex = block_excl_scan_256(c0 + c1, s_scan, &tot);
-		for (int w = 0; w < RS_WAVES; ++w) { s_cnt[w][d0] = ex + w0[w]; s_cnt[w][d1] = ex + c0 + w1[w]; }
-		if (d0 <= mask) s_gb[d0] = gofs[(size_t)d0 * nb + blockIdx.x] - ex;
-		if (d1 <= mask) s_gb[d1] = gofs[(size_t)d1 * nb + blockIdx.x] - (ex + c0);
+	{ // thread t owns RS_DPT consecutive digits: waves' counts -> exclusive over waves; tile counts -> exclusive over digits
+		constexpr int RS_DPT = RS_BINS / RS_THREADS;
+		const unsigned d0 = RS_DPT * threadIdx.x;
+		uint32_t cd[RS_DPT], wo[RS_DPT][RS_WAVES], sum = 0;
+#pragma unroll
+		for (int k = 0; k < RS_DPT; ++k) {
+			uint32_t cc = 0;
+			for (int w = 0; w < RS_WAVES; ++w) { wo[k][w] = cc; cc += s_cnt[w][d0 + k]; }
+			cd[k] = cc; sum += cc;
+		}
+		uint32_t tot, ex = block_excl_scan_256(sum, s_scan, &tot);
+#pragma unroll
+		for (int k = 0; k < RS_DPT; ++k) {
+			for (int w = 0; w < RS_WAVES; ++w) s_cnt[w][d0 + k] = ex + wo[k][w];
+			if (d0 + k <= mask) s_gb[d0 + k] = gofs[(size_t)(d0 + k) * nb + blockIdx.x] - ex;
+			ex += cd[k];
+		}
 	}
 	__syncthreads();
 #pragma unroll

@@ -12,7 +12,8 @@
 //                 lies in  ->  per chain the minimum over such vertices; the chain whose minimum beats its twin's is emitted
 //   numbering   : unitigs are numbered in order of that discovery vertex -> one exclusive scan over the vertex set
 //   members     : a segmented gather (head offset + rank) writes `vertex << 32 | length to the next read`, the last read of a
-//                 linear unitig contributes its whole length (asm.c:151-153); lengths are summed with integer atomics
+//                 linear unitig contributes its whole length (asm.c:151-153); the ranking pass carries the running length along,
+//                 so a unitig's length is read off its last vertex (no atomics, however long the unitig)
 //   unitig arcs : arcs of the string graph that join a unitig end to a unitig start (asm.c:185-207), compacted in arc order
 //
 // Only the text writer (and the reference-order sort of the handful of unitig arcs) stays on the host.
@@ -22,7 +23,7 @@
 uint32_t graph_nseq(const mahip_ctx *c);
 
 struct UgBufs {
-	DevBuf nxt, prv, mn[2], ptr[2], dist[2], cm, tail, uid, flag, pos, circ, ishead;
+	DevBuf nxt, prv, wt, mn[2], ptr[2], dist[2], ws[2], cm, tail, uid, flag, pos, circ, ishead;
 	DevBuf u_head, u_n, u_len, u_start, u_end, u_off, ua, mark, akeep, apos, arcs;
 	uint32_t n_utg = 0, n_mem = 0, n_uarc = 0;
 };
@@ -37,7 +38,7 @@ void ug_free(mahip_ctx *c)
 {
 	UgBufs *b = (UgBufs*)c->ug;
 	if (!b) return;
-	DevBuf *all[] = { &b->nxt, &b->prv, &b->mn[0], &b->mn[1], &b->ptr[0], &b->ptr[1], &b->dist[0], &b->dist[1], &b->cm, &b->tail, &b->uid, &b->flag, &b->pos, &b->circ, &b->ishead,
+	DevBuf *all[] = { &b->nxt, &b->prv, &b->wt, &b->ws[0], &b->ws[1], &b->mn[0], &b->mn[1], &b->ptr[0], &b->ptr[1], &b->dist[0], &b->dist[1], &b->cm, &b->tail, &b->uid, &b->flag, &b->pos, &b->circ, &b->ishead,
 		&b->u_head, &b->u_n, &b->u_len, &b->u_start, &b->u_end, &b->u_off, &b->ua, &b->mark, &b->akeep, &b->apos, &b->arcs };
 	for (DevBuf *x : all) dev_free(c, *x);
 	delete b;
@@ -45,9 +46,8 @@ void ug_free(mahip_ctx *c)
 }
 
 __global__ __launch_bounds__(256) void k_ug_link(ug_t a) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_link(&a, w); }
-__global__ __launch_bounds__(256) void k_ug_jump_init(ug_t a, uint32_t *ptr, uint32_t *mn, uint32_t *dist) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_jump_init(&a, w, ptr, mn, dist); }
-__global__ __launch_bounds__(256) void k_ug_jump(uint32_t n_vtx, const uint32_t *ptr, const uint32_t *mn, const uint32_t *dist, uint32_t *ptr2, uint32_t *mn2, uint32_t *dist2)
-{ uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < n_vtx) ugk_jump(w, ptr, mn, dist, ptr2, mn2, dist2); }
+__global__ __launch_bounds__(256) void k_ug_jump_init(ug_t a, ug_rank_t r) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_jump_init(&a, w, r); }
+__global__ __launch_bounds__(256) void k_ug_jump(uint32_t n_vtx, ug_rank_t i, ug_rank_t o) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < n_vtx) ugk_jump(w, i, o); }
 // does any member sit on a chain without a head (a cycle)?  Cycles are rare: the cut and the second ranking only run when one exists
 __global__ __launch_bounds__(256) void k_ug_cycle_check(ug_t a, const uint32_t *ptr, unsigned long long *ctr)
 {
@@ -58,9 +58,9 @@ __global__ __launch_bounds__(256) void k_ug_cycle_check(ug_t a, const uint32_t *
 }
 __global__ __launch_bounds__(256) void k_ug_heads(ug_t a, uint8_t *is_head) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) is_head[w] = a.prv[w] == UG_NONE; }
 __global__ __launch_bounds__(256) void k_ug_cut(ug_t a, const uint32_t *ptr, const uint32_t *mn, const uint8_t *is_head) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_cut(&a, w, ptr, mn, is_head); }
-__global__ __launch_bounds__(256) void k_ug_chain(ug_t a, const uint32_t *ptr) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_chain(&a, w, ptr); }
+__global__ __launch_bounds__(256) void k_ug_chain(ug_t a, ug_rank_t r) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_chain(&a, w, r); }
 __global__ __launch_bounds__(256) void k_ug_pick(ug_t a, const uint32_t *ptr) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_pick(&a, w, ptr); }
-__global__ __launch_bounds__(256) void k_ug_units(ug_t a, const uint32_t *ptr, const uint32_t *dist) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_units(&a, w, ptr, dist); }
+__global__ __launch_bounds__(256) void k_ug_units(ug_t a, ug_rank_t r) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_units(&a, w, r); }
 __global__ __launch_bounds__(256) void k_ug_fill(ug_t a, const uint32_t *ptr, const uint32_t *dist) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_fill(&a, w, ptr, dist); }
 __global__ __launch_bounds__(256) void k_ug_mark(ug_t a, uint32_t n_utg) { uint32_t k = blockIdx.x * 256 + threadIdx.x; if (k < n_utg) ugk_mark(&a, k); }
 __global__ __launch_bounds__(256) void k_ug_arc_keep(ug_t a, size_t n, uint32_t *keep) { size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; if (e < n) keep[e] = ugk_arc_keep(&a, e); }
@@ -72,17 +72,22 @@ __global__ __launch_bounds__(256) void k_ug_arc_emit(ug_t a, size_t n, const uin
 
 static int bitlen32(uint32_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
 
-// ranking of every member along prv: afterwards ptr = chain head (or a cycle vertex), mn = minimum over the stretch skipped, dist = links to the head
-static int ug_rank(mahip_ctx *c, UgBufs *b, const ug_t &a, bool want_mn, bool want_dist, int *gen_out)
+static ug_rank_t rank_bufs(UgBufs *b, int g)
+{
+	ug_rank_t r;
+	r.ptr = P<uint32_t>(b->ptr[g]); r.mn = P<uint32_t>(b->mn[g]); r.dist = P<uint32_t>(b->dist[g]); r.ws = P<uint32_t>(b->ws[g]);
+	return r;
+}
+
+// list ranking of every member along prv by pointer jumping: afterwards ptr = chain head (or, on a cycle, some cycle vertex) and over the
+// stretch head..w: mn = smallest vertex with an arc, dist = links, ws = length contributions
+static int ug_rank(mahip_ctx *c, UgBufs *b, const ug_t &a, int *gen_out)
 {
 	const uint32_t V = a.n_vtx;
 	int g = 0;
-	hipLaunchKernelGGL(k_ug_jump_init, dim3(grid_for(V, 256)), dim3(256), 0, c->st, a, P<uint32_t>(b->ptr[0]),
-	                   want_mn ? P<uint32_t>(b->mn[0]) : (uint32_t*)nullptr, want_dist ? P<uint32_t>(b->dist[0]) : (uint32_t*)nullptr);
+	hipLaunchKernelGGL(k_ug_jump_init, dim3(grid_for(V, 256)), dim3(256), 0, c->st, a, rank_bufs(b, 0));
 	for (int k = bitlen32(V) + 1; k > 0; --k, g ^= 1)
-		hipLaunchKernelGGL(k_ug_jump, dim3(grid_for(V, 256)), dim3(256), 0, c->st, V, (const uint32_t*)P<uint32_t>(b->ptr[g]),
-		                   want_mn ? (const uint32_t*)P<uint32_t>(b->mn[g]) : (const uint32_t*)nullptr, want_dist ? (const uint32_t*)P<uint32_t>(b->dist[g]) : (const uint32_t*)nullptr,
-		                   P<uint32_t>(b->ptr[g ^ 1]), want_mn ? P<uint32_t>(b->mn[g ^ 1]) : (uint32_t*)nullptr, want_dist ? P<uint32_t>(b->dist[g ^ 1]) : (uint32_t*)nullptr);
+		hipLaunchKernelGGL(k_ug_jump, dim3(grid_for(V, 256)), dim3(256), 0, c->st, V, rank_bufs(b, g), rank_bufs(b, g ^ 1));
 	*gen_out = g;
 	return 0;
 }
@@ -100,7 +105,7 @@ extern "C" int mahip_ug_gen(mahip_ctx_t *c, uint32_t *n_utg, uint32_t *n_members
 	if (n_uarc) *n_uarc = 0;
 	if (V == 0) return 0;
 	const size_t vb = ((size_t)V + 16) * 4;
-	DevBuf *vbufs[] = { &b->nxt, &b->prv, &b->mn[0], &b->mn[1], &b->ptr[0], &b->ptr[1], &b->dist[0], &b->dist[1], &b->cm, &b->tail, &b->uid, &b->flag, &b->pos,
+	DevBuf *vbufs[] = { &b->nxt, &b->prv, &b->wt, &b->ws[0], &b->ws[1], &b->mn[0], &b->mn[1], &b->ptr[0], &b->ptr[1], &b->dist[0], &b->dist[1], &b->cm, &b->tail, &b->uid, &b->flag, &b->pos,
 		&b->u_head, &b->u_n, &b->u_len, &b->u_start, &b->u_end, &b->u_off, &b->mark };
 	for (DevBuf *x : vbufs) CHK(dev_reserve(c, *x, vb));
 	CHK(dev_reserve(c, b->ua, ((size_t)V + 16) * 8));
@@ -109,7 +114,7 @@ extern "C" int mahip_ug_gen(mahip_ctx_t *c, uint32_t *n_utg, uint32_t *n_members
 	ug_t a;
 	a.au = P<uint32_t>(c->au[ag]); a.av = P<uint32_t>(c->av[ag]); a.alen = P<uint32_t>(c->alen[ag]); a.aol = P<uint32_t>(c->aol[ag]);
 	a.idx = P<unsigned long long>(c->idx); a.sdel = P<uint8_t>(c->sdel); a.slen = P<uint32_t>(c->slen); a.n_vtx = V;
-	a.nxt = P<uint32_t>(b->nxt); a.prv = P<uint32_t>(b->prv); a.cm = P<uint32_t>(b->cm); a.tail = P<uint32_t>(b->tail); a.uid = P<uint32_t>(b->uid);
+	a.nxt = P<uint32_t>(b->nxt); a.prv = P<uint32_t>(b->prv); a.wt = P<uint32_t>(b->wt); a.cm = P<uint32_t>(b->cm); a.tail = P<uint32_t>(b->tail); a.uid = P<uint32_t>(b->uid);
 	a.flag = P<uint32_t>(b->flag); a.pos = P<uint32_t>(b->pos); a.circ = P<uint8_t>(b->circ); a.mark = P<int32_t>(b->mark);
 	a.u_head = P<uint32_t>(b->u_head); a.u_n = P<uint32_t>(b->u_n); a.u_len = P<uint32_t>(b->u_len); a.u_start = P<uint32_t>(b->u_start); a.u_end = P<uint32_t>(b->u_end);
 	a.u_off = P<uint32_t>(b->u_off); a.ua = P<unsigned long long>(b->ua);
@@ -120,18 +125,19 @@ extern "C" int mahip_ug_gen(mahip_ctx_t *c, uint32_t *n_utg, uint32_t *n_members
 	int g = 0;
 	HIPCHK(hipMemsetAsync(b->circ.p, 0, (size_t)V, c->st));
 	CHK(ctr_zero(c));
-	CHK(ug_rank(c, b, a, true, true, &g));          // head, offset and the minimum over each chain in one ranking pass
+	CHK(ug_rank(c, b, a, &g));                      // head, offset, discovery vertex and length of every chain in one ranking pass
 	hipLaunchKernelGGL(k_ug_cycle_check, dim3(gv), dim3(256), 0, c->st, a, (const uint32_t*)P<uint32_t>(b->ptr[g]), ctr);
 	CHK(ctr_fetch(c));
 	if (c->h_ctr[CT_OVF]) { // some chain has no head: cut every cycle in front of its smallest vertex, rank again
 		hipLaunchKernelGGL(k_ug_heads, dim3(gv), dim3(256), 0, c->st, a, P<uint8_t>(b->ishead));
 		hipLaunchKernelGGL(k_ug_cut, dim3(gv), dim3(256), 0, c->st, a, (const uint32_t*)P<uint32_t>(b->ptr[g]), (const uint32_t*)P<uint32_t>(b->mn[g]), (const uint8_t*)P<uint8_t>(b->ishead));
-		CHK(ug_rank(c, b, a, false, true, &g));
+		CHK(ug_rank(c, b, a, &g));
 	}
-	const uint32_t *ptr = P<uint32_t>(b->ptr[g]), *dist = P<uint32_t>(b->dist[g]);
+	const ug_rank_t rk = rank_bufs(b, g);
+	const uint32_t *ptr = rk.ptr, *dist = rk.dist;
 	HIPCHK(hipMemsetAsync(b->cm.p, 0xff, (size_t)V * 4, c->st));
 	HIPCHK(hipMemsetAsync(b->tail.p, 0xff, (size_t)V * 4, c->st));
-	hipLaunchKernelGGL(k_ug_chain, dim3(gv), dim3(256), 0, c->st, a, ptr);
+	hipLaunchKernelGGL(k_ug_chain, dim3(gv), dim3(256), 0, c->st, a, rk);
 	HIPCHK(hipMemsetAsync(b->flag.p, 0, (size_t)V * 4, c->st));
 	hipLaunchKernelGGL(k_ug_pick, dim3(gv), dim3(256), 0, c->st, a, ptr);
 	uint32_t *d_tot = (uint32_t*)(ctr + CT_TOTAL);
@@ -141,9 +147,8 @@ extern "C" int mahip_ug_gen(mahip_ctx_t *c, uint32_t *n_utg, uint32_t *n_members
 	b->n_utg = U;
 	if (n_utg) *n_utg = U;
 	if (U == 0) return 0;
-	hipLaunchKernelGGL(k_ug_units, dim3(gv), dim3(256), 0, c->st, a, ptr, dist);
+	hipLaunchKernelGGL(k_ug_units, dim3(gv), dim3(256), 0, c->st, a, rk);
 	CHK(scan_exclusive_u32(c, P<uint32_t>(b->u_n), P<uint32_t>(b->u_off), U, d_tot));
-	HIPCHK(hipMemsetAsync(b->u_len.p, 0, (size_t)U * 4, c->st));
 	hipLaunchKernelGGL(k_ug_fill, dim3(gv), dim3(256), 0, c->st, a, ptr, dist);
 	// arcs between unitig ends
 	HIPCHK(hipMemsetAsync(b->mark.p, 0xff, (size_t)V * 4, c->st));

@@ -27,7 +27,7 @@ typedef struct {
 	const uint32_t *slen;
 	uint32_t n_vtx;
 	/* per vertex */
-	uint32_t *nxt, *prv, *cm, *tail, *uid, *flag, *pos;
+	uint32_t *nxt, *prv, *wt, *cm, *tail, *uid, *flag, *pos;
 	uint8_t *circ;
 	int32_t *mark;
 	/* per unitig */
@@ -48,24 +48,33 @@ UG_HD void ugk_link(const ug_t *a, uint32_t w)
 		if (ug_deg(a, w ^ 1) == 1) { uint32_t t = a->av[ug_first(a, w ^ 1)] ^ 1; if (ug_deg(a, t) == 1) p = t; }      /* backward step, asm.c:155-157 */
 	}
 	a->nxt[w] = n; a->prv[w] = member ? p : UG_OUT;
+	/* what w contributes to its unitig's length: the arc to the next read, or -- last read of a linear unitig -- its whole length (asm.c:144-153) */
+	a->wt[w] = !member ? 0u : n != UG_NONE ? a->alen[ug_first(a, w)] : (a->slen[w >> 1] & 0x7fffffffu);
 }
 
-UG_HD void ugk_jump_init(const ug_t *a, uint32_t w, uint32_t *ptr, uint32_t *mn, uint32_t *dist)
+/* List ranking state per vertex: ptr (where the stretch covered so far begins), and over that stretch: mn = the smallest vertex
+ * that has an arc (the reference discovers a unitig there), dist = links, ws = length contributions. */
+typedef struct { uint32_t *ptr, *mn, *dist, *ws; } ug_rank_t;
+
+UG_HD void ugk_jump_init(const ug_t *a, uint32_t w, ug_rank_t r)
 {
 	const uint32_t p = a->prv[w];
 	const int linked = p < UG_OUT;
-	ptr[w] = linked ? p : w;
-	if (mn) mn[w] = w;
-	if (dist) dist[w] = linked ? 1u : 0u;
+	r.ptr[w] = linked ? p : w;
+	r.mn[w] = ug_deg(a, w) > 0 && p != UG_OUT ? w : UG_NONE;
+	r.dist[w] = linked ? 1u : 0u;
+	r.ws[w] = linked ? a->wt[w] : 0u; /* like dist, the sum leaves the head out (it is re-added every round once the pointer rests there): the head's share is added at the end */
 }
 
-/* one round of pointer jumping: the pointer doubles its reach, the minimum / the distance over the skipped stretch is folded in */
-UG_HD void ugk_jump(uint32_t w, const uint32_t *ptr, const uint32_t *mn, const uint32_t *dist, uint32_t *ptr2, uint32_t *mn2, uint32_t *dist2)
+/* one round of pointer jumping: the pointer doubles its reach; minimum, distance and length over the skipped stretch are folded in */
+UG_HD void ugk_jump(uint32_t w, ug_rank_t i, ug_rank_t o)
 {
-	const uint32_t p = ptr[w];
-	ptr2[w] = ptr[p];
-	if (mn) { uint32_t x = mn[w], y = mn[p]; mn2[w] = x < y ? x : y; }
-	if (dist) dist2[w] = dist[w] + (p != w ? dist[p] : 0u);
+	const uint32_t p = i.ptr[w];
+	const uint32_t x = i.mn[w], y = i.mn[p];
+	o.ptr[w] = i.ptr[p];
+	o.mn[w] = x < y ? x : y;
+	o.dist[w] = i.dist[w] + (p != w ? i.dist[p] : 0u);
+	o.ws[w] = i.ws[w] + (p != w ? i.ws[p] : 0u);
 }
 
 /* a member whose chain has no head sits on a cycle; the cycle is cut in front of its smallest vertex (where the reference's
@@ -76,17 +85,18 @@ UG_HD void ugk_cut(const ug_t *a, uint32_t w, const uint32_t *ptr, const uint32_
 	a->circ[w] = 0;
 	if (p >= UG_OUT) return;              /* a head, or not a member */
 	if (is_head[ptr[w]]) return;          /* the chain has a head: linear */
-	if (mn[w] == w) { a->circ[w] = 1; a->prv[w] = UG_NONE; a->nxt[p] = UG_NONE; }
+	if (mn[w] == w) { a->circ[w] = 1; a->prv[w] = UG_NONE; a->nxt[p] = UG_NONE; } /* (wt keeps the arc length of the closing link: a circular unitig has no last read) */
 }
 
-/* per chain (keyed by its head): last vertex, smallest vertex that has an arc */
-UG_HD void ugk_chain(const ug_t *a, uint32_t w, const uint32_t *ptr)
+/* per chain (keyed by its head): its last vertex; the ranking state of the last vertex covers the whole chain, so the chain's
+ * discovery vertex is simply its mn (one writer per chain: no atomics, however long the unitig) */
+UG_HD void ugk_chain(const ug_t *a, uint32_t w, ug_rank_t r)
 {
 	uint32_t h;
-	if (a->prv[w] == UG_OUT) return;
-	h = ptr[w];
-	if (a->nxt[w] == UG_NONE) a->tail[h] = w;
-	if (ug_deg(a, w) > 0) UG_MIN_U32(&a->cm[h], w);
+	if (a->prv[w] == UG_OUT || a->nxt[w] != UG_NONE) return;
+	h = r.ptr[w];
+	a->tail[h] = w;
+	a->cm[h] = r.mn[w];
 }
 
 /* The orientation the reference emits: it discovers a unitig at its smallest vertex that has an arc; that vertex lies in one of
@@ -104,14 +114,15 @@ UG_HD void ugk_pick(const ug_t *a, uint32_t h, const uint32_t *ptr)
 }
 
 /* unitig records in discovery order: number = rank of the discovery vertex among the flagged vertices (pos = scan of flag) */
-UG_HD void ugk_units(const ug_t *a, uint32_t h, const uint32_t *ptr, const uint32_t *dist)
+UG_HD void ugk_units(const ug_t *a, uint32_t h, ug_rank_t r)
 {
+	const uint32_t *ptr = r.ptr;
 	uint32_t k, t;
 	a->uid[h] = UG_NONE;
 	if (!ug_emitted(a, h, ptr)) return;
 	k = a->pos[a->cm[h]]; t = a->tail[h];
 	a->uid[h] = k;
-	a->u_head[k] = h; a->u_n[k] = dist[t] + 1;
+	a->u_head[k] = h; a->u_n[k] = r.dist[t] + 1; a->u_len[k] = r.ws[t] + a->wt[h];
 	a->u_start[k] = a->circ[h] ? UG_NONE : h; a->u_end[k] = a->circ[h] ? UG_NONE : (t ^ 1);
 }
 
@@ -123,9 +134,9 @@ UG_HD void ugk_fill(const ug_t *a, uint32_t w, const uint32_t *ptr, const uint32
 	if (a->prv[w] == UG_OUT) return;
 	h = ptr[w]; k = a->uid[h];
 	if (k == UG_NONE) return;
-	l = (a->nxt[w] != UG_NONE || a->circ[h]) ? a->alen[ug_first(a, w)] : (a->slen[w >> 1] & 0x7fffffffu);
+	(void)h;
+	l = a->wt[w];
 	a->ua[a->u_off[k] + dist[w]] = (unsigned long long)w << 32 | l;
-	UG_ADD_U32(&a->u_len[k], l);
 }
 
 UG_HD void ugk_mark(const ug_t *a, uint32_t k) /* asm.c:180-184 */

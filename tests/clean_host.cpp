@@ -84,38 +84,43 @@ extern "C" int clh_ug(uint32_t n_seq, uint32_t n_arc, const arc_t *arc, const ui
 	const uint32_t V = 2 * n_seq;
 	*n_utg = *n_mem = *n_uarc = 0;
 	if (V == 0) return 0;
-	std::vector<uint32_t> nxt(V), prv(V), cm(V, UG_NONE), tail(V, UG_NONE), uid(V), flag(V, 0), pos(V + 1, 0), ptr[2], mn[2], dist[2];
+	std::vector<uint32_t> nxt(V), prv(V), wt(V), cm(V, UG_NONE), tail(V, UG_NONE), uid(V), flag(V, 0), pos(V + 1, 0), ptr[2], mn[2], dist[2], ws[2];
 	std::vector<uint32_t> uh(V), un(V), ul(V, 0), us(V), ue(V), uo(V + 1, 0);
 	std::vector<uint8_t> circ(V, 0), ishead(V, 0);
 	std::vector<int32_t> mark(V, -1);
 	std::vector<unsigned long long> ua(V + 1);
-	for (int k = 0; k < 2; ++k) ptr[k].resize(V), mn[k].resize(V), dist[k].resize(V);
+	for (int k = 0; k < 2; ++k) ptr[k].resize(V), mn[k].resize(V), dist[k].resize(V), ws[k].resize(V);
 	ug_t a;
 	a.au = G.au.data(); a.av = G.av.data(); a.alen = G.alen.data(); a.aol = G.aol.data(); a.idx = G.idx.data(); a.sdel = G.sdel.data(); a.slen = G.slen.data(); a.n_vtx = V;
-	a.nxt = nxt.data(); a.prv = prv.data(); a.cm = cm.data(); a.tail = tail.data(); a.uid = uid.data(); a.flag = flag.data(); a.pos = pos.data(); a.circ = circ.data(); a.mark = mark.data();
+	a.nxt = nxt.data(); a.prv = prv.data(); a.wt = wt.data(); a.cm = cm.data(); a.tail = tail.data(); a.uid = uid.data(); a.flag = flag.data(); a.pos = pos.data(); a.circ = circ.data(); a.mark = mark.data();
 	a.u_head = uh.data(); a.u_n = un.data(); a.u_len = ul.data(); a.u_start = us.data(); a.u_end = ue.data(); a.u_off = uo.data(); a.ua = ua.data();
 	int bits = 0; for (uint32_t x = V; x; x >>= 1) ++bits;
-	auto rank = [&](bool want_mn, bool want_dist) {
+	auto rb = [&](int g) { ug_rank_t r; r.ptr = ptr[g].data(); r.mn = mn[g].data(); r.dist = dist[g].data(); r.ws = ws[g].data(); return r; };
+	auto rank = [&]() {
 		int g = 0;
-		for (uint32_t w = 0; w < V; ++w) ugk_jump_init(&a, w, ptr[0].data(), want_mn ? mn[0].data() : 0, want_dist ? dist[0].data() : 0);
+		for (uint32_t w = 0; w < V; ++w) ugk_jump_init(&a, w, rb(0));
 		for (int k = bits + 1; k > 0; --k, g ^= 1)
-			for (uint32_t w = 0; w < V; ++w)
-				ugk_jump(w, ptr[g].data(), want_mn ? mn[g].data() : 0, want_dist ? dist[g].data() : 0, ptr[g ^ 1].data(), want_mn ? mn[g ^ 1].data() : 0, want_dist ? dist[g ^ 1].data() : 0);
+			for (uint32_t w = 0; w < V; ++w) ugk_jump(w, rb(g), rb(g ^ 1));
 		return g;
 	};
 	for (uint32_t w = 0; w < V; ++w) ugk_link(&a, w);
-	int g = rank(true, false);
-	for (uint32_t w = 0; w < V; ++w) ishead[w] = prv[w] == UG_NONE;
-	for (uint32_t w = 0; w < V; ++w) ugk_cut(&a, w, ptr[g].data(), mn[g].data(), ishead.data());
-	g = rank(false, true);
-	const uint32_t *P = ptr[g].data(), *D = dist[g].data();
-	for (uint32_t w = 0; w < V; ++w) ugk_chain(&a, w, P);
+	int g = rank();
+	bool cyc = false;
+	for (uint32_t w = 0; w < V; ++w) cyc = cyc || (prv[w] < UG_OUT && prv[ptr[g][w]] != UG_NONE);
+	if (cyc) { // as the device: cut + second ranking only when some chain has no head
+		for (uint32_t w = 0; w < V; ++w) ishead[w] = prv[w] == UG_NONE;
+		for (uint32_t w = 0; w < V; ++w) ugk_cut(&a, w, ptr[g].data(), mn[g].data(), ishead.data());
+		g = rank();
+	}
+	const ug_rank_t RK = rb(g);
+	const uint32_t *P = RK.ptr, *D = RK.dist;
+	for (uint32_t w = 0; w < V; ++w) ugk_chain(&a, w, RK);
 	for (uint32_t w = 0; w < V; ++w) ugk_pick(&a, w, P);
 	uint32_t U = 0;
 	for (uint32_t w = 0; w < V; ++w) { pos[w] = U; U += flag[w]; }
 	*n_utg = U;
 	if (U == 0) return 0;
-	for (uint32_t w = 0; w < V; ++w) ugk_units(&a, w, P, D);
+	for (uint32_t w = 0; w < V; ++w) ugk_units(&a, w, RK);
 	uint32_t M = 0;
 	for (uint32_t k = 0; k < U; ++k) { uo[k] = M; M += un[k]; }
 	*n_mem = M;
