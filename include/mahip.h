@@ -160,6 +160,13 @@ int mahip_asg_pop_bubble(mahip_ctx_t *c, int max_dist, uint32_t *n_pop, uint32_t
  * reference sorts them with its own sort afterwards, asm.c:208). */
 int mahip_ug_gen(mahip_ctx_t *c, uint32_t *n_utg, uint32_t *n_members, uint32_t *n_uarc);
 int mahip_ug_download(mahip_ctx_t *c, uint32_t *u_n, uint32_t *u_len, uint32_t *u_start, uint32_t *u_end, uint32_t *u_off, uint64_t *members, asg_arc_t *uarcs);
+/* asm.c:216-290 ma_ug_seq as a device byte gather (csrc/useq.hip).  The host reads the sequence file and hands the bases of the
+ * reads that sit on a unitig over in batches; a job copies `len` bases from the batch buffer to the unitig arena -- the first `len`
+ * bases at src_off (forward) or the reverse complement of the last `len` of the src_len bases there (reverse). */
+typedef struct { uint64_t src_off, dst_off; uint32_t src_len, len; uint32_t rev, pad; } mahip_useq_job_t;
+int mahip_useq_begin(mahip_ctx_t *c, size_t arena_bytes);          /* arena of all unitig strings, filled with 'N' */
+int mahip_useq_batch(mahip_ctx_t *c, const char *h_seq, size_t seq_bytes, const mahip_useq_job_t *h_jobs, size_t n_jobs);
+int mahip_useq_end(mahip_ctx_t *c, char *h_arena);                 /* the arena back to the host */
 uint32_t mahip_asg_n_arc(mahip_ctx_t *c);
 /* fills g (arc/seq/idx malloc'ed, is_srt=1) in the squeezed numbering */
 int mahip_asg_download(mahip_ctx_t *c, asg_t *g);

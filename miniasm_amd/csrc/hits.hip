@@ -20,8 +20,8 @@
 // ------------------------------------------------------------------------------------------------ sort
 // Sort keys for ma_hit_sort (hit.c:12-22, key = qns = qid<<32 | qs), squeezed to their significant bits:
 //   packed (pk = 1): key = qid << (bs+bi) | qs << bi | input position >> drop   (8-byte elements, no value array).  drop > 0 when the
-//                    three fields are a few bits too wide for 64: the low bits of the position are left out and the gather picks the
-//                    record among the 2^drop neighbours of the position (one or two cache lines it reads anyway), see k_hit_gather
+//                    three fields are ONE bit too wide for 64 (BASELINE configs[3]: 21 + 16 + 28): the lowest bit of the position is left
+//                    out and the gather picks the record out of the pair of neighbours it reads anyway (one 64-byte line), see k_hit_gather
 //   pairs  (pk = 0): key = qid << bs | qs, value = input position        (when the three fields exceed 64 bits)
 // keep[i] = hit belongs to this context's read range (sharded mode).
 __global__ __launch_bounds__(256) void k_hit_keys(const ma_hit_t *__restrict__ h, size_t n, uint64_t *__restrict__ key,
@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
                                                      int qshift, int bi, size_t n, uint32_t n_seq, HitCols c, uint32_t *__restrict__ goff, uint32_t *__restrict__ sidx,
                                                      int drop, int bs, size_t n_in)
 { // sidx (optional): input position of the record in every sorted slot -- what the tie-order repair needs to find a slot's original key
-  // drop > 0: the key holds (input position >> drop); the record is the r-th one among the 2^drop candidates whose (qid,qs) equals the key's,
-  // r = this slot's rank inside its run of equal keys (the sort is stable and candidates of one run are in input order)
+  // drop == 1: the key holds (input position >> 1); the record is the one of the pair whose (qid,qs) equals the key's -- the second one if
+  // both do and this slot is the second of its run of equal keys (the sort is stable: candidates of one run are in input order)
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (i > n) return;
 	uint32_t q = n_seq, qprev = 0;
@@ -107,26 +107,16 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 		else if (skey) {
 			const uint64_t K = skey[i];
 			j = (size_t)(K & ((1ull << bi) - 1)) << drop;
-			if (drop) { // all candidates are fetched at once (they share one or two cache lines): no dependent second round trip
-				const uint32_t span = 1u << drop;
+			if (drop) { // drop == 1: the record is one of the pair (j, j+1) -- one 64-byte line, fetched whole; four independent loads, no second round trip
 				const uint64_t want = K >> bi;
-				uint32_t r = 0, seen = 0, pick = 0;
-				uint4 ca[8];
-				while (r + 1 < span && i > r && skey[i - 1 - r] == K) ++r;
-#pragma unroll
-				for (uint32_t t = 0; t < 8; ++t) if (t < span && j + t < n_in) ca[t] = ((const uint4*)(h + j + t))[0];
-				uint4 cb0 = ((const uint4*)(h + j))[1], cb1 = span > 1 && j + 1 < n_in ? ((const uint4*)(h + j + 1))[1] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-				for (uint32_t t = 0; t < 8; ++t)
-					if (t < span && j + t < n_in) {
-						const uint64_t kk = ((uint64_t)ca[t].y << bs) | ca[t].x; // a = {qs, qid, qe, tn}
-						if (kk == want) { if (seen == r) pick = t; ++seen; }
-					}
-				a = ca[0];
-#pragma unroll
-				for (uint32_t t = 1; t < 8; ++t) if (t == pick) a = ca[t];
-				b = pick == 0 ? cb0 : pick == 1 ? cb1 : ((const uint4*)(h + j + pick))[1];
-				j += pick;
+				const uint4 *p = (const uint4*)(h + j);
+				const bool two = j + 1 < n_in;
+				const uint4 a0 = p[0], b0 = p[1], a1 = two ? p[2] : a0, b1 = two ? p[3] : b0;
+				const bool second_of_run = i > 0 && skey[i - 1] == K;                 // equal keys are adjacent and in input order (stable sort)
+				const bool m0 = (((uint64_t)a0.y << bs) | a0.x) == want;               // a = {qs, qid, qe, tn}
+				const bool pick1 = two && (second_of_run || !m0);
+				a = pick1 ? a1 : a0; b = pick1 ? b1 : b0;
+				j += pick1;
 				have = true;
 			}
 		}
@@ -437,13 +427,14 @@ __device__ __forceinline__ uint64_t sub_sweep(const uint32_t *ev, uint32_t *up, 
 // tier B: one 256-thread block per oversized read; events (and run starts) in LDS when they fit, else in global
 // scratch (ev at 2*goff[q], up at goff[q]: disjoint per read by construction)
 template <bool FUSE>
-__global__ __launch_bounds__(256) void k_hit_sub_big(HitCols c, const uint32_t *__restrict__ goff, const uint32_t *__restrict__ ovf, uint32_t n_ovf,
+__global__ __launch_bounds__(256) void k_hit_sub_big(HitCols c, const uint32_t *__restrict__ goff, const uint32_t *__restrict__ ovf, const unsigned long long *__restrict__ n_ovf_dev,
                                                       int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
                                                       uint32_t *__restrict__ gev, uint32_t *__restrict__ gup, unsigned long long *__restrict__ ctr, SubFuse f)
 {
 	__shared__ uint32_t s_ev[SUB_LDS_EVENTS], s_up[SUB_LDS_EVENTS / 2];
 	__shared__ uint32_t s_n, s_live;
 	SubAcc acc = {0, 0, 0};
+	const uint32_t n_ovf = (uint32_t)*n_ovf_dev; // the list the register tiers just wrote: read on the device, no host round trip in between
 	for (uint32_t k = blockIdx.x; k < n_ovf; k += gridDim.x) {
 		uint32_t q = ovf[k], beg = goff[q], end = goff[q + 1];
 		const bool in_lds = 2 * (end - beg) <= SUB_LDS_EVENTS;
@@ -853,7 +844,7 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	if (bi == 0) bi = 1;
 	int drop = bq + bs + bi - 64; // bits the packed key is too wide by
 	if (drop < 0) drop = 0;
-	const int pk = drop <= 3 && bi > drop;
+	const int pk = drop <= 1 && bi > drop; // one bit over: packed key without the lowest position bit; more: (key, value) pairs
 	if (!pk) drop = 0;
 	const size_t n_in = n;
 	bi -= drop;
@@ -941,16 +932,14 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 		hipLaunchKernelGGL((k_hit_sub<false, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse);
 	}
-	CHK(ctr_fetch(c));
-	uint32_t n_ovf = (uint32_t)c->h_ctr[CT_OVF];
-	if (n_ovf) {
+	if (R) { // tier B always runs behind the register tiers on a small grid: it finds its work list (usually empty) in the device counter
 		CHK(dev_reserve(c, c->big0, (2 * c->n_hits + 8) * 4));
 		CHK(dev_reserve(c, c->big1, (c->n_hits + 8) * 4));
 		ProfScope ps(c, "k_hit_sub_big", 0);
-		hipLaunchKernelGGL(k_hit_sub_big<false>, dim3(n_ovf < 1024 ? n_ovf : 1024), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), (const uint32_t*)P<uint32_t>(c->ovf), n_ovf,
+		hipLaunchKernelGGL(k_hit_sub_big<false>, dim3(256), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), (const uint32_t*)P<uint32_t>(c->ovf), (const unsigned long long*)(ctr + CT_OVF),
 		                   min_dp, min_iden, end_clip, sub, P<uint32_t>(c->big0), P<uint32_t>(c->big1), ctr, nofuse);
-		CHK(ctr_fetch(c));
 	}
+	CHK(ctr_fetch(c));
 	HIPCHK(hipGetLastError());
 	if (n_remained) *n_remained = (size_t)c->h_ctr[CT_REMAIN];
 	return 0;
@@ -979,13 +968,11 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
 		hipLaunchKernelGGL((k_hit_sub<true, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, f);
 	}
-	CHK(ctr_fetch(c));
-	uint32_t n_ovf = (uint32_t)c->h_ctr[CT_OVF];
-	if (n_ovf) {
+	if (R) {
 		CHK(dev_reserve(c, c->big0, (2 * c->n_hits + 8) * 4));
 		CHK(dev_reserve(c, c->big1, (c->n_hits + 8) * 4));
 		ProfScope ps(c, "k_hit_sub_big", 0);
-		hipLaunchKernelGGL(k_hit_sub_big<true>, dim3(n_ovf < 1024 ? n_ovf : 1024), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), (const uint32_t*)P<uint32_t>(c->ovf), n_ovf,
+		hipLaunchKernelGGL(k_hit_sub_big<true>, dim3(256), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), (const uint32_t*)P<uint32_t>(c->ovf), (const unsigned long long*)(ctr + CT_OVF),
 		                   min_dp, min_iden, end_clip, sub, P<uint32_t>(c->big0), P<uint32_t>(c->big1), ctr, f);
 	}
 	if (R) hipLaunchKernelGGL(k_flt_totlen, dim3(grid_for(R, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, f.cut_sub, (const uint8_t*)P<uint8_t>(c->r_live), R, ctr);

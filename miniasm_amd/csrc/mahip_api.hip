@@ -52,6 +52,56 @@ int ctr_fetch(mahip_ctx *c)
 	return 0;
 }
 
+// Keep the process on the NUMA node the GPU hangs off: staging copies (page cache -> pinned slots -> DMA) and the driver's own
+// page-table work run at half speed from the far socket of a two-socket host (measured: 35 vs 18 GB/s file -> HBM).  The calling
+// thread's mask is narrowed once; threads created later inherit it.  MA_NO_NUMA_PIN=1 leaves the affinity alone.
+#include <sched.h>
+#include <ctype.h>
+#include <dirent.h>
+static void pin_to_gpu_node(int device)
+{
+	static int done = 0;
+	if (done || getenv("MA_NO_NUMA_PIN")) return;
+	done = 1;
+	char bdf[64], path[256], buf[4096];
+	if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) return;
+	for (char *p = bdf; *p; ++p) *p = (char)tolower((unsigned char)*p);
+	snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+	FILE *f = fopen(path, "r");
+	int node = -1;
+	if (!f) return;
+	if (fscanf(f, "%d", &node) != 1) node = -1;
+	fclose(f);
+	if (node < 0) return;
+	snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+	f = fopen(path, "r");
+	if (!f) return;
+	if (!fgets(buf, sizeof(buf), f)) { fclose(f); return; }
+	fclose(f);
+	cpu_set_t want, have;
+	CPU_ZERO(&want);
+	int n_set = 0;
+	for (char *p = buf; *p;) { // "0-63,128-191"
+		char *e;
+		long a = strtol(p, &e, 10), b = a;
+		if (e == p) break;
+		if (*e == '-') b = strtol(e + 1, &e, 10);
+		for (long k = a; k <= b && k < CPU_SETSIZE; ++k) { CPU_SET((int)k, &want); ++n_set; }
+		p = *e == ',' ? e + 1 : e;
+		if (*e != ',' ) break;
+	}
+	if (n_set == 0 || sched_getaffinity(0, sizeof(have), &have) != 0) return;
+	CPU_AND(&want, &want, &have); // never widen what the launcher allowed
+	if (CPU_COUNT(&want) == 0) return;
+	DIR *dp = opendir("/proc/self/task"); // every thread that exists now (the context may be created on a helper thread); later ones inherit
+	if (!dp) { (void)sched_setaffinity(0, sizeof(want), &want); return; }
+	for (struct dirent *de; (de = readdir(dp)) != nullptr;) {
+		const long tid = atol(de->d_name);
+		if (tid > 0) (void)sched_setaffinity((pid_t)tid, sizeof(want), &want);
+	}
+	closedir(dp);
+}
+
 extern "C" mahip_ctx_t *mahip_create(int device, void *stream)
 {
 	int n = 0;
@@ -62,6 +112,7 @@ extern "C" mahip_ctx_t *mahip_create(int device, void *stream)
 	}
 	if (device < 0 || device >= n) { mahip_set_error("mahip_create: device %d out of range (0..%d)", device, n - 1); return nullptr; }
 	if (hipSetDevice(device) != hipSuccess) { mahip_set_error("mahip_create: hipSetDevice(%d) failed", device); return nullptr; }
+	pin_to_gpu_node(device);
 	mahip_ctx *c = new mahip_ctx();
 	c->dev = device;
 	if (stream) c->st = (hipStream_t)stream, c->own_stream = false;
@@ -93,6 +144,7 @@ extern "C" void mahip_destroy(mahip_ctx_t *c)
 	paf_free(c);
 	clean_free(c);
 	ug_free(c);
+	useq_free(c);
 	xfer_pool_free(c);
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	if (c->own_stream) (void)hipStreamDestroy(c->st);

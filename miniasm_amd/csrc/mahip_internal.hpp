@@ -73,6 +73,7 @@ struct mahip_ctx {
 	DevBuf xb[2];             // exchange buffers of the sharded mode
 	void *clean = nullptr;    // scratch of the graph cleaners (clean.hip)
 	void *ug = nullptr;       // unitig arrays (ug.hip)
+	void *useq = nullptr;     // unitig sequence arena (useq.hip)
 
 	// ---- scratch ----
 	DevBuf keep, pos;         // u32 flags / scanned positions
@@ -137,6 +138,7 @@ int xfer_from_fd(mahip_ctx *c, void *dev_ptr, int fd, size_t bytes);
 void paf_free(mahip_ctx *c);
 void clean_free(mahip_ctx *c);
 void ug_free(mahip_ctx *c);
+void useq_free(mahip_ctx *c);
 
 static inline unsigned grid_for(size_t n, unsigned per_block, unsigned cap = 0x7fffffffu)
 {

@@ -355,37 +355,35 @@ static int fq_read(fq_stream_t *f, int *last, fq_str_t *name, fq_str_t *seq)
 	return (int)seq->l;
 }
 
-/* complement of a base letter (IUPAC codes included), identity elsewhere; same mapping as the reference's table
- * (asm.c:225-234), including its one oddity: 0x60 maps to 0x40 */
-static inline int base_comp(int c)
-{
-	static const char from[] = "ABCDGHKMRTUVYabcdghkmrtuvy", to[] = "TVGHCDMKYAABRtvghcdmkyaabr";
-	const char *p;
-	if (c == 0x60) return 0x40;
-	if (c <= 0 || c >= 128) return c;
-	p = strchr(from, c);
-	return p ? to[p - from] : c;
-}
-
 typedef struct { uint32_t utg:31, ori:1, start, len; } utg_place_t;
 
+/* The file is read here (one inflate stream, the reference's record rules); the bases of every read that sits on a unitig go to
+ * the device in batches and a byte-gather kernel places them (forward copy / reverse complement, csrc/useq.hip); the unitig
+ * strings come back once, at the end. */
+#define USEQ_BATCH_BYTES ((size_t)256 << 20)
 int ma_ug_seq(ma_ug_t *g, const sdict_t *d, const ma_sub_t *sub, const char *fn)
 {
+	mahip_ctx_t *c;
 	fq_stream_t f;
 	fq_str_t name = {0, 0, 0}, seq = {0, 0, 0};
 	utg_place_t *pl;
+	uint64_t *uoff, tot = 0;
+	char *batch, *arena;
+	mahip_useq_job_t *jobs;
+	size_t n_jobs = 0, m_jobs = 1 << 16, n_batch = 0, m_batch = USEQ_BATCH_BYTES;
 	uint32_t i, j;
 	int last = 0;
 	memset(&f, 0, sizeof(f));
 	f.fp = fn && strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(fileno(stdin), "r");
 	if (f.fp == 0) return -1;
+	c = ma_gpu();
 	f.buf = (unsigned char*)malloc(FQ_BUF);
 	pl = (utg_place_t*)calloc(d->n_seq ? d->n_seq : 1, sizeof(utg_place_t));
-	for (i = 0; i < g->u.n; ++i) { /* where every read lands */
-		ma_utg_t *u = &g->u.a[i];
+	uoff = (uint64_t*)malloc((g->u.n + 1) * 8);
+	for (i = 0; i < g->u.n; ++i) { /* where every read lands; unitig strings back to back, each with its terminator */
+		const ma_utg_t *u = &g->u.a[i];
 		uint32_t l = 0;
-		u->s = (char*)calloc(1, (size_t)u->len + 1);
-		memset(u->s, 'N', u->len);
+		uoff[i] = tot; tot += (uint64_t)u->len + 1;
 		for (j = 0; j < u->n; ++j) {
 			utg_place_t *t = &pl[u->a[j] >> 33];
 			assert(t->len == 0);
@@ -394,21 +392,40 @@ int ma_ug_seq(ma_ug_t *g, const sdict_t *d, const ma_sub_t *sub, const char *fn)
 			l += t->len;
 		}
 	}
+	GPU(mahip_useq_begin(c, (size_t)tot));
+	batch = (char*)malloc(m_batch);
+	jobs = (mahip_useq_job_t*)malloc(m_jobs * sizeof(mahip_useq_job_t));
 	while (fq_read(&f, &last, &name, &seq) >= 0) {
 		int32_t id = name.s ? sd_get(d, name.s) : -1;
 		const utg_place_t *t;
-		char *us, *rs = seq.s;
+		const char *rs = seq.s;
 		size_t rl = seq.l;
 		if (id < 0 || pl[id].len == 0) continue;
 		t = &pl[id];
-		us = g->u.a[t->utg].s + t->start;
 		if (sub) {
 			assert(sub[id].e - sub[id].s <= rl);
 			rs += sub[id].s; rl = sub[id].e - sub[id].s;
 		}
-		if (!t->ori) for (i = 0; i < t->len; ++i) us[i] = rs[i];
-		else for (i = 0; i < t->len; ++i) { int c = (uint8_t)rs[rl - 1 - i]; us[i] = c >= 128 ? 'N' : (char)base_comp(c); }
+		if (n_batch + rl > m_batch || n_jobs == m_jobs) { /* batch full: place what is there */
+			GPU(mahip_useq_batch(c, batch, n_batch, jobs, n_jobs));
+			n_batch = 0; n_jobs = 0;
+			if (rl > m_batch) { m_batch = rl; batch = (char*)realloc(batch, m_batch); }
+		}
+		memcpy(batch + n_batch, rs, rl);
+		jobs[n_jobs].src_off = n_batch; jobs[n_jobs].dst_off = uoff[t->utg] + t->start;
+		jobs[n_jobs].src_len = (uint32_t)rl; jobs[n_jobs].len = t->len; jobs[n_jobs].rev = t->ori; jobs[n_jobs].pad = 0;
+		++n_jobs; n_batch += rl;
 	}
+	GPU(mahip_useq_batch(c, batch, n_batch, jobs, n_jobs));
+	arena = (char*)malloc(tot ? tot : 1);
+	GPU(mahip_useq_end(c, arena));
+	for (i = 0; i < g->u.n; ++i) { /* ma_ug_destroy frees every string on its own */
+		ma_utg_t *u = &g->u.a[i];
+		u->s = (char*)malloc((size_t)u->len + 1);
+		memcpy(u->s, arena + uoff[i], u->len);
+		u->s[u->len] = 0;
+	}
+	free(arena); free(batch); free(jobs); free(uoff);
 	free(pl); free(name.s); free(seq.s); free(f.buf);
 	gzclose(f.fp);
 	return 0;

@@ -305,8 +305,10 @@ def test_parallel_ingest_matches_reference(tmpdir_s, monkeypatch):
 
 
 @needs_ref
+@pytest.mark.gpu
 def test_unitig_sequences_match_reference(tmpdir_s):
-    """ma_ug_seq (-f): FASTA and FASTQ (gz, multi-line, CRLF, lower case, IUPAC, reads not in the graph)"""
+    """ma_ug_seq (-f): FASTA and FASTQ (gz, multi-line, CRLF, lower case, IUPAC, reads not in the graph).  The record reader is host
+    code, the placement of the bases a device byte gather (csrc/useq.hip): needs the GPU."""
     import random
     paf = R.pafgen(os.path.join(tmpdir_s, "seq.paf"), 1500, 40000, 27, ["-L", "uniform", "-d", "0.3", "-x", "0.03"])
     opt = ma.default_opt()
