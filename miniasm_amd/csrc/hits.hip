@@ -107,15 +107,17 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 		else if (skey) {
 			const uint64_t K = skey[i];
 			j = (size_t)(K & ((1ull << bi) - 1)) << drop;
-			if (drop) { // drop == 1: the record is one of the pair (j, j+1) -- one 64-byte line, fetched whole; four independent loads, no second round trip
+			if (drop) { // drop == 1: the record is one of the pair (j, j+1), which share a 64-byte line.  The first half of the even record
+				// decides; only the halves that are needed are requested (measured: asking for all four quarters of the line per lane
+				// costs more than the dependent second request -- the kernel is bound by outstanding requests, not by bytes)
 				const uint64_t want = K >> bi;
 				const uint4 *p = (const uint4*)(h + j);
 				const bool two = j + 1 < n_in;
-				const uint4 a0 = p[0], b0 = p[1], a1 = two ? p[2] : a0, b1 = two ? p[3] : b0;
+				const uint4 a0 = p[0];                                                  // a = {qs, qid, qe, tn}
 				const bool second_of_run = i > 0 && skey[i - 1] == K;                 // equal keys are adjacent and in input order (stable sort)
-				const bool m0 = (((uint64_t)a0.y << bs) | a0.x) == want;               // a = {qs, qid, qe, tn}
+				const bool m0 = (((uint64_t)a0.y << bs) | a0.x) == want;
 				const bool pick1 = two && (second_of_run || !m0);
-				a = pick1 ? a1 : a0; b = pick1 ? b1 : b0;
+				if (pick1) { a = p[2]; b = p[3]; } else { a = a0; b = p[1]; }
 				j += pick1;
 				have = true;
 			}

@@ -17,6 +17,8 @@ all_tests)
 graphapi)
   timeout 1500 python -m pytest tests/test_gpu_graph_api.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/tests_graphapi.log 2>&1; echo "rc=$?" >> gpurun_out/tests_graphapi.log
   grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_graphapi.log | tail -40 ;;
+e2ecfg4)
+  NOREF=1 bash tools/e2e_cfg4.sh | tail -60 ;;
 bignoisy)
   MA_PIPE_TIMING=2 bash tools/e2e_big.sh 1000000 50000000 3 "-L uniform -d 0.35 -x 0.03" ref | tail -70 ;;
 ties)
