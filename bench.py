@@ -251,9 +251,9 @@ def main():
 
     class ShardStats(C.Structure):  # host/ma_host.h: ma_shard_stats_t
         _fields_ = [("n_rem1", C.c_uint64), ("n_rem2", C.c_uint64), ("n_hits", C.c_uint64), ("n_seq_new", C.c_uint32), ("n_arc", C.c_uint32), ("n_loc_arc", C.c_uint32),
-                    ("n_red", C.c_uint32), ("n_multi", C.c_uint32), ("n_asymm", C.c_uint32), ("tie_groups", C.c_uint64)]
+                    ("n_red", C.c_uint32), ("n_multi", C.c_uint32), ("n_asymm", C.c_uint32), ("tie_groups", C.c_uint64), ("push_conflicts", C.c_uint64), ("tie_repaired", C.c_int)]
     L.ma_pipeline_head_sharded.restype = C.c_int
-    L.ma_pipeline_head_sharded.argtypes = [vp, C.POINTER(ma.MaOpt), C.c_uint32, C.POINTER(ShardStats)]
+    L.ma_pipeline_head_sharded.argtypes = [vp, C.POINTER(ma.MaOpt), C.c_uint32, C.c_int, C.POINTER(ShardStats)]
     overlap = not args.no_overlap
 
     # Passes are pipelined over the stream of batches: the device part of pass k+1 starts as soon as pass k's reduced graph
@@ -305,7 +305,7 @@ def main():
                 assert L.ma_pipeline_head(ctx.h, C.byref(opt), W.d, b"ug", 100, 0, C.byref(st)) == 0
             else:  # sharded: device passes + RCCL exchanges on every rank (host/sharded.c), graph cleaning + unitigs + GFA on rank 0
                 stats = ShardStats()
-                assert L.ma_pipeline_head_sharded(ctx.h, C.byref(opt), W.n_seq, C.byref(stats)) == 0
+                assert L.ma_pipeline_head_sharded(ctx.h, C.byref(opt), W.n_seq, 0, C.byref(stats)) == 0  # 0: this rank holds its own records only
                 if rank != 0:
                     return
                 st = (C.c_uint32 * 4)(1, 1, stats.n_red, 1)

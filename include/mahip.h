@@ -78,8 +78,8 @@ int mahip_memcpy_d2h(mahip_ctx_t *c, void *h_dst, const void *d_src, size_t byte
  *           equal (qid,qs), over the hit keys too; the device re-gathers.  Hit dumps (mahip_hits_download) are put in the
  *           reference's order when tied hits exist.
  *   mode 1: the same repair, unconditionally.      mode 0: never (stable total order (key, input position)).
- * Initial value: MA_EXACT_TIES in the environment (unset = 2).  On a shard (mahip_set_shard) the repair is not available:
- * mode 1 fails there, mode 2 reports the census (mahip_tie_stats) and leaves the stable order. */
+ * Initial value: MA_EXACT_TIES in the environment (unset = 2).  On a shard (mahip_set_shard) the census and the repair run after the
+ * arc exchange, driven by the orchestrator (host/sharded.c; the split entry points are listed with the sharded building blocks). */
 int mahip_set_exact_ties(mahip_ctx_t *c, int mode);
 typedef struct {
 	uint64_t arc_tie_groups;   /* groups of >= 2 arcs with equal (u,len) after the last ma_sg_gen */
@@ -194,6 +194,17 @@ int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc);
 int mahip_asg_export_rows(mahip_ctx_t *c, void *d_dst);
 /* replace the graph by the concatenation of n_ranks blocks of rows (block r holds counts[r] rows at d_src + r*stride rows) */
 int mahip_asg_import_rows(mahip_ctx_t *c, const void *d_src, const uint32_t *counts, int n_ranks, size_t stride);
+/* Tie repair on shards: after the arc exchange every rank holds the whole sorted graph and its tie census
+ * (mahip_tie_stats).  With tie groups: (1) mahip_sg_push_conflicts counts this rank's consecutive pushed arcs whose hits had equal
+ * (qid,qs); if the sum over the ranks is > 0, mahip_sg_push_fix puts this rank's pushed arcs into the reference's hit order -- it
+ * walks ALL hit keys, so the context must hold the whole input (mahip_set_full_input(c, 1), the default; a caller that only handed
+ * over the rank's own records says 0 and gets an error here); (2) the ranks exchange their push-order rows
+ * (mahip_asg_export_rows_push) and mahip_asg_import_push_rows builds the reference's arc order from the global push sequence. */
+int mahip_set_full_input(mahip_ctx_t *c, int full);
+int mahip_sg_push_conflicts(mahip_ctx_t *c, uint64_t *n_conf);
+int mahip_sg_push_fix(mahip_ctx_t *c);
+int mahip_asg_export_rows_push(mahip_ctx_t *c, void *d_dst);
+int mahip_asg_import_push_rows(mahip_ctx_t *c, const void *d_src, const uint32_t *counts, int n_ranks, size_t stride);
 /* asg.c:148-186 marking for the vertices [v_beg, v_end) only, no cleanup */
 int mahip_asg_del_trans_range(mahip_ctx_t *c, int fuzz, uint32_t v_beg, uint32_t v_end, uint32_t *n_reduced);
 /* the ol|del column of arcs [first, first+count) out of / into the graph */

@@ -444,6 +444,24 @@ __global__ __launch_bounds__(256) void k_seq_to_aos(const uint32_t *__restrict__
 
 // ================================================================================================ host side
 
+// ---- sharded mode: arcs as packed rows {u, v, len, ol} ----
+__global__ __launch_bounds__(256) void k_arc_rows_out(ArcCols a, size_t n, uint4 *__restrict__ rows)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) rows[i] = make_uint4(a.u[i], a.v[i], a.len[i], a.ol[i]);
+}
+__global__ __launch_bounds__(256) void k_arc_rows_in(const uint4 *__restrict__ rows, size_t n, size_t dst0, ArcCols a)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) { uint4 r = rows[i]; a.u[dst0 + i] = r.x; a.v[dst0 + i] = r.y; a.len[dst0 + i] = r.z; a.ol[dst0 + i] = r.w; }
+}
+
+__global__ __launch_bounds__(256) void k_rows_permute(const uint4 *__restrict__ in, size_t n, const uint32_t *__restrict__ perm, uint4 *__restrict__ out)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) out[i] = in[perm[i]];
+}
+
 // reads of the graph / the map that still has to be applied when it leaves the device
 uint32_t graph_nseq(const mahip_ctx *c) { return c->gsq ? c->n_seq_new : c->n_seq; }
 static const int32_t *graph_map(mahip_ctx *c) { return c->has_map && !c->gsq ? (const int32_t*)P<int32_t>(c->map) : (const int32_t*)nullptr; }
@@ -526,7 +544,7 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 	if (c->prof) prof_patch_last(c, "k_sg_arcs", 64.0 * (double)c->n_live); // units = hits left after containment (64 B each)
 	c->n_arc = 0; c->ag = 0;
 	const bool sharded = c->q_beg > 0 || (c->n_seq && c->q_end < c->n_seq);
-	const bool want_slots = c->tie_mode != 0 && c->sorted_here && c->sidx.p != nullptr && !sharded; // the hit order can be repaired
+	const bool want_slots = c->tie_mode != 0 && c->sorted_here && c->sidx.p != nullptr; // the hit order can be repaired (on a shard: by the orchestrator, after the exchange)
 	{ const uint64_t keep_hit_ties = c->tie.hit_ties; const int keep_walk = c->hrank_ready; memset(&c->tie, 0, sizeof(c->tie)); c->tie.hit_ties = keep_hit_ties; c->tie.hit_walk = keep_walk; }
 	if (n) {
 		const size_t n_tiles = (n + SG_TILE - 1) / SG_TILE;
@@ -551,30 +569,35 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 			                   want_slots ? P<uint32_t>(c->aslot) : (uint32_t*)nullptr);
 		}
 	} else CHK(reserve_arcs(c, 0));
+	c->n_push = 0;
+	if (sharded && c->tie_mode != 0) { // keep this rank's arcs in push order: the exchange overwrites the arc arrays, a tie repair needs them (sharded.c)
+		CHK(dev_reserve(c, c->pushrows[0], ((size_t)c->n_arc + 1) * 16));
+		if (c->n_arc) hipLaunchKernelGGL(k_arc_rows_out, dim3(grid_for(c->n_arc, 256)), dim3(256), 0, c->st, arcs_of(c, c->ag), (size_t)c->n_arc, (uint4*)c->pushrows[0].p);
+		c->n_push = c->n_arc;
+	}
 	if (c->n_arc > 1) {
 		size_t m = c->n_arc;
 		for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }
 		ArcCols in = arcs_of(c, c->ag), out = arcs_of(c, c->ag ^ 1);
 		unsigned long long *ctr = P<unsigned long long>(c->ctr);
 		const int32_t *map = c->has_map ? (const int32_t*)P<int32_t>(c->map) : (const int32_t*)nullptr;
-		int gen = 0, need_walk = c->tie_mode == 1;
-		if (c->tie_mode != 1) { // stable sort (asg.c:24 up to the order of equal keys), then the census
+		int gen = 0, need_walk = c->tie_mode == 1 && !sharded;
+		if (c->tie_mode != 1 || sharded) { // stable sort (asg.c:24 up to the order of equal keys), then the census (on a shard: after the exchange, sharded.c)
 			hipLaunchKernelGGL(k_arc_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
 			CHK(radix_sort_pairs(c, m, 0, bitlen_u64(c->h_ctr[CT_MAXLEN]), 32, 32 + bitlen_u64(2ull * R), &gen));
 			{
 				ProfScope ps(c, "k_arc_permute", 36.0 * (double)m);
 				hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, (const uint32_t*)P<uint32_t>(c->val[gen]), out);
 			}
-			if (c->tie_mode == 2) {
+			if (c->tie_mode == 2 && !sharded) {
 				HIPCHK(hipMemsetAsync(ctr + CT_STICKY, 0, (64 - CT_STICKY) * 8, c->st));
 				ProfScope ps(c, "k_arc_tie_census", 8.0 * (double)m);
 				hipLaunchKernelGGL(k_arc_tie_census, dim3(grid_for(m, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[gen]), m, ctr);
 				CHK(ctr_fetch(c));
 				c->tie.arc_tie_groups = c->h_ctr[ST_ARC_TIE_GROUPS]; c->tie.arc_tie_arcs = c->h_ctr[ST_ARC_TIE_ARCS];
 				need_walk = c->tie.arc_tie_groups > 0;
-				if (need_walk && sharded) need_walk = 0, c->tie.unrepaired = 1; // the order is a function of the whole graph: reported, not repaired, on a shard
 			}
-		} else if (sharded) { mahip_set_error("mahip_sg_gen: exact tie order (mode 1) is not available on a shard"); return -1; }
+		}
 		if (need_walk) {
 			// (1) the push order: arcs leave ma_sg_gen in hit order (asm.c:18-35), and the reference's hit order differs from the stable
 			//     one inside runs of equal (qid,qs).  Only if two arcs come from one such run does that reach the arcs.
@@ -622,18 +645,6 @@ extern "C" int mahip_sg_gen(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, co
 	return mahip_sg_finish(c, n_arc);
 }
 
-// ---- sharded mode: arcs as packed rows {u, v, len, ol} ----
-__global__ __launch_bounds__(256) void k_arc_rows_out(ArcCols a, size_t n, uint4 *__restrict__ rows)
-{
-	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (i < n) rows[i] = make_uint4(a.u[i], a.v[i], a.len[i], a.ol[i]);
-}
-__global__ __launch_bounds__(256) void k_arc_rows_in(const uint4 *__restrict__ rows, size_t n, size_t dst0, ArcCols a)
-{
-	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (i < n) { uint4 r = rows[i]; a.u[dst0 + i] = r.x; a.v[dst0 + i] = r.y; a.len[dst0 + i] = r.z; a.ol[dst0 + i] = r.w; }
-}
-
 extern "C" int mahip_asg_export_rows(mahip_ctx_t *c, void *d_dst)
 {
 	HIPCHK(hipSetDevice(c->dev));
@@ -672,6 +683,77 @@ extern "C" int mahip_asg_import_rows(mahip_ctx_t *c, const void *d_src, const ui
 		c->tie.unrepaired = c->tie.arc_tie_groups > 0;
 	}
 	if (c->own_stream) HIPCHK(hipStreamSynchronize(c->st)); // a caller-owned stream orders the exchange itself (sharded mode: the collectives are queued on it)
+	c->graph_ready = true;
+	return 0;
+}
+
+// ---- tie repair on shards (host/sharded.c) ----
+// consecutive arcs this rank pushed from hits with equal original (qid,qs) keys
+extern "C" int mahip_sg_push_conflicts(mahip_ctx_t *c, uint64_t *n_conf)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	*n_conf = 0;
+	if (c->n_push < 2 || !c->aslot.p || !c->sidx.p) return 0;
+	unsigned long long *ctr = P<unsigned long long>(c->ctr);
+	HIPCHK(hipMemsetAsync(ctr + ST_PUSH_CONFLICTS, 0, 8, c->st));
+	hipLaunchKernelGGL(k_arc_push_conflicts, dim3(grid_for(c->n_push, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->aslot), (size_t)c->n_push, c->d_aos,
+	                   (const uint32_t*)P<uint32_t>(c->sidx), ctr);
+	CHK(ctr_fetch(c));
+	*n_conf = c->h_ctr[ST_PUSH_CONFLICTS];
+	return 0;
+}
+
+// this rank's pushed arcs into the order the reference's hit order gives them (needs the whole input on this context: mahip_set_full_input)
+extern "C" int mahip_sg_push_fix(mahip_ctx_t *c)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	const size_t m = c->n_push;
+	if (m < 2) return 0;
+	CHK(hits_reference_rank(c));
+	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }
+	CHK(dev_reserve(c, c->pushrows[1], (m + 1) * 16));
+	hipLaunchKernelGGL(k_arc_push_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->aslot), (const uint32_t*)P<uint32_t>(c->hrank), m, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
+	int g = 0;
+	CHK(radix_sort_pairs(c, m, 0, 32, 0, 0, &g)); // hrank holds positions in the global order: up to 32 bits
+	hipLaunchKernelGGL(k_rows_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint4*)c->pushrows[0].p, m, (const uint32_t*)P<uint32_t>(c->val[g]), (uint4*)c->pushrows[1].p);
+	HIPCHK(hipMemcpyAsync(c->pushrows[0].p, c->pushrows[1].p, m * 16, hipMemcpyDeviceToDevice, c->st));
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int mahip_asg_export_rows_push(mahip_ctx_t *c, void *d_dst)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (c->n_push) HIPCHK(hipMemcpyAsync(d_dst, c->pushrows[0].p, (size_t)c->n_push * 16, hipMemcpyDeviceToDevice, c->st));
+	return 0;
+}
+
+// Replace the graph by the reference's sort of the GLOBAL push sequence: n_ranks blocks of rows in push order (rank order = hit order), keys from
+// the squeezed ids, the host walk (identical on every rank), permute, index.  Every rank calls it with the same data and gets the same graph.
+extern "C" int mahip_asg_import_push_rows(mahip_ctx_t *c, const void *d_src, const uint32_t *counts, int n_ranks, size_t stride)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	size_t tot = 0;
+	for (int r = 0; r < n_ranks; ++r) tot += counts[r];
+	if (tot >= 0x7fffffffull) { mahip_set_error("mahip_asg_import_push_rows: too many arcs"); return -1; }
+	CHK(reserve_arcs(c, tot));
+	c->ag = 0; c->gsq = false;
+	ArcCols in = arcs_of(c, 0), out = arcs_of(c, 1);
+	size_t off = 0;
+	for (int r = 0; r < n_ranks; ++r) {
+		if (counts[r]) hipLaunchKernelGGL(k_arc_rows_in, dim3(grid_for(counts[r], 256)), dim3(256), 0, c->st, (const uint4*)d_src + (size_t)r * stride, (size_t)counts[r], off, in);
+		off += counts[r];
+	}
+	c->n_arc = (uint32_t)tot;
+	if (tot > 1) {
+		for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (tot + 1) * 8)); CHK(dev_reserve(c, c->val[k], (tot + 1) * 4)); }
+		hipLaunchKernelGGL(k_arc_keys_ref, dim3(grid_for(tot, 256)), dim3(256), 0, c->st, in, tot, graph_map(c), P<uint64_t>(c->key[0]));
+		CHK(reference_order(c, P<uint64_t>(c->key[0]), tot, P<uint32_t>(c->val[1])));
+		hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(tot, 256)), dim3(256), 0, c->st, in, tot, (const uint32_t*)P<uint32_t>(c->val[1]), out);
+		c->ag = 1;
+	}
+	CHK(arc_reindex(c));
+	c->tie.arc_walk = 1; c->tie.unrepaired = 0;
 	c->graph_ready = true;
 	return 0;
 }

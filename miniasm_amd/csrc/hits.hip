@@ -683,7 +683,7 @@ static int reserve_read_arrays(mahip_ctx *c)
 
 static int hits_common_setup(mahip_ctx *c, size_t n, uint32_t n_seq)
 {
-	c->n_hits = n; c->n_live = n; c->n_seq = n_seq; c->n_seq_new = n_seq;
+	c->n_hits = n; c->n_in = n; c->n_live = n; c->n_seq = n_seq; c->n_seq_new = n_seq;
 	c->soa_ready = false; c->has_map = false; c->graph_ready = false;
 	c->hint_max_qs = 0; // hints describe one upload: set them again after every upload/adopt
 	c->lazy_squeeze = false;
@@ -756,6 +756,12 @@ extern "C" int mahip_set_shard(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end)
 	return 0;
 }
 
+extern "C" int mahip_set_full_input(mahip_ctx_t *c, int full)
+{
+	c->full_input = full != 0;
+	return 0;
+}
+
 
 extern "C" int mahip_set_hints(mahip_ctx_t *c, uint32_t max_qs)
 {
@@ -802,16 +808,17 @@ __global__ __launch_bounds__(256) void k_hit_rank(const uint32_t *__restrict__ s
 int hits_reference_rank(mahip_ctx *c)
 {
 	if (c->hrank_ready) return 0;
-	const size_t n = c->n_hits;
+	const size_t n = c->n_hits, N = c->n_in; // slots of this context / records of the input
 	if (!c->sorted_here || !c->sidx.p || !c->d_aos) { mahip_set_error("hits_reference_rank: the hits were not sorted by this context"); return -1; }
-	if (ctx_sharded(c)) { mahip_set_error("hits_reference_rank: the reference's tie order is a function of the whole input; not available on a shard"); return -1; }
+	if (ctx_sharded(c) && !c->full_input) { mahip_set_error("hits_reference_rank: the reference's tie order is a function of the whole input; this context only holds a shard of it"); return -1; }
 	CHK(dev_reserve(c, c->hrank, (n + 1) * 4));
 	if (n == 0) { c->hrank_ready = true; return 0; }
-	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (n + 1) * 8)); CHK(dev_reserve(c, c->val[k], (n + 1) * 4)); }
-	hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
+	// the walk runs over ALL input records (on a shard: every rank repeats it and keeps the ranks of its own slots; sidx holds global positions)
+	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (N + 1) * 8)); CHK(dev_reserve(c, c->val[k], (N + 1) * 4)); }
+	hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(N, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, N, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
 	                   (uint32_t*)nullptr, P<unsigned long long>(c->ctr), 0u, 0xffffffffu, 32, 0, 0, 0); // key = qid<<32 | qs, input order
-	CHK(reference_order(c, P<uint64_t>(c->key[0]), n, P<uint32_t>(c->val[1])));
-	hipLaunchKernelGGL(k_perm_invert, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->val[1]), n, P<uint32_t>(c->val[0]));
+	CHK(reference_order(c, P<uint64_t>(c->key[0]), N, P<uint32_t>(c->val[1])));
+	hipLaunchKernelGGL(k_perm_invert, dim3(grid_for(N, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->val[1]), N, P<uint32_t>(c->val[0]));
 	hipLaunchKernelGGL(k_hit_rank, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->sidx), (const uint32_t*)P<uint32_t>(c->val[0]), n, P<uint32_t>(c->hrank));
 	HIPCHK(hipGetLastError());
 	c->hrank_ready = true;

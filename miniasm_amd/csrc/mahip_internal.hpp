@@ -33,6 +33,8 @@ struct mahip_ctx {
 
 	// ---- hits ----
 	size_t n_hits = 0;        // slots (live + dead)
+	size_t n_in = 0;          // records at d_aos (= n_hits unless a shard range dropped some at the sort)
+	bool full_input = true;   // d_aos holds the WHOLE input (false: the caller handed over this rank's records only)
 	size_t n_live = 0;
 	uint32_t n_seq = 0;       // reads, original numbering
 	uint32_t q_beg = 0, q_end = 0xffffffffu; // shard
@@ -56,6 +58,8 @@ struct mahip_ctx {
 	DevBuf sidx;              // u32 [n_hits] input position of the record in each sorted slot
 	DevBuf hrank;             // u32 [n_hits] position of each sorted slot in the reference's order (identity outside tie runs)
 	DevBuf aslot;             // u32 [n_arc]  hit slot every pushed arc came from
+	DevBuf pushrows[2];       // sharded mode: this rank's arcs in push order as packed rows (the arc arrays are overwritten by the exchange)
+	uint32_t n_push = 0;
 	bool sorted_here = false, hrank_ready = false; // hits sorted by mahip_hits_sort (d_aos = the unsorted input) / hrank valid
 	mahip_tie_info_t tie = {0, 0, 0, 0, 0, 0, 0};
 	uint32_t n_seq_new = 0;

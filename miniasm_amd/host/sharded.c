@@ -58,8 +58,8 @@ static void exchange_flags(mahip_ctx_t *c, uint32_t n_seq, int world, int n_whic
 
 /* The device passes of one input on this rank's shard, up to the reduced graph.  c holds the unsorted hits of (at least) this
  * rank's read range and a communicator (mahip_comm_init*).  Afterwards rank 0's context holds the reduced, symmetrised graph. */
-int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq, ma_shard_stats_t *st)
-{
+int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq, int full_input, ma_shard_stats_t *st)
+{ /* full_input: c holds ALL hit records of the input (every rank parsed the text), not just this rank's: the tie repair can then also restore the hit order */
 	const int world = mahip_comm_world(c), rank = mahip_comm_rank(c);
 	uint32_t per, q0, q1, n_loc = 0, n_red = 0, n_seq_new = 0, i;
 	size_t n_rem1 = 0, n_rem2 = 0, n_cut = 0, n_flt = 0, n_hits = 0;
@@ -69,6 +69,7 @@ int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq
 	size_t stride = 1, first = 0, tot = 0;
 	memset(st, 0, sizeof(*st));
 	shard_range(n_seq, world, rank, &per, &q0, &q1);
+	GPU(mahip_set_full_input(c, full_input || world == 1));
 	GPU(mahip_set_shard(c, world > 1 ? q0 : 0, world > 1 ? q1 : 0xffffffffu));
 	GPU(mahip_hits_sort(c));
 	GPU(mahip_hits_sub(c, opt->min_dp, opt->min_iden, 0, 0, &n_rem1));
@@ -98,7 +99,27 @@ int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq
 		GPU(mahip_comm_all_gather(c, rows, all, stride * 16));
 		GPU(mahip_asg_import_rows(c, all, counts, world, stride));
 	}
-	{ mahip_tie_info_t ti; mahip_tie_stats(c, &ti); st->tie_groups = ti.arc_tie_groups; }
+	if (world > 1) { /* tie order: the census ran on the merged graph; groups of equal (u,len) keys -> the reference's order */
+		mahip_tie_info_t ti;
+		mahip_tie_stats(c, &ti);
+		st->tie_groups = ti.arc_tie_groups;
+		if (ti.unrepaired) {
+			uint64_t conf = 0;
+			GPU(mahip_sg_push_conflicts(c, &conf));
+			GPU(mahip_comm_all_reduce_sum_u64(c, &conf, 1));
+			st->push_conflicts = conf;
+			if (conf == 0 || full_input) {
+				void *rows, *all;
+				if (conf) GPU(mahip_sg_push_fix(c)); /* every rank walks the hit keys of the whole input and keeps the ranks of its own hits */
+				GPU(mahip_xbuf(c, 0, stride * 16, &rows));
+				GPU(mahip_xbuf(c, 1, stride * 16 * world, &all));
+				GPU(mahip_asg_export_rows_push(c, rows));
+				GPU(mahip_comm_all_gather(c, rows, all, stride * 16));
+				GPU(mahip_asg_import_push_rows(c, all, counts, world, stride)); /* the same walk over the same global push sequence on every rank */
+				st->tie_repaired = 1;
+			}
+		}
+	} else { mahip_tie_info_t ti; mahip_tie_stats(c, &ti); st->tie_groups = ti.arc_tie_groups; st->tie_repaired = ti.arc_walk; }
 	GPU(mahip_asg_del_trans_range(c, opt->gap_fuzz, 2 * q0, world > 1 ? 2 * q1 : 2 * n_seq, &n_red));
 	if (world > 1) { /* the del flags of the own block -> everyone (only rank 0 needs them; kept symmetric) */
 		char *fl, *all;
@@ -175,7 +196,7 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 	r = ma_hit_ingest_gpu_excl(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), (flags & 8) != 0, opt->max_hang, opt->int_frac);
 	if (r == -1) { fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn); exit(1); }
 	if (r != 0) { fprintf(stderr, "[E::%s] the text does not fit the device stage; MA_GPUS > 1 needs the device parser\n", __func__); exit(1); }
-	ma_pipeline_head_sharded(c, opt, d->n_seq, &st);
+	ma_pipeline_head_sharded(c, opt, d->n_seq, 1, &st);
 	if (rank == 0) {
 		fprintf(lg, "[M::%s] ===> Step 2: 1-pass (crude) read selection <===\n", "main");
 		if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)st.n_rem1);
@@ -186,9 +207,9 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 		}
 		fprintf(lg, "[M::%s] ===> Step 4: graph cleaning <===\n", "main");
 		fprintf(lg, "[M::%s] read %d arcs\n", "ma_sg_gen", st.n_arc);
-		if (st.tie_groups && world > 1)
-			fprintf(stderr, "[W::%s] %llu groups of arcs with equal (u,len) keys: the reference leaves such arcs in an order that depends on the whole input; "
-			        "it is reproduced on one GPU, not on shards -- the output may differ from the reference's inside those groups\n", __func__, (unsigned long long)st.tie_groups);
+		if (st.tie_groups && !st.tie_repaired)
+			fprintf(stderr, "[W::%s] %llu groups of arcs with equal (u,len) keys were left in the stable order: the output may differ from the reference's inside those groups\n",
+			        __func__, (unsigned long long)st.tie_groups);
 		fprintf(lg, "[M::%s] ===> Step 4.1: transitive reduction <===\n", "main");
 		fprintf(lg, "[M::%s] transitively reduced %d arcs\n", "asg_arc_del_trans", st.n_red);
 		if (st.n_red) {

@@ -145,6 +145,26 @@ def test_cli_on_n_ranks_matches_one_gpu_and_reference(world, case, tmpdir_s):
     assert r.returncode == 0 and r.stdout == R.run_cli(ma.CLI_PATH, ["-p", "sg"], paf)[0]
 
 
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("world", [2, 3])
+def test_cli_on_n_ranks_reproduces_the_reference_tie_order(world, tmpdir_s):
+    """tie-rich input on shards: the census runs on the merged graph, the ranks restore the reference's hit order for their own pushed arcs
+    (every rank holds the whole input) and rebuild the reference's arc order from the global push sequence -- GFA and string-graph dump
+    byte-identical to the reference's, as on one GPU"""
+    import subprocess
+    paf = R.pafgen(os.path.join(tmpdir_s, "shc_ties.paf"), 3000, 80000, 5, ["-q", "16", "-L", "uniform", "-d", "0.3", "-x", "0.03"])
+    ref_sg, _ = R.run_cli(R.REF_BIN, ["-p", "sg", "-S5"], paf)
+    assert R.arc_tie_groups(ref_sg) >= 5
+    env = dict(os.environ, MA_GPUS=str(world), MA_COMM="shm")
+    env.pop("MA_EXACT_TIES", None)
+    for args in ([], ["-p", "sg", "-S6"], ["-p", "sg"]):
+        ref, _ = R.run_cli(R.REF_BIN, args, paf)
+        r = subprocess.run([ma.CLI_PATH] + args + [paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert b"left in the stable order" not in r.stderr
+        assert r.stdout == ref, "%d ranks, %s: bytes differ from the reference" % (world, " ".join(args))
+
+
 @pytest.mark.skipif(ma.lib().mahip_device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
 def test_cli_on_two_gpus_over_rccl(tmpdir_s):
     import subprocess

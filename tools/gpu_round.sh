@@ -17,6 +17,10 @@ all_tests)
 graphapi)
   timeout 1500 python -m pytest tests/test_gpu_graph_api.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/tests_graphapi.log 2>&1; echo "rc=$?" >> gpurun_out/tests_graphapi.log
   grep -vE "^\[M::|^\[pafgen" gpurun_out/tests_graphapi.log | tail -40 ;;
+benchtiming)
+  MA_PIPE_TIMING=1 timeout 900 python bench.py --no-cpu --no-text --steps 5 --warmup 1 > gpurun_out/bench_timing.json 2> gpurun_out/bench_timing.log; echo "rc=$?"
+  grep -E "^\[bench\]|T::paf|T::xfer|T::ingest" gpurun_out/bench_timing.log | head -40; python3 -c "
+import json; d=json.load(open('gpurun_out/bench_timing.json')); print(d['ms_per_step'], d['e2e'], d['setup']); [print(k['name'], k['launches_per_step'], k['avg_ms']) for k in d['kernels'][:8]]" ;;
 e2ecfg4)
   NOREF=1 bash tools/e2e_cfg4.sh | tail -60 ;;
 bignoisy)
