@@ -89,50 +89,59 @@ struct HitCols { uint32_t *qid, *qs, *qe, *tn, *ts, *te, *ml, *bl; };
 // AoS (input order) -> SoA (sorted order): one 32-byte record per lane as 2 x dwordx4 through the permutation held
 // in the sorted keys (low bi bits) or in perm[]; group offsets from the query-id boundaries of the sorted keys.
 // skey == nullptr: identity (input already grouped: the per-symbol path).
+#define GATHER_ILP 2 // slots per thread: two independent request chains in flight per lane (the record fetch is a dependent chain: key -> record)
 __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__ h, const uint64_t *__restrict__ skey, const uint32_t *__restrict__ perm,
                                                      int qshift, int bi, size_t n, uint32_t n_seq, HitCols c, uint32_t *__restrict__ goff, uint32_t *__restrict__ sidx,
                                                      int drop, int bs, size_t n_in)
 { // sidx (optional): input position of the record in every sorted slot -- what the tie-order repair needs to find a slot's original key
   // drop == 1: the key holds (input position >> 1); the record is the one of the pair whose (qid,qs) equals the key's -- the second one if
   // both do and this slot is the second of its run of equal keys (the sort is stable: candidates of one run are in input order)
-	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (i > n) return;
-	uint32_t q = n_seq, qprev = 0;
-	int first = (i == 0);
-	if (i < n) {
-		size_t j = i;
-		uint4 a, b;
-		bool have = false;
-		if (perm) j = perm[i];
-		else if (skey) {
-			const uint64_t K = skey[i];
-			j = (size_t)(K & ((1ull << bi) - 1)) << drop;
-			if (drop) { // drop == 1: the record is one of the pair (j, j+1), which share a 64-byte line.  The first half of the even record
-				// decides; only the halves that are needed are requested (measured: asking for all four quarters of the line per lane
-				// costs more than the dependent second request -- the kernel is bound by outstanding requests, not by bytes)
-				const uint64_t want = K >> bi;
-				const uint4 *p = (const uint4*)(h + j);
-				const bool two = j + 1 < n_in;
-				const uint4 a0 = p[0];                                                  // a = {qs, qid, qe, tn}
-				const bool second_of_run = i > 0 && skey[i - 1] == K;                 // equal keys are adjacent and in input order (stable sort)
-				const bool m0 = (((uint64_t)a0.y << bs) | a0.x) == want;
-				const bool pick1 = two && (second_of_run || !m0);
-				if (pick1) { a = p[2]; b = p[3]; } else { a = a0; b = p[1]; }
-				j += pick1;
-				have = true;
-			}
+	size_t i[GATHER_ILP], j[GATHER_ILP];
+	uint64_t K[GATHER_ILP];
+	uint4 a[GATHER_ILP], b[GATHER_ILP];
+	bool act[GATHER_ILP], pick1[GATHER_ILP];
+#pragma unroll
+	for (int u = 0; u < GATHER_ILP; ++u) { // keys / permutation entries of all slots first
+		i[u] = ((size_t)blockIdx.x * GATHER_ILP + u) * 256 + threadIdx.x;
+		act[u] = i[u] < n; pick1[u] = false; K[u] = 0; j[u] = i[u];
+		if (act[u]) {
+			if (perm) j[u] = perm[i[u]];
+			else if (skey) { K[u] = skey[i[u]]; j[u] = (size_t)(K[u] & ((1ull << bi) - 1)) << drop; }
 		}
-		if (!have) { const uint4 *p = (const uint4*)(h + j); a = p[0]; b = p[1]; } // a = {qs, qid, qe, tn}  b = {ts, te, ml|rev, bl|del}
-		q = a.y;
-		if (sidx) sidx[i] = (uint32_t)j;
-		c.qid[i] = a.y; c.qs[i] = a.x; c.qe[i] = a.z; c.tn[i] = a.w;
-		c.ts[i] = b.x; c.te[i] = b.y; c.ml[i] = b.z; c.bl[i] = b.w & ~DEAD;
 	}
-	if (!first) qprev = skey ? (uint32_t)(skey[i - 1] >> qshift) : (uint32_t)(h[perm ? perm[i - 1] : i - 1].qns >> 32);
-	// reads qprev+1 .. q start at slot i (reads without hits get empty groups)
-	uint32_t r0 = first ? 0 : qprev + 1;
-	if (q > n_seq) q = n_seq;
-	for (uint32_t r = r0; r <= q && r <= n_seq; ++r) goff[r] = (uint32_t)i;
+#pragma unroll
+	for (int u = 0; u < GATHER_ILP; ++u) if (act[u]) a[u] = ((const uint4*)(h + j[u]))[0]; // a = {qs, qid, qe, tn}
+	if (drop && skey && !perm) {
+#pragma unroll
+		for (int u = 0; u < GATHER_ILP; ++u)
+			if (act[u]) { // the pair (j, j+1) shares a 64-byte line; the first half of the even record decides
+				const bool two = j[u] + 1 < n_in, second_of_run = i[u] > 0 && skey[i[u] - 1] == K[u];
+				const bool m0 = (((uint64_t)a[u].y << bs) | a[u].x) == (K[u] >> bi);
+				pick1[u] = two && (second_of_run || !m0);
+				j[u] += pick1[u];
+			}
+	}
+#pragma unroll
+	for (int u = 0; u < GATHER_ILP; ++u)
+		if (act[u]) { const uint4 *p = (const uint4*)(h + j[u]); if (pick1[u]) a[u] = p[0]; b[u] = p[1]; } // b = {ts, te, ml|rev, bl|del}
+#pragma unroll
+	for (int u = 0; u < GATHER_ILP; ++u) {
+		if (i[u] > n) continue;
+		uint32_t q = n_seq, qprev = 0;
+		const bool first = i[u] == 0;
+		if (act[u]) {
+			const size_t s = i[u];
+			q = a[u].y;
+			if (sidx) sidx[s] = (uint32_t)j[u];
+			c.qid[s] = a[u].y; c.qs[s] = a[u].x; c.qe[s] = a[u].z; c.tn[s] = a[u].w;
+			c.ts[s] = b[u].x; c.te[s] = b[u].y; c.ml[s] = b[u].z; c.bl[s] = b[u].w & ~DEAD;
+		}
+		if (!first) qprev = skey ? (uint32_t)(skey[i[u] - 1] >> qshift) : (uint32_t)(h[perm ? perm[i[u] - 1] : i[u] - 1].qns >> 32);
+		// reads qprev+1 .. q start at slot i (reads without hits get empty groups)
+		const uint32_t r0 = first ? 0 : qprev + 1;
+		if (q > n_seq) q = n_seq;
+		for (uint32_t r = r0; r <= q && r <= n_seq; ++r) goff[r] = (uint32_t)i[u];
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ ma_hit_sub
@@ -899,7 +908,7 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	else CHK(radix_sort_pairs(c, n, 0, bs + bq, 0, 0, &gen));
 	{
 		ProfScope ps(c, "k_hit_gather", (pk ? 72.0 : 76.0) * (double)n); // key 8 (+ index 4) + record 32 + columns 32
-		hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)P<uint64_t>(c->key[gen]),
+		hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256 * GATHER_ILP)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)P<uint64_t>(c->key[gen]),
 		                   pk ? (const uint32_t*)nullptr : (const uint32_t*)P<uint32_t>(c->val[gen]), pk ? bi + bs : bs, bi, n, c->n_seq, h, P<uint32_t>(c->goff),
 		                   want_sidx ? P<uint32_t>(c->sidx) : (uint32_t*)nullptr, drop, bs, n_in);
 	}
@@ -914,7 +923,7 @@ extern "C" int mahip_hits_index(mahip_ctx_t *c)
 	size_t n = c->n_hits;
 	HitCols h = cols_of(c);
 	ProfScope ps(c, "k_hit_gather", 64.0 * (double)n);
-	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)nullptr, (const uint32_t*)nullptr, 32, 0, n, c->n_seq, h, P<uint32_t>(c->goff), (uint32_t*)nullptr, 0, 0, n);
+	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256 * GATHER_ILP)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)nullptr, (const uint32_t*)nullptr, 32, 0, n, c->n_seq, h, P<uint32_t>(c->goff), (uint32_t*)nullptr, 0, 0, n);
 	HIPCHK(hipGetLastError());
 	c->soa_ready = true;
 	c->sorted_here = false; c->hrank_ready = false; // the caller's order is final (per-symbol path: already the reference's)
