@@ -383,6 +383,12 @@ def main():
                     "frac_counter": round(traffic / (dom["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                     "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
                     "note": "achieved = SURVEY 8(d) algorithmic bytes of the reference passes this kernel replaces / HIP-event launch time"}
+            # the whole hit chain by the same accounting: SURVEY 8(d) sums the reference's passes to 584 B per stored hit
+            chain_bytes = 584.0 * float(W.n_my)
+            step_s = dt / args.steps
+            roof["hit_chain"] = {"alg_bytes_per_step": chain_bytes, "achieved": round(chain_bytes / step_s / 1e9, 1), "unit": "GB/s",
+                                 "frac": round(chain_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                                 "note": "584 B per stored hit (SURVEY 8(d), sum over the reference's passes) x hits of this rank / measured step time"}
     run.close()
 
     # ---- the same job started one stage earlier: PAF TEXT resident in HBM -> device-side parse + dictionary -> ... -> GFA

@@ -61,8 +61,8 @@ int mahip_hits_raw_download(mahip_ctx_t *c, ma_hit_t *out);                 /* t
  * them); *n_out = their number.  Lets a caller keep the records of one read-range shard (bench.py, multi-GPU set-up). */
 int mahip_hits_raw_extract(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end, void *d_dst, size_t *n_out);
 
-/* optional: an upper bound of the query starts (e.g. the longest read) lets the sort plan its digits without a
- * device round trip; 0 = unknown */
+/* optional: an upper bound of the query starts (e.g. the longest read) lets the on-demand (qid,qs) sorts (hit dumps, push order
+ * of the arcs) plan their digits without a sweep over the records; 0 = unknown */
 int mahip_set_hints(mahip_ctx_t *c, uint32_t max_qs);
 /* Bulk copies between pageable host memory and device memory at PCIe speed: worker threads stage slices through
  * pinned slots while their DMAs run (a plain hipMemcpy of pageable memory is staged by one runtime thread).
@@ -90,7 +90,10 @@ typedef struct {
 	int unrepaired;            /* 1 if tie groups exist and the stable order was kept (mode 0, or a shard) */
 } mahip_tie_info_t;
 int mahip_tie_stats(mahip_ctx_t *c, mahip_tie_info_t *out);
-/* hit.c:19-22 ma_hit_sort: LSD radix sort by (query id, query start, input order) -> SoA + group offsets */
+/* hit.c:19-22 ma_hit_sort.  The resident layout is GROUPED by query id (stable LSD radix sort on the id bits -> SoA + group offsets),
+ * input order inside a group: ma_hit_sub / cut / flt / contained do not look at the order inside a group (hit.c:109-160 sorts its own
+ * events).  The (qid, qs) order of ma_hit_sort -- with the reference's order of equal keys, see "Tie order" above -- is produced where
+ * it can be observed: mahip_hits_download sorts the slots' original keys on demand, mahip_sg_finish orders the pushed arcs. */
 int mahip_hits_sort(mahip_ctx_t *c);
 /* same layout change without sorting (input already grouped by query id: the per-symbol ABI path) */
 int mahip_hits_index(mahip_ctx_t *c);
@@ -126,7 +129,8 @@ int mahip_map_download(mahip_ctx_t *c, int32_t *map);                          /
 uint32_t mahip_n_seq_new(mahip_ctx_t *c);                                      /* reads left after contained (else n_seq) */
 int mahip_survivors_download(mahip_ctx_t *c, uint32_t *old_ids);               /* [n_seq_new] new id -> old id */
 size_t mahip_hits_live(mahip_ctx_t *c);
-/* live hits, compacted in array order, ids renumbered if contained has run; out must hold mahip_hits_live() */
+/* live hits, compacted, in the order ma_hit_sort + the order-preserving filters leave them in (hit.c:19-22, 162-258), ids renumbered
+ * if contained has run; out must hold mahip_hits_live() */
 int mahip_hits_download(mahip_ctx_t *c, ma_hit_t *out, size_t *n);
 
 /* ---- string graph ---------------------------------------------------------------------------------- */
@@ -195,8 +199,8 @@ int mahip_asg_export_rows(mahip_ctx_t *c, void *d_dst);
 /* replace the graph by the concatenation of n_ranks blocks of rows (block r holds counts[r] rows at d_src + r*stride rows) */
 int mahip_asg_import_rows(mahip_ctx_t *c, const void *d_src, const uint32_t *counts, int n_ranks, size_t stride);
 /* Tie repair on shards: after the arc exchange every rank holds the whole sorted graph and its tie census
- * (mahip_tie_stats).  With tie groups: (1) mahip_sg_push_conflicts counts this rank's consecutive pushed arcs whose hits had equal
- * (qid,qs); if the sum over the ranks is > 0, mahip_sg_push_fix puts this rank's pushed arcs into the reference's hit order -- it
+ * (mahip_tie_stats).  With tie groups: (1) mahip_sg_push_conflicts puts this rank's pushed arcs into the stable (qid, qs, input position)
+ * order of their hits and counts consecutive ones whose hits had equal (qid,qs); if the sum over the ranks is > 0, mahip_sg_push_fix puts this rank's pushed arcs into the reference's hit order -- it
  * walks ALL hit keys, so the context must hold the whole input (mahip_set_full_input(c, 1), the default; a caller that only handed
  * over the rank's own records says 0 and gets an error here); (2) the ranks exchange their push-order rows
  * (mahip_asg_export_rows_push) and mahip_asg_import_push_rows builds the reference's arc order from the global push sequence. */

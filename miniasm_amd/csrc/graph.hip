@@ -59,10 +59,10 @@ __global__ __launch_bounds__(256) void k_sg_seq(const uint2 *__restrict__ sub, c
 
 // asm.c:18-35 per hit.  The arcs a read pair yields are few next to the hit slots (after containment 99 % of the slots are
 // dead), so nothing is materialised per slot: pass A only applies the seq.del side effects (asm.c:27-34) and takes the
-// maxima; once seq.del is final (after the exchange in the sharded mode) pass B counts the surviving arcs per tile of
-// SG_TILE consecutive hits and pass C -- after a scan of the tile counts -- recomputes them and writes them densely,
-// in hit order (= the reference's push order).  Three sweeps over the dead bits instead of 16 B of arc per slot.
-#define SG_TILE 2048u
+// maxima and leaves one candidate bit per slot; once seq.del is final (after the exchange in the sharded mode) pass B counts the
+// surviving arcs per tile of SG_TILE consecutive hits and pass C -- after a scan of the tile counts -- recomputes them and writes
+// them densely, in slot order.  One sweep over the hits and two over the candidate bits instead of 16 B of arc per slot.
+#define SG_TILE 16384u // hits per tile of passes B and C = 256 mask words
 
 __device__ __forceinline__ int sg_candidate(const HitColsG &h, size_t i, const uint32_t *__restrict__ slen, int max_hang, float int_frac, int min_ovlp,
                                             const uint8_t *__restrict__ lazy_del, mc_arc_t *x, uint32_t *q_, uint32_t *t_, int *self_rc)
@@ -105,35 +105,33 @@ __global__ __launch_bounds__(256) void k_sg_arcs(HitColsG h, size_t n, const uin
 	blk_add_u64(&ctr[CT_LIVE], n_live);
 }
 
-// passes B (out.u == nullptr: count per tile) and C (write): tile b = hits [b*SG_TILE, (b+1)*SG_TILE), row j of a tile = 256 consecutive hits
+// passes B (out.u == nullptr: count per tile) and C (write): one thread per 64-slot word of the candidate mask, tile b = the words
+// [b*256, (b+1)*256) = SG_TILE consecutive hits.  Candidates are rare (a handful per tile): a thread walks the set bits of its word
+// and recomputes those arcs; threads, and the bits inside a word, are in hit order, so the dense slots are too.
 __global__ __launch_bounds__(256) void k_sg_emit(HitColsG h, size_t n, const uint32_t *__restrict__ slen, const uint8_t *__restrict__ sdel,
                                                   int max_hang, float int_frac, int min_ovlp, const unsigned long long *__restrict__ cmask,
                                                   uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off, ArcCols out, uint32_t *__restrict__ aslot)
-{ // aslot (optional, pass C): the hit slot each pushed arc comes from (tie-order repair)
+{ // aslot (optional, pass C): the hit slot each pushed arc comes from (push order, tie-order repair)
 	__shared__ uint32_t s_w[4];
-	const size_t base = (size_t)blockIdx.x * SG_TILE;
-	uint32_t run = out.u ? tile_off[blockIdx.x] : 0, total = 0;
-	for (uint32_t j = 0; j < SG_TILE / 256; ++j) {
-		const size_t i = base + (size_t)j * 256 + threadIdx.x;
-		mc_arc_t x;
-		int keep = 0;
-		if (i < n && (cmask[i >> 6] >> (i & 63) & 1)) { // an arc-yielding slot: recompute the arc (a handful per tile)
-			uint32_t q = 0, t = 0;
-			int self_rc = 0;
-			sg_candidate(h, i, slen, max_hang, int_frac, min_ovlp, nullptr, &x, &q, &t, &self_rc);
-			keep = !sdel[q] && !sdel[t]; // asg_arc_rm on the fresh arcs (asg.c:57-70): endpoints must be alive
-		}
-		if (out.u) { // dense slot = arcs of earlier tiles + earlier rows + earlier lanes of this row
-			uint32_t tot, ex = block_excl_scan_256((uint32_t)keep, s_w, &tot);
-			if (keep) { uint32_t p = run + ex; out.u[p] = x.u; out.v[p] = x.v; out.len[p] = x.len; out.ol[p] = x.ol; if (aslot) aslot[p] = (uint32_t)i; }
-			run += tot;
-		} else total += (uint32_t)keep;
+	const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x, n_words = (n + 63) >> 6;
+	unsigned long long m = w < n_words ? cmask[w] : 0ull, kept = 0;
+	uint32_t cnt = 0;
+	for (unsigned long long rest = m; rest; rest &= rest - 1) { // which candidates survive asg_arc_rm on the fresh arcs (asg.c:57-70): endpoints must be alive
+		const int b = __ffsll((long long)rest) - 1;
+		const size_t i = (w << 6) + (size_t)b;
+		if (i < n && !sdel[h.qid[i]] && !sdel[h.tn[i]]) kept |= 1ull << b, ++cnt;
 	}
-	if (!out.u) {
-		total = wv_sum_u32(total);
-		if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = total;
-		__syncthreads();
-		if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+	uint32_t tot, ex = block_excl_scan_256(cnt, s_w, &tot);
+	if (!out.u) { if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot; return; }
+	uint32_t p = tile_off[blockIdx.x] + ex;
+	for (; kept; kept &= kept - 1, ++p) {
+		const size_t i = (w << 6) + (size_t)(__ffsll((long long)kept) - 1);
+		mc_arc_t x;
+		uint32_t q = 0, t = 0;
+		int self_rc = 0;
+		sg_candidate(h, i, slen, max_hang, int_frac, min_ovlp, nullptr, &x, &q, &t, &self_rc);
+		out.u[p] = x.u; out.v[p] = x.v; out.len[p] = x.len; out.ol[p] = x.ol;
+		if (aslot) aslot[p] = (uint32_t)i;
 	}
 }
 
@@ -184,13 +182,18 @@ __global__ __launch_bounds__(256) void k_arc_tie_census(const uint64_t *__restri
 	blk_add_u64(&ctr[ST_ARC_TIE_GROUPS], groups);
 	blk_add_u64(&ctr[ST_ARC_TIE_ARCS], members);
 }
-// consecutive pushed arcs whose hits had the same ORIGINAL (qid,qs) key: only then does the order of tied hits reach the arcs
-__global__ __launch_bounds__(256) void k_arc_push_conflicts(const uint32_t *__restrict__ aslot, size_t n, const ma_hit_t *__restrict__ h, const uint32_t *__restrict__ sidx,
-                                                             unsigned long long *__restrict__ ctr)
+// the key ma_hit_sort ordered the hit of a pushed arc by: the ORIGINAL qns of the slot's record
+__global__ __launch_bounds__(256) void k_arc_slot_keys(const uint32_t *__restrict__ aslot, size_t n, const ma_hit_t *__restrict__ h, const uint32_t *__restrict__ sidx,
+                                                        uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) { key[i] = h[sidx[aslot[i]]].qns; val[i] = (uint32_t)i; }
+}
+// consecutive pushed arcs (stable push order) whose hits had the same original (qid,qs) key: only then does the order of tied hits reach the arcs
+__global__ __launch_bounds__(256) void k_arc_push_conflicts(const uint64_t *__restrict__ skey, size_t n, unsigned long long *__restrict__ ctr)
 {
 	uint32_t cnt = 0;
-	for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x + 1; p < n; p += (size_t)gridDim.x * 256)
-		cnt += h[sidx[aslot[p]]].qns == h[sidx[aslot[p - 1]]].qns;
+	for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x + 1; p < n; p += (size_t)gridDim.x * 256) cnt += skey[p] == skey[p - 1];
 	blk_add_u64(&ctr[ST_PUSH_CONFLICTS], cnt);
 }
 // sort key of a pushed arc in the reference's hit order
@@ -534,6 +537,48 @@ extern "C" int mahip_sg_flags(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, 
 	return 0;
 }
 
+// ---- push order (asm.c:18-35: arcs are pushed in hit order) ----
+// The slots are grouped by query id only (hits.hip), so the arcs leave k_sg_emit in (qid, input position) order; the reference pushes them
+// in ma_hit_sort's order.  That order matters only when arcs with equal (u,len) exist -- or in the stable mode, which is DEFINED as the
+// stable sort of the stable push order -- and then it is made here, for the arcs alone: a stable sort of the m arcs by the original
+// (qid,qs) of their hits = the (qid, qs, input position) order.  c->val[*gen] <- the permutation; *conflicts <- consecutive arcs with equal keys.
+static int push_stable_order(mahip_ctx *c, size_t m, int *gen, uint64_t *conflicts)
+{
+	unsigned long long *ctr = P<unsigned long long>(c->ctr);
+	const int bs = hits_qs_bits(c);
+	int bq = 0;
+	for (uint64_t x = c->n_seq ? c->n_seq - 1 : 0xffffffffull; x; x >>= 1) ++bq;
+	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }
+	hipLaunchKernelGGL(k_arc_slot_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->aslot), m, c->d_aos, (const uint32_t*)P<uint32_t>(c->sidx),
+	                   P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
+	*gen = 0;
+	CHK(radix_sort_pairs(c, m, 0, bs, 32, 32 + (bq ? bq : 1), gen));
+	HIPCHK(hipMemsetAsync(ctr + ST_PUSH_CONFLICTS, 0, 8, c->st));
+	hipLaunchKernelGGL(k_arc_push_conflicts, dim3(grid_for(m, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[*gen]), m, ctr);
+	CHK(ctr_fetch(c));
+	*conflicts = c->h_ctr[ST_PUSH_CONFLICTS];
+	return 0;
+}
+
+// exact: where two consecutive arcs come from hits with equal keys, the reference's (unstable) hit order decides: walk over the hits
+static int push_order(mahip_ctx *c, size_t m, bool exact, int *gen)
+{
+	uint64_t conf = 0;
+	CHK(push_stable_order(c, m, gen, &conf));
+	c->tie.push_conflicts = conf;
+	if (exact && conf) {
+		CHK(hits_reference_rank(c)); // uses key[]/val[] as scratch
+		for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }
+		hipLaunchKernelGGL(k_arc_push_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->aslot), (const uint32_t*)P<uint32_t>(c->hrank), m,
+		                   P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
+		*gen = 0;
+		int bh = 0;
+		for (uint64_t x = c->n_in; x; x >>= 1) ++bh;
+		CHK(radix_sort_pairs(c, m, 0, bh ? bh : 1, 0, 0, gen)); // hrank = position among all input records
+	}
+	return 0;
+}
+
 extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 { // asg_cleanup (asg.c:72-80) on the candidates: arc_rm (order preserving), sort by (u,len), index
 	HIPCHK(hipSetDevice(c->dev));
@@ -544,7 +589,8 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 	if (c->prof) prof_patch_last(c, "k_sg_arcs", 64.0 * (double)c->n_live); // units = hits left after containment (64 B each)
 	c->n_arc = 0; c->ag = 0;
 	const bool sharded = c->q_beg > 0 || (c->n_seq && c->q_end < c->n_seq);
-	const bool want_slots = c->tie_mode != 0 && c->sorted_here && c->sidx.p != nullptr; // the hit order can be repaired (on a shard: by the orchestrator, after the exchange)
+	const bool want_slots = c->sorted_here && c->sidx.p != nullptr; // the arcs can be put into the reference's push order (on a shard: by the orchestrator, after the exchange)
+	const int blen = bitlen_u64(c->h_ctr[CT_MAXLEN]);
 	{ const uint64_t keep_hit_ties = c->tie.hit_ties; const int keep_walk = c->hrank_ready; memset(&c->tie, 0, sizeof(c->tie)); c->tie.hit_ties = keep_hit_ties; c->tie.hit_walk = keep_walk; }
 	if (n) {
 		const size_t n_tiles = (n + SG_TILE - 1) / SG_TILE;
@@ -569,7 +615,7 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 			                   want_slots ? P<uint32_t>(c->aslot) : (uint32_t*)nullptr);
 		}
 	} else CHK(reserve_arcs(c, 0));
-	c->n_push = 0;
+	c->n_push = 0; c->push_ordered = false;
 	if (sharded && c->tie_mode != 0) { // keep this rank's arcs in push order: the exchange overwrites the arc arrays, a tie repair needs them (sharded.c)
 		CHK(dev_reserve(c, c->pushrows[0], ((size_t)c->n_arc + 1) * 16));
 		if (c->n_arc) hipLaunchKernelGGL(k_arc_rows_out, dim3(grid_for(c->n_arc, 256)), dim3(256), 0, c->st, arcs_of(c, c->ag), (size_t)c->n_arc, (uint4*)c->pushrows[0].p);
@@ -582,14 +628,21 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 		unsigned long long *ctr = P<unsigned long long>(c->ctr);
 		const int32_t *map = c->has_map ? (const int32_t*)P<int32_t>(c->map) : (const int32_t*)nullptr;
 		int gen = 0, need_walk = c->tie_mode == 1 && !sharded;
+		if (c->tie_mode == 0 && want_slots) { // the documented stable order: the stable sort of the stable push order
+			int g0 = 0;
+			CHK(push_order(c, m, false, &g0));
+			hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, (const uint32_t*)P<uint32_t>(c->val[g0]), out);
+			c->ag ^= 1;
+			in = arcs_of(c, c->ag); out = arcs_of(c, c->ag ^ 1);
+		}
 		if (c->tie_mode != 1 || sharded) { // stable sort (asg.c:24 up to the order of equal keys), then the census (on a shard: after the exchange, sharded.c)
 			hipLaunchKernelGGL(k_arc_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
-			CHK(radix_sort_pairs(c, m, 0, bitlen_u64(c->h_ctr[CT_MAXLEN]), 32, 32 + bitlen_u64(2ull * R), &gen));
+			CHK(radix_sort_pairs(c, m, 0, blen, 32, 32 + bitlen_u64(2ull * R), &gen));
 			{
 				ProfScope ps(c, "k_arc_permute", 36.0 * (double)m);
 				hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, (const uint32_t*)P<uint32_t>(c->val[gen]), out);
 			}
-			if (c->tie_mode == 2 && !sharded) {
+			if (c->tie_mode == 2 && !sharded) { // without equal (u,len) keys the sorted sequence is unique: whatever order the arcs were pushed in
 				HIPCHK(hipMemsetAsync(ctr + CT_STICKY, 0, (64 - CT_STICKY) * 8, c->st));
 				ProfScope ps(c, "k_arc_tie_census", 8.0 * (double)m);
 				hipLaunchKernelGGL(k_arc_tie_census, dim3(grid_for(m, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[gen]), m, ctr);
@@ -599,24 +652,10 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 			}
 		}
 		if (need_walk) {
-			// (1) the push order: arcs leave ma_sg_gen in hit order (asm.c:18-35), and the reference's hit order differs from the stable
-			//     one inside runs of equal (qid,qs).  Only if two arcs come from one such run does that reach the arcs.
-			int fix_push = 0;
+			// (1) the push order: arcs leave ma_sg_gen in the order ma_hit_sort left the hits in (asm.c:18-35)
 			if (want_slots) {
-				HIPCHK(hipMemsetAsync(ctr + ST_PUSH_CONFLICTS, 0, 8, c->st));
-				hipLaunchKernelGGL(k_arc_push_conflicts, dim3(grid_for(m, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->aslot), m, c->d_aos,
-				                   (const uint32_t*)P<uint32_t>(c->sidx), ctr);
-				CHK(ctr_fetch(c));
-				c->tie.push_conflicts = c->h_ctr[ST_PUSH_CONFLICTS];
-				fix_push = c->tie.push_conflicts > 0;
-			}
-			if (fix_push) {
-				CHK(hits_reference_rank(c)); // uses key[]/val[] as scratch
-				for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }
-				hipLaunchKernelGGL(k_arc_push_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->aslot), (const uint32_t*)P<uint32_t>(c->hrank), m,
-				                   P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
 				int g2 = 0;
-				CHK(radix_sort_pairs(c, m, 0, bitlen_u64(c->n_hits), 0, 0, &g2));
+				CHK(push_order(c, m, true, &g2));
 				hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, (const uint32_t*)P<uint32_t>(c->val[g2]), out);
 				c->ag ^= 1; // `out` now holds the arcs in the reference's push order
 				in = arcs_of(c, c->ag); out = arcs_of(c, c->ag ^ 1);
@@ -688,18 +727,23 @@ extern "C" int mahip_asg_import_rows(mahip_ctx_t *c, const void *d_src, const ui
 }
 
 // ---- tie repair on shards (host/sharded.c) ----
-// consecutive arcs this rank pushed from hits with equal original (qid,qs) keys
+// this rank's pushed arcs into the stable push order (pushrows[1]); *n_conf = consecutive arcs from hits with equal original (qid,qs) keys
 extern "C" int mahip_sg_push_conflicts(mahip_ctx_t *c, uint64_t *n_conf)
 {
 	HIPCHK(hipSetDevice(c->dev));
 	*n_conf = 0;
-	if (c->n_push < 2 || !c->aslot.p || !c->sidx.p) return 0;
-	unsigned long long *ctr = P<unsigned long long>(c->ctr);
-	HIPCHK(hipMemsetAsync(ctr + ST_PUSH_CONFLICTS, 0, 8, c->st));
-	hipLaunchKernelGGL(k_arc_push_conflicts, dim3(grid_for(c->n_push, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->aslot), (size_t)c->n_push, c->d_aos,
-	                   (const uint32_t*)P<uint32_t>(c->sidx), ctr);
-	CHK(ctr_fetch(c));
-	*n_conf = c->h_ctr[ST_PUSH_CONFLICTS];
+	const size_t m = c->n_push;
+	CHK(dev_reserve(c, c->pushrows[1], (m + 1) * 16));
+	if (m < 2 || !c->aslot.p || !c->sidx.p) {
+		if (m) HIPCHK(hipMemcpyAsync(c->pushrows[1].p, c->pushrows[0].p, m * 16, hipMemcpyDeviceToDevice, c->st));
+		c->push_ordered = true;
+		return 0;
+	}
+	int g = 0;
+	CHK(push_stable_order(c, m, &g, n_conf));
+	hipLaunchKernelGGL(k_rows_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint4*)c->pushrows[0].p, m, (const uint32_t*)P<uint32_t>(c->val[g]), (uint4*)c->pushrows[1].p);
+	HIPCHK(hipGetLastError());
+	c->push_ordered = true;
 	return 0;
 }
 
@@ -716,15 +760,16 @@ extern "C" int mahip_sg_push_fix(mahip_ctx_t *c)
 	int g = 0;
 	CHK(radix_sort_pairs(c, m, 0, 32, 0, 0, &g)); // hrank holds positions in the global order: up to 32 bits
 	hipLaunchKernelGGL(k_rows_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint4*)c->pushrows[0].p, m, (const uint32_t*)P<uint32_t>(c->val[g]), (uint4*)c->pushrows[1].p);
-	HIPCHK(hipMemcpyAsync(c->pushrows[0].p, c->pushrows[1].p, m * 16, hipMemcpyDeviceToDevice, c->st));
 	HIPCHK(hipGetLastError());
+	c->push_ordered = true;
 	return 0;
 }
 
 extern "C" int mahip_asg_export_rows_push(mahip_ctx_t *c, void *d_dst)
 {
 	HIPCHK(hipSetDevice(c->dev));
-	if (c->n_push) HIPCHK(hipMemcpyAsync(d_dst, c->pushrows[0].p, (size_t)c->n_push * 16, hipMemcpyDeviceToDevice, c->st));
+	if (!c->push_ordered) { uint64_t conf; CHK(mahip_sg_push_conflicts(c, &conf)); }
+	if (c->n_push) HIPCHK(hipMemcpyAsync(d_dst, c->pushrows[1].p, (size_t)c->n_push * 16, hipMemcpyDeviceToDevice, c->st));
 	return 0;
 }
 

@@ -18,32 +18,34 @@
 #define DEAD 0x80000000u
 
 // ------------------------------------------------------------------------------------------------ sort
-// Sort keys for ma_hit_sort (hit.c:12-22, key = qns = qid<<32 | qs), squeezed to their significant bits:
-//   packed (pk = 1): key = qid << (bs+bi) | qs << bi | input position >> drop   (8-byte elements, no value array).  drop > 0 when the
-//                    three fields are ONE bit too wide for 64 (BASELINE configs[3]: 21 + 16 + 28): the lowest bit of the position is left
-//                    out and the gather picks the record out of the pair of neighbours it reads anyway (one 64-byte line), see k_hit_gather
-//   pairs  (pk = 0): key = qid << bs | qs, value = input position        (when the three fields exceed 64 bits)
+// ma_hit_sort (hit.c:12-22) orders the hits by qns = qid<<32 | qs.  Everything between the sort and ma_sg_gen only needs the hits of a
+// read to be ADJACENT: ma_hit_sub sorts its own events, cut / flt / contained are per hit.  The order inside a read's group shows in two
+// places only: a hit dump, and the push order of the (few) arcs when arcs with equal (u,len) exist.  So the resident layout is grouped by
+// query id, input order inside a group -- a sort on the id bits alone (BASELINE configs[3]: 21 instead of 37 key bits, 3 digit passes
+// instead of 5) -- and the two consumers re-establish the (qid, qs, input position) order for what they look at: hits_order_rank() for a
+// dump, push_stable_order() (graph.hip) for the arcs.
+//   key = qid << bi | input position   (8-byte elements, no value array; qid and position are 32-bit: always fits)
 // keep[i] = hit belongs to this context's read range (sharded mode).
 __global__ __launch_bounds__(256) void k_hit_keys(const ma_hit_t *__restrict__ h, size_t n, uint64_t *__restrict__ key,
                                                    uint32_t *__restrict__ val, uint32_t *__restrict__ keep, unsigned long long *__restrict__ ctr,
-                                                   uint32_t q_beg, uint32_t q_end, int bs, int bi, int pk, int drop)
-{
+                                                   uint32_t q_beg, uint32_t q_end, int bi, int full)
+{ // full: key = qns, val = input position (the walk of the reference's sort over the original keys)
 	uint32_t cnt = 0;
 	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
 		uint64_t k = h[i].qns;
-		uint32_t q = (uint32_t)(k >> 32), qs = (uint32_t)k;
+		uint32_t q = (uint32_t)(k >> 32);
 		int in = q >= q_beg && q < q_end;
 		cnt += in;
-		if (pk) key[i] = ((uint64_t)q << bs | qs) << bi | (i >> drop);
-		else key[i] = (uint64_t)q << bs | qs, val[i] = (uint32_t)i;
+		if (full) key[i] = k, val[i] = (uint32_t)i;
+		else key[i] = (uint64_t)q << bi | i;
 		if (keep) keep[i] = in;
 	}
 	blk_add_u64(&ctr[CT_LIVE], cnt);
 }
 
-// The same for the packed layout of an unsharded context, one block per radix tile: the block also counts the first sort
-// digit of its keys, which is exactly the per-tile histogram the first radix pass needs (saves one sweep over the keys).
-__global__ __launch_bounds__(256) void k_hit_keys_tiled(const ma_hit_t *__restrict__ h, size_t n, uint64_t *__restrict__ key, int bs, int bi, int drop,
+// The same for an unsharded context, one block per radix tile: the block also counts the first sort digit of its keys, which
+// is exactly the per-tile histogram the first radix pass needs (saves one sweep over the keys).
+__global__ __launch_bounds__(256) void k_hit_keys_tiled(const ma_hit_t *__restrict__ h, size_t n, uint64_t *__restrict__ key, int bi,
                                                          uint32_t *__restrict__ hist, unsigned nb, unsigned tile, int shift, unsigned mask)
 {
 	__shared__ uint32_t s_cnt[1024]; // up to 10-bit digits (radix.hip: RS_MAXBITS)
@@ -53,8 +55,7 @@ __global__ __launch_bounds__(256) void k_hit_keys_tiled(const ma_hit_t *__restri
 	for (unsigned it = 0; it < tile / 256; ++it) {
 		const size_t i = base + (size_t)it * 256 + threadIdx.x;
 		if (i < n) {
-			const uint64_t k = h[i].qns;
-			const uint64_t kk = ((uint64_t)(uint32_t)(k >> 32) << bs | (uint32_t)k) << bi | (i >> drop);
+			const uint64_t kk = (uint64_t)(uint32_t)(h[i].qns >> 32) << bi | i;
 			key[i] = kk;
 			atomicAdd(&s_cnt[(unsigned)(kk >> shift) & mask], 1u);
 		}
@@ -86,44 +87,25 @@ __global__ __launch_bounds__(256) void k_key_compact(const uint64_t *__restrict_
 
 struct HitCols { uint32_t *qid, *qs, *qe, *tn, *ts, *te, *ml, *bl; };
 
-// AoS (input order) -> SoA (sorted order): one 32-byte record per lane as 2 x dwordx4 through the permutation held
-// in the sorted keys (low bi bits) or in perm[]; group offsets from the query-id boundaries of the sorted keys.
+// AoS (input order) -> SoA (grouped by query id): one 32-byte record per lane as 2 x dwordx4 through the permutation held
+// in the low bi bits of the sorted keys; group offsets from the query-id boundaries of the sorted keys.
 // skey == nullptr: identity (input already grouped: the per-symbol path).
 #define GATHER_ILP 2 // slots per thread: two independent request chains in flight per lane (the record fetch is a dependent chain: key -> record)
-__global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__ h, const uint64_t *__restrict__ skey, const uint32_t *__restrict__ perm,
-                                                     int qshift, int bi, size_t n, uint32_t n_seq, HitCols c, uint32_t *__restrict__ goff, uint32_t *__restrict__ sidx,
-                                                     int drop, int bs, size_t n_in)
-{ // sidx (optional): input position of the record in every sorted slot -- what the tie-order repair needs to find a slot's original key
-  // drop == 1: the key holds (input position >> 1); the record is the one of the pair whose (qid,qs) equals the key's -- the second one if
-  // both do and this slot is the second of its run of equal keys (the sort is stable: candidates of one run are in input order)
+__global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__ h, const uint64_t *__restrict__ skey, int bi, size_t n, uint32_t n_seq,
+                                                     HitCols c, uint32_t *__restrict__ goff, uint32_t *__restrict__ sidx)
+{ // sidx (optional): input position of the record in every slot -- how the order inside a group is re-established (hits_order_rank, push_stable_order)
 	size_t i[GATHER_ILP], j[GATHER_ILP];
-	uint64_t K[GATHER_ILP];
 	uint4 a[GATHER_ILP], b[GATHER_ILP];
-	bool act[GATHER_ILP], pick1[GATHER_ILP];
+	bool act[GATHER_ILP];
 #pragma unroll
-	for (int u = 0; u < GATHER_ILP; ++u) { // keys / permutation entries of all slots first
+	for (int u = 0; u < GATHER_ILP; ++u) { // keys of all slots first
 		i[u] = ((size_t)blockIdx.x * GATHER_ILP + u) * 256 + threadIdx.x;
-		act[u] = i[u] < n; pick1[u] = false; K[u] = 0; j[u] = i[u];
-		if (act[u]) {
-			if (perm) j[u] = perm[i[u]];
-			else if (skey) { K[u] = skey[i[u]]; j[u] = (size_t)(K[u] & ((1ull << bi) - 1)) << drop; }
-		}
-	}
-#pragma unroll
-	for (int u = 0; u < GATHER_ILP; ++u) if (act[u]) a[u] = ((const uint4*)(h + j[u]))[0]; // a = {qs, qid, qe, tn}
-	if (drop && skey && !perm) {
-#pragma unroll
-		for (int u = 0; u < GATHER_ILP; ++u)
-			if (act[u]) { // the pair (j, j+1) shares a 64-byte line; the first half of the even record decides
-				const bool two = j[u] + 1 < n_in, second_of_run = i[u] > 0 && skey[i[u] - 1] == K[u];
-				const bool m0 = (((uint64_t)a[u].y << bs) | a[u].x) == (K[u] >> bi);
-				pick1[u] = two && (second_of_run || !m0);
-				j[u] += pick1[u];
-			}
+		act[u] = i[u] < n; j[u] = i[u];
+		if (act[u] && skey) j[u] = (size_t)(skey[i[u]] & ((1ull << bi) - 1));
 	}
 #pragma unroll
 	for (int u = 0; u < GATHER_ILP; ++u)
-		if (act[u]) { const uint4 *p = (const uint4*)(h + j[u]); if (pick1[u]) a[u] = p[0]; b[u] = p[1]; } // b = {ts, te, ml|rev, bl|del}
+		if (act[u]) { const uint4 *p = (const uint4*)(h + j[u]); a[u] = p[0]; b[u] = p[1]; } // a = {qs, qid, qe, tn}, b = {ts, te, ml|rev, bl|del}
 #pragma unroll
 	for (int u = 0; u < GATHER_ILP; ++u) {
 		if (i[u] > n) continue;
@@ -136,7 +118,7 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 			c.qid[s] = a[u].y; c.qs[s] = a[u].x; c.qe[s] = a[u].z; c.tn[s] = a[u].w;
 			c.ts[s] = b[u].x; c.te[s] = b[u].y; c.ml[s] = b[u].z; c.bl[s] = b[u].w & ~DEAD;
 		}
-		if (!first) qprev = skey ? (uint32_t)(skey[i[u] - 1] >> qshift) : (uint32_t)(h[perm ? perm[i[u] - 1] : i[u] - 1].qns >> 32);
+		if (!first) qprev = skey ? (uint32_t)(skey[i[u] - 1] >> bi) : (uint32_t)(h[i[u] - 1].qns >> 32);
 		// reads qprev+1 .. q start at slot i (reads without hits get empty groups)
 		const uint32_t r0 = first ? 0 : qprev + 1;
 		if (q > n_seq) q = n_seq;
@@ -696,7 +678,7 @@ static int hits_common_setup(mahip_ctx *c, size_t n, uint32_t n_seq)
 	c->soa_ready = false; c->has_map = false; c->graph_ready = false;
 	c->hint_max_qs = 0; // hints describe one upload: set them again after every upload/adopt
 	c->lazy_squeeze = false;
-	c->sorted_here = false; c->hrank_ready = false;
+	c->sorted_here = false; c->hrank_ready = false; c->orank_ready = false;
 	memset(&c->tie, 0, sizeof(c->tie));
 	CHK(reserve_read_arrays(c));
 	for (int k = 0; k < 8; ++k) CHK(dev_reserve(c, c->col[k], (n + 1) * 4));
@@ -792,14 +774,18 @@ extern "C" int mahip_tie_stats(mahip_ctx_t *c, mahip_tie_info_t *out)
 
 static inline bool ctx_sharded(const mahip_ctx *c) { return c->q_beg > 0 || (c->n_seq && c->q_end < c->n_seq); }
 
-// ---- the reference's order of hits with equal (qid, qs) ----
-// A slot's ORIGINAL key is the qns of its input record (cuts rewrite the qs column, never the input records).
-__global__ __launch_bounds__(256) void k_hit_tie_count(const ma_hit_t *__restrict__ h, const uint32_t *__restrict__ sidx, size_t n, unsigned long long *__restrict__ ctr)
+// ---- the order ma_hit_sort leaves the hits in (hit.c:19-22): by the ORIGINAL qns of each slot's record, ties as the reference has them ----
+// A slot's original key is the qns of its input record (cuts rewrite the qs column, never the input records).
+__global__ __launch_bounds__(256) void k_slot_keys(const ma_hit_t *__restrict__ h, const uint32_t *__restrict__ sidx, size_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
 {
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) { key[i] = h[sidx[i]].qns; val[i] = (uint32_t)i; }
+}
+__global__ __launch_bounds__(256) void k_key_tie_count(const uint64_t *__restrict__ skey, size_t n, unsigned long long *__restrict__ ctr, int slot)
+{ // adjacent equal keys of a sorted sequence
 	uint32_t cnt = 0;
-	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + 1; i < n; i += (size_t)gridDim.x * 256)
-		cnt += h[sidx[i]].qns == h[sidx[i - 1]].qns;
-	blk_add_u64(&ctr[ST_HIT_TIES], cnt);
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x + 1; i < n; i += (size_t)gridDim.x * 256) cnt += skey[i] == skey[i - 1];
+	blk_add_u64(&ctr[slot], cnt);
 }
 __global__ __launch_bounds__(256) void k_perm_invert(const uint32_t *__restrict__ perm, size_t n, uint32_t *__restrict__ inv)
 {
@@ -825,7 +811,7 @@ int hits_reference_rank(mahip_ctx *c)
 	// the walk runs over ALL input records (on a shard: every rank repeats it and keeps the ranks of its own slots; sidx holds global positions)
 	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (N + 1) * 8)); CHK(dev_reserve(c, c->val[k], (N + 1) * 4)); }
 	hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(N, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, N, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
-	                   (uint32_t*)nullptr, P<unsigned long long>(c->ctr), 0u, 0xffffffffu, 32, 0, 0, 0); // key = qid<<32 | qs, input order
+	                   (uint32_t*)nullptr, P<unsigned long long>(c->ctr), 0u, 0xffffffffu, 0, 1); // key = qid<<32 | qs, input order
 	CHK(reference_order(c, P<uint64_t>(c->key[0]), N, P<uint32_t>(c->val[1])));
 	hipLaunchKernelGGL(k_perm_invert, dim3(grid_for(N, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->val[1]), N, P<uint32_t>(c->val[0]));
 	hipLaunchKernelGGL(k_hit_rank, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->sidx), (const uint32_t*)P<uint32_t>(c->val[0]), n, P<uint32_t>(c->hrank));
@@ -835,8 +821,61 @@ int hits_reference_rank(mahip_ctx *c)
 	return 0;
 }
 
-extern "C" int mahip_hits_sort(mahip_ctx_t *c)
+// bits of the largest query start (the caller's hint, else one sweep over the records)
+int hits_qs_bits(mahip_ctx *c)
 {
+	if (c->hint_max_qs) return bitlen(c->hint_max_qs);
+	if (c->n_in == 0 || !c->d_aos) return 32;
+	if (ctr_zero(c) != 0) return 32;
+	hipLaunchKernelGGL(k_hit_bounds, dim3(grid_for(c->n_in, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, c->n_in, P<unsigned long long>(c->ctr));
+	if (ctr_fetch(c) != 0) return 32;
+	int b = bitlen(c->h_ctr[CT_MAXQS]);
+	return b ? b : 1;
+}
+
+// *rank = device array: position of every slot in the order the reference's ma_hit_sort leaves the hits in (nullptr: the slots are
+// in that order already).  Without equal (qid,qs) keys that is a stable device sort of the slots' original keys; with them it is
+// the walk of hits_reference_rank() (whole input on this context), or -- on a shard in the automatic mode -- the stable order, reported
+// as unrepaired.
+static int hits_order_rank(mahip_ctx *c, const uint32_t **rank)
+{
+	*rank = nullptr;
+	if (!c->sorted_here || !c->sidx.p || !c->d_aos) return 0;
+	const size_t n = c->n_hits;
+	if (n < 2) return 0;
+	if (c->hrank_ready && !ctx_sharded(c)) { *rank = P<uint32_t>(c->hrank); return 0; }
+	if (!c->orank_ready) {
+		unsigned long long *ctr = P<unsigned long long>(c->ctr);
+		const int bs = hits_qs_bits(c), bq = c->n_seq ? bitlen(c->n_seq - 1) : 32;
+		for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (n + 1) * 8)); CHK(dev_reserve(c, c->val[k], (n + 1) * 4)); }
+		CHK(dev_reserve(c, c->orank, (n + 1) * 4));
+		hipLaunchKernelGGL(k_slot_keys, dim3(grid_for(n, 256)), dim3(256), 0, c->st, c->d_aos, (const uint32_t*)P<uint32_t>(c->sidx), n, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
+		int g = 0;
+		CHK(radix_sort_pairs(c, n, 0, bs, 32, 32 + (bq ? bq : 1), &g)); // stable: equal keys stay in slot order = input order
+		HIPCHK(hipMemsetAsync(ctr + ST_HIT_TIES, 0, 8, c->st));
+		hipLaunchKernelGGL(k_key_tie_count, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[g]), n, ctr, (int)ST_HIT_TIES);
+		hipLaunchKernelGGL(k_perm_invert, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->val[g]), n, P<uint32_t>(c->orank));
+		CHK(ctr_fetch(c));
+		HIPCHK(hipGetLastError());
+		c->tie.hit_ties = c->h_ctr[ST_HIT_TIES];
+		c->orank_ready = true;
+	}
+	if (c->tie.hit_ties && c->tie_mode != 0) {
+		if (ctx_sharded(c)) { // hrank counts positions in the whole input: not an order of this shard's slots alone
+			if (c->tie_mode == 1) { mahip_set_error("mahip_hits_download: exact tie order is not available on a shard"); return -1; }
+			c->tie.unrepaired = 1;
+		} else {
+			CHK(hits_reference_rank(c));
+			*rank = P<uint32_t>(c->hrank);
+			return 0;
+		}
+	}
+	*rank = P<uint32_t>(c->orank);
+	return 0;
+}
+
+extern "C" int mahip_hits_sort(mahip_ctx_t *c)
+{ // groups the hits by query id (input order inside a group); see the note at the top of the sort section
 	HIPCHK(hipSetDevice(c->dev));
 	size_t n = c->n_hits;
 	HitCols h = cols_of(c);
@@ -845,55 +884,50 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 		c->soa_ready = true; c->n_live = 0;
 		return 0;
 	}
-	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (n + 1) * 8)); CHK(dev_reserve(c, c->val[k], (n + 1) * 4)); }
+	if (n >= 0xffffffffull) { mahip_set_error("mahip_hits_sort: too many hits"); return -1; }
+	for (int k = 0; k < 2; ++k) CHK(dev_reserve(c, c->key[k], (n + 1) * 8));
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
-	const bool want_sidx = c->tie_mode != 0;
-	if (want_sidx) CHK(dev_reserve(c, c->sidx, (n + 1) * 4));
-	c->sorted_here = true; c->hrank_ready = false;
-	// digit plan: bits of the query start, of the query id, of the record index
-	int bs, bq, bi = bitlen(n - 1);
-	if (c->hint_max_qs && c->n_seq) bs = bitlen(c->hint_max_qs), bq = bitlen(c->n_seq - 1); // no device round trip
+	CHK(dev_reserve(c, c->sidx, (n + 1) * 4));
+	c->sorted_here = true; c->hrank_ready = false; c->orank_ready = false;
+	// digit plan: bits of the query id above the bits of the record index
+	int bq, bi = bitlen(n - 1);
+	if (c->n_seq) bq = bitlen(c->n_seq - 1); // ids are < n_seq by contract (sdict.c:45-57 hands them out densely)
 	else {
 		CHK(ctr_zero(c));
 		hipLaunchKernelGGL(k_hit_bounds, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, ctr);
 		CHK(ctr_fetch(c));
-		bs = bitlen(c->h_ctr[CT_MAXQS]); bq = bitlen(c->h_ctr[CT_MAXQID]);
+		bq = bitlen(c->h_ctr[CT_MAXQID]);
 	}
 	if (bi == 0) bi = 1;
-	int drop = bq + bs + bi - 64; // bits the packed key is too wide by
-	if (drop < 0) drop = 0;
-	const int pk = drop <= 1 && bi > drop; // one bit over: packed key without the lowest position bit; more: (key, value) pairs
-	if (!pk) drop = 0;
-	const size_t n_in = n;
-	bi -= drop;
+	if (bq == 0) bq = 1;
 	const bool sharded = c->q_beg > 0 || (c->n_seq && c->q_end < c->n_seq);
 	int gen = 0;
 	if (sharded) { CHK(dev_reserve(c, c->keep, (n + 16) * 4)); CHK(dev_reserve(c, c->pos, (n + 16) * 4)); }
 	CHK(ctr_zero(c));
 	bool first_hist = false;
-	if (pk && !sharded) { // keys + the first pass's per-tile histogram in one sweep
+	if (!sharded) { // keys + the first pass's per-tile histogram in one sweep
 		int sh0, bt0; unsigned tile;
-		radix_first_digit(bi, bi + bs + bq, &sh0, &bt0, &tile);
+		radix_first_digit(bi, bi + bq, &sh0, &bt0, &tile);
 		if (bt0 > 0 && bt0 <= 10) {
 			const unsigned nb = (unsigned)((n + tile - 1) / tile);
 			CHK(radix_reserve_hist(c, n));
 			ProfScope ps(c, "k_hit_keys", 16.0 * (double)n);
-			hipLaunchKernelGGL(k_hit_keys_tiled, dim3(nb), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), bs, bi, drop, P<uint32_t>(c->hist), nb, tile, sh0, (1u << bt0) - 1);
+			hipLaunchKernelGGL(k_hit_keys_tiled, dim3(nb), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), bi, P<uint32_t>(c->hist), nb, tile, sh0, (1u << bt0) - 1);
 			first_hist = true;
 		}
 	}
 	if (!first_hist) {
-		ProfScope ps(c, "k_hit_keys", (pk ? 16.0 : 20.0) * (double)n); // reads qns (8 B), writes the key (+ index)
-		hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
-		                   sharded ? P<uint32_t>(c->keep) : (uint32_t*)nullptr, ctr, c->q_beg, c->q_end, bs, bi, pk, drop);
+		ProfScope ps(c, "k_hit_keys", 16.0 * (double)n); // reads qns (8 B), writes the key
+		hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), (uint32_t*)nullptr,
+		                   sharded ? P<uint32_t>(c->keep) : (uint32_t*)nullptr, ctr, c->q_beg, c->q_end, bi, 0);
 	}
 	if (sharded) { // this context only keeps the hits whose query read lies in its range
 		CHK(ctr_fetch(c));
 		size_t n_in = (size_t)c->h_ctr[CT_LIVE];
 		if (n_in < n) {
 			CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), n, nullptr));
-			hipLaunchKernelGGL(k_key_compact, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[0]), pk ? (const uint32_t*)nullptr : (const uint32_t*)P<uint32_t>(c->val[0]),
-			                   n, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), P<uint64_t>(c->key[1]), P<uint32_t>(c->val[1]));
+			hipLaunchKernelGGL(k_key_compact, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[0]), (const uint32_t*)nullptr,
+			                   n, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), P<uint64_t>(c->key[1]), (uint32_t*)nullptr);
 			gen = 1;
 			c->n_hits = n = n_in;
 		}
@@ -904,13 +938,11 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 		c->soa_ready = true;
 		return 0;
 	}
-	if (pk) CHK(radix_sort_keys(c, n, bi, bi + bs + bq, &gen, first_hist));
-	else CHK(radix_sort_pairs(c, n, 0, bs + bq, 0, 0, &gen));
+	CHK(radix_sort_keys(c, n, bi, bi + bq, &gen, first_hist));
 	{
-		ProfScope ps(c, "k_hit_gather", (pk ? 72.0 : 76.0) * (double)n); // key 8 (+ index 4) + record 32 + columns 32
+		ProfScope ps(c, "k_hit_gather", 76.0 * (double)n); // key 8 + record 32 + columns 32 + input position 4
 		hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256 * GATHER_ILP)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)P<uint64_t>(c->key[gen]),
-		                   pk ? (const uint32_t*)nullptr : (const uint32_t*)P<uint32_t>(c->val[gen]), pk ? bi + bs : bs, bi, n, c->n_seq, h, P<uint32_t>(c->goff),
-		                   want_sidx ? P<uint32_t>(c->sidx) : (uint32_t*)nullptr, drop, bs, n_in);
+		                   bi, n, c->n_seq, h, P<uint32_t>(c->goff), P<uint32_t>(c->sidx));
 	}
 	HIPCHK(hipGetLastError());
 	c->soa_ready = true;
@@ -923,10 +955,10 @@ extern "C" int mahip_hits_index(mahip_ctx_t *c)
 	size_t n = c->n_hits;
 	HitCols h = cols_of(c);
 	ProfScope ps(c, "k_hit_gather", 64.0 * (double)n);
-	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256 * GATHER_ILP)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)nullptr, (const uint32_t*)nullptr, 32, 0, n, c->n_seq, h, P<uint32_t>(c->goff), (uint32_t*)nullptr, 0, 0, n);
+	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256 * GATHER_ILP)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)nullptr, 0, n, c->n_seq, h, P<uint32_t>(c->goff), (uint32_t*)nullptr);
 	HIPCHK(hipGetLastError());
 	c->soa_ready = true;
-	c->sorted_here = false; c->hrank_ready = false; // the caller's order is final (per-symbol path: already the reference's)
+	c->sorted_here = false; c->hrank_ready = false; c->orank_ready = false; // the caller's order is final (per-symbol path: already the reference's)
 	return 0;
 }
 
@@ -942,7 +974,7 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 	uint2 *sub = P<uint2>(c->sub[slot]);
 	SubFuse nofuse = {nullptr, 0, 0, 0, nullptr};
 	if (R) {
-		ProfScope ps(c, "k_hit_sub", 24.0 * (double)c->n_hits + 8.0 * R);
+		ProfScope ps(c, "k_hit_sub", 48.0 * (double)c->n_hits + 8.0 * R); // 32 r + 8 w events + 8 r events per stored hit
 		hipLaunchKernelGGL((k_hit_sub<false, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse);
 		hipLaunchKernelGGL((k_hit_sub<false, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
@@ -1262,21 +1294,9 @@ extern "C" int mahip_hits_download(mahip_ctx_t *c, ma_hit_t *out, size_t *n_out)
 	if (n_out) *n_out = c->n_live;
 	if (n == 0 || c->n_live == 0) return 0;
 	HitCols h = cols_of(c);
-	// the order of hits with equal (qid,qs) is visible in a hit dump: reproduce the reference's when there are any
+	// a dump shows the order of ma_hit_sort: the slots are only grouped by read, the rank of each slot in that order is made on demand
 	const uint32_t *rank = nullptr;
-	if (c->tie_mode != 0 && c->sorted_here && c->sidx.p) {
-		if (!c->hrank_ready) {
-			HIPCHK(hipMemsetAsync(P<unsigned long long>(c->ctr) + ST_HIT_TIES, 0, 8, c->st));
-			hipLaunchKernelGGL(k_hit_tie_count, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, (const uint32_t*)P<uint32_t>(c->sidx), n, P<unsigned long long>(c->ctr));
-			CHK(ctr_fetch(c));
-			c->tie.hit_ties = c->h_ctr[ST_HIT_TIES];
-			if (c->tie.hit_ties) {
-				if (ctx_sharded(c)) { if (c->tie_mode == 1) { mahip_set_error("mahip_hits_download: exact tie order is not available on a shard"); return -1; } c->tie.unrepaired = 1; }
-				else CHK(hits_reference_rank(c));
-			}
-		}
-		if (c->hrank_ready) rank = P<uint32_t>(c->hrank);
-	}
+	CHK(hits_order_rank(c, &rank));
 	CHK(dev_reserve(c, c->keep, (n + 16) * 4));
 	CHK(dev_reserve(c, c->pos, (n + 16) * 4));
 	CHK(dev_reserve(c, c->key[0], (c->n_live + 1) * sizeof(ma_hit_t))); // staging for the dense AoS

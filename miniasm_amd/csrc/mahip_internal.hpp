@@ -55,12 +55,14 @@ struct mahip_ctx {
 	// reproduced (host walk over the keys) for the arcs and, when two arcs were pushed from hits with equal (qid,qs), for the hits.
 	// tie_mode 1: always reproduce it.  tie_mode 0: never (documented total order).
 	int tie_mode = 2;
-	DevBuf sidx;              // u32 [n_hits] input position of the record in each sorted slot
-	DevBuf hrank;             // u32 [n_hits] position of each sorted slot in the reference's order (identity outside tie runs)
+	DevBuf sidx;              // u32 [n_hits] input position of the record in each slot (slots: grouped by query id, input order inside a group)
+	DevBuf hrank;             // u32 [n_hits] position of each slot's record in the order the reference's ma_hit_sort gives the input (host walk)
+	DevBuf orank;             // u32 [n_hits] position of each slot in the stable (qid, qs, input position) order (device sort, on demand)
 	DevBuf aslot;             // u32 [n_arc]  hit slot every pushed arc came from
 	DevBuf pushrows[2];       // sharded mode: this rank's arcs in push order as packed rows (the arc arrays are overwritten by the exchange)
 	uint32_t n_push = 0;
-	bool sorted_here = false, hrank_ready = false; // hits sorted by mahip_hits_sort (d_aos = the unsorted input) / hrank valid
+	bool sorted_here = false, hrank_ready = false, orank_ready = false; // hits grouped by mahip_hits_sort (d_aos = the unsorted input) / hrank valid / orank valid
+	bool push_ordered = false; // sharded mode: pushrows[1] holds this rank's arcs in push order
 	mahip_tie_info_t tie = {0, 0, 0, 0, 0, 0, 0};
 	uint32_t n_seq_new = 0;
 
@@ -133,8 +135,10 @@ void radix_first_digit(int lo, int hi, int *shift, int *bits, unsigned *tile);
 int radix_reserve_hist(mahip_ctx *c, size_t n);
 // the permutation the reference's (unstable) sort applies to d_keys[0..n) (input order), written to d_perm
 int reference_order(mahip_ctx *c, const uint64_t *d_keys, size_t n, uint32_t *d_perm);
-// position of every sorted hit slot in the reference's order -> c->hrank (hits.hip)
+// position of every hit slot in the reference's order -> c->hrank (hits.hip)
 int hits_reference_rank(mahip_ctx *c);
+// bits of the largest query start of the input records
+int hits_qs_bits(mahip_ctx *c);
 // bulk pageable<->device copy through per-thread pinned slots (xfer.hip); returns after the copy is complete
 int xfer_copy(mahip_ctx *c, void *dev_ptr, void *host_ptr, size_t bytes, int to_device);
 void xfer_pool_free(mahip_ctx *c);
