@@ -12,7 +12,8 @@ CSRC      = $(PKG)/csrc
 HOST      = $(PKG)/host
 B         = build/obj
 
-HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function -Iinclude -I$(CSRC)
+# EXTRA: experiment switches, e.g. EXTRA='-DRS_ITEMS=8' (tools/variants.sh builds such libraries next to the product one)
+HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function -Iinclude -I$(CSRC) $(EXTRA)
 CFLAGS    = -O2 -g -Wall -fPIC -Iinclude -I$(HOST) -I$(CSRC)
 
 HIP_SRC   = scan radix hits graph clean ug useq comm paf mahip_api xfer

@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "miniasm_amd")
-LIB_PATH = os.path.join(PKG, "lib", "libminiasm_amd.so")
+LIB_PATH = os.environ.get("MINIASM_AMD_LIB") or os.path.join(PKG, "lib", "libminiasm_amd.so")  # the override is for kernel-variant experiments (tools/variants.sh)
 CLI_PATH = os.path.join(PKG, "bin", "miniasm")
 PAFGEN_PATH = os.path.join(PKG, "bin", "pafgen")
 

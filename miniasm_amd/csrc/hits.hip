@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_hit_keys(const ma_hit_t *__restrict__ h
 __global__ __launch_bounds__(256) void k_hit_keys_tiled(const ma_hit_t *__restrict__ h, size_t n, uint64_t *__restrict__ key, int bi,
                                                          uint32_t *__restrict__ hist, unsigned nb, unsigned tile, int shift, unsigned mask)
 {
-	__shared__ uint32_t s_cnt[1024]; // up to 10-bit digits (radix.hip: RS_MAXBITS)
+	__shared__ uint32_t s_cnt[1 << RS_MAXBITS];
 	for (unsigned d = threadIdx.x; d <= mask; d += 256) s_cnt[d] = 0;
 	__syncthreads();
 	const size_t base = (size_t)blockIdx.x * tile;
@@ -90,7 +90,10 @@ struct HitCols { uint32_t *qid, *qs, *qe, *tn, *ts, *te, *ml, *bl; };
 // AoS (input order) -> SoA (grouped by query id): one 32-byte record per lane as 2 x dwordx4 through the permutation held
 // in the low bi bits of the sorted keys; group offsets from the query-id boundaries of the sorted keys.
 // skey == nullptr: identity (input already grouped: the per-symbol path).
-#define GATHER_ILP 2 // slots per thread: two independent request chains in flight per lane (the record fetch is a dependent chain: key -> record)
+#ifndef GATHER_ILP
+#define GATHER_ILP 2
+#endif
+// GATHER_ILP slots per thread: two independent request chains in flight per lane (the record fetch is a dependent chain: key -> record)
 __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__ h, const uint64_t *__restrict__ skey, int bi, size_t n, uint32_t n_seq,
                                                      HitCols c, uint32_t *__restrict__ goff, uint32_t *__restrict__ sidx)
 { // sidx (optional): input position of the record in every slot -- how the order inside a group is re-established (hits_order_rank, push_stable_order)
@@ -219,6 +222,7 @@ __device__ __forceinline__ int fuse_cut_flt_v(const HitCols &c, uint32_t i, cons
                                               uint32_t &qs, uint32_t &qe, uint32_t ml, uint32_t bl, SubAcc &acc, uint2 rt, uint32_t ts, uint32_t te)
 { // rt = the target's interval, ts/te = the hit's target columns: fetched by the caller (ahead of time in the SMALL kernels)
 	int keep = 0;
+	const uint32_t oqs = qs, oqe = qe, ots = ts, ote = te;
 	if (!(rq.x & DEAD) && !(rt.x & DEAD) && mc_cut(&qs, &qe, &ts, &te, ml >> 31, (int32_t)rq.x, rq.y, (int32_t)rt.x, rt.y, f.min_span)) {
 		mc_arc_t a;
 		uint32_t ql = rq.y - (rq.x & 0x7fffffffu), tl = rt.y - (rt.x & 0x7fffffffu);
@@ -228,7 +232,10 @@ __device__ __forceinline__ int fuse_cut_flt_v(const HitCols &c, uint32_t i, cons
 			keep = 1; ++acc.n_flt;
 			acc.dp += r >= 0 ? (uint32_t)r : r == MC_HT_QCONT ? ql : tl;
 			f.r_live[q] = 1;
-			c.qs[i] = qs; c.qe[i] = qe; c.ts[i] = ts; c.te[i] = te;
+			if (qs != oqs) c.qs[i] = qs; // untouched columns are not written back
+			if (qe != oqe) c.qe[i] = qe;
+			if (ts != ots) c.ts[i] = ts;
+			if (te != ote) c.te[i] = te;
 		}
 	}
 	if (!keep) c.bl[i] = bl | DEAD;
@@ -571,10 +578,14 @@ __global__ __launch_bounds__(256) void k_hit_cut_contained(HitCols c, size_t n, 
 		uint32_t q = c.qid[i], t = c.tn[i], ml = c.ml[i];
 		uint2 rq = cut_sub[q], rt = cut_sub[t];
 		uint32_t qs = c.qs[i], qe = c.qe[i], ts = c.ts[i], te = c.te[i];
+		const uint32_t oqs = qs, oqe = qe, ots = ts, ote = te;
 		if (!(rq.x & DEAD) && !(rt.x & DEAD) && mc_cut(&qs, &qe, &ts, &te, ml >> 31, (int32_t)rq.x, rq.y, (int32_t)rt.x, rt.y, min_span)) {
 			uint2 sq = cls_sub[q], st = cls_sub[t];
 			mc_arc_t a;
-			c.qs[i] = qs; c.qe[i] = qe; c.ts[i] = ts; c.te[i] = te;
+			if (qs != oqs) c.qs[i] = qs; // most hits lie inside both intervals: untouched columns are not written back
+			if (qe != oqe) c.qe[i] = qe;
+			if (ts != ots) c.ts[i] = ts;
+			if (te != ote) c.te[i] = te;
 			++n_keep;
 			int r = mc_hit2arc(q, qs, qe, t, ts, te, ml >> 31, (int)(sq.y - (sq.x & 0x7fffffffu)), (int)(st.y - (st.x & 0x7fffffffu)), max_hang, int_frac, min_ovlp, &a);
 			if (r == MC_HT_QCONT) r_cont[q] = 1;
@@ -908,7 +919,7 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	if (!sharded) { // keys + the first pass's per-tile histogram in one sweep
 		int sh0, bt0; unsigned tile;
 		radix_first_digit(bi, bi + bq, &sh0, &bt0, &tile);
-		if (bt0 > 0 && bt0 <= 10) {
+		if (bt0 > 0 && bt0 <= RS_MAXBITS) {
 			const unsigned nb = (unsigned)((n + tile - 1) / tile);
 			CHK(radix_reserve_hist(c, n));
 			ProfScope ps(c, "k_hit_keys", 16.0 * (double)n);

@@ -128,6 +128,9 @@ int ctr_fetch(mahip_ctx *c); // D2H + sync into c->h_ctr
 // exclusive prefix sum of n u32; if d_total != nullptr the grand total is written there (may alias out+n)
 int scan_exclusive_u32(mahip_ctx *c, const uint32_t *in, uint32_t *out, size_t n, uint32_t *d_total);
 // stable LSD radix sort of (u64 key, u32 val) pairs on key bits [lo0,hi0) and [lo1,hi1); result in key[*gen], val[*gen]
+#ifndef RS_MAXBITS
+#define RS_MAXBITS 9 // widest radix digit
+#endif
 int radix_sort_pairs(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1, int *gen);
 // same for bare u64 keys (a payload such as the record index may ride in the bits below lo): key bits [lo,hi)
 int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen, bool first_hist_ready = false);

@@ -15,11 +15,12 @@
 #include "mahip_internal.hpp"
 
 #define RS_THREADS 256
+#ifndef RS_ITEMS
 #define RS_ITEMS 16
+#endif
 #define RS_TILE (RS_THREADS * RS_ITEMS)
 #define RS_WAVES (RS_THREADS / 64)
-#define RS_MAXBITS 9 // (10-bit digits were measured: one pass less at cfg4, every pass 30 % slower -- a wash)
-#define RS_BINS (1 << RS_MAXBITS)
+#define RS_BINS (1 << RS_MAXBITS) // RS_MAXBITS: mahip_internal.hpp
 
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint64_t *__restrict__ key, uint32_t *__restrict__ hist,
                                                             size_t n, unsigned nb, int shift, unsigned mask)
