@@ -510,7 +510,7 @@ static int bitlen_u64(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b;
 extern "C" int mahip_sg_flags(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, const uint32_t *seq_len, const uint8_t *seq_del)
 { // asm.c:14-35: seq.len/seq.del, one candidate arc per hit at the hit's slot, local seq.del side effects
 	HIPCHK(hipSetDevice(c->dev));
-	if (!c->soa_ready) { mahip_set_error("mahip_sg_gen: hits not indexed"); return -1; }
+	CHK(hits_need_cols(c, "mahip_sg_gen"));
 	size_t n = c->n_hits;
 	uint32_t R = c->n_seq;
 	CHK(dev_reserve(c, c->slen, ((size_t)R + 4) * 4)); CHK(dev_reserve(c, c->sdel, (size_t)R + 16));
@@ -883,7 +883,7 @@ extern "C" int mahip_asg_upload(mahip_ctx_t *c, const asg_t *g)
 	HIPCHK(hipSetDevice(c->dev));
 	size_t n = g->n_arc;
 	uint32_t R = g->n_seq;
-	c->n_seq = R; c->n_seq_new = R; c->has_map = false; c->soa_ready = false; c->gsq = false;
+	c->n_seq = R; c->n_seq_new = R; c->has_map = false; c->soa_ready = false; c->gather_pending = false; c->gsq = false;
 	CHK(reserve_arcs(c, n));
 	CHK(dev_reserve(c, c->slen, ((size_t)R + 4) * 4)); CHK(dev_reserve(c, c->sdel, (size_t)R + 16));
 	CHK(dev_reserve(c, c->idx, (2 * (size_t)R + 2) * 8));

@@ -129,6 +129,17 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 	}
 }
 
+// group offsets alone, from the sorted keys (the gather itself is left to the first coverage pass: k_hit_sub<false,*,true>)
+__global__ __launch_bounds__(256) void k_hit_goff(const uint64_t *__restrict__ skey, int bi, size_t n, uint32_t n_seq, uint32_t *__restrict__ goff)
+{
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i <= n; i += (size_t)gridDim.x * 256) {
+		uint32_t q = i < n ? (uint32_t)(skey[i] >> bi) : n_seq;
+		const uint32_t r0 = i ? (uint32_t)(skey[i - 1] >> bi) + 1 : 0;
+		if (q > n_seq) q = n_seq;
+		for (uint32_t r = r0; r <= q; ++r) goff[r] = (uint32_t)i; // reads qprev+1 .. q start at slot i (reads without hits get empty groups)
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ ma_hit_sub
 // reference hit.c:109-160: per query read, the first longest interval covered by >= min_dp hits.
 //
@@ -268,11 +279,52 @@ __device__ __forceinline__ void sub_preload(const HitCols &c, const uint32_t *__
 	}
 }
 
+// Gather mode (first coverage pass of a context whose hits were just grouped by mahip_hits_sort): the wave that is about to sweep a read
+// fetches the read's records itself -- through the permutation in the low bits of the sorted keys -- and writes the SoA columns on the way.
+// The gather is a chain of dependent random fetches (memory latency), the sweep is a register sort (VALU): in one kernel the two overlap
+// across the waves of a SIMD instead of adding up as two launches.
+struct SubGather { const uint64_t *skey; const ma_hit_t *aos; uint32_t *sidx; int bi; };
+struct GKeys { uint32_t beg, end, j[2]; };                 // group bounds + input positions of the (up to 128) records, two slots per lane
+struct GRecs { uint32_t beg, end, j[2]; uint4 a[2], b[2]; }; // a = {qs, qid, qe, tn}, b = {ts, te, ml|rev, bl|del}
+
+__device__ __forceinline__ uint32_t gather_pos(const SubGather &g, size_t i)
+{ // little endian: the low word of key i; the input position sits in its low bi bits (bi <= 32)
+	const uint32_t lo = ((const uint32_t*)g.skey)[2 * i];
+	return g.bi >= 32 ? lo : lo & ((1u << g.bi) - 1u);
+}
+__device__ __forceinline__ void gather_keys(const SubGather &g, const uint32_t *__restrict__ goff, uint32_t q, unsigned lane, GKeys &k)
+{
+	k.beg = goff[q]; k.end = goff[q + 1];
+	const uint32_t H = k.end - k.beg;
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const uint32_t i = k.beg + h * 64 + lane;
+		k.j[h] = (H <= 128u && i < k.end) ? gather_pos(g, i) : 0xffffffffu;
+	}
+}
+__device__ __forceinline__ void gather_recs(const SubGather &g, const GKeys &k, GRecs &r)
+{
+	r.beg = k.beg; r.end = k.end;
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		r.j[h] = k.j[h];
+		r.a[h] = make_uint4(0, 0, 0, 0); r.b[h] = make_uint4(0, 0, 0, DEAD);
+		if (k.j[h] != 0xffffffffu) { const uint4 *p = (const uint4*)(g.aos + k.j[h]); r.a[h] = p[0]; r.b[h] = p[1]; }
+	}
+}
+__device__ __forceinline__ void gather_store(const HitCols &c, const SubGather &g, uint32_t i, uint32_t j, uint4 a, uint4 b)
+{
+	c.qid[i] = a.y; c.qs[i] = a.x; c.qe[i] = a.z; c.tn[i] = a.w;
+	c.ts[i] = b.x; c.te[i] = b.y; c.ml[i] = b.z; c.bl[i] = b.w & ~DEAD;
+	g.sidx[i] = j;
+}
+
 // one read in registers; returns 1 if the read keeps an interval (value identical on all lanes).  pre != nullptr: the
 // columns of the (at most 128) hits are already in registers
-template <int ITEMS, bool FUSE>
+template <int ITEMS, bool FUSE, bool GATHER = false>
 __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q, uint32_t beg, uint32_t end, int min_dp, float min_iden,
-                                                   int end_clip, uint2 *__restrict__ sub, unsigned lane, const SubFuse &f, SubAcc &acc, const SubPre *pre = nullptr)
+                                                   int end_clip, uint2 *__restrict__ sub, unsigned lane, const SubFuse &f, SubAcc &acc, const SubPre *pre = nullptr,
+                                                   const SubGather *g = nullptr)
 {
 	uint32_t x[ITEMS];
 	int live_any = 0, ev_any = 0;
@@ -288,6 +340,13 @@ __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q,
 			if (pre && h < 2) {
 				bl = pre->bl[h]; ml = pre->ml[h]; qs = pre->qs[h]; qe = pre->qe[h]; tn = pre->tn[h];
 				alive = !(bl & DEAD) && (!FUSE || fuse_cut_flt_v(c, i, f, q, rq, tn, qs, qe, ml, bl, acc, pre->rt[h], pre->ts[h], pre->te[h]));
+			} else if (GATHER) { // the record through the sorted key; the columns are written on the way
+				const uint32_t j = gather_pos(*g, i);
+				const uint4 *p = (const uint4*)(g->aos + j);
+				const uint4 a = p[0], b = p[1];
+				gather_store(c, *g, i, j, a, b);
+				bl = b.w & ~DEAD; ml = b.z; qs = a.x; qe = a.z; tn = a.w;
+				alive = 1;
 			} else {
 				bl = c.bl[i]; ml = c.ml[i]; qs = c.qs[i]; qe = c.qe[i]; tn = c.tn[i]; // independent loads
 				alive = !(bl & DEAD) && (!FUSE || fuse_cut_flt(c, i, f, q, rq, tn, qs, qe, ml, bl, acc));
@@ -350,14 +409,43 @@ __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q,
 // Three instantiations per fusion mode share the work by read size, so that each runs at the occupancy its register
 // need allows: CLS 0 = reads with <= 128 hits (4 events per lane, 8 waves/SIMD, software-pipelined loads), CLS 1 = 129..256
 // hits (16 events per lane), CLS 2 = 257..512 hits (32 events per lane); larger reads go to the block kernel (tier B).
-template <bool FUSE, int CLS>
+template <bool FUSE, int CLS, bool GATHER = false>
 __global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
                                                   int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
-                                                  uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr, SubFuse f)
+                                                  uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr, SubFuse f, SubGather g)
 {
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t n_kept = 0;
 	SubAcc acc = {0, 0, 0};
+	if (CLS == 0 && GATHER) { // two-deep software pipeline: keys of the read after next and records of the next read are in flight while this read is swept
+		const uint32_t stride = gridDim.x * 4;
+		uint32_t q = blockIdx.x * 4 + wave;
+		GKeys kn;
+		GRecs cur, nxt;
+		if (q < n_seq) { gather_keys(g, goff, q, lane, kn); gather_recs(g, kn, cur); }
+		if (q + stride < n_seq) gather_keys(g, goff, q + stride, lane, kn);
+		while (q < n_seq) {
+			const uint32_t qn = q + stride;
+			if (qn < n_seq) gather_recs(g, kn, nxt);
+			if (qn + stride < n_seq) gather_keys(g, goff, qn + stride, lane, kn);
+			const uint32_t beg = cur.beg, end = cur.end, H = end - beg;
+			if (H == 0) { if (lane == 0) sub[q] = make_uint2(0, 0); } // never a query: calloc'ed zero (hit.c:115)
+			else if (H <= 128) {
+				SubPre pre;
+				pre.beg = beg; pre.end = end;
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const uint32_t i = beg + h * 64 + lane;
+					if (i < end) gather_store(c, g, i, cur.j[h], cur.a[h], cur.b[h]);
+					pre.bl[h] = cur.b[h].w & ~DEAD; pre.ml[h] = cur.b[h].z; pre.qs[h] = cur.a[h].x; pre.qe[h] = cur.a[h].z; pre.tn[h] = cur.a[h].w;
+					pre.ts[h] = pre.te[h] = 0;
+				}
+				if (H <= 64) n_kept += sub_group_regs<2, false>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc, &pre);
+				else n_kept += sub_group_regs<4, false>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc, &pre);
+			}
+			cur = nxt; q = qn;
+		}
+	} else
 	if (CLS == 0) { // software pipeline: the hits of the wave's next read are in flight while the current read is processed
 		const uint32_t stride = gridDim.x * 4;
 		uint32_t q = blockIdx.x * 4 + wave;
@@ -381,10 +469,18 @@ __global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__re
 	for (uint32_t q = blockIdx.x * 4 + wave; q < n_seq; q += gridDim.x * 4) {
 		uint32_t beg = goff[q], end = goff[q + 1], H = end - beg;
 		if (CLS == 1) {
-			if (H > 128 && H <= 256) n_kept += sub_group_regs<8, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc);
+			if (H > 128 && H <= 256) n_kept += sub_group_regs<8, FUSE, GATHER>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc, nullptr, &g);
 		} else {
-			if (H > 256 && H <= SUB_REG_MAX_HITS) n_kept += sub_group_regs<16, FUSE>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc);
-			else if (H > SUB_REG_MAX_HITS && lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF], 1ull); ovf[k] = q; } // tier B
+			if (H > 256 && H <= SUB_REG_MAX_HITS) n_kept += sub_group_regs<16, FUSE, GATHER>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc, nullptr, &g);
+			else if (H > SUB_REG_MAX_HITS) { // tier B sweeps it from the columns: in gather mode they are written here
+				if (GATHER)
+					for (uint32_t i = beg + lane; i < end; i += 64) {
+						const uint32_t j = gather_pos(g, i);
+						const uint4 *p = (const uint4*)(g.aos + j);
+						gather_store(c, g, i, j, p[0], p[1]);
+					}
+				if (lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF], 1ull); ovf[k] = q; }
+			}
 		}
 	}
 	blk_add_u64(&ctr[CT_REMAIN], lane == 0 ? n_kept : 0);
@@ -686,7 +782,7 @@ static int reserve_read_arrays(mahip_ctx *c)
 static int hits_common_setup(mahip_ctx *c, size_t n, uint32_t n_seq)
 {
 	c->n_hits = n; c->n_in = n; c->n_live = n; c->n_seq = n_seq; c->n_seq_new = n_seq;
-	c->soa_ready = false; c->has_map = false; c->graph_ready = false;
+	c->soa_ready = false; c->has_map = false; c->graph_ready = false; c->gather_pending = false;
 	c->hint_max_qs = 0; // hints describe one upload: set them again after every upload/adopt
 	c->lazy_squeeze = false;
 	c->sorted_here = false; c->hrank_ready = false; c->orank_ready = false;
@@ -889,7 +985,6 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 { // groups the hits by query id (input order inside a group); see the note at the top of the sort section
 	HIPCHK(hipSetDevice(c->dev));
 	size_t n = c->n_hits;
-	HitCols h = cols_of(c);
 	if (n == 0) {
 		HIPCHK(hipMemsetAsync(c->goff.p, 0, ((size_t)c->n_seq + 1) * 4, c->st));
 		c->soa_ready = true; c->n_live = 0;
@@ -950,13 +1045,27 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 		return 0;
 	}
 	CHK(radix_sort_keys(c, n, bi, bi + bq, &gen, first_hist));
-	{
-		ProfScope ps(c, "k_hit_gather", 76.0 * (double)n); // key 8 + record 32 + columns 32 + input position 4
-		hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256 * GATHER_ILP)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)P<uint64_t>(c->key[gen]),
-		                   bi, n, c->n_seq, h, P<uint32_t>(c->goff), P<uint32_t>(c->sidx));
+	{ // the records stay where they are for now: the first consumer moves them (hits_need_cols), ma_hit_sub while it sweeps them
+		ProfScope ps(c, "k_hit_goff", 8.0 * (double)n);
+		hipLaunchKernelGGL(k_hit_goff, dim3(grid_for(n + 1, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[gen]), bi, n, c->n_seq, P<uint32_t>(c->goff));
 	}
 	HIPCHK(hipGetLastError());
+	c->gather_pending = true; c->gk_gen = gen; c->gk_bi = bi;
 	c->soa_ready = true;
+	return 0;
+}
+
+// the SoA columns of a context whose gather is still pending (mahip_hits_sort leaves it to the first consumer)
+int hits_need_cols(mahip_ctx *c, const char *who)
+{
+	if (!c->soa_ready) { mahip_set_error("%s: hits not indexed", who); return -1; }
+	if (!c->gather_pending) return 0;
+	const size_t n = c->n_hits;
+	ProfScope ps(c, "k_hit_gather", 76.0 * (double)n); // key 8 + record 32 + columns 32 + input position 4
+	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256 * GATHER_ILP)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)P<uint64_t>(c->key[c->gk_gen]),
+	                   c->gk_bi, n, c->n_seq, cols_of(c), P<uint32_t>(c->goff), P<uint32_t>(c->sidx));
+	HIPCHK(hipGetLastError());
+	c->gather_pending = false;
 	return 0;
 }
 
@@ -968,7 +1077,7 @@ extern "C" int mahip_hits_index(mahip_ctx_t *c)
 	ProfScope ps(c, "k_hit_gather", 64.0 * (double)n);
 	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256 * GATHER_ILP)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)nullptr, 0, n, c->n_seq, h, P<uint32_t>(c->goff), (uint32_t*)nullptr);
 	HIPCHK(hipGetLastError());
-	c->soa_ready = true;
+	c->soa_ready = true; c->gather_pending = false;
 	c->sorted_here = false; c->hrank_ready = false; c->orank_ready = false; // the caller's order is final (per-symbol path: already the reference's)
 	return 0;
 }
@@ -984,14 +1093,27 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	uint2 *sub = P<uint2>(c->sub[slot]);
 	SubFuse nofuse = {nullptr, 0, 0, 0, nullptr};
-	if (R) {
+	SubGather nog = {nullptr, nullptr, nullptr, 0};
+	const bool fuse_gather = c->gather_pending && R && c->n_hits && !getenv("MA_NO_GATHER_FUSE");
+	if (c->gather_pending && !fuse_gather) CHK(hits_need_cols(c, "mahip_hits_sub"));
+	if (fuse_gather) { // the sweep fetches the records itself and writes the columns on the way
+		SubGather g = {(const uint64_t*)P<uint64_t>(c->key[c->gk_gen]), c->d_aos, P<uint32_t>(c->sidx), c->gk_bi};
+		ProfScope ps(c, "k_hit_sub<gather>", (76.0 + 48.0) * (double)c->n_hits + 8.0 * R); // the sort's data movement + ma_hit_sub
+		hipLaunchKernelGGL((k_hit_sub<false, 0, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+		hipLaunchKernelGGL((k_hit_sub<false, 1, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+		hipLaunchKernelGGL((k_hit_sub<false, 2, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+		c->gather_pending = false;
+	} else if (R) {
 		ProfScope ps(c, "k_hit_sub", 48.0 * (double)c->n_hits + 8.0 * R); // 32 r + 8 w events + 8 r events per stored hit
 		hipLaunchKernelGGL((k_hit_sub<false, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, nofuse);
+		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, nog);
 		hipLaunchKernelGGL((k_hit_sub<false, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, nofuse);
+		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, nog);
 		hipLaunchKernelGGL((k_hit_sub<false, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, nofuse);
+		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, nog);
 	}
 	if (R) { // tier B always runs behind the register tiers on a small grid: it finds its work list (usually empty) in the device counter
 		CHK(dev_reserve(c, c->big0, (2 * c->n_hits + 8) * 4));
@@ -1011,7 +1133,7 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
                                      int out_slot, size_t *n_cut, size_t *n_flt, float *cov, size_t *n_remained)
 {
 	HIPCHK(hipSetDevice(c->dev));
-	if (!c->soa_ready) { mahip_set_error("mahip_hits_cutflt_sub: hits not indexed"); return -1; }
+	CHK(hits_need_cols(c, "mahip_hits_cutflt_sub"));
 	HitCols h = cols_of(c);
 	uint32_t R = c->n_seq;
 	CHK(ctr_zero(c));
@@ -1023,11 +1145,11 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
 	if (R) {
 		ProfScope ps(c, "k_hit_sub<cut+flt>", (80.0 + 80.0 + 48.0) * (double)c->n_hits + 8.0 * R); // cut 80 + flt 80 + sub 48 B per hit
 		hipLaunchKernelGGL((k_hit_sub<true, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f);
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0});
 		hipLaunchKernelGGL((k_hit_sub<true, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f);
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0});
 		hipLaunchKernelGGL((k_hit_sub<true, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f);
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0});
 	}
 	if (R) {
 		CHK(dev_reserve(c, c->big0, (2 * c->n_hits + 8) * 4));
@@ -1053,7 +1175,7 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
 extern "C" int mahip_hits_cut_contained_flags(mahip_ctx_t *c, int cut_slot, int min_span, const ma_opt_t *opt)
 {
 	HIPCHK(hipSetDevice(c->dev));
-	if (!c->soa_ready) { mahip_set_error("mahip_hits_cut_contained: hits not indexed"); return -1; }
+	CHK(hits_need_cols(c, "mahip_hits_cut_contained"));
 	size_t n = c->n_hits;
 	uint32_t R = c->n_seq;
 	CHK(ctr_zero(c));
@@ -1103,7 +1225,7 @@ extern "C" int mahip_hits_cut_contained(mahip_ctx_t *c, int cut_slot, int min_sp
 extern "C" int mahip_hits_cut(mahip_ctx_t *c, int slot, int min_span, size_t *n_live)
 {
 	HIPCHK(hipSetDevice(c->dev));
-	if (!c->soa_ready) { mahip_set_error("mahip_hits_cut: hits not indexed"); return -1; }
+	CHK(hits_need_cols(c, "mahip_hits_cut"));
 	size_t n = c->n_hits;
 	CHK(ctr_zero(c));
 	if (n) {
@@ -1119,7 +1241,7 @@ extern "C" int mahip_hits_cut(mahip_ctx_t *c, int slot, int min_span, size_t *n_
 extern "C" int mahip_hits_flt(mahip_ctx_t *c, int slot, int max_hang, int min_ovlp, size_t *n_live, float *cov)
 {
 	HIPCHK(hipSetDevice(c->dev));
-	if (!c->soa_ready) { mahip_set_error("mahip_hits_flt: hits not indexed"); return -1; }
+	CHK(hits_need_cols(c, "mahip_hits_flt"));
 	size_t n = c->n_hits;
 	uint32_t R = c->n_seq;
 	CHK(ctr_zero(c));
@@ -1151,7 +1273,7 @@ extern "C" int mahip_sub_merge(mahip_ctx_t *c)
 extern "C" int mahip_hits_contained_flags(mahip_ctx_t *c, const ma_opt_t *opt)
 {
 	HIPCHK(hipSetDevice(c->dev));
-	if (!c->soa_ready) { mahip_set_error("mahip_hits_contained: hits not indexed"); return -1; }
+	CHK(hits_need_cols(c, "mahip_hits_contained"));
 	size_t n = c->n_hits;
 	uint32_t R = c->n_seq;
 	HIPCHK(hipMemsetAsync(c->r_cont.p, 0, R, c->st));
@@ -1293,7 +1415,7 @@ extern "C" int mahip_survivors_download(mahip_ctx_t *c, uint32_t *old_ids)
 extern "C" int mahip_hits_download(mahip_ctx_t *c, ma_hit_t *out, size_t *n_out)
 {
 	HIPCHK(hipSetDevice(c->dev));
-	if (!c->soa_ready) { mahip_set_error("mahip_hits_download: hits not indexed"); return -1; }
+	CHK(hits_need_cols(c, "mahip_hits_download"));
 	size_t n = c->n_hits;
 	if (c->lazy_squeeze && n) { // the resident pipeline postponed the squeeze of the hits: do it now
 		CHK(ctr_zero(c));

@@ -62,6 +62,7 @@ struct mahip_ctx {
 	DevBuf pushrows[2];       // sharded mode: this rank's arcs in push order as packed rows (the arc arrays are overwritten by the exchange)
 	uint32_t n_push = 0;
 	bool sorted_here = false, hrank_ready = false, orank_ready = false; // hits grouped by mahip_hits_sort (d_aos = the unsorted input) / hrank valid / orank valid
+	bool gather_pending = false; int gk_gen = 0, gk_bi = 0; // mahip_hits_sort left the records in place: sorted keys in key[gk_gen], position in their low gk_bi bits
 	bool push_ordered = false; // sharded mode: pushrows[1] holds this rank's arcs in push order
 	mahip_tie_info_t tie = {0, 0, 0, 0, 0, 0, 0};
 	uint32_t n_seq_new = 0;
@@ -142,6 +143,8 @@ int reference_order(mahip_ctx *c, const uint64_t *d_keys, size_t n, uint32_t *d_
 int hits_reference_rank(mahip_ctx *c);
 // bits of the largest query start of the input records
 int hits_qs_bits(mahip_ctx *c);
+// make sure the SoA columns exist (the gather after mahip_hits_sort is lazy)
+int hits_need_cols(mahip_ctx *c, const char *who);
 // bulk pageable<->device copy through per-thread pinned slots (xfer.hip); returns after the copy is complete
 int xfer_copy(mahip_ctx *c, void *dev_ptr, void *host_ptr, size_t bytes, int to_device);
 void xfer_pool_free(mahip_ctx *c);
