@@ -131,12 +131,18 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 
 // group offsets alone, from the sorted keys (the gather itself is left to the first coverage pass: k_hit_sub<false,*,true>)
 __global__ __launch_bounds__(256) void k_hit_goff(const uint64_t *__restrict__ skey, int bi, size_t n, uint32_t n_seq, uint32_t *__restrict__ goff)
-{
-	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i <= n; i += (size_t)gridDim.x * 256) {
-		uint32_t q = i < n ? (uint32_t)(skey[i] >> bi) : n_seq;
-		const uint32_t r0 = i ? (uint32_t)(skey[i - 1] >> bi) + 1 : 0;
-		if (q > n_seq) q = n_seq;
-		for (uint32_t r = r0; r <= q; ++r) goff[r] = (uint32_t)i; // reads qprev+1 .. q start at slot i (reads without hits get empty groups)
+{ // two slots per thread (one 16-byte load); slot n is the sentinel that closes the last groups
+	for (size_t base = (size_t)blockIdx.x * 512; base <= n; base += (size_t)gridDim.x * 512) {
+		const size_t i0 = base + 2 * (size_t)threadIdx.x;
+		uint32_t q0 = n_seq, q1 = n_seq;
+		if (i0 + 1 < n) { const ulonglong2 kk = *(const ulonglong2*)(skey + i0); q0 = (uint32_t)(kk.x >> bi); q1 = (uint32_t)(kk.y >> bi); }
+		else if (i0 < n) q0 = (uint32_t)(skey[i0] >> bi);
+		if (q0 > n_seq) q0 = n_seq;
+		if (q1 > n_seq) q1 = n_seq;
+		uint32_t qprev = __shfl_up(q1, 1, 64); // the predecessor's id from the neighbouring lane; only the first lane of a wave loads it
+		if ((threadIdx.x & 63) == 0 && i0 && i0 <= n) qprev = (uint32_t)(skey[i0 - 1] >> bi);
+		if (i0 <= n) for (uint32_t r = i0 ? qprev + 1 : 0; r <= q0; ++r) goff[r] = (uint32_t)i0; // reads qprev+1 .. q start at slot i (reads without hits: empty groups)
+		if (i0 + 1 <= n) for (uint32_t r = q0 + 1; r <= q1; ++r) goff[r] = (uint32_t)(i0 + 1);
 	}
 }
 
@@ -150,6 +156,7 @@ __global__ __launch_bounds__(256) void k_hit_goff(const uint64_t *__restrict__ s
 // wave max-reduce on (length, -position).  Reads with more than 512 hits go to tier B.
 // Tier B: one 256-thread block per read, events in LDS (<= 8192) or in global scratch (any size).
 // grid of the coverage kernels (blocks of 4 waves, one read per wave at a time); env MA_SUB_BLOCKS for experiments
+static unsigned sub_lds() { static int v = -1; if (v < 0) { const char *e = getenv("MA_EXP_SUB_LDS"); v = e ? atoi(e) : 0; } return (unsigned)v; } // experiment: dynamic LDS bytes per block = an occupancy cap
 static unsigned sub_blocks() { static unsigned v = 0; if (!v) { const char *e = getenv("MA_SUB_BLOCKS"); v = e ? (unsigned)atoi(e) : 2 * MA_STREAM_BLOCKS; /* 2 x the resident capacity: the dispatcher evens out the tail (measured 2048: 0.51, 4096: 0.46, 8192: 0.45 ms; more blocks = more end-of-block atomics) */ if (v < 1) v = 1; } return v; }
 #define MA_SUB_BLOCKS sub_blocks()
 #define EV_PAD 0xffffffffu
@@ -283,33 +290,44 @@ __device__ __forceinline__ void sub_preload(const HitCols &c, const uint32_t *__
 // fetches the read's records itself -- through the permutation in the low bits of the sorted keys -- and writes the SoA columns on the way.
 // The gather is a chain of dependent random fetches (memory latency), the sweep is a register sort (VALU): in one kernel the two overlap
 // across the waves of a SIMD instead of adding up as two launches.
-struct SubGather { const uint64_t *skey; const ma_hit_t *aos; uint32_t *sidx; int bi; };
-struct GKeys { uint32_t beg, end, j[2]; };                 // group bounds + input positions of the (up to 128) records, two slots per lane
-struct GRecs { uint32_t beg, end, j[2]; uint4 a[2], b[2]; }; // a = {qs, qid, qe, tn}, b = {ts, te, ml|rev, bl|del}
+struct SubGather { const uint64_t *skey; const ma_hit_t *aos; uint32_t *sidx; int bi; uint32_t n; }; // n = slots
+struct GBounds { uint32_t beg, end; };                     // a read's slots
+struct GKeys { uint32_t beg, end, j[2]; };                 // + low words of the sorted keys of its (up to 128) slots, two slots per lane
+struct GRecs { uint32_t beg, end, j[2]; uint4 a[2], b[2]; }; // + input positions and records: a = {qs, qid, qe, tn}, b = {ts, te, ml|rev, bl|del}
 
 __device__ __forceinline__ uint32_t gather_pos(const SubGather &g, size_t i)
 { // little endian: the low word of key i; the input position sits in its low bi bits (bi <= 32)
 	const uint32_t lo = ((const uint32_t*)g.skey)[2 * i];
 	return g.bi >= 32 ? lo : lo & ((1u << g.bi) - 1u);
 }
-__device__ __forceinline__ void gather_keys(const SubGather &g, const uint32_t *__restrict__ goff, uint32_t q, unsigned lane, GKeys &k)
+// The three stages of the pipelined chain.  All loads are UNCONDITIONAL (indices clamped into range, lanes without a slot fetch
+// record 0): straight-line code lets the compiler count the outstanding loads (s_waitcnt vmcnt(N)) instead of draining the queue at
+// every join, which is what keeps the next read's fetches in flight during the sweep of the current one.
+__device__ __forceinline__ void gather_bounds(const uint32_t *__restrict__ goff, uint64_t q, uint32_t n_seq, GBounds &b)
 {
-	k.beg = goff[q]; k.end = goff[q + 1];
-	const uint32_t H = k.end - k.beg;
+	const uint32_t qc = q < n_seq ? (uint32_t)q : n_seq - 1;
+	b.beg = goff[qc]; b.end = goff[qc + 1];
+}
+__device__ __forceinline__ void gather_keys(const SubGather &g, const GBounds &b, unsigned lane, GKeys &k)
+{
+	k.beg = b.beg; k.end = b.end;
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const uint32_t i = b.beg + h * 64 + lane, ic = i < g.n ? i : g.n - 1;
+		k.j[h] = ((const uint32_t*)g.skey)[2 * (size_t)ic];
+	}
+}
+__device__ __forceinline__ void gather_recs(const SubGather &g, const GKeys &k, unsigned lane, GRecs &r)
+{
+	r.beg = k.beg; r.end = k.end;
+	const bool mine = k.end - k.beg <= 128u;
+	const uint32_t mask = g.bi >= 32 ? 0xffffffffu : (1u << g.bi) - 1u;
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint32_t i = k.beg + h * 64 + lane;
-		k.j[h] = (H <= 128u && i < k.end) ? gather_pos(g, i) : 0xffffffffu;
-	}
-}
-__device__ __forceinline__ void gather_recs(const SubGather &g, const GKeys &k, GRecs &r)
-{
-	r.beg = k.beg; r.end = k.end;
-#pragma unroll
-	for (int h = 0; h < 2; ++h) {
-		r.j[h] = k.j[h];
-		r.a[h] = make_uint4(0, 0, 0, 0); r.b[h] = make_uint4(0, 0, 0, DEAD);
-		if (k.j[h] != 0xffffffffu) { const uint4 *p = (const uint4*)(g.aos + k.j[h]); r.a[h] = p[0]; r.b[h] = p[1]; }
+		r.j[h] = (mine && i < k.end) ? (k.j[h] & mask) : 0u;
+		const uint4 *p = (const uint4*)(g.aos + r.j[h]);
+		r.a[h] = p[0]; r.b[h] = p[1];
 	}
 }
 __device__ __forceinline__ void gather_store(const HitCols &c, const SubGather &g, uint32_t i, uint32_t j, uint4 a, uint4 b)
@@ -409,41 +427,59 @@ __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q,
 // Three instantiations per fusion mode share the work by read size, so that each runs at the occupancy its register
 // need allows: CLS 0 = reads with <= 128 hits (4 events per lane, 8 waves/SIMD, software-pipelined loads), CLS 1 = 129..256
 // hits (16 events per lane), CLS 2 = 257..512 hits (32 events per lane); larger reads go to the block kernel (tier B).
+#ifdef EXP_SUB_WAVES // experiment: occupancy target of the coverage kernels
+#define SUB_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(EXP_SUB_WAVES, 8)))
+#else
+#define SUB_WAVES_ATTR
+#endif
 template <bool FUSE, int CLS, bool GATHER = false>
-__global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
+__global__ __launch_bounds__(256) SUB_WAVES_ATTR void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
                                                   int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
                                                   uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr, SubFuse f, SubGather g)
 {
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t n_kept = 0;
 	SubAcc acc = {0, 0, 0};
-	if (CLS == 0 && GATHER) { // two-deep software pipeline: keys of the read after next and records of the next read are in flight while this read is swept
-		const uint32_t stride = gridDim.x * 4;
-		uint32_t q = blockIdx.x * 4 + wave;
+	if (CLS == 0 && GATHER) { // three-deep software pipeline over the chain bounds -> keys -> records: every load is issued a whole sweep before its
+		// first use, and nothing in between waits for it
+		const uint64_t stride = (uint64_t)gridDim.x * 4;
+		uint64_t q = blockIdx.x * 4 + wave;
+		GBounds bn;
 		GKeys kn;
 		GRecs cur, nxt;
-		if (q < n_seq) { gather_keys(g, goff, q, lane, kn); gather_recs(g, kn, cur); }
-		if (q + stride < n_seq) gather_keys(g, goff, q + stride, lane, kn);
+		gather_bounds(goff, q, n_seq, bn); gather_keys(g, bn, lane, kn); gather_recs(g, kn, lane, cur);
+		gather_bounds(goff, q + stride, n_seq, bn); gather_keys(g, bn, lane, kn);
+		gather_bounds(goff, q + 2 * stride, n_seq, bn);
 		while (q < n_seq) {
-			const uint32_t qn = q + stride;
-			if (qn < n_seq) gather_recs(g, kn, nxt);
-			if (qn + stride < n_seq) gather_keys(g, goff, qn + stride, lane, kn);
 			const uint32_t beg = cur.beg, end = cur.end, H = end - beg;
+			// (1) the columns of this read FIRST, and unconditionally (lanes without a slot write to the spare slots behind the arrays): the
+			// memory counter is in order, so a store issued after the next read's loads would have to be acknowledged before those loads
+			// count as complete -- every sweep would start by waiting for its predecessor's write-back
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const uint32_t i = beg + h * 64 + lane;
+				gather_store(c, g, (H <= 128u && i < end) ? i : g.n + lane, cur.j[h], cur.a[h], cur.b[h]);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			// (2) the fetches of the reads behind it
+			gather_recs(g, kn, lane, nxt);
+			gather_keys(g, bn, lane, kn);
+			gather_bounds(goff, q + 3 * stride, n_seq, bn);
+			__builtin_amdgcn_sched_barrier(0);
+			// (3) the sweep
 			if (H == 0) { if (lane == 0) sub[q] = make_uint2(0, 0); } // never a query: calloc'ed zero (hit.c:115)
 			else if (H <= 128) {
 				SubPre pre;
 				pre.beg = beg; pre.end = end;
 #pragma unroll
 				for (int h = 0; h < 2; ++h) {
-					const uint32_t i = beg + h * 64 + lane;
-					if (i < end) gather_store(c, g, i, cur.j[h], cur.a[h], cur.b[h]);
 					pre.bl[h] = cur.b[h].w & ~DEAD; pre.ml[h] = cur.b[h].z; pre.qs[h] = cur.a[h].x; pre.qe[h] = cur.a[h].z; pre.tn[h] = cur.a[h].w;
 					pre.ts[h] = pre.te[h] = 0;
 				}
-				if (H <= 64) n_kept += sub_group_regs<2, false>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc, &pre);
-				else n_kept += sub_group_regs<4, false>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc, &pre);
+				if (H <= 64) n_kept += sub_group_regs<2, false>(c, (uint32_t)q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc, &pre);
+				else n_kept += sub_group_regs<4, false>(c, (uint32_t)q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc, &pre);
 			}
-			cur = nxt; q = qn;
+			cur = nxt; q += stride;
 		}
 	} else
 	if (CLS == 0) { // software pipeline: the hits of the wave's next read are in flight while the current read is processed
@@ -788,7 +824,7 @@ static int hits_common_setup(mahip_ctx *c, size_t n, uint32_t n_seq)
 	c->sorted_here = false; c->hrank_ready = false; c->orank_ready = false;
 	memset(&c->tie, 0, sizeof(c->tie));
 	CHK(reserve_read_arrays(c));
-	for (int k = 0; k < 8; ++k) CHK(dev_reserve(c, c->col[k], (n + 1) * 4));
+	for (int k = 0; k < 8; ++k) CHK(dev_reserve(c, c->col[k], (n + 128) * 4)); // + spare slots (k_hit_sub gather mode: lanes without a slot)
 	return 0;
 }
 
@@ -993,7 +1029,7 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	if (n >= 0xffffffffull) { mahip_set_error("mahip_hits_sort: too many hits"); return -1; }
 	for (int k = 0; k < 2; ++k) CHK(dev_reserve(c, c->key[k], (n + 1) * 8));
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
-	CHK(dev_reserve(c, c->sidx, (n + 1) * 4));
+	CHK(dev_reserve(c, c->sidx, (n + 128) * 4));
 	c->sorted_here = true; c->hrank_ready = false; c->orank_ready = false;
 	// digit plan: bits of the query id above the bits of the record index
 	int bq, bi = bitlen(n - 1);
@@ -1047,7 +1083,7 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	CHK(radix_sort_keys(c, n, bi, bi + bq, &gen, first_hist));
 	{ // the records stay where they are for now: the first consumer moves them (hits_need_cols), ma_hit_sub while it sweeps them
 		ProfScope ps(c, "k_hit_goff", 8.0 * (double)n);
-		hipLaunchKernelGGL(k_hit_goff, dim3(grid_for(n + 1, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[gen]), bi, n, c->n_seq, P<uint32_t>(c->goff));
+		hipLaunchKernelGGL(k_hit_goff, dim3(grid_for(n + 1, 512, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[gen]), bi, n, c->n_seq, P<uint32_t>(c->goff));
 	}
 	HIPCHK(hipGetLastError());
 	c->gather_pending = true; c->gk_gen = gen; c->gk_bi = bi;
@@ -1093,26 +1129,26 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	uint2 *sub = P<uint2>(c->sub[slot]);
 	SubFuse nofuse = {nullptr, 0, 0, 0, nullptr};
-	SubGather nog = {nullptr, nullptr, nullptr, 0};
+	SubGather nog = {nullptr, nullptr, nullptr, 0, 0};
 	const bool fuse_gather = c->gather_pending && R && c->n_hits && !getenv("MA_NO_GATHER_FUSE");
 	if (c->gather_pending && !fuse_gather) CHK(hits_need_cols(c, "mahip_hits_sub"));
 	if (fuse_gather) { // the sweep fetches the records itself and writes the columns on the way
-		SubGather g = {(const uint64_t*)P<uint64_t>(c->key[c->gk_gen]), c->d_aos, P<uint32_t>(c->sidx), c->gk_bi};
+		SubGather g = {(const uint64_t*)P<uint64_t>(c->key[c->gk_gen]), c->d_aos, P<uint32_t>(c->sidx), c->gk_bi, (uint32_t)c->n_hits};
 		ProfScope ps(c, "k_hit_sub<gather>", (76.0 + 48.0) * (double)c->n_hits + 8.0 * R); // the sort's data movement + ma_hit_sub
-		hipLaunchKernelGGL((k_hit_sub<false, 0, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 0, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-		hipLaunchKernelGGL((k_hit_sub<false, 1, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 1, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-		hipLaunchKernelGGL((k_hit_sub<false, 2, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 2, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
 		c->gather_pending = false;
 	} else if (R) {
 		ProfScope ps(c, "k_hit_sub", 48.0 * (double)c->n_hits + 8.0 * R); // 32 r + 8 w events + 8 r events per stored hit
-		hipLaunchKernelGGL((k_hit_sub<false, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, nog);
-		hipLaunchKernelGGL((k_hit_sub<false, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, nog);
-		hipLaunchKernelGGL((k_hit_sub<false, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, nog);
 	}
 	if (R) { // tier B always runs behind the register tiers on a small grid: it finds its work list (usually empty) in the device counter
@@ -1144,12 +1180,12 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
 	SubFuse f = {(const uint2*)P<uint2>(c->sub[cut_slot]), min_span, max_hang, min_ovlp, P<uint8_t>(c->r_live)};
 	if (R) {
 		ProfScope ps(c, "k_hit_sub<cut+flt>", (80.0 + 80.0 + 48.0) * (double)c->n_hits + 8.0 * R); // cut 80 + flt 80 + sub 48 B per hit
-		hipLaunchKernelGGL((k_hit_sub<true, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0});
-		hipLaunchKernelGGL((k_hit_sub<true, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0});
-		hipLaunchKernelGGL((k_hit_sub<true, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0});
+		hipLaunchKernelGGL((k_hit_sub<true, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0});
+		hipLaunchKernelGGL((k_hit_sub<true, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0});
+		hipLaunchKernelGGL((k_hit_sub<true, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0});
 	}
 	if (R) {
 		CHK(dev_reserve(c, c->big0, (2 * c->n_hits + 8) * 4));
