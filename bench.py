@@ -107,9 +107,9 @@ def pmc_traffic(kernel, workload):
         return None, None
     names = {k.replace("void ", ""): v for k, v in d.items()}
     per_launch = lambda v: v["fetch_bytes_x2"] + v["write_bytes"]
-    scope = {"k_hit_sub<cut+flt>": "k_hit_sub<true,", "k_hit_sub": "k_hit_sub<false,"}.get(kernel)
+    scope = {"k_hit_sub<cut+flt>": ("k_hit_sub<true,", None), "k_hit_sub": ("k_hit_sub<false,", False), "k_hit_sub<gather>": ("k_hit_sub<false,", True)}.get(kernel)
     if scope:  # a timed scope of the coverage passes = one launch of each size-class kernel: their bytes add up
-        parts = [v for k, v in names.items() if k.startswith(scope)]
+        parts = [v for k, v in names.items() if k.startswith(scope[0]) and (scope[1] is None or k.endswith(", true>") == scope[1])]
         return (round(sum(per_launch(v) for v in parts)) if parts else None), os.path.relpath(path, ROOT)
     base = kernel.split("<")[0]
     hits = [v for k, v in names.items() if k.split("<")[0] == base]

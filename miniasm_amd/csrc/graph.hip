@@ -67,9 +67,11 @@ __global__ __launch_bounds__(256) void k_sg_seq(const uint2 *__restrict__ sub, c
 __device__ __forceinline__ int sg_candidate(const HitColsG &h, size_t i, const uint32_t *__restrict__ slen, int max_hang, float int_frac, int min_ovlp,
                                             const uint8_t *__restrict__ lazy_del, mc_arc_t *x, uint32_t *q_, uint32_t *t_, int *self_rc)
 { // <0: dead slot; else mc_hit2arc's verdict (r >= 0: arc in *x), *self_rc: the palindromic self hit of asm.c:27-30
+	const uint32_t q = h.qid[i];
+	if (lazy_del && lazy_del[q]) return -100; // first: after containment most READS are gone, and a group's lanes share q -- whole waves leave here with one column read
 	if (h.bl[i] & DEAD) return -100;
-	uint32_t q = h.qid[i], t = h.tn[i];
-	if (lazy_del && (lazy_del[q] || lazy_del[t])) return -100;
+	const uint32_t t = h.tn[i];
+	if (lazy_del && lazy_del[t]) return -100;
 	uint32_t qs = h.qs[i], qe = h.qe[i], ts = h.ts[i], te = h.te[i];
 	int rev = h.ml[i] >> 31;
 	*q_ = q; *t_ = t;
@@ -262,11 +264,18 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t *lv = s_v[wave], *ll = s_l[wave], *slot = s_slot[wave], *hk = s_hk[wave], *hm = s_hm[wave];
 	uint32_t n_red = 0;
-	for (uint32_t v = v_beg + blockIdx.x * 4 + wave; v < n_vtx; v += gridDim.x * 4) {
-		unsigned long long x = idx[v];
+	// a wave takes 64 consecutive vertices at a time: one coalesced load of their CSR entries, then only the vertices that have arcs (of this
+	// instantiation's size class) are visited -- after containment most vertices have none, and a dependent load per vertex is pure latency
+	for (uint64_t vb = (uint64_t)v_beg + (uint64_t)(blockIdx.x * 4 + wave) * 64; vb < n_vtx; vb += (uint64_t)gridDim.x * 256) {
+	const unsigned long long xl = vb + lane < n_vtx ? idx[vb + lane] : 0ull;
+	const uint32_t nvl = (uint32_t)xl;
+	unsigned long long todo = wv_ballot(nvl != 0 && !(SMALL ? nvl > (uint32_t)CAP : nvl <= 128u));
+	while (todo) {
+		const int vbit = __ffsll((long long)todo) - 1;
+		todo &= todo - 1;
+		const uint32_t v = (uint32_t)vb + (uint32_t)vbit;
+		const unsigned long long x = __shfl(xl, vbit, 64);
 		uint32_t st = (uint32_t)(x >> 32), nv = (uint32_t)x;
-		if (nv == 0) continue;
-		if (SMALL ? nv > (uint32_t)CAP : nv <= 128u) continue; // the other instantiation's vertices
 		if (sdel[v >> 1]) { // asg.c:158-161
 			for (uint32_t i = lane; i < nv; i += 64) aol[st + i] |= ADEL, ++n_red;
 			continue;
@@ -326,6 +335,7 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 		for (uint32_t i = lane; i < nv; i += 64)
 			if (hm[slot[i]] == (i << 2 | 2u)) aol[st + i] |= ADEL, ++n_red;
 		wv_sync();
+	}
 	}
 	blk_add_u64(&ctr[CT_NRED], n_red);
 }
@@ -917,9 +927,9 @@ extern "C" int mahip_asg_del_trans_range(mahip_ctx_t *c, int fuzz, uint32_t v_be
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	if (v_end > v_beg && c->n_arc) {
 		ProfScope ps(c, "k_asg_trans", 32.0 * (double)c->n_arc); // 16*(A+I)/A per arc, I ~ A on clean data
-		hipLaunchKernelGGL((k_asg_trans<128, 256, true>), dim3(grid_for(v_end - v_beg, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
+		hipLaunchKernelGGL((k_asg_trans<128, 256, true>), dim3(grid_for(((size_t)(v_end - v_beg) + 63) / 64, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
 		                   (const unsigned long long*)P<unsigned long long>(c->idx), (const uint8_t*)P<uint8_t>(c->sdel), v_beg, v_end, (uint32_t)fuzz, P<uint32_t>(c->ovf), ctr);
-		hipLaunchKernelGGL((k_asg_trans<TR_CAP, TR_HASH, false>), dim3(grid_for(v_end - v_beg, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
+		hipLaunchKernelGGL((k_asg_trans<TR_CAP, TR_HASH, false>), dim3(grid_for(((size_t)(v_end - v_beg) + 63) / 64, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
 		                   (const unsigned long long*)P<unsigned long long>(c->idx), (const uint8_t*)P<uint8_t>(c->sdel), v_beg, v_end, (uint32_t)fuzz, P<uint32_t>(c->ovf), ctr);
 	}
 	CHK(ctr_fetch(c));

@@ -161,6 +161,7 @@ static unsigned sub_blocks() { static unsigned v = 0; if (!v) { const char *e = 
 #define MA_SUB_BLOCKS sub_blocks()
 #define EV_PAD 0xffffffffu
 #define SUB_REG_MAX_HITS 512u
+#define SUB_CHUNK 16u // reads whose bounds a wave of the larger size classes fetches at once
 #define SUB_LDS_EVENTS 8192u
 
 #define MA_CE(a, b) do { uint32_t lo_ = (a) < (b) ? (a) : (b), hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
@@ -502,8 +503,17 @@ __global__ __launch_bounds__(256) SUB_WAVES_ATTR void k_hit_sub(HitCols c, const
 			cur = nxt; q = qn;
 		}
 	} else
-	for (uint32_t q = blockIdx.x * 4 + wave; q < n_seq; q += gridDim.x * 4) {
-		uint32_t beg = goff[q], end = goff[q + 1], H = end - beg;
+	// a wave takes SUB_CHUNK consecutive reads at a time: their bounds come with one coalesced load, and only the reads of this instantiation's
+	// size class are visited (a dependent load per read, most of them somebody else's, is pure latency)
+	for (uint64_t qb = (uint64_t)(blockIdx.x * 4 + wave) * SUB_CHUNK; qb < n_seq; qb += (uint64_t)gridDim.x * 4 * SUB_CHUNK) {
+	const bool in = lane < SUB_CHUNK && qb + lane < n_seq;
+	const uint32_t beg_l = in ? goff[qb + lane] : 0, end_l = in ? goff[qb + lane + 1] : 0, H_l = end_l - beg_l;
+	unsigned long long todo = wv_ballot(CLS == 1 ? (H_l > 128 && H_l <= 256) : H_l > 256);
+	while (todo) {
+		const int qbit = __ffsll((long long)todo) - 1;
+		todo &= todo - 1;
+		const uint32_t q = (uint32_t)qb + (uint32_t)qbit;
+		const uint32_t beg = __shfl(beg_l, qbit, 64), end = __shfl(end_l, qbit, 64), H = end - beg;
 		if (CLS == 1) {
 			if (H > 128 && H <= 256) n_kept += sub_group_regs<8, FUSE, GATHER>(c, q, beg, end, min_dp, min_iden, end_clip, sub, lane, f, acc, nullptr, &g);
 		} else {
@@ -518,6 +528,7 @@ __global__ __launch_bounds__(256) SUB_WAVES_ATTR void k_hit_sub(HitCols c, const
 				if (lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF], 1ull); ovf[k] = q; }
 			}
 		}
+	}
 	}
 	blk_add_u64(&ctr[CT_REMAIN], lane == 0 ? n_kept : 0);
 	if (FUSE) { blk_add_u64(&ctr[CT_CUT], acc.n_cut); blk_add_u64(&ctr[CT_LIVE], acc.n_flt); blk_add_u64(&ctr[CT_TOTDP], acc.dp); }
