@@ -331,6 +331,21 @@ __device__ __forceinline__ void gather_recs(const SubGather &g, const GKeys &k, 
 		r.a[h] = p[0]; r.b[h] = p[1];
 	}
 }
+// one dword into column[beg_s + voff/4] through a raw buffer descriptor over [beg_s, beg_s + bytes_s/4): out-of-range lanes are dropped by
+// the hardware's bounds check -- a predicated store without control flow (wave-uniform beg_s / bytes_s)
+__device__ __forceinline__ void col_store_bounded(uint32_t *col, uint32_t beg_s, uint32_t bytes_s, uint32_t voff, uint32_t val)
+{
+	__amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(col + beg_s, 0, (int)bytes_s, 0x00020000); // gfx9 raw buffer, dword format
+	__builtin_amdgcn_raw_buffer_store_b32(val, r, (int)voff, 0, 0);
+}
+__device__ __forceinline__ void gather_store_bounded(const HitCols &c, const SubGather &g, uint32_t beg_s, uint32_t bytes_s, uint32_t voff, uint32_t j, uint4 a, uint4 b)
+{
+	col_store_bounded(c.qid, beg_s, bytes_s, voff, a.y); col_store_bounded(c.qs, beg_s, bytes_s, voff, a.x);
+	col_store_bounded(c.qe, beg_s, bytes_s, voff, a.z); col_store_bounded(c.tn, beg_s, bytes_s, voff, a.w);
+	col_store_bounded(c.ts, beg_s, bytes_s, voff, b.x); col_store_bounded(c.te, beg_s, bytes_s, voff, b.y);
+	col_store_bounded(c.ml, beg_s, bytes_s, voff, b.z); col_store_bounded(c.bl, beg_s, bytes_s, voff, b.w & ~DEAD);
+	col_store_bounded(g.sidx, beg_s, bytes_s, voff, j);
+}
 __device__ __forceinline__ void gather_store(const HitCols &c, const SubGather &g, uint32_t i, uint32_t j, uint4 a, uint4 b)
 {
 	c.qid[i] = a.y; c.qs[i] = a.x; c.qe[i] = a.z; c.tn[i] = a.w;
@@ -453,13 +468,14 @@ __global__ __launch_bounds__(256) SUB_WAVES_ATTR void k_hit_sub(HitCols c, const
 		gather_bounds(goff, q + 2 * stride, n_seq, bn);
 		while (q < n_seq) {
 			const uint32_t beg = cur.beg, end = cur.end, H = end - beg;
-			// (1) the columns of this read FIRST, and unconditionally (lanes without a slot write to the spare slots behind the arrays): the
-			// memory counter is in order, so a store issued after the next read's loads would have to be acknowledged before those loads
-			// count as complete -- every sweep would start by waiting for its predecessor's write-back
+			// (1) the columns of this read FIRST, and without a branch: the memory counter is in order, so a store issued after the next
+			// read's loads would have to be acknowledged before those loads count as complete -- every sweep would start by waiting for
+			// its predecessor's write-back.  Lanes without a slot are masked by the bounds check of a buffer descriptor that covers
+			// exactly this read's slots (a read of another size class: zero records)
+			const uint32_t beg_s = __builtin_amdgcn_readfirstlane(beg), bytes_s = __builtin_amdgcn_readfirstlane(H <= 128u ? H * 4u : 0u);
 #pragma unroll
 			for (int h = 0; h < 2; ++h) {
-				const uint32_t i = beg + h * 64 + lane;
-				gather_store(c, g, (H <= 128u && i < end) ? i : g.n + lane, cur.j[h], cur.a[h], cur.b[h]);
+				gather_store_bounded(c, g, beg_s, bytes_s, (h * 64 + lane) * 4u, cur.j[h], cur.a[h], cur.b[h]);
 			}
 			__builtin_amdgcn_sched_barrier(0);
 			// (2) the fetches of the reads behind it

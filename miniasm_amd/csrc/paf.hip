@@ -31,11 +31,12 @@
 #define PC_MAXQS CT_MAXQS
 #define PC_OVERFLOW CT_OVF2
 #define PC_HITS CT_NRED
+#define PC_DISTINCT CT_NMULTI
 
 struct PafBufs {
 	DevBuf text, lstart, tile;
 	DevBuf flags, num[8], tnoff, qlen, tlen, hq, ht, qslot, tslot;
-	DevBuf tab, tmin, slot_id, blv, scal, excl;
+	DevBuf tab, tmin, info, slot_id, blv, scal, excl;
 	DevBuf name_off, name_len, name_pos, seq_len, names;
 	size_t nbytes = 0, name_bytes = 0;
 	uint32_t n_seq = 0;
@@ -60,7 +61,7 @@ void paf_free(mahip_ctx *c)
 {
 	PafBufs *b = (PafBufs*)c->paf;
 	if (!b) return;
-	DevBuf *all[] = { &b->text, &b->lstart, &b->tile, &b->flags, &b->tnoff, &b->qlen, &b->tlen, &b->hq, &b->ht, &b->qslot, &b->tslot, &b->tab, &b->tmin,
+	DevBuf *all[] = { &b->text, &b->lstart, &b->tile, &b->flags, &b->tnoff, &b->qlen, &b->tlen, &b->hq, &b->ht, &b->qslot, &b->tslot, &b->tab, &b->tmin, &b->info,
 		&b->slot_id, &b->blv, &b->scal, &b->excl, &b->name_off, &b->name_len, &b->name_pos, &b->seq_len, &b->names };
 	for (DevBuf *d : all) dev_free(c, *d);
 	for (int k = 0; k < 8; ++k) dev_free(c, b->num[k]);
@@ -249,36 +250,57 @@ __global__ __launch_bounds__(256) void k_paf_bl_fill(const uint32_t *__restrict_
 // ------------------------------------------------------------------------------------------------ name dictionary
 
 __device__ __forceinline__ bool name_eq(const unsigned char *__restrict__ a, const unsigned char *__restrict__ b, uint32_t len)
-{
-	for (uint32_t k = 0; k < len; ++k) if (a[k] != b[k]) return false;
+{ // 8 bytes at a time (global loads need no alignment), the tail byte by byte
+	uint32_t k = 0;
+	for (; k + 8 <= len; k += 8) {
+		unsigned long long x, y;
+		__builtin_memcpy(&x, a + k, 8); __builtin_memcpy(&y, b + k, 8);
+		if (x != y) return false;
+	}
+	for (; k < len; ++k) if (a[k] != b[k]) return false;
 	return true;
 }
 
 // One thread per stored line: query name, then target name.  Slot word = tag(32) | occurrence of the name's first
 // inserter; tmin[slot] = smallest occurrence (2*line + column) of the name = its first appearance in the file.
+// info[slot] = text offset << 24 | length of the slot's name, written by the inserter right after its CAS: a prober that finds it compares
+// the bytes after ONE dependent fetch; one that does not see it yet (the store is not ordered with the CAS, a stale L1 line) goes the
+// long way through the occurrence (line start, column offset, length: three more random fetches) -- both ways read the same bytes.
+#define PAF_INFO_LEN_BITS 24
 __global__ __launch_bounds__(256) void k_dict_insert(const unsigned char *__restrict__ text, const uint64_t *__restrict__ lstart, uint32_t L, PafCols o,
-                                                      unsigned long long *__restrict__ tab, uint32_t *__restrict__ tmin, uint32_t mask, unsigned long long *__restrict__ ctr)
+                                                      unsigned long long *__restrict__ tab, uint32_t *__restrict__ tmin, unsigned long long *__restrict__ info,
+                                                      uint32_t mask, unsigned long long *__restrict__ ctr)
 {
-	uint32_t fail = 0;
+	uint32_t fail = 0, fresh = 0;
 	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < L; i += gridDim.x * 256u) {
 		if (!(o.flags[i] & 2)) continue;
 		const uint64_t ls = lstart[i];
 		for (uint32_t col = 0; col < 2; ++col) {
 			const uint64_t h = col ? o.ht[i] : o.hq[i];
 			const uint32_t len = col ? o.tlen[i] : o.qlen[i], occ = i * 2u + col;
-			const unsigned char *nm = text + ls + (col ? o.tnoff[i] : 0u);
+			const uint64_t noff = ls + (col ? o.tnoff[i] : 0u);
+			const unsigned char *nm = text + noff;
 			const uint32_t tag = (uint32_t)(h >> 32);
 			uint32_t s = (uint32_t)h & mask, slot = 0xffffffffu;
 			for (uint32_t probe = 0; probe < PAF_PROBE_LIMIT; ++probe, s = (s + 1) & mask) {
 				unsigned long long e = tab[s];
 				if (e == PAF_EMPTY) {
 					e = atomicCAS(&tab[s], PAF_EMPTY, (unsigned long long)tag << 32 | occ);
-					if (e == PAF_EMPTY) { atomicMin(&tmin[s], occ); slot = s; break; }
+					if (e == PAF_EMPTY) {
+						if (len < (1u << PAF_INFO_LEN_BITS) && noff < (1ull << (64 - PAF_INFO_LEN_BITS))) info[s] = noff << PAF_INFO_LEN_BITS | len;
+						atomicMin(&tmin[s], occ); slot = s; ++fresh; break;
+					}
 				}
 				if ((uint32_t)(e >> 32) == tag) {
-					const uint32_t r = (uint32_t)e, rl = r >> 1;
-					const uint32_t rlen = (r & 1) ? o.tlen[rl] : o.qlen[rl];
-					if (rlen == len && name_eq(nm, text + lstart[rl] + ((r & 1) ? o.tnoff[rl] : 0u), len)) {
+					const unsigned long long inf = info[s];
+					bool same;
+					if (inf != PAF_EMPTY) same = (uint32_t)(inf & ((1u << PAF_INFO_LEN_BITS) - 1)) == len && name_eq(nm, text + (inf >> PAF_INFO_LEN_BITS), len);
+					else {
+						const uint32_t r = (uint32_t)e, rl = r >> 1;
+						const uint32_t rlen = (r & 1) ? o.tlen[rl] : o.qlen[rl];
+						same = rlen == len && name_eq(nm, text + lstart[rl] + ((r & 1) ? o.tnoff[rl] : 0u), len);
+					}
+					if (same) {
 						if (tmin[s] > occ) atomicMin(&tmin[s], occ);
 						slot = s; break;
 					}
@@ -289,6 +311,7 @@ __global__ __launch_bounds__(256) void k_dict_insert(const unsigned char *__rest
 		}
 	}
 	blk_add_u64(&ctr[PC_OVERFLOW], fail);
+	blk_add_u64(&ctr[PC_DISTINCT], fresh);
 }
 
 // ---- -R (ma_hit_no_cont, hit.c:38-68) on the parsed columns: reads that are clearly contained are excluded BEFORE ids are given out
@@ -524,21 +547,31 @@ extern "C" int mahip_paf_parse_excl(mahip_ctx_t *c, int min_span, int min_match,
 	// ---- dictionary: distinct names, ids in order of first appearance
 	uint32_t R = 0;
 	if (n_pass) {
-		uint32_t cap = pow2_at_least(n_pass / 2 + 65536);
+		// The number of distinct names is not known before the pass (<= 2 per stored line; in overlap files a read has tens of lines).  Start with a
+		// table sized for 16 lines per name -- 8x smaller than the safe size, it stays in the last-level cache -- count the names as they go in, and
+		// repeat the pass with a table for 4x that many only if the load factor came out above 1/2 (or a probe sequence ran out)
+		const uint32_t cap_max = pow2_at_least(4 * (uint64_t)n_pass + 65536); // load <= 1/2 whatever the file holds
+		uint32_t cap = pow2_at_least(n_pass / 16 + 65536);
+		if (const char *e = getenv("MA_DICT_CAP_LOG2")) { int l2 = atoi(e); if (l2 >= 4 && l2 <= 31) cap = 1u << l2; } // tests: force the growth path
 		for (int attempt = 0;; ++attempt) {
 			CHK(dev_reserve(c, b->tab, (size_t)cap * 8)); CHK(dev_reserve(c, b->tmin, (size_t)cap * 4)); CHK(dev_reserve(c, b->slot_id, (size_t)cap * 4));
+			CHK(dev_reserve(c, b->info, (size_t)cap * 8));
 			HIPCHK(hipMemsetAsync(b->tab.p, 0xff, (size_t)cap * 8, c->st));
+			HIPCHK(hipMemsetAsync(b->info.p, 0xff, (size_t)cap * 8, c->st));
 			HIPCHK(hipMemsetAsync(b->tmin.p, 0xff, (size_t)cap * 4, c->st));
 			CHK(ctr_zero(c));
 			{
 				ProfScope ps(c, "k_dict_insert", 2.0 * 40.0 * (double)n_pass);
 				hipLaunchKernelGGL(k_dict_insert, dim3(grid_for(L, 256, 8192)), dim3(256), 0, c->st, text, (const uint64_t*)P<uint64_t>(b->lstart), L, o,
-				                   P<unsigned long long>(b->tab), P<uint32_t>(b->tmin), cap - 1, ctr);
+				                   P<unsigned long long>(b->tab), P<uint32_t>(b->tmin), P<unsigned long long>(b->info), cap - 1, ctr);
 			}
 			CHK(ctr_fetch(c));
-			if (c->h_ctr[PC_OVERFLOW] == 0) break;
-			if (attempt >= 1 || cap >= 0x80000000u) { mahip_set_error("mahip_paf_parse: name table overflow"); return -1; }
-			cap = pow2_at_least(4 * (uint64_t)n_pass + 65536); // at most 2 names per stored line: load <= 1/2
+			const uint64_t distinct = c->h_ctr[PC_DISTINCT];
+			if (c->h_ctr[PC_OVERFLOW] == 0 && 2 * distinct <= cap) break;
+			if (attempt >= 3 || cap >= cap_max) { if (c->h_ctr[PC_OVERFLOW] == 0) break; mahip_set_error("mahip_paf_parse: name table overflow"); return -1; }
+			uint32_t want = pow2_at_least(4 * distinct + 65536);
+			if (want <= cap) want = cap < 0x10000000u ? cap << 3 : cap_max; // a probe sequence ran out: the count is incomplete
+			cap = want < cap_max ? want : cap_max;
 		}
 		if (no_cont) { // hit.c:38-68 + hit.c:86
 			CHK(dev_reserve(c, b->excl, (size_t)cap + 16));

@@ -87,6 +87,20 @@ def test_ingest_adversarial_text(tmpdir_s):
     ctx.close()
 
 
+def test_name_table_growth(tmpdir_s, monkeypatch):
+    """the name table starts small (sized for 16 lines per name) and the insert pass is repeated with a larger one when the
+    load factor comes out above 1/2 or a probe sequence runs out: force both from tiny start sizes"""
+    ctx = ma.Ctx(0)
+    adv = _adversarial(os.path.join(tmpdir_s, "gi_grow_adv.paf"))
+    paf = R.pafgen(os.path.join(tmpdir_s, "gi_grow.paf"), 3000, 80000, 41, [])
+    for log2 in ("4", "8", "11"):
+        monkeypatch.setenv("MA_DICT_CAP_LOG2", log2)
+        assert _same_as_host(ctx, adv) > 1000
+        assert _same_as_host(ctx, paf) > 0
+    monkeypatch.delenv("MA_DICT_CAP_LOG2")
+    ctx.close()
+
+
 @pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
 def test_ingest_matches_reference_library(tmpdir_s):
     """straight against the reference's ma_hit_read (sorted there, so compare canonicalised records) and its dictionary"""
