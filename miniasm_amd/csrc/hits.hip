@@ -159,9 +159,11 @@ __global__ __launch_bounds__(256) void k_hit_goff(const uint64_t *__restrict__ s
 static unsigned sub_lds() { static int v = -1; if (v < 0) { const char *e = getenv("MA_EXP_SUB_LDS"); v = e ? atoi(e) : 0; } return (unsigned)v; } // experiment: dynamic LDS bytes per block = an occupancy cap
 static unsigned sub_blocks() { static unsigned v = 0; if (!v) { const char *e = getenv("MA_SUB_BLOCKS"); v = e ? (unsigned)atoi(e) : 2 * MA_STREAM_BLOCKS; /* 2 x the resident capacity: the dispatcher evens out the tail (measured 2048: 0.51, 4096: 0.46, 8192: 0.45 ms; more blocks = more end-of-block atomics) */ if (v < 1) v = 1; } return v; }
 #define MA_SUB_BLOCKS sub_blocks()
+// reads per bounds fetch in the larger tiers: up to SUB_CHUNK, fewer when there are not enough reads to give every wave of the grid a chunk
+static uint32_t sub_chunk(uint32_t R) { uint64_t waves = 4ull * grid_for(R, 4, MA_SUB_BLOCKS), k = waves ? R / waves : 1; return (uint32_t)(k < 1 ? 1 : k > 16 ? 16 : k); }
 #define EV_PAD 0xffffffffu
 #define SUB_REG_MAX_HITS 512u
-#define SUB_CHUNK 16u // reads whose bounds a wave of the larger size classes fetches at once
+#define SUB_CHUNK 16u // most reads whose bounds a wave of the larger size classes fetches at once
 #define SUB_LDS_EVENTS 8192u
 
 #define MA_CE(a, b) do { uint32_t lo_ = (a) < (b) ? (a) : (b), hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
@@ -291,7 +293,7 @@ __device__ __forceinline__ void sub_preload(const HitCols &c, const uint32_t *__
 // fetches the read's records itself -- through the permutation in the low bits of the sorted keys -- and writes the SoA columns on the way.
 // The gather is a chain of dependent random fetches (memory latency), the sweep is a register sort (VALU): in one kernel the two overlap
 // across the waves of a SIMD instead of adding up as two launches.
-struct SubGather { const uint64_t *skey; const ma_hit_t *aos; uint32_t *sidx; int bi; uint32_t n; }; // n = slots
+struct SubGather { const uint64_t *skey; const ma_hit_t *aos; uint32_t *sidx; int bi; uint32_t n, chunk; }; // n = slots; chunk = reads per bounds fetch of the larger tiers
 struct GBounds { uint32_t beg, end; };                     // a read's slots
 struct GKeys { uint32_t beg, end, j[2]; };                 // + low words of the sorted keys of its (up to 128) slots, two slots per lane
 struct GRecs { uint32_t beg, end, j[2]; uint4 a[2], b[2]; }; // + input positions and records: a = {qs, qid, qe, tn}, b = {ts, te, ml|rev, bl|del}
@@ -456,6 +458,7 @@ __global__ __launch_bounds__(256) SUB_WAVES_ATTR void k_hit_sub(HitCols c, const
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t n_kept = 0;
 	SubAcc acc = {0, 0, 0};
+	const uint32_t chunk = g.chunk ? g.chunk : 1u; // larger tiers: reads per bounds fetch (few reads: one per wave, so that the launch still spreads over the chip)
 	if (CLS == 0 && GATHER) { // three-deep software pipeline over the chain bounds -> keys -> records: every load is issued a whole sweep before its
 		// first use, and nothing in between waits for it
 		const uint64_t stride = (uint64_t)gridDim.x * 4;
@@ -521,8 +524,8 @@ __global__ __launch_bounds__(256) SUB_WAVES_ATTR void k_hit_sub(HitCols c, const
 	} else
 	// a wave takes SUB_CHUNK consecutive reads at a time: their bounds come with one coalesced load, and only the reads of this instantiation's
 	// size class are visited (a dependent load per read, most of them somebody else's, is pure latency)
-	for (uint64_t qb = (uint64_t)(blockIdx.x * 4 + wave) * SUB_CHUNK; qb < n_seq; qb += (uint64_t)gridDim.x * 4 * SUB_CHUNK) {
-	const bool in = lane < SUB_CHUNK && qb + lane < n_seq;
+	for (uint64_t qb = (uint64_t)(blockIdx.x * 4 + wave) * chunk; qb < n_seq; qb += (uint64_t)gridDim.x * 4 * chunk) {
+	const bool in = lane < chunk && qb + lane < n_seq;
 	const uint32_t beg_l = in ? goff[qb + lane] : 0, end_l = in ? goff[qb + lane + 1] : 0, H_l = end_l - beg_l;
 	unsigned long long todo = wv_ballot(CLS == 1 ? (H_l > 128 && H_l <= 256) : H_l > 256);
 	while (todo) {
@@ -1156,11 +1159,11 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	uint2 *sub = P<uint2>(c->sub[slot]);
 	SubFuse nofuse = {nullptr, 0, 0, 0, nullptr};
-	SubGather nog = {nullptr, nullptr, nullptr, 0, 0};
+	SubGather nog = {nullptr, nullptr, nullptr, 0, 0, sub_chunk(R)};
 	const bool fuse_gather = c->gather_pending && R && c->n_hits && !getenv("MA_NO_GATHER_FUSE");
 	if (c->gather_pending && !fuse_gather) CHK(hits_need_cols(c, "mahip_hits_sub"));
 	if (fuse_gather) { // the sweep fetches the records itself and writes the columns on the way
-		SubGather g = {(const uint64_t*)P<uint64_t>(c->key[c->gk_gen]), c->d_aos, P<uint32_t>(c->sidx), c->gk_bi, (uint32_t)c->n_hits};
+		SubGather g = {(const uint64_t*)P<uint64_t>(c->key[c->gk_gen]), c->d_aos, P<uint32_t>(c->sidx), c->gk_bi, (uint32_t)c->n_hits, sub_chunk(R)};
 		ProfScope ps(c, "k_hit_sub<gather>", (76.0 + 48.0) * (double)c->n_hits + 8.0 * R); // the sort's data movement + ma_hit_sub
 		hipLaunchKernelGGL((k_hit_sub<false, 0, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
@@ -1208,11 +1211,11 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
 	if (R) {
 		ProfScope ps(c, "k_hit_sub<cut+flt>", (80.0 + 80.0 + 48.0) * (double)c->n_hits + 8.0 * R); // cut 80 + flt 80 + sub 48 B per hit
 		hipLaunchKernelGGL((k_hit_sub<true, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0});
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(R)});
 		hipLaunchKernelGGL((k_hit_sub<true, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0});
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(R)});
 		hipLaunchKernelGGL((k_hit_sub<true, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0});
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(R)});
 	}
 	if (R) {
 		CHK(dev_reserve(c, c->big0, (2 * c->n_hits + 8) * 4));

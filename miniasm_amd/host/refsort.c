@@ -60,10 +60,11 @@ static void pool_push(rs_pool_t *p, ma_ki_t *a, size_t n, int shift)
 }
 
 /* one level of ksort.h:153-179 on a[0..n); pool == NULL: finish everything below on this thread */
+static void ki_permute(rs_pool_t *pool, ma_ki_t *a, size_t *tail, int shift);
+
 static void ki_level(rs_pool_t *pool, ma_ki_t *a, size_t n, int shift)
 {
-	size_t head[256], tail[256], start[257], i;
-	int k;
+	size_t tail[256], i;
 	/* A level on which the digit does not vary leaves the range untouched and recurses into the same range (n > 64
 	 * here).  One sweep gives the varying bits and, optimistically, the histogram of the current digit. */
 	for (;;) {
@@ -74,6 +75,72 @@ static void ki_level(rs_pool_t *pool, ma_ki_t *a, size_t n, int shift)
 		if ((diff >> shift & 0xff) != 0) break;
 		while (shift > 0 && (diff >> shift & 0xff) == 0) shift -= 8;
 	}
+	ki_permute(pool, a, tail, shift);
+}
+
+static void *pool_worker(void *arg)
+{
+	rs_pool_t *p = (rs_pool_t*)arg;
+	pthread_mutex_lock(&p->mu);
+	for (;;) {
+		while (p->nq == 0 && p->busy > 0) pthread_cond_wait(&p->cv, &p->mu);
+		if (p->nq == 0) break; /* nothing queued, nobody running: done */
+		{
+			rs_task_t t = p->q[--p->nq];
+			++p->busy;
+			pthread_mutex_unlock(&p->mu);
+			ki_level(p, t.a, t.n, t.shift);
+			pthread_mutex_lock(&p->mu);
+			--p->busy;
+			if (p->busy == 0 && p->nq == 0) pthread_cond_broadcast(&p->cv);
+		}
+	}
+	pthread_mutex_unlock(&p->mu);
+	return 0;
+}
+
+/* parallel sweeps over a big range: OR of (key ^ key[0]) and, with shift >= 0, the histogram of one digit */
+typedef struct { const ma_ki_t *a; size_t beg, end; int shift; uint64_t diff; size_t cnt[256]; } sweep_t;
+
+static void *sweep_worker(void *arg)
+{
+	sweep_t *w = (sweep_t*)arg;
+	const ma_ki_t *a = w->a;
+	const uint64_t k0 = a[0].key;
+	uint64_t diff = 0;
+	size_t i;
+	memset(w->cnt, 0, sizeof(w->cnt));
+	if (w->shift >= 0) for (i = w->beg; i < w->end; ++i) diff |= a[i].key ^ k0, ++w->cnt[a[i].key >> w->shift & 0xff];
+	else for (i = w->beg; i < w->end; ++i) diff |= a[i].key ^ k0;
+	w->diff = diff;
+	return 0;
+}
+
+static uint64_t sweep_run(const ma_ki_t *a, size_t n, int shift, size_t *cnt, int n_threads)
+{
+	sweep_t w[64];
+	pthread_t th[64];
+	uint64_t diff = 0;
+	int t, k;
+	if (n_threads > 64) n_threads = 64;
+	if (n_threads < 1) n_threads = 1;
+	for (t = 0; t < n_threads; ++t) w[t].a = a, w[t].shift = shift, w[t].beg = n / n_threads * t, w[t].end = t == n_threads - 1 ? n : n / n_threads * (t + 1);
+	for (t = 1; t < n_threads; ++t) pthread_create(&th[t], 0, sweep_worker, &w[t]);
+	sweep_worker(&w[0]);
+	for (t = 1; t < n_threads; ++t) pthread_join(th[t], 0);
+	if (cnt) memset(cnt, 0, 256 * sizeof(size_t));
+	for (t = 0; t < n_threads; ++t) {
+		diff |= w[t].diff;
+		if (cnt) for (k = 0; k < 256; ++k) cnt[k] += w[t].cnt[k];
+	}
+	return diff;
+}
+
+/* the cycle-leader permutation of one level (ksort.h:153-176) given the digit counts; then the buckets below */
+static void ki_permute(rs_pool_t *pool, ma_ki_t *a, size_t *tail, int shift)
+{
+	size_t head[256], start[257];
+	int k;
 	start[0] = 0;
 	for (k = 0; k < 256; ++k) start[k + 1] = start[k] + tail[k], head[k] = start[k], tail[k] = start[k + 1];
 	for (k = 0; k < 256;) {
@@ -104,27 +171,6 @@ static void ki_level(rs_pool_t *pool, ma_ki_t *a, size_t n, int shift)
 	}
 }
 
-static void *pool_worker(void *arg)
-{
-	rs_pool_t *p = (rs_pool_t*)arg;
-	pthread_mutex_lock(&p->mu);
-	for (;;) {
-		while (p->nq == 0 && p->busy > 0) pthread_cond_wait(&p->cv, &p->mu);
-		if (p->nq == 0) break; /* nothing queued, nobody running: done */
-		{
-			rs_task_t t = p->q[--p->nq];
-			++p->busy;
-			pthread_mutex_unlock(&p->mu);
-			ki_level(p, t.a, t.n, t.shift);
-			pthread_mutex_lock(&p->mu);
-			--p->busy;
-			if (p->busy == 0 && p->nq == 0) pthread_cond_broadcast(&p->cv);
-		}
-	}
-	pthread_mutex_unlock(&p->mu);
-	return 0;
-}
-
 void ma_refsort_ki(ma_ki_t *a, size_t n, int n_threads)
 {
 	if (n <= RS_SMALL) { ki_insertion(a, n); return; } /* ksort.h:182 */
@@ -132,15 +178,27 @@ void ma_refsort_ki(ma_ki_t *a, size_t n, int n_threads)
 	{
 		rs_pool_t p;
 		pthread_t *th;
-		int t;
+		size_t cnt[256];
+		int t, shift = 56;
+		uint64_t diff;
 		memset(&p, 0, sizeof(p));
 		pthread_mutex_init(&p.mu, 0);
 		pthread_cond_init(&p.cv, 0);
 		if (n_threads > 64) n_threads = 64;
 		p.n_threads = n_threads;
-		pool_push(&p, a, n, 56);
+		/* the top level: its two sweeps (which bits vary; the digit counts) run on all threads, only the walk itself is sequential */
+		diff = sweep_run(a, n, -1, 0, n_threads);
+		if (diff == 0) { pthread_mutex_destroy(&p.mu); pthread_cond_destroy(&p.cv); return; } /* all keys equal: every level is the identity */
+		while (shift > 0 && (diff >> shift & 0xff) == 0) shift -= 8;
+		sweep_run(a, n, shift, cnt, n_threads);
 		th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
+		++p.busy; /* the top-level walk below produces tasks: workers must not leave while it runs */
 		for (t = 0; t < n_threads; ++t) pthread_create(&th[t], 0, pool_worker, &p);
+		ki_permute(&p, a, cnt, shift);
+		pthread_mutex_lock(&p.mu);
+		--p.busy;
+		pthread_cond_broadcast(&p.cv);
+		pthread_mutex_unlock(&p.mu);
 		for (t = 0; t < n_threads; ++t) pthread_join(th[t], 0);
 		free(th); free(p.q);
 		pthread_mutex_destroy(&p.mu);
