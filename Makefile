@@ -36,7 +36,7 @@ $(B) $(PKG)/lib $(PKG)/bin:
 $(B)/%.hip.o: $(CSRC)/%.hip $(CSRC)/mahip_internal.hpp $(CSRC)/ma_core.h $(CSRC)/clean_core.h $(CSRC)/ug_core.h include/mahip.h include/miniasm_amd.h | $(B)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(B)/%.o: $(HOST)/%.c $(HOST)/ma_host.h include/mahip.h include/miniasm_amd.h | $(B)
+$(B)/%.o: $(HOST)/%.c $(HOST)/ma_host.h $(HOST)/refsort_body.h include/mahip.h include/miniasm_amd.h | $(B)
 	$(CC) $(CFLAGS) -c $< -o $@
 
 $(LIB): $(HIP_OBJ) $(HOST_OBJ) | $(PKG)/lib

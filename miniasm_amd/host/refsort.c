@@ -24,29 +24,24 @@
 #define RS_SMALL 64           /* RS_MIN_SIZE ksort.h:132 */
 #define TASK_MIN (1u << 11)   /* buckets smaller than this are finished by the thread that made them */
 
-static void ki_insertion(ma_ki_t *a, size_t n) /* ksort.h:142-152: stable insertion sort on the whole key */
-{
-	size_t i, j;
-	for (i = 1; i < n; ++i) {
-		if (a[i].key < a[i-1].key) {
-			ma_ki_t t = a[i];
-			for (j = i; j > 0 && t.key < a[j-1].key; --j) a[j] = a[j-1];
-			a[j] = t;
-		}
-	}
-}
+/* Element layouts.  wide: {key, index} (16 bytes).  packed: when the bits of the key's high word (bh), of its low word (bl) and of the
+ * index (bi) fit into 64, one word (hi << bl | lo) << bi | index -- half the memory traffic of a walk that is bound by it.  The reference
+ * takes its 8-bit digits from the ORIGINAL key hi << 32 | lo; RS_LEVEL maps such a digit to a position and mask inside the word. */
+typedef struct { int bi, bl; uint64_t lomask; } rs_cfg_t;
 
-typedef struct { ma_ki_t *a; size_t n; int shift; } rs_task_t;
+typedef struct { void *a; size_t n; int shift; } rs_task_t;
 
-typedef struct {
+typedef struct rs_pool_s {
 	pthread_mutex_t mu;
 	pthread_cond_t cv;
 	rs_task_t *q;
-	size_t nq, mq;
+	size_t nq, mq, elem;
 	int busy, n_threads;
+	rs_cfg_t cfg;
+	void (*run)(struct rs_pool_s*, void*, size_t, int);
 } rs_pool_t;
 
-static void pool_push(rs_pool_t *p, ma_ki_t *a, size_t n, int shift)
+static void pool_push(rs_pool_t *p, void *a, size_t n, int shift)
 {
 	pthread_mutex_lock(&p->mu);
 	if (p->nq == p->mq) {
@@ -57,25 +52,6 @@ static void pool_push(rs_pool_t *p, ma_ki_t *a, size_t n, int shift)
 	++p->nq;
 	pthread_cond_signal(&p->cv);
 	pthread_mutex_unlock(&p->mu);
-}
-
-/* one level of ksort.h:153-179 on a[0..n); pool == NULL: finish everything below on this thread */
-static void ki_permute(rs_pool_t *pool, ma_ki_t *a, size_t *tail, int shift);
-
-static void ki_level(rs_pool_t *pool, ma_ki_t *a, size_t n, int shift)
-{
-	size_t tail[256], i;
-	/* A level on which the digit does not vary leaves the range untouched and recurses into the same range (n > 64
-	 * here).  One sweep gives the varying bits and, optimistically, the histogram of the current digit. */
-	for (;;) {
-		uint64_t diff = 0, k0 = a[0].key;
-		memset(tail, 0, sizeof(tail));
-		for (i = 0; i < n; ++i) diff |= a[i].key ^ k0, ++tail[a[i].key >> shift & 0xff];
-		if (diff == 0) return; /* all keys equal: every remaining level is the identity */
-		if ((diff >> shift & 0xff) != 0) break;
-		while (shift > 0 && (diff >> shift & 0xff) == 0) shift -= 8;
-	}
-	ki_permute(pool, a, tail, shift);
 }
 
 static void *pool_worker(void *arg)
@@ -89,7 +65,7 @@ static void *pool_worker(void *arg)
 			rs_task_t t = p->q[--p->nq];
 			++p->busy;
 			pthread_mutex_unlock(&p->mu);
-			ki_level(p, t.a, t.n, t.shift);
+			p->run(p, t.a, t.n, t.shift);
 			pthread_mutex_lock(&p->mu);
 			--p->busy;
 			if (p->busy == 0 && p->nq == 0) pthread_cond_broadcast(&p->cv);
@@ -99,126 +75,89 @@ static void *pool_worker(void *arg)
 	return 0;
 }
 
-/* parallel sweeps over a big range: OR of (key ^ key[0]) and, with shift >= 0, the histogram of one digit */
-typedef struct { const ma_ki_t *a; size_t beg, end; int shift; uint64_t diff; size_t cnt[256]; } sweep_t;
+typedef struct { const void *a; const rs_cfg_t *cfg; size_t beg, end; int shift; uint64_t diff; size_t cnt[256]; } sweep_t;
 
-static void *sweep_worker(void *arg)
+static uint64_t sweep_run(void *(*worker)(void*), const void *a, size_t n, int shift, size_t *cnt, const rs_cfg_t *cfg, int n_threads)
 {
-	sweep_t *w = (sweep_t*)arg;
-	const ma_ki_t *a = w->a;
-	const uint64_t k0 = a[0].key;
-	uint64_t diff = 0;
-	size_t i;
-	memset(w->cnt, 0, sizeof(w->cnt));
-	if (w->shift >= 0) for (i = w->beg; i < w->end; ++i) diff |= a[i].key ^ k0, ++w->cnt[a[i].key >> w->shift & 0xff];
-	else for (i = w->beg; i < w->end; ++i) diff |= a[i].key ^ k0;
-	w->diff = diff;
-	return 0;
-}
-
-static uint64_t sweep_run(const ma_ki_t *a, size_t n, int shift, size_t *cnt, int n_threads)
-{
-	sweep_t w[64];
+	sweep_t *w;
 	pthread_t th[64];
 	uint64_t diff = 0;
 	int t, k;
 	if (n_threads > 64) n_threads = 64;
 	if (n_threads < 1) n_threads = 1;
-	for (t = 0; t < n_threads; ++t) w[t].a = a, w[t].shift = shift, w[t].beg = n / n_threads * t, w[t].end = t == n_threads - 1 ? n : n / n_threads * (t + 1);
-	for (t = 1; t < n_threads; ++t) pthread_create(&th[t], 0, sweep_worker, &w[t]);
-	sweep_worker(&w[0]);
+	w = (sweep_t*)malloc(sizeof(sweep_t) * n_threads);
+	for (t = 0; t < n_threads; ++t) w[t].a = a, w[t].cfg = cfg, w[t].shift = shift, w[t].beg = n / n_threads * t, w[t].end = t == n_threads - 1 ? n : n / n_threads * (t + 1);
+	for (t = 1; t < n_threads; ++t) pthread_create(&th[t], 0, worker, &w[t]);
+	worker(&w[0]);
 	for (t = 1; t < n_threads; ++t) pthread_join(th[t], 0);
 	if (cnt) memset(cnt, 0, 256 * sizeof(size_t));
 	for (t = 0; t < n_threads; ++t) {
 		diff |= w[t].diff;
 		if (cnt) for (k = 0; k < 256; ++k) cnt[k] += w[t].cnt[k];
 	}
+	free(w);
 	return diff;
 }
 
-/* the cycle-leader permutation of one level (ksort.h:153-176) given the digit counts; then the buckets below */
-static void ki_permute(rs_pool_t *pool, ma_ki_t *a, size_t *tail, int shift)
-{
-	size_t head[256], start[257];
-	int k;
-	start[0] = 0;
-	for (k = 0; k < 256; ++k) start[k + 1] = start[k] + tail[k], head[k] = start[k], tail[k] = start[k + 1];
-	for (k = 0; k < 256;) {
-		int dst;
-		if (head[k] == tail[k]) { ++k; continue; }
-		dst = (int)(a[head[k]].key >> shift & 0xff);
-		if (dst == k) { ++head[k]; continue; }
-		{
-			ma_ki_t carry = a[head[k]];
-			do {
-				ma_ki_t evicted = a[head[dst]];
-				a[head[dst]++] = carry;
-				carry = evicted;
-				dst = (int)(carry.key >> shift & 0xff);
-			} while (dst != k);
-			a[head[k]++] = carry;
-		}
-	}
-	if (shift) {
-		int next = shift > 8 ? shift - 8 : 0;
-		for (k = 0; k < 256; ++k) {
-			size_t m = start[k + 1] - start[k];
-			if (m > RS_SMALL) {
-				if (pool && m >= TASK_MIN) pool_push(pool, a + start[k], m, next);
-				else ki_level(pool, a + start[k], m, next);
-			} else if (m > 1) ki_insertion(a + start[k], m);
-		}
-	}
-}
+/* ---- wide elements ---- */
+#define RS_T ma_ki_t
+#define RS_NAME(x) wide_##x
+#define RS_WORD(e) ((e).key)
+#define RS_ORIG(e, cfg) ((e).key)
+#define RS_CMPKEY(e, cfg) ((e).key)
+#define RS_LEVEL(cfg, shift, sh, m) do { (void)(cfg); (sh) = (shift); (m) = 0xffu; } while (0)
+#include "refsort_body.h"
+#undef RS_T
+#undef RS_NAME
+#undef RS_WORD
+#undef RS_ORIG
+#undef RS_CMPKEY
+#undef RS_LEVEL
+
+/* ---- packed elements ---- */
+#define RS_T uint64_t
+#define RS_NAME(x) packed_##x
+#define RS_WORD(e) (e)
+#define RS_ORIG(e, cfg) (((e) >> ((cfg)->bl + (cfg)->bi)) << 32 | (((e) >> (cfg)->bi) & (cfg)->lomask))
+#define RS_CMPKEY(e, cfg) ((e) >> (cfg)->bi)
+/* digit at `shift` of hi << 32 | lo: the high word's digits sit above the low word's bl bits; a digit of the low word may be cut off by bl */
+#define RS_LEVEL(cfg, shift, sh, m) do { \
+		if ((shift) >= 32) (sh) = (cfg)->bl + (cfg)->bi + ((shift) - 32), (m) = 0xffu; \
+		else (sh) = (cfg)->bi + (shift), (m) = (shift) + 8 <= (cfg)->bl ? 0xffu : (shift) < (cfg)->bl ? (1u << ((cfg)->bl - (shift))) - 1u : 0u; \
+	} while (0)
+#include "refsort_body.h"
+#undef RS_T
+#undef RS_NAME
+#undef RS_WORD
+#undef RS_ORIG
+#undef RS_CMPKEY
+#undef RS_LEVEL
 
 void ma_refsort_ki(ma_ki_t *a, size_t n, int n_threads)
 {
-	if (n <= RS_SMALL) { ki_insertion(a, n); return; } /* ksort.h:182 */
-	if (n_threads <= 1 || n < (1u << 17)) { ki_level(0, a, n, 56); return; }
-	{
-		rs_pool_t p;
-		pthread_t *th;
-		size_t cnt[256];
-		int t, shift = 56;
-		uint64_t diff;
-		memset(&p, 0, sizeof(p));
-		pthread_mutex_init(&p.mu, 0);
-		pthread_cond_init(&p.cv, 0);
-		if (n_threads > 64) n_threads = 64;
-		p.n_threads = n_threads;
-		/* the top level: its two sweeps (which bits vary; the digit counts) run on all threads, only the walk itself is sequential */
-		diff = sweep_run(a, n, -1, 0, n_threads);
-		if (diff == 0) { pthread_mutex_destroy(&p.mu); pthread_cond_destroy(&p.cv); return; } /* all keys equal: every level is the identity */
-		while (shift > 0 && (diff >> shift & 0xff) == 0) shift -= 8;
-		sweep_run(a, n, shift, cnt, n_threads);
-		th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
-		++p.busy; /* the top-level walk below produces tasks: workers must not leave while it runs */
-		for (t = 0; t < n_threads; ++t) pthread_create(&th[t], 0, pool_worker, &p);
-		ki_permute(&p, a, cnt, shift);
-		pthread_mutex_lock(&p.mu);
-		--p.busy;
-		pthread_cond_broadcast(&p.cv);
-		pthread_mutex_unlock(&p.mu);
-		for (t = 0; t < n_threads; ++t) pthread_join(th[t], 0);
-		free(th); free(p.q);
-		pthread_mutex_destroy(&p.mu);
-		pthread_cond_destroy(&p.cv);
-	}
+	rs_cfg_t cfg = { 0, 32, 0xffffffffull };
+	wide_sort(a, n, &cfg, n_threads);
 }
 
 /* perm[i] = input position of the record the reference's sort leaves at position i */
-typedef struct { const uint64_t *keys; ma_ki_t *a; uint32_t *perm; size_t beg, end; int phase; } fill_t;
+typedef struct { const uint64_t *keys; ma_ki_t *a; uint64_t *pk; uint32_t *perm; size_t beg, end; int phase; rs_cfg_t cfg; uint64_t mhi, mlo; } fill_t;
 
 static void *fill_worker(void *arg)
 {
 	fill_t *f = (fill_t*)arg;
 	size_t i;
-	if (f->phase == 0) for (i = f->beg; i < f->end; ++i) f->a[i].key = f->keys[i], f->a[i].idx = (uint32_t)i, f->a[i].pad = 0;
-	else for (i = f->beg; i < f->end; ++i) f->perm[i] = f->a[i].idx;
+	if (f->phase == 0) { /* bounds of the two key words */
+		uint64_t mhi = 0, mlo = 0;
+		for (i = f->beg; i < f->end; ++i) { const uint64_t k = f->keys[i], hi = k >> 32, lo = k & 0xffffffffull; mhi = hi > mhi ? hi : mhi; mlo = lo > mlo ? lo : mlo; }
+		f->mhi = mhi, f->mlo = mlo;
+	} else if (f->phase == 1) for (i = f->beg; i < f->end; ++i) f->a[i].key = f->keys[i], f->a[i].idx = (uint32_t)i, f->a[i].pad = 0;
+	else if (f->phase == 2) for (i = f->beg; i < f->end; ++i) f->perm[i] = f->a[i].idx;
+	else if (f->phase == 3) for (i = f->beg; i < f->end; ++i) { const uint64_t k = f->keys[i]; f->pk[i] = ((k >> 32) << f->cfg.bl | (k & 0xffffffffull)) << f->cfg.bi | i; }
+	else { const uint64_t im = f->cfg.bi >= 64 ? ~0ull : (1ull << f->cfg.bi) - 1; for (i = f->beg; i < f->end; ++i) f->perm[i] = (uint32_t)(f->pk[i] & im); }
 	return 0;
 }
 
-static void fill_run(const uint64_t *keys, ma_ki_t *a, uint32_t *perm, size_t n, int phase, int n_threads)
+static void fill_run(fill_t *proto, size_t n, int phase, int n_threads)
 {
 	fill_t f[64];
 	pthread_t th[64];
@@ -226,24 +165,44 @@ static void fill_run(const uint64_t *keys, ma_ki_t *a, uint32_t *perm, size_t n,
 	if (n_threads > 64) n_threads = 64;
 	if (n < (1u << 20) || n_threads < 2) n_threads = 1;
 	for (t = 0; t < n_threads; ++t) {
-		f[t].keys = keys, f[t].a = a, f[t].perm = perm, f[t].phase = phase;
+		f[t] = *proto; f[t].phase = phase;
 		f[t].beg = n / n_threads * t, f[t].end = t == n_threads - 1 ? n : n / n_threads * (t + 1);
 	}
-	if (n_threads == 1) { fill_worker(&f[0]); return; }
-	for (t = 0; t < n_threads; ++t) pthread_create(&th[t], 0, fill_worker, &f[t]);
-	for (t = 0; t < n_threads; ++t) pthread_join(th[t], 0);
+	for (t = 1; t < n_threads; ++t) pthread_create(&th[t], 0, fill_worker, &f[t]);
+	fill_worker(&f[0]);
+	for (t = 1; t < n_threads; ++t) pthread_join(th[t], 0);
+	if (phase == 0) { proto->mhi = proto->mlo = 0; for (t = 0; t < n_threads; ++t) { if (f[t].mhi > proto->mhi) proto->mhi = f[t].mhi; if (f[t].mlo > proto->mlo) proto->mlo = f[t].mlo; } }
 }
+
+static int bits_of64(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
 
 int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm)
 {
-	ma_ki_t *a;
 	const int nt = ma_ingest_threads();
+	fill_t f;
+	int bh, bl, bi;
 	if (n == 0) return 0;
-	a = (ma_ki_t*)malloc(n * sizeof(ma_ki_t));
-	if (a == 0) return -1;
-	fill_run(keys, a, perm, n, 0, nt);
-	ma_refsort_ki(a, n, nt);
-	fill_run(keys, a, perm, n, 1, nt);
-	free(a);
+	memset(&f, 0, sizeof(f));
+	f.keys = keys; f.perm = perm;
+	fill_run(&f, n, 0, nt);
+	bh = bits_of64(f.mhi); bl = bits_of64(f.mlo); bi = bits_of64(n - 1);
+	if (bl == 0) bl = 1;
+	if (bi == 0) bi = 1;
+	if (bh + bl + bi <= 64 && !getenv("MA_REFSORT_WIDE")) { /* one word per element */
+		f.cfg.bi = bi; f.cfg.bl = bl; f.cfg.lomask = (1ull << bl) - 1;
+		f.pk = (uint64_t*)malloc(n * sizeof(uint64_t));
+		if (f.pk == 0) return -1;
+		fill_run(&f, n, 3, nt);
+		packed_sort(f.pk, n, &f.cfg, nt);
+		fill_run(&f, n, 4, nt);
+		free(f.pk);
+		return 0;
+	}
+	f.a = (ma_ki_t*)malloc(n * sizeof(ma_ki_t));
+	if (f.a == 0) return -1;
+	fill_run(&f, n, 1, nt);
+	ma_refsort_ki(f.a, n, nt);
+	fill_run(&f, n, 2, nt);
+	free(f.a);
 	return 0;
 }

@@ -1,0 +1,140 @@
+/* refsort_body.h -- the walk of host/refsort.c for one element layout; included twice (wide: {key, index} records, packed: one 64-bit
+ * word holding the squeezed key above the index).  Parameters: RS_T element type, RS_NAME(x) name mangling, RS_ORIG(e, cfg) the
+ * original 64-bit key of an element, RS_CMPKEY(e, cfg) something ordered like it (the insertion sort compares nothing else),
+ * RS_LEVEL(cfg, shift, sh, m) the position and mask of the reference's 8-bit digit at `shift` inside the element's word RS_WORD(e). */
+
+static void RS_NAME(insertion)(RS_T *a, size_t n, const rs_cfg_t *cfg) /* ksort.h:142-152: stable insertion sort on the whole key */
+{
+	size_t i, j;
+	(void)cfg;
+	for (i = 1; i < n; ++i) {
+		if (RS_CMPKEY(a[i], cfg) < RS_CMPKEY(a[i-1], cfg)) {
+			RS_T t = a[i];
+			const uint64_t tk = RS_CMPKEY(t, cfg);
+			for (j = i; j > 0 && tk < RS_CMPKEY(a[j-1], cfg); --j) a[j] = a[j-1];
+			a[j] = t;
+		}
+	}
+}
+
+static void RS_NAME(level)(rs_pool_t *pool, RS_T *a, size_t n, int shift);
+
+/* the cycle-leader permutation of one level (ksort.h:153-176) given the digit counts in tail[]; then the buckets below */
+static void RS_NAME(permute)(rs_pool_t *pool, RS_T *a, size_t *tail, int shift)
+{
+	const rs_cfg_t *cfg = &pool->cfg;
+	size_t head[256], start[257];
+	int k, sh;
+	unsigned m;
+	RS_LEVEL(cfg, shift, sh, m);
+	start[0] = 0;
+	for (k = 0; k < 256; ++k) start[k + 1] = start[k] + tail[k], head[k] = start[k], tail[k] = start[k + 1];
+	for (k = 0; k < 256;) {
+		int dst;
+		if (head[k] == tail[k]) { ++k; continue; }
+		dst = (int)(RS_WORD(a[head[k]]) >> sh & m);
+		if (dst == k) { ++head[k]; continue; }
+		{
+			RS_T carry = a[head[k]];
+			do {
+				RS_T evicted = a[head[dst]];
+				a[head[dst]++] = carry;
+				carry = evicted;
+				dst = (int)(RS_WORD(carry) >> sh & m);
+			} while (dst != k);
+			a[head[k]++] = carry;
+		}
+	}
+	if (shift) {
+		int next = shift > 8 ? shift - 8 : 0;
+		for (k = 0; k < 256; ++k) {
+			size_t cnt = start[k + 1] - start[k];
+			if (cnt > RS_SMALL) {
+				if (pool->n_threads > 1 && cnt >= TASK_MIN) pool_push(pool, a + start[k], cnt, next);
+				else RS_NAME(level)(pool, a + start[k], cnt, next);
+			} else if (cnt > 1) RS_NAME(insertion)(a + start[k], cnt, cfg);
+		}
+	}
+}
+
+/* one level of ksort.h:153-179 on a[0..n) */
+static void RS_NAME(level)(rs_pool_t *pool, RS_T *a, size_t n, int shift)
+{
+	const rs_cfg_t *cfg = &pool->cfg;
+	size_t tail[256], i;
+	/* A level on which the digit does not vary leaves the range untouched and recurses into the same range (n > 64
+	 * here).  One sweep gives the varying bits and, optimistically, the histogram of the current digit. */
+	for (;;) {
+		uint64_t diff = 0;
+		const uint64_t k0 = RS_ORIG(a[0], cfg);
+		int sh;
+		unsigned m;
+		RS_LEVEL(cfg, shift, sh, m);
+		memset(tail, 0, sizeof(tail));
+		for (i = 0; i < n; ++i) diff |= RS_ORIG(a[i], cfg) ^ k0, ++tail[RS_WORD(a[i]) >> sh & m];
+		if (diff == 0) return; /* all keys equal: every remaining level is the identity */
+		if ((diff >> shift & 0xff) != 0) break;
+		while (shift > 0 && (diff >> shift & 0xff) == 0) shift -= 8;
+	}
+	RS_NAME(permute)(pool, a, tail, shift);
+}
+
+/* parallel sweeps over a big range: OR of (key ^ key[0]) and, with shift >= 0, the histogram of one digit */
+static void *RS_NAME(sweep_worker)(void *arg)
+{
+	sweep_t *w = (sweep_t*)arg;
+	const RS_T *a = (const RS_T*)w->a;
+	const rs_cfg_t *cfg = w->cfg;
+	const uint64_t k0 = RS_ORIG(a[0], cfg);
+	uint64_t diff = 0;
+	size_t i;
+	memset(w->cnt, 0, sizeof(w->cnt));
+	if (w->shift >= 0) {
+		int sh;
+		unsigned m;
+		RS_LEVEL(cfg, w->shift, sh, m);
+		for (i = w->beg; i < w->end; ++i) diff |= RS_ORIG(a[i], cfg) ^ k0, ++w->cnt[RS_WORD(a[i]) >> sh & m];
+	} else for (i = w->beg; i < w->end; ++i) diff |= RS_ORIG(a[i], cfg) ^ k0;
+	w->diff = diff;
+	return 0;
+}
+
+static void RS_NAME(task)(rs_pool_t *pool, void *a, size_t n, int shift) { RS_NAME(level)(pool, (RS_T*)a, n, shift); }
+
+/* the whole sort of a[0..n) */
+static void RS_NAME(sort)(RS_T *a, size_t n, const rs_cfg_t *cfg, int n_threads)
+{
+	rs_pool_t p;
+	memset(&p, 0, sizeof(p));
+	p.cfg = *cfg; p.n_threads = 1; p.run = RS_NAME(task); p.elem = sizeof(RS_T);
+	if (n <= RS_SMALL) { RS_NAME(insertion)(a, n, cfg); return; } /* ksort.h:182 */
+	if (n_threads <= 1 || n < (1u << 17)) { RS_NAME(level)(&p, a, n, 56); return; }
+	{
+		pthread_t *th;
+		size_t cnt[256];
+		int t, shift = 56;
+		uint64_t diff;
+		pthread_mutex_init(&p.mu, 0);
+		pthread_cond_init(&p.cv, 0);
+		if (n_threads > 64) n_threads = 64;
+		p.n_threads = n_threads;
+		/* the top level: its two sweeps (which bits vary; the digit counts) run on all threads, only the walk itself is sequential */
+		diff = sweep_run(RS_NAME(sweep_worker), a, n, -1, 0, cfg, n_threads);
+		if (diff != 0) {
+			while (shift > 0 && (diff >> shift & 0xff) == 0) shift -= 8;
+			sweep_run(RS_NAME(sweep_worker), a, n, shift, cnt, cfg, n_threads);
+			th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
+			++p.busy; /* the top-level walk below produces tasks: workers must not leave while it runs */
+			for (t = 0; t < n_threads; ++t) pthread_create(&th[t], 0, pool_worker, &p);
+			RS_NAME(permute)(&p, a, cnt, shift);
+			pthread_mutex_lock(&p.mu);
+			--p.busy;
+			pthread_cond_broadcast(&p.cv);
+			pthread_mutex_unlock(&p.mu);
+			for (t = 0; t < n_threads; ++t) pthread_join(th[t], 0);
+			free(th); free(p.q);
+		}
+		pthread_mutex_destroy(&p.mu);
+		pthread_cond_destroy(&p.cv);
+	}
+}
