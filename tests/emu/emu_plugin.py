@@ -16,3 +16,8 @@ import miniasm_amd as ma  # noqa: E402
 assert ma.LIB_PATH == EMU_LIB
 ma.CLI_PATH = EMU_CLI
 ma.IS_EMU = True
+
+sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
+import refapi as R  # noqa: E402
+
+R.DROPIN_BIN = os.path.join(HERE, "_build", "miniasm_dropin")

@@ -1,0 +1,71 @@
+"""The `-m gpu` parity tests, run WITHOUT a GPU: the product's kernel sources (miniasm_amd/csrc/*.hip, unmodified) are
+compiled a second time for the CPU against tests/emu -- a fiber-based stand-in for the HIP runtime that models wave64
+shuffles, ballots, DPP controls, barriers and atomics -- and the GPU test modules are run against that build in a
+subprocess (`-p emu_plugin` swaps the library path of the ctypes harness).  This is test infrastructure: it proves the
+kernels' logic (every stage bit-exact against the oracle and the reference library) on the box that has no GPU; it says
+nothing about speed, stream ordering or memory-model behaviour, which only the `-m gpu` run on an MI355X covers.
+
+By default a subset that finishes in about three minutes runs; MA_EMU_FULL=1 runs every GPU test module except the
+BASELINE-scale inputs and the RCCL tests (about 25 minutes on 8 cores)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu")
+FULL = os.environ.get("MA_EMU_FULL", "0") == "1"
+
+
+@pytest.fixture(scope="module")
+def emu_built(built):
+    r = subprocess.run(["make", "-C", EMU, "-j8", "all", "_build/emu_selftest"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-4000:]
+    return True
+
+
+def run_gpu_tests(args, timeout):
+    env = dict(os.environ)
+    env["PYTHONPATH"] = EMU + os.pathsep + env.get("PYTHONPATH", "")
+    env.pop("MINIASM_AMD_LIB", None)
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-p", "emu_plugin", "-x", "-q", "-p", "no:cacheprovider"] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+    tail = r.stdout[-6000:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and " failed" not in tail, tail
+    return tail
+
+
+def test_emulator_selftest(emu_built):
+    """the stand-in itself: shuffles, ballot, every DPP control the kernels use, barriers with early exits, divergent loops"""
+    r = subprocess.run([os.path.join(EMU, "_build", "emu_selftest")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout
+
+
+def test_kernels_stage_parity_on_cpu(emu_built):
+    """tests/test_gpu_parity.py: every HIP pass against the oracle and the reference library (incl. the second tiers)"""
+    sel = [] if FULL else ["-k", "lognormal or noisy or lowid or deep_groups or sort_random or sub_"]
+    run_gpu_tests(["tests/test_gpu_parity.py"] + sel, 3000)
+
+
+def test_kernels_graph_api_on_cpu(emu_built):
+    """tests/test_gpu_graph_api.py: device cleaners and unitigs after every call, through the per-symbol ABI"""
+    run_gpu_tests(["tests/test_gpu_graph_api.py"], 1800)
+
+
+def test_kernels_ingest_on_cpu(emu_built):
+    """tests/test_gpu_ingest.py: device PAF parser + dictionary against the host reader and the reference"""
+    run_gpu_tests(["tests/test_gpu_ingest.py"], 1800)
+
+
+@pytest.mark.skipif(not FULL, reason="MA_EMU_FULL=1 runs the CLI and sharded suites on the emulator (about 20 minutes)")
+def test_cli_suite_on_cpu(emu_built):
+    run_gpu_tests(["tests/test_gpu_cli.py", "-k", "not baseline_scale"], 5000)
+
+
+def test_sharded_suite_on_cpu(emu_built):
+    """tests/test_gpu_sharded.py: `MA_GPUS=N miniasm` -- host/sharded.c, N forked ranks over the shared-memory double of the collectives --
+    against the single-rank run and the reference binary (tie-rich input included).  The torch-driven virtual-rank test needs a real device."""
+    sel = "not rccl and not virtual_ranks" + ("" if FULL else " and (2-lognormal or 3-noisy or tie_order)")
+    run_gpu_tests(["tests/test_gpu_sharded.py", "-k", sel], 5000)
