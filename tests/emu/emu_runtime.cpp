@@ -14,6 +14,7 @@
 #include <thread>
 #include <vector>
 #include <map>
+#include <string>
 
 namespace emu {
 
@@ -123,6 +124,19 @@ void block_barrier()
 
 static std::atomic<uint64_t> g_divergent_ops{0}, g_wave_ops{0}, g_launches{0};
 static int g_verbose = 0;
+// EMU_VERBOSE=1: per-kernel table at exit -- launches, blocks, cross-lane operations, and how many of those were resolved for only part of
+// the wave's live lanes (divergent call sites: the emulator orders those by code address, which is a heuristic -- audit them)
+struct KStat { uint64_t launches = 0, blocks = 0, ops = 0, div = 0; };
+static std::mutex g_kstat_mu;
+static std::map<std::string, KStat> g_kstat;
+static thread_local uint64_t t_ops = 0, t_div = 0;
+static void kstat_dump()
+{
+	fprintf(stderr, "[hip-emu] %-56s %9s %10s %12s %10s\n", "kernel", "launches", "blocks", "wave-ops", "partial");
+	for (auto &kv : g_kstat)
+		fprintf(stderr, "[hip-emu] %-56.56s %9llu %10llu %12llu %10llu\n", kv.first.c_str(), (unsigned long long)kv.second.launches,
+			(unsigned long long)kv.second.blocks, (unsigned long long)kv.second.ops, (unsigned long long)kv.second.div);
+}
 
 static void run_block(Worker *w, dim3 bid, dim3 bdim, dim3 gdim)
 {
@@ -184,6 +198,7 @@ static void run_block(Worker *w, dim3 bid, dim3 bdim, dim3 gdim)
 	for (unsigned i = 0; i < n; ++i)
 		if (*(uint64_t *)(w->stacks + (size_t)i * w->stack_bytes) != CANARY) fatal("fiber stack overflow (raise EMU_STACK_KB)");
 	g_wave_ops += n_wave_ops, g_divergent_ops += n_div;
+	t_ops += n_wave_ops, t_div += n_div;
 	t_block = nullptr, t_fiber = nullptr;
 }
 
@@ -191,7 +206,7 @@ static void run_block(Worker *w, dim3 bid, dim3 bdim, dim3 gdim)
 struct Job {
 	dim3 grid, block;
 	LaunchFn fn;
-	std::atomic<uint64_t> next{0};
+	std::atomic<uint64_t> next{0}, ops{0}, div{0};
 	uint64_t total = 0;
 };
 
@@ -199,6 +214,7 @@ static void run_job(Job *j)
 {
 	Worker *w = worker();
 	w->fn = j->fn;
+	t_ops = t_div = 0;
 	const uint64_t chunk = j->total > 4096 ? 16 : 1;
 	for (;;) {
 		uint64_t b0 = j->next.fetch_add(chunk);
@@ -209,6 +225,7 @@ static void run_job(Job *j)
 			run_block(w, bid, j->block, j->grid);
 		}
 	}
+	j->ops += t_ops, j->div += t_div;
 }
 
 struct Pool {
@@ -276,7 +293,7 @@ static Pool *pool()
 	return g_pool;
 }
 
-void launch(dim3 grid, dim3 block, size_t shmem, LaunchFn fn)
+void launch(const char *name, dim3 grid, dim3 block, size_t shmem, LaunchFn fn)
 {
 	(void)shmem;
 	const unsigned n = block.x * block.y * block.z;
@@ -299,6 +316,12 @@ void launch(dim3 grid, dim3 block, size_t shmem, LaunchFn fn)
 		std::unique_lock<std::mutex> lk(p->mu);
 		p->cv_done.wait(lk, [&] { return p->busy == 0; });
 	} else run_job(&j);
+	if (g_verbose) {
+		std::lock_guard<std::mutex> lk(g_kstat_mu);
+		if (g_kstat.empty()) atexit(kstat_dump);
+		KStat &k = g_kstat[name];
+		k.launches++, k.blocks += j.total, k.ops += j.ops, k.div += j.div;
+	}
 }
 
 // ---- cross-lane operations that are not templates ----

@@ -85,7 +85,7 @@ extern thread_local Block *t_block;
 Wave *wave_op(uint64_t val, unsigned op, uintptr_t site);
 void block_barrier();
 struct LaunchFn { void (*call)(void *); void *arg; };
-void launch(dim3 grid, dim3 block, size_t shmem, LaunchFn fn);
+void launch(const char *name, dim3 grid, dim3 block, size_t shmem, LaunchFn fn);
 [[noreturn]] void fatal(const char *fmt, ...);
 } // namespace emu
 
@@ -97,13 +97,13 @@ void launch(dim3 grid, dim3 block, size_t shmem, LaunchFn fn);
 
 #define EMU_SITE ((uintptr_t)__builtin_return_address(0))
 
-template <typename F> static inline void emu_launch_(dim3 g, dim3 b, size_t sh, F &&f)
+template <typename F> static inline void emu_launch_(const char *name, dim3 g, dim3 b, size_t sh, F &&f)
 {
 	emu::LaunchFn fn = {[](void *p) { (*(F *)p)(); }, (void *)&f};
-	emu::launch(g, b, sh, fn);
+	emu::launch(name, g, b, sh, fn);
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-	emu_launch_((grid), (block), (shmem), [&]() { (kernel)(__VA_ARGS__); })
+	emu_launch_(#kernel, (grid), (block), (shmem), [&]() { (kernel)(__VA_ARGS__); })
 
 // ---- cross-lane operations ----
 namespace emu {
