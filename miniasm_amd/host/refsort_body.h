@@ -39,6 +39,7 @@ static void RS_NAME(permute)(rs_pool_t *pool, RS_T *a, size_t *tail, int shift)
 			do {
 				RS_T evicted = a[head[dst]];
 				a[head[dst]++] = carry;
+				RS_PREFETCH(&a[head[dst]]);
 				carry = evicted;
 				dst = (int)(RS_WORD(carry) >> sh & m);
 			} while (dst != k);
@@ -119,19 +120,23 @@ static void RS_NAME(sort)(RS_T *a, size_t n, const rs_cfg_t *cfg, int n_threads)
 		if (n_threads > 64) n_threads = 64;
 		p.n_threads = n_threads;
 		/* the top level: its two sweeps (which bits vary; the digit counts) run on all threads, only the walk itself is sequential */
+		RS_T0;
 		diff = sweep_run(RS_NAME(sweep_worker), a, n, -1, 0, cfg, n_threads);
 		if (diff != 0) {
 			while (shift > 0 && (diff >> shift & 0xff) == 0) shift -= 8;
 			sweep_run(RS_NAME(sweep_worker), a, n, shift, cnt, cfg, n_threads);
+			RS_LAP(" sweeps");
 			th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
 			++p.busy; /* the top-level walk below produces tasks: workers must not leave while it runs */
 			for (t = 0; t < n_threads; ++t) pthread_create(&th[t], 0, pool_worker, &p);
 			RS_NAME(permute)(&p, a, cnt, shift);
+			RS_LAP(" top walk");
 			pthread_mutex_lock(&p.mu);
 			--p.busy;
 			pthread_cond_broadcast(&p.cv);
 			pthread_mutex_unlock(&p.mu);
 			for (t = 0; t < n_threads; ++t) pthread_join(th[t], 0);
+			RS_LAP(" buckets");
 			free(th); free(p.q);
 		}
 		pthread_mutex_destroy(&p.mu);

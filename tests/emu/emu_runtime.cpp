@@ -123,6 +123,9 @@ void block_barrier()
 }
 
 static std::atomic<uint64_t> g_divergent_ops{0}, g_wave_ops{0}, g_launches{0};
+}
+static std::atomic<uint64_t> g_syncs{0}, g_d2h{0}, g_h2d{0};
+namespace emu {
 static int g_verbose = 0;
 // EMU_VERBOSE=1: per-kernel table at exit -- launches, blocks, cross-lane operations, and how many of those were resolved for only part of
 // the wave's live lanes (divergent call sites: the emulator orders those by code address, which is a heuristic -- audit them)
@@ -132,6 +135,7 @@ static std::map<std::string, KStat> g_kstat;
 static thread_local uint64_t t_ops = 0, t_div = 0;
 static void kstat_dump()
 {
+	fprintf(stderr, "[hip-emu] %llu stream syncs, %llu D2H and %llu H2D copies\n", (unsigned long long)g_syncs.load(), (unsigned long long)g_d2h.load(), (unsigned long long)g_h2d.load());
 	fprintf(stderr, "[hip-emu] %-56s %9s %10s %12s %10s\n", "kernel", "launches", "blocks", "wave-ops", "partial");
 	for (auto &kv : g_kstat)
 		fprintf(stderr, "[hip-emu] %-56.56s %9llu %10llu %12llu %10llu\n", kv.first.c_str(), (unsigned long long)kv.second.launches,
@@ -455,13 +459,13 @@ hipError_t hipFree(void *p) { return emu::dev_release(p) == 0 ? hipSuccess : hip
 hipError_t hipHostMalloc(void **p, size_t bytes, unsigned flags) { (void)flags; *p = emu::dev_alloc(bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void *p) { return emu::dev_release(p) == 0 ? hipSuccess : hipErrorInvalidValue; }
 hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) { (void)kind; if (bytes) memmove(dst, src, bytes); return hipSuccess; }
-hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st) { (void)kind; (void)st; if (bytes) memmove(dst, src, bytes); return hipSuccess; }
+hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st) { (void)st; if (kind == hipMemcpyDeviceToHost) ++g_d2h; else if (kind == hipMemcpyHostToDevice) ++g_h2d; if (bytes) memmove(dst, src, bytes); return hipSuccess; }
 hipError_t hipMemset(void *dst, int v, size_t bytes) { if (bytes) memset(dst, v, bytes); return hipSuccess; }
 hipError_t hipMemsetAsync(void *dst, int v, size_t bytes, hipStream_t st) { (void)st; if (bytes) memset(dst, v, bytes); return hipSuccess; }
 hipError_t hipStreamCreate(hipStream_t *st) { *st = new emu_stream{0}; return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned flags) { *st = new emu_stream{(int)flags}; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t st) { delete st; return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t st) { (void)st; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t st) { (void)st; ++g_syncs; return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event{0}; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags) { (void)flags; *e = new emu_event{0}; return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
