@@ -473,13 +473,22 @@ __global__ __launch_bounds__(256) SUB_WAVES_ATTR void k_hit_sub(HitCols c, const
 			const uint32_t beg = cur.beg, end = cur.end, H = end - beg;
 			// (1) the columns of this read FIRST, and without a branch: the memory counter is in order, so a store issued after the next
 			// read's loads would have to be acknowledged before those loads count as complete -- every sweep would start by waiting for
-			// its predecessor's write-back.  Lanes without a slot are masked by the bounds check of a buffer descriptor that covers
-			// exactly this read's slots (a read of another size class: zero records)
+			// its predecessor's write-back.  Lanes without a slot write to the spare slots behind the arrays (the variant every number in
+			// profiles/ was measured with); EXP_BOUNDED_STORE masks them with the bounds check of a buffer descriptor that covers exactly
+			// this read's slots instead (a read of another size class: zero records) -- to be measured
+#ifdef EXP_BOUNDED_STORE
 			const uint32_t beg_s = __builtin_amdgcn_readfirstlane(beg), bytes_s = __builtin_amdgcn_readfirstlane(H <= 128u ? H * 4u : 0u);
 #pragma unroll
 			for (int h = 0; h < 2; ++h) {
 				gather_store_bounded(c, g, beg_s, bytes_s, (h * 64 + lane) * 4u, cur.j[h], cur.a[h], cur.b[h]);
 			}
+#else
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const uint32_t i = beg + h * 64 + lane;
+				gather_store(c, g, (H <= 128u && i < end) ? i : g.n + lane, cur.j[h], cur.a[h], cur.b[h]);
+			}
+#endif
 			__builtin_amdgcn_sched_barrier(0);
 			// (2) the fetches of the reads behind it
 			gather_recs(g, kn, lane, nxt);
