@@ -127,6 +127,7 @@ static std::atomic<uint64_t> g_divergent_ops{0}, g_wave_ops{0}, g_launches{0};
 static std::atomic<uint64_t> g_syncs{0}, g_d2h{0}, g_h2d{0};
 namespace emu {
 static int g_verbose = 0;
+static int g_reverse = 0; // EMU_ORDER=reverse: lanes, waves and blocks run in descending order (shakes out code that leans on lock-step or launch order)
 // EMU_VERBOSE=1: per-kernel table at exit -- launches, blocks, cross-lane operations, and how many of those were resolved for only part of
 // the wave's live lanes (divergent call sites: the emulator orders those by code address, which is a heuristic -- audit them)
 struct KStat { uint64_t launches = 0, blocks = 0, ops = 0, div = 0; };
@@ -164,11 +165,14 @@ static void run_block(Worker *w, dim3 bid, dim3 bdim, dim3 gdim)
 	uint64_t n_wave_ops = 0, n_div = 0;
 	for (;;) {
 		unsigned done = 0;
-		for (unsigned wv = 0; wv < nw; ++wv) {
+		for (unsigned wi = 0; wi < nw; ++wi) {
+			const unsigned wv = g_reverse ? nw - 1 - wi : wi;
 			Fiber *fb = &w->fibers[wv * 64];
 			const unsigned nl = (wv + 1) * 64 <= n ? 64 : n - wv * 64;
-			for (unsigned l = 0; l < nl; ++l)
+			for (unsigned li = 0; li < nl; ++li) {
+				const unsigned l = g_reverse ? nl - 1 - li : li;
 				if (fb[l].state == F_RUNNABLE) resume(w, &fb[l]);
+			}
 			for (;;) { // resolve the wave's pending cross-lane operations: the earliest call site first
 				uintptr_t site = 0;
 				unsigned op = 0, waiting = 0, live = 0;
@@ -189,8 +193,10 @@ static void run_block(Worker *w, dim3 bid, dim3 bdim, dim3 gdim)
 				if ((unsigned)__builtin_popcountll(mask) != live) ++n_div;
 				for (unsigned l = 0; l < nl; ++l)
 					if (mask >> l & 1) fb[l].state = F_RUNNABLE;
-				for (unsigned l = 0; l < nl; ++l)
+				for (unsigned li = 0; li < nl; ++li) {
+					const unsigned l = g_reverse ? nl - 1 - li : li;
 					if (mask >> l & 1) resume(w, &fb[l]);
+				}
 			}
 			for (unsigned l = 0; l < nl; ++l)
 				if (fb[l].state == F_DONE) ++done;
@@ -224,7 +230,8 @@ static void run_job(Job *j)
 		uint64_t b0 = j->next.fetch_add(chunk);
 		if (b0 >= j->total) break;
 		uint64_t b1 = b0 + chunk < j->total ? b0 + chunk : j->total;
-		for (uint64_t b = b0; b < b1; ++b) {
+		for (uint64_t bi = b0; bi < b1; ++bi) {
+			const uint64_t b = g_reverse ? j->total - 1 - bi : bi;
 			dim3 bid((unsigned)(b % j->grid.x), (unsigned)(b / j->grid.x % j->grid.y), (unsigned)(b / ((uint64_t)j->grid.x * j->grid.y)));
 			run_block(w, bid, j->block, j->grid);
 		}
@@ -249,6 +256,7 @@ struct Pool {
 		if (nthreads < 1) nthreads = 1;
 		if ((e = getenv("EMU_STACK_KB")) != nullptr && atoi(e) >= 16) g_stack_bytes = (size_t)atoi(e) << 10;
 		if ((e = getenv("EMU_VERBOSE")) != nullptr) g_verbose = atoi(e);
+		if ((e = getenv("EMU_ORDER")) != nullptr) g_reverse = !strcmp(e, "reverse");
 	}
 	void start()
 	{
