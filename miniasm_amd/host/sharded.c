@@ -19,6 +19,8 @@
 #include <string.h>
 #include <unistd.h>
 #include <sys/wait.h>
+#include <sys/prctl.h>
+#include <signal.h>
 #include "ma_host.h"
 
 #define GPU(call) do { if ((call) != 0) ma_gpu_fail(__func__); } while (0)
@@ -151,6 +153,36 @@ int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq
  * and parses the whole text on its own GPU (its own PCIe link; the device parser makes this cheaper than routing records:
  * DESIGN section 6) and keeps the hits of its read range; rank 0 cleans the graph and writes the output, the others leave
  * after the last collective.  MA_COMM=shm selects the host-staged test double (all ranks on MA_GPU_DEVICE / device 0). */
+/* A rank that fails must not leave the others waiting in a collective: children die with the parent (PR_SET_PDEATHSIG), the parent
+ * ends the run when a child ends abnormally (SIGCHLD) and takes the remaining children with it when it leaves early (atexit). */
+static pid_t *g_kids;
+static int g_n_kids;
+static volatile sig_atomic_t g_kids_done;
+
+static void kids_kill(void)
+{
+	int r;
+	for (r = 1; r < g_n_kids; ++r) if (g_kids && g_kids[r] > 0) kill(g_kids[r], SIGKILL);
+}
+
+static void on_sigchld(int sig)
+{
+	int status, r;
+	pid_t p;
+	(void)sig;
+	while ((p = waitpid(-1, &status, WNOHANG)) > 0) {
+		for (r = 1; r < g_n_kids; ++r) if (g_kids[r] == p) break;
+		if (r == g_n_kids) continue; /* not a rank */
+		g_kids[r] = 0;
+		if (!g_kids_done && !(WIFEXITED(status) && WEXITSTATUS(status) == 0)) {
+			static const char msg[] = "[E::ma_pipeline_run_sharded] a rank ended abnormally; stopping the run\n";
+			if (write(2, msg, sizeof(msg) - 1) < 0) {}
+			kids_kill();
+			_exit(1);
+		}
+	}
+}
+
 int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *outfmt, int stage, int flags, FILE *out, int world)
 {
 	const char *kind = getenv("MA_COMM");
@@ -164,14 +196,33 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 	ma_shard_stats_t st;
 	uint32_t pst[4];
 	FILE *lg;
+	/* everything that can be refused is refused BEFORE the ranks exist */
+	if (strcmp(outfmt, "ug") != 0 && strcmp(outfmt, "sg") != 0) { fprintf(stderr, "[E::%s] MA_GPUS > 1 produces -p ug or -p sg\n", __func__); exit(1); }
+	if (world > 32) { fprintf(stderr, "[E::%s] at most 32 ranks\n", __func__); exit(1); }
 	memset(id, 0, sizeof(id));
 	snprintf(shm_name, sizeof(shm_name), "miniasm_amd_%d", (int)getpid());
 	fflush(stdout); fflush(stderr);
+	g_kids = kids; g_n_kids = world; g_kids_done = 0;
+	{
+		struct sigaction sa;
+		memset(&sa, 0, sizeof(sa));
+		sa.sa_handler = on_sigchld;
+		sa.sa_flags = SA_RESTART | SA_NOCLDSTOP;
+		sigaction(SIGCHLD, &sa, 0);
+		atexit(kids_kill);
+	}
 	for (r = 1; r < world; ++r) {
+		const pid_t parent = getpid();
 		if (pipe(pipes[r]) != 0) { perror("pipe"); exit(1); }
 		kids[r] = fork();
 		if (kids[r] < 0) { perror("fork"); exit(1); }
-		if (kids[r] == 0) { rank = r; close(pipes[r][1]); break; }
+		if (kids[r] == 0) {
+			rank = r; close(pipes[r][1]);
+			g_kids = 0; g_n_kids = 0; signal(SIGCHLD, SIG_DFL);
+			prctl(PR_SET_PDEATHSIG, SIGKILL);
+			if (getppid() != parent) _exit(1); /* the parent left between fork and prctl */
+			break;
+		}
 		close(pipes[r][0]);
 	}
 	if (rank == 0) {
@@ -196,6 +247,10 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 	r = ma_hit_ingest_gpu_excl(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), (flags & 8) != 0, opt->max_hang, opt->int_frac);
 	if (r == -1) { fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn); exit(1); }
 	if (r != 0) { fprintf(stderr, "[E::%s] the text does not fit the device stage; MA_GPUS > 1 needs the device parser\n", __func__); exit(1); }
+	{ /* test hook: a rank that dies in the middle of a run (tests/test_gpu_sharded.py checks that nobody is left waiting) */
+		const char *e = getenv("MA_TEST_FAIL_RANK");
+		if (e && atoi(e) == rank) { fprintf(stderr, "[E::%s] rank %d: MA_TEST_FAIL_RANK\n", __func__, rank); _exit(3); }
+	}
 	ma_pipeline_head_sharded(c, opt, d->n_seq, 1, &st);
 	if (rank == 0) {
 		fprintf(lg, "[M::%s] ===> Step 2: 1-pass (crude) read selection <===\n", "main");
@@ -217,14 +272,21 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 			fprintf(lg, "[M::%s] removed %d asymmetric arcs\n", "asg_arc_del_asymm", st.n_asymm);
 		}
 		pst[0] = 1; pst[1] = 1; pst[2] = st.n_red; pst[3] = 1;
-		if (strcmp(outfmt, "ug") != 0 && strcmp(outfmt, "sg") != 0) { fprintf(stderr, "[E::%s] MA_GPUS > 1 produces -p ug or -p sg\n", __func__); exit(1); }
 		ma_pipeline_tail(c, opt, d, outfmt, stage, pst, out);
 	}
 	GPU(mahip_comm_barrier(c));
 	mahip_comm_destroy(c);
 	sd_destroy(d);
 	if (rank != 0) exit(0); /* orderly: the context's atexit teardown runs */
-	for (r = 1; r < world; ++r) { int status = 0; waitpid(kids[r], &status, 0); if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) fprintf(stderr, "[W::%s] rank %d ended abnormally\n", __func__, r); }
+	g_kids_done = 1; /* the work is done: from here a rank's exit status is only reported */
+	for (r = 1; r < world; ++r) {
+		int status = 0;
+		const pid_t k = kids[r];
+		if (k > 0 && waitpid(k, &status, 0) == k && (!WIFEXITED(status) || WEXITSTATUS(status) != 0)) fprintf(stderr, "[W::%s] rank %d ended abnormally\n", __func__, r);
+		kids[r] = 0;
+	}
+	signal(SIGCHLD, SIG_DFL);
+	g_kids = 0; g_n_kids = 0;
 	free(pipes); free(kids);
 	return 0;
 }

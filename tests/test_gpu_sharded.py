@@ -165,6 +165,29 @@ def test_cli_on_n_ranks_reproduces_the_reference_tie_order(world, tmpdir_s):
         assert r.stdout == ref, "%d ranks, %s: bytes differ from the reference" % (world, " ".join(args))
 
 
+@pytest.mark.parametrize("who", ["refused", "child", "parent"])
+def test_cli_on_n_ranks_never_leaves_a_rank_waiting(who, tmpdir_s):
+    """a run that cannot go on ends on every rank: a request MA_GPUS > 1 does not serve is refused before the ranks exist; when one rank dies in
+    the middle, the others are not left in a collective (children die with the parent, the parent stops when a child ends abnormally)"""
+    import subprocess
+    import time
+    paf = R.pafgen(os.path.join(tmpdir_s, "shc_fail.paf"), 800, 12000, 7, [])
+    env = dict(os.environ, MA_GPUS="3", MA_COMM="shm")
+    args = [paf]
+    if who == "refused":
+        args = ["-p", "paf", paf]
+    else:
+        env["MA_TEST_FAIL_RANK"] = "1" if who == "child" else "0"
+    t0 = time.time()
+    r = subprocess.run([ma.CLI_PATH] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert r.returncode != 0 and time.time() - t0 < 60
+    if who == "refused":
+        assert b"produces -p ug or -p sg" in r.stderr
+    time.sleep(0.5)
+    left = subprocess.run(["pgrep", "-f", paf], stdout=subprocess.PIPE).stdout.split()
+    assert not left, "ranks still alive: %r" % left
+
+
 @pytest.mark.skipif(ma.lib().mahip_device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
 def test_cli_on_two_gpus_over_rccl(tmpdir_s):
     import subprocess
