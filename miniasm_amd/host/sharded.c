@@ -196,8 +196,13 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 	ma_shard_stats_t st;
 	uint32_t pst[4];
 	FILE *lg;
-	/* everything that can be refused is refused BEFORE the ranks exist */
-	if (strcmp(outfmt, "ug") != 0 && strcmp(outfmt, "sg") != 0) { fprintf(stderr, "[E::%s] MA_GPUS > 1 produces -p ug or -p sg\n", __func__); exit(1); }
+	/* The sharded head is the full graph path (both read selections, containment, graph, reduction).  Any other request -- a hit dump, an
+	 * early -S stage, -1 / -2 -- is decided BEFORE the ranks exist and runs on one GPU: the output is the same, only not spread out. */
+	if ((strcmp(outfmt, "ug") != 0 && strcmp(outfmt, "sg") != 0) || (flags & 3) || stage < 6) {
+		fprintf(stderr, "[W::%s] MA_GPUS=%d serves -p ug / -p sg with both read selections and -S >= 6; this request runs on one GPU\n", __func__, world);
+		free(pipes); free(kids); sd_destroy(d);
+		return ma_pipeline_run(opt, fn, outfmt, stage, flags, out);
+	}
 	if (world > 32) { fprintf(stderr, "[E::%s] at most 32 ranks\n", __func__); exit(1); }
 	memset(id, 0, sizeof(id));
 	snprintf(shm_name, sizeof(shm_name), "miniasm_amd_%d", (int)getpid());

@@ -165,24 +165,25 @@ def test_cli_on_n_ranks_reproduces_the_reference_tie_order(world, tmpdir_s):
         assert r.stdout == ref, "%d ranks, %s: bytes differ from the reference" % (world, " ".join(args))
 
 
-@pytest.mark.parametrize("who", ["refused", "child", "parent"])
+@pytest.mark.parametrize("who", ["one_gpu", "child", "parent"])
 def test_cli_on_n_ranks_never_leaves_a_rank_waiting(who, tmpdir_s):
-    """a run that cannot go on ends on every rank: a request MA_GPUS > 1 does not serve is refused before the ranks exist; when one rank dies in
-    the middle, the others are not left in a collective (children die with the parent, the parent stops when a child ends abnormally)"""
+    """no rank is ever left waiting: a request the sharded head does not serve (hit dumps, early -S stages, -1 / -2) is decided before the ranks
+    exist and runs on one GPU with the same output; when one rank dies in the middle, the others are not left in a collective (children die
+    with the parent, the parent stops when a child ends abnormally)"""
     import subprocess
     import time
     paf = R.pafgen(os.path.join(tmpdir_s, "shc_fail.paf"), 800, 12000, 7, [])
     env = dict(os.environ, MA_GPUS="3", MA_COMM="shm")
-    args = [paf]
-    if who == "refused":
-        args = ["-p", "paf", paf]
+    if who == "one_gpu":
+        for args in (["-p", "paf"], ["-p", "sg", "-S3"], ["-1"], ["-2", "-p", "sg"], ["-p", "bed"]):
+            r = subprocess.run([ma.CLI_PATH] + args + [paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+            assert r.returncode == 0 and b"runs on one GPU" in r.stderr
+            assert r.stdout == R.run_cli(ma.CLI_PATH, args, paf)[0]
     else:
         env["MA_TEST_FAIL_RANK"] = "1" if who == "child" else "0"
-    t0 = time.time()
-    r = subprocess.run([ma.CLI_PATH] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
-    assert r.returncode != 0 and time.time() - t0 < 60
-    if who == "refused":
-        assert b"produces -p ug or -p sg" in r.stderr
+        t0 = time.time()
+        r = subprocess.run([ma.CLI_PATH, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+        assert r.returncode != 0 and time.time() - t0 < 60
     time.sleep(0.5)
     left = subprocess.run(["pgrep", "-f", paf], stdout=subprocess.PIPE).stdout.split()
     assert not left, "ranks still alive: %r" % left
