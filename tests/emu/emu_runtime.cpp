@@ -15,6 +15,7 @@
 #include <vector>
 #include <map>
 #include <string>
+#include <execinfo.h>
 
 namespace emu {
 
@@ -473,7 +474,21 @@ hipError_t hipMemsetAsync(void *dst, int v, size_t bytes, hipStream_t st) { (voi
 hipError_t hipStreamCreate(hipStream_t *st) { *st = new emu_stream{0}; return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned flags) { *st = new emu_stream{(int)flags}; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t st) { delete st; return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t st) { (void)st; ++g_syncs; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t st)
+{
+	(void)st;
+	++g_syncs;
+	if (emu::g_verbose >= 2) { // who waits for the device: the callers of this sync (build with -rdynamic for names)
+		void *bt[6];
+		int n = backtrace(bt, 6);
+		char **sym = backtrace_symbols(bt, n);
+		fprintf(stderr, "[hip-emu] sync:");
+		for (int i = 1; i < n && i < 5; ++i) { const char *p = strrchr(sym[i], '/'); fprintf(stderr, " <- %s", p ? p + 1 : sym[i]); }
+		fprintf(stderr, "\n");
+		free(sym);
+	}
+	return hipSuccess;
+}
 hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event{0}; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags) { (void)flags; *e = new emu_event{0}; return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }

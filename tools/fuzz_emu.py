@@ -139,7 +139,11 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--ranks", type=int, default=0, help="also run every case as MA_GPUS=N (shared-memory double)")
     ap.add_argument("--keep", default=None, help="directory for failing inputs")
+    ap.add_argument("--emu", default=None, help="the CPU build's miniasm (default tests/emu/_build/miniasm; point it at a copy to keep fuzzing across rebuilds)")
     a = ap.parse_args()
+    global EMU
+    if a.emu:
+        EMU = a.emu
     for p in (REF, EMU, PAFGEN):
         if not os.path.exists(p):
             sys.exit("missing " + p)
@@ -156,7 +160,7 @@ def main():
         if a.text:
             data = mutate_text(rng, open(paf, "rb").read())
             open(paf, "wb").write(data)
-            args = rng.choice([["-p", "paf", "-S1"], ["-p", "paf"], ["-p", "bed"], ["-p", "sg"], [], ["-R", "-p", "paf", "-S1"], ["-B", "-p", "paf", "-S1"]])
+            args = rng.choice([["-p", "paf", "-S2"], ["-p", "paf"], ["-p", "bed"], ["-p", "sg"], [], ["-R", "-p", "paf"], ["-B", "-p", "paf", "-S2"], ["-s", "0", "-m", "0", "-p", "paf", "-S2"]])
         rc0, out0, err0 = run(REF, args, paf)
         if rc0 < 0:  # the reference itself dies on this combination (e.g. -p bed -S1 dereferences the intervals before they exist): nothing to compare
             skipped += 1
