@@ -69,3 +69,15 @@ def test_sharded_suite_on_cpu(emu_built):
     against the single-rank run and the reference binary (tie-rich input included).  The torch-driven virtual-rank test needs a real device."""
     sel = "not rccl and not virtual_ranks" + ("" if FULL else " and (2-lognormal or 3-noisy or tie_order)")
     run_gpu_tests(["tests/test_gpu_sharded.py", "-k", sel], 5000)
+
+
+@pytest.mark.parametrize("mode", ["options", "text", "ranks"])
+def test_randomised_reference_vs_kernels_on_cpu(mode, emu_built):
+    """tools/fuzz_emu.py, a fixed slice of it: random generator parameters x random options x every dump format ("options"), damaged PAF text
+    ("text"), and the same through `MA_GPUS=2` ("ranks"): the reference binary's bytes against the CPU build of the kernels"""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "miniasm_ref")):
+        pytest.skip("oracle/_ref not built")
+    n = 150 if FULL else 30
+    args = {"options": ["--seed", "101"], "text": ["--seed", "102", "--text"], "ranks": ["--seed", "103", "--ranks", "2"]}[mode]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_emu.py"), "--cases", str(n)] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=3000)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout.splitlines()[-1], r.stdout[-3000:]
