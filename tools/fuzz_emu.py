@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref", "miniasm_ref")
 EMU = os.path.join(ROOT, "tests", "emu", "_build", "miniasm")
 PAFGEN = os.path.join(ROOT, "miniasm_amd", "bin", "pafgen")
+TIES = False
 
 
 def run(binary, args, paf, env=None, stdin=None):
@@ -38,7 +39,7 @@ def rand_case(rng):
         gen += ["-i", "%.2f" % rng.choice([0.1, 0.3])]
     if rng.random() < 0.3:
         gen += ["-g"]
-    if rng.random() < 0.4:
+    if rng.random() < (1.0 if TIES else 0.4):
         gen += ["-q", str(rng.choice([4, 16, 64, 256]))]  # coordinates on a grid: equal sort keys everywhere
     if rng.random() < 0.3:
         gen += ["-m", str(rng.choice([1500, 3000, 20000]))]
@@ -138,10 +139,12 @@ def main():
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--ranks", type=int, default=0, help="also run every case as MA_GPUS=N (shared-memory double)")
+    ap.add_argument("--ties", action="store_true", help="every input on a coordinate grid (equal sort keys everywhere: tie census, push conflicts, both walks)")
     ap.add_argument("--keep", default=None, help="directory for failing inputs")
     ap.add_argument("--emu", default=None, help="the CPU build's miniasm (default tests/emu/_build/miniasm; point it at a copy to keep fuzzing across rebuilds)")
     a = ap.parse_args()
-    global EMU
+    global EMU, TIES
+    TIES = a.ties
     if a.emu:
         EMU = a.emu
     for p in (REF, EMU, PAFGEN):
@@ -151,6 +154,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="ma_fuzz_")
     paf = os.path.join(tmp, "f.paf")
     bad = skipped = 0
+    paths = {}
     for k in range(a.cases):
         gen, args = rand_case(rng)
         r = subprocess.run([PAFGEN] + gen + ["-o", paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
@@ -169,7 +173,17 @@ def main():
         if a.ranks > 1:  # requests the sharded head does not serve fall back to one GPU: the bytes must be the same either way
             runs.append(("emu x%d" % a.ranks, {"MA_GPUS": str(a.ranks), "MA_COMM": "shm"}))
         for name, env in runs:
+            env = dict(env, MA_PIPE_TIMING="1")  # the [T::ties] line: which tie path the run took
             rc1, out1, err1 = run(EMU, args, paf, env)
+            for ln in err1.decode(errors="replace").splitlines():
+                if ln.startswith("[T::ties]") and "arc tie groups" in ln:
+                    import re
+                    mm = re.search(r"(\d+) arc tie groups .*?, (\d+) push conflicts", ln)
+                    if not mm:
+                        continue
+                    groups, conf = int(mm.group(1)), int(mm.group(2))
+                    key = "no arc ties" if groups == 0 else "arc walk" if conf == 0 else "arc walk + hit walk"
+                    paths[key] = paths.get(key, 0) + 1
             ok = rc0 == rc1 and out0 == out1
             if not ok:
                 bad += 1
@@ -181,6 +195,7 @@ def main():
                     os.replace(paf, os.path.join(a.keep, "case%d.paf" % k))
         if (k + 1) % 20 == 0:
             print("%d cases, %d mismatches" % (k + 1, bad), flush=True)
+    print("tie paths taken:", paths)
     print("done: %d cases, %d mismatches, %d skipped (reference crashed)" % (a.cases, bad, skipped))
     sys.exit(1 if bad else 0)
 
