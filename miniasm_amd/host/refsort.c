@@ -84,9 +84,9 @@ static void *pool_worker(void *arg)
 	return 0;
 }
 
-typedef struct { const void *a; const rs_cfg_t *cfg; size_t beg, end; int shift; uint64_t diff; size_t cnt[256]; } sweep_t;
+typedef struct { const void *a; const rs_cfg_t *cfg; size_t beg, end; int shift; uint64_t diff; size_t cnt[256]; uint8_t *dig; } sweep_t;
 
-static uint64_t sweep_run(void *(*worker)(void*), const void *a, size_t n, int shift, size_t *cnt, const rs_cfg_t *cfg, int n_threads)
+static uint64_t sweep_run(void *(*worker)(void*), const void *a, size_t n, int shift, size_t *cnt, const rs_cfg_t *cfg, int n_threads, uint8_t *dig)
 {
 	sweep_t *w;
 	pthread_t th[64];
@@ -95,7 +95,7 @@ static uint64_t sweep_run(void *(*worker)(void*), const void *a, size_t n, int s
 	if (n_threads > 64) n_threads = 64;
 	if (n_threads < 1) n_threads = 1;
 	w = (sweep_t*)malloc(sizeof(sweep_t) * n_threads);
-	for (t = 0; t < n_threads; ++t) w[t].a = a, w[t].cfg = cfg, w[t].shift = shift, w[t].beg = n / n_threads * t, w[t].end = t == n_threads - 1 ? n : n / n_threads * (t + 1);
+	for (t = 0; t < n_threads; ++t) w[t].a = a, w[t].cfg = cfg, w[t].shift = shift, w[t].dig = dig, w[t].diff = 0, w[t].beg = n / n_threads * t, w[t].end = t == n_threads - 1 ? n : n / n_threads * (t + 1);
 	for (t = 1; t < n_threads; ++t) pthread_create(&th[t], 0, worker, &w[t]);
 	worker(&w[0]);
 	for (t = 1; t < n_threads; ++t) pthread_join(th[t], 0);

@@ -19,6 +19,59 @@ static void RS_NAME(insertion)(RS_T *a, size_t n, const rs_cfg_t *cfg) /* ksort.
 
 static void RS_NAME(level)(rs_pool_t *pool, RS_T *a, size_t n, int shift);
 
+/* the buckets a level leaves behind (ksort.h:177-182): radix again when larger than 64, else the stable insertion sort */
+static void RS_NAME(dispatch)(rs_pool_t *pool, RS_T *a, const size_t *start, int shift)
+{
+	const rs_cfg_t *cfg = &pool->cfg;
+	int k, next = shift > 8 ? shift - 8 : 0;
+	if (!shift) return;
+	for (k = 0; k < 256; ++k) {
+		size_t cnt = start[k + 1] - start[k];
+		if (cnt > RS_SMALL) {
+			if (pool->n_threads > 1 && cnt >= TASK_MIN) pool_push(pool, a + start[k], cnt, next);
+			else RS_NAME(level)(pool, a + start[k], cnt, next);
+		} else if (cnt > 1) RS_NAME(insertion)(a + start[k], cnt, cfg);
+	}
+}
+
+/* The same permutation for the top level of a big input, where the walk is the one thing no other thread can help with.  The walk only ever
+ * evicts ORIGINAL elements -- a slot at or behind a bucket's head has not been written yet -- so where it goes next is a function of the
+ * input's digits alone: dig[] (one byte per element, written by the parallel sweep that counts the digits) replaces the look into the evicted
+ * element, and nd[d] = digit of the element at bucket d's head is kept ready per bucket.  The walk's dependent chain is then ONE load per
+ * step (d -> nd[d]); the element moves themselves hang off the bucket heads, not off each other, and overlap. */
+typedef struct { size_t head; uint32_t nd; uint32_t pad; } RS_NAME(bk_t);
+static void RS_NAME(permute_top)(rs_pool_t *pool, RS_T *a, const size_t *cnt, const uint8_t *dig /* n + 1 bytes */, int shift)
+{
+	RS_NAME(bk_t) b[256];
+	size_t start[257];
+	int k;
+	start[0] = 0;
+	for (k = 0; k < 256; ++k) start[k + 1] = start[k] + cnt[k], b[k].head = start[k], b[k].nd = dig[start[k]], b[k].pad = 0;
+	for (k = 0; k < 256;) {
+		unsigned d;
+		if (b[k].head == start[k + 1]) { ++k; continue; }
+		d = b[k].nd;
+		if (d == (unsigned)k) { b[k].nd = dig[++b[k].head]; continue; }
+		{
+			RS_T carry = a[b[k].head];
+			do {
+				const size_t slot = b[d].head;
+				const unsigned dn = b[d].nd;
+				const RS_T evicted = a[slot];
+				b[d].head = slot + 1;
+				b[d].nd = dig[slot + 1];
+				a[slot] = carry;
+				RS_PREFETCH(&a[slot]);
+				carry = evicted;
+				d = dn;
+			} while (d != (unsigned)k);
+			a[b[k].head] = carry;
+			b[k].nd = dig[++b[k].head];
+		}
+	}
+	RS_NAME(dispatch)(pool, a, start, shift);
+}
+
 /* the cycle-leader permutation of one level (ksort.h:153-176) given the digit counts in tail[]; then the buckets below */
 static void RS_NAME(permute)(rs_pool_t *pool, RS_T *a, size_t *tail, int shift)
 {
@@ -46,16 +99,7 @@ static void RS_NAME(permute)(rs_pool_t *pool, RS_T *a, size_t *tail, int shift)
 			a[head[k]++] = carry;
 		}
 	}
-	if (shift) {
-		int next = shift > 8 ? shift - 8 : 0;
-		for (k = 0; k < 256; ++k) {
-			size_t cnt = start[k + 1] - start[k];
-			if (cnt > RS_SMALL) {
-				if (pool->n_threads > 1 && cnt >= TASK_MIN) pool_push(pool, a + start[k], cnt, next);
-				else RS_NAME(level)(pool, a + start[k], cnt, next);
-			} else if (cnt > 1) RS_NAME(insertion)(a + start[k], cnt, cfg);
-		}
-	}
+	RS_NAME(dispatch)(pool, a, start, shift);
 }
 
 /* one level of ksort.h:153-179 on a[0..n) */
@@ -94,7 +138,8 @@ static void *RS_NAME(sweep_worker)(void *arg)
 		int sh;
 		unsigned m;
 		RS_LEVEL(cfg, w->shift, sh, m);
-		for (i = w->beg; i < w->end; ++i) diff |= RS_ORIG(a[i], cfg) ^ k0, ++w->cnt[RS_WORD(a[i]) >> sh & m];
+		if (w->dig) for (i = w->beg; i < w->end; ++i) { const unsigned dgt = (unsigned)(RS_WORD(a[i]) >> sh & m); w->dig[i] = (uint8_t)dgt; ++w->cnt[dgt]; }
+		else for (i = w->beg; i < w->end; ++i) diff |= RS_ORIG(a[i], cfg) ^ k0, ++w->cnt[RS_WORD(a[i]) >> sh & m];
 	} else for (i = w->beg; i < w->end; ++i) diff |= RS_ORIG(a[i], cfg) ^ k0;
 	w->diff = diff;
 	return 0;
@@ -121,15 +166,19 @@ static void RS_NAME(sort)(RS_T *a, size_t n, const rs_cfg_t *cfg, int n_threads)
 		p.n_threads = n_threads;
 		/* the top level: its two sweeps (which bits vary; the digit counts) run on all threads, only the walk itself is sequential */
 		RS_T0;
-		diff = sweep_run(RS_NAME(sweep_worker), a, n, -1, 0, cfg, n_threads);
+		diff = sweep_run(RS_NAME(sweep_worker), a, n, -1, 0, cfg, n_threads, 0);
 		if (diff != 0) {
+			uint8_t *dig = (uint8_t*)malloc(n + 1);
 			while (shift > 0 && (diff >> shift & 0xff) == 0) shift -= 8;
-			sweep_run(RS_NAME(sweep_worker), a, n, shift, cnt, cfg, n_threads);
+			if (dig) dig[n] = 0;
+			sweep_run(RS_NAME(sweep_worker), a, n, shift, cnt, cfg, n_threads, dig);
 			RS_LAP(" sweeps");
 			th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
 			++p.busy; /* the top-level walk below produces tasks: workers must not leave while it runs */
 			for (t = 0; t < n_threads; ++t) pthread_create(&th[t], 0, pool_worker, &p);
-			RS_NAME(permute)(&p, a, cnt, shift);
+			if (dig) RS_NAME(permute_top)(&p, a, cnt, dig, shift);
+			else RS_NAME(permute)(&p, a, cnt, shift);
+			free(dig);
 			RS_LAP(" top walk");
 			pthread_mutex_lock(&p.mu);
 			--p.busy;
