@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--no-text", action="store_true", help="skip the text-resident leg (device-side parse inside the step)")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (cfg2, tie-rich input, CLI end to end)")
     ap.add_argument("--no-overlap", action="store_true", help="run each pass's host tail before the next pass's device part starts")
+    ap.add_argument("--tail-ctx", action="store_true", help="second context on the same GPU for the latency-bound rest of a batch (cleaners, unitigs, downloads): "
+                    "it runs beside the next batch's hit passes (mahip_tail_handoff); not measured yet, off by default")
     ap.add_argument("--prof-steps", type=int, default=3)
     args = ap.parse_args()
     args.gen_extra = [] if args.model == "lognormal" else ["-L", args.model]
@@ -271,6 +273,10 @@ def main():
             self.out = {"n": 0, "rc": 0, "buf": None}
             self.q = queue.Queue(maxsize=1)  # one batch may wait while another is being finished
             self.worker = None
+            # --tail-ctx: the device tail of a batch (graph cleaning, unitigs, downloads -- many small launches and counter fetches) moves to a
+            # second context and to the worker thread; this thread goes straight on to the next batch's hit passes
+            self.ctx2 = ma.Ctx(local) if (args.tail_ctx and overlap and rank == 0) else None
+            self.ctx2_free = threading.Semaphore(1)
             if overlap and rank == 0:
                 self.worker = threading.Thread(target=self._work, daemon=True)
                 self.worker.start()
@@ -286,6 +292,13 @@ def main():
             while True:
                 job = self.q.get()
                 try:
+                    if isinstance(job, tuple):  # (status words of the head): the device tail is still to do, on the second context
+                        st = job[0]
+                        try:
+                            job = L.ma_pipeline_tail_fetch(self.ctx2.h, C.byref(opt), self.W.d, b"ug", 100, C.byref(st))
+                        finally:
+                            self.ctx2_free.release()
+                        assert job
                     if job is not None:
                         self._finish(job)
                 except Exception as e:  # never leave the fence waiting on a dead worker
@@ -309,6 +322,11 @@ def main():
                 if rank != 0:
                     return
                 st = (C.c_uint32 * 4)(1, 1, stats.n_red, 1)
+            if self.ctx2:
+                self.ctx2_free.acquire()  # the previous batch's device tail has left the second context
+                ma._chk(L.mahip_tail_handoff(ctx.h, self.ctx2.h), "tail_handoff")
+                self.q.put((st,))
+                return
             job = L.ma_pipeline_tail_fetch(ctx.h, C.byref(opt), W.d, b"ug", 100, C.byref(st))
             assert job
             if self.worker:
@@ -345,7 +363,11 @@ def main():
             if self.out["buf"]:
                 L.free_buf(self.out["buf"])
                 self.out["buf"] = None
+            if self.ctx2:
+                self.ctx2.close()
+                self.ctx2 = None
 
+    L.mahip_tail_handoff.argtypes = [vp, vp]
     run = Runner(W)
     dt = run.timed(args.warmup, args.steps)
     if world > 1:
@@ -495,7 +517,8 @@ def main():
                 "BASELINE configs[3]" if cfg_name == "cfg4" else "BASELINE configs[1]" if cfg_name == "cfg2" else cfg_name,
                 args.model, args.seed, W.n_lines, W.n_seq, W.n_all / max(W.n_seq, 1), " (sharded by query-read range)" if world > 1 else "", len(gfa)),
                 "global_overlaps": W.n_lines, "per_gpu_hits": W.n_my,
-                "pipelining": "host tail of pass k (cleaners, unitigs, GFA text) overlaps the device part of pass k+1; all K outputs complete inside the timed region" if overlap else "none (--no-overlap)",
+                "pipelining": ("device tail (cleaners, unitigs) on a second context + host tail (GFA text) of pass k overlap the hit passes of pass k+1; all K outputs complete inside the timed region" if args.tail_ctx else
+                               "host tail of pass k (GFA text) overlaps the device part of pass k+1; all K outputs complete inside the timed region") if overlap else "none (--no-overlap)",
                 "parallelism": "read-range shards x%d, RCCL all-gather of sub/flags/arcs from C (host/sharded.c)" % world if world > 1 else "single GPU"},
             "gfa_identical": parity["gfa_identical"] if parity else None, "parity": parity,
             "tie_groups": tie["arc_tie_groups"] if tie else None,

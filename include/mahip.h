@@ -152,6 +152,13 @@ int mahip_asg_del_short(mahip_ctx_t *c, float drop_ratio, uint32_t *n_short);
  * on): a relabelling -- arc order and CSR positions are unchanged -- after which the cleaners and the unitig pass sweep the
  * surviving reads only.  No-op when no squeeze map is pending. */
 int mahip_asg_squeeze(mahip_ctx_t *c);
+/* Streams of inputs: hand the reduced graph to a SECOND context on the same device, so that the latency-bound rest of a batch (cleaners,
+ * unitigs, downloads: ma_pipeline_tail_fetch on `to`, from another host thread) runs beside the next batch's hit passes on `from`.
+ * `from` must hold a graph (after mahip_asg_del_trans / symm); it is squeezed first.  `to` receives the squeezed graph, the surviving reads'
+ * intervals (sub slot 0) and their old ids -- O(survivors + arcs) bytes, device to device -- and answers the same queries a context answers
+ * after ma_hit_contained + ma_sg_gen (mahip_n_seq_new, mahip_survivors_download, mahip_sub_download, the graph passes, mahip_ug_gen).
+ * Returns when the copies are complete: `from` may be reused at once. */
+int mahip_tail_handoff(mahip_ctx_t *from, mahip_ctx_t *to);
 /* The order-dependent cleaners (asg.c:238-433) as a device fixpoint over versioned state (csrc/clean_core.h); each includes the
  * asg_cleanup the reference runs when something was cut.  Results equal the reference's sequential sweeps exactly. */
 int mahip_asg_cut_tip(mahip_ctx_t *c, int max_ext, uint32_t *n_cut);                       /* asg.c:238-254 */

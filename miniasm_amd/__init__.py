@@ -392,3 +392,25 @@ def run_resident(ctx, opt, ingest, outfmt="ug", stage=100, flags=0):
     out = C.string_at(buf, ln.value)
     L.free_buf(buf)
     return out
+
+
+def run_resident_handoff(ctx, ctx2, opt, ingest, outfmt="ug", stage=100, flags=0):
+    """The same job split over two contexts of one device (include/mahip.h: mahip_tail_handoff): hit passes, graph and reduction on ctx,
+    cleaners + unitigs + downloads on ctx2 -- what a caller with a stream of inputs overlaps with the next input's hit passes."""
+    L = lib()
+    vp = C.c_void_p
+    L.ma_pipeline_head.restype = C.c_int
+    L.ma_pipeline_head.argtypes = [vp, C.POINTER(MaOpt), C.POINTER(Sdict), C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint32 * 4)]
+    L.ma_pipeline_tail_mem.restype = C.c_int
+    L.ma_pipeline_tail_mem.argtypes = [vp, C.POINTER(MaOpt), C.POINTER(Sdict), C.c_char_p, C.c_int, C.POINTER(C.c_uint32 * 4), C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.mahip_tail_handoff.argtypes = [vp, vp]
+    st = (C.c_uint32 * 4)(0, 0, 0, 0)
+    if L.ma_pipeline_head(ctx.h, C.byref(opt), ingest.d, outfmt.encode(), stage, flags, C.byref(st)) != 0:
+        raise GpuError("pipeline head failed: %s" % L.mahip_strerror().decode())
+    _chk(L.mahip_tail_handoff(ctx.h, ctx2.h), "tail_handoff")
+    buf, ln = vp(0), C.c_size_t(0)
+    if L.ma_pipeline_tail_mem(ctx2.h, C.byref(opt), ingest.d, outfmt.encode(), stage, C.byref(st), C.byref(buf), C.byref(ln)) != 0:
+        raise GpuError("pipeline tail failed: %s" % L.mahip_strerror().decode())
+    out = C.string_at(buf, ln.value)
+    L.free_buf(buf)
+    return out

@@ -878,6 +878,52 @@ extern "C" int mahip_asg_squeeze(mahip_ctx_t *c)
 	return 0;
 }
 
+__global__ __launch_bounds__(256) void k_sub_squeeze_g(const uint2 *__restrict__ sub, const int32_t *__restrict__ map, uint32_t n_seq, uint2 *__restrict__ out)
+{ // sdict.c:78-85 on the interval array: survivors move to their new ids
+	uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	if (r < n_seq && map[r] >= 0) out[map[r]] = sub[r];
+}
+
+extern "C" int mahip_tail_handoff(mahip_ctx_t *s, mahip_ctx_t *d)
+{
+	if (s == d || s->dev != d->dev) { mahip_set_error("mahip_tail_handoff: two contexts on one device"); return -1; }
+	HIPCHK(hipSetDevice(s->dev));
+	if (!s->graph_ready) { mahip_set_error("mahip_tail_handoff: no graph"); return -1; }
+	CHK(mahip_asg_squeeze(s));
+	const uint32_t Rn = s->has_map ? s->n_seq_new : s->n_seq;
+	const size_t n = s->n_arc;
+	const bool have_sub = s->sub[0].p != nullptr && s->n_seq > 0;
+	// the receiving buffers (allocation only: nothing of `d` is in flight -- its owner finished the previous batch before asking for the next)
+	CHK(reserve_arcs(d, n));
+	CHK(dev_reserve(d, d->slen, ((size_t)Rn + 4) * 4)); CHK(dev_reserve(d, d->sdel, (size_t)Rn + 16));
+	CHK(dev_reserve(d, d->idx, (2 * (size_t)Rn + 2) * 8));
+	CHK(dev_reserve(d, d->sub[0], ((size_t)Rn + 1) * 8)); CHK(dev_reserve(d, d->surv, ((size_t)Rn + 1) * 4));
+	// everything below is queued on the sender's stream, behind the kernels that made the graph
+	if (n) {
+		HIPCHK(hipMemcpyAsync(d->au[0].p, s->au[s->ag].p, n * 4, hipMemcpyDeviceToDevice, s->st));
+		HIPCHK(hipMemcpyAsync(d->av[0].p, s->av[s->ag].p, n * 4, hipMemcpyDeviceToDevice, s->st));
+		HIPCHK(hipMemcpyAsync(d->alen[0].p, s->alen[s->ag].p, n * 4, hipMemcpyDeviceToDevice, s->st));
+		HIPCHK(hipMemcpyAsync(d->aol[0].p, s->aol[s->ag].p, n * 4, hipMemcpyDeviceToDevice, s->st));
+	}
+	if (Rn) {
+		HIPCHK(hipMemcpyAsync(d->slen.p, s->slen.p, (size_t)Rn * 4, hipMemcpyDeviceToDevice, s->st));
+		HIPCHK(hipMemcpyAsync(d->sdel.p, s->sdel.p, (size_t)Rn, hipMemcpyDeviceToDevice, s->st));
+		HIPCHK(hipMemcpyAsync(d->idx.p, s->idx.p, 2 * (size_t)Rn * 8, hipMemcpyDeviceToDevice, s->st));
+		if (have_sub) {
+			if (s->has_map) hipLaunchKernelGGL(k_sub_squeeze_g, dim3(grid_for(s->n_seq, 256)), dim3(256), 0, s->st, (const uint2*)P<uint2>(s->sub[0]), (const int32_t*)P<int32_t>(s->map), s->n_seq, P<uint2>(d->sub[0]));
+			else HIPCHK(hipMemcpyAsync(d->sub[0].p, s->sub[0].p, (size_t)Rn * 8, hipMemcpyDeviceToDevice, s->st));
+		}
+		if (s->has_map || s->surv_ready) HIPCHK(hipMemcpyAsync(d->surv.p, s->surv.p, (size_t)Rn * 4, hipMemcpyDeviceToDevice, s->st));
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(s->st));
+	d->n_seq = Rn; d->n_seq_new = Rn; d->has_map = false; d->surv_ready = s->has_map || s->surv_ready; d->gsq = true; d->lazy_squeeze = false;
+	d->soa_ready = false; d->gather_pending = false; d->sorted_here = false; d->n_hits = 0; d->n_live = 0;
+	d->ag = 0; d->n_arc = (uint32_t)n; d->graph_ready = true;
+	d->tie = s->tie;
+	return 0;
+}
+
 extern "C" int mahip_asg_cleanup(mahip_ctx_t *c, uint32_t *n_arc)
 {
 	HIPCHK(hipSetDevice(c->dev));
@@ -893,7 +939,7 @@ extern "C" int mahip_asg_upload(mahip_ctx_t *c, const asg_t *g)
 	HIPCHK(hipSetDevice(c->dev));
 	size_t n = g->n_arc;
 	uint32_t R = g->n_seq;
-	c->n_seq = R; c->n_seq_new = R; c->has_map = false; c->soa_ready = false; c->gather_pending = false; c->gsq = false;
+	c->n_seq = R; c->n_seq_new = R; c->has_map = false; c->surv_ready = false; c->soa_ready = false; c->gather_pending = false; c->gsq = false;
 	CHK(reserve_arcs(c, n));
 	CHK(dev_reserve(c, c->slen, ((size_t)R + 4) * 4)); CHK(dev_reserve(c, c->sdel, (size_t)R + 16));
 	CHK(dev_reserve(c, c->idx, (2 * (size_t)R + 2) * 8));

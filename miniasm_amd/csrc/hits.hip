@@ -857,7 +857,7 @@ static int reserve_read_arrays(mahip_ctx *c)
 static int hits_common_setup(mahip_ctx *c, size_t n, uint32_t n_seq)
 {
 	c->n_hits = n; c->n_in = n; c->n_live = n; c->n_seq = n_seq; c->n_seq_new = n_seq;
-	c->soa_ready = false; c->has_map = false; c->graph_ready = false; c->gather_pending = false;
+	c->soa_ready = false; c->has_map = false; c->surv_ready = false; c->graph_ready = false; c->gather_pending = false;
 	c->hint_max_qs = 0; // hints describe one upload: set them again after every upload/adopt
 	c->lazy_squeeze = false;
 	c->sorted_here = false; c->hrank_ready = false; c->orank_ready = false;
@@ -1481,7 +1481,7 @@ extern "C" uint32_t mahip_n_seq_new(mahip_ctx_t *c) { return c->has_map ? c->n_s
 extern "C" int mahip_survivors_download(mahip_ctx_t *c, uint32_t *old_ids)
 {
 	HIPCHK(hipSetDevice(c->dev));
-	if (!c->has_map) { mahip_set_error("mahip_survivors_download: no squeeze map"); return -1; }
+	if (!c->has_map && !c->surv_ready) { mahip_set_error("mahip_survivors_download: no squeeze map"); return -1; }
 	if (c->n_seq_new) HIPCHK(hipMemcpyAsync(old_ids, c->surv.p, (size_t)c->n_seq_new * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipStreamSynchronize(c->st));
 	return 0;

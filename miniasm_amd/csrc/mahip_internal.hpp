@@ -49,6 +49,7 @@ struct mahip_ctx {
 	DevBuf map;               // int32 [n_seq]  old -> new id, -1 dropped
 	DevBuf surv;              // u32 [n_seq_new] new -> old id
 	bool soa_ready = false, has_map = false, lazy_squeeze = false;
+	bool surv_ready = false;  // surv holds the old ids of this context's reads although no map is pending (mahip_tail_handoff)
 	int sg_max_hang = 0, sg_min_ovlp = 0; float sg_int_frac = 0; // classifier options of the last mahip_sg_flags (pass B/C recompute the arcs)
 	// ---- tie order.  The device sorts are stable; the reference's are not.  tie_mode 2 (default): after the arc
 	// sort a census counts (u,len) tie groups; none => the stable order IS the reference's result; some => the reference's order is

@@ -33,7 +33,7 @@ void sys_init(void)
 
 const char *sys_timestamp(void)
 {
-	static char stamp[256];
+	static __thread char stamp[256]; /* the tail of one batch may log beside the head of the next (two contexts, two threads) */
 	double rt = sys_realtime(), ct = sys_cputime();
 	snprintf(stamp, sizeof(stamp) - 1, "%.3f*%.2f", rt, ct / rt);
 	return stamp;

@@ -65,3 +65,107 @@ def test_device_cleaners_unitigs_gfa_match_reference(name, reads, lines, seed, e
     LR.ma_ug_destroy(ug_r); LP.ma_ug_destroy(ug_p)
     LR.asg_destroy(g_ref)
     LR.sd_destroy(dr); LP.sd_destroy(d)
+
+
+@pytest.mark.parametrize("case", ["lognormal", "noisy"])
+def test_tail_on_a_second_context_gives_the_same_output(case, tmpdir_s):
+    """mahip_tail_handoff: the reduced graph, the survivors and their intervals move to a second context of the same device, which cleans the
+    graph and builds the unitigs while the first one is free for the next input -- same bytes as the single-context run (and the reference's);
+    the first context is overwritten by another input before the second one finishes, as a streaming caller would"""
+    extra = {"lognormal": [], "noisy": ["-L", "uniform", "-d", "0.35", "-x", "0.03"]}[case]
+    paf = R.pafgen(os.path.join(tmpdir_s, "ho_%s.paf" % case), 3000, 90000, 77, extra)
+    other = R.pafgen(os.path.join(tmpdir_s, "ho_other.paf"), 500, 9000, 78, [])
+    opt = ma.default_opt()
+    ing, ing2 = ma.Ingest(paf, opt), ma.Ingest(other, opt)
+    c1, c2 = ma.Ctx(0), ma.Ctx(0)
+    for fmt in ("ug", "sg"):
+        c1.hits_upload(ing.hits, ing.n_seq)
+        want = ma.run_resident(c1, opt, ing, fmt)
+        c1.hits_upload(ing.hits, ing.n_seq)
+        L = ma.lib()
+        vp = C.c_void_p
+        L.ma_pipeline_head.argtypes = [vp, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint32 * 4)]
+        L.ma_pipeline_tail_mem.argtypes = [vp, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.POINTER(C.c_uint32 * 4), C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.mahip_tail_handoff.argtypes = [vp, vp]
+        st = (C.c_uint32 * 4)(0, 0, 0, 0)
+        assert L.ma_pipeline_head(c1.h, C.byref(opt), ing.d, fmt.encode(), 100, 0, C.byref(st)) == 0
+        ma._chk(L.mahip_tail_handoff(c1.h, c2.h), "tail_handoff")
+        c1.hits_upload(ing2.hits, ing2.n_seq)  # the first context moves on
+        st2 = (C.c_uint32 * 4)(0, 0, 0, 0)
+        assert L.ma_pipeline_head(c1.h, C.byref(opt), ing2.d, fmt.encode(), 100, 0, C.byref(st2)) == 0
+        buf, ln = vp(0), C.c_size_t(0)
+        assert L.ma_pipeline_tail_mem(c2.h, C.byref(opt), ing.d, fmt.encode(), 100, C.byref(st), C.byref(buf), C.byref(ln)) == 0
+        got = C.string_at(buf, ln.value)
+        L.free_buf(buf)
+        assert got == want, "%s: output of the two-context run differs" % fmt
+        if R.have_ref() and fmt == "ug":
+            ref_sg, _ = R.run_cli(R.REF_BIN, ["-p", "sg", "-S5"], paf)
+            if R.arc_tie_groups(ref_sg) == 0:
+                assert got == R.run_cli(R.REF_BIN, [], paf)[0]
+        c1.hits_upload(ing.hits, ing.n_seq)
+        assert ma.run_resident_handoff(c1, c2, opt, ing, fmt) == want  # and again through the harness, contexts reused
+    for x in (ing, ing2):
+        x.close()
+    c1.close(); c2.close()
+
+
+@pytest.mark.skipif(not getattr(ma, "IS_EMU", False) and os.environ.get("MA_TEST_TAIL_CTX") != "1",
+                    reason="two host threads on two contexts: validated on the CPU build; set MA_TEST_TAIL_CTX=1 to run it on the GPU (bench.py --tail-ctx is opt-in until measured)")
+def test_streaming_with_the_tail_on_a_second_context_and_thread(tmpdir_s):
+    """the shape of bench.py --tail-ctx: this thread runs the hit passes of batch k+1 on the first context while a worker thread cleans batch k's
+    graph and builds its unitigs on the second; a semaphore keeps the hand-over from overwriting a context that is still in use"""
+    import queue
+    import threading
+    opt = ma.default_opt()
+    pafs = [R.pafgen(os.path.join(tmpdir_s, "st_%d.paf" % k), 1500 + 400 * k, 40000 + 9000 * k, 90 + k, [] if k % 2 == 0 else ["-L", "uniform", "-d", "0.3", "-x", "0.03"]) for k in range(3)]
+    ings = [ma.Ingest(p, opt) for p in pafs]
+    c1, c2 = ma.Ctx(0), ma.Ctx(0)
+    want = []
+    for ing in ings:
+        c1.hits_upload(ing.hits, ing.n_seq)
+        want.append(ma.run_resident(c1, opt, ing, "ug"))
+    L = ma.lib()
+    vp = C.c_void_p
+    L.ma_pipeline_head.argtypes = [vp, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint32 * 4)]
+    L.ma_pipeline_tail_mem.argtypes = [vp, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.POINTER(C.c_uint32 * 4), C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.mahip_tail_handoff.argtypes = [vp, vp]
+    q, free2, got, errs = queue.Queue(maxsize=1), threading.Semaphore(1), [], []
+
+    def work():
+        while True:
+            item = q.get()
+            try:
+                if item is None:
+                    return
+                k, st = item
+                buf, ln = vp(0), C.c_size_t(0)
+                rc = L.ma_pipeline_tail_mem(c2.h, C.byref(opt), ings[k].d, b"ug", 100, C.byref(st), C.byref(buf), C.byref(ln))
+                free2.release()
+                if rc != 0:
+                    errs.append("tail %d failed" % k)
+                    continue
+                got.append((k, C.string_at(buf, ln.value)))
+                L.free_buf(buf)
+            finally:
+                q.task_done()
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    order = [0, 1, 2, 1, 0, 2, 2, 0]
+    for k in order:
+        c1.hits_upload(ings[k].hits, ings[k].n_seq)
+        st = (C.c_uint32 * 4)(0, 0, 0, 0)
+        assert L.ma_pipeline_head(c1.h, C.byref(opt), ings[k].d, b"ug", 100, 0, C.byref(st)) == 0
+        free2.acquire()
+        ma._chk(L.mahip_tail_handoff(c1.h, c2.h), "tail_handoff")
+        q.put((k, st))
+    q.join()
+    q.put(None)
+    t.join()
+    assert not errs, errs
+    assert [k for k, _ in got] == order
+    for k, out in got:
+        assert out == want[k], "batch of input %d differs" % k
+    for ing in ings:
+        ing.close()
+    c1.close(); c2.close()
