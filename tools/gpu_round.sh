@@ -53,6 +53,16 @@ benchsmall)
 bench)
   timeout 1700 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.log; echo "rc=$?" >> gpurun_out/bench.log
   grep -E "^\[bench\]|rc=" gpurun_out/bench.log | tail -12; cat gpurun_out/bench.json ;;
+tailctx)
+  # the device tail on a second context (bench.py --tail-ctx, mahip_tail_handoff): same workload with and without, cfg4 and cfg2, GFA compared
+  MA_TEST_TAIL_CTX=1 timeout 900 python -m pytest tests/test_gpu_graph_api.py -m gpu -q --tb=short -p no:cacheprovider -k "second_context or streaming" > gpurun_out/tests_tailctx.log 2>&1; echo "tests rc=$?"
+  for v in "" "--tail-ctx"; do for cfg in "" "--reads 200000 --lines 10000000 --seed 1"; do
+    timeout 900 python bench.py --no-cpu --no-legs --no-text --prof-steps 0 --steps 20 --warmup 3 $cfg $v > gpurun_out/bench_tailctx.json 2> gpurun_out/bench_tailctx.log; echo "[$cfg $v] rc=$?"
+    python3 -c "import json; d=json.load(open('gpurun_out/bench_tailctx.json')); print('   ms_per_step %.3f  value %.3g' % (d['ms_per_step'], d['value']))"
+  done; done ;;
+expstore)
+  # EXP_BOUNDED_STORE: masked column stores of the first coverage pass through a buffer descriptor instead of the spare slots
+  bash tools/variants.sh build base:"" bounded:"-DEXP_BOUNDED_STORE" | tail -4; bash tools/variants.sh run base bounded ;;
 benchcfg2)
   timeout 900 python bench.py --reads 200000 --lines 10000000 --seed 1 --no-legs > gpurun_out/bench_cfg2.json 2> gpurun_out/bench_cfg2.log; echo "rc=$?" >> gpurun_out/bench_cfg2.log
   grep -E "^\[bench\]|rc=" gpurun_out/bench_cfg2.log | tail -8; cat gpurun_out/bench_cfg2.json ;;
