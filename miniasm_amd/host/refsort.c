@@ -21,6 +21,7 @@
 #include <string.h>
 #include "ma_host.h"
 #include <time.h>
+#include <unistd.h>
 #include <stdio.h>
 static double rs_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 static int rs_timing = -1;
@@ -185,9 +186,18 @@ static void fill_run(fill_t *proto, size_t n, int phase, int n_threads)
 
 static int bits_of64(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
 
+/* the buckets below the top level are independent and memory-latency bound: they scale past the 16 threads the text reader settles on */
+static int refsort_threads(void)
+{
+	const char *s = getenv("MA_THREADS");
+	long n = s ? atol(s) : sysconf(_SC_NPROCESSORS_ONLN);
+	if (!s && n > 32) n = 32;
+	return n < 1 ? 1 : n > 64 ? 64 : (int)n;
+}
+
 int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm)
 {
-	const int nt = ma_ingest_threads();
+	const int nt = refsort_threads();
 	fill_t f;
 	int bh, bl, bi;
 	if (n == 0) return 0;
