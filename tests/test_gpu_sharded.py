@@ -172,6 +172,8 @@ def test_cli_on_n_ranks_never_leaves_a_rank_waiting(who, tmpdir_s):
     with the parent, the parent stops when a child ends abnormally)"""
     import subprocess
     import time
+    if who != "one_gpu" and not getattr(ma, "IS_EMU", False) and os.environ.get("MA_TEST_KILL") != "1":
+        pytest.skip("kills ranks in the middle of a run: host-side process handling, exercised on the CPU build; MA_TEST_KILL=1 runs it on the GPU")
     paf = R.pafgen(os.path.join(tmpdir_s, "shc_fail.paf"), 800, 12000, 7, [])
     env = dict(os.environ, MA_GPUS="3", MA_COMM="shm")
     if who == "one_gpu":
