@@ -165,6 +165,37 @@ def test_cli_on_n_ranks_reproduces_the_reference_tie_order(world, tmpdir_s):
         assert r.stdout == ref, "%d ranks, %s: bytes differ from the reference" % (world, " ".join(args))
 
 
+@pytest.mark.parametrize("tail_ctx", [0, 1])
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_that_hold_only_their_own_records(world, tail_ctx, tmpdir_s):
+    """the shape of `bench.py --gpus N` without torch: every rank is a process that holds ONLY the records of its read range, three steps over
+    the shared-memory double, rank 0 finishes each batch on its own context or (tail_ctx) on a second one (mahip_tail_handoff); every step's GFA
+    equals the single-context run and the reference's"""
+    import subprocess
+    import sys
+    paf = R.pafgen(os.path.join(tmpdir_s, "own_%d.paf" % world), 2500, 70000, 55, ["-L", "uniform", "-d", "0.3"])
+    out = os.path.join(tmpdir_s, "own_%d_%d.out" % (world, tail_ctx))
+    env = dict(os.environ, MA_WORKER_EMU="1" if getattr(ma, "IS_EMU", False) else "0")
+    env.pop("MA_GPUS", None)
+    name = "ma_own_%d_%d_%d" % (os.getpid(), world, tail_ctx)
+    procs = [subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "shard_step_worker.py"), paf, str(r), str(world), name, str(tail_ctx), out],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(world)]
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, err.decode()[-2000:]
+    data = open(out, "rb").read()
+    assert data.startswith(b"OK\n"), "a step's GFA differs from the single-context run"
+    if R.have_ref():
+        ref_sg, _ = R.run_cli(R.REF_BIN, ["-p", "sg", "-S5"], paf)
+        if R.arc_tie_groups(ref_sg) == 0:
+            assert data[3:] == R.run_cli(R.REF_BIN, [], paf)[0]
+
+
 @pytest.mark.parametrize("who", ["one_gpu", "child", "parent"])
 def test_cli_on_n_ranks_never_leaves_a_rank_waiting(who, tmpdir_s):
     """no rank is ever left waiting: a request the sharded head does not serve (hit dumps, early -S stages, -1 / -2) is decided before the ranks
