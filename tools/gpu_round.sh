@@ -63,6 +63,13 @@ tailctx)
 expstore)
   # EXP_BOUNDED_STORE: masked column stores of the first coverage pass through a buffer descriptor instead of the spare slots
   bash tools/variants.sh build base:"" bounded:"-DEXP_BOUNDED_STORE" | tail -4; bash tools/variants.sh run base bounded ;;
+expparse)
+  # the parse kernel with byte-wise LDS reads (the round-2 measured form) against the register-window reader: parse kernel times of the ingest bench
+  bash tools/variants.sh build base:"" bytewise:"-DEXP_PARSE_BYTEWISE" | tail -4
+  for v in base bytewise; do
+    MINIASM_AMD_LIB=$PWD/build/variants/$v/libminiasm_amd.so timeout 900 python bench.py --no-cpu --no-legs --steps 4 --warmup 1 --prof-steps 0 > gpurun_out/bench_parse_$v.json 2> gpurun_out/bench_parse_$v.log; echo "[$v] rc=$?"
+    python3 -c "import json,sys; d=json.load(open('gpurun_out/bench_parse_$v.json')); print('   from_text %.2f ms/step, setup parse+dictionary %.3f s' % (d['from_text']['ms_per_step'], d['setup']['parse_dictionary_s']))"
+  done ;;
 benchcfg2)
   timeout 900 python bench.py --reads 200000 --lines 10000000 --seed 1 --no-legs > gpurun_out/bench_cfg2.json 2> gpurun_out/bench_cfg2.log; echo "rc=$?" >> gpurun_out/bench_cfg2.log
   grep -E "^\[bench\]|rc=" gpurun_out/bench_cfg2.log | tail -8; cat gpurun_out/bench_cfg2.json ;;

@@ -12,7 +12,7 @@ build)
     name=${spec%%:*}; extra=${spec#*:}
     d=build/variants/$name; mkdir -p $d/obj
     cp -p build/obj/*.o $d/obj/
-    rm -f $d/obj/radix.hip.o $d/obj/hits.hip.o $d/obj/graph.hip.o
+    rm -f $d/obj/radix.hip.o $d/obj/hits.hip.o $d/obj/graph.hip.o $d/obj/paf.hip.o
     make lib B=$d/obj LIB=$d/libminiasm_amd.so EXTRA="$extra" 2>&1 | grep -E "error|warning" ; ls -la $d/libminiasm_amd.so
   done ;;
 run)
