@@ -183,9 +183,14 @@ struct LdsBytes {
 	}
 };
 
+// the column starts of the block's 256 lines in LDS, column-major: lane i's k-th entry sits at [k][i], so a wave's accesses never share a bank
+struct FsCols {
+	uint32_t *b;
+	__device__ __forceinline__ uint32_t &operator[](uint32_t k) const { return b[k * 256u]; }
+};
 // column starts: fs[k] = position after the k-th TAB of the line (k < 12); returns the number of TABs
 template <typename PTR>
-__device__ __forceinline__ uint32_t paf_tabs(PTR &p, uint32_t l, uint32_t *fs)
+__device__ __forceinline__ uint32_t paf_tabs(PTR &p, uint32_t l, FsCols fs)
 {
 	uint32_t t = 0;
 	fs[0] = 0;
@@ -195,7 +200,7 @@ __device__ __forceinline__ uint32_t paf_tabs(PTR &p, uint32_t l, uint32_t *fs)
 }
 #ifndef EXP_PARSE_BYTEWISE
 // the same over the 8-byte words of the tile: a SWAR mask of the bytes that equal TAB (exact, as nl_mask), then only the set bits are visited
-__device__ __forceinline__ uint32_t paf_tabs(LdsBytes &p, uint32_t l, uint32_t *fs)
+__device__ __forceinline__ uint32_t paf_tabs(LdsBytes &p, uint32_t l, FsCols fs)
 {
 	uint32_t t = 0;
 	fs[0] = 0;
@@ -223,7 +228,7 @@ struct PafLine { uint32_t valid, hasbl, rev, ql, qs, qe, tl, ts, te, ml, bl, tno
 // One line: first the column starts (one pass over the bytes, starts kept in LDS), then each column with straight-line
 // code -- every lane is in the same routine at the same time, only the trip counts differ.
 template <typename PTR>
-__device__ __forceinline__ void paf_line(PTR p, uint32_t l, uint32_t *fs /* LDS, 12 entries, stride 1 */, PafLine &o)
+__device__ __forceinline__ void paf_line(PTR p, uint32_t l, FsCols fs /* LDS, 12 entries */, PafLine &o)
 {
 	if (l > 1 && p[l - 1] == '\r') --l;
 	uint32_t t = paf_tabs(p, l, fs);
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(256) void k_paf_parse(const unsigned char *__restri
 		const uint64_t ls = lstart[i];
 		const uint32_t l = (uint32_t)(lstart[i + 1] - 1 - ls);
 		PafLine r;
-		uint32_t *fs = s_fs + threadIdx.x * 12;
+		const FsCols fs = { s_fs + threadIdx.x };
 #ifdef EXP_PARSE_BYTEWISE
 		if (in_lds) paf_line((const unsigned char*)(s_text + (ls - a0)), l, fs, r); // LDS byte reads
 #else
