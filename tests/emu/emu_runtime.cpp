@@ -355,6 +355,29 @@ uint32_t readfirstlane(unsigned op, uint32_t v)
 
 void wave_barrier(unsigned op) { wave_op(0, op, EMU_SITE); }
 
+int ds_bpermute(unsigned op, int addr, int v)
+{
+	Wave *w = wave_op((uint32_t)v, op, EMU_SITE);
+	const unsigned s = ((unsigned)addr >> 2) & 63u;
+	return (w->mask >> s & 1) ? (int)(uint32_t)w->slot[s] : 0;
+}
+
+int ds_permute(unsigned op, int addr, int v)
+{ // every participant deposits (destination, value); a lane collects what was sent to it
+	Wave *w = wave_op((uint64_t)(((unsigned)addr >> 2) & 63u) << 32 | (uint32_t)v, op, EMU_SITE);
+	const unsigned me = t_fiber->lane;
+	int r = 0;
+	for (unsigned l = 0; l < 64; ++l)
+		if ((w->mask >> l & 1) && (unsigned)(w->slot[l] >> 32) == me) r = (int)(uint32_t)w->slot[l];
+	return r;
+}
+
+int readlane(unsigned op, int v, int lane)
+{
+	Wave *w = wave_op((uint32_t)v, op, EMU_SITE);
+	return (int)(uint32_t)w->slot[(unsigned)lane & 63u];
+}
+
 static inline int dpp_resolve(Wave *w, unsigned lane, int old, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
 {
 	const unsigned row = lane >> 4, col = lane & 15, bank = col >> 2;

@@ -38,6 +38,16 @@ __global__ void k_dpp(uint32_t *out)
 	out[t * 8 + 7] = (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x111, 0xf, 0xf, true); // row_shr:1, 0 at the row start
 }
 
+__global__ void k_perm(uint32_t *out)
+{
+	unsigned lane = threadIdx.x & 63;
+	int v = (int)(lane * 7 + 3);
+	out[lane * 4 + 0] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 5) & 63) << 2), v);
+	out[lane * 4 + 1] = (uint32_t)__builtin_amdgcn_ds_permute((int)(((lane * 3) & 63) << 2), v); // lane*3 mod 64 is a bijection
+	out[lane * 4 + 2] = (uint32_t)__builtin_amdgcn_readlane(v, 17);
+	out[lane * 4 + 3] = __builtin_amdgcn_mbcnt_hi(0xF0F0F0F0u, __builtin_amdgcn_mbcnt_lo(0x0F0F0F0Fu, 0));
+}
+
 // block reduction through LDS with barriers; threads beyond n leave early; one atomic per block
 __global__ void k_reduce(const uint32_t *in, size_t n, unsigned long long *total, uint32_t *maxv)
 {
@@ -132,6 +142,18 @@ int main()
 		for (unsigned l = 0; l < 64; ++l) {
 			EXPECT(d[64 + l] == total);
 			if (!(l & 1)) EXPECT(d[128 + l] == 32);
+		}
+	}
+	{
+		hipLaunchKernelGGL(k_perm, dim3(1), dim3(64), 0, nullptr, d);
+		for (unsigned l = 0; l < 64; ++l) {
+			EXPECT(d[l * 4 + 0] == ((l + 5) & 63) * 7 + 3);
+			unsigned src = 0;
+			for (unsigned m = 0; m < 64; ++m) if (((m * 3) & 63) == l) src = m;
+			EXPECT(d[l * 4 + 1] == src * 7 + 3);
+			EXPECT(d[l * 4 + 2] == 17 * 7 + 3);
+			const uint64_t mask = (uint64_t)0xF0F0F0F0u << 32 | 0x0F0F0F0Fu;
+			EXPECT(d[l * 4 + 3] == (uint32_t)__builtin_popcountll(mask & ((1ull << l) - 1ull)));
 		}
 	}
 	hipFree(d);

@@ -149,6 +149,11 @@ template <typename T> __attribute__((noinline)) T shfl_down(unsigned op, T v, un
 	if (s >= base + (unsigned)width) return v;
 	return (w->mask >> s & 1) ? from_bits<T>(w->slot[s]) : T(0);
 }
+// ds_bpermute_b32: lane i reads the value of lane (addr_i >> 2) & 63; ds_permute_b32: lane i sends its value to lane (addr_i >> 2) & 63 (the highest
+// sending lane wins, a lane nobody sends to reads 0); v_readlane_b32: the value of one lane for all
+__attribute__((noinline)) int ds_bpermute(unsigned op, int addr, int v);
+__attribute__((noinline)) int ds_permute(unsigned op, int addr, int v);
+__attribute__((noinline)) int readlane(unsigned op, int v, int lane);
 __attribute__((noinline)) uint64_t ballot(unsigned op, int p);
 __attribute__((noinline)) uint32_t readfirstlane(unsigned op, uint32_t v);
 __attribute__((noinline)) void wave_barrier(unsigned op);
@@ -175,6 +180,19 @@ struct BufRsrc { char *base; uint32_t num_records; };
 #define __threadfence_block() ((void)0)
 #define __builtin_amdgcn_mov_dpp(src, ctrl, rm, bm, bc) emu::mov_dpp(EMU_OP, (int)(src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu::update_dpp(EMU_OP, (int)(old), (int)(src), (ctrl), (rm), (bm), (bc))
+#define __builtin_amdgcn_ds_bpermute(addr, v) emu::ds_bpermute(EMU_OP, (int)(addr), (int)(v))
+#define __builtin_amdgcn_ds_permute(addr, v) emu::ds_permute(EMU_OP, (int)(addr), (int)(v))
+#define __builtin_amdgcn_readlane(v, l) emu::readlane(EMU_OP, (int)(v), (int)(l))
+#define __builtin_amdgcn_ballot_w64(p) emu::ballot(EMU_OP, (p) ? 1 : 0)
+#define __builtin_amdgcn_mbcnt_lo(m, c) ((unsigned)(c) + (unsigned)__builtin_popcount((unsigned)(m) & (unsigned)((emu::t_fiber->lane >= 32 ? ~0ull : (1ull << emu::t_fiber->lane) - 1ull))))
+#define __builtin_amdgcn_mbcnt_hi(m, c) ((unsigned)(c) + (unsigned)__builtin_popcount((unsigned)(m) & (unsigned)(emu::t_fiber->lane < 32 ? 0ull : (1ull << (emu::t_fiber->lane - 32)) - 1ull)))
+#define __builtin_amdgcn_alignbyte(hi, lo, sh) ((uint32_t)((((uint64_t)(uint32_t)(hi) << 32) | (uint32_t)(lo)) >> (8u * ((unsigned)(sh) & 3u))))
+#define __builtin_amdgcn_alignbit(hi, lo, sh) ((uint32_t)((((uint64_t)(uint32_t)(hi) << 32) | (uint32_t)(lo)) >> ((unsigned)(sh) & 31u)))
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_s_setprio(n) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(n) ((void)0)
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) ((void)(*(p) = (v)))
 #define __builtin_amdgcn_readfirstlane(v) emu::readfirstlane(EMU_OP, (uint32_t)(v))
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier(EMU_OP)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
