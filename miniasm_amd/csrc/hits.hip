@@ -400,10 +400,7 @@ __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q,
 	int net = 0;
 #pragma unroll
 	for (int r = 0; r < ITEMS; ++r) if (x[r] != EV_PAD) net += (x[r] & 1) ? -1 : 1;
-	int incl = net;
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(incl, o, 64); if (lane >= (unsigned)o) incl += y; }
-	int dp = incl - net;
+	int dp = wv_scan_incl_i32(net, lane) - net;
 	// walk the lane's events: runs opened and closed here are resolved at once; at most one run per lane was
 	// opened in an earlier lane (its closing event is the lane's first down before any local up)
 	const uint32_t NONE = 0xffffffffu;
@@ -424,20 +421,17 @@ __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q,
 			} else pend_pos = e >> 1, pend_idx = lane * ITEMS + r;
 		}
 	}
-	uint32_t carry = last_up; // start of the run that is open at the end of each lane: "last defined" scan
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(carry, o, 64); if (lane >= (unsigned)o && carry == NONE) carry = y; }
-	uint32_t before = __shfl_up(carry, 1, 64);
-	if (lane == 0) before = NONE;
+	const uint32_t carry = wv_scan_last_u32(last_up, NONE, lane); // start of the run that is open at the end of each lane: "last defined" scan
+	const uint32_t before = wv_prev_lane_u32(carry, NONE, lane);
 	if (pend_pos != NONE && before != NONE) {
 		uint64_t cand = (uint64_t)(pend_pos - before) << 32 | (0xffffffffu - pend_idx);
 		if (cand > best) best = cand, best_s = before;
 	}
-	uint64_t gbest = wv_max_u64(best);
+	uint64_t gbest = wv_max_u64_full(best);
 	uint32_t len = (uint32_t)(gbest >> 32);
 	if (len == 0) { if (lane == 0) sub[q] = make_uint2(DEAD, 0); return 0; } // strict '>' against an empty best (hit.c:142,146)
 	uint64_t own = wv_ballot(best == gbest);
-	uint32_t s = __shfl(best_s, __ffsll((long long)own) - 1, 64);
+	uint32_t s = wv_read_lane_u32(best_s, __ffsll((long long)own) - 1);
 	if (lane == 0) sub[q] = make_uint2((s - (uint32_t)end_clip) & 0x7fffffffu, s + len + (uint32_t)end_clip);
 	return 1;
 }

@@ -201,6 +201,66 @@ __device__ __forceinline__ uint64_t wv_sum_u64(uint64_t x)
 	}
 	return x;
 }
+// ---- wave64 scans for a FULL wave (all 64 lanes active), as the coverage sweep needs them.
+// EXP_DPP_SCAN: DPP row shifts + the gfx9 row broadcasts (row_bcast:15 / :31, the sequence LLVM's atomic optimizer emits for wave64) -- one
+// VALU instruction per step, nothing through the LDS crossbar.  Default (the form every number in profiles/ was measured with): __shfl_up,
+// i.e. one ds_bpermute round trip per step.  The coverage sweep of one read chains 18 such steps; to be measured.
+#ifdef EXP_DPP_SCAN
+#define WV_DPP(old, x, ctrl, rm) __builtin_amdgcn_update_dpp((int)(old), (int)(x), (ctrl), (rm), 0xf, false)
+__device__ __forceinline__ int wv_scan_incl_i32(int x, unsigned lane)
+{
+	(void)lane;
+	x += WV_DPP(0, x, 0x111, 0xf); x += WV_DPP(0, x, 0x112, 0xf); x += WV_DPP(0, x, 0x114, 0xf); x += WV_DPP(0, x, 0x118, 0xf); // inside the rows
+	x += WV_DPP(0, x, 0x142, 0xa); // row_bcast:15 -> rows 1 and 3
+	x += WV_DPP(0, x, 0x143, 0xc); // row_bcast:31 -> rows 2 and 3
+	return x;
+}
+// inclusive scan of "the last value that is not `none`"
+__device__ __forceinline__ uint32_t wv_scan_last_u32(uint32_t x, uint32_t none, unsigned lane)
+{
+	(void)lane;
+	uint32_t t;
+	t = (uint32_t)WV_DPP(none, x, 0x111, 0xf); x = x == none ? t : x;
+	t = (uint32_t)WV_DPP(none, x, 0x112, 0xf); x = x == none ? t : x;
+	t = (uint32_t)WV_DPP(none, x, 0x114, 0xf); x = x == none ? t : x;
+	t = (uint32_t)WV_DPP(none, x, 0x118, 0xf); x = x == none ? t : x;
+	t = (uint32_t)WV_DPP(none, x, 0x142, 0xa); x = x == none ? t : x;
+	t = (uint32_t)WV_DPP(none, x, 0x143, 0xc); x = x == none ? t : x;
+	return x;
+}
+// value of the lane below (lane 0: fill)
+__device__ __forceinline__ uint32_t wv_prev_lane_u32(uint32_t x, uint32_t fill, unsigned lane) { (void)lane; return (uint32_t)WV_DPP(fill, x, 0x138, 0xf); } // wave_shr:1
+// maximum over the wave, the same value in every lane: an inclusive max-scan, then lane 63 read back through the scalar unit
+#define WV_MAX64_STEP(ctrl, rm) do { \
+		const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, (ctrl), (rm), 0xf, false); \
+		const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), (ctrl), (rm), 0xf, false); \
+		const uint64_t y_ = (uint64_t)hi_ << 32 | lo_; \
+		x = y_ > x ? y_ : x; } while (0)
+__device__ __forceinline__ uint64_t wv_max_u64_full(uint64_t x)
+{
+	WV_MAX64_STEP(0x111, 0xf); WV_MAX64_STEP(0x112, 0xf); WV_MAX64_STEP(0x114, 0xf); WV_MAX64_STEP(0x118, 0xf);
+	WV_MAX64_STEP(0x142, 0xa); WV_MAX64_STEP(0x143, 0xc);
+	return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 63) << 32 | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63);
+}
+#undef WV_MAX64_STEP
+// the value one lane holds, for all (src is the same in every lane)
+__device__ __forceinline__ uint32_t wv_read_lane_u32(uint32_t x, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)x, src); }
+#undef WV_DPP
+#else
+__device__ __forceinline__ int wv_scan_incl_i32(int x, unsigned lane)
+{
+	for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= (unsigned)o) x += y; }
+	return x;
+}
+__device__ __forceinline__ uint32_t wv_scan_last_u32(uint32_t x, uint32_t none, unsigned lane)
+{
+	for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= (unsigned)o && x == none) x = y; }
+	return x;
+}
+__device__ __forceinline__ uint32_t wv_prev_lane_u32(uint32_t x, uint32_t fill, unsigned lane) { uint32_t y = __shfl_up(x, 1, 64); return lane == 0 ? fill : y; }
+__device__ __forceinline__ uint64_t wv_max_u64_full(uint64_t x) { return wv_max_u64(x); }
+__device__ __forceinline__ uint32_t wv_read_lane_u32(uint32_t x, int src) { return __shfl(x, src, 64); }
+#endif
 // one atomicAdd per wave of the number of lanes with p set
 __device__ __forceinline__ void wv_count_add(unsigned long long *ctr, int p)
 {

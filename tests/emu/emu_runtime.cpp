@@ -393,8 +393,8 @@ static inline int dpp_resolve(Wave *w, unsigned lane, int old, int ctrl, int row
 	else if (ctrl == 0x13c) s = (int)((lane + 63) & 63);             // wave_ror:1
 	else if (ctrl == 0x140) s = (int)((lane & ~15u) | (15 - col));   // row_mirror
 	else if (ctrl == 0x141) s = (int)((lane & ~7u) | (7 - (lane & 7))); // row_half_mirror
-	else if (ctrl == 0x142) { if (col != 0 || row == 0) return old; s = (int)(lane - 1); }          // row_bcast:15 (lane 15 of a row -> the next row)
-	else if (ctrl == 0x143) { if (lane < 32) return old; s = 31; }                                  // row_bcast:31
+	else if (ctrl == 0x142) s = row == 0 ? -1 : (int)(row * 16 - 1);                                  // row_bcast:15: every lane of a row reads lane 15 of the row before it
+	else if (ctrl == 0x143) s = lane < 32 ? -1 : 31;                                                  // row_bcast:31: rows 2 and 3 read lane 31
 	else fatal("DPP control 0x%x is not modelled", ctrl);
 	if (s < 0 || !(w->mask >> s & 1)) return bound_ctrl ? 0 : old;
 	return (int)(uint32_t)w->slot[s];

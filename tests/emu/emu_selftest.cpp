@@ -48,6 +48,22 @@ __global__ void k_perm(uint32_t *out)
 	out[lane * 4 + 3] = __builtin_amdgcn_mbcnt_hi(0xF0F0F0F0u, __builtin_amdgcn_mbcnt_lo(0x0F0F0F0Fu, 0));
 }
 
+// the gfx9 wave64 inclusive scan out of DPP row shifts and row broadcasts (what LLVM's atomic optimizer emits), a wave_shr:1 and a readlane
+__global__ void k_dpp_scan(int *out)
+{
+	unsigned lane = threadIdx.x & 63;
+	int x = (int)(lane * lane % 11) - 3;
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+	out[lane * 3 + 0] = x;
+	out[lane * 3 + 1] = __builtin_amdgcn_update_dpp(-7, x, 0x138, 0xf, 0xf, false);
+	out[lane * 3 + 2] = __builtin_amdgcn_readlane(x, 63);
+}
+
 // block reduction through LDS with barriers; threads beyond n leave early; one atomic per block
 __global__ void k_reduce(const uint32_t *in, size_t n, unsigned long long *total, uint32_t *maxv)
 {
@@ -155,6 +171,18 @@ int main()
 			const uint64_t mask = (uint64_t)0xF0F0F0F0u << 32 | 0x0F0F0F0Fu;
 			EXPECT(d[l * 4 + 3] == (uint32_t)__builtin_popcountll(mask & ((1ull << l) - 1ull)));
 		}
+	}
+	{
+		hipLaunchKernelGGL(k_dpp_scan, dim3(1), dim3(64), 0, nullptr, (int*)d);
+		const int *r = (const int*)d;
+		int run = 0, prev = -7;
+		for (unsigned l = 0; l < 64; ++l) {
+			run += (int)(l * l % 11) - 3;
+			EXPECT(r[l * 3 + 0] == run);
+			EXPECT(r[l * 3 + 1] == prev);
+			prev = run;
+		}
+		for (unsigned l = 0; l < 64; ++l) EXPECT(r[l * 3 + 2] == run);
 	}
 	hipFree(d);
 	uint64_t a, b, c;

@@ -62,7 +62,8 @@ tailctx)
   done; done ;;
 expstore)
   # EXP_BOUNDED_STORE: masked column stores of the first coverage pass through a buffer descriptor instead of the spare slots
-  bash tools/variants.sh build base:"" bounded:"-DEXP_BOUNDED_STORE" | tail -4; bash tools/variants.sh run base bounded ;;
+  # EXP_DPP_SCAN: the coverage sweep's three wave scans out of DPP row shifts / row broadcasts instead of ds_bpermute round trips
+  bash tools/variants.sh build base:"" bounded:"-DEXP_BOUNDED_STORE" dppscan:"-DEXP_DPP_SCAN" both:"-DEXP_BOUNDED_STORE -DEXP_DPP_SCAN" | tail -6; bash tools/variants.sh run base bounded dppscan both ;;
 expparse)
   # the parse kernel with byte-wise LDS reads (the round-2 measured form) against the register-window reader: parse kernel times of the ingest bench
   bash tools/variants.sh build base:"" bytewise:"-DEXP_PARSE_BYTEWISE" | tail -4
