@@ -5,8 +5,9 @@ import os
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-EMU_LIB = os.path.join(HERE, "_build", "libminiasm_amd_emu.so")
-EMU_CLI = os.path.join(HERE, "_build", "miniasm")
+BUILD = os.environ.get("MA_EMU_BUILD", "_build")  # another build directory of tests/emu/Makefile (B=..., EXTRA=-DEXP_...): kernel variants
+EMU_LIB = os.path.join(HERE, BUILD, "libminiasm_amd_emu.so")
+EMU_CLI = os.path.join(HERE, BUILD, "miniasm")
 
 os.environ["MINIASM_AMD_LIB"] = EMU_LIB
 os.environ.setdefault("MA_COMM", "shm")
@@ -20,4 +21,4 @@ ma.IS_EMU = True
 sys.path.insert(0, os.path.join(os.path.dirname(HERE)))
 import refapi as R  # noqa: E402
 
-R.DROPIN_BIN = os.path.join(HERE, "_build", "miniasm_dropin")
+R.DROPIN_BIN = os.path.join(HERE, BUILD, "miniasm_dropin")

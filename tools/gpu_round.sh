@@ -63,7 +63,9 @@ tailctx)
 expstore)
   # EXP_BOUNDED_STORE: masked column stores of the first coverage pass through a buffer descriptor instead of the spare slots
   # EXP_DPP_SCAN: the coverage sweep's three wave scans out of DPP row shifts / row broadcasts instead of ds_bpermute round trips
-  bash tools/variants.sh build base:"" bounded:"-DEXP_BOUNDED_STORE" dppscan:"-DEXP_DPP_SCAN" both:"-DEXP_BOUNDED_STORE -DEXP_DPP_SCAN" | tail -6; bash tools/variants.sh run base bounded dppscan both ;;
+  # EXP_RS_ATOMIC_RANK: the radix scatter's per-item digit counts as 16 pipelined returning LDS atomics instead of 16 read / sync / write rounds
+  bash tools/variants.sh build base:"" bounded:"-DEXP_BOUNDED_STORE" dppscan:"-DEXP_DPP_SCAN" rsatomic:"-DEXP_RS_ATOMIC_RANK" all3:"-DEXP_BOUNDED_STORE -DEXP_DPP_SCAN -DEXP_RS_ATOMIC_RANK" | tail -8
+  bash tools/variants.sh run base bounded dppscan rsatomic all3 ;;
 expparse)
   # the parse kernel with byte-wise LDS reads (the round-2 measured form) against the register-window reader: parse kernel times of the ingest bench
   bash tools/variants.sh build base:"" bytewise:"-DEXP_PARSE_BYTEWISE" | tail -4
