@@ -168,6 +168,12 @@ static uint32_t sub_chunk(uint32_t R) { uint64_t waves = 4ull * grid_for(R, 4, M
 
 #define MA_CE(a, b) do { uint32_t lo_ = (a) < (b) ? (a) : (b), hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
 
+// what a lane keeps of a compare-exchange with its partner's value y: the smaller one in the lower lane, the larger one in the upper
+#ifdef EXP_CE_MINMAX // min / max can take the DPP operand themselves and the select reads the lane mask from scalar registers: no compare + xor on vcc
+#define MA_KEEP(x, y, lower) ((lower) ? ((x) < (y) ? (x) : (y)) : ((x) < (y) ? (y) : (x)))
+#else
+#define MA_KEEP(x, y, lower) ((((x) < (y)) != (lower)) ? (y) : (x))
+#endif
 // Value of lane (lane ^ M) for a compile-time M.  Exchanges inside a row of 16 lanes are DPP modifiers of a VALU move
 // (quad_perm, row_half_mirror, row_mirror, row_ror, banked row_shl/shr): no LDS crossbar round trip, no s_waitcnt.
 // Only the exchanges across rows (16, 31, 63) go through ds_bpermute.
@@ -210,7 +216,7 @@ __device__ __forceinline__ void wave_sort_regs(uint32_t (&x)[ITEMS], unsigned la
 #pragma unroll
 			for (int r = 0; r < ITEMS; ++r) y[r] = lane_xor(x[ITEMS - 1 - r], L - 1);
 #pragma unroll
-			for (int r = 0; r < ITEMS; ++r) x[r] = ((x[r] < y[r]) != lower) ? y[r] : x[r]; // lower half keeps the min, upper the max
+			for (int r = 0; r < ITEMS; ++r) x[r] = MA_KEEP(x[r], y[r], lower); // lower half keeps the min, upper the max
 		}
 #pragma unroll
 		for (int m = L >> 2; m > 0; m >>= 1) { // half cleaners across lanes
@@ -218,7 +224,7 @@ __device__ __forceinline__ void wave_sort_regs(uint32_t (&x)[ITEMS], unsigned la
 #pragma unroll
 			for (int r = 0; r < ITEMS; ++r) {
 				uint32_t y = lane_xor(x[r], m);
-				x[r] = ((x[r] < y) != lower) ? y : x[r];
+				x[r] = MA_KEEP(x[r], y, lower);
 			}
 		}
 #pragma unroll

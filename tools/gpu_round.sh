@@ -62,17 +62,18 @@ tailctx)
   done; done ;;
 expbuild)
   # run this HERE before the GPU visit (hipcc cross-compiles): the experiment libraries travel with the snapshot
-  bash tools/variants.sh build base:"" bounded:"-DEXP_BOUNDED_STORE" dppscan:"-DEXP_DPP_SCAN" rsatomic:"-DEXP_RS_ATOMIC_RANK" \
+  bash tools/variants.sh build base:"" bounded:"-DEXP_BOUNDED_STORE" dppscan:"-DEXP_DPP_SCAN" rsatomic:"-DEXP_RS_ATOMIC_RANK" minmax:"-DEXP_CE_MINMAX" \
        all3:"-DEXP_BOUNDED_STORE -DEXP_DPP_SCAN -DEXP_RS_ATOMIC_RANK" bytewise:"-DEXP_PARSE_BYTEWISE" | tail -8 ;;
 expstore)
   # EXP_BOUNDED_STORE: masked column stores of the first coverage pass through a buffer descriptor instead of the spare slots
   # EXP_DPP_SCAN: the coverage sweep's three wave scans out of DPP row shifts / row broadcasts instead of ds_bpermute round trips
   # EXP_RS_ATOMIC_RANK: the radix scatter's per-item digit counts as 16 pipelined returning LDS atomics instead of 16 read / sync / write rounds
+  # EXP_CE_MINMAX: the sort's compare-exchange as v_min_u32_dpp / v_max_u32_dpp + select instead of mov_dpp + compare + xor on vcc + select (-9 % instructions, +3 % VALU)
   [ -f build/variants/all3/libminiasm_amd.so ] || bash tools/gpu_round.sh expbuild
-  for v in dppscan rsatomic bounded; do # parity first: a variant that is not bit-exact is not worth timing
+  for v in dppscan rsatomic bounded minmax; do # parity first: a variant that is not bit-exact is not worth timing
     MINIASM_AMD_LIB=$PWD/build/variants/$v/libminiasm_amd.so timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line -p no:cacheprovider -x > gpurun_out/tests_var_$v.log 2>&1; echo "[$v] parity rc=$?"
   done
-  bash tools/variants.sh run base bounded dppscan rsatomic all3 ;;
+  bash tools/variants.sh run base bounded dppscan rsatomic minmax all3 ;;
 expparse)
   # the parse kernel with byte-wise LDS reads (the round-2 measured form) against the register-window reader
   [ -f build/variants/bytewise/libminiasm_amd.so ] || bash tools/gpu_round.sh expbuild
