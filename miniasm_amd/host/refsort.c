@@ -132,7 +132,7 @@ static uint64_t sweep_run(void *(*worker)(void*), const void *a, size_t n, int s
 #define RS_CMPKEY(e, cfg) ((e) >> (cfg)->bi)
 /* digit at `shift` of hi << 32 | lo: the high word's digits sit above the low word's bl bits; a digit of the low word may be cut off by bl */
 #define RS_LEVEL(cfg, shift, sh, m) do { \
-		if ((shift) >= 32) (sh) = (cfg)->bl + (cfg)->bi + ((shift) - 32), (m) = 0xffu; \
+		if ((shift) >= 32) { (sh) = (cfg)->bl + (cfg)->bi + ((shift) - 32), (m) = 0xffu; if ((sh) >= 64) (sh) = 0, (m) = 0u; /* a digit above the word's bits is 0 in every key */ } \
 		else (sh) = (cfg)->bi + (shift), (m) = (shift) + 8 <= (cfg)->bl ? 0xffu : (shift) < (cfg)->bl ? (1u << ((cfg)->bl - (shift))) - 1u : 0u; \
 	} while (0)
 #include "refsort_body.h"
