@@ -184,7 +184,7 @@ def main():
                     groups, conf = int(mm.group(1)), int(mm.group(2))
                     key = "no arc ties" if groups == 0 else "arc walk" if conf == 0 else "arc walk + hit walk"
                     paths[key] = paths.get(key, 0) + 1
-            ok = rc0 == rc1 and out0 == out1 and b"runtime error" not in err1  # the last clause: a -fsanitize=undefined build of tests/emu (CXX="g++ -fsanitize=undefined")
+            ok = rc0 == rc1 and out0 == out1 and b"runtime error" not in err1 and b"AddressSanitizer" not in err1  # the last clause: a sanitizer build of tests/emu (make B=_build_san CXX="g++ -fsanitize=address,undefined" CC="gcc -fsanitize=address,undefined")
             if not ok:
                 bad += 1
                 print("case %d MISMATCH [%s]: pafgen %s | miniasm %s | rc %d vs %d, %d vs %d bytes, md5 %s vs %s" % (
