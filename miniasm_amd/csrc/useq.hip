@@ -41,8 +41,11 @@ __global__ __launch_bounds__(256) void k_useq_gather(const unsigned char *__rest
 		const mahip_useq_job_t jb = jobs[j];
 		const unsigned char *src = seq + jb.src_off;
 		unsigned char *dst = arena + jb.dst_off;
-		if (!jb.rev) for (uint32_t i = threadIdx.x; i < jb.len; i += 256) dst[i] = src[i];
-		else for (uint32_t i = threadIdx.x; i < jb.len; i += 256) { const unsigned ch = src[jb.src_len - 1 - i]; dst[i] = ch >= 128 ? 'N' : s_comp[ch]; } // asm.c:283-285
+		// a read file that disagrees with the PAF may hold fewer bases than the unitig takes from the read: the reference then reads outside its
+		// buffer (asm.c:279-285, undefined); here those positions keep the arena's 'N' and nothing outside the batch is touched
+		const uint32_t len = jb.len < jb.src_len ? jb.len : jb.src_len;
+		if (!jb.rev) for (uint32_t i = threadIdx.x; i < len; i += 256) dst[i] = src[i];
+		else for (uint32_t i = threadIdx.x; i < len; i += 256) { const unsigned ch = src[jb.src_len - 1 - i]; dst[i] = ch >= 128 ? 'N' : s_comp[ch]; } // asm.c:283-285
 	}
 }
 

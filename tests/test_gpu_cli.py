@@ -122,6 +122,35 @@ def test_cli_unitig_sequences_with_reads_file(tmpdir_s):
     _same(R.DROPIN_BIN, ["-f", fa], paf, ref_out, ref_log, "dropin -f")
 
 
+def test_cli_reads_file_shorter_than_the_paf_says(tmpdir_s):
+    """-f with a reads file that disagrees with the PAF: a read shorter than the lengths in the PAF makes the reference read outside its buffer
+    (asm.c:279-285, undefined).  Here the missing bases stay 'N' and nothing outside the batch is touched: no fault, same unitig lengths.
+    (-1 -2: without read selection the placement uses the full PAF lengths; with it the reference -- and this library -- assert.)"""
+    import random
+    import subprocess
+    paf = R.pafgen(os.path.join(tmpdir_s, "cli_short.paf"), 600, 20000, 21, ["-L", "uniform"])
+    lens = {}
+    for ln in open(paf, "rb"):
+        f = ln.split(b"\t")
+        lens.setdefault(f[0], int(f[1]))
+        lens.setdefault(f[5], int(f[6]))
+    rnd = random.Random(3)
+    fa = os.path.join(tmpdir_s, "cli_short.fa")
+    with open(fa, "w") as out:
+        for k, (nm, n) in enumerate(lens.items()):
+            n = n - 9 if k % 7 == 0 else n
+            out.write(">%s\n%s\n" % (nm.decode(), "".join(rnd.choice("ACGT") for _ in range(n))))
+    r = subprocess.run([ma.CLI_PATH, "-1", "-2", "-f", fa, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    plain = subprocess.run([ma.CLI_PATH, "-1", "-2", paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    seqs = [l.split(b"\t") for l in r.stdout.split(b"\n") if l.startswith(b"S\t")]
+    want = [l.split(b"\t") for l in plain.stdout.split(b"\n") if l.startswith(b"S\t")]
+    assert len(seqs) == len(want) and len(seqs) > 0
+    for a, b in zip(seqs, want):
+        assert a[1] == b[1] and a[3] == b[3] and len(a[2]) == int(b[3].split(b":")[2])  # same unitig, same LN, a base (or N) for every position
+        assert set(a[2]) <= set(b"ACGTN")
+
+
 TIE_INPUTS = {  # coordinates on a grid (pafgen -q): hundreds of equal (qid,qs) hit keys and (u,len) arc keys
     "grid16": dict(reads=3000, lines=80000, seed=5, extra=["-q", "16", "-L", "uniform", "-d", "0.3", "-x", "0.03"]),
     "grid200": dict(reads=3000, lines=80000, seed=6, extra=["-q", "200", "-L", "uniform", "-d", "0.3", "-x", "0.03"]),

@@ -133,8 +133,43 @@ def mutate_text(rng, data):
     return out
 
 
+def write_reads(rng, paf, path):
+    """a reads file for -f (asm.c:216-290 ma_ug_seq): FASTA or FASTQ, mixed case, N's, wrapped lines, some reads missing, some longer or shorter
+    than the PAF says, reads the PAF never mentions"""
+    lens = {}
+    for ln in open(paf, "rb"):
+        f = ln.rstrip(b"\n").split(b"\t")
+        if len(f) > 6:
+            try:
+                lens.setdefault(f[0], int(f[1]))
+                lens.setdefault(f[5], int(f[6]))
+            except ValueError:
+                pass
+    fq = rng.random() < 0.4
+    wrap = rng.choice([0, 0, 60, 1000])
+    names = list(lens)
+    rng.shuffle(names)
+    with open(path, "wb") as out:
+        for nm in names + [b"not_in_paf"]:
+            if rng.random() < 0.03:
+                continue                                    # a read without a sequence
+            n = lens.get(nm, 500)
+            if rng.random() < 0.05:
+                n = n + rng.choice([3, 50, 1000])            # longer than the PAF says (shorter ones make the reference read outside its buffer: undefined)
+            alphabet = "ACGT" if rng.random() < 0.7 else "ACGTNacgtn"
+            seq = "".join(rng.choice(alphabet) for _ in range(n)).encode()
+            hdr = nm + (b" extra comment" if rng.random() < 0.3 else b"")
+            if fq:
+                out.write(b"@" + hdr + b"\n" + seq + b"\n+\n" + b"I" * n + b"\n")
+            elif wrap:
+                out.write(b">" + hdr + b"\n" + b"\n".join(seq[k:k + wrap] for k in range(0, n, wrap)) + b"\n")
+            else:
+                out.write(b">" + hdr + b"\n" + seq + b"\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--seq", action="store_true", help="unitig sequences: every case also gets a random reads file and runs with -f (ma_ug_seq; the device byte gather)")
     ap.add_argument("--text", action="store_true", help="damage the PAF text (reader / dictionary semantics) instead of varying the options")
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
@@ -165,6 +200,10 @@ def main():
             data = mutate_text(rng, open(paf, "rb").read())
             open(paf, "wb").write(data)
             args = rng.choice([["-p", "paf", "-S2"], ["-p", "paf"], ["-p", "bed"], ["-p", "sg"], [], ["-R", "-p", "paf"], ["-B", "-p", "paf", "-S2"], ["-s", "0", "-m", "0", "-p", "paf", "-S2"]])
+        if a.seq:
+            reads = os.path.join(tmp, "reads.fx")
+            write_reads(rng, paf, reads)
+            args = [x for x in args if x not in ("-p", "sg", "paf", "bed", "ug") and not x.startswith("-S")] + ["-f", reads]
         rc0, out0, err0 = run(REF, args, paf)
         if rc0 < 0:  # the reference itself dies on this combination (e.g. -p bed -S1 dereferences the intervals before they exist): nothing to compare
             skipped += 1
