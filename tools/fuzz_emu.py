@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--ranks", type=int, default=0, help="also run every case as MA_GPUS=N (shared-memory double)")
     ap.add_argument("--ties", action="store_true", help="every input on a coordinate grid (equal sort keys everywhere: tie census, push conflicts, both walks)")
+    ap.add_argument("--env", action="append", default=[], help="KEY=VALUE for the runs of the CPU build (e.g. MA_HOST_PARSE=1, MA_NO_FUSE=1, MA_EXACT_TIES=1, MA_THREADS=3)")
     ap.add_argument("--keep", default=None, help="directory for failing inputs")
     ap.add_argument("--emu", default=None, help="the CPU build's miniasm (default tests/emu/_build/miniasm; point it at a copy to keep fuzzing across rebuilds)")
     a = ap.parse_args()
@@ -213,6 +214,7 @@ def main():
             runs.append(("emu x%d" % a.ranks, {"MA_GPUS": str(a.ranks), "MA_COMM": "shm"}))
         for name, env in runs:
             env = dict(env, MA_PIPE_TIMING="1")  # the [T::ties] line: which tie path the run took
+            env.update(kv.split("=", 1) for kv in a.env)
             rc1, out1, err1 = run(EMU, args, paf, env)
             for ln in err1.decode(errors="replace").splitlines():
                 if ln.startswith("[T::ties]") and "arc tie groups" in ln:
