@@ -182,3 +182,79 @@ def test_cli_falls_back_to_host_reader_when_text_stage_does_not_fit(tmpdir_s, mo
     r = subprocess.run([R.DROPIN_BIN, "-p", "ug", paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE) if R.have_ref() else None
     if r is not None:
         assert r.returncode == 0 and r.stdout == base and b"using the host reader" in r.stderr
+
+
+def _dev_buffer(nbytes):
+    """device memory for the C ABI: a torch tensor on the GPU; on the CPU build of the kernels (tests/emu) device pointers are host pointers"""
+    if getattr(ma, "IS_EMU", False):
+        a = np.zeros(max(nbytes, 1), dtype=np.uint8)
+        return a, a.ctypes.data
+    import torch
+    t = torch.empty(max(nbytes, 1), dtype=torch.uint8, device="cuda")
+    return t, t.data_ptr()
+
+
+@pytest.mark.parametrize("case", ["lognormal", "noisy"])
+def test_bench_shaped_steps_from_resident_records(case, tmpdir_s):
+    """the sequence bench.py times, through the same C entry points: file -> HBM, device parse, the unsorted records carved out by read range
+    (mahip_hits_raw_extract) into caller-owned device memory, then per step adopt + hint + head + tail; every step's GFA equals the CLI's and the
+    reference's; the ranges of a 3-way split are disjoint, in input order, and add up to the whole"""
+    L = ma.lib()
+    vp = C.c_void_p
+    extra = {"lognormal": [], "noisy": ["-L", "uniform", "-d", "0.35", "-x", "0.03"]}[case]
+    paf = R.pafgen(os.path.join(tmpdir_s, "bs_%s.paf" % case), 3000, 90000, 61, extra)
+    opt = ma.default_opt()
+    L.ma_paf_load_file.argtypes = [vp, C.c_char_p]
+    L.ma_hit_ingest_loaded.argtypes = [vp, C.c_int, C.c_int, C.POINTER(ma.Sdict), C.POINTER(C.c_size_t), C.c_int, C.c_int]
+    L.mahip_hits_raw_extract.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_size_t)]
+    L.mahip_paf_max_qs.restype = C.c_uint32
+    L.mahip_paf_max_qs.argtypes = [vp]
+    L.ma_pipeline_head.argtypes = [vp, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint32 * 4)]
+    L.ma_pipeline_tail_mem.argtypes = [vp, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.POINTER(C.c_uint32 * 4), C.POINTER(vp), C.POINTER(C.c_size_t)]
+    ctx = ma.Ctx(0)
+    assert L.ma_paf_load_file(ctx.h, paf.encode()) == 0
+    d = L.sd_init()
+    nh = C.c_size_t(0)
+    assert L.ma_hit_ingest_loaded(ctx.h, opt.min_span, opt.min_match, d, C.byref(nh), 1, 1) == 0
+    n_seq, max_qs = d.contents.n_seq, L.mahip_paf_max_qs(ctx.h)
+    host = ma.Ingest(paf, opt)  # the host reader's records: the same records in the same order
+    assert nh.value == host.n and n_seq == host.n_seq
+
+    def extract(q0, q1):
+        n = C.c_size_t(0)
+        ma._chk(L.mahip_hits_raw_extract(ctx.h, q0, q1, None, C.byref(n)), "raw_extract")
+        keep, ptr = _dev_buffer(n.value * 32)
+        ma._chk(L.mahip_hits_raw_extract(ctx.h, q0, q1, vp(ptr), C.byref(n)), "raw_extract")
+        L.mahip_sync(ctx.h)
+        out = np.zeros(n.value, dtype=ma.HIT_DT)
+        if n.value:
+            ma._chk(L.mahip_memcpy_d2h(ctx.h, out.ctypes.data, vp(ptr), n.value * 32), "d2h")
+        return keep, ptr, out
+
+    keep_all, ptr_all, all_recs = extract(0, 0xffffffff)
+    assert all_recs.tobytes() == host.hits.tobytes()
+    per = (n_seq + 2) // 3
+    parts = [extract(min(r * per, n_seq), min((r + 1) * per, n_seq))[2] for r in range(3)]
+    assert sum(len(p) for p in parts) == len(all_recs)
+    qid = (host.hits["qns"] >> np.uint64(32)).astype(np.int64)
+    for r, p in enumerate(parts):
+        assert p.tobytes() == host.hits[(qid >= r * per) & (qid < (r + 1) * per)].tobytes()
+    want, _ = R.run_cli(ma.CLI_PATH, [], paf)
+    for step in range(3):
+        ma._chk(L.mahip_hits_adopt(ctx.h, vp(ptr_all), len(all_recs), n_seq), "adopt")
+        L.mahip_set_hints(ctx.h, max_qs)
+        st = (C.c_uint32 * 4)(0, 0, 0, 0)
+        assert L.ma_pipeline_head(ctx.h, C.byref(opt), d, b"ug", 100, 0, C.byref(st)) == 0
+        buf, ln = vp(0), C.c_size_t(0)
+        assert L.ma_pipeline_tail_mem(ctx.h, C.byref(opt), d, b"ug", 100, C.byref(st), C.byref(buf), C.byref(ln)) == 0
+        got = C.string_at(buf, ln.value)
+        L.free_buf(buf)
+        assert got == want, "step %d differs from the CLI" % step
+    if R.have_ref():
+        ref_sg, _ = R.run_cli(R.REF_BIN, ["-p", "sg", "-S5"], paf)
+        if R.arc_tie_groups(ref_sg) == 0:
+            assert want == R.run_cli(R.REF_BIN, [], paf)[0]
+    L.sd_destroy(d)
+    host.close()
+    ctx.close()
+    del keep_all
