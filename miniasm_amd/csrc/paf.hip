@@ -254,7 +254,7 @@ __device__ __forceinline__ void paf_line(PTR p, uint32_t l, FsCols fs /* LDS, 12
 __global__ __launch_bounds__(256) void k_paf_parse(const unsigned char *__restrict__ text, size_t n, const uint64_t *__restrict__ lstart, uint32_t L,
                                                     int min_span, int min_match, PafCols o, uint32_t *__restrict__ f_hasbl, unsigned long long *__restrict__ ctr, uint32_t lds_bytes)
 {
-	extern __shared__ unsigned char s_text[]; // lds_bytes (+ slack): sized by the host from the mean line length, so that several blocks fit a CU
+	extern __shared__ __attribute__((aligned(16))) unsigned char s_text[]; // lds_bytes (+ slack); read and written 16 / 8 bytes at a time: sized by the host from the mean line length, so that several blocks fit a CU
 	__shared__ uint32_t s_fs[256 * 12];
 	const uint32_t i0 = blockIdx.x * 256u, i1 = i0 + 256u < L ? i0 + 256u : L;
 	const uint64_t b0 = lstart[i0], e1 = lstart[i1] - 1; // bytes of these lines: [b0, e1)
