@@ -169,3 +169,72 @@ def test_streaming_with_the_tail_on_a_second_context_and_thread(tmpdir_s):
     for ing in ings:
         ing.close()
     c1.close(); c2.close()
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+def test_circular_unitigs_on_the_device(tmpdir_s):
+    """rings of reads: a chain without a head is a cycle; the device cuts it in front of its smallest vertex (where the reference's sweep enters it,
+    asm.c:132-172) and ranks again.  Hand-made graphs through the per-symbol ma_ug_gen: small rings with mixed strands, a ring next to linear
+    pieces and isolated reads, a 3000-read ring (every pointer-jumping round sees the cycle), 40 rings of different sizes; unitigs (circular flag,
+    members, lengths, ends), unitig arcs and the GFA text must equal the reference's."""
+    LR, LP = R.ref(), product_graph_api()
+    LR.ma_ug_gen.restype = C.c_void_p
+    LR.ma_ug_gen.argtypes = [C.POINTER(ma.Asg)]
+    LR.ma_ug_print.argtypes = [C.c_void_p, C.POINTER(ma.Sdict), C.c_void_p, C.c_void_p]
+    LR.ma_ug_destroy.argtypes = [C.c_void_p]
+    for L in (LR, LP):
+        L.sd_init.restype = C.POINTER(ma.Sdict)
+        L.sd_put.restype = C.c_int32
+        L.sd_put.argtypes = [C.POINTER(ma.Sdict), C.c_char_p, C.c_uint32]
+
+    def build(n_seq, arcs_uv):
+        rows = []
+        for (u, v, ln, ol) in arcs_uv:
+            rows.append((u, v, ln, ol))
+            rows.append((v ^ 1, u ^ 1, ln + 7, ol))
+        a = np.zeros(len(rows), dtype=ma.ARC_DT)
+        for i, (u, v, ln, ol) in enumerate(rows):
+            a[i] = ((u << 32) | ln, v, ol)
+        a = a[np.argsort(a["ul"], kind="stable")]
+        seq = np.array([5000 + 13 * (i % 97) for i in range(n_seq)], dtype="<u4")
+        idx = np.zeros(2 * n_seq, dtype="<u8")
+        R.orc().orc_arc_index(n_seq, len(a), a.ctypes.data, idx.ctypes.data)
+        g = ma.Asg()
+        for field, arr in (("arc", a), ("seq", seq), ("idx", idx)):
+            p = libc.malloc(max(arr.nbytes, 16))
+            C.memmove(p, arr.ctypes.data, arr.nbytes)
+            setattr(g, field, p)
+        g.m_arc, g.n_arc_srt, g.m_seq, g.n_seq_symm = max(len(a), 1), len(a) | 1 << 31, max(n_seq, 1), n_seq | 1 << 31
+        return g
+
+    def ring(first, n, mixed=False):
+        out = []
+        for i in range(n):
+            u = 2 * (first + i) + ((i % 2) if mixed else 0)
+            v = 2 * (first + (i + 1) % n) + (((i + 1) % 2) if mixed else 0)
+            out.append((u, v, 900 + i % 50, 3000))
+        return out
+
+    cases = [(5, ring(0, 5)), (9, ring(3, 4, True) + [(0, 2, 700, 2000), (2, 5, 800, 2100)]), (3000, ring(0, 3000)), (2, ring(0, 2))]
+    many, first = [], 0
+    for k in range(40):
+        many += ring(first, 3 + k, k % 3 == 0 and (3 + k) % 2 == 0)
+        first += 3 + k + (k % 2)  # now and then a read without arcs in between
+    cases.append((first + 2, many))
+    for n_seq, arcs_uv in cases:
+        outs = []
+        for tag, L in (("ref", LR), ("mine", LP)):
+            g = build(n_seq, arcs_uv)
+            d = L.sd_init()
+            for i in range(n_seq):
+                L.sd_put(d, b"r%d" % i, 0)
+            ug = L.ma_ug_gen(C.byref(g))
+            path = os.path.join(tmpdir_s, "ring_%s.gfa" % tag)
+            fp = libc.fopen(path.encode(), b"w")
+            L.ma_ug_print(ug, d, None, fp)
+            libc.fclose(fp)
+            outs.append(open(path, "rb").read())
+            L.ma_ug_destroy(ug)
+        assert outs[0] == outs[1], "GFA of a ring graph differs (%d reads)" % n_seq
+        import re
+        assert re.search(rb"^S\tutg\d+c\t", outs[0], re.M), "the case should contain a circular unitig"
