@@ -238,3 +238,55 @@ def test_circular_unitigs_on_the_device(tmpdir_s):
         assert outs[0] == outs[1], "GFA of a ring graph differs (%d reads)" % n_seq
         import re
         assert re.search(rb"^S\tutg\d+c\t", outs[0], re.M), "the case should contain a circular unitig"
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+def test_reduction_on_handmade_graphs_deleted_reads_and_big_multi_arc_vertices():
+    """asg_arc_del_trans through the per-symbol ABI on graphs the synthetic inputs do not produce: a read that is flagged deleted but still has
+    arcs (asg.c:158-161: all its arcs go), and vertices with more than 512 arcs, several of them to the same target (the block tier's literal
+    replay of asg.c:181-184, where only the first arc to a reduced target is deleted).  Random transitive structure; graph after the call
+    (arcs, seq, index) must equal the reference's."""
+    LR, LP = R.ref(), product_graph_api()
+    for L in (LR, LP):
+        L.asg_arc_del_trans.restype = C.c_int
+        L.asg_arc_del_trans.argtypes = [C.POINTER(ma.Asg), C.c_int]
+    rng = np.random.default_rng(77)
+    for n_seq, hub_deg, dup, n_del in ((50, 0, 0, 5), (900, 700, 40, 0), (1500, 1300, 200, 30), (300, 40, 10, 10)):
+        rows = []
+        pos = np.sort(rng.integers(0, 200000, n_seq))  # reads on a line: an arc u -> v with len = pos[v] - pos[u] for nearby v (transitive by construction)
+        for u in range(n_seq):
+            for v in range(u + 1, min(n_seq, u + 1 + int(rng.integers(2, 7)))):
+                ln = int(pos[v] - pos[u]) + 1
+                rows.append((2 * u, 2 * v, ln, 5000))
+        hub = 0
+        if hub_deg:  # one vertex with a very long arc list, some targets twice
+            tg = rng.choice(np.arange(1, n_seq), size=hub_deg, replace=False)
+            for v in tg:
+                rows.append((2 * hub, 2 * int(v), int(pos[v] - pos[hub]) + 1, 4000))
+            for v in tg[:dup]:
+                rows.append((2 * hub, 2 * int(v), int(pos[v] - pos[hub]) + 1 + int(rng.integers(0, 3)), 3999))
+        full = []
+        for (u, v, ln, ol) in rows:
+            full.append((u, v, ln, ol))
+            full.append((v ^ 1, u ^ 1, ln + 3, ol))
+        a = np.zeros(len(full), dtype=ma.ARC_DT)
+        for i, (u, v, ln, ol) in enumerate(full):
+            a[i] = ((u << 32) | ln, v, ol)
+        a = a[np.argsort(a["ul"], kind="stable")]
+        seq = np.full(n_seq, 9000, dtype="<u4")
+        for r in rng.choice(n_seq, size=n_del, replace=False):
+            seq[r] |= 1 << 31  # deleted read that still has arcs
+        idx = np.zeros(2 * n_seq, dtype="<u8")
+        R.orc().orc_arc_index(n_seq, len(a), a.ctypes.data, idx.ctypes.data)
+        res = []
+        for L in (LR, LP):
+            g = ma.Asg()
+            for field, arr in (("arc", a), ("seq", seq), ("idx", idx)):
+                p = libc.malloc(max(arr.nbytes, 16))
+                C.memmove(p, arr.ctypes.data, arr.nbytes)
+                setattr(g, field, p)
+            g.m_arc, g.n_arc_srt, g.m_seq, g.n_seq_symm = max(len(a), 1), len(a) | 1 << 31, n_seq, n_seq
+            n_red = L.asg_arc_del_trans(C.byref(g), 1000)
+            res.append((n_red, snapshot(C.pointer(g))))
+        assert res[0][0] == res[1][0], "reduced %d vs %d arcs (%d reads)" % (res[0][0], res[1][0], n_seq)
+        assert res[0][1] == res[1][1], "graph differs after the reduction (%d reads, hub %d)" % (n_seq, hub_deg)
