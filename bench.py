@@ -489,6 +489,17 @@ def main():
                        "end_to_end_s": ref["wall"]}
         except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
             log("cpu baseline failed:", e)
+    if rank == 0 and world > 1:  # N ranks: no reference run here (65 s at cfg4), but the N = 1 run of the same work directory left its GFA behind
+        try:
+            ref_path = os.path.join(args.workdir, "ref_%s.gfa" % cfg_name)
+            if os.path.exists(ref_path) and os.path.getmtime(ref_path) >= os.path.getmtime(paf):
+                with open(ref_path, "rb") as f:
+                    ref_md5 = md5_pair(f.read())
+                mine = md5_pair(gfa)
+                parity = {"gfa_identical": mine[0] == ref_md5[0], "gfa_identical_sorted": mine[1] == ref_md5[1], "gfa_md5": mine[0], "ref_md5": ref_md5[0],
+                          "ref_from": "the reference's GFA of this file, kept by the N = 1 run in the work directory"}
+        except Exception as e:
+            log("parity against the cached reference GFA failed:", e)
     if rank == 0 and world == 1 and not args.no_legs:
         try:  # the command line, process start -> GFA on disk (north_star's ">= 10x reference wall-clock" is about this)
             outp = os.path.join(args.workdir, "cli_%s.gfa" % cfg_name)

@@ -81,3 +81,72 @@ def test_randomised_reference_vs_kernels_on_cpu(mode, emu_built):
     args = {"options": ["--seed", "101"], "text": ["--seed", "102", "--text"], "ranks": ["--seed", "103", "--ranks", "2"]}[mode]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_emu.py"), "--cases", str(n)] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=3000)
     assert r.returncode == 0 and "0 mismatches" in r.stdout.splitlines()[-1], r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("mode", ["default", "tail_ctx"])
+def test_bench_py_runs_on_the_cpu_build(mode, emu_built, tmp_path):
+    """bench.py itself -- Workload (file -> device parse -> records by read range), Runner with its worker thread, the profiled steps, the
+    text-resident leg, the reference run and the GFA comparison, the JSON line -- executed against the CPU build of the kernels with a numpy-backed
+    stand-in for the few torch calls it makes (tests/emu/fake_torch).  `tail_ctx`: the second context + hand-over thread of `--tail-ctx`.
+    Numbers mean nothing here; the control flow, the parity check and the shape of the line do."""
+    import json
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "miniasm_ref")):
+        pytest.skip("oracle/_ref not built")
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.path.join(EMU, "fake_torch") + os.pathsep + env.get("PYTHONPATH", "")
+    env["MINIASM_AMD_LIB"] = os.path.join(EMU, "_build", "libminiasm_amd_emu.so")
+    env["MA_BENCH_DIR"] = str(tmp_path)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "2500", "--lines", "70000", "--seed", "5", "--steps", "3", "--warmup", "1", "--no-legs"]
+    if mode == "tail_ctx":
+        cmd.append("--tail-ctx")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "bench.py prints ONE JSON line"
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["vs_baseline"] is None
+    assert d["gfa_identical"] is True and d["parity"]["gfa_md5"] == d["parity"]["ref_md5"]
+    assert d["roofline"]["bound"] == "hbm" and d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["cores"] == 1
+    assert d["from_text"] and d["from_text"]["value"] > 0
+    assert ("second context" in d["config"]["pipelining"]) == (mode == "tail_ctx")
+
+
+def test_bench_py_on_two_ranks_on_the_cpu_build(emu_built, tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* in the environment), on the CPU build:
+    the control plane is a file-based stand-in for torch.distributed, the collectives go through the shared-memory double
+    (MA_BENCH_ONE_GPU_DEBUG, the hook bench.py has for one-GPU boxes), rank 0 runs its tail on a second context.  A one-rank run first leaves
+    the reference's GFA in the work directory; the two-rank line must say `gfa_identical: true` against it and report whole-job throughput."""
+    import json
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "miniasm_ref")):
+        pytest.skip("oracle/_ref not built")
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.path.join(EMU, "fake_torch") + os.pathsep + env.get("PYTHONPATH", "")
+    env["MINIASM_AMD_LIB"] = os.path.join(EMU, "_build", "libminiasm_amd_emu.so")
+    env["MA_BENCH_DIR"] = str(tmp_path)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "2500", "--lines", "70000", "--seed", "5", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(base + ["--no-legs", "--no-text"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    one = json.loads(r.stdout.strip().splitlines()[-1])
+    assert one["gfa_identical"] is True
+    procs = []
+    for rank in range(2):
+        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(20000 + os.getpid() % 20000),
+                 MA_FAKE_DIST_DIR=str(tmp_path), MA_BENCH_ONE_GPU_DEBUG="1")
+        procs.append(subprocess.Popen(base + ["--gpus", "2", "--tail-ctx"], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, err = p.communicate(timeout=1800)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, err[-3000:]
+        outs.append(o)
+    assert outs[1].strip() == "", "only rank 0 prints"
+    d = json.loads(outs[0].strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["gfa_identical"] is True and d["parity"]["gfa_md5"] == one["parity"]["ref_md5"]
+    assert d["config"]["global_overlaps"] == one["config"]["global_overlaps"] and d["config"]["per_gpu_hits"] < one["config"]["per_gpu_hits"]
