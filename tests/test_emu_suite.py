@@ -25,8 +25,9 @@ def emu_built(built):
     return True
 
 
-def run_gpu_tests(args, timeout):
+def run_gpu_tests(args, timeout, extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
     env["PYTHONPATH"] = EMU + os.pathsep + env.get("PYTHONPATH", "")
     env.pop("MINIASM_AMD_LIB", None)
     cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-p", "emu_plugin", "-x", "-q", "-p", "no:cacheprovider"] + args
@@ -47,6 +48,13 @@ def test_kernels_stage_parity_on_cpu(emu_built):
     """tests/test_gpu_parity.py: every HIP pass against the oracle and the reference library (incl. the second tiers)"""
     sel = [] if FULL else ["-k", "lognormal or noisy or lowid or deep_groups or sort_random or sub_"]
     run_gpu_tests(["tests/test_gpu_parity.py"] + sel, 3000)
+
+
+def test_kernels_with_reversed_schedule_and_guard_pages(emu_built):
+    """the same kernels with lanes, waves and blocks executed in DESCENDING order (code that leans on lock-step execution or on launch order
+    without a barrier breaks) and every device allocation ending at a faulting page (an out-of-bounds access crashes)"""
+    run_gpu_tests(["tests/test_gpu_parity.py", "-k", "noisy or deep_groups or sort_random", "tests/test_gpu_ingest.py"], 3000,
+                  {"EMU_ORDER": "reverse", "EMU_GUARD": "1"})
 
 
 def test_kernels_graph_api_on_cpu(emu_built):
