@@ -46,7 +46,7 @@ def test_emulator_selftest(emu_built):
 
 def test_kernels_stage_parity_on_cpu(emu_built):
     """tests/test_gpu_parity.py: every HIP pass against the oracle and the reference library (incl. the second tiers)"""
-    sel = [] if FULL else ["-k", "lognormal or noisy or lowid or deep_groups or sort_random or sub_"]
+    sel = [] if FULL else ["-k", "lognormal or noisy or lowid or deep_groups or sort_random or sub_ or random_hit"]
     run_gpu_tests(["tests/test_gpu_parity.py"] + sel, 3000)
 
 

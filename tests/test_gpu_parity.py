@@ -197,3 +197,45 @@ def test_graph_passes_on_uploaded_graph(gpu_ctx, tmpdir_s):
         got, _, _ = gpu_ctx.asg_download()
         assert got.tobytes() == exp[:m].tobytes()
     ing.close()
+
+
+def random_hits(seed):
+    """hit arrays no overlapper writes: a few very deep reads, coordinates on a coarse grid (ties everywhere, zero-length and full-length overlaps),
+    start > end, self hits, ml > bl, bl = 0 -- the passes are integer arithmetic with C's wrap-around rules, so garbage in must give the oracle's
+    garbage out, bit for bit"""
+    rng = np.random.default_rng(seed)
+    R_ = int(rng.choice([1, 3, 20, 200, 2000]))
+    n = int(rng.choice([1, 2, 50, 3000, 60000]))
+    mode = int(rng.integers(0, 4))
+    rl = rng.integers(500, 20000, R_)
+    q = rng.integers(0, R_, n) if mode != 3 else np.minimum(rng.geometric(0.05, n) - 1, R_ - 1)
+    t = rng.integers(0, R_, n)
+    ql, tl = rl[q], rl[t]
+    if mode == 0:
+        qs = (rng.random(n) * ql * 0.8).astype(np.int64); qe = qs + 1 + (rng.random(n) * (ql - qs - 1)).astype(np.int64)
+        ts = (rng.random(n) * tl * 0.8).astype(np.int64); te = ts + 1 + (rng.random(n) * (tl - ts - 1)).astype(np.int64)
+    elif mode == 1:
+        g = 250
+        qs = rng.integers(0, 8, n) * g; qe = np.minimum(qs + rng.integers(0, 40, n) * g, ql)
+        ts = rng.integers(0, 8, n) * g; te = np.minimum(ts + rng.integers(0, 40, n) * g, tl)
+    else:
+        qs = rng.integers(0, ql + 1); qe = rng.integers(0, ql + 1)
+        ts = rng.integers(0, tl + 1); te = rng.integers(0, tl + 1)
+    bl = rng.integers(0, 30000, n)
+    ml = (bl * rng.random(n) * 1.2).astype(np.int64)
+    h = np.zeros(n, dtype=ma.HIT_DT)
+    h["qns"] = (q.astype(np.uint64) << np.uint64(32)) | (qs.astype(np.uint64) & np.uint64(0xffffffff))
+    h["qe"] = qe.astype(np.uint32); h["tn"] = t.astype(np.uint32); h["ts"] = ts.astype(np.uint32); h["te"] = te.astype(np.uint32)
+    h["mlrev"] = (ml.astype(np.uint32) & np.uint32(0x7fffffff)) | (rng.integers(0, 2, n).astype(np.uint32) << np.uint32(31))
+    h["bldel"] = bl.astype(np.uint32) & np.uint32(0x7fffffff)
+    return h, R_
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_hit_arrays_match_the_oracle_at_every_stage(block, gpu_ctx):
+    opt = ma.default_opt()
+    for seed in range(block * 8, block * 8 + 8):
+        h, n_seq = random_hits(seed)
+        orc = ST.orc_stages(h, n_seq, opt)
+        gpu = ST.gpu_stages(gpu_ctx, h, n_seq, opt)
+        ST.compare(orc, gpu, "random hits, seed %d" % seed, exact_order=True, graph=True)
