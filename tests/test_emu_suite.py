@@ -60,7 +60,7 @@ def test_kernels_with_reversed_schedule_and_guard_pages(emu_built):
 def test_kernels_graph_api_on_cpu(emu_built):
     """tests/test_gpu_graph_api.py, test_gpu_graph_fuzz.py: device cleaners and unitigs after every call, through the per-symbol ABI (pipeline graphs,
     hand-made rings and hubs, random graphs with random scripts)"""
-    run_gpu_tests(["tests/test_gpu_graph_api.py", "tests/test_gpu_graph_fuzz.py"], 1800)
+    run_gpu_tests(["tests/test_gpu_graph_api.py", "tests/test_gpu_graph_fuzz.py"] + ([] if FULL else ["-k", "not noisy_big"]), 1800)
 
 
 def test_kernels_ingest_on_cpu(emu_built):
