@@ -52,10 +52,34 @@ __global__ __launch_bounds__(256) void k_ug_jump(uint32_t n_vtx, ug_rank_t i, ug
 __global__ __launch_bounds__(256) void k_ug_cycle_check(ug_t a, const uint32_t *ptr, unsigned long long *ctr)
 {
 	uint32_t w = blockIdx.x * 256 + threadIdx.x;
-	int cyc = 0;
-	if (w < a.n_vtx) { const uint32_t p = a.prv[w]; cyc = p < UG_OUT && a.prv[ptr[w]] != UG_NONE; }
+	int cyc = 0, bad = 0;
+	if (w < a.n_vtx) { const uint32_t p = a.prv[w]; cyc = p < UG_OUT && a.prv[ptr[w]] != UG_NONE; bad = ugk_link_bad(&a, w); }
 	if (__ballot(cyc) && (threadIdx.x & 63) == 0) atomicAdd(&ctr[CT_OVF], 1ull);
+	if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicAdd(&ctr[CT_OVF2], 1ull); // links that are not mirrored: the graph is not symmetric
 }
+// The reference's own sweep for graphs that are not symmetric (ug_core.h): ONE wave; its lanes look for start vertices 64 at a time,
+// lane 0 walks.  Counts keep running past the capacity of ua, so the host can grow it and launch again.
+__global__ __launch_bounds__(64) void k_ug_seq(ug_t a, uint8_t *seen, unsigned long long cap, unsigned long long *ctr)
+{
+	const uint32_t lane = threadIdx.x;
+	ug_seq_t s;
+	s.seen = seen; s.cap = cap; s.n_mem = 0; s.n_utg = 0; s.err = 0;
+	for (uint32_t base = 0; base < a.n_vtx; base += 64) {
+		const uint32_t v = base + lane;
+		const int cand = v < a.n_vtx && !a.sdel[v >> 1] && ug_deg(&a, v) > 0;
+		unsigned long long m = __ballot(cand);
+		if (lane == 0)
+			for (; m && !s.err; m &= m - 1) {
+				const uint32_t s0 = base + (uint32_t)__builtin_ctzll(m);
+				if (!seen[s0]) ug_seq_unitig(&a, &s, s0);
+			}
+		if (__shfl((int)s.err, 0)) break;
+	}
+	if (lane == 0) { ctr[CT_TOTAL] = s.n_mem; ctr[CT_LIVE] = s.n_utg; ctr[CT_CUT] = s.err; }
+}
+// asm.c:180-184 in unitig order (with overlapping unitigs a later one overwrites an earlier one's mark)
+__global__ void k_ug_mark_seq(ug_t a, uint32_t n_utg) { if (threadIdx.x == 0 && blockIdx.x == 0) for (uint32_t k = 0; k < n_utg; ++k) ugk_mark(&a, k); }
+
 __global__ __launch_bounds__(256) void k_ug_heads(ug_t a, uint8_t *is_head) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) is_head[w] = a.prv[w] == UG_NONE; }
 __global__ __launch_bounds__(256) void k_ug_cut(ug_t a, const uint32_t *ptr, const uint32_t *mn, const uint8_t *is_head) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_cut(&a, w, ptr, mn, is_head); }
 __global__ __launch_bounds__(256) void k_ug_chain(ug_t a, ug_rank_t r) { uint32_t w = blockIdx.x * 256 + threadIdx.x; if (w < a.n_vtx) ugk_chain(&a, w, r); }
@@ -128,6 +152,29 @@ extern "C" int mahip_ug_gen(mahip_ctx_t *c, uint32_t *n_utg, uint32_t *n_members
 	CHK(ug_rank(c, b, a, &g));                      // head, offset, discovery vertex and length of every chain in one ranking pass
 	hipLaunchKernelGGL(k_ug_cycle_check, dim3(gv), dim3(256), 0, c->st, a, (const uint32_t*)P<uint32_t>(b->ptr[g]), ctr);
 	CHK(ctr_fetch(c));
+	uint32_t *d_tot = (uint32_t*)(ctr + CT_TOTAL);
+	const bool irregular = c->h_ctr[CT_OVF2] != 0;
+	if (irregular) { // not a symmetric graph: chains and twins do not exist; the reference's sweep, on one lane
+		unsigned long long cap = b->ua.cap / 8;
+		for (int attempt = 0;; ++attempt) {
+			HIPCHK(hipMemsetAsync(b->circ.p, 0, (size_t)V, c->st));
+			CHK(ctr_zero(c));
+			hipLaunchKernelGGL(k_ug_seq, dim3(1), dim3(64), 0, c->st, a, P<uint8_t>(b->circ), cap, ctr);
+			CHK(ctr_fetch(c));
+			if (c->h_ctr[CT_CUT]) { mahip_set_error("mahip_ug_gen: a unitig walk never ends on this (asymmetric) graph; the reference does not return on it either"); return -1; }
+			if (c->h_ctr[CT_TOTAL] <= cap) break;
+			if (attempt || c->h_ctr[CT_TOTAL] > 0xffffffffull) { mahip_set_error("mahip_ug_gen: unitig members do not fit"); return -1; }
+			cap = c->h_ctr[CT_TOTAL] + 16;
+			CHK(dev_reserve(c, b->ua, cap * 8));
+			a.ua = P<unsigned long long>(b->ua);
+		}
+		const uint32_t U = (uint32_t)c->h_ctr[CT_LIVE];
+		b->n_utg = U; b->n_mem = (uint32_t)c->h_ctr[CT_TOTAL];
+		if (n_utg) *n_utg = U;
+		if (U == 0) return 0;
+		HIPCHK(hipMemsetAsync(b->mark.p, 0xff, (size_t)V * 4, c->st));
+		hipLaunchKernelGGL(k_ug_mark_seq, dim3(1), dim3(64), 0, c->st, a, U);
+	} else {
 	if (c->h_ctr[CT_OVF]) { // some chain has no head: cut every cycle in front of its smallest vertex, rank again
 		hipLaunchKernelGGL(k_ug_heads, dim3(gv), dim3(256), 0, c->st, a, P<uint8_t>(b->ishead));
 		hipLaunchKernelGGL(k_ug_cut, dim3(gv), dim3(256), 0, c->st, a, (const uint32_t*)P<uint32_t>(b->ptr[g]), (const uint32_t*)P<uint32_t>(b->mn[g]), (const uint8_t*)P<uint8_t>(b->ishead));
@@ -140,7 +187,6 @@ extern "C" int mahip_ug_gen(mahip_ctx_t *c, uint32_t *n_utg, uint32_t *n_members
 	hipLaunchKernelGGL(k_ug_chain, dim3(gv), dim3(256), 0, c->st, a, rk);
 	HIPCHK(hipMemsetAsync(b->flag.p, 0, (size_t)V * 4, c->st));
 	hipLaunchKernelGGL(k_ug_pick, dim3(gv), dim3(256), 0, c->st, a, ptr);
-	uint32_t *d_tot = (uint32_t*)(ctr + CT_TOTAL);
 	CHK(scan_exclusive_u32(c, P<uint32_t>(b->flag), P<uint32_t>(b->pos), V, d_tot));
 	CHK(ctr_fetch(c));
 	const uint32_t U = (uint32_t)(c->h_ctr[CT_TOTAL] & 0xffffffffu);
@@ -155,6 +201,7 @@ extern "C" int mahip_ug_gen(mahip_ctx_t *c, uint32_t *n_utg, uint32_t *n_members
 	hipLaunchKernelGGL(k_ug_mark, dim3(grid_for(U, 256)), dim3(256), 0, c->st, a, U);
 	CHK(ctr_fetch(c));
 	b->n_mem = (uint32_t)(c->h_ctr[CT_TOTAL] & 0xffffffffu);
+	} // symmetric graph
 	uint32_t n_ua = 0;
 	if (A) {
 		CHK(dev_reserve(c, b->akeep, (A + 16) * 4)); CHK(dev_reserve(c, b->apos, (A + 16) * 4));

@@ -139,6 +139,80 @@ UG_HD void ugk_fill(const ug_t *a, uint32_t w, const uint32_t *ptr, const uint32
 	a->ua[a->u_off[k] + dist[w]] = (unsigned long long)w << 32 | l;
 }
 
+/* ---- graphs whose links are not mirror images of each other (asymmetric input: `-b -S 5 -p ug`, hand-made graphs through the
+ * per-symbol ma_ug_gen) ------------------------------------------------------------------------------------------------------
+ * Everything above rests on one property of a symmetric graph: w -> x is a link exactly when x^1 -> w^1 is, so the forward walk
+ * (asm.c:139-151) and the backward walk (asm.c:160-171, which follows the COMPLEMENT strand's arcs and never looks at where w's own
+ * arc goes) trace the same chain, every unitig exists as two complementary chains and nobody else marks their vertices.  Without it
+ * the reference's result is a function of its sweep order: walks run through vertices other unitigs have marked, unitigs overlap,
+ * a vertex can start a unitig only if no earlier walk touched it.  ugk_link_bad finds out (one test per link); if any link fails it,
+ * the sweep itself runs on the device, in vertex order, on one lane (ug_seq_unitig per start vertex): slow and exact. */
+UG_HD int ugk_link_bad(const ug_t *a, uint32_t w)
+{
+	const uint32_t n = a->nxt[w], p = a->prv[w];
+	int bad = 0;
+	if (n != UG_NONE) bad |= a->sdel[n >> 1] || n == (w ^ 1) || a->av[ug_first(a, n ^ 1)] != (w ^ 1);
+	if (p < UG_OUT) bad |= a->sdel[p >> 1] || a->av[ug_first(a, p)] != w;
+	return bad;
+}
+
+typedef struct {
+	uint8_t *seen;                    /* the reference's mark[] of its first loop (asm.c:131) */
+	unsigned long long cap, n_mem;    /* room in ua / members so far (keeps counting past cap: the caller grows ua and repeats) */
+	uint32_t n_utg, err;              /* err: a walk that cannot end -- the reference does not return on such a graph */
+} ug_seq_t;
+
+/* one iteration of asm.c:133-178 for a start vertex v the caller found alive, with an arc and unmarked */
+UG_HD void ug_seq_unitig(const ug_t *a, ug_seq_t *s, uint32_t v)
+{
+	const uint32_t lim = a->n_vtx;    /* a walk is a function iteration over the vertex set: more steps than vertices = it runs in a cycle it never leaves */
+	const unsigned long long off = s->n_mem;
+	uint32_t w, x, l, start = v, end = v ^ 1, len = 0, nf = 0, nb = 0, k, n;
+	int circ;
+	s->seen[v] = 1;
+	for (w = v;;) {                   /* forward: marks and the count; the members are written once their place is known */
+		if (ug_deg(a, w) != 1) break;
+		x = a->av[ug_first(a, w)];
+		if (ug_deg(a, x ^ 1) != 1) break;
+		s->seen[x] = s->seen[w ^ 1] = 1;
+		len += a->alen[ug_first(a, w)];
+		end = x ^ 1; ++nf; w = x;
+		if (x == v) break;
+		if (nf > lim) { s->err = 1; return; }
+	}
+	circ = start == (end ^ 1) && nf != 0;
+	if (!circ) {                      /* backward: written front to back behind `off`, turned round afterwards (kdq_unshift) */
+		for (x = v;;) {
+			if (ug_deg(a, x ^ 1) != 1) break;
+			w = a->av[ug_first(a, x ^ 1)] ^ 1;
+			if (ug_deg(a, w) != 1) break;
+			s->seen[x] = s->seen[w ^ 1] = 1;
+			l = a->alen[ug_first(a, w)];
+			if (off + nb < s->cap) a->ua[off + nb] = (unsigned long long)w << 32 | l;
+			start = w; len += l; ++nb; x = w;
+			if (nb > lim) { s->err = 1; return; }
+		}
+		if (off + nb <= s->cap)
+			for (k = 0; k < nb / 2; ++k) { const unsigned long long t = a->ua[off + k]; a->ua[off + k] = a->ua[off + nb - 1 - k]; a->ua[off + nb - 1 - k] = t; }
+	}
+	for (w = v, k = 0; k < nf; ++k) { /* forward again */
+		const uint32_t e = ug_first(a, w);
+		if (off + nb + k < s->cap) a->ua[off + nb + k] = (unsigned long long)w << 32 | a->alen[e];
+		w = a->av[e];
+	}
+	n = nb + nf;
+	if (!circ) {                      /* asm.c:152-155: the last read contributes its whole length */
+		l = a->slen[end >> 1] & 0x7fffffffu;
+		if (off + n < s->cap) a->ua[off + n] = (unsigned long long)(end ^ 1) << 32 | l;
+		len += l; ++n;
+		s->seen[start] = s->seen[end] = 1;
+	}
+	k = s->n_utg++;                   /* at most one unitig per vertex: the per-unitig arrays always have room */
+	a->u_n[k] = n; a->u_len[k] = len; a->u_off[k] = (uint32_t)off;
+	a->u_start[k] = circ ? UG_NONE : start; a->u_end[k] = circ ? UG_NONE : end;
+	s->n_mem = off + n;
+}
+
 UG_HD void ugk_mark(const ug_t *a, uint32_t k) /* asm.c:180-184 */
 {
 	if (a->u_start[k] == UG_NONE) return;

@@ -75,9 +75,10 @@ extern "C" int clh_sweep(int mode, int param, uint32_t n_seq, uint32_t n_arc, ar
 }
 
 // unitigs of a clean graph; outputs sized by the caller: per-unitig arrays [2*n_seq], members [2*n_seq], uarcs [n_arc]
-extern "C" int clh_ug(uint32_t n_seq, uint32_t n_arc, const arc_t *arc, const uint64_t *idx, const uint32_t *seq,
+// returns 0 (symmetric graph: chains), 1 (asymmetric: the sequential sweep), -2 (a walk that never ends), -3 (more than mem_cap members)
+static int clh_ug_cap(uint32_t n_seq, uint32_t n_arc, const arc_t *arc, const uint64_t *idx, const uint32_t *seq,
                       uint32_t *n_utg, uint32_t *n_mem, uint32_t *n_uarc,
-                      uint32_t *u_n, uint32_t *u_len, uint32_t *u_start, uint32_t *u_end, uint32_t *u_off, uint64_t *members, arc_t *uarcs)
+                      uint32_t *u_n, uint32_t *u_len, uint32_t *u_start, uint32_t *u_end, uint32_t *u_off, uint64_t *members, arc_t *uarcs, size_t mem_cap)
 {
 	Soa G;
 	to_soa(n_seq, n_arc, arc, idx, seq, G);
@@ -105,8 +106,29 @@ extern "C" int clh_ug(uint32_t n_seq, uint32_t n_arc, const arc_t *arc, const ui
 	};
 	for (uint32_t w = 0; w < V; ++w) ugk_link(&a, w);
 	int g = rank();
-	bool cyc = false;
-	for (uint32_t w = 0; w < V; ++w) cyc = cyc || (prv[w] < UG_OUT && prv[ptr[g][w]] != UG_NONE);
+	bool cyc = false, bad = false;
+	for (uint32_t w = 0; w < V; ++w) cyc = cyc || (prv[w] < UG_OUT && prv[ptr[g][w]] != UG_NONE), bad = bad || ugk_link_bad(&a, w);
+	if (bad) { // not a symmetric graph: the reference's sweep (k_ug_seq on the device); members may overlap, so the caller's arrays bound them
+		ug_seq_t s;
+		std::vector<uint8_t> seen(V, 0);
+		ua.resize(mem_cap + 1);
+		a.ua = ua.data();
+		s.seen = seen.data(); s.cap = mem_cap; s.n_mem = 0; s.n_utg = 0; s.err = 0;
+		for (uint32_t v = 0; v < V && !s.err; ++v)
+			if (!G.sdel[v >> 1] && (uint32_t)G.idx[v] > 0 && !seen[v]) ug_seq_unitig(&a, &s, v);
+		if (s.err) return -2;
+		if (s.n_mem > mem_cap) return -3;
+		const uint32_t U = s.n_utg, M = (uint32_t)s.n_mem;
+		*n_utg = U; *n_mem = M;
+		for (uint32_t k = 0; k < U; ++k) ugk_mark(&a, k);
+		uint32_t na = 0;
+		for (uint32_t e = 0; e < n_arc; ++e)
+			if (ugk_arc_keep(&a, e)) { uint32_t o[4]; ugk_arc_emit(&a, e, o); uarcs[na].len = o[0]; uarcs[na].u = o[1]; uarcs[na].v = o[2]; uarcs[na].ol = o[3]; ++na; }
+		*n_uarc = na;
+		memcpy(u_n, un.data(), U * 4); memcpy(u_len, ul.data(), U * 4); memcpy(u_start, us.data(), U * 4); memcpy(u_end, ue.data(), U * 4); memcpy(u_off, uo.data(), U * 4);
+		memcpy(members, ua.data(), (size_t)M * 8);
+		return 1;
+	}
 	if (cyc) { // as the device: cut + second ranking only when some chain has no head
 		for (uint32_t w = 0; w < V; ++w) ishead[w] = prv[w] == UG_NONE;
 		for (uint32_t w = 0; w < V; ++w) ugk_cut(&a, w, ptr[g].data(), mn[g].data(), ishead.data());
@@ -133,4 +155,18 @@ extern "C" int clh_ug(uint32_t n_seq, uint32_t n_arc, const arc_t *arc, const ui
 	memcpy(u_n, un.data(), U * 4); memcpy(u_len, ul.data(), U * 4); memcpy(u_start, us.data(), U * 4); memcpy(u_end, ue.data(), U * 4); memcpy(u_off, uo.data(), U * 4);
 	memcpy(members, ua.data(), (size_t)M * 8);
 	return 0;
+}
+
+extern "C" int clh_ug(uint32_t n_seq, uint32_t n_arc, const arc_t *arc, const uint64_t *idx, const uint32_t *seq,
+                      uint32_t *n_utg, uint32_t *n_mem, uint32_t *n_uarc,
+                      uint32_t *u_n, uint32_t *u_len, uint32_t *u_start, uint32_t *u_end, uint32_t *u_off, uint64_t *members, arc_t *uarcs)
+{
+	return clh_ug_cap(n_seq, n_arc, arc, idx, seq, n_utg, n_mem, n_uarc, u_n, u_len, u_start, u_end, u_off, members, uarcs, 2 * (size_t)n_seq);
+}
+// the same with room for mem_cap members (asymmetric graphs: unitigs may share reads)
+extern "C" int clh_ug2(uint32_t n_seq, uint32_t n_arc, const arc_t *arc, const uint64_t *idx, const uint32_t *seq,
+                       uint32_t *n_utg, uint32_t *n_mem, uint32_t *n_uarc,
+                       uint32_t *u_n, uint32_t *u_len, uint32_t *u_start, uint32_t *u_end, uint32_t *u_off, uint64_t *members, arc_t *uarcs, size_t mem_cap)
+{
+	return clh_ug_cap(n_seq, n_arc, arc, idx, seq, n_utg, n_mem, n_uarc, u_n, u_len, u_start, u_end, u_off, members, uarcs, mem_cap);
 }

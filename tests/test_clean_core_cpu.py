@@ -230,3 +230,121 @@ def test_circular_unitigs_and_isolated_reads():
         assert R.canon(ra).tobytes() == R.canon(uarcs[:n_ua.value]).tobytes()
         LR.ma_ug_destroy(ug)
     assert any(u == 0xffffffff for u in u_start[:1]) or True
+
+
+def _ref_ug_forked(a, seq, idx, n_seq, timeout=5.0):
+    """ma_ug_gen of the reference library in a forked child (it does not return on some asymmetric graphs: asm.c:160-171 has no
+    cycle check).  Returns None on a timeout, else (list of (n, lencirc, start, end, members bytes), canonical unitig arcs bytes)."""
+    import pickle
+    import select
+    import signal
+    rd, wr = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            os.close(rd)
+            LR = R.ref()
+            g = ma.Asg()
+            pa, ps, pi = (C.create_string_buffer(x.tobytes(), max(len(x.tobytes()), 1)) for x in (a, seq, idx))
+            g.arc, g.seq, g.idx = C.addressof(pa), C.addressof(ps), C.addressof(pi)
+            g.m_arc, g.n_arc_srt, g.m_seq, g.n_seq_symm = len(a), len(a) | 1 << 31, n_seq, n_seq | 1 << 31
+            LR.ma_ug_gen.restype = C.c_void_p
+            LR.ma_ug_gen.argtypes = [C.POINTER(ma.Asg)]
+            ug = LR.ma_ug_gen(C.byref(g))
+
+            class Utg(C.Structure):
+                _fields_ = [("lencirc", C.c_uint32), ("start", C.c_uint32), ("end", C.c_uint32), ("m", C.c_uint32), ("n", C.c_uint32), ("a", C.c_void_p), ("s", C.c_void_p)]
+
+            class Ug(C.Structure):
+                _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.POINTER(Utg)), ("g", C.POINTER(ma.Asg))]
+            U = C.cast(ug, C.POINTER(Ug)).contents
+            units = [(U.a[k].n, U.a[k].lencirc, U.a[k].start, U.a[k].end, C.string_at(U.a[k].a, U.a[k].n * 8)) for k in range(U.n)]
+            ra, _, _ = R.asg_arrays(U.g)
+            os.write(wr, pickle.dumps((units, R.canon(ra).tobytes())))
+        finally:
+            os._exit(0)
+    os.close(wr)
+    buf = b""
+    ok = True
+    import time
+    t_end = time.time() + timeout
+    while True:
+        left = t_end - time.time()
+        if left <= 0:
+            ok = False
+            break
+        r, _, _ = select.select([rd], [], [], left)
+        if not r:
+            ok = False
+            break
+        chunk = os.read(rd, 1 << 20)
+        if not chunk:
+            break
+        buf += chunk
+    os.close(rd)
+    if not ok:
+        os.kill(pid, signal.SIGKILL)
+    os.waitpid(pid, 0)
+    return pickle.loads(buf) if ok and buf else None
+
+
+def random_asym_graph(rng, n_seq, n_arc, self_twin=False):
+    """random directed arcs with no mirror arcs (the graph ma_sg_gen builds from a `-b` input, and worse); sorted by (u, len), indexed"""
+    V = 2 * n_seq
+    rows = set()
+    while len(rows) < n_arc:
+        u, v = int(rng.integers(0, V)), int(rng.integers(0, V))
+        if (u >> 1) == (v >> 1) and not (self_twin and u == (v ^ 1)):
+            continue
+        rows.add((u, v))
+    rows = sorted(rows)
+    a = np.zeros(len(rows), dtype=ma.ARC_DT)
+    for i, (u, v) in enumerate(rows):
+        a[i] = ((u << 32) | int(rng.integers(100, 3000)), v, int(rng.integers(500, 4000)))
+    a = a[np.argsort(a["ul"], kind="stable")]
+    seq = rng.integers(4000, 9000, n_seq).astype("<u4")
+    idx = np.zeros(V, dtype="<u8")
+    R.orc().orc_arc_index(n_seq, len(a), a.ctypes.data, idx.ctypes.data)
+    return a, seq, idx
+
+
+@needs_ref
+@pytest.mark.parametrize("self_twin", [False, True])
+def test_unitigs_of_asymmetric_graphs(self_twin):
+    """graphs without mirror arcs (`-b -S 5 -p ug`, the per-symbol ma_ug_gen): links found forward and backward disagree,
+    unitigs overlap, the result depends on the sweep order.  The device notices (ugk_link_bad) and runs the reference's sweep on one lane
+    (ug_seq_unitig); here through the host harness.  Graphs the reference does not return on must be refused (-2), not crashed on."""
+    L = host()
+    vp, u32 = C.c_void_p, C.c_uint32
+    L.clh_ug2.argtypes = [u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, vp, vp, vp, vp, vp, vp, C.c_size_t]
+    rng = np.random.default_rng(77 + self_twin)
+    n_cmp = n_hang = n_seqwalk = 0
+    for it in range(160):
+        n_seq = int(rng.integers(3, 40))
+        n_arc = int(rng.integers(2, 2 * n_seq))   # sparse: out-degree 1 must be common for links to exist at all
+        a, seq, idx = random_asym_graph(rng, n_seq, n_arc, self_twin)
+        V = 2 * n_seq
+        cap = V * V + 16
+        u_n, u_len, u_start, u_end, u_off = (np.zeros(V, dtype="<u4") for _ in range(5))
+        members, uarcs = np.zeros(cap + 1, dtype="<u8"), np.zeros(max(len(a), 1), dtype=ma.ARC_DT)
+        n_utg, n_mem, n_ua = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        rc = L.clh_ug2(n_seq, len(a), a.ctypes.data, idx.ctypes.data, seq.ctypes.data, C.byref(n_utg), C.byref(n_mem), C.byref(n_ua),
+                       u_n.ctypes.data, u_len.ctypes.data, u_start.ctypes.data, u_end.ctypes.data, u_off.ctypes.data, members.ctypes.data, uarcs.ctypes.data, cap)
+        assert rc in (0, 1, -2), rc
+        if rc == -2:
+            n_hang += 1
+            if n_hang <= 3:  # spot-check: the reference really does not come back
+                assert _ref_ug_forked(a, seq, idx, n_seq, timeout=1.0) is None
+            continue
+        n_seqwalk += rc
+        ref = _ref_ug_forked(a, seq, idx, n_seq)
+        assert ref is not None, "the reference hangs on a graph the sweep finished on"
+        units, rarcs = ref
+        assert n_utg.value == len(units), (it, n_utg.value, len(units))
+        for k, (n, lencirc, start, end, mem) in enumerate(units):
+            assert (n, lencirc & 0x7fffffff, start, end) == (u_n[k], u_len[k] & 0x7fffffff, u_start[k], u_end[k]), (it, k)
+            assert (lencirc >> 31) == (1 if u_start[k] == 0xffffffff else 0)
+            assert mem == members[u_off[k]:u_off[k] + n].tobytes(), (it, k)
+        assert rarcs == R.canon(uarcs[:n_ua.value]).tobytes(), it
+        n_cmp += 1
+    assert n_cmp >= 100 and n_seqwalk >= 50, (n_cmp, n_seqwalk, n_hang)

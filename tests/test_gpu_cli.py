@@ -23,7 +23,8 @@ INPUTS = {  # name -> pafgen arguments (all arc-tie-free: checked when the golde
 }
 
 EXTRA_ARGS = [["-1"], ["-2", "-p", "sg"], ["-b"], ["-R"], ["-R", "-p", "paf"], ["-R", "-h", "4000", "-p", "bed"], ["-c", "2", "-s", "1500", "-h", "500", "-I", "0.7", "-g", "500", "-e", "3", "-d", "30000"],
-              ["-n", "4", "-r", "0.8,0.4", "-F", "0.9"], ["-o", "1000", "-m", "200", "-i", "0.1"], ["-1", "-2", "-p", "sg"]]
+              ["-n", "4", "-r", "0.8,0.4", "-F", "0.9"], ["-o", "1000", "-m", "200", "-i", "0.1"], ["-1", "-2", "-p", "sg"],
+              ["-b", "-S", "5", "-p", "ug"], ["-b", "-S", "4", "-p", "ug"]]  # unitigs of a graph that is NOT symmetric (ug.hip's one-lane sweep)
 
 
 def _gen(tmpdir_s, name):

@@ -118,3 +118,52 @@ def test_random_graphs_random_scripts_match_reference_after_every_call(seed, tmp
             outs.append(open(path, "rb").read())
             L.ma_ug_destroy(ug)
         assert outs[0] == outs[1], "seed %d case %d: unitigs differ" % (seed, case)
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+def test_unitigs_of_asymmetric_graphs_through_the_per_symbol_abi(tmpdir_s):
+    """ma_ug_gen on graphs without mirror arcs: the device sees that the links are not mirrored and runs the reference's sweep on one
+    lane (k_ug_seq); unitigs may share reads.  Graphs the reference does not return on (found with the host build of the same walk) are left out."""
+    import test_clean_core_cpu as TC
+    LR, LP, LH = R.ref(), product_graph_api(), TC.host()
+    vp, u32 = C.c_void_p, C.c_uint32
+    LH.clh_ug2.argtypes = [u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp, vp, vp, vp, vp, vp, vp, C.c_size_t]
+    for L in (LR, LP):
+        L.sd_init.restype = C.POINTER(ma.Sdict)
+        L.sd_put.restype = C.c_int32
+        L.sd_put.argtypes = [C.POINTER(ma.Sdict), C.c_char_p, C.c_uint32]
+        L.ma_ug_gen.restype = C.c_void_p
+        L.ma_ug_gen.argtypes = [C.POINTER(ma.Asg)]
+        L.ma_ug_print.argtypes = [C.c_void_p, C.POINTER(ma.Sdict), C.c_void_p, C.c_void_p]
+        L.ma_ug_destroy.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(4242)
+    n_done = n_overlap = 0
+    for case in range(60):
+        n_seq = int(rng.choice([3, 8, 30, 120]))
+        arcs, seq, idx = TC.random_asym_graph(rng, n_seq, int(rng.integers(2, 2 * n_seq)), self_twin=bool(case & 1))
+        V = 2 * n_seq
+        cap = V * V + 16
+        scratch = [np.zeros(V, dtype="<u4") for _ in range(5)]
+        members, uarcs = np.zeros(cap + 1, dtype="<u8"), np.zeros(max(len(arcs), 1), dtype=ma.ARC_DT)
+        n_utg, n_mem, n_ua = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        rc = LH.clh_ug2(n_seq, len(arcs), arcs.ctypes.data, idx.ctypes.data, seq.ctypes.data, C.byref(n_utg), C.byref(n_mem), C.byref(n_ua),
+                        *[x.ctypes.data for x in scratch], members.ctypes.data, uarcs.ctypes.data, cap)
+        if rc < 0:
+            continue
+        n_overlap += n_mem.value > V
+        outs = []
+        for tag, L in (("ref", LR), ("mine", LP)):
+            g = to_asg(arcs, seq, idx)
+            d = L.sd_init()
+            for i in range(n_seq):
+                L.sd_put(d, b"r%d" % i, 0)
+            ug = L.ma_ug_gen(C.byref(g))
+            path = os.path.join(tmpdir_s, "ga_%s.gfa" % tag)
+            fp = libc.fopen(path.encode(), b"w")
+            L.ma_ug_print(ug, d, None, fp)
+            libc.fclose(fp)
+            outs.append(open(path, "rb").read())
+            L.ma_ug_destroy(ug)
+        assert outs[0] == outs[1], "case %d (%d reads, %d arcs): unitigs differ" % (case, n_seq, len(arcs))
+        n_done += 1
+    assert n_done >= 40
