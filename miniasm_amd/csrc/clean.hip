@@ -43,23 +43,27 @@ __global__ __launch_bounds__(256) void k_bubble_list(const uint32_t *__restrict_
 	if (v < n_vtx && keep[v]) list[pos[v]] = v;
 }
 
+// src[0..n_src): the sources this launch probes.  A probe that fills its table leaves the source in ovf[] (any order: the stamps are
+// minima, the counts are sums) for a later launch with fewer threads and bigger tables; everybody else's stamps are final for this
+// iteration.
 __global__ __launch_bounds__(64) void k_clean_bubble(cl_view_t g, cl_stamps_t s, const uint32_t *__restrict__ src, uint32_t n_src, uint32_t max_dist,
-                                                      cl_binfo_t *__restrict__ tabs, uint32_t *__restrict__ aux, uint32_t cap, unsigned long long *__restrict__ ctr)
+                                                      cl_binfo_t *__restrict__ tabs, uint32_t *__restrict__ aux, uint32_t cap, uint32_t n_tab, uint32_t *__restrict__ ovf,
+                                                      unsigned long long *__restrict__ ctr)
 {
 	const uint32_t tid = blockIdx.x * 64 + threadIdx.x;
+	if (tid >= n_tab) return; // one table per working thread (the big tiers have fewer tables than a wave has lanes)
 	cl_bscratch_t b;
 	b.tab = tabs + (size_t)tid * cap; b.used = aux + (size_t)tid * 2 * cap; b.stack = b.used + cap; b.cap = cap; b.n_used = 0;
-	uint32_t pops = 0, tips = 0, ovf = 0;
-	for (uint32_t k = tid; k < n_src; k += gridDim.x * 64) {
+	uint32_t pops = 0, tips = 0;
+	for (uint32_t k = tid; k < n_src; k += n_tab) {
 		const uint32_t v0 = src[k];
 		uint32_t sink = 0, nt = 0;
 		int r = cl_bubble_probe(&g, v0, max_dist, &b, &sink, &nt);
 		if (r > 0) { cl_bubble_stamp(&g, s, v0, sink, &b); ++pops; tips += nt; }
-		else if (r < 0) ovf = 1;
+		else if (r < 0) ovf[atomicAdd(&ctr[CT_OVF], 1ull)] = v0;
 	}
 	if (pops) atomicAdd(&ctr[CT_LIVE], (unsigned long long)pops); // pops are rare: a handful of atomics per launch
 	if (tips) atomicAdd(&ctr[CT_REMAIN], (unsigned long long)tips);
-	if (ovf) atomicAdd(&ctr[CT_OVF], 1ull);
 }
 
 __global__ __launch_bounds__(256) void k_table_init(cl_binfo_t *__restrict__ tabs, size_t n)
@@ -84,7 +88,11 @@ __global__ __launch_bounds__(256) void k_clean_apply(const uint32_t *__restrict_
 	if (i < n_arc && ast[i] != CL_NONE) aol[i] |= CL_ADEL;
 }
 
-struct CleanBufs { DevBuf st[2], src, tabs, aux; uint32_t cap = 0; unsigned threads = 0; }; // st[k]: read stamps [R rounded up] then arc stamps [A]
+// bubble tables: tier 0 = one small table per thread of the full-width launch; tiers above (16x the slots, 1/16 of the threads: the same
+// bytes) only ever see the sources that overflowed the tier below
+enum { BUB_CAP0 = 64, BUB_THREADS0 = 65536, BUB_TIERS = 5 }; // 64 .. 4 M slots; 32 B per slot: 128 MiB per tier that is ever needed
+struct BubTier { DevBuf tabs, aux; bool ready = false; };
+struct CleanBufs { DevBuf st[2], src, ovf[2]; BubTier tier[BUB_TIERS]; uint32_t max_tier = 0; }; // st[k]: read stamps [R rounded up] then arc stamps [A]
 
 static CleanBufs *clean_bufs(mahip_ctx *c)
 {
@@ -96,10 +104,46 @@ void clean_free(mahip_ctx *c)
 {
 	CleanBufs *b = (CleanBufs*)c->clean;
 	if (!b) return;
-	DevBuf *all[] = { &b->st[0], &b->st[1], &b->src, &b->tabs, &b->aux };
+	DevBuf *all[] = { &b->st[0], &b->st[1], &b->src, &b->ovf[0], &b->ovf[1] };
 	for (DevBuf *x : all) dev_free(c, *x);
+	for (BubTier &t : b->tier) { dev_free(c, t.tabs); dev_free(c, t.aux); }
 	delete b;
 	c->clean = nullptr;
+}
+
+static inline uint32_t bub_cap(int tier)
+{
+	static uint32_t base = 0; // MA_BUBBLE_CAP0 (a power of two >= 4): the tests shrink tier 0 so that small graphs reach the tiers above
+	if (!base) { const char *e = getenv("MA_BUBBLE_CAP0"); base = e && atoi(e) >= 4 && !(atoi(e) & (atoi(e) - 1)) ? (uint32_t)atoi(e) : (uint32_t)BUB_CAP0; }
+	return base << (4 * tier);
+}
+static inline unsigned bub_threads(int tier, uint32_t n_src)
+{
+	const unsigned most = (unsigned)BUB_THREADS0 >> (4 * tier) ? (unsigned)BUB_THREADS0 >> (4 * tier) : 1u; // 65536, 4096, 256, 16, 1
+	return n_src < most ? n_src : most;
+}
+
+// one launch of the bubble probes over src[0..n_src) with the tables of `tier`; sources that need more room are appended to ovf
+static int bubble_launch(mahip_ctx *c, CleanBufs *b, int tier, const cl_view_t &g, const cl_stamps_t &s, const uint32_t *src, uint32_t n_src, uint32_t max_dist, uint32_t *ovf)
+{
+	BubTier &t = b->tier[tier];
+	const uint32_t cap = bub_cap(tier);
+	const unsigned threads = bub_threads(tier, n_src);
+	const size_t slots = (size_t)threads * cap;
+	if (t.tabs.cap < slots * sizeof(cl_binfo_t)) {
+		CHK(dev_reserve(c, t.tabs, slots * sizeof(cl_binfo_t)));
+		CHK(dev_reserve(c, t.aux, slots * 2 * 4));
+		t.ready = false;
+	}
+	if (!t.ready) { // probes leave their table empty (also the ones that give up): initialise once per allocation
+		const size_t all = t.tabs.cap / sizeof(cl_binfo_t);
+		hipLaunchKernelGGL(k_table_init, dim3(grid_for(all, 256)), dim3(256), 0, c->st, (cl_binfo_t*)t.tabs.p, all);
+		t.ready = true;
+	}
+	ProfScope ps(c, "k_clean_bubble", 0);
+	hipLaunchKernelGGL(k_clean_bubble, dim3((threads + 63) / 64), dim3(64), 0, c->st, g, s, src, n_src, max_dist, (cl_binfo_t*)t.tabs.p, P<uint32_t>(t.aux), cap, threads, ovf, P<unsigned long long>(c->ctr));
+	if ((uint32_t)tier > b->max_tier) b->max_tier = tier;
+	return 0;
 }
 
 // mode 0..2: the short-unitig rules with param = max_ext; mode 3: bubbles with param = max_dist.
@@ -121,6 +165,7 @@ static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_
 		if (A == 0) return 0;
 		CHK(dev_reserve(c, c->keep, ((size_t)V + 16) * 4)); CHK(dev_reserve(c, c->pos, ((size_t)V + 16) * 4));
 		CHK(dev_reserve(c, b->src, ((size_t)V + 4) * 4));
+		for (int k = 0; k < 2; ++k) CHK(dev_reserve(c, b->ovf[k], ((size_t)V + 4) * 4));
 		uint32_t *d_tot = (uint32_t*)(ctr + CT_TOTAL);
 		hipLaunchKernelGGL(k_bubble_cand, dim3(grid_for(V, 256)), dim3(256), 0, c->st, (const unsigned long long*)P<unsigned long long>(c->idx), V, P<uint32_t>(c->keep));
 		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), V, d_tot));
@@ -128,14 +173,12 @@ static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_
 		CHK(ctr_fetch(c));
 		n_src = (uint32_t)(c->h_ctr[CT_TOTAL] & 0xffffffffu);
 		if (n_src == 0) return 0;
-		if (b->cap == 0) b->cap = 64;
 	}
 	cl_view_t g;
 	const int ag = c->ag;
 	g.av = P<uint32_t>(c->av[ag]); g.alen = P<uint32_t>(c->alen[ag]); g.aol = P<uint32_t>(c->aol[ag]);
 	g.idx = P<unsigned long long>(c->idx); g.sdel = P<uint8_t>(c->sdel); g.n_vtx = V;
 	int cur = 0;
-	bool tables_ready = false;
 	for (int it = 0;; ++it) {
 		if (it > 100000) { mahip_set_error("graph cleaner: no fixpoint"); return -1; }
 		cl_stamps_t s; s.rst = P<uint32_t>(b->st[cur ^ 1]); s.ast = s.rst + Rp;
@@ -144,20 +187,7 @@ static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_
 		HIPCHK(hipMemsetAsync(s.rst, 0xff, W * 4, c->st));
 		CHK(ctr_zero(c));
 		if (mode == 3) {
-			const unsigned want = n_src < 65536u ? (n_src + 63) / 64 * 64 : 65536u;
-			if (b->threads < want || b->tabs.cap < (size_t)want * b->cap * sizeof(cl_binfo_t)) {
-				b->threads = want;
-				CHK(dev_reserve(c, b->tabs, (size_t)want * b->cap * sizeof(cl_binfo_t)));
-				CHK(dev_reserve(c, b->aux, (size_t)want * b->cap * 2 * 4));
-				tables_ready = false;
-			}
-			if (!tables_ready) { // probes leave their table empty: initialise once per (re)allocation and after an overflow
-				hipLaunchKernelGGL(k_table_init, dim3(grid_for((size_t)b->threads * b->cap, 256)), dim3(256), 0, c->st, (cl_binfo_t*)b->tabs.p, (size_t)b->threads * b->cap);
-				tables_ready = true;
-			}
-			ProfScope ps(c, "k_clean_bubble", 0);
-			hipLaunchKernelGGL(k_clean_bubble, dim3(want / 64), dim3(64), 0, c->st, g, s, (const uint32_t*)P<uint32_t>(b->src), n_src, (uint32_t)param,
-			                   (cl_binfo_t*)b->tabs.p, P<uint32_t>(b->aux), b->cap, ctr);
+			CHK(bubble_launch(c, b, 0, g, s, P<uint32_t>(b->src), n_src, (uint32_t)param, P<uint32_t>(b->ovf[0])));
 		} else {
 			ProfScope ps(c, "k_clean_rule", 0);
 			const unsigned grid = grid_for(V, 256, MA_STREAM_BLOCKS);
@@ -168,11 +198,22 @@ static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_
 		if (it > 0) hipLaunchKernelGGL(k_clean_diff, dim3(grid_for(W, 256, 1024)), dim3(256), 0, c->st, g.rst, (const uint32_t*)s.rst, W, ctr);
 		CHK(ctr_fetch(c));
 		HIPCHK(hipGetLastError());
-		if (c->h_ctr[CT_OVF]) { // a probe filled its table: bigger tables, same iteration again
-			if (b->cap >= (1u << 20)) { mahip_set_error("asg_pop_bubble: a probe visits more than %u vertices", b->cap); return -1; }
-			b->cap <<= 2; b->threads = 0; tables_ready = false;
-			--it;
-			continue;
+		if (mode == 3 && c->h_ctr[CT_OVF]) { // some probes filled their tables: those sources again, tier by tier, then the comparison once more
+			const unsigned long long pops = c->h_ctr[CT_LIVE], tips = c->h_ctr[CT_REMAIN];
+			unsigned long long more_pops = 0, more_tips = 0;
+			uint32_t n_ovf = (uint32_t)c->h_ctr[CT_OVF];
+			for (int tier = 1, w = 0; n_ovf; ++tier, w ^= 1) {
+				if (tier >= BUB_TIERS) { mahip_set_error("asg_pop_bubble: a probe visits more than %u vertices", bub_cap(BUB_TIERS - 1) / 4 * 3); return -1; }
+				CHK(ctr_zero(c));
+				CHK(bubble_launch(c, b, tier, g, s, P<uint32_t>(b->ovf[w]), n_ovf, (uint32_t)param, P<uint32_t>(b->ovf[w ^ 1])));
+				CHK(ctr_fetch(c));
+				more_pops += c->h_ctr[CT_LIVE]; more_tips += c->h_ctr[CT_REMAIN];
+				n_ovf = (uint32_t)c->h_ctr[CT_OVF];
+			}
+			CHK(ctr_zero(c));
+			if (it > 0) hipLaunchKernelGGL(k_clean_diff, dim3(grid_for(W, 256, 1024)), dim3(256), 0, c->st, g.rst, (const uint32_t*)s.rst, W, ctr);
+			CHK(ctr_fetch(c));
+			c->h_ctr[CT_LIVE] = pops + more_pops; c->h_ctr[CT_REMAIN] = tips + more_tips;
 		}
 		cur ^= 1;
 		if (n_iter) *n_iter = it + 1;
@@ -189,11 +230,13 @@ static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_
 	return 0;
 }
 
-static void clean_timing(const char *what, int n_iter, uint32_t cnt)
+static void clean_timing(const char *what, int n_iter, uint32_t cnt, int tier = -1)
 {
 	static int on = -1;
 	if (on < 0) on = getenv("MA_PIPE_TIMING") && atoi(getenv("MA_PIPE_TIMING")) >= 2;
-	if (on) fprintf(stderr, "[T::clean] %-14s %2d iterations, %u actions\n", what, n_iter, cnt);
+	if (!on) return;
+	if (tier < 0) fprintf(stderr, "[T::clean] %-14s %2d iterations, %u actions\n", what, n_iter, cnt);
+	else fprintf(stderr, "[T::clean] %-14s %2d iterations, %u actions; biggest probe table used so far: %u slots (tier %d)\n", what, n_iter, cnt, bub_cap(tier), tier);
 }
 
 extern "C" int mahip_asg_cut_tip(mahip_ctx_t *c, int max_ext, uint32_t *n_cut)
@@ -224,7 +267,7 @@ extern "C" int mahip_asg_pop_bubble(mahip_ctx_t *c, int max_dist, uint32_t *n_po
 {
 	uint32_t a = 0, b = 0; int it = 0;
 	CHK(clean_sweep(c, 3, max_dist, &a, &b, &it));
-	clean_timing("pop_bubble", it, a);
+	clean_timing("pop_bubble", it, a, c->clean ? (int)((CleanBufs*)c->clean)->max_tier : 0);
 	if (n_pop) *n_pop = a;
 	if (n_tips) *n_tips = b;
 	return 0;

@@ -271,3 +271,17 @@ def test_cli_matches_reference_at_baseline_scale(name, tmpdir_s):
         assert digests[0] == digests[1], "%s %s: bytes differ from the reference (raw md5, no normalisation)" % (name, " ".join(args))
         assert digests[0][1] > 1000
     os.remove(paf)
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+def test_bubble_probes_that_outgrow_their_tables(tmpdir_s, monkeypatch):
+    """a bubble probe that fills its table hands its source to a launch with bigger tables (csrc/clean.hip, tiers); with tier 0
+    shrunk to 4 slots nearly every probe of this input takes that road, twice, and the output must not change"""
+    paf = _gen(tmpdir_s, "noisy")
+    monkeypatch.setenv("MA_BUBBLE_CAP0", "4")
+    monkeypatch.setenv("MA_PIPE_TIMING", "2")
+    for args in ([], ["-p", "sg"]):
+        ref_out, _ = R.run_cli(R.REF_BIN, args, paf)
+        out, log = R.run_cli(ma.CLI_PATH, args, paf)
+        assert out == ref_out
+        assert "(tier 2)" in log, "the input was supposed to reach the third tier of probe tables"
