@@ -90,33 +90,44 @@ def run_reference(paf, out_path, runs=1):
     return best
 
 
-def pmc_traffic(kernel, workload):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC run of this same command (profiles/, made by
-    `tools/gpu_round.sh pmc`: FETCH_SIZE and WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md's HBM section
-    prescribes).  PMC counters cannot be read from inside this process: the figure is attached only when the workload is
-    the profiled one, and is labelled with its source."""
-    d = None
-    for rnd in ("r02", "r01"):  # the newest profile of this workload
+def pmc_profile(workload):
+    """the committed rocprofv3 PMC run of this same command (profiles/rNN_pmc_traffic_<workload>.json, made by `tools/gpu_round.sh pmc`:
+    FETCH_SIZE and WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md's HBM section prescribes).  PMC counters cannot be
+    read from inside this process: the figures are attached only when the workload is the profiled one, and are labelled with the file
+    and the commit the profile was taken at (its `_meta`)."""
+    for rnd in ("r03", "r02", "r01"):  # the newest profile of this workload
         path = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, workload))
         try:
             d = json.load(open(path))
-            break
         except Exception:
-            pass
-    if d is None:
-        return None, None
-    names = {k.replace("void ", ""): v for k, v in d.items()}
+            continue
+        meta = d.pop("_meta", {})
+        src = "%s @ commit %s" % (os.path.relpath(path, ROOT), meta.get("commit", "unknown (before round 3)"))
+        return {k.replace("void ", ""): v for k, v in d.items()}, src
+    return None, None
+
+
+def pmc_traffic(names, kernel):
+    """HBM bytes per launch of the timed scope `kernel` (fetch, corrected, + write) from pmc_profile()'s table"""
+    if not names:
+        return None
     per_launch = lambda v: v["fetch_bytes_x2"] + v["write_bytes"]
     scope = {"k_hit_sub<cut+flt>": ("k_hit_sub<true,", None), "k_hit_sub": ("k_hit_sub<false,", False), "k_hit_sub<gather>": ("k_hit_sub<false,", True)}.get(kernel)
     if scope:  # a timed scope of the coverage passes = one launch of each size-class kernel: their bytes add up
         parts = [v for k, v in names.items() if k.startswith(scope[0]) and (scope[1] is None or k.endswith(", true>") == scope[1])]
-        return (round(sum(per_launch(v) for v in parts)) if parts else None), os.path.relpath(path, ROOT)
-    base = kernel.split("<")[0]
+        return round(sum(per_launch(v) for v in parts)) if parts else None
+    base = {"k_hit_keys": "k_hit_keys_tiled"}.get(kernel, kernel.split("<")[0])
     hits = [v for k, v in names.items() if k.split("<")[0] == base]
     if not hits:
-        return None, None
-    tot = sum(per_launch(v) * v["launches"] for v in hits) / max(sum(v["launches"] for v in hits), 1)
-    return round(tot), os.path.relpath(path, ROOT)
+        return None
+    return round(sum(per_launch(v) * v["launches"] for v in hits) / max(sum(v["launches"] for v in hits), 1))
+
+
+# Timed scopes whose byte figure is NOT a SURVEY 8(d) row of its own: 8(d) prices the hit sort at 64 B per hit "counted once regardless of
+# digit passes" and that row is billed to the scope that moves the records (k_hit_sub<gather>: sort 64 + ma_hit_sub 48 B per hit); what the
+# key / digit / offset kernels report is the traffic of this design (keys 16, a digit pass 8 + 16, offsets 8 B per hit): `design_GBs`.
+DESIGN_ONLY = ("k_hit_keys", "k_radix_hist", "k_radix_scatter", "k_hit_goff", "scan_exclusive_u32", "k_arc_keys", "k_arc_permute")
+SORT_GROUP = ("k_hit_keys", "k_radix_hist", "k_radix_scatter", "k_hit_goff", "k_hit_sub<gather>")
 
 
 class Workload:
@@ -177,10 +188,12 @@ def main():
     ap.add_argument("--no-text", action="store_true", help="skip the text-resident leg (device-side parse inside the step)")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (cfg2, tie-rich input, CLI end to end)")
     ap.add_argument("--no-overlap", action="store_true", help="run each pass's host tail before the next pass's device part starts")
-    ap.add_argument("--tail-ctx", action="store_true", help="second context on the same GPU for the latency-bound rest of a batch (cleaners, unitigs, downloads): "
-                    "it runs beside the next batch's hit passes (mahip_tail_handoff); not measured yet, off by default")
+    ap.add_argument("--no-tail-ctx", action="store_true", help="keep the latency-bound rest of a batch (cleaners, unitigs, downloads) on the context that runs the hit passes.  "
+                    "Default: it moves to a second context on the same GPU and runs beside the next batch's hit passes (mahip_tail_handoff; round 3, measured: "
+                    "cfg4 20.0 -> 19.2 ms per step, cfg2 3.23 -> 2.79 ms)")
     ap.add_argument("--prof-steps", type=int, default=3)
     args = ap.parse_args()
+    args.tail_ctx = not args.no_tail_ctx
     args.gen_extra = [] if args.model == "lognormal" else ["-L", args.model]
     cfg_name = {(2000000, 100000000, 2, "lognormal"): "cfg4", (200000, 10000000, 1, "lognormal"): "cfg2"}.get((args.reads, args.lines, args.seed, args.model), "custom")
 
@@ -390,21 +403,35 @@ def main():
         recs = ctx.prof_get()
         ctx.prof_enable(False)
         tot_ms = sum(r["total_ms"] for r in recs) or 1.0
+        pmc, pmc_src = pmc_profile(cfg_name)
         for r in sorted(recs, key=lambda r: -r["total_ms"]):
             per = r["total_ms"] / max(r["launches"], 1)
+            gbs = round(r["alg_bytes"] / max(r["launches"], 1) / (per * 1e-3) / 1e9, 1) if per > 0 and r["alg_bytes"] > 0 else None
+            design = r["name"] in DESIGN_ONLY
+            tr = pmc_traffic(pmc, r["name"])
             kernels.append({"name": r["name"], "launches_per_step": r["launches"] / max(args.prof_steps, 1), "avg_ms": round(per, 5),
-                            "share": round(r["total_ms"] / tot_ms, 4),
-                            "alg_GBs": round(r["alg_bytes"] / max(r["launches"], 1) / (per * 1e-3) / 1e9, 1) if per > 0 and r["alg_bytes"] > 0 else None})
+                            "share": round(r["total_ms"] / tot_ms, 4), "alg_GBs": None if design else gbs, "design_GBs": gbs if design else None,
+                            # the bytes the launch really moved (rocprofv3 PMC profile of this command) / this run's launch time: cannot exceed the peak
+                            "counter_GBs": round(tr / (per * 1e-3) / 1e9, 1) if tr and per > 0 else None})
         dom = next((k for k in kernels if k["alg_GBs"]), None)
         if dom:
-            traffic, src = pmc_traffic(dom["name"], cfg_name)
+            traffic = pmc_traffic(pmc, dom["name"])
             roof = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["alg_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(dom["alg_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": src and "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)" % src,
+                    "traffic_source": pmc_src and "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)" % pmc_src,
                     # the same kernel priced by the bytes it really moved: a fused kernel cannot exceed 1 here
                     "frac_counter": round(traffic / (dom["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                     "avg_launch_ms": dom["avg_ms"], "launches_per_step": dom["launches_per_step"],
-                    "note": "achieved = SURVEY 8(d) algorithmic bytes of the reference passes this kernel replaces / HIP-event launch time"}
+                    "note": "achieved = SURVEY 8(d) algorithmic bytes of the reference passes this kernel replaces (k_hit_sub<gather>: hit sort 64 + ma_hit_sub 48 B per stored hit) / HIP-event launch time"}
+            # the sort + first coverage pass as a group: ALL kernels that make up the reference's hit sort + first ma_hit_sub, priced at 8(d)'s 64 + 48 B per hit
+            grp = [k for k in kernels if k["name"] in SORT_GROUP]
+            grp_ms = sum(k["avg_ms"] * k["launches_per_step"] for k in grp)
+            if grp_ms > 0:
+                grp_tr = [pmc_traffic(pmc, k["name"]) for k in grp]
+                grp_bytes = 112.0 * float(W.n_my)
+                roof["sort_group"] = {"kernels": [k["name"] for k in grp], "ms_per_step": round(grp_ms, 4), "alg_bytes_per_step": grp_bytes,
+                                      "achieved": round(grp_bytes / (grp_ms * 1e-3) / 1e9, 1), "frac": round(grp_bytes / (grp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "traffic": round(sum(t * k["launches_per_step"] for t, k in zip(grp_tr, grp))) if all(grp_tr) else None}
             # the whole hit chain by the same accounting: SURVEY 8(d) sums the reference's passes to 584 B per stored hit
             chain_bytes = 584.0 * float(W.n_my)
             step_s = dt / args.steps

@@ -156,7 +156,6 @@ __global__ __launch_bounds__(256) void k_hit_goff(const uint64_t *__restrict__ s
 // wave max-reduce on (length, -position).  Reads with more than 512 hits go to tier B.
 // Tier B: one 256-thread block per read, events in LDS (<= 8192) or in global scratch (any size).
 // grid of the coverage kernels (blocks of 4 waves, one read per wave at a time); env MA_SUB_BLOCKS for experiments
-static unsigned sub_lds() { static int v = -1; if (v < 0) { const char *e = getenv("MA_EXP_SUB_LDS"); v = e ? atoi(e) : 0; } return (unsigned)v; } // experiment: dynamic LDS bytes per block = an occupancy cap
 static unsigned sub_blocks() { static unsigned v = 0; if (!v) { const char *e = getenv("MA_SUB_BLOCKS"); v = e ? (unsigned)atoi(e) : 2 * MA_STREAM_BLOCKS; /* 2 x the resident capacity: the dispatcher evens out the tail (measured 2048: 0.51, 4096: 0.46, 8192: 0.45 ms; more blocks = more end-of-block atomics) */ if (v < 1) v = 1; } return v; }
 #define MA_SUB_BLOCKS sub_blocks()
 // reads per bounds fetch in the larger tiers: up to SUB_CHUNK, fewer when there are not enough reads to give every wave of the grid a chunk
@@ -168,12 +167,10 @@ static uint32_t sub_chunk(uint32_t R) { uint64_t waves = 4ull * grid_for(R, 4, M
 
 #define MA_CE(a, b) do { uint32_t lo_ = (a) < (b) ? (a) : (b), hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
 
-// what a lane keeps of a compare-exchange with its partner's value y: the smaller one in the lower lane, the larger one in the upper
-#ifdef EXP_CE_MINMAX // min / max can take the DPP operand themselves and the select reads the lane mask from scalar registers: no compare + xor on vcc
+// what a lane keeps of a compare-exchange with its partner's value y: the smaller one in the lower lane, the larger one in the upper;
+// min / max take the DPP operand themselves and the select reads the lane mask from scalar registers (round 3: -5 % on the fused pass
+// against mov_dpp + compare + xor on vcc + select)
 #define MA_KEEP(x, y, lower) ((lower) ? ((x) < (y) ? (x) : (y)) : ((x) < (y) ? (y) : (x)))
-#else
-#define MA_KEEP(x, y, lower) ((((x) < (y)) != (lower)) ? (y) : (x))
-#endif
 // Value of lane (lane ^ M) for a compile-time M.  Exchanges inside a row of 16 lanes are DPP modifiers of a VALU move
 // (quad_perm, row_half_mirror, row_mirror, row_ror, banked row_shl/shr): no LDS crossbar round trip, no s_waitcnt.
 // Only the exchanges across rows (16, 31, 63) go through ds_bpermute.
@@ -339,21 +336,6 @@ __device__ __forceinline__ void gather_recs(const SubGather &g, const GKeys &k, 
 		r.a[h] = p[0]; r.b[h] = p[1];
 	}
 }
-// one dword into column[beg_s + voff/4] through a raw buffer descriptor over [beg_s, beg_s + bytes_s/4): out-of-range lanes are dropped by
-// the hardware's bounds check -- a predicated store without control flow (wave-uniform beg_s / bytes_s)
-__device__ __forceinline__ void col_store_bounded(uint32_t *col, uint32_t beg_s, uint32_t bytes_s, uint32_t voff, uint32_t val)
-{
-	__amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(col + beg_s, 0, (int)bytes_s, 0x00020000); // gfx9 raw buffer, dword format
-	__builtin_amdgcn_raw_buffer_store_b32(val, r, (int)voff, 0, 0);
-}
-__device__ __forceinline__ void gather_store_bounded(const HitCols &c, const SubGather &g, uint32_t beg_s, uint32_t bytes_s, uint32_t voff, uint32_t j, uint4 a, uint4 b)
-{
-	col_store_bounded(c.qid, beg_s, bytes_s, voff, a.y); col_store_bounded(c.qs, beg_s, bytes_s, voff, a.x);
-	col_store_bounded(c.qe, beg_s, bytes_s, voff, a.z); col_store_bounded(c.tn, beg_s, bytes_s, voff, a.w);
-	col_store_bounded(c.ts, beg_s, bytes_s, voff, b.x); col_store_bounded(c.te, beg_s, bytes_s, voff, b.y);
-	col_store_bounded(c.ml, beg_s, bytes_s, voff, b.z); col_store_bounded(c.bl, beg_s, bytes_s, voff, b.w & ~DEAD);
-	col_store_bounded(g.sidx, beg_s, bytes_s, voff, j);
-}
 __device__ __forceinline__ void gather_store(const HitCols &c, const SubGather &g, uint32_t i, uint32_t j, uint4 a, uint4 b)
 {
 	c.qid[i] = a.y; c.qs[i] = a.x; c.qe[i] = a.z; c.tn[i] = a.w;
@@ -445,13 +427,8 @@ __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q,
 // Three instantiations per fusion mode share the work by read size, so that each runs at the occupancy its register
 // need allows: CLS 0 = reads with <= 128 hits (4 events per lane, 8 waves/SIMD, software-pipelined loads), CLS 1 = 129..256
 // hits (16 events per lane), CLS 2 = 257..512 hits (32 events per lane); larger reads go to the block kernel (tier B).
-#ifdef EXP_SUB_WAVES // experiment: occupancy target of the coverage kernels
-#define SUB_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(EXP_SUB_WAVES, 8)))
-#else
-#define SUB_WAVES_ATTR
-#endif
 template <bool FUSE, int CLS, bool GATHER = false>
-__global__ __launch_bounds__(256) SUB_WAVES_ATTR void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
+__global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
                                                   int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
                                                   uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr, SubFuse f, SubGather g)
 {
@@ -473,22 +450,14 @@ __global__ __launch_bounds__(256) SUB_WAVES_ATTR void k_hit_sub(HitCols c, const
 			const uint32_t beg = cur.beg, end = cur.end, H = end - beg;
 			// (1) the columns of this read FIRST, and without a branch: the memory counter is in order, so a store issued after the next
 			// read's loads would have to be acknowledged before those loads count as complete -- every sweep would start by waiting for
-			// its predecessor's write-back.  Lanes without a slot write to the spare slots behind the arrays (the variant every number in
-			// profiles/ was measured with); EXP_BOUNDED_STORE masks them with the bounds check of a buffer descriptor that covers exactly
-			// this read's slots instead (a read of another size class: zero records) -- to be measured
-#ifdef EXP_BOUNDED_STORE
-			const uint32_t beg_s = __builtin_amdgcn_readfirstlane(beg), bytes_s = __builtin_amdgcn_readfirstlane(H <= 128u ? H * 4u : 0u);
-#pragma unroll
-			for (int h = 0; h < 2; ++h) {
-				gather_store_bounded(c, g, beg_s, bytes_s, (h * 64 + lane) * 4u, cur.j[h], cur.a[h], cur.b[h]);
-			}
-#else
+			// its predecessor's write-back.  Lanes without a slot write to the spare slots behind the arrays.  (Masking them with the bounds
+			// check of a raw buffer descriptor instead was measured in round 3: 6.60 vs 6.80 ms alone, nothing when combined with the other
+			// changes -- within the box's noise, dropped.)
 #pragma unroll
 			for (int h = 0; h < 2; ++h) {
 				const uint32_t i = beg + h * 64 + lane;
 				gather_store(c, g, (H <= 128u && i < end) ? i : g.n + lane, cur.j[h], cur.a[h], cur.b[h]);
 			}
-#endif
 			__builtin_amdgcn_sched_barrier(0);
 			// (2) the fetches of the reads behind it
 			gather_recs(g, kn, lane, nxt);
@@ -1173,21 +1142,21 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 	if (c->gather_pending && !fuse_gather) CHK(hits_need_cols(c, "mahip_hits_sub"));
 	if (fuse_gather) { // the sweep fetches the records itself and writes the columns on the way
 		SubGather g = {(const uint64_t*)P<uint64_t>(c->key[c->gk_gen]), c->d_aos, P<uint32_t>(c->sidx), c->gk_bi, (uint32_t)c->n_hits, sub_chunk(R)};
-		ProfScope ps(c, "k_hit_sub<gather>", (76.0 + 48.0) * (double)c->n_hits + 8.0 * R); // the sort's data movement + ma_hit_sub
-		hipLaunchKernelGGL((k_hit_sub<false, 0, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		ProfScope ps(c, "k_hit_sub<gather>", (64.0 + 48.0) * (double)c->n_hits); // hit sort 64 (32 r + 32 w, counted once whatever the digit passes) + ma_hit_sub 48 B per stored hit
+		hipLaunchKernelGGL((k_hit_sub<false, 0, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-		hipLaunchKernelGGL((k_hit_sub<false, 1, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 1, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-		hipLaunchKernelGGL((k_hit_sub<false, 2, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 2, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
 		c->gather_pending = false;
 	} else if (R) {
 		ProfScope ps(c, "k_hit_sub", 48.0 * (double)c->n_hits + 8.0 * R); // 32 r + 8 w events + 8 r events per stored hit
-		hipLaunchKernelGGL((k_hit_sub<false, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, nog);
-		hipLaunchKernelGGL((k_hit_sub<false, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, nog);
-		hipLaunchKernelGGL((k_hit_sub<false, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, nog);
 	}
 	if (R) { // tier B always runs behind the register tiers on a small grid: it finds its work list (usually empty) in the device counter
@@ -1219,11 +1188,11 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
 	SubFuse f = {(const uint2*)P<uint2>(c->sub[cut_slot]), min_span, max_hang, min_ovlp, P<uint8_t>(c->r_live)};
 	if (R) {
 		ProfScope ps(c, "k_hit_sub<cut+flt>", (80.0 + 80.0 + 48.0) * (double)c->n_hits + 8.0 * R); // cut 80 + flt 80 + sub 48 B per hit
-		hipLaunchKernelGGL((k_hit_sub<true, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<true, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(R)});
-		hipLaunchKernelGGL((k_hit_sub<true, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<true, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(R)});
-		hipLaunchKernelGGL((k_hit_sub<true, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), sub_lds(), c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<true, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(R)});
 	}
 	if (R) {

@@ -202,10 +202,9 @@ __device__ __forceinline__ uint64_t wv_sum_u64(uint64_t x)
 	return x;
 }
 // ---- wave64 scans for a FULL wave (all 64 lanes active), as the coverage sweep needs them.
-// EXP_DPP_SCAN: DPP row shifts + the gfx9 row broadcasts (row_bcast:15 / :31, the sequence LLVM's atomic optimizer emits for wave64) -- one
-// VALU instruction per step, nothing through the LDS crossbar.  Default (the form every number in profiles/ was measured with): __shfl_up,
-// i.e. one ds_bpermute round trip per step.  The coverage sweep of one read chains 18 such steps; to be measured.
-#ifdef EXP_DPP_SCAN
+// DPP row shifts + the gfx9 row broadcasts (row_bcast:15 / :31, the sequence LLVM's atomic optimizer emits for wave64): one VALU
+// instruction per step, nothing through the LDS crossbar (round 3: -6 % on the fused coverage pass against the __shfl_up form, whose 18
+// chained steps per read were ds_bpermute round trips).
 #define WV_DPP(old, x, ctrl, rm) __builtin_amdgcn_update_dpp((int)(old), (int)(x), (ctrl), (rm), 0xf, false)
 __device__ __forceinline__ int wv_scan_incl_i32(int x, unsigned lane)
 {
@@ -246,21 +245,6 @@ __device__ __forceinline__ uint64_t wv_max_u64_full(uint64_t x)
 // the value one lane holds, for all (src is the same in every lane)
 __device__ __forceinline__ uint32_t wv_read_lane_u32(uint32_t x, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)x, src); }
 #undef WV_DPP
-#else
-__device__ __forceinline__ int wv_scan_incl_i32(int x, unsigned lane)
-{
-	for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o, 64); if (lane >= (unsigned)o) x += y; }
-	return x;
-}
-__device__ __forceinline__ uint32_t wv_scan_last_u32(uint32_t x, uint32_t none, unsigned lane)
-{
-	for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o, 64); if (lane >= (unsigned)o && x == none) x = y; }
-	return x;
-}
-__device__ __forceinline__ uint32_t wv_prev_lane_u32(uint32_t x, uint32_t fill, unsigned lane) { uint32_t y = __shfl_up(x, 1, 64); return lane == 0 ? fill : y; }
-__device__ __forceinline__ uint64_t wv_max_u64_full(uint64_t x) { return wv_max_u64(x); }
-__device__ __forceinline__ uint32_t wv_read_lane_u32(uint32_t x, int src) { return __shfl(x, src, 64); }
-#endif
 // one atomicAdd per wave of the number of lanes with p set
 __device__ __forceinline__ void wv_count_add(unsigned long long *ctr, int p)
 {

@@ -166,23 +166,6 @@ __device__ __forceinline__ uint64_t paf_name(PTR &p, uint32_t beg, uint32_t end,
 	return h;
 }
 
-// The staged text seen through a one-word window.  A line is scanned front to back (TAB positions, then column after column), and every byte
-// used to be an LDS load of its own with the whole LDS latency in front of the next one -- at two blocks per CU there are not enough waves to
-// hide that.  One aligned 8-byte load now serves eight consecutive bytes; the bytes come out of registers.  (EXP_PARSE_BYTEWISE: the old reads.)
-struct LdsBytes {
-	const unsigned long long *w; // the staged tile (16-byte aligned)
-	uint32_t off;                // where the line starts inside it
-	uint32_t idx;
-	unsigned long long cur;
-	__device__ __forceinline__ LdsBytes(const unsigned char *tile, uint32_t line_off) : w((const unsigned long long*)tile), off(line_off), idx(0xffffffffu), cur(0) {}
-	__device__ __forceinline__ unsigned operator[](uint32_t pos)
-	{
-		const uint32_t a = off + pos, i = a >> 3;
-		if (i != idx) { cur = w[i]; idx = i; }
-		return (unsigned)(cur >> ((a & 7u) * 8u)) & 0xffu;
-	}
-};
-
 // the column starts of the block's 256 lines in LDS, column-major: lane i's k-th entry sits at [k][i], so a wave's accesses never share a bank
 struct FsCols {
 	uint32_t *b;
@@ -198,30 +181,6 @@ __device__ __forceinline__ uint32_t paf_tabs(PTR &p, uint32_t l, FsCols fs)
 		if (p[pos] == '\t') { ++t; if (t < 12) fs[t] = pos + 1; }
 	return t;
 }
-#ifndef EXP_PARSE_BYTEWISE
-// the same over the 8-byte words of the tile: a SWAR mask of the bytes that equal TAB (exact, as nl_mask), then only the set bits are visited
-__device__ __forceinline__ uint32_t paf_tabs(LdsBytes &p, uint32_t l, FsCols fs)
-{
-	uint32_t t = 0;
-	fs[0] = 0;
-	if (l == 0) return 0;
-	const uint32_t a0 = p.off, a1 = p.off + l; // byte range of the line inside the tile
-	for (uint32_t i = a0 >> 3; i <= (a1 - 1) >> 3; ++i) {
-		const unsigned long long x = p.w[i] ^ 0x0909090909090909ull;
-		const unsigned long long s7 = 0x7f7f7f7f7f7f7f7full;
-		unsigned long long m = ~(((x & s7) + s7) | x | s7); // 0x80 in every byte of the word that is a TAB
-		const uint32_t base = i << 3;
-		if (base < a0) m &= ~0ull << ((a0 - base) * 8u);                  // bytes in front of the line
-		if (base + 8u > a1) m &= ~0ull >> ((base + 8u - a1) * 8u);       // bytes behind it
-		for (; m; m &= m - 1) {
-			const uint32_t pos = base + ((uint32_t)(__ffsll((long long)m) - 1) >> 3) - a0;
-			++t;
-			if (t < 12) fs[t] = pos + 1;
-		}
-	}
-	return t;
-}
-#endif
 
 struct PafLine { uint32_t valid, hasbl, rev, ql, qs, qe, tl, ts, te, ml, bl, tnoff, qlen, tlen; uint64_t hq, ht; };
 
@@ -272,11 +231,7 @@ __global__ __launch_bounds__(256) void k_paf_parse(const unsigned char *__restri
 		const uint32_t l = (uint32_t)(lstart[i + 1] - 1 - ls);
 		PafLine r;
 		const FsCols fs = { s_fs + threadIdx.x };
-#ifdef EXP_PARSE_BYTEWISE
 		if (in_lds) paf_line((const unsigned char*)(s_text + (ls - a0)), l, fs, r); // LDS byte reads
-#else
-		if (in_lds) paf_line(LdsBytes(s_text, (uint32_t)(ls - a0)), l, fs, r);      // LDS reads through a register window
-#endif
 		else paf_line(text + ls, l, fs, r);                                              // oversized lines: straight from global memory
 		valid = r.valid;
 		pass = valid && !(r.qe - r.qs < (uint32_t)min_span || r.te - r.ts < (uint32_t)min_span || (int)r.ml < min_match); // hit.c:85

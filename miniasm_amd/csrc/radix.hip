@@ -74,30 +74,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
 		k[it] = i < n ? kin[i] : 0;
 		if (HAS_VAL) v[it] = i < n ? vin[i] : 0;
 	}
-#ifdef EXP_RS_ATOMIC_RANK
-	// Stable rank inside the wave = lanes with my digit before me + the digit's count over the earlier items.  The measured form (#else) keeps that
-	// count in LDS with a read, two wave syncs and a write PER ITEM -- sixteen dependent LDS round trips per tile.  Here the first lane of every
-	// digit group adds its group's size with ONE returning LDS atomic per item (a wave's LDS operations execute in issue order, so item it is
-	// counted before item it + 1), all sixteen are in flight together, and the groups pick up their leader's old value afterwards.  To be measured.
-	uint32_t prev[RS_ITEMS], lead[RS_ITEMS];
-#pragma unroll
-	for (int it = 0; it < RS_ITEMS; ++it) {
-		size_t i = wbase + (size_t)it * 64 + lane;
-		int valid = i < n;
-		unsigned d = (unsigned)(k[it] >> shift) & mask;
-		uint64_t peers = wv_ballot(valid);
-		for (int b = 0; b < nbits; ++b) {
-			uint64_t bal = wv_ballot((d >> b) & 1);
-			peers &= ((d >> b) & 1) ? bal : ~bal;
-		}
-		r[it] = (uint32_t)__popcll(peers & lt);
-		lead[it] = peers ? (uint32_t)(__ffsll((long long)peers) - 1) : lane;
-		prev[it] = 0;
-		if (valid && (peers & lt) == 0) prev[it] = atomicAdd(&s_cnt[wave][d], (uint32_t)__popcll(peers));
-	}
-#pragma unroll
-	for (int it = 0; it < RS_ITEMS; ++it) r[it] += __shfl(prev[it], (int)lead[it], 64);
-#else
 #pragma unroll
 	for (int it = 0; it < RS_ITEMS; ++it) { // stable rank inside the wave: lanes with my digit before me + earlier items
 		size_t i = wbase + (size_t)it * 64 + lane;
@@ -114,7 +90,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
 		wv_sync();
 		r[it] = prev + (uint32_t)__popcll(peers & lt);
 	}
-#endif
 	__syncthreads();
 	{ // thread t owns RS_DPT consecutive digits: waves' counts -> exclusive over waves; tile counts -> exclusive over digits
 		constexpr int RS_DPT = RS_BINS / RS_THREADS;

@@ -92,11 +92,11 @@ def test_randomised_reference_vs_kernels_on_cpu(mode, emu_built):
     assert r.returncode == 0 and "0 mismatches" in r.stdout.splitlines()[-1], r.stdout[-3000:]
 
 
-@pytest.mark.parametrize("mode", ["default", "tail_ctx"])
+@pytest.mark.parametrize("mode", ["default", "no_tail_ctx"])
 def test_bench_py_runs_on_the_cpu_build(mode, emu_built, tmp_path):
     """bench.py itself -- Workload (file -> device parse -> records by read range), Runner with its worker thread, the profiled steps, the
     text-resident leg, the reference run and the GFA comparison, the JSON line -- executed against the CPU build of the kernels with a numpy-backed
-    stand-in for the few torch calls it makes (tests/emu/fake_torch).  `tail_ctx`: the second context + hand-over thread of `--tail-ctx`.
+    stand-in for the few torch calls it makes (tests/emu/fake_torch).  Default: the second context + hand-over thread; `no_tail_ctx`: one context.
     Numbers mean nothing here; the control flow, the parity check and the shape of the line do."""
     import json
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "miniasm_ref")):
@@ -106,8 +106,8 @@ def test_bench_py_runs_on_the_cpu_build(mode, emu_built, tmp_path):
     env["MINIASM_AMD_LIB"] = os.path.join(EMU, "_build", "libminiasm_amd_emu.so")
     env["MA_BENCH_DIR"] = str(tmp_path)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "2500", "--lines", "70000", "--seed", "5", "--steps", "3", "--warmup", "1", "--no-legs"]
-    if mode == "tail_ctx":
-        cmd.append("--tail-ctx")
+    if mode == "no_tail_ctx":
+        cmd.append("--no-tail-ctx")
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -119,7 +119,9 @@ def test_bench_py_runs_on_the_cpu_build(mode, emu_built, tmp_path):
     assert d["gfa_identical"] is True and d["parity"]["gfa_md5"] == d["parity"]["ref_md5"]
     assert d["roofline"]["bound"] == "hbm" and d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["cores"] == 1
     assert d["from_text"] and d["from_text"]["value"] > 0
-    assert ("second context" in d["config"]["pipelining"]) == (mode == "tail_ctx")
+    assert ("second context" in d["config"]["pipelining"]) == (mode == "default")
+    assert d["roofline"]["sort_group"]["alg_bytes_per_step"] == 112.0 * d["config"]["per_gpu_hits"] and "k_hit_sub<gather>" in d["roofline"]["sort_group"]["kernels"]
+    assert all(k["alg_GBs"] is None for k in d["kernels"] if k["name"] in ("k_hit_keys", "k_radix_scatter", "k_radix_hist", "k_hit_goff"))
 
 
 def test_bench_py_on_two_ranks_on_the_cpu_build(emu_built, tmp_path):
@@ -143,7 +145,7 @@ def test_bench_py_on_two_ranks_on_the_cpu_build(emu_built, tmp_path):
     for rank in range(2):
         e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(20000 + os.getpid() % 20000),
                  MA_FAKE_DIST_DIR=str(tmp_path), MA_BENCH_ONE_GPU_DEBUG="1")
-        procs.append(subprocess.Popen(base + ["--gpus", "2", "--tail-ctx"], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        procs.append(subprocess.Popen(base + ["--gpus", "2"], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
         try:

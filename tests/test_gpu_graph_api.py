@@ -109,10 +109,8 @@ def test_tail_on_a_second_context_gives_the_same_output(case, tmpdir_s):
     c1.close(); c2.close()
 
 
-@pytest.mark.skipif(not getattr(ma, "IS_EMU", False) and os.environ.get("MA_TEST_TAIL_CTX") != "1",
-                    reason="two host threads on two contexts: validated on the CPU build; set MA_TEST_TAIL_CTX=1 to run it on the GPU (bench.py --tail-ctx is opt-in until measured)")
 def test_streaming_with_the_tail_on_a_second_context_and_thread(tmpdir_s):
-    """the shape of bench.py --tail-ctx: this thread runs the hit passes of batch k+1 on the first context while a worker thread cleans batch k's
+    """the shape of bench.py's default pipelining (round 3: measured, adopted): this thread runs the hit passes of batch k+1 on the first context while a worker thread cleans batch k's
     graph and builds its unitigs on the second; a semaphore keeps the hand-over from overwriting a context that is still in use"""
     import queue
     import threading

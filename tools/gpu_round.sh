@@ -55,32 +55,21 @@ bench)
   grep -E "^\[bench\]|rc=" gpurun_out/bench.log | tail -12; cat gpurun_out/bench.json ;;
 tailctx)
   # the device tail on a second context (bench.py --tail-ctx, mahip_tail_handoff): same workload with and without, cfg4 and cfg2, GFA compared
-  MA_TEST_TAIL_CTX=1 timeout 900 python -m pytest tests/test_gpu_graph_api.py -m gpu -q --tb=short -p no:cacheprovider -k "second_context or streaming" > gpurun_out/tests_tailctx.log 2>&1; echo "tests rc=$?"
-  for v in "" "--tail-ctx"; do for cfg in "" "--reads 200000 --lines 10000000 --seed 1"; do
+  timeout 900 python -m pytest tests/test_gpu_graph_api.py -m gpu -q --tb=short -p no:cacheprovider -k "second_context or streaming" > gpurun_out/tests_tailctx.log 2>&1; echo "tests rc=$?"
+  for v in "" "--no-tail-ctx"; do for cfg in "" "--reads 200000 --lines 10000000 --seed 1"; do
     timeout 900 python bench.py --no-cpu --no-legs --no-text --prof-steps 0 --steps 20 --warmup 3 $cfg $v > gpurun_out/bench_tailctx.json 2> gpurun_out/bench_tailctx.log; echo "[$cfg $v] rc=$?"
     python3 -c "import json; d=json.load(open('gpurun_out/bench_tailctx.json')); print('   ms_per_step %.3f  value %.3g' % (d['ms_per_step'], d['value']))"
   done; done ;;
 expbuild)
-  # run this HERE before the GPU visit (hipcc cross-compiles): the experiment libraries travel with the snapshot
-  bash tools/variants.sh build base:"" bounded:"-DEXP_BOUNDED_STORE" dppscan:"-DEXP_DPP_SCAN" rsatomic:"-DEXP_RS_ATOMIC_RANK" minmax:"-DEXP_CE_MINMAX" \
-       all3:"-DEXP_BOUNDED_STORE -DEXP_DPP_SCAN -DEXP_RS_ATOMIC_RANK" bytewise:"-DEXP_PARSE_BYTEWISE" | tail -8 ;;
-expstore)
-  # EXP_BOUNDED_STORE: masked column stores of the first coverage pass through a buffer descriptor instead of the spare slots
-  # EXP_DPP_SCAN: the coverage sweep's three wave scans out of DPP row shifts / row broadcasts instead of ds_bpermute round trips
-  # EXP_RS_ATOMIC_RANK: the radix scatter's per-item digit counts as 16 pipelined returning LDS atomics instead of 16 read / sync / write rounds
-  # EXP_CE_MINMAX: the sort's compare-exchange as v_min_u32_dpp / v_max_u32_dpp + select instead of mov_dpp + compare + xor on vcc + select (-9 % instructions, +3 % VALU)
-  [ -f build/variants/all3/libminiasm_amd.so ] || bash tools/gpu_round.sh expbuild
-  for v in dppscan rsatomic bounded minmax; do # parity first: a variant that is not bit-exact is not worth timing
+  # run this HERE before the GPU visit (hipcc cross-compiles): the experiment libraries travel with the snapshot.
+  # VARIANTS="name:-DFLAG name2:'-DA -DB'" (always builds `base`)
+  eval "bash tools/variants.sh build base:\"\" $VARIANTS" | tail -8 ;;
+exprun)
+  # parity first (a variant that is not bit-exact is not worth timing), then bench.py per variant
+  for v in $VARIANT_NAMES; do
     MINIASM_AMD_LIB=$PWD/build/variants/$v/libminiasm_amd.so timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line -p no:cacheprovider -x > gpurun_out/tests_var_$v.log 2>&1; echo "[$v] parity rc=$?"
   done
-  bash tools/variants.sh run base bounded dppscan rsatomic minmax all3 ;;
-expparse)
-  # the parse kernel with byte-wise LDS reads (the round-2 measured form) against the register-window reader
-  [ -f build/variants/bytewise/libminiasm_amd.so ] || bash tools/gpu_round.sh expbuild
-  for v in base bytewise; do
-    MINIASM_AMD_LIB=$PWD/build/variants/$v/libminiasm_amd.so timeout 900 python bench.py --no-cpu --no-legs --steps 4 --warmup 1 --prof-steps 0 > gpurun_out/bench_parse_$v.json 2> gpurun_out/bench_parse_$v.log; echo "[$v] rc=$?"
-    python3 -c "import json,sys; d=json.load(open('gpurun_out/bench_parse_$v.json')); print('   from_text %.2f ms/step, setup parse+dictionary %.3f s' % (d['from_text']['ms_per_step'], d['setup']['parse_dictionary_s']))"
-  done ;;
+  bash tools/variants.sh run base $VARIANT_NAMES ;;
 benchcfg2)
   timeout 900 python bench.py --reads 200000 --lines 10000000 --seed 1 --no-legs > gpurun_out/bench_cfg2.json 2> gpurun_out/bench_cfg2.log; echo "rc=$?" >> gpurun_out/bench_cfg2.log
   grep -E "^\[bench\]|rc=" gpurun_out/bench_cfg2.log | tail -8; cat gpurun_out/bench_cfg2.json ;;
