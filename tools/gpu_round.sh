@@ -23,6 +23,14 @@ benchtiming)
 import json; d=json.load(open('gpurun_out/bench_timing.json')); print(d['ms_per_step'], d['e2e'], d['setup']); [print(k['name'], k['launches_per_step'], k['avg_ms']) for k in d['kernels'][:8]]" ;;
 e2ecfg4)
   NOREF=1 bash tools/e2e_cfg4.sh | tail -60 ;;
+probe)
+  # random 32-byte-record gather ceiling + what FETCH_SIZE reports for that access pattern (tools/probes/gather_probe.hip, built here by hipcc)
+  tools/probes/gather_probe > gpurun_out/gather_probe.txt 2>&1; cat gpurun_out/gather_probe.txt
+  rm -rf gpurun_out/probe_pmc; mkdir -p gpurun_out/probe_pmc
+  (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /root/repo/gpurun_out/probe_pmc -o r --output-format csv -- /root/repo/tools/probes/gather_probe > /dev/null 2>&1); echo "probe pmc rc=$?"
+  python tools/pmc_generic.py gpurun_out/probe_pmc --filter k_ --each >> gpurun_out/gather_probe.txt 2>&1; tail -30 gpurun_out/gather_probe.txt ;;
+bigthree)
+  bash tools/e2e_three.sh ;;
 bignoisy)
   MA_PIPE_TIMING=2 bash tools/e2e_big.sh 1000000 50000000 3 "-L uniform -d 0.35 -x 0.03" ref | tail -70 ;;
 ties)
