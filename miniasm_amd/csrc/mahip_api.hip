@@ -45,11 +45,44 @@ int ctr_zero(mahip_ctx *c)
 	return 0;
 }
 
+// The counters come back through a mailbox: a one-wave kernel behind the pass copies the 64 words into host-coherent pinned memory and then
+// raises a sequence number there; the host spins on that word.  A copy + hipStreamSynchronize costs a blit launch plus the runtime's wake-up
+// (20-30 us of idle GPU per fetch in the round-3 kernel trace, about 50 fetches per input: 1.3 ms of a 21 ms pass at cfg4, 40 % of one at cfg2);
+// the spin sees the word a microsecond or two after the kernel wrote it.  h_ctr[64] = the sequence word.  MA_CTR_COPY=1: the old copy + sync.
+__global__ __launch_bounds__(64) void k_ctr_publish(const unsigned long long *__restrict__ ctr, volatile unsigned long long *h, unsigned long long seq)
+{
+	h[threadIdx.x] = ctr[threadIdx.x];
+	__threadfence_system();
+	__syncthreads();
+	if (threadIdx.x == 0) { h[64] = seq; __threadfence_system(); }
+}
+
+static int ctr_mode()
+{
+	static int v = -1;
+	if (v < 0) v = getenv("MA_CTR_COPY") ? 0 : 1;
+	return v;
+}
+
 int ctr_fetch(mahip_ctx *c)
 {
-	HIPCHK(hipMemcpyAsync(c->h_ctr, c->ctr.p, 64 * 8, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipStreamSynchronize(c->st));
-	return 0;
+	if (!ctr_mode()) {
+		HIPCHK(hipMemcpyAsync(c->h_ctr, c->ctr.p, 64 * 8, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));
+		return 0;
+	}
+	const unsigned long long seq = ++c->ctr_seq;
+	hipLaunchKernelGGL(k_ctr_publish, dim3(1), dim3(64), 0, c->st, (const unsigned long long*)c->ctr.p, (volatile unsigned long long*)c->h_ctr, seq);
+	volatile unsigned long long *flag = (volatile unsigned long long*)c->h_ctr + 64;
+	for (unsigned long spins = 0;; ++spins) {
+		if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
+		__builtin_ia32_pause();
+		if ((spins & 0xffff) == 0xffff) { // every few hundred microseconds: has the stream ended without the word (a fault)?
+			hipError_t e = hipStreamQuery(c->st);
+			if (e == hipSuccess) { if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0; HIPCHK(hipStreamSynchronize(c->st)); if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0; mahip_set_error("ctr_fetch: the stream is idle but the counters never arrived"); return -1; }
+			if (e != hipErrorNotReady) { mahip_set_error("ctr_fetch: %s", hipGetErrorString(e)); return -1; }
+		}
+	}
 }
 
 // Keep the process on the NUMA node the GPU hangs off: staging copies (page cache -> pinned slots -> DMA) and the driver's own
@@ -113,6 +146,7 @@ extern "C" mahip_ctx_t *mahip_create(int device, void *stream)
 	if (device < 0 || device >= n) { mahip_set_error("mahip_create: device %d out of range (0..%d)", device, n - 1); return nullptr; }
 	if (hipSetDevice(device) != hipSuccess) { mahip_set_error("mahip_create: hipSetDevice(%d) failed", device); return nullptr; }
 	pin_to_gpu_node(device);
+	if (getenv("MA_SYNC_SPIN")) (void)hipSetDeviceFlags(hipDeviceScheduleSpin); // experiment: the runtime's own waits spin instead of blocking
 	mahip_ctx *c = new mahip_ctx();
 	c->dev = device;
 	if (stream) c->st = (hipStream_t)stream, c->own_stream = false;
@@ -121,8 +155,8 @@ extern "C" mahip_ctx_t *mahip_create(int device, void *stream)
 		c->own_stream = true;
 	}
 	if (dev_reserve(c, c->ctr, 64 * 8) != 0) { delete c; return nullptr; }
-	if (hipHostMalloc((void**)&c->h_ctr, 64 * 8, hipHostMallocDefault) != hipSuccess) { mahip_set_error("mahip_create: hipHostMalloc failed"); delete c; return nullptr; }
-	memset(c->h_ctr, 0, 64 * 8);
+	if (hipHostMalloc((void**)&c->h_ctr, 72 * 8, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { mahip_set_error("mahip_create: hipHostMalloc failed"); delete c; return nullptr; }
+	memset(c->h_ctr, 0, 72 * 8);
 	if (hipMemsetAsync(c->ctr.p, 0, 64 * 8, c->st) != hipSuccess) { mahip_set_error("mahip_create: memset failed"); delete c; return nullptr; }
 	{ const char *s = getenv("MA_EXACT_TIES"); c->tie_mode = s == 0 || *s == 0 ? 2 : atoi(s) != 0 ? 1 : 0; } // unset: automatic
 	return c;

@@ -93,7 +93,9 @@ struct mahip_ctx {
 	DevBuf big0, big1;        // lazily allocated global scratch for oversized groups
 	DevBuf marks;             // trans-reduce tier-2 mark arrays
 	DevBuf sgmask;            // ma_sg_gen: one candidate bit per hit slot
-	uint64_t *h_ctr = nullptr; // pinned host mirror of ctr
+	uint64_t *h_ctr = nullptr; // pinned host mirror of ctr (host-coherent; word 64 = sequence number of the last publish, see ctr_fetch)
+	unsigned long long ctr_seq = 0;
+	uint32_t scan_ticket = 0, scan_epoch = 0; // scan.hip: tickets handed out so far, launch number
 	void *xfer = nullptr;      // staged-copy worker pool (xfer.hip)
 	void *paf = nullptr;       // text-ingest buffers (paf.hip)
 

@@ -39,7 +39,8 @@ typedef struct emu_event *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipStreamDefault = 0, hipStreamNonBlocking = 1 };
 enum { hipEventDefault = 0, hipEventBlockingSync = 1, hipEventDisableTiming = 2 };
-enum { hipHostMallocDefault = 0 };
+enum { hipHostMallocDefault = 0, hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000 };
+enum { hipDeviceScheduleSpin = 1 };
 
 struct dim3 {
 	unsigned x, y, z;
@@ -178,6 +179,7 @@ struct BufRsrc { char *base; uint32_t num_records; };
 #define __syncthreads() emu::block_barrier()
 #define __threadfence() ((void)0)
 #define __threadfence_block() ((void)0)
+#define __threadfence_system() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define __builtin_amdgcn_mov_dpp(src, ctrl, rm, bm, bc) emu::mov_dpp(EMU_OP, (int)(src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu::update_dpp(EMU_OP, (int)(old), (int)(src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_ds_bpermute(addr, v) emu::ds_bpermute(EMU_OP, (int)(addr), (int)(v))
@@ -279,6 +281,8 @@ hipError_t hipStreamCreate(hipStream_t *st);
 hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t st);
 hipError_t hipStreamSynchronize(hipStream_t st);
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; } /* launches are synchronous here */
+static inline hipError_t hipSetDeviceFlags(unsigned) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e);
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);
