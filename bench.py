@@ -264,9 +264,7 @@ def main():
     L.ma_pipeline_tail_finish_mem.restype = C.c_int
     L.ma_pipeline_tail_finish_mem.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
 
-    class ShardStats(C.Structure):  # host/ma_host.h: ma_shard_stats_t
-        _fields_ = [("n_rem1", C.c_uint64), ("n_rem2", C.c_uint64), ("n_hits", C.c_uint64), ("n_seq_new", C.c_uint32), ("n_arc", C.c_uint32), ("n_loc_arc", C.c_uint32),
-                    ("n_red", C.c_uint32), ("n_multi", C.c_uint32), ("n_asymm", C.c_uint32), ("tie_groups", C.c_uint64), ("push_conflicts", C.c_uint64), ("tie_repaired", C.c_int)]
+    ShardStats = ma.ShardStats
     L.ma_pipeline_head_sharded.restype = C.c_int
     L.ma_pipeline_head_sharded.argtypes = [vp, C.POINTER(ma.MaOpt), C.c_uint32, C.c_int, C.POINTER(ShardStats)]
     overlap = not args.no_overlap
@@ -284,6 +282,7 @@ def main():
         def __init__(self, W):
             self.W = W
             self.out = {"n": 0, "rc": 0, "buf": None}
+            self.head_wall, self.tail_wall, self.last_stats = [], [], None  # sharded mode: wall time of each head on this rank / of each tail on rank 0
             self.q = queue.Queue(maxsize=1)  # one batch may wait while another is being finished
             self.worker = None
             # --tail-ctx: the device tail of a batch (graph cleaning, unitigs, downloads -- many small launches and counter fetches) moves to a
@@ -294,9 +293,11 @@ def main():
                 self.worker = threading.Thread(target=self._work, daemon=True)
                 self.worker.start()
 
-        def _finish(self, job):
+        def _finish(self, job, t_start=None):
             b, l = vp(0), C.c_size_t(0)
             rc = L.ma_pipeline_tail_finish_mem(job, C.byref(b), C.byref(l))
+            if t_start is not None:
+                self.tail_wall.append(time.perf_counter() - t_start)
             if self.out["buf"]:
                 L.free_buf(self.out["buf"])
             self.out["n"], self.out["rc"], self.out["buf"] = l.value, self.out["rc"] or rc, b  # the last output is kept for the parity check
@@ -305,15 +306,17 @@ def main():
             while True:
                 job = self.q.get()
                 try:
+                    t_tail = None
                     if isinstance(job, tuple):  # (status words of the head): the device tail is still to do, on the second context
                         st = job[0]
+                        t_tail = time.perf_counter()
                         try:
                             job = L.ma_pipeline_tail_fetch(self.ctx2.h, C.byref(opt), self.W.d, b"ug", 100, C.byref(st))
                         finally:
                             self.ctx2_free.release()
                         assert job
                     if job is not None:
-                        self._finish(job)
+                        self._finish(job, t_tail)
                 except Exception as e:  # never leave the fence waiting on a dead worker
                     self.out["rc"] = self.out["rc"] or -1
                     log("host tail failed:", e)
@@ -331,7 +334,10 @@ def main():
                 assert L.ma_pipeline_head(ctx.h, C.byref(opt), W.d, b"ug", 100, 0, C.byref(st)) == 0
             else:  # sharded: device passes + RCCL exchanges on every rank (host/sharded.c), graph cleaning + unitigs + GFA on rank 0
                 stats = ShardStats()
+                t_h = time.perf_counter()
                 assert L.ma_pipeline_head_sharded(ctx.h, C.byref(opt), W.n_seq, 0, C.byref(stats)) == 0  # 0: this rank holds its own records only
+                self.head_wall.append(time.perf_counter() - t_h)
+                self.last_stats = stats
                 if rank != 0:
                     return
                 st = (C.c_uint32 * 4)(1, 1, stats.n_red, 1)
@@ -381,6 +387,7 @@ def main():
                 self.ctx2 = None
 
     L.mahip_tail_handoff.argtypes = [vp, vp]
+    L.ma_shard_phases.argtypes = [C.c_int]
     run = Runner(W)
     dt = run.timed(args.warmup, args.steps)
     if world > 1:
@@ -396,9 +403,32 @@ def main():
     if rank == 0:
         ctx.prof_enable(True)
         ctx.prof_reset()
+    if world > 1:
+        L.ma_shard_phases(1)
+        run.head_wall, run.tail_wall = [], []
     for _ in range(args.prof_steps):  # a step is collective in the sharded mode: EVERY rank runs it, rank 0 is the one instrumented
         run.step()
     run.fence()
+    phases = None
+    if world > 1:  # where a sharded step spends its time: device time per phase (HIP events between the phases of host/sharded.c), maximum over the ranks
+        L.ma_shard_phases(0)
+        stt = run.last_stats
+        mine = [float(x) for x in stt.phase_ms] + [sum(run.head_wall) / max(len(run.head_wall), 1) * 1e3]
+        t = torch.tensor(mine, dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmin = t.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            names = ma.SHARD_PHASE_NAMES
+            dev_sum = float(sum(tmax[:len(names)]))
+            phases = {"what": "one sharded head (the last instrumented step): device time between the phase marks of host/sharded.c, max over ranks [min]; x:* = exchanges",
+                      "phase_ms": {n: [round(float(tmax[i]), 4), round(float(tmin[i]), 4)] for i, n in enumerate(names)},
+                      "exchange_bytes_per_rank": {names[i]: int(stt.xchg_bytes[i]) for i in range(len(names)) if stt.xchg_bytes[i]},
+                      "device_ms_sum_of_max": round(dev_sum, 4), "head_wall_ms_max": round(float(tmax[-1]), 4), "head_wall_ms_min": round(float(tmin[-1]), 4),
+                      "host_wait_ms": round(float(tmax[-1]) - dev_sum, 4),
+                      "rank0_tail_wall_ms": round(sum(run.tail_wall) / max(len(run.tail_wall), 1) * 1e3, 4) if run.tail_wall else None,
+                      "rank0_tail_where": "second context + worker thread, beside the next step's head" if run.ctx2 else "same context, after the head"}
     if rank == 0:
         recs = ctx.prof_get()
         ctx.prof_enable(False)
@@ -561,7 +591,7 @@ def main():
             "gfa_identical": parity["gfa_identical"] if parity else None, "parity": parity,
             "tie_groups": tie["arc_tie_groups"] if tie else None,
             "tie_path": None if not tie else ("arc walk%s" % (" + hit walk" if tie["hit_walk"] else "") if tie["arc_walk"] else "unrepaired" if tie["unrepaired"] else "stable order (census: no arc ties => provably the reference's order)"),
-            "roofline": roof, "cpu_baseline": cpu, "e2e": e2e, "from_text": from_text, "legs": legs, "kernels": kernels[:14],
+            "phases": phases, "roofline": roof, "cpu_baseline": cpu, "e2e": e2e, "from_text": from_text, "legs": legs, "kernels": kernels[:14],
             "setup": {"gen_s": t_gen, "file_to_hbm_s": W.t_load, "file_to_hbm_GBs": W.size / W.t_load / 1e9, "parse_dictionary_s": W.t_parse, "hbm_bytes_held": ctx.mem_bytes()},
         }
         print(json.dumps(out), flush=True)

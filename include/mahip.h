@@ -233,6 +233,7 @@ int mahip_comm_init_shm(mahip_ctx_t *c, const char *name, int rank, int world);
 void mahip_comm_destroy(mahip_ctx_t *c);
 int mahip_comm_rank(mahip_ctx_t *c);
 int mahip_comm_world(mahip_ctx_t *c);
+int mahip_comm_active(mahip_ctx_t *c);   /* more than one rank -- or one RCCL rank with MA_RCCL_ONE_RANK=1 (the collectives really run) */
 int mahip_comm_all_gather(mahip_ctx_t *c, const void *d_send, void *d_recv, size_t bytes_per_rank);  /* d_recv: world x bytes, rank-major */
 int mahip_comm_all_reduce_max_u8(mahip_ctx_t *c, void *d_buf, size_t n);                               /* OR of 0/1 flag bytes */
 int mahip_comm_all_reduce_sum_u64(mahip_ctx_t *c, uint64_t *h_vals, size_t n);                         /* <= 32 host counters */
@@ -247,6 +248,9 @@ int mahip_prof_reset(mahip_ctx_t *c);
 /* writes up to max entries; returns the number of distinct kernels seen */
 typedef struct { const char *name; uint64_t launches; double total_ms; double alg_bytes; } mahip_prof_t;
 int mahip_prof_get(mahip_ctx_t *c, mahip_prof_t *out, int max);
+/* phase marks: an event on the stream per slot (0..63); after a sync, ms[i] = time from mark first+i to mark first+i+1 (0 if either is missing) */
+int mahip_mark(mahip_ctx_t *c, int slot);
+int mahip_marks_ms(mahip_ctx_t *c, int first, int n, float *ms);
 /* bytes of HBM currently held by the context */
 size_t mahip_mem_bytes(mahip_ctx_t *c);
 /* device pointers for multi-GPU exchanges done outside (RCCL via torch.distributed): which = MAHIP_PTR_* */

@@ -25,6 +25,17 @@ ARC_DT = np.dtype([("ul", "<u8"), ("v", "<u4"), ("oldel", "<u4")])
 assert HIT_DT.itemsize == 32 and SUB_DT.itemsize == 8 and ARC_DT.itemsize == 16
 
 
+SHARD_N_PHASES = 16
+SHARD_PHASE_NAMES = ["sort", "sub#1", "x:sub0", "cut+flt+sub#2", "x:sub1", "merge+cut+contained", "x:flags", "squeeze+sg flags", "x:seq.del", "local arcs",
+                     "x:arc counts", "x:arc blocks", "tie repair", "reduction (own vertices)", "x:del flags", "rank 0: cleanup+symm"]  # host/sharded.c: ma_shard_phase_name
+
+
+class ShardStats(C.Structure):  # host/ma_host.h: ma_shard_stats_t
+    _fields_ = [("n_rem1", C.c_uint64), ("n_rem2", C.c_uint64), ("n_hits", C.c_uint64), ("n_seq_new", C.c_uint32), ("n_arc", C.c_uint32), ("n_loc_arc", C.c_uint32),
+                ("n_red", C.c_uint32), ("n_multi", C.c_uint32), ("n_asymm", C.c_uint32), ("tie_groups", C.c_uint64), ("push_conflicts", C.c_uint64), ("tie_repaired", C.c_int),
+                ("n_red_local", C.c_uint32), ("reduced", C.c_int), ("have_phases", C.c_int), ("phase_ms", C.c_float * SHARD_N_PHASES), ("xchg_bytes", C.c_uint64 * SHARD_N_PHASES)]
+
+
 class MaOpt(C.Structure):  # miniasm.h:12-27
     _fields_ = [("min_span", C.c_int), ("min_match", C.c_int), ("min_dp", C.c_int), ("min_iden", C.c_float),
                 ("max_hang", C.c_int), ("min_ovlp", C.c_int), ("int_frac", C.c_float),

@@ -129,6 +129,11 @@ extern "C" int mahip_comm_init_shm(mahip_ctx_t *c, const char *name, int rank, i
 	return 0;
 }
 
+// MA_RCCL_ONE_RANK=1: a one-rank RCCL communicator still goes through ncclAllGather / ncclAllReduce (symbol binding, datatypes, in-place
+// conventions and stream ordering run on hardware wherever a single GPU is all there is); default: one rank = plain copies
+static bool one_rank_forced() { static int v = -1; if (v < 0) { const char *e = getenv("MA_RCCL_ONE_RANK"); v = e && atoi(e) != 0; } return v != 0; }
+static inline bool comm_live(const Comm *m) { return m && (m->world > 1 || (m->kind == 1 && one_rank_forced())); }
+extern "C" int mahip_comm_active(mahip_ctx_t *c) { return comm_live((Comm*)c->comm) ? 1 : 0; }
 extern "C" int mahip_comm_rank(mahip_ctx_t *c) { return c->comm ? ((Comm*)c->comm)->rank : 0; }
 extern "C" int mahip_comm_world(mahip_ctx_t *c) { return c->comm ? ((Comm*)c->comm)->world : 1; }
 
@@ -137,7 +142,7 @@ extern "C" int mahip_comm_all_gather(mahip_ctx_t *c, const void *d_send, void *d
 {
 	HIPCHK(hipSetDevice(c->dev));
 	Comm *m = (Comm*)c->comm;
-	if (!m || m->world == 1) { if (bytes && d_recv != d_send) HIPCHK(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, c->st)); return 0; }
+	if (!comm_live(m)) { if (bytes && d_recv != d_send) HIPCHK(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, c->st)); return 0; }
 	if (bytes == 0) return 0;
 	if (m->kind == 1) { NCCLCHK(g_rccl.AllGather(d_send, d_recv, bytes, ncclUint8, m->nccl, c->st)); return 0; }
 	if (bytes > SHM_SLOT_BYTES) { mahip_set_error("shm all-gather: %zu bytes per rank exceed the slot", bytes); return -1; }
@@ -155,7 +160,7 @@ extern "C" int mahip_comm_all_reduce_max_u8(mahip_ctx_t *c, void *d_buf, size_t 
 {
 	HIPCHK(hipSetDevice(c->dev));
 	Comm *m = (Comm*)c->comm;
-	if (!m || m->world == 1 || n == 0) return 0;
+	if (!comm_live(m) || n == 0) return 0;
 	if (m->kind == 1) { NCCLCHK(g_rccl.AllReduce(d_buf, d_buf, n, ncclUint8, ncclMax, m->nccl, c->st)); return 0; }
 	if (n > SHM_SLOT_BYTES) { mahip_set_error("shm all-reduce: %zu bytes exceed the slot", n); return -1; }
 	uint8_t *mine = (uint8_t*)(m->slots + (size_t)m->rank * SHM_SLOT_BYTES);
@@ -177,7 +182,7 @@ extern "C" int mahip_comm_all_reduce_sum_u64(mahip_ctx_t *c, uint64_t *h_vals, s
 {
 	HIPCHK(hipSetDevice(c->dev));
 	Comm *m = (Comm*)c->comm;
-	if (!m || m->world == 1 || n == 0) return 0;
+	if (!comm_live(m) || n == 0) return 0;
 	if (n > 32) { mahip_set_error("mahip_comm_all_reduce_sum_u64: at most 32 counters"); return -1; }
 	if (m->kind == 1) {
 		unsigned long long *d = P<unsigned long long>(c->ctr) + 16; // scratch words of the counter block (not sticky, not in use between passes)

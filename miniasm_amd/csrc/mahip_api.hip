@@ -168,6 +168,7 @@ extern "C" void mahip_destroy(mahip_ctx_t *c)
 	(void)hipSetDevice(c->dev);
 	(void)hipStreamSynchronize(c->st);
 	for (auto &e : c->pev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+	for (hipEvent_t e : c->mark_ev) if (e) (void)hipEventDestroy(e);
 	DevBuf *all[] = { &c->aos_own, &c->goff, &c->sub[0], &c->sub[1], &c->r_cont, &c->r_used, &c->r_del, &c->r_live, &c->map, &c->surv,
 		&c->au[0], &c->au[1], &c->av[0], &c->av[1], &c->alen[0], &c->alen[1], &c->aol[0], &c->aol[1], &c->idx, &c->sdel, &c->slen,
 		&c->keep, &c->pos, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->hist, &c->scan_tmp[0], &c->scan_tmp[1], &c->scan_tmp[2],
@@ -252,6 +253,28 @@ int prof_collect(mahip_ctx *c)
 		(void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
 	}
 	c->pev.clear();
+	return 0;
+}
+
+extern "C" int mahip_mark(mahip_ctx_t *c, int slot)
+{
+	if (slot < 0 || slot >= 64) { mahip_set_error("mahip_mark: bad slot"); return -1; }
+	HIPCHK(hipSetDevice(c->dev));
+	if (!c->mark_ev[slot]) HIPCHK(hipEventCreate(&c->mark_ev[slot]));
+	HIPCHK(hipEventRecord(c->mark_ev[slot], c->st));
+	c->mark_set |= 1ull << slot;
+	return 0;
+}
+
+extern "C" int mahip_marks_ms(mahip_ctx_t *c, int first, int n, float *ms)
+{
+	for (int i = 0; i < n; ++i) {
+		const int a = first + i, b = a + 1;
+		ms[i] = 0;
+		if (a < 0 || b >= 64 || !(c->mark_set >> a & 1) || !(c->mark_set >> b & 1)) continue;
+		if (hipEventElapsedTime(&ms[i], c->mark_ev[a], c->mark_ev[b]) != hipSuccess) ms[i] = 0;
+	}
+	c->mark_set = 0;
 	return 0;
 }
 

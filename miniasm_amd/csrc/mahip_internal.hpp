@@ -99,6 +99,8 @@ struct mahip_ctx {
 	void *xfer = nullptr;      // staged-copy worker pool (xfer.hip)
 	void *paf = nullptr;       // text-ingest buffers (paf.hip)
 
+	hipEvent_t mark_ev[64] = {}; // phase marks (mahip_mark)
+	unsigned long long mark_set = 0;
 	// ---- profiling ----
 	bool prof = false;
 	std::vector<ProfEvent> pev;

@@ -28,8 +28,17 @@ int ma_pipeline_tail_finish(ma_tail_job_t *job, FILE *out);
 int ma_pipeline_tail_finish_mem(ma_tail_job_t *job, char **buf, size_t *len);
 
 /* the device passes on N GPUs (sharded.c): c carries the hits of this rank's read range and a communicator */
-typedef struct { uint64_t n_rem1, n_rem2, n_hits; uint32_t n_seq_new, n_arc, n_loc_arc, n_red, n_multi, n_asymm; uint64_t tie_groups, push_conflicts; int tie_repaired; } ma_shard_stats_t;
+#define MA_SHARD_N_PHASES 16
+typedef struct {
+	uint64_t n_rem1, n_rem2, n_hits; uint32_t n_seq_new, n_arc, n_loc_arc, n_red, n_multi, n_asymm; uint64_t tie_groups, push_conflicts; int tie_repaired;
+	uint32_t n_red_local; int reduced, have_phases; /* this rank's reduced arcs / the counters are sums over the ranks / phase_ms is filled in */
+	float phase_ms[MA_SHARD_N_PHASES];        /* device time between the phase marks (ma_shard_phases(1)); names: ma_shard_phase_name[] */
+	uint64_t xchg_bytes[MA_SHARD_N_PHASES];   /* bytes every rank receives in the exchange phases */
+} ma_shard_stats_t; /* mirrored by miniasm_amd.ShardStats (ctypes) */
+extern const char *const ma_shard_phase_name[MA_SHARD_N_PHASES];
+void ma_shard_phases(int on);
 int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq, int full_input, ma_shard_stats_t *st);
+int ma_shard_stats_reduce(mahip_ctx_t *c, ma_shard_stats_t *st);
 int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *outfmt, int stage, int flags, FILE *out, int world);
 ma_ug_t *ma_ug_from_device(mahip_ctx_t *c); /* unitigs of the graph resident in c (unitig_gfa.c over csrc/ug.hip) */
 void ma_sd_reindex(sdict_t *d);    /* build the name index from seq[] (for dictionaries assembled by hand) */

@@ -34,74 +34,102 @@ static void shard_range(uint32_t n_seq, int world, int rank, uint32_t *per, uint
 	*q1 = (uint32_t)(e < n_seq ? e : n_seq);
 }
 
+/* Per-phase device time of one sharded head (bench.py --gpus N reports the maximum over the ranks): a HIP event on the stream between the
+ * phases, read after the step.  Off by default (ma_shard_phases(1) turns it on for the following calls). */
+static int g_phases;
+void ma_shard_phases(int on) { g_phases = on; }
+size_t ma_shard_stats_sizeof(void) { return sizeof(ma_shard_stats_t); } /* tests/test_abi.py checks the ctypes mirror against it */
+const char *const ma_shard_phase_name[MA_SHARD_N_PHASES] = {
+	"sort", "sub#1", "x:sub0", "cut+flt+sub#2", "x:sub1", "merge+cut+contained", "x:flags", "squeeze+sg flags", "x:seq.del", "local arcs",
+	"x:arc counts", "x:arc blocks", "tie repair", "reduction (own vertices)", "x:del flags", "rank 0: cleanup+symm" };
+#define MARK(k) do { if (g_phases) GPU(mahip_mark(c, (k))); } while (0)
+
 /* all-gather of the owned slices of one of the read-indexed arrays (element size es): afterwards every rank holds all n_seq entries */
-static void exchange_slices(mahip_ctx_t *c, int which, size_t es, uint32_t n_seq, uint32_t per, uint32_t q0, uint32_t q1, int world)
+static size_t exchange_slices(mahip_ctx_t *c, int which, size_t es, uint32_t n_seq, uint32_t per, uint32_t q0, uint32_t q1, int world)
 {
 	void *loc, *all;
-	if (world == 1) return;
+	if (!mahip_comm_active(c)) return 0;
 	GPU(mahip_xbuf(c, 0, (size_t)per * es, &loc));
 	GPU(mahip_xbuf(c, 1, (size_t)per * es * world, &all));
 	GPU(mahip_copy_out(c, which, loc, q0, q1 - q0));
 	GPU(mahip_comm_all_gather(c, loc, all, (size_t)per * es));
 	GPU(mahip_copy_in(c, which, all, 0, n_seq));
+	return (size_t)per * es * world;
 }
 
 /* OR of 0/1 byte flag arrays over the ranks = one max-all-reduce over their concatenation */
-static void exchange_flags(mahip_ctx_t *c, uint32_t n_seq, int world, int n_which, const int *which)
+static size_t exchange_flags(mahip_ctx_t *c, uint32_t n_seq, int n_which, const int *which)
 {
 	char *t;
 	int k;
-	if (world == 1) return;
+	if (!mahip_comm_active(c)) return 0;
 	GPU(mahip_xbuf(c, 0, (size_t)n_seq * n_which, (void**)&t));
 	for (k = 0; k < n_which; ++k) GPU(mahip_copy_out(c, which[k], t + (size_t)k * n_seq, 0, n_seq));
 	GPU(mahip_comm_all_reduce_max_u8(c, t, (size_t)n_seq * n_which));
 	for (k = 0; k < n_which; ++k) GPU(mahip_copy_in(c, which[k], t + (size_t)k * n_seq, 0, n_seq));
+	return (size_t)n_seq * n_which;
 }
 
 /* The device passes of one input on this rank's shard, up to the reduced graph.  c holds the unsorted hits of (at least) this
- * rank's read range and a communicator (mahip_comm_init*).  Afterwards rank 0's context holds the reduced, symmetrised graph. */
+ * rank's read range and a communicator (mahip_comm_init*).  Afterwards rank 0's context holds the reduced, symmetrised graph.
+ * Host round trips between the ranks: ONE (the sizes of the arc blocks); the counters of the passes stay local until
+ * ma_shard_stats_reduce() is called -- after the step, off the critical path. */
 int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq, int full_input, ma_shard_stats_t *st)
 { /* full_input: c holds ALL hit records of the input (every rank parsed the text), not just this rank's: the tie repair can then also restore the hit order */
-	const int world = mahip_comm_world(c), rank = mahip_comm_rank(c);
+	const int world = mahip_comm_world(c), rank = mahip_comm_rank(c), active = mahip_comm_active(c);
 	uint32_t per, q0, q1, n_loc = 0, n_red = 0, n_seq_new = 0, i;
 	size_t n_rem1 = 0, n_rem2 = 0, n_cut = 0, n_flt = 0, n_hits = 0;
 	float cov = 0;
-	uint64_t cnt[64], sums[4];
+	uint64_t cnt[64];
 	uint32_t *counts = (uint32_t*)calloc((size_t)world + 1, 4);
 	size_t stride = 1, first = 0, tot = 0;
 	memset(st, 0, sizeof(*st));
 	shard_range(n_seq, world, rank, &per, &q0, &q1);
 	GPU(mahip_set_full_input(c, full_input || world == 1));
 	GPU(mahip_set_shard(c, world > 1 ? q0 : 0, world > 1 ? q1 : 0xffffffffu));
+	MARK(0);
 	GPU(mahip_hits_sort(c));
+	MARK(1);
 	GPU(mahip_hits_sub(c, opt->min_dp, opt->min_iden, 0, 0, &n_rem1));
-	exchange_slices(c, MAHIP_BUF_SUB0, 8, n_seq, per, q0, q1, world);
+	MARK(2);
+	st->xchg_bytes[2] = exchange_slices(c, MAHIP_BUF_SUB0, 8, n_seq, per, q0, q1, world);
+	MARK(3);
 	GPU(mahip_hits_cutflt_sub(c, 0, opt->min_span, (int)(opt->max_hang * 1.5), (int)(opt->min_ovlp * .5), opt->min_dp, opt->min_iden, opt->min_span / 2,
 	                          1, &n_cut, &n_flt, &cov, &n_rem2)); /* hit.c:162-216 + the second ma_hit_sub: needs the complete first-pass intervals */
-	exchange_slices(c, MAHIP_BUF_SUB1, 8, n_seq, per, q0, q1, world);
+	MARK(4);
+	st->xchg_bytes[4] = exchange_slices(c, MAHIP_BUF_SUB1, 8, n_seq, per, q0, q1, world);
+	MARK(5);
 	GPU(mahip_sub_merge(c)); /* on the complete arrays: identical on every rank */
 	GPU(mahip_hits_cut_contained_flags(c, 1, opt->min_span, opt));
-	{ const int w[2] = { MAHIP_BUF_RCONT, MAHIP_BUF_RUSED }; exchange_flags(c, n_seq, world, 2, w); }
+	MARK(6);
+	{ const int w[2] = { MAHIP_BUF_RCONT, MAHIP_BUF_RUSED }; st->xchg_bytes[6] = exchange_flags(c, n_seq, 2, w); }
+	MARK(7);
 	GPU(mahip_hits_cut_contained_finish(c, &n_cut, &n_seq_new));
 	GPU(mahip_sg_flags(c, opt, 1, 0, 0));
-	{ const int w[1] = { MAHIP_BUF_SDEL }; exchange_flags(c, n_seq, world, 1, w); }
+	MARK(8);
+	{ const int w[1] = { MAHIP_BUF_SDEL }; st->xchg_bytes[8] = exchange_flags(c, n_seq, 1, w); }
+	MARK(9);
 	GPU(mahip_sg_finish(c, &n_loc));
 	n_hits = mahip_hits_live(c);
+	MARK(10);
 	/* the arc all-gather: block sizes first (one counter per rank), then the blocks padded to the largest */
 	memset(cnt, 0, sizeof(cnt));
 	if (world > 32) { fprintf(stderr, "[E::%s] at most 32 ranks\n", __func__); exit(1); }
 	cnt[rank] = n_loc;
 	GPU(mahip_comm_all_reduce_sum_u64(c, cnt, (size_t)world));
 	for (i = 0; i < (uint32_t)world; ++i) { counts[i] = (uint32_t)cnt[i]; if (cnt[i] > stride) stride = cnt[i]; if ((int)i < rank) first += cnt[i]; tot += cnt[i]; }
-	if (world > 1) {
+	MARK(11);
+	if (active) {
 		void *rows, *all;
 		GPU(mahip_xbuf(c, 0, stride * 16, &rows));
 		GPU(mahip_xbuf(c, 1, stride * 16 * world, &all));
 		GPU(mahip_asg_export_rows(c, rows));
 		GPU(mahip_comm_all_gather(c, rows, all, stride * 16));
 		GPU(mahip_asg_import_rows(c, all, counts, world, stride));
+		st->xchg_bytes[11] = stride * 16 * world;
 	}
-	if (world > 1) { /* tie order: the census ran on the merged graph; groups of equal (u,len) keys -> the reference's order */
+	MARK(12);
+	if (active) { /* tie order: the census ran on the merged graph; groups of equal (u,len) keys -> the reference's order */
 		mahip_tie_info_t ti;
 		mahip_tie_stats(c, &ti);
 		st->tie_groups = ti.arc_tie_groups;
@@ -110,7 +138,7 @@ int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq
 			GPU(mahip_sg_push_conflicts(c, &conf));
 			GPU(mahip_comm_all_reduce_sum_u64(c, &conf, 1));
 			st->push_conflicts = conf;
-			if (conf == 0 || full_input) {
+			if (conf == 0 || full_input || world == 1) {
 				void *rows, *all;
 				if (conf) GPU(mahip_sg_push_fix(c)); /* every rank walks the hit keys of the whole input and keeps the ranks of its own hits */
 				GPU(mahip_xbuf(c, 0, stride * 16, &rows));
@@ -122,8 +150,10 @@ int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq
 			}
 		}
 	} else { mahip_tie_info_t ti; mahip_tie_stats(c, &ti); st->tie_groups = ti.arc_tie_groups; st->tie_repaired = ti.arc_walk; }
+	MARK(13);
 	GPU(mahip_asg_del_trans_range(c, opt->gap_fuzz, 2 * q0, world > 1 ? 2 * q1 : 2 * n_seq, &n_red));
-	if (world > 1) { /* the del flags of the own block -> everyone (only rank 0 needs them; kept symmetric) */
+	MARK(14);
+	if (active) { /* the del flags of the own block -> everyone (only rank 0 needs them; kept symmetric) */
 		char *fl, *all;
 		size_t off = 0;
 		GPU(mahip_xbuf(c, 0, stride * 4, (void**)&fl));
@@ -134,17 +164,41 @@ int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq
 			if ((int)i != rank && counts[i]) GPU(mahip_asg_flags_in(c, all + (size_t)i * stride * 4, off, counts[i]));
 			off += counts[i];
 		}
+		st->xchg_bytes[14] = stride * 4 * world;
 	}
-	sums[0] = n_rem1; sums[1] = n_rem2; sums[2] = n_hits; sums[3] = n_red;
-	GPU(mahip_comm_all_reduce_sum_u64(c, sums, 4)); /* the per-pass counters: one reduction at the end */
-	st->n_rem1 = sums[0]; st->n_rem2 = sums[1]; st->n_hits = sums[2]; st->n_red = (uint32_t)sums[3];
+	MARK(15);
+	st->n_rem1 = n_rem1; st->n_rem2 = n_rem2; st->n_hits = n_hits; st->n_red = st->n_red_local = n_red; /* this rank's share: ma_shard_stats_reduce() sums them */
 	st->n_seq_new = n_seq_new; st->n_arc = (uint32_t)tot; st->n_loc_arc = n_loc;
-	if (rank == 0 && st->n_red) {
+	if (rank == 0) { /* asg.c:187-190: cleanup + symm when anything was reduced.  Rank 0 holds every rank's del flags: what the cleanup removes IS the global count */
 		uint32_t n_arc = 0;
-		GPU(mahip_asg_cleanup(c, &n_arc));
-		GPU(mahip_asg_symm(c, &st->n_multi, &st->n_asymm));
+		if (world > 1) {
+			GPU(mahip_asg_cleanup(c, &n_arc));
+			st->n_red = (uint32_t)(tot - n_arc);
+			if (st->n_red) GPU(mahip_asg_symm(c, &st->n_multi, &st->n_asymm));
+		} else if (st->n_red) {
+			GPU(mahip_asg_cleanup(c, &n_arc));
+			GPU(mahip_asg_symm(c, &st->n_multi, &st->n_asymm));
+		}
+	}
+	MARK(16);
+	if (g_phases) {
+		GPU(mahip_sync(c));
+		GPU(mahip_marks_ms(c, 0, MA_SHARD_N_PHASES, st->phase_ms));
+		st->have_phases = 1;
 	}
 	free(counts);
+	return 0;
+}
+
+/* the counters of the passes, summed over the ranks (log lines, statistics): a collective every rank must call; not part of the step */
+int ma_shard_stats_reduce(mahip_ctx_t *c, ma_shard_stats_t *st)
+{
+	uint64_t sums[4];
+	if (st->reduced) return 0;
+	sums[0] = st->n_rem1; sums[1] = st->n_rem2; sums[2] = st->n_hits; sums[3] = st->n_red_local;
+	GPU(mahip_comm_all_reduce_sum_u64(c, sums, 4));
+	st->n_rem1 = sums[0]; st->n_rem2 = sums[1]; st->n_hits = sums[2]; st->n_red = (uint32_t)sums[3]; /* (= what rank 0's cleanup removed) */
+	st->reduced = 1;
 	return 0;
 }
 
@@ -257,6 +311,7 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 		if (e && atoi(e) == rank) { fprintf(stderr, "[E::%s] rank %d: MA_TEST_FAIL_RANK\n", __func__, rank); _exit(3); }
 	}
 	ma_pipeline_head_sharded(c, opt, d->n_seq, 1, &st);
+	ma_shard_stats_reduce(c, &st); /* the log lines below want the sums */
 	if (rank == 0) {
 		fprintf(lg, "[M::%s] ===> Step 2: 1-pass (crude) read selection <===\n", "main");
 		if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)st.n_rem1);

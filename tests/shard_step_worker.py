@@ -28,9 +28,7 @@ def main():
     qid = (ing.hits["qns"] >> np.uint64(32)).astype(np.int64)
     mine = np.ascontiguousarray(ing.hits[(qid >= q0) & (qid < q1)])  # this rank's records, input order kept
 
-    class ShardStats(C.Structure):  # host/ma_host.h: ma_shard_stats_t
-        _fields_ = [("n_rem1", C.c_uint64), ("n_rem2", C.c_uint64), ("n_hits", C.c_uint64), ("n_seq_new", C.c_uint32), ("n_arc", C.c_uint32), ("n_loc_arc", C.c_uint32),
-                    ("n_red", C.c_uint32), ("n_multi", C.c_uint32), ("n_asymm", C.c_uint32), ("tie_groups", C.c_uint64), ("push_conflicts", C.c_uint64), ("tie_repaired", C.c_int)]
+    ShardStats = ma.ShardStats
     L.ma_pipeline_head_sharded.restype = C.c_int
     L.ma_pipeline_head_sharded.argtypes = [vp, C.POINTER(ma.MaOpt), C.c_uint32, C.c_int, C.POINTER(ShardStats)]
     L.mahip_comm_init_shm.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]

@@ -55,6 +55,10 @@ def test_record_layouts():
     o = ma.default_opt()
     assert (o.min_span, o.min_match, o.min_dp, o.max_hang, o.min_ovlp, o.gap_fuzz, o.n_rounds, o.bub_dist, o.max_ext) == (2000, 100, 3, 1000, 2000, 1000, 2, 50000, 4)
     assert abs(o.min_iden - .05) < 1e-7 and abs(o.int_frac - .8) < 1e-7
+    L = ma.lib()
+    L.ma_shard_stats_sizeof.restype = C.c_size_t
+    assert L.ma_shard_stats_sizeof() == C.sizeof(ma.ShardStats), "miniasm_amd.ShardStats is out of step with host/ma_host.h: ma_shard_stats_t"
+    assert len(ma.SHARD_PHASE_NAMES) == ma.SHARD_N_PHASES
 
 
 def test_no_cpu_fallback(tmp_path):
