@@ -46,7 +46,7 @@ static int rccl_load(void)
 #define NCCLCHK(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { mahip_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, g_rccl.GetErrorString(r_)); return -1; } } while (0)
 
 // ---- shared-memory test double ----
-struct ShmHeader { volatile unsigned arrive, sense; unsigned world; size_t slot; };
+struct ShmHeader { volatile unsigned arrive, sense; unsigned world; size_t slot; volatile unsigned turn_lock; };
 #define SHM_SLOT_BYTES ((size_t)1 << 30) // per rank, sparse: pages exist only where a collective wrote
 
 struct Comm {
@@ -58,6 +58,13 @@ struct Comm {
 	unsigned my_sense = 0;
 	char name[128] = "";
 };
+
+// MA_SHM_SERIAL=1 (tools/shard_projection.py): the ranks of a shared-memory run take turns on the one GPU they share -- a rank holds the lock
+// while it computes and gives it up for the length of a collective -- so that the device time of a rank's phases (mahip_mark) is what the rank
+// would see on a GPU of its own.
+static bool shm_serial() { static int v = -1; if (v < 0) { const char *e = getenv("MA_SHM_SERIAL"); v = e && atoi(e) != 0; } return v != 0; }
+static void shm_turn_take(Comm *m) { if (shm_serial()) while (__atomic_exchange_n(&m->hdr->turn_lock, 1u, __ATOMIC_ACQUIRE)) sched_yield(); }
+static void shm_turn_give(Comm *m) { if (shm_serial()) __atomic_store_n(&m->hdr->turn_lock, 0u, __ATOMIC_RELEASE); }
 
 static void shm_barrier(Comm *m)
 {
@@ -83,7 +90,7 @@ extern "C" void mahip_comm_destroy(mahip_ctx_t *c)
 	Comm *m = (Comm*)c->comm;
 	if (!m) return;
 	if (m->kind == 1 && m->nccl) (void)g_rccl.CommDestroy(m->nccl);
-	if (m->kind == 2 && m->hdr) { munmap((void*)m->hdr, m->map_bytes); if (m->rank == 0) shm_unlink(m->name); }
+	if (m->kind == 2 && m->hdr) { shm_turn_give(m); munmap((void*)m->hdr, m->map_bytes); }
 	delete m;
 	c->comm = nullptr;
 }
@@ -122,17 +129,19 @@ extern "C" int mahip_comm_init_shm(mahip_ctx_t *c, const char *name, int rank, i
 	close(fd);
 	if (p == MAP_FAILED) { mahip_set_error("mahip_comm_init_shm: mmap failed"); delete m; return -1; }
 	m->hdr = (ShmHeader*)p; m->slots = (char*)p + 4096;
-	if (rank == 0) { m->hdr->arrive = 0; m->hdr->sense = 0; m->hdr->slot = SHM_SLOT_BYTES; __atomic_store_n(&m->hdr->world, (unsigned)world, __ATOMIC_RELEASE); }
+	if (rank == 0) { m->hdr->arrive = 0; m->hdr->sense = 0; m->hdr->slot = SHM_SLOT_BYTES; m->hdr->turn_lock = 0; __atomic_store_n(&m->hdr->world, (unsigned)world, __ATOMIC_RELEASE); }
 	else while (__atomic_load_n(&m->hdr->world, __ATOMIC_ACQUIRE) != (unsigned)world) sched_yield();
 	c->comm = m;
 	shm_barrier(m);
+	if (rank == 0) shm_unlink(m->name); // every rank has mapped it: the name can go now, so that no run -- however it ends -- leaves a segment behind
+	shm_turn_take(m);
 	return 0;
 }
 
 // MA_RCCL_ONE_RANK=1: a one-rank RCCL communicator still goes through ncclAllGather / ncclAllReduce (symbol binding, datatypes, in-place
 // conventions and stream ordering run on hardware wherever a single GPU is all there is); default: one rank = plain copies
 static bool one_rank_forced() { static int v = -1; if (v < 0) { const char *e = getenv("MA_RCCL_ONE_RANK"); v = e && atoi(e) != 0; } return v != 0; }
-static inline bool comm_live(const Comm *m) { return m && (m->world > 1 || (m->kind == 1 && one_rank_forced())); }
+static inline bool comm_live(const Comm *m) { return m && (m->world > 1 || one_rank_forced()); }
 extern "C" int mahip_comm_active(mahip_ctx_t *c) { return comm_live((Comm*)c->comm) ? 1 : 0; }
 extern "C" int mahip_comm_rank(mahip_ctx_t *c) { return c->comm ? ((Comm*)c->comm)->rank : 0; }
 extern "C" int mahip_comm_world(mahip_ctx_t *c) { return c->comm ? ((Comm*)c->comm)->world : 1; }
@@ -148,10 +157,12 @@ extern "C" int mahip_comm_all_gather(mahip_ctx_t *c, const void *d_send, void *d
 	if (bytes > SHM_SLOT_BYTES) { mahip_set_error("shm all-gather: %zu bytes per rank exceed the slot", bytes); return -1; }
 	HIPCHK(hipMemcpyAsync(m->slots + (size_t)m->rank * SHM_SLOT_BYTES, d_send, bytes, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipStreamSynchronize(c->st));
+	shm_turn_give(m);
 	shm_barrier(m);
 	for (int r = 0; r < m->world; ++r) HIPCHK(hipMemcpyAsync((char*)d_recv + (size_t)r * bytes, m->slots + (size_t)r * SHM_SLOT_BYTES, bytes, hipMemcpyHostToDevice, c->st));
 	HIPCHK(hipStreamSynchronize(c->st));
 	shm_barrier(m);
+	shm_turn_take(m);
 	return 0;
 }
 
@@ -166,6 +177,7 @@ extern "C" int mahip_comm_all_reduce_max_u8(mahip_ctx_t *c, void *d_buf, size_t 
 	uint8_t *mine = (uint8_t*)(m->slots + (size_t)m->rank * SHM_SLOT_BYTES);
 	HIPCHK(hipMemcpyAsync(mine, d_buf, n, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipStreamSynchronize(c->st));
+	shm_turn_give(m);
 	shm_barrier(m);
 	uint8_t *acc = (uint8_t*)malloc(n);
 	memcpy(acc, m->slots, n);
@@ -174,6 +186,7 @@ extern "C" int mahip_comm_all_reduce_max_u8(mahip_ctx_t *c, void *d_buf, size_t 
 	HIPCHK(hipMemcpyAsync(d_buf, acc, n, hipMemcpyHostToDevice, c->st));
 	HIPCHK(hipStreamSynchronize(c->st));
 	free(acc);
+	shm_turn_take(m);
 	return 0;
 }
 
@@ -193,12 +206,14 @@ extern "C" int mahip_comm_all_reduce_sum_u64(mahip_ctx_t *c, uint64_t *h_vals, s
 		return 0;
 	}
 	memcpy(m->slots + (size_t)m->rank * SHM_SLOT_BYTES, h_vals, n * 8);
+	if (shm_serial()) { HIPCHK(hipStreamSynchronize(c->st)); shm_turn_give(m); }
 	shm_barrier(m);
 	uint64_t acc[32];
 	memset(acc, 0, sizeof(acc));
 	for (int r = 0; r < m->world; ++r) { const uint64_t *s = (const uint64_t*)(m->slots + (size_t)r * SHM_SLOT_BYTES); for (size_t i = 0; i < n; ++i) acc[i] += s[i]; }
 	shm_barrier(m);
 	memcpy(h_vals, acc, n * 8);
+	shm_turn_take(m);
 	return 0;
 }
 

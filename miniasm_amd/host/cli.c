@@ -92,7 +92,8 @@ int main(int argc, char *argv[])
 	{
 		const char *g = getenv("MA_GPUS"); /* N > 1: one process per GPU, read-range shards, RCCL exchanges (host/sharded.c) */
 		const int world = g ? atoi(g) : 1;
-		if (world > 1) ma_pipeline_run_sharded(&opt, argv[optind], outfmt, stage, flags, stdout, world);
+		const char *one = getenv("MA_RCCL_ONE_RANK"); /* with MA_GPUS=1: the sharded runner on a one-rank RCCL communicator, every collective really called */
+		if (world > 1 || (g && world == 1 && one && atoi(one) != 0)) ma_pipeline_run_sharded(&opt, argv[optind], outfmt, stage, flags, stdout, world);
 		else ma_pipeline_run(&opt, argv[optind], outfmt, stage, flags, stdout);
 	}
 

@@ -70,7 +70,8 @@ uint32_t ma_ingest_max_qs(void); /* largest query start stored by the last ma_hi
 void ma_refsort_arcs(asg_arc_t *beg, asg_arc_t *end);
 /* the same procedure on (key, input index) pairs, sub-buckets on worker threads (refsort.c): exact-tie mode */
 typedef struct { uint64_t key; uint32_t idx, pad; } ma_ki_t;
-void ma_refsort_ki(ma_ki_t *a, size_t n, int n_threads);
+void ma_refsort_ki(ma_ki_t **pa, size_t n, int n_threads);
+void *ma_big_malloc(size_t bytes); /* malloc; blocks of 32 MiB and more are offered to transparent huge pages */
 int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm); /* perm[i] = input position of the i-th record in reference order */
 
 #ifdef __cplusplus

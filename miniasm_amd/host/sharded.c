@@ -270,6 +270,11 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 		sigaction(SIGCHLD, &sa, 0);
 		atexit(kids_kill);
 	}
+	{ /* a child that ends before its pid is in kids[] must not be taken for "not a rank": no SIGCHLD until the table is complete */
+		sigset_t blk;
+		sigemptyset(&blk); sigaddset(&blk, SIGCHLD);
+		sigprocmask(SIG_BLOCK, &blk, 0);
+	}
 	for (r = 1; r < world; ++r) {
 		const pid_t parent = getpid();
 		if (pipe(pipes[r]) != 0) { perror("pipe"); exit(1); }
@@ -283,6 +288,11 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 			break;
 		}
 		close(pipes[r][0]);
+	}
+	{
+		sigset_t blk;
+		sigemptyset(&blk); sigaddset(&blk, SIGCHLD);
+		sigprocmask(SIG_UNBLOCK, &blk, 0); /* (the children inherit the blocked mask: they have no children of their own) */
 	}
 	if (rank == 0) {
 		if (!use_shm) GPU(mahip_comm_unique_id(id));

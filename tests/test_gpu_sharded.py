@@ -234,6 +234,22 @@ def test_cli_on_two_gpus_over_rccl(tmpdir_s):
     assert r.stdout == one
 
 
+@pytest.mark.skipif(getattr(ma, "IS_EMU", False), reason="RCCL needs a GPU")
+def test_cli_on_one_rank_really_calls_rccl(tmpdir_s):
+    """MA_GPUS=1 MA_RCCL_ONE_RANK=1: the sharded runner (host/sharded.c) on a ONE-rank RCCL communicator with the one-rank short cuts off -- every
+    ncclAllGather / ncclAllReduce of the step is issued on the context's stream (symbol binding, datatypes, in-place reduction, ordering against the
+    kernels around them), which is as much of the RCCL path as a box with one GPU can run.  Output = the plain single-GPU run's, tie-rich input included."""
+    import subprocess
+    for k, extra in enumerate((["-L", "uniform", "-d", "0.3", "-x", "0.03"], ["-q", "16", "-L", "uniform", "-d", "0.3", "-x", "0.03"])):
+        paf = R.pafgen(os.path.join(tmpdir_s, "shc_rccl1_%d.paf" % k), 5000, 150000, 84 + k, extra)
+        one, _ = R.run_cli(ma.CLI_PATH, [], paf)
+        env = dict(os.environ, MA_GPUS="1", MA_RCCL_ONE_RANK="1")
+        env.pop("MA_COMM", None)
+        r = subprocess.run([ma.CLI_PATH, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert r.stdout == one
+
+
 def test_rccl_loads_and_initialises_a_one_rank_communicator():
     """librccl is opened at run time (dlopen); a one-rank communicator comes up on this GPU and the collectives degenerate to copies"""
     L = ma.lib()

@@ -245,6 +245,24 @@ def test_refsort_perm_matches_reference_sort(threads, monkeypatch):
         LR.radix_sort_hit(ref.ctypes.data, ref.ctypes.data + n * 32)
         assert (np.diff(ref["qns"].astype(np.int64)) >= 0).all()
         assert hits[perm].tobytes() == ref.tobytes(), "hit order differs for n=%d" % n
+    # the shape of a PAF file: keys that are almost sorted already (a query's overlaps are listed together, the mirrored records point at reads
+    # nearby): the top-level walk (host/refsort_body.h: permute_top) then runs over long stretches of elements that are already home -- identity at
+    # the bucket it works on, shifted by one everywhere else, recorded as segments when long
+    for n, per, spread in ((300000, 3, 40), (1500000, 20, 3), (1500000, 20, 70000), (2000000, 7, 1)):
+        nr = n // per
+        q = np.sort(rng.integers(0, nr, n // 2)).astype(np.int64)
+        t = np.clip(q + rng.integers(-spread, spread + 1, n // 2), 0, nr - 1)
+        qid = np.empty(n, dtype=np.uint64)
+        qid[0::2], qid[1::2] = q.astype(np.uint64), t.astype(np.uint64)
+        hits = np.zeros(n, dtype=ma.HIT_DT)
+        hits["qns"] = (qid << np.uint64(32)) | (rng.integers(0, 50, n).astype(np.uint64) * 16)
+        hits["tn"] = np.arange(n)
+        perm = np.zeros(n, dtype=np.uint32)
+        keys = np.ascontiguousarray(hits["qns"])
+        assert LP.ma_refsort_perm(keys.ctypes.data, n, perm.ctypes.data) == 0
+        ref = hits.copy()
+        LR.radix_sort_hit(ref.ctypes.data, ref.ctypes.data + n * 32)
+        assert hits[perm].tobytes() == ref.tobytes(), "hit order differs for the nearly sorted input n=%d per=%d spread=%d" % (n, per, spread)
     LR.asg_arc_sort.argtypes = [C.POINTER(ma.Asg)]
     for n, nu, nl in ((300, 8, 6), (400000, 5000, 12), (600000, 400000, 3)):
         arcs = np.zeros(n, dtype=ma.ARC_DT)
