@@ -116,8 +116,8 @@ def pmc_traffic(names, kernel):
     if scope:  # a timed scope of the coverage passes = one launch of each size-class kernel: their bytes add up
         parts = [v for k, v in names.items() if k.startswith(scope[0]) and (scope[1] is None or k.endswith(", true>") == scope[1])]
         return round(sum(per_launch(v) for v in parts)) if parts else None
-    base = {"k_hit_keys": "k_hit_keys_tiled"}.get(kernel, kernel.split("<")[0])
-    hits = [v for k, v in names.items() if k.split("<")[0] == base]
+    base = kernel.split("<")[0]
+    hits = [v for k, v in names.items() if k.split("<")[0] in (base, {"k_hit_keys": "k_hit_keys_tiled"}.get(base, base))]
     if not hits:
         return None
     return round(sum(per_launch(v) * v["launches"] for v in hits) / max(sum(v["launches"] for v in hits), 1))
@@ -192,6 +192,7 @@ def main():
                     "Default: it moves to a second context on the same GPU and runs beside the next batch's hit passes (mahip_tail_handoff; round 3, measured: "
                     "cfg4 20.0 -> 19.2 ms per step, cfg2 3.23 -> 2.79 ms)")
     ap.add_argument("--prof-steps", type=int, default=3)
+    ap.add_argument("--inflight", type=int, default=1, help="experiment: batches in flight on the one GPU (each on its own context and host thread)")
     args = ap.parse_args()
     args.tail_ctx = not args.no_tail_ctx
     args.gen_extra = [] if args.model == "lognormal" else ["-L", args.model]
@@ -279,8 +280,9 @@ def main():
     class Runner:
         """the timed step over one workload"""
 
-        def __init__(self, W):
+        def __init__(self, W, hctx=None):
             self.W = W
+            self.hctx = hctx or ctx  # the context the hit passes run on
             self.out = {"n": 0, "rc": 0, "buf": None}
             self.head_wall, self.tail_wall, self.last_stats = [], [], None  # sharded mode: wall time of each head on this rank / of each tail on rank 0
             self.q = queue.Queue(maxsize=1)  # one batch may wait while another is being finished
@@ -327,15 +329,15 @@ def main():
 
         def step(self):
             W = self.W
-            ma._chk(L.mahip_hits_adopt(ctx.h, W.hits_dev.data_ptr(), W.n_my, W.n_seq), "adopt")
-            L.mahip_set_hints(ctx.h, W.max_qs)
+            ma._chk(L.mahip_hits_adopt(self.hctx.h, W.hits_dev.data_ptr(), W.n_my, W.n_seq), "adopt")
+            L.mahip_set_hints(self.hctx.h, W.max_qs)
             st = (C.c_uint32 * 4)(0, 0, 0, 0)
             if world == 1:  # single GPU: the C pipeline's device half
-                assert L.ma_pipeline_head(ctx.h, C.byref(opt), W.d, b"ug", 100, 0, C.byref(st)) == 0
+                assert L.ma_pipeline_head(self.hctx.h, C.byref(opt), W.d, b"ug", 100, 0, C.byref(st)) == 0
             else:  # sharded: device passes + RCCL exchanges on every rank (host/sharded.c), graph cleaning + unitigs + GFA on rank 0
                 stats = ShardStats()
                 t_h = time.perf_counter()
-                assert L.ma_pipeline_head_sharded(ctx.h, C.byref(opt), W.n_seq, 0, C.byref(stats)) == 0  # 0: this rank holds its own records only
+                assert L.ma_pipeline_head_sharded(self.hctx.h, C.byref(opt), W.n_seq, 0, C.byref(stats)) == 0  # 0: this rank holds its own records only
                 self.head_wall.append(time.perf_counter() - t_h)
                 self.last_stats = stats
                 if rank != 0:
@@ -343,10 +345,10 @@ def main():
                 st = (C.c_uint32 * 4)(1, 1, stats.n_red, 1)
             if self.ctx2:
                 self.ctx2_free.acquire()  # the previous batch's device tail has left the second context
-                ma._chk(L.mahip_tail_handoff(ctx.h, self.ctx2.h), "tail_handoff")
+                ma._chk(L.mahip_tail_handoff(self.hctx.h, self.ctx2.h), "tail_handoff")
                 self.q.put((st,))
                 return
-            job = L.ma_pipeline_tail_fetch(ctx.h, C.byref(opt), W.d, b"ug", 100, C.byref(st))
+            job = L.ma_pipeline_tail_fetch(self.hctx.h, C.byref(opt), W.d, b"ug", 100, C.byref(st))
             assert job
             if self.worker:
                 self.q.put(job)
@@ -389,7 +391,34 @@ def main():
     L.mahip_tail_handoff.argtypes = [vp, vp]
     L.ma_shard_phases.argtypes = [C.c_int]
     run = Runner(W)
-    dt = run.timed(args.warmup, args.steps)
+    if args.inflight > 1 and world == 1:
+        # EXPERIMENT (--inflight N): N batches in flight on one GPU, each on a context (stream + buffers) of its own, driven by its own host thread; the
+        # kernels of different batches share the chip (a VALU-bound coverage pass of one beside the HBM-bound sort passes of another)
+        others = [Runner(W, ma.Ctx(local)) for _ in range(args.inflight - 1)]
+        team = [run] + others
+
+        def spin(r, k):
+            for _ in range(k):
+                r.step()
+        def many(k_total):
+            share = [k_total // len(team) + (1 if i < k_total % len(team) else 0) for i in range(len(team))]
+            th = [threading.Thread(target=spin, args=(r, k)) for r, k in zip(team, share)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            for r in team:
+                r.fence()
+        many(args.warmup * len(team))
+        t0 = time.perf_counter()
+        many(args.steps)
+        dt = time.perf_counter() - t0
+        for r in others:
+            assert r.output() == run.output()
+            r.close()
+            r.hctx.close()
+    else:
+        dt = run.timed(args.warmup, args.steps)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -414,10 +443,9 @@ def main():
         L.ma_shard_phases(0)
         stt = run.last_stats
         mine = [float(x) for x in stt.phase_ms] + [sum(run.head_wall) / max(len(run.head_wall), 1) * 1e3]
-        t = torch.tensor(mine, dtype=torch.float64)
-        tmax = t.clone()
+        tmax = torch.tensor(mine, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tmin = t.clone()
+        tmin = torch.tensor(mine, dtype=torch.float64)
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         if rank == 0:
             names = ma.SHARD_PHASE_NAMES
@@ -587,7 +615,7 @@ def main():
                 "global_overlaps": W.n_lines, "per_gpu_hits": W.n_my,
                 "pipelining": ("device tail (cleaners, unitigs) on a second context + host tail (GFA text) of pass k overlap the hit passes of pass k+1; all K outputs complete inside the timed region" if args.tail_ctx else
                                "host tail of pass k (GFA text) overlaps the device part of pass k+1; all K outputs complete inside the timed region") if overlap else "none (--no-overlap)",
-                "parallelism": "read-range shards x%d, RCCL all-gather of sub/flags/arcs from C (host/sharded.c)" % world if world > 1 else "single GPU"},
+                "parallelism": "read-range shards x%d, RCCL all-gather of sub/flags/arcs from C (host/sharded.c)" % world if world > 1 else "single GPU" + (", %d batches in flight" % args.inflight if args.inflight > 1 else "")},
             "gfa_identical": parity["gfa_identical"] if parity else None, "parity": parity,
             "tie_groups": tie["arc_tie_groups"] if tie else None,
             "tie_path": None if not tie else ("arc walk%s" % (" + hit walk" if tie["hit_walk"] else "") if tie["arc_walk"] else "unrepaired" if tie["unrepaired"] else "stable order (census: no arc ties => provably the reference's order)"),

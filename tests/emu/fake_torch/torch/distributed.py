@@ -9,6 +9,7 @@ import time
 class ReduceOp:
     MAX = "max"
     SUM = "sum"
+    MIN = "min"
 
 
 _S = {"rank": 0, "world": 1, "dir": None, "seq": 0}
@@ -60,7 +61,7 @@ def all_reduce(t, op=ReduceOp.MAX):
     vals = _exchange(t.a.copy())
     acc = vals[0].copy()
     for v in vals[1:]:
-        acc = np.maximum(acc, v) if op == ReduceOp.MAX else acc + v
+        acc = np.maximum(acc, v) if op == ReduceOp.MAX else np.minimum(acc, v) if op == ReduceOp.MIN else acc + v
     t.a[...] = acc
 
 

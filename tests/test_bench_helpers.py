@@ -26,10 +26,14 @@ def test_pmc_traffic_scopes_sum_their_kernels():
     fused = sum(per(v) for k, v in d.items() if k.startswith("k_hit_sub<true,"))
     plain = sum(per(v) for k, v in d.items() if k.startswith("k_hit_sub<false,"))
     assert fused > 0 and plain > 0
-    if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_traffic_cfg2.json")):
+    if any(os.path.exists(os.path.join(ROOT, "profiles", "%s_pmc_traffic_cfg2.json" % r)) for r in ("r02", "r03a", "r03")):
         return  # a newer profile of this workload takes precedence: the arithmetic below is about the r01 file
-    assert b.pmc_traffic("k_hit_sub<cut+flt>", "cfg2")[0] == round(fused)   # one launch of each size-class kernel per timed scope
-    assert b.pmc_traffic("k_hit_sub", "cfg2")[0] == round(plain)
-    assert abs(b.pmc_traffic("k_hit_keys", "cfg2")[0] - 800e6) < 5e6         # 640 MB of strided record reads + 160 MB of keys
-    assert b.pmc_traffic("no_such_kernel", "cfg2") == (None, None)
-    assert b.pmc_traffic("k_hit_sub", "no_such_workload") == (None, None)   # counters belong to the profiled workload only
+    names, src = b.pmc_profile("cfg2")
+    assert src.startswith("profiles/r01_pmc_traffic_cfg2.json")
+    assert b.pmc_traffic(names, "k_hit_sub<cut+flt>") == round(fused)   # one launch of each size-class kernel per timed scope
+    assert b.pmc_traffic(names, "k_hit_sub") == round(plain)
+    assert abs(b.pmc_traffic(names, "k_hit_keys") - 800e6) < 5e6         # 640 MB of strided record reads + 160 MB of keys
+    assert b.pmc_traffic(names, "no_such_kernel") is None
+    assert b.pmc_profile("no_such_workload") == (None, None)             # counters belong to the profiled workload only
+    names4, src4 = b.pmc_profile("cfg4")
+    assert "commit" in src4 and b.pmc_traffic(names4, "k_hit_sub<gather>") > 1e10

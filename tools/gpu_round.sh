@@ -34,6 +34,10 @@ syncexp)
   for cfg in "" "--reads 200000 --lines 10000000 --seed 1"; do for v in "" "MA_CTR_COPY=1" "MA_CTR_COPY=1 MA_SYNC_SPIN=1"; do
     env $v timeout 900 python bench.py --no-cpu --no-legs --no-text --prof-steps 0 --steps 20 --warmup 3 $cfg > gpurun_out/bench_sync.json 2> gpurun_out/bench_sync.log; echo "[$cfg | ${v:-mailbox}] rc=$?"
     python3 -c "import json; d=json.load(open('gpurun_out/bench_sync.json')); print('   ms_per_step %.3f  value %.3g' % (d['ms_per_step'], d['value']))"
+  done; done
+  for cfg in "" "--reads 200000 --lines 10000000 --seed 1"; do for n in 2 3; do
+    timeout 900 python bench.py --no-cpu --no-legs --no-text --prof-steps 0 --steps 24 --warmup 3 --inflight $n $cfg > gpurun_out/bench_sync.json 2> gpurun_out/bench_sync.log; echo "[$cfg | inflight $n] rc=$?"
+    python3 -c "import json; d=json.load(open('gpurun_out/bench_sync.json')); print('   ms_per_step %.3f  value %.3g' % (d['ms_per_step'], d['value']))"
   done; done ;;
 tiewalk)
   # the host walk that reproduces the reference's tie order: laps of host/refsort.c on the 50 M noisy input and on BASELINE configs[4], run-skipping digit walk vs the element-moving one
