@@ -53,7 +53,9 @@ int mahip_paf_parse(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, mah
 /* the same with the -R pre-filter folded in (hit.c:38-68 ma_hit_no_cont + the exclusion test of hit.c:86): names of reads that some line shows
  * to be clearly contained are excluded before ids are given out; lines touching them are dropped */
 int mahip_paf_parse_excl(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, int no_cont, int max_hang, float int_frac, mahip_paf_info_t *info);
-int mahip_paf_names(mahip_ctx_t *c, char *names, uint32_t *lens);          /* names[name_bytes], lens[n_seq] = first-seen read lengths */
+int mahip_paf_names(mahip_ctx_t *c, char *names, uint32_t *lens);
+/* the same as ready-made sd_seq_t records (sdict.h:6-10) whose name pointers point into `names` (a host block of name_bytes): seqs16[n_seq * 16 bytes] */
+int mahip_paf_seqs(mahip_ctx_t *c, char *names, void *seqs16, uint64_t *tot_len);          /* names[name_bytes], lens[n_seq] = first-seen read lengths */
 int mahip_paf_release(mahip_ctx_t *c);                                      /* free the text and the per-line columns */
 uint32_t mahip_paf_max_qs(mahip_ctx_t *c);                                  /* info.max_qs of the last parse (a sort hint for later mahip_hits_adopt calls) */
 int mahip_hits_raw_download(mahip_ctx_t *c, ma_hit_t *out);                 /* the unsorted records held by the context (n_hits of them) */

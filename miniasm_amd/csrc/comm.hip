@@ -43,6 +43,15 @@ static int rccl_load(void)
 	return 0;
 }
 
+// RCCL writes its version banner and its NCCL_DEBUG lines to STDOUT -- the stream this program's result goes to (the GFA of the command line, the
+// JSON line of bench.py).  Found on the GPU box in round 3: the first one-rank run's GFA began with "RCCL version ...".  Its log goes to stderr
+// unless the user asked for a file, and whatever the first calls still print is kept away from descriptor 1.
+struct StdoutToStderr {
+	int saved;
+	StdoutToStderr() { setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0); fflush(stdout); saved = dup(1); if (saved >= 0) (void)dup2(2, 1); }
+	~StdoutToStderr() { if (saved >= 0) { fflush(stdout); (void)dup2(saved, 1); close(saved); } }
+};
+
 #define NCCLCHK(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { mahip_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, g_rccl.GetErrorString(r_)); return -1; } } while (0)
 
 // ---- shared-memory test double ----
@@ -80,7 +89,7 @@ extern "C" int mahip_comm_unique_id(void *id128)
 {
 	CHK(rccl_load());
 	ncclUniqueId id;
-	NCCLCHK(g_rccl.GetUniqueId(&id));
+	{ StdoutToStderr quiet; NCCLCHK(g_rccl.GetUniqueId(&id)); }
 	memcpy(id128, &id, sizeof(id));
 	return 0;
 }
@@ -104,7 +113,8 @@ extern "C" int mahip_comm_init(mahip_ctx_t *c, const void *id128, int rank, int 
 	m->kind = 1; m->rank = rank; m->world = world;
 	ncclUniqueId id;
 	memcpy(&id, id128, sizeof(id));
-	ncclResult_t r = g_rccl.CommInitRank(&m->nccl, world, id, rank);
+	ncclResult_t r;
+	{ StdoutToStderr quiet; r = g_rccl.CommInitRank(&m->nccl, world, id, rank); }
 	if (r != ncclSuccess) { mahip_set_error("ncclCommInitRank(rank %d of %d on device %d): %s", rank, world, c->dev, g_rccl.GetErrorString(r)); delete m; return -1; }
 	c->comm = m;
 	return 0;

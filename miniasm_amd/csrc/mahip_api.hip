@@ -48,7 +48,8 @@ int ctr_zero(mahip_ctx *c)
 // The counters come back through a mailbox: a one-wave kernel behind the pass copies the 64 words into host-coherent pinned memory and then
 // raises a sequence number there; the host spins on that word.  A copy + hipStreamSynchronize costs a blit launch plus the runtime's wake-up
 // (20-30 us of idle GPU per fetch in the round-3 kernel trace, about 50 fetches per input: 1.3 ms of a 21 ms pass at cfg4, 40 % of one at cfg2);
-// the spin sees the word a microsecond or two after the kernel wrote it.  h_ctr[64] = the sequence word.  MA_CTR_COPY=1: the old copy + sync.
+// the spin sees the word a microsecond or two after the kernel wrote it.  h_ctr[64] = the sequence word.  Measured (round 3, profiles/
+// r03_experiments.txt): 19.47 -> 19.02 ms per pass at cfg4, 2.81 -> 2.74 at cfg2; making the runtime's own waits spin (hipDeviceScheduleSpin) instead: nothing.
 __global__ __launch_bounds__(64) void k_ctr_publish(const unsigned long long *__restrict__ ctr, volatile unsigned long long *h, unsigned long long seq)
 {
 	h[threadIdx.x] = ctr[threadIdx.x];
@@ -57,20 +58,8 @@ __global__ __launch_bounds__(64) void k_ctr_publish(const unsigned long long *__
 	if (threadIdx.x == 0) { h[64] = seq; __threadfence_system(); }
 }
 
-static int ctr_mode()
-{
-	static int v = -1;
-	if (v < 0) v = getenv("MA_CTR_COPY") ? 0 : 1;
-	return v;
-}
-
 int ctr_fetch(mahip_ctx *c)
 {
-	if (!ctr_mode()) {
-		HIPCHK(hipMemcpyAsync(c->h_ctr, c->ctr.p, 64 * 8, hipMemcpyDeviceToHost, c->st));
-		HIPCHK(hipStreamSynchronize(c->st));
-		return 0;
-	}
 	const unsigned long long seq = ++c->ctr_seq;
 	hipLaunchKernelGGL(k_ctr_publish, dim3(1), dim3(64), 0, c->st, (const unsigned long long*)c->ctr.p, (volatile unsigned long long*)c->h_ctr, seq);
 	volatile unsigned long long *flag = (volatile unsigned long long*)c->h_ctr + 64;
@@ -146,7 +135,6 @@ extern "C" mahip_ctx_t *mahip_create(int device, void *stream)
 	if (device < 0 || device >= n) { mahip_set_error("mahip_create: device %d out of range (0..%d)", device, n - 1); return nullptr; }
 	if (hipSetDevice(device) != hipSuccess) { mahip_set_error("mahip_create: hipSetDevice(%d) failed", device); return nullptr; }
 	pin_to_gpu_node(device);
-	if (getenv("MA_SYNC_SPIN")) (void)hipSetDeviceFlags(hipDeviceScheduleSpin); // experiment: the runtime's own waits spin instead of blocking
 	mahip_ctx *c = new mahip_ctx();
 	c->dev = device;
 	if (stream) c->st = (hipStream_t)stream, c->own_stream = false;

@@ -207,13 +207,12 @@ int radix_reserve_hist(mahip_ctx *c, size_t n)
 // The order the reference's in-place MSD radix sort gives to equal keys is a sequential function of the whole
 // input; the host computes it from the keys (host/refsort.c) and the device gathers through the permutation.
 extern "C" int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm);
-extern "C" void *ma_big_malloc(size_t bytes);
 
 int reference_order(mahip_ctx *c, const uint64_t *d_keys, size_t n, uint32_t *d_perm)
 {
 	if (n == 0) return 0;
-	uint64_t *hk = (uint64_t*)ma_big_malloc(n * 8);
-	uint32_t *hp = (uint32_t*)ma_big_malloc(n * 4);
+	uint64_t *hk = (uint64_t*)malloc(n * 8);
+	uint32_t *hp = (uint32_t*)malloc(n * 4);
 	if (!hk || !hp) { free(hk); free(hp); mahip_set_error("reference_order: out of host memory"); return -1; }
 	int rc = 0;
 	if (xfer_copy(c, (void*)d_keys, hk, n * 8, 0) != 0) rc = -1;

@@ -56,7 +56,7 @@ int ma_hit_ingest_loaded_excl(mahip_ctx_t *c, int min_span, int min_match, sdict
 	const int timing = getenv("MA_PIPE_TIMING") != 0;
 	double t1 = sys_realtime(), t2, t3;
 	mahip_paf_info_t info;
-	size_t i, tot_len = 0;
+	size_t tot_len = 0;
 	GPU(mahip_set_shard(c, 0, 0xffffffffu));
 	GPU_SOFT(mahip_paf_parse_excl(c, min_span, min_match, bi_dir, no_cont, max_hang, int_frac, &info));
 	if (no_cont) {
@@ -64,14 +64,15 @@ int ma_hit_ingest_loaded_excl(mahip_ctx_t *c, int min_span, int min_match, sdict
 		fprintf(MA_LOG, "[M::%s] ===> Step 1: reading read mappings <===\n", "main");
 	}
 	t2 = sys_realtime();
-	/* the dictionary: names (one block, adopted as the dictionary's arena: no per-name allocation) and first-seen lengths */
+	/* the dictionary: the names in one block (the dictionary's arena) and the sd_seq_t records the device wrote for that block -- two copies, no
+	 * per-name work on the host */
 	{
 		char *names = (char*)malloc(info.name_bytes ? info.name_bytes : 1);
-		uint32_t *lens = (uint32_t*)malloc(((size_t)info.n_seq + 1) * 4);
-		GPU(mahip_paf_names(c, names, lens));
-		ma_sd_fill(d, names, info.name_bytes, info.n_seq, lens);
-		for (i = 0; i < info.n_seq; ++i) tot_len += lens[i];
-		free(lens);
+		sd_seq_t *seq = (sd_seq_t*)malloc(((size_t)info.n_seq + 1) * sizeof(sd_seq_t));
+		uint64_t tl = 0;
+		GPU(mahip_paf_seqs(c, names, seq, &tl));
+		ma_sd_adopt(d, names, info.name_bytes, info.n_seq, seq);
+		tot_len = (size_t)tl;
 	}
 	if (release) GPU(mahip_paf_release(c));
 	t3 = sys_realtime();

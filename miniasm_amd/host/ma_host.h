@@ -44,6 +44,7 @@ ma_ug_t *ma_ug_from_device(mahip_ctx_t *c); /* unitigs of the graph resident in 
 void ma_sd_reindex(sdict_t *d);    /* build the name index from seq[] (for dictionaries assembled by hand) */
 void ma_sd_drop_index(sdict_t *d);
 void ma_sd_fill(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, const uint32_t *lens); /* bulk fill; the dictionary owns arena */
+void ma_sd_adopt(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, sd_seq_t *seq);         /* records ready-made; the dictionary owns both blocks */
 
 /* the process-wide GPU context of the per-symbol entry points; exits with an error if no GPU is usable */
 mahip_ctx_t *ma_gpu(void);
@@ -70,8 +71,7 @@ uint32_t ma_ingest_max_qs(void); /* largest query start stored by the last ma_hi
 void ma_refsort_arcs(asg_arc_t *beg, asg_arc_t *end);
 /* the same procedure on (key, input index) pairs, sub-buckets on worker threads (refsort.c): exact-tie mode */
 typedef struct { uint64_t key; uint32_t idx, pad; } ma_ki_t;
-void ma_refsort_ki(ma_ki_t **pa, size_t n, int n_threads);
-void *ma_big_malloc(size_t bytes); /* malloc; blocks of 32 MiB and more are offered to transparent huge pages */
+void ma_refsort_ki(ma_ki_t *a, size_t n, int n_threads);
 int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm); /* perm[i] = input position of the i-th record in reference order */
 
 #ifdef __cplusplus

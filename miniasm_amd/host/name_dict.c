@@ -132,6 +132,22 @@ void ma_sd_fill(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, const
 	}
 }
 
+/* the same with the records ready-made (csrc/paf.hip: k_dict_seqs wrote them for this arena): the dictionary takes both blocks over */
+void ma_sd_adopt(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, sd_seq_t *seq)
+{
+	uint32_t i;
+	sd_index_t *ix = (sd_index_t*)d->h;
+	for (i = 0; i < d->n_seq; ++i)
+		if (!in_arena(ix, d->seq[i].name)) free(d->seq[i].name);
+	if (ix == 0) { ix = (sd_index_t*)calloc(1, sizeof(sd_index_t)); d->h = ix; }
+	free(ix->arena);
+	ix->arena = arena; ix->arena_len = arena_len;
+	ix_table(ix, 0);
+	free(d->seq);
+	d->seq = seq;
+	d->n_seq = d->m_seq = n_seq;
+}
+
 int32_t sd_get(const sdict_t *d, const char *name)
 {
 	const sd_index_t *ix = (const sd_index_t*)d->h;

@@ -28,11 +28,6 @@ static int rs_timing = -1;
 #define RS_T0 double t0_ = rs_now()
 #define RS_LAP(what) do { if (rs_timing < 0) rs_timing = getenv("MA_REFSORT_TIMING") != 0; if (rs_timing) { double t1_ = rs_now(); fprintf(stderr, "[T::refsort] %-12s %.3f s\n", what, t1_ - t0_); t0_ = t1_; } } while (0)
 
-/* big scratch blocks (8 - 16 bytes per hit).  Offering them to transparent huge pages (madvise) was tried in round 3: with the usual
- * "defrag on madvise" setting the first touch then compacts memory in the faulting thread -- 20 to 60 times slower sweeps on a box that has been up
- * for a while -- so they stay ordinary pages. */
-void *ma_big_malloc(size_t bytes) { return malloc(bytes); }
-
 #define RS_SMALL 64           /* RS_MIN_SIZE ksort.h:132 */
 /* The walk touches the 256 bucket heads in an order the hardware prefetchers cannot follow (they track a few dozen streams), so every
  * new cache line of a bucket used to be a miss on the walk's dependent chain; each store now asks for the line a few ahead of its head. */
@@ -148,10 +143,10 @@ static uint64_t sweep_run(void *(*worker)(void*), const void *a, size_t n, int s
 #undef RS_CMPKEY
 #undef RS_LEVEL
 
-void ma_refsort_ki(ma_ki_t **pa, size_t n, int n_threads) /* *pa is malloc'ed; a big input comes back in a new block (the old one is freed) */
+void ma_refsort_ki(ma_ki_t *a, size_t n, int n_threads)
 {
 	rs_cfg_t cfg = { 0, 32, 0xffffffffull };
-	wide_sort(pa, n, &cfg, n_threads);
+	wide_sort(a, n, &cfg, n_threads);
 }
 
 /* perm[i] = input position of the record the reference's sort leaves at position i */
@@ -216,21 +211,21 @@ int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm)
 	if (bi == 0) bi = 1;
 	if (bh + bl + bi <= 64 && !getenv("MA_REFSORT_WIDE")) { /* one word per element */
 		f.cfg.bi = bi; f.cfg.bl = bl; f.cfg.lomask = (1ull << bl) - 1;
-		f.pk = (uint64_t*)ma_big_malloc(n * sizeof(uint64_t));
+		f.pk = (uint64_t*)malloc(n * sizeof(uint64_t));
 		if (f.pk == 0) return -1;
 		fill_run(&f, n, 3, nt);
 		RS_LAP("pack");
-		packed_sort(&f.pk, n, &f.cfg, nt);
+		packed_sort(f.pk, n, &f.cfg, nt);
 		RS_LAP("sort");
 		fill_run(&f, n, 4, nt);
 		RS_LAP("unpack");
 		free(f.pk);
 		return 0;
 	}
-	f.a = (ma_ki_t*)ma_big_malloc(n * sizeof(ma_ki_t));
+	f.a = (ma_ki_t*)malloc(n * sizeof(ma_ki_t));
 	if (f.a == 0) return -1;
 	fill_run(&f, n, 1, nt);
-	ma_refsort_ki(&f.a, n, nt);
+	ma_refsort_ki(f.a, n, nt);
 	fill_run(&f, n, 2, nt);
 	free(f.a);
 	return 0;

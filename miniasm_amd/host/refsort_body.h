@@ -34,114 +34,17 @@ static void RS_NAME(dispatch)(rs_pool_t *pool, RS_T *a, const size_t *start, int
 	}
 }
 
-/* The same permutation for the top level of a big input, where the walk is the one thing no other thread can help with -- computed from the
- * DIGITS alone and without moving anything.  The walk only ever evicts ORIGINAL elements (a slot at or behind a bucket's head has not been written
- * yet), so (a) where it goes next is a function of dig[] (one byte per element, written by the parallel sweep that counts the digits), and (b) the
- * element it picks up at a slot is the one that started there: the result can be written down as perm[slot] = original position of the arrival.
- * Runs are taken at once.  At the base bucket k a stretch of elements that are already home stays where it is (perm is the identity there, filled
- * beforehand by all threads).  Elsewhere an arrival at the head of a stretch of m home elements pushes every one of them one slot to the right
- * before the walk can leave with the first stranger: perm[slot + j] = slot + j - 1, written as one run -- or, when long, noted as a segment for the
- * parallel copy afterwards.  PAF files list a query's overlaps together, so half of the records (all of them, for a generator that writes reads in
- * genome order) are home at the top level: what cost 4.3 ns per element as a dependent chain is a byte scan there.  The elements are then moved once,
- * by all threads (rs_apply), instead of one by one inside the chain. */
-typedef struct { size_t dst, src, len; } RS_NAME(seg_t);
-typedef struct { const RS_T *in; RS_T *out; const uint32_t *perm; const RS_NAME(seg_t) *seg; size_t n, n_seg, beg, end; int phase; } RS_NAME(apply_t);
-
-static inline size_t RS_NAME(run)(const uint8_t *dig, size_t p, size_t lim, unsigned d) /* length of the stretch of digit d that starts at p (not beyond lim) */
-{
-	const uint64_t pat = 0x0101010101010101ull * d;
-	size_t q = p;
-	while (q + 8 <= lim) {
-		uint64_t x;
-		memcpy(&x, dig + q, 8);
-		x ^= pat;
-		if (x) return q + ((size_t)__builtin_ctzll(x) >> 3) - p;
-		q += 8;
-	}
-	while (q < lim && dig[q] == d) ++q;
-	return q - p;
-}
-
-static void *RS_NAME(apply_worker)(void *arg)
-{
-	RS_NAME(apply_t) *w = (RS_NAME(apply_t)*)arg;
-	size_t i;
-	if (w->phase == 0) for (i = w->beg; i < w->end; ++i) ((uint32_t*)w->perm)[i] = (uint32_t)i;
-	else if (w->phase == 1) for (i = w->beg; i < w->end; ++i) w->out[i] = w->in[w->perm[i]];
-	else if (w->phase == 2) { /* the shifted stretches: every thread takes its share [beg, end) of the destination range */
-		for (i = 0; i < w->n_seg; ++i) {
-			const size_t lo = w->seg[i].dst > w->beg ? w->seg[i].dst : w->beg, e0 = w->seg[i].dst + w->seg[i].len, hi = e0 < w->end ? e0 : w->end;
-			if (lo < hi) memcpy(w->out + lo, w->in + (w->seg[i].src + (lo - w->seg[i].dst)), (hi - lo) * sizeof(RS_T));
-		}
-	}
-	return 0;
-}
-
-static void RS_NAME(apply_run)(RS_NAME(apply_t) *proto, int phase, int n_threads)
-{
-	RS_NAME(apply_t) w[64];
-	pthread_t th[64];
-	int t;
-	if (n_threads > 64) n_threads = 64;
-	if (n_threads < 1) n_threads = 1;
-	for (t = 0; t < n_threads; ++t) { w[t] = *proto; w[t].phase = phase; w[t].beg = proto->n / n_threads * t; w[t].end = t == n_threads - 1 ? proto->n : proto->n / n_threads * (t + 1); }
-	for (t = 1; t < n_threads; ++t) pthread_create(&th[t], 0, RS_NAME(apply_worker), &w[t]);
-	RS_NAME(apply_worker)(&w[0]);
-	for (t = 1; t < n_threads; ++t) pthread_join(th[t], 0);
-}
-
-#define RS_SEG_MIN 4096 /* shifted stretches at least this long are copied by the threads afterwards instead of being written out inside the walk */
-static int RS_NAME(permute_top)(rs_pool_t *pool, RS_T **pa, size_t n, const size_t *cnt, const uint8_t *dig /* n + 8 bytes */, int shift)
-{ /* *pa (malloc'ed) is replaced by the permuted copy */
-	RS_T *a = *pa;
-	size_t start[257], head[256];
-	uint32_t *perm = (uint32_t*)ma_big_malloc((n + 1) * sizeof(uint32_t));
-	RS_T *out = (RS_T*)ma_big_malloc((n + 1) * sizeof(RS_T));
-	RS_NAME(seg_t) *seg = 0;
-	size_t n_seg = 0, m_seg = 0;
-	RS_NAME(apply_t) ap;
-	int k;
-	if (perm == 0 || out == 0) { free(perm); free(out); return -1; }
-	memset(&ap, 0, sizeof(ap));
-	ap.in = a; ap.out = out; ap.perm = perm; ap.n = n;
-	RS_NAME(apply_run)(&ap, 0, pool->n_threads); /* perm = identity */
-	start[0] = 0;
-	for (k = 0; k < 256; ++k) start[k + 1] = start[k] + cnt[k], head[k] = start[k];
-	for (k = 0; k < 256; ++k) {
-		const size_t end_k = start[k + 1];
-		for (;;) {
-			size_t carry;
-			unsigned l;
-			head[k] += RS_NAME(run)(dig, head[k], end_k, (unsigned)k); /* already home */
-			if (head[k] == end_k) break;
-			carry = head[k]; l = dig[carry];
-			do {
-				const size_t slot = head[l], m = RS_NAME(run)(dig, slot, start[l + 1], l); /* m elements of bucket l wait at its head: each moves up by one */
-				perm[slot] = (uint32_t)carry;
-				if (m >= RS_SEG_MIN) {
-					if (n_seg == m_seg) { m_seg = m_seg ? m_seg << 1 : 256; seg = (RS_NAME(seg_t)*)realloc(seg, m_seg * sizeof(*seg)); }
-					seg[n_seg].dst = slot + 1; seg[n_seg].src = slot; seg[n_seg].len = m; ++n_seg;
-				} else { size_t j; for (j = 1; j <= m; ++j) perm[slot + j] = (uint32_t)(slot + j - 1); }
-				carry = slot + m; /* the first stranger behind them leaves */
-				head[l] = slot + m + 1;
-				l = dig[carry];
-			} while (l != (unsigned)k);
-			perm[head[k]++] = (uint32_t)carry;
-		}
-	}
-	ap.seg = seg; ap.n_seg = n_seg;
-	if (rs_timing > 0) fprintf(stderr, "[T::refsort]  top walk: %zu shifted stretches of >= %d elements left to the copy threads\n", n_seg, RS_SEG_MIN);
-	RS_NAME(apply_run)(&ap, 1, pool->n_threads);
-	if (n_seg) RS_NAME(apply_run)(&ap, 2, pool->n_threads);
-	free(perm); free(seg); free(a);
-	*pa = out;
-	RS_NAME(dispatch)(pool, out, start, shift);
-	return 0;
-}
-
-/* (round 2's form, kept for one comparison run: MA_REFSORT_MOVES=1) the digit walk that moves the elements as it goes */
+/* The same permutation for the top level of a big input, where the walk is the one thing no other thread can help with.  The walk only ever
+ * evicts ORIGINAL elements -- a slot at or behind a bucket's head has not been written yet -- so where it goes next is a function of the
+ * input's digits alone: dig[] (one byte per element, written by the parallel sweep that counts the digits) replaces the look into the evicted
+ * element, and nd[d] = digit of the element at bucket d's head is kept ready per bucket.  The walk's dependent chain is then ONE load per
+ * step (d -> nd[d]); the element moves themselves hang off the bucket heads, not off each other, and overlap.
+ * Round 3 tried the walk on the digits ALONE -- a permutation written down with runs of home elements taken at once, the elements moved afterwards
+ * by all threads: 0.62 s against 0.32 s for this form on the 50 M-overlap noisy input, 8.0 s against 2.8 s at BASELINE configs[4] on the EPYC of the
+ * GPU box (profiles/r03_tiewalk.txt): noisy PAFs have few long runs, and a separate 4-byte permutation plus a gather is more memory traffic than
+ * moving 8-byte elements once.  Dropped. */
 typedef struct { size_t head; uint32_t nd; uint32_t pad; } RS_NAME(bk_t);
-static void RS_NAME(permute_top_moves)(rs_pool_t *pool, RS_T *a, const size_t *cnt, const uint8_t *dig /* n + 1 bytes */, int shift)
+static void RS_NAME(permute_top)(rs_pool_t *pool, RS_T *a, const size_t *cnt, const uint8_t *dig /* n + 1 bytes */, int shift)
 {
 	RS_NAME(bk_t) b[256];
 	size_t start[257];
@@ -249,9 +152,8 @@ static void *RS_NAME(sweep_worker)(void *arg)
 static void RS_NAME(task)(rs_pool_t *pool, void *a, size_t n, int shift) { RS_NAME(level)(pool, (RS_T*)a, n, shift); }
 
 /* the whole sort of a[0..n) */
-static void RS_NAME(sort)(RS_T **pa, size_t n, const rs_cfg_t *cfg, int n_threads)
-{ /* *pa is malloc'ed and may be replaced */
-	RS_T *a = *pa;
+static void RS_NAME(sort)(RS_T *a, size_t n, const rs_cfg_t *cfg, int n_threads)
+{
 	rs_pool_t p;
 	memset(&p, 0, sizeof(p));
 	p.cfg = *cfg; p.n_threads = 1; p.run = RS_NAME(task); p.elem = sizeof(RS_T);
@@ -270,7 +172,7 @@ static void RS_NAME(sort)(RS_T **pa, size_t n, const rs_cfg_t *cfg, int n_thread
 		RS_T0;
 		diff = sweep_run(RS_NAME(sweep_worker), a, n, -1, 0, cfg, n_threads, 0);
 		if (diff != 0) {
-			uint8_t *dig = (uint8_t*)ma_big_malloc(n + 16);
+			uint8_t *dig = (uint8_t*)malloc(n + 16);
 			while (shift > 0 && (diff >> shift & 0xff) == 0) shift -= 8;
 			if (dig) memset(dig + n, 0, 16);
 			sweep_run(RS_NAME(sweep_worker), a, n, shift, cnt, cfg, n_threads, dig);
@@ -278,8 +180,8 @@ static void RS_NAME(sort)(RS_T **pa, size_t n, const rs_cfg_t *cfg, int n_thread
 			th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
 			++p.busy; /* the top-level walk below produces tasks: workers must not leave while it runs */
 			for (t = 0; t < n_threads; ++t) pthread_create(&th[t], 0, pool_worker, &p);
-			if (dig && getenv("MA_REFSORT_MOVES")) RS_NAME(permute_top_moves)(&p, a, cnt, dig, shift);
-			else if (dig == 0 || RS_NAME(permute_top)(&p, pa, n, cnt, dig, shift) != 0) RS_NAME(permute)(&p, a, cnt, shift); /* (no memory for the digit walk: the plain one) */
+			if (dig) RS_NAME(permute_top)(&p, a, cnt, dig, shift);
+			else RS_NAME(permute)(&p, a, cnt, shift);
 			free(dig);
 			RS_LAP(" top walk");
 			pthread_mutex_lock(&p.mu);

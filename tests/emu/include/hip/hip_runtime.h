@@ -180,6 +180,9 @@ struct BufRsrc { char *base; uint32_t num_records; };
 #define __threadfence() ((void)0)
 #define __threadfence_block() ((void)0)
 #define __threadfence_system() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
 #define __builtin_amdgcn_mov_dpp(src, ctrl, rm, bm, bc) emu::mov_dpp(EMU_OP, (int)(src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu::update_dpp(EMU_OP, (int)(old), (int)(src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_ds_bpermute(addr, v) emu::ds_bpermute(EMU_OP, (int)(addr), (int)(v))

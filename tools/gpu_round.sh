@@ -29,29 +29,21 @@ probe)
   rm -rf gpurun_out/probe_pmc; mkdir -p gpurun_out/probe_pmc
   (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /root/repo/gpurun_out/probe_pmc -o r --output-format csv -- /root/repo/tools/probes/gather_probe > /dev/null 2>&1); echo "probe pmc rc=$?"
   python tools/pmc_generic.py gpurun_out/probe_pmc --filter k_ --each >> gpurun_out/gather_probe.txt 2>&1; tail -30 gpurun_out/gather_probe.txt ;;
-syncexp)
-  # how the counters come back: mailbox (default) vs copy + hipStreamSynchronize (MA_CTR_COPY=1), the latter also with the runtime spinning (MA_SYNC_SPIN=1)
-  for cfg in "" "--reads 200000 --lines 10000000 --seed 1"; do for v in "" "MA_CTR_COPY=1" "MA_CTR_COPY=1 MA_SYNC_SPIN=1"; do
-    env $v timeout 900 python bench.py --no-cpu --no-legs --no-text --prof-steps 0 --steps 20 --warmup 3 $cfg > gpurun_out/bench_sync.json 2> gpurun_out/bench_sync.log; echo "[$cfg | ${v:-mailbox}] rc=$?"
-    python3 -c "import json; d=json.load(open('gpurun_out/bench_sync.json')); print('   ms_per_step %.3f  value %.3g' % (d['ms_per_step'], d['value']))"
-  done; done
-  for cfg in "" "--reads 200000 --lines 10000000 --seed 1"; do for n in 2 3; do
+inflight)
+  # batches in flight on the one GPU (bench.py --inflight N, each on a context and host thread of its own)
+  for cfg in "" "--reads 200000 --lines 10000000 --seed 1"; do for n in 1 2 3; do
     timeout 900 python bench.py --no-cpu --no-legs --no-text --prof-steps 0 --steps 24 --warmup 3 --inflight $n $cfg > gpurun_out/bench_sync.json 2> gpurun_out/bench_sync.log; echo "[$cfg | inflight $n] rc=$?"
     python3 -c "import json; d=json.load(open('gpurun_out/bench_sync.json')); print('   ms_per_step %.3f  value %.3g' % (d['ms_per_step'], d['value']))"
   done; done ;;
 tiewalk)
-  # the host walk that reproduces the reference's tie order: laps of host/refsort.c on the 50 M noisy input and on BASELINE configs[4], run-skipping digit walk vs the element-moving one
+  # the host walk that reproduces the reference's tie order: laps of host/refsort.c on the 50 M noisy input and (TIEWALK_CFG5=1) on BASELINE configs[4]
   miniasm_amd/bin/pafgen -r 1000000 -n 50000000 -s 3 -L uniform -d 0.35 -x 0.03 -o /tmp/tw50.paf 2>/dev/null
-  for v in "" "MA_REFSORT_MOVES=1"; do
-    env $v MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm /tmp/tw50.paf 2> gpurun_out/tiewalk50_${v:-runs}.log | md5sum
-    grep -E "T::refsort|T::ties|T::head\] sg_gen|Real time|T::xfer.*HBM->host" gpurun_out/tiewalk50_${v:-runs}.log | head -30
-  done
+  MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm /tmp/tw50.paf 2> gpurun_out/tiewalk50.log | md5sum
+  grep -E "T::refsort|T::ties|T::head\\] sg_gen|Real time|T::xfer.*HBM->host" gpurun_out/tiewalk50.log | head -30
   if [ -n "$TIEWALK_CFG5" ]; then
     miniasm_amd/bin/pafgen -r 5000000 -n 500000000 -s 3 -L uniform -d 0.35 -x 0.03 -o /tmp/tw5.paf 2>/dev/null
-    for v in "" "MA_REFSORT_MOVES=1"; do
-      env $v MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 900 miniasm_amd/bin/miniasm /tmp/tw5.paf 2> gpurun_out/tiewalk5_${v:-runs}.log | md5sum
-      grep -E "T::refsort|T::ties|T::head\] sg_gen|Real time|T::xfer.*HBM->host" gpurun_out/tiewalk5_${v:-runs}.log | head -30
-    done
+    MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 900 miniasm_amd/bin/miniasm /tmp/tw5.paf 2> gpurun_out/tiewalk5.log | md5sum
+    grep -E "T::refsort|T::ties|T::head\\] sg_gen|Real time|T::xfer.*HBM->host" gpurun_out/tiewalk5.log | head -40
     echo "(reference md5 of this input, profiles/r03_e2e_cfg5_500M.txt: fa9c76984d44526d1a9a9e70132d01da)"
   fi ;;
 projection)

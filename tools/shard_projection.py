@@ -21,6 +21,10 @@ LAT_US = 25.0      # per collective
 
 
 def worker(a):
+    import torch  # first: its HIP runtime has to be the one the process initialises (bench.py's order), or torch sees no device afterwards
+    if not torch.cuda.is_available():
+        sys.exit("shard_projection.py needs a GPU")
+    torch.cuda.set_device(0)
     import miniasm_amd as ma
     import bench
     L = ma.lib()
