@@ -427,8 +427,42 @@ __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q,
 // Three instantiations per fusion mode share the work by read size, so that each runs at the occupancy its register
 // need allows: CLS 0 = reads with <= 128 hits (4 events per lane, 8 waves/SIMD, software-pipelined loads), CLS 1 = 129..256
 // hits (16 events per lane), CLS 2 = 257..512 hits (32 events per lane); larger reads go to the block kernel (tier B).
+// Workgroups go to the 8 XCDs round-robin (workgroup i runs on XCD i mod 8), and every XCD has an L2 of its own.  The first coverage pass fetches
+// records through the sorted keys; the record of a line and its mirror share a 64-byte sector and belong to two reads that lie close together in
+// id order, so reads that are neighbours should be swept on the SAME XCD: its L2 then serves the second half of the sector instead of fetching it
+// again.  With XCD_REMAP the block ids one XCD sees are made consecutive: block (x, k) -> x * G/8 + k.  (experiment switch, default off)
+#ifndef XCD_REMAP
+#define XCD_REMAP 0
+#endif
+__device__ __forceinline__ unsigned sub_block_id()
+{
+#if XCD_REMAP
+	const unsigned b = blockIdx.x, g8 = gridDim.x & ~7u;
+	return b < g8 ? (b & 7u) * (g8 >> 3) + (b >> 3) : b;
+#else
+	return blockIdx.x;
+#endif
+}
+#ifndef SUB_WPE_G0   // experiment knobs: waves per SIMD the compiler must fit (0 = its own choice) -- gather tier 0 / fused tier 0 / fused tier 1
+#define SUB_WPE_G0 0
+#endif
+#ifndef SUB_WPE_F0
+#define SUB_WPE_F0 0
+#endif
+#ifndef SUB_WPE_F1
+#define SUB_WPE_F1 0
+#endif
+#ifndef SUB_WPE_G1
+#define SUB_WPE_G1 0
+#endif
+#if defined(__HIP__) && defined(__clang__) /* (the CPU test build of this file is g++) */
+#define SUB_WPE_ATTR(F, C, G) __attribute__((amdgpu_waves_per_eu(sub_wpe(F, C, G))))
+#else
+#define SUB_WPE_ATTR(F, C, G)
+#endif
+constexpr unsigned sub_wpe(bool fuse, int cls, bool gather) { return gather && cls == 0 ? SUB_WPE_G0 : gather && cls == 1 ? SUB_WPE_G1 : fuse && cls == 0 ? SUB_WPE_F0 : fuse && cls == 1 ? SUB_WPE_F1 : 0; }
 template <bool FUSE, int CLS, bool GATHER = false>
-__global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
+__global__ __launch_bounds__(256) SUB_WPE_ATTR(FUSE, CLS, GATHER) void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
                                                   int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
                                                   uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr, SubFuse f, SubGather g)
 {
@@ -439,7 +473,7 @@ __global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__re
 	if (CLS == 0 && GATHER) { // three-deep software pipeline over the chain bounds -> keys -> records: every load is issued a whole sweep before its
 		// first use, and nothing in between waits for it
 		const uint64_t stride = (uint64_t)gridDim.x * 4;
-		uint64_t q = blockIdx.x * 4 + wave;
+		uint64_t q = sub_block_id() * 4 + wave;
 		GBounds bn;
 		GKeys kn;
 		GRecs cur, nxt;
@@ -482,7 +516,7 @@ __global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__re
 	} else
 	if (CLS == 0) { // software pipeline: the hits of the wave's next read are in flight while the current read is processed
 		const uint32_t stride = gridDim.x * 4;
-		uint32_t q = blockIdx.x * 4 + wave;
+		uint32_t q = sub_block_id() * 4 + wave;
 		SubPre cur, nxt;
 		if (q < n_seq) sub_preload<FUSE>(c, goff, q, lane, cur);
 		while (q < n_seq) {
@@ -502,7 +536,7 @@ __global__ __launch_bounds__(256) void k_hit_sub(HitCols c, const uint32_t *__re
 	} else
 	// a wave takes SUB_CHUNK consecutive reads at a time: their bounds come with one coalesced load, and only the reads of this instantiation's
 	// size class are visited (a dependent load per read, most of them somebody else's, is pure latency)
-	for (uint64_t qb = (uint64_t)(blockIdx.x * 4 + wave) * chunk; qb < n_seq; qb += (uint64_t)gridDim.x * 4 * chunk) {
+	for (uint64_t qb = (uint64_t)(sub_block_id() * 4 + wave) * chunk; qb < n_seq; qb += (uint64_t)gridDim.x * 4 * chunk) {
 	const bool in = lane < chunk && qb + lane < n_seq;
 	const uint32_t beg_l = in ? goff[qb + lane] : 0, end_l = in ? goff[qb + lane + 1] : 0, H_l = end_l - beg_l;
 	unsigned long long todo = wv_ballot(CLS == 1 ? (H_l > 128 && H_l <= 256) : H_l > 256);
@@ -1126,6 +1160,24 @@ extern "C" int mahip_hits_index(mahip_ctx_t *c)
 	return 0;
 }
 
+
+// EXPERIMENT (MA_SUB_STREAMS=1): the three size-class launches of a coverage pass side by side on three streams instead of back to back -- each
+// visits all reads and works on its own class only, so together they are one pass; side by side the later classes fill the first one's tail.
+static bool sub_streams() { static int v = -1; if (v < 0) { const char *e = getenv("MA_SUB_STREAMS"); v = e && atoi(e) != 0; } return v != 0; }
+struct SubFork {
+	mahip_ctx *c; bool on;
+	hipStream_t side[2]; hipEvent_t start, done[2];
+	SubFork(mahip_ctx *c_) : c(c_), on(sub_streams()) {
+		if (!on) return;
+		if (!c->sub_side[0]) { for (int k = 0; k < 2; ++k) (void)hipStreamCreateWithFlags(&c->sub_side[k], hipStreamNonBlocking); for (int k = 0; k < 3; ++k) (void)hipEventCreateWithFlags(&c->sub_ev[k], hipEventDisableTiming); }
+		side[0] = c->sub_side[0]; side[1] = c->sub_side[1]; start = c->sub_ev[0]; done[0] = c->sub_ev[1]; done[1] = c->sub_ev[2];
+		(void)hipEventRecord(start, c->st);
+		for (int k = 0; k < 2; ++k) (void)hipStreamWaitEvent(side[k], start, 0);
+	}
+	hipStream_t st(int cls) const { return on && cls > 0 ? side[cls - 1] : c->st; }
+	void join() { if (!on) return; for (int k = 0; k < 2; ++k) { (void)hipEventRecord(done[k], side[k]); (void)hipStreamWaitEvent(c->st, done[k], 0); } }
+};
+
 extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int end_clip, int slot, size_t *n_remained)
 {
 	HIPCHK(hipSetDevice(c->dev));
@@ -1143,12 +1195,14 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 	if (fuse_gather) { // the sweep fetches the records itself and writes the columns on the way
 		SubGather g = {(const uint64_t*)P<uint64_t>(c->key[c->gk_gen]), c->d_aos, P<uint32_t>(c->sidx), c->gk_bi, (uint32_t)c->n_hits, sub_chunk(R)};
 		ProfScope ps(c, "k_hit_sub<gather>", (64.0 + 48.0) * (double)c->n_hits); // hit sort 64 (32 r + 32 w, counted once whatever the digit passes) + ma_hit_sub 48 B per stored hit
-		hipLaunchKernelGGL((k_hit_sub<false, 0, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		SubFork fk(c);
+		hipLaunchKernelGGL((k_hit_sub<false, 0, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(0), h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-		hipLaunchKernelGGL((k_hit_sub<false, 1, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 1, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(1), h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-		hipLaunchKernelGGL((k_hit_sub<false, 2, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 2, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(2), h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+		fk.join();
 		c->gather_pending = false;
 	} else if (R) {
 		ProfScope ps(c, "k_hit_sub", 48.0 * (double)c->n_hits + 8.0 * R); // 32 r + 8 w events + 8 r events per stored hit
@@ -1188,12 +1242,14 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
 	SubFuse f = {(const uint2*)P<uint2>(c->sub[cut_slot]), min_span, max_hang, min_ovlp, P<uint8_t>(c->r_live)};
 	if (R) {
 		ProfScope ps(c, "k_hit_sub<cut+flt>", (80.0 + 80.0 + 48.0) * (double)c->n_hits + 8.0 * R); // cut 80 + flt 80 + sub 48 B per hit
-		hipLaunchKernelGGL((k_hit_sub<true, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		SubFork fk(c);
+		hipLaunchKernelGGL((k_hit_sub<true, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(0), h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(R)});
-		hipLaunchKernelGGL((k_hit_sub<true, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<true, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(1), h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(R)});
-		hipLaunchKernelGGL((k_hit_sub<true, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<true, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(2), h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(R)});
+		fk.join();
 	}
 	if (R) {
 		CHK(dev_reserve(c, c->big0, (2 * c->n_hits + 8) * 4));

@@ -22,13 +22,29 @@
 #define RS_WAVES (RS_THREADS / 64)
 #define RS_BINS (1 << RS_MAXBITS) // RS_MAXBITS: mahip_internal.hpp
 
+// experiment (XCD_REMAP_RADIX): tiles that are neighbours write neighbouring runs of every digit; on the same XCD (workgroup i runs on XCD i mod 8, one
+// L2 each) the pieces of a cache line they share meet in one L2 before they are written back
+#ifndef XCD_REMAP_RADIX
+#define XCD_REMAP_RADIX 0
+#endif
+__device__ __forceinline__ unsigned rs_tile_id()
+{
+#if XCD_REMAP_RADIX
+	const unsigned b = blockIdx.x, g8 = gridDim.x & ~7u;
+	return b < g8 ? (b & 7u) * (g8 >> 3) + (b >> 3) : b;
+#else
+	return blockIdx.x;
+#endif
+}
+
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint64_t *__restrict__ key, uint32_t *__restrict__ hist,
                                                             size_t n, unsigned nb, int shift, unsigned mask)
 {
 	__shared__ uint32_t s_cnt[RS_BINS];
 	for (unsigned d = threadIdx.x; d <= mask; d += RS_THREADS) s_cnt[d] = 0;
 	__syncthreads();
-	size_t base = (size_t)blockIdx.x * RS_TILE;
+	const unsigned tid_ = rs_tile_id();
+	size_t base = (size_t)tid_ * RS_TILE;
 	if (base + RS_TILE <= n) { // full tile: two keys per 16-byte load, all loads in flight before the first LDS atomic
 		const ulonglong2 *p = (const ulonglong2*)(key + base);
 		ulonglong2 kk[RS_ITEMS / 2];
@@ -46,7 +62,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint64_t *__res
 		}
 	}
 	__syncthreads();
-	for (unsigned d = threadIdx.x; d <= mask; d += RS_THREADS) hist[(size_t)d * nb + blockIdx.x] = s_cnt[d];
+	for (unsigned d = threadIdx.x; d <= mask; d += RS_THREADS) hist[(size_t)d * nb + tid_] = s_cnt[d];
 }
 
 // Element order inside a tile is (wave, item, lane): element index = tile + wave*64*ITEMS + item*64 + lane.
@@ -64,7 +80,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
 	const uint64_t lt = wv_lt(lane);
 	for (unsigned d = threadIdx.x; d < RS_WAVES * RS_BINS; d += RS_THREADS) (&s_cnt[0][0])[d] = 0;
 	__syncthreads();
-	const size_t tile = (size_t)blockIdx.x * RS_TILE, wbase = tile + (size_t)wave * 64 * RS_ITEMS;
+	const unsigned tid_ = rs_tile_id();
+	const size_t tile = (size_t)tid_ * RS_TILE, wbase = tile + (size_t)wave * 64 * RS_ITEMS;
 	const unsigned n_tile = (unsigned)(n - tile < RS_TILE ? n - tile : RS_TILE);
 	uint64_t k[RS_ITEMS];
 	uint32_t v[RS_ITEMS], r[RS_ITEMS];
@@ -105,7 +122,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
 #pragma unroll
 		for (int k = 0; k < RS_DPT; ++k) {
 			for (int w = 0; w < RS_WAVES; ++w) s_cnt[w][d0 + k] = ex + wo[k][w];
-			if (d0 + k <= mask) s_gb[d0 + k] = gofs[(size_t)(d0 + k) * nb + blockIdx.x] - ex;
+			if (d0 + k <= mask) s_gb[d0 + k] = gofs[(size_t)(d0 + k) * nb + tid_] - ex;
 			ex += cd[k];
 		}
 	}

@@ -286,6 +286,7 @@ hipError_t hipStreamDestroy(hipStream_t st);
 hipError_t hipStreamSynchronize(hipStream_t st);
 static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; } /* launches are synchronous here */
 static inline hipError_t hipSetDeviceFlags(unsigned) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; } /* launches are synchronous here */
 hipError_t hipEventCreate(hipEvent_t *e);
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);

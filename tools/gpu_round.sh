@@ -46,6 +46,9 @@ tiewalk)
     grep -E "T::refsort|T::ties|T::head\\] sg_gen|Real time|T::xfer.*HBM->host" gpurun_out/tiewalk5.log | head -40
     echo "(reference md5 of this input, profiles/r03_e2e_cfg5_500M.txt: fa9c76984d44526d1a9a9e70132d01da)"
   fi ;;
+benchtext)
+  timeout 900 python bench.py --no-cpu --no-legs --steps 6 --warmup 2 --prof-steps 0 > gpurun_out/bench_text.json 2> gpurun_out/bench_text.log; echo "rc=$?"
+  python3 -c "import json; d=json.load(open('gpurun_out/bench_text.json')); print('   step %.3f ms, from_text %.2f ms/step, parse+dictionary %.3f s' % (d['ms_per_step'], d['from_text']['ms_per_step'], d['setup']['parse_dictionary_s']))" ;;
 projection)
   timeout 1500 python tools/shard_projection.py --ranks 1,2,4,8 --steps 3 > gpurun_out/shard_projection.log 2>&1; echo "rc=$?"; grep -E "^N=" gpurun_out/shard_projection.log ;;
 bigthree)
@@ -93,7 +96,8 @@ expbuild)
   eval "bash tools/variants.sh build base:\"\" $VARIANTS" | tail -8 ;;
 exprun)
   # parity first (a variant that is not bit-exact is not worth timing), then bench.py per variant
-  for v in $VARIANT_NAMES; do
+  for v in ${PARITY_NAMES:-$VARIANT_NAMES}; do
+    case $v in *+*) continue ;; esac
     MINIASM_AMD_LIB=$PWD/build/variants/$v/libminiasm_amd.so timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=line -p no:cacheprovider -x > gpurun_out/tests_var_$v.log 2>&1; echo "[$v] parity rc=$?"
   done
   bash tools/variants.sh run base $VARIANT_NAMES ;;

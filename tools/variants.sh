@@ -17,17 +17,18 @@ build)
   done ;;
 run)
   mkdir -p gpurun_out/variants
-  for name in "$@"; do
-    lib=$PWD/build/variants/$name/libminiasm_amd.so
+  for spec in "$@"; do # name, or name+ENV=VALUE (the variant's library with an environment switch on)
+    name=${spec//+/_}; vlib=${spec%%+*}; venv=""; [ "$spec" != "$vlib" ] && venv=${spec#*+}
+    lib=$PWD/build/variants/$vlib/libminiasm_amd.so
     [ -f $lib ] || { echo "$name: not built"; continue; }
-    MINIASM_AMD_LIB=$lib timeout 600 python bench.py --no-cpu --no-legs --no-text --steps 5 --warmup 1 > gpurun_out/variants/$name.json 2> gpurun_out/variants/$name.log
+    env $venv MINIASM_AMD_LIB=$lib timeout 600 python bench.py --no-cpu --no-legs --no-text --steps 8 --warmup 2 > gpurun_out/variants/$name.json 2> gpurun_out/variants/$name.log
     python3 - $name <<'PY'
 import json, sys
 n = sys.argv[1]
 try:
     d = json.load(open("gpurun_out/variants/%s.json" % n))
     ks = {k["name"]: (k["launches_per_step"], k["avg_ms"]) for k in d["kernels"]}
-    print("%-12s step %.3f ms | " % (n, d["ms_per_step"]) + "  ".join("%s %gx%.3f" % (k, v[0], v[1]) for k, v in ks.items() if k in ("k_hit_gather", "k_radix_scatter", "k_radix_hist", "k_hit_keys", "k_hit_sub", "k_hit_sub<cut+flt>", "k_hit_cut_contained", "k_sg_emit")))
+    print("%-12s step %.3f ms | " % (n, d["ms_per_step"]) + "  ".join("%s %gx%.3f" % (k, v[0], v[1]) for k, v in ks.items() if k in ("k_hit_sub<gather>", "k_radix_scatter", "k_radix_hist", "k_hit_keys", "k_hit_sub<cut+flt>", "k_hit_cut_contained")))
 except Exception as e:
     print(n, "failed:", e)
 PY
