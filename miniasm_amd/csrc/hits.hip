@@ -430,37 +430,21 @@ __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q,
 // Workgroups go to the 8 XCDs round-robin (workgroup i runs on XCD i mod 8), and every XCD has an L2 of its own.  The first coverage pass fetches
 // records through the sorted keys; the record of a line and its mirror share a 64-byte sector and belong to two reads that lie close together in
 // id order, so reads that are neighbours should be swept on the SAME XCD: its L2 then serves the second half of the sector instead of fetching it
-// again.  With XCD_REMAP the block ids one XCD sees are made consecutive: block (x, k) -> x * G/8 + k.  (experiment switch, default off)
-#ifndef XCD_REMAP
-#define XCD_REMAP 0
-#endif
+// again.  The block ids one XCD sees are therefore made consecutive: block (x, k) -> x * G/8 + k.
 __device__ __forceinline__ unsigned sub_block_id()
 {
-#if XCD_REMAP
 	const unsigned b = blockIdx.x, g8 = gridDim.x & ~7u;
 	return b < g8 ? (b & 7u) * (g8 >> 3) + (b >> 3) : b;
-#else
-	return blockIdx.x;
-#endif
 }
-#ifndef SUB_WPE_G0   // experiment knobs: waves per SIMD the compiler must fit (0 = its own choice) -- gather tier 0 / fused tier 0 / fused tier 1
-#define SUB_WPE_G0 0
-#endif
-#ifndef SUB_WPE_F0
-#define SUB_WPE_F0 0
-#endif
-#ifndef SUB_WPE_F1
-#define SUB_WPE_F1 0
-#endif
-#ifndef SUB_WPE_G1
-#define SUB_WPE_G1 0
-#endif
+// Waves per SIMD the compiler has to fit (0 = its own choice): the gather tier 0 needs 82 VGPRs of its own accord (5 waves), 80 with the target (6);
+// the fused tier 1 98 (4 waves) against 96 (5).  Round 3, all four changes together (these two, the XCD order here and in radix.hip, the size classes
+// side by side): 20.18 -> 19.11 ms per pass on the same box, k_hit_sub<gather> 6.67 -> 5.98 ms, the fused pass 3.77 -> 3.42 ms (profiles/r03_experiments.txt).
 #if defined(__HIP__) && defined(__clang__) /* (the CPU test build of this file is g++) */
 #define SUB_WPE_ATTR(F, C, G) __attribute__((amdgpu_waves_per_eu(sub_wpe(F, C, G))))
 #else
 #define SUB_WPE_ATTR(F, C, G)
 #endif
-constexpr unsigned sub_wpe(bool fuse, int cls, bool gather) { return gather && cls == 0 ? SUB_WPE_G0 : gather && cls == 1 ? SUB_WPE_G1 : fuse && cls == 0 ? SUB_WPE_F0 : fuse && cls == 1 ? SUB_WPE_F1 : 0; }
+constexpr unsigned sub_wpe(bool fuse, int cls, bool gather) { return gather && cls == 0 ? 6 : fuse && cls == 1 ? 5 : 0; }
 template <bool FUSE, int CLS, bool GATHER = false>
 __global__ __launch_bounds__(256) SUB_WPE_ATTR(FUSE, CLS, GATHER) void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
                                                   int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
@@ -1161,13 +1145,12 @@ extern "C" int mahip_hits_index(mahip_ctx_t *c)
 }
 
 
-// EXPERIMENT (MA_SUB_STREAMS=1): the three size-class launches of a coverage pass side by side on three streams instead of back to back -- each
-// visits all reads and works on its own class only, so together they are one pass; side by side the later classes fill the first one's tail.
-static bool sub_streams() { static int v = -1; if (v < 0) { const char *e = getenv("MA_SUB_STREAMS"); v = e && atoi(e) != 0; } return v != 0; }
+// The three size-class launches of a coverage pass run side by side on three streams instead of back to back -- each visits all reads and works
+// on its own class only, so together they are one pass; side by side the later classes fill the first one's tail (round 3: the fused pass 3.77 -> 3.42 ms).
 struct SubFork {
 	mahip_ctx *c; bool on;
 	hipStream_t side[2]; hipEvent_t start, done[2];
-	SubFork(mahip_ctx *c_) : c(c_), on(sub_streams()) {
+	SubFork(mahip_ctx *c_) : c(c_), on(true) {
 		if (!on) return;
 		if (!c->sub_side[0]) { for (int k = 0; k < 2; ++k) (void)hipStreamCreateWithFlags(&c->sub_side[k], hipStreamNonBlocking); for (int k = 0; k < 3; ++k) (void)hipEventCreateWithFlags(&c->sub_ev[k], hipEventDisableTiming); }
 		side[0] = c->sub_side[0]; side[1] = c->sub_side[1]; start = c->sub_ev[0]; done[0] = c->sub_ev[1]; done[1] = c->sub_ev[2];

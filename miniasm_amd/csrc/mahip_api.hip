@@ -157,6 +157,8 @@ extern "C" void mahip_destroy(mahip_ctx_t *c)
 	(void)hipStreamSynchronize(c->st);
 	for (auto &e : c->pev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 	for (hipEvent_t e : c->mark_ev) if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : c->sub_ev) if (e) (void)hipEventDestroy(e);
+	for (hipStream_t t : c->sub_side) if (t) (void)hipStreamDestroy(t);
 	DevBuf *all[] = { &c->aos_own, &c->goff, &c->sub[0], &c->sub[1], &c->r_cont, &c->r_used, &c->r_del, &c->r_live, &c->map, &c->surv,
 		&c->au[0], &c->au[1], &c->av[0], &c->av[1], &c->alen[0], &c->alen[1], &c->aol[0], &c->aol[1], &c->idx, &c->sdel, &c->slen,
 		&c->keep, &c->pos, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->hist, &c->scan_tmp[0], &c->scan_tmp[1], &c->scan_tmp[2],

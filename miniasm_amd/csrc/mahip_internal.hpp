@@ -100,7 +100,7 @@ struct mahip_ctx {
 	void *paf = nullptr;       // text-ingest buffers (paf.hip)
 
 	hipEvent_t mark_ev[64] = {}; // phase marks (mahip_mark)
-	hipStream_t sub_side[2] = {}; hipEvent_t sub_ev[3] = {}; // experiment MA_SUB_STREAMS (hits.hip)
+	hipStream_t sub_side[2] = {}; hipEvent_t sub_ev[3] = {}; // side streams of the coverage passes' size classes (hits.hip: SubFork)
 	unsigned long long mark_set = 0;
 	// ---- profiling ----
 	bool prof = false;

@@ -22,19 +22,12 @@
 #define RS_WAVES (RS_THREADS / 64)
 #define RS_BINS (1 << RS_MAXBITS) // RS_MAXBITS: mahip_internal.hpp
 
-// experiment (XCD_REMAP_RADIX): tiles that are neighbours write neighbouring runs of every digit; on the same XCD (workgroup i runs on XCD i mod 8, one
-// L2 each) the pieces of a cache line they share meet in one L2 before they are written back
-#ifndef XCD_REMAP_RADIX
-#define XCD_REMAP_RADIX 0
-#endif
+// Tiles that are neighbours write neighbouring runs of every digit; on the same XCD (workgroup i runs on XCD i mod 8, one L2 each) the pieces of a cache
+// line they share meet in one L2 before they are written back: the tile a block works on is chosen so that an XCD sees consecutive tiles.
 __device__ __forceinline__ unsigned rs_tile_id()
 {
-#if XCD_REMAP_RADIX
 	const unsigned b = blockIdx.x, g8 = gridDim.x & ~7u;
 	return b < g8 ? (b & 7u) * (g8 >> 3) + (b >> 3) : b;
-#else
-	return blockIdx.x;
-#endif
 }
 
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint64_t *__restrict__ key, uint32_t *__restrict__ hist,
