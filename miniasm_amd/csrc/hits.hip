@@ -125,13 +125,21 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 		// reads qprev+1 .. q start at slot i (reads without hits get empty groups)
 		const uint32_t r0 = first ? 0 : qprev + 1;
 		if (q > n_seq) q = n_seq;
-		for (uint32_t r = r0; r <= q && r <= n_seq; ++r) goff[r] = (uint32_t)i[u];
+		if (goff) for (uint32_t r = r0; r <= q && r <= n_seq; ++r) goff[r] = (uint32_t)i[u];
 	}
 }
 
 // group offsets alone, from the sorted keys (the gather itself is left to the first coverage pass: k_hit_sub<false,*,true>)
-__global__ __launch_bounds__(256) void k_hit_goff(const uint64_t *__restrict__ skey, int bi, size_t n, uint32_t n_seq, uint32_t *__restrict__ goff)
-{ // two slots per thread (one 16-byte load); slot n is the sentinel that closes the last groups
+// On a shard the reads below q_lo and above q_hi have no hits here: their (empty) groups are written by k_goff_outside, all lanes at once -- left to the
+// thread that meets the first hit / the sentinel they were one serial loop over up to 7/8 of the reads (found by the round-3 projection: 17 - 29 ms per pass
+// on every rank of a sharded run, however small its shard).
+__global__ __launch_bounds__(256) void k_goff_outside(uint32_t *__restrict__ goff, uint32_t q_lo, uint32_t q_hi, uint32_t n_seq, uint32_t n)
+{
+	for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r <= n_seq; r += gridDim.x * 256u)
+		if (r < q_lo) goff[r] = 0u; else if (r > q_hi) goff[r] = n;
+}
+__global__ __launch_bounds__(256) void k_hit_goff(const uint64_t *__restrict__ skey, int bi, size_t n, uint32_t n_seq, uint32_t *__restrict__ goff, uint32_t q_lo, uint32_t q_hi)
+{ // two slots per thread (one 16-byte load); slot n is the sentinel that closes the last groups.  Groups of the reads q_lo .. q_hi only (k_goff_outside: the rest)
 	for (size_t base = (size_t)blockIdx.x * 512; base <= n; base += (size_t)gridDim.x * 512) {
 		const size_t i0 = base + 2 * (size_t)threadIdx.x;
 		uint32_t q0 = n_seq, q1 = n_seq;
@@ -141,8 +149,11 @@ __global__ __launch_bounds__(256) void k_hit_goff(const uint64_t *__restrict__ s
 		if (q1 > n_seq) q1 = n_seq;
 		uint32_t qprev = __shfl_up(q1, 1, 64); // the predecessor's id from the neighbouring lane; only the first lane of a wave loads it
 		if ((threadIdx.x & 63) == 0 && i0 && i0 <= n) qprev = (uint32_t)(skey[i0 - 1] >> bi);
-		if (i0 <= n) for (uint32_t r = i0 ? qprev + 1 : 0; r <= q0; ++r) goff[r] = (uint32_t)i0; // reads qprev+1 .. q start at slot i (reads without hits: empty groups)
-		if (i0 + 1 <= n) for (uint32_t r = q0 + 1; r <= q1; ++r) goff[r] = (uint32_t)(i0 + 1);
+		if (i0 <= n) { // reads qprev+1 .. q start at slot i (reads without hits: empty groups)
+			const uint32_t lo = i0 ? qprev + 1 : q_lo, hi = q0 < q_hi ? q0 : q_hi;
+			for (uint32_t r = lo > q_lo ? lo : q_lo; r <= hi; ++r) goff[r] = (uint32_t)i0;
+		}
+		if (i0 + 1 <= n) { const uint32_t hi = q1 < q_hi ? q1 : q_hi; for (uint32_t r = q0 + 1 > q_lo ? q0 + 1 : q_lo; r <= hi; ++r) goff[r] = (uint32_t)(i0 + 1); }
 	}
 }
 
@@ -1109,7 +1120,9 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	CHK(radix_sort_keys(c, n, bi, bi + bq, &gen, first_hist));
 	{ // the records stay where they are for now: the first consumer moves them (hits_need_cols), ma_hit_sub while it sweeps them
 		ProfScope ps(c, "k_hit_goff", 8.0 * (double)n);
-		hipLaunchKernelGGL(k_hit_goff, dim3(grid_for(n + 1, 512, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[gen]), bi, n, c->n_seq, P<uint32_t>(c->goff));
+		const uint32_t q_lo = sharded ? c->q_beg : 0u, q_hi = sharded && c->q_end < c->n_seq ? c->q_end : c->n_seq;
+		if (sharded) hipLaunchKernelGGL(k_goff_outside, dim3(grid_for((size_t)c->n_seq + 1, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, P<uint32_t>(c->goff), q_lo, q_hi, c->n_seq, (uint32_t)n);
+		hipLaunchKernelGGL(k_hit_goff, dim3(grid_for(n + 1, 512, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[gen]), bi, n, c->n_seq, P<uint32_t>(c->goff), q_lo, q_hi);
 	}
 	HIPCHK(hipGetLastError());
 	c->gather_pending = true; c->gk_gen = gen; c->gk_bi = bi;
@@ -1125,7 +1138,7 @@ int hits_need_cols(mahip_ctx *c, const char *who)
 	const size_t n = c->n_hits;
 	ProfScope ps(c, "k_hit_gather", 76.0 * (double)n); // key 8 + record 32 + columns 32 + input position 4
 	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256 * GATHER_ILP)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)P<uint64_t>(c->key[c->gk_gen]),
-	                   c->gk_bi, n, c->n_seq, cols_of(c), P<uint32_t>(c->goff), P<uint32_t>(c->sidx));
+	                   c->gk_bi, n, c->n_seq, cols_of(c), (uint32_t*)nullptr /* the group offsets are there already (k_hit_goff) */, P<uint32_t>(c->sidx));
 	HIPCHK(hipGetLastError());
 	c->gather_pending = false;
 	return 0;

@@ -46,6 +46,14 @@ tiewalk)
     grep -E "T::refsort|T::ties|T::head\\] sg_gen|Real time|T::xfer.*HBM->host" gpurun_out/tiewalk5.log | head -40
     echo "(reference md5 of this input, profiles/r03_e2e_cfg5_500M.txt: fa9c76984d44526d1a9a9e70132d01da)"
   fi ;;
+parseprof)
+  # per-kernel times of the text-resident leg (device parse + dictionary inside the step)
+  rm -rf gpurun_out/parseprof; mkdir -p gpurun_out/parseprof
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/parseprof -o r --output-format csv -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu --no-legs --prof-steps 0 > /root/repo/gpurun_out/parseprof/bench.json 2> /root/repo/gpurun_out/parseprof/bench.log); echo "rc=$?"
+  f=$(find gpurun_out/parseprof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "k_paf|k_dict|k_rec_|k_scan" "$f" | cut -c1-60,200-400 | head -20; python3 -c "import json; d=json.load(open('gpurun_out/parseprof/bench.json')); print('from_text %.2f ms/step' % d['from_text']['ms_per_step'])"
+  find gpurun_out/parseprof -name "*trace*.csv" -size +8M -delete ;;
+shardsort)
+  timeout 900 python tools/shard_sort_probe.py 2>&1 | grep -E "^rank|Error|error" ;;
 benchtext)
   timeout 900 python bench.py --no-cpu --no-legs --steps 6 --warmup 2 --prof-steps 0 > gpurun_out/bench_text.json 2> gpurun_out/bench_text.log; echo "rc=$?"
   python3 -c "import json; d=json.load(open('gpurun_out/bench_text.json')); print('   step %.3f ms, from_text %.2f ms/step, parse+dictionary %.3f s' % (d['ms_per_step'], d['from_text']['ms_per_step'], d['setup']['parse_dictionary_s']))" ;;
