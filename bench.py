@@ -159,6 +159,11 @@ class Workload:
         _, q0, q1 = shard_range(self.n_seq, world, rank)
         if world == 1:
             q0, q1 = 0, 0xffffffff
+        else:  # read ranges with equally many hits; the table stays in the context for the sharded head (host/sharded.c)
+            L.mahip_hits_balance.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]
+            bounds = (C.c_uint32 * (world + 1))()
+            ma._chk(L.mahip_hits_balance(ctx.h, world, bounds), "balance")
+            q0, q1 = bounds[rank], bounds[rank + 1]
         n_my = C.c_size_t(0)
         ma._chk(L.mahip_hits_raw_extract(ctx.h, q0, q1, None, C.byref(n_my)), "raw_extract")
         self.n_my = n_my.value

@@ -33,6 +33,12 @@ int mahip_hits_upload(mahip_ctx_t *c, const ma_hit_t *h, size_t n, uint32_t n_se
 int mahip_hits_adopt(mahip_ctx_t *c, const void *d_hits, size_t n, uint32_t n_seq);
 /* Multi-GPU: this context owns the hits whose query id lies in [q_beg,q_end); call before sort/index. */
 int mahip_set_shard(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end);
+/* Read ranges that hold equally many hits: bounds[0..world], rank r owns [bounds[r], bounds[r+1]).  mahip_hits_balance computes the table from the unsorted
+ * records in the context (identical on every rank that holds the whole input) and keeps it; mahip_set_shard_bounds installs a table made elsewhere;
+ * the orchestrator (host/sharded.c) uses the table of its world size when there is one, equal read counts otherwise. */
+int mahip_hits_balance(mahip_ctx_t *c, int world, uint32_t *bounds);
+int mahip_set_shard_bounds(mahip_ctx_t *c, const uint32_t *bounds, int world);
+const uint32_t *mahip_shard_bounds(mahip_ctx_t *c, int *world);
 
 /* ---- PAF text ingest on the device (replaces paf.c:34-67 paf_parse/paf_read + sdict.c:27-45 sd_put + hit.c:70-101, the part of
  * ma_hit_read before the sort).  Load the whole (decompressed) text, parse: afterwards the context holds the unsorted hit

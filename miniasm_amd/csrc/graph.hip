@@ -699,7 +699,7 @@ extern "C" int mahip_asg_export_rows(mahip_ctx_t *c, void *d_dst)
 	HIPCHK(hipSetDevice(c->dev));
 	if (!c->graph_ready) { mahip_set_error("mahip_asg_export_rows: no graph"); return -1; }
 	if (c->n_arc) hipLaunchKernelGGL(k_arc_rows_out, dim3(grid_for(c->n_arc, 256)), dim3(256), 0, c->st, arcs_of(c, c->ag), (size_t)c->n_arc, (uint4*)d_dst);
-	if (c->own_stream) HIPCHK(hipStreamSynchronize(c->st)); // a caller-owned stream orders the exchange itself (sharded mode: the collectives are queued on it)
+	if (xchg_needs_sync(c)) HIPCHK(hipStreamSynchronize(c->st)); // the exchange runs on somebody else's stream (mahip_internal.hpp)
 	return 0;
 }
 
@@ -731,7 +731,7 @@ extern "C" int mahip_asg_import_rows(mahip_ctx_t *c, const void *d_src, const ui
 		c->tie.arc_tie_groups = c->h_ctr[ST_ARC_TIE_GROUPS]; c->tie.arc_tie_arcs = c->h_ctr[ST_ARC_TIE_ARCS];
 		c->tie.unrepaired = c->tie.arc_tie_groups > 0;
 	}
-	if (c->own_stream) HIPCHK(hipStreamSynchronize(c->st)); // a caller-owned stream orders the exchange itself (sharded mode: the collectives are queued on it)
+	if (xchg_needs_sync(c)) HIPCHK(hipStreamSynchronize(c->st)); // the exchange runs on somebody else's stream (mahip_internal.hpp)
 	c->graph_ready = true;
 	return 0;
 }
@@ -818,7 +818,7 @@ extern "C" int mahip_asg_flags_out(mahip_ctx_t *c, void *d_dst, size_t first, si
 	HIPCHK(hipSetDevice(c->dev));
 	if (first + count > c->n_arc) { mahip_set_error("mahip_asg_flags_out: bad range"); return -1; }
 	if (count) HIPCHK(hipMemcpyAsync(d_dst, P<uint32_t>(c->aol[c->ag]) + first, count * 4, hipMemcpyDeviceToDevice, c->st));
-	if (c->own_stream) HIPCHK(hipStreamSynchronize(c->st)); // a caller-owned stream orders the exchange itself (sharded mode: the collectives are queued on it)
+	if (xchg_needs_sync(c)) HIPCHK(hipStreamSynchronize(c->st)); // the exchange runs on somebody else's stream (mahip_internal.hpp)
 	return 0;
 }
 
@@ -827,7 +827,7 @@ extern "C" int mahip_asg_flags_in(mahip_ctx_t *c, const void *d_src, size_t firs
 	HIPCHK(hipSetDevice(c->dev));
 	if (first + count > c->n_arc) { mahip_set_error("mahip_asg_flags_in: bad range"); return -1; }
 	if (count) HIPCHK(hipMemcpyAsync(P<uint32_t>(c->aol[c->ag]) + first, d_src, count * 4, hipMemcpyDeviceToDevice, c->st));
-	if (c->own_stream) HIPCHK(hipStreamSynchronize(c->st)); // a caller-owned stream orders the exchange itself (sharded mode: the collectives are queued on it)
+	if (xchg_needs_sync(c)) HIPCHK(hipStreamSynchronize(c->st)); // the exchange runs on somebody else's stream (mahip_internal.hpp)
 	return 0;
 }
 

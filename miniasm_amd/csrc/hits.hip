@@ -307,7 +307,7 @@ __device__ __forceinline__ void sub_preload(const HitCols &c, const uint32_t *__
 // fetches the read's records itself -- through the permutation in the low bits of the sorted keys -- and writes the SoA columns on the way.
 // The gather is a chain of dependent random fetches (memory latency), the sweep is a register sort (VALU): in one kernel the two overlap
 // across the waves of a SIMD instead of adding up as two launches.
-struct SubGather { const uint64_t *skey; const ma_hit_t *aos; uint32_t *sidx; int bi; uint32_t n, chunk; }; // n = slots; chunk = reads per bounds fetch of the larger tiers
+struct SubGather { const uint64_t *skey; const ma_hit_t *aos; uint32_t *sidx; int bi; uint32_t n, chunk, q_lo; }; // n = slots; chunk = reads per bounds fetch of the larger tiers; q_lo = first read to visit (a shard: its own range only; the kernel's n_seq argument is then the range's end)
 struct GBounds { uint32_t beg, end; };                     // a read's slots
 struct GKeys { uint32_t beg, end, j[2]; };                 // + low words of the sorted keys of its (up to 128) slots, two slots per lane
 struct GRecs { uint32_t beg, end, j[2]; uint4 a[2], b[2]; }; // + input positions and records: a = {qs, qid, qe, tn}, b = {ts, te, ml|rev, bl|del}
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) SUB_WPE_ATTR(FUSE, CLS, GATHER) void k_hit_sub
 	if (CLS == 0 && GATHER) { // three-deep software pipeline over the chain bounds -> keys -> records: every load is issued a whole sweep before its
 		// first use, and nothing in between waits for it
 		const uint64_t stride = (uint64_t)gridDim.x * 4;
-		uint64_t q = sub_block_id() * 4 + wave;
+		uint64_t q = (uint64_t)g.q_lo + sub_block_id() * 4 + wave;
 		GBounds bn;
 		GKeys kn;
 		GRecs cur, nxt;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) SUB_WPE_ATTR(FUSE, CLS, GATHER) void k_hit_sub
 	} else
 	if (CLS == 0) { // software pipeline: the hits of the wave's next read are in flight while the current read is processed
 		const uint32_t stride = gridDim.x * 4;
-		uint32_t q = sub_block_id() * 4 + wave;
+		uint32_t q = g.q_lo + sub_block_id() * 4 + wave;
 		SubPre cur, nxt;
 		if (q < n_seq) sub_preload<FUSE>(c, goff, q, lane, cur);
 		while (q < n_seq) {
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) SUB_WPE_ATTR(FUSE, CLS, GATHER) void k_hit_sub
 	} else
 	// a wave takes SUB_CHUNK consecutive reads at a time: their bounds come with one coalesced load, and only the reads of this instantiation's
 	// size class are visited (a dependent load per read, most of them somebody else's, is pure latency)
-	for (uint64_t qb = (uint64_t)(sub_block_id() * 4 + wave) * chunk; qb < n_seq; qb += (uint64_t)gridDim.x * 4 * chunk) {
+	for (uint64_t qb = (uint64_t)g.q_lo + (uint64_t)(sub_block_id() * 4 + wave) * chunk; qb < n_seq; qb += (uint64_t)gridDim.x * 4 * chunk) {
 	const bool in = lane < chunk && qb + lane < n_seq;
 	const uint32_t beg_l = in ? goff[qb + lane] : 0, end_l = in ? goff[qb + lane + 1] : 0, H_l = end_l - beg_l;
 	unsigned long long todo = wv_ballot(CLS == 1 ? (H_l > 128 && H_l <= 256) : H_l > 256);
@@ -921,6 +921,57 @@ extern "C" int mahip_hits_raw_extract(mahip_ctx_t *c, uint32_t q_beg, uint32_t q
 	return 0;
 }
 
+// ---- read ranges that hold equally many HITS (the sharded mode's unit of work), instead of equally many reads ----
+__global__ __launch_bounds__(256) void k_qid_count(const ma_hit_t *__restrict__ h, size_t n, uint32_t n_seq, uint32_t *__restrict__ cnt)
+{
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+		const uint32_t q = (uint32_t)(h[i].qns >> 32);
+		if (q < n_seq) atomicAdd(&cnt[q], 1u);
+	}
+}
+// bounds[0..world]: rank r owns the reads [bounds[r], bounds[r+1]); computed from the unsorted records in the context (every rank that holds the whole
+// input computes the same table).  The table is kept in the context (mahip_shard_bounds) for the orchestrator.
+extern "C" int mahip_hits_balance(mahip_ctx_t *c, int world, uint32_t *bounds)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	const uint32_t R = c->n_seq;
+	const size_t n = c->n_hits;
+	if (world < 1 || world > 1024) { mahip_set_error("mahip_hits_balance: bad world size"); return -1; }
+	std::vector<uint32_t> b((size_t)world + 1, R);
+	b[0] = 0;
+	if (R && n && c->d_aos && world > 1) {
+		CHK(dev_reserve(c, c->keep, ((size_t)R + 16) * 4));
+		HIPCHK(hipMemsetAsync(c->keep.p, 0, (size_t)R * 4, c->st));
+		hipLaunchKernelGGL(k_qid_count, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, R, P<uint32_t>(c->keep));
+		std::vector<uint32_t> cnt(R);
+		HIPCHK(hipMemcpyAsync(cnt.data(), c->keep.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));
+		unsigned long long run = 0;
+		int r = 1;
+		for (uint32_t q = 0; q < R && r < world; ++q) { // rank r starts at the first read behind which r/world of the hits lie
+			run += cnt[q];
+			while (r < world && run * (unsigned long long)world >= (unsigned long long)n * (unsigned long long)r) b[r++] = q + 1;
+		}
+	} else if (world > 1) { // nothing to weigh: equal read counts
+		const uint32_t per = (uint32_t)(((uint64_t)R + world - 1) / world);
+		for (int r = 1; r < world; ++r) b[r] = (uint64_t)r * per < R ? (uint32_t)((uint64_t)r * per) : R;
+	}
+	c->shard_bounds = b;
+	if (bounds) memcpy(bounds, b.data(), b.size() * 4);
+	return 0;
+}
+extern "C" int mahip_set_shard_bounds(mahip_ctx_t *c, const uint32_t *bounds, int world)
+{
+	if (!bounds || world < 1) { c->shard_bounds.clear(); return 0; }
+	c->shard_bounds.assign(bounds, bounds + world + 1);
+	return 0;
+}
+extern "C" const uint32_t *mahip_shard_bounds(mahip_ctx_t *c, int *world)
+{
+	if (world) *world = c->shard_bounds.empty() ? 0 : (int)c->shard_bounds.size() - 1;
+	return c->shard_bounds.empty() ? nullptr : c->shard_bounds.data();
+}
+
 extern "C" int mahip_set_shard(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end)
 {
 	c->q_beg = q_beg; c->q_end = q_end;
@@ -953,6 +1004,8 @@ extern "C" int mahip_tie_stats(mahip_ctx_t *c, mahip_tie_info_t *out)
 }
 
 static inline bool ctx_sharded(const mahip_ctx *c) { return c->q_beg > 0 || (c->n_seq && c->q_end < c->n_seq); }
+static inline uint32_t shard_lo(const mahip_ctx *c) { return c->q_beg < c->n_seq ? c->q_beg : c->n_seq; }
+static inline uint32_t shard_hi(const mahip_ctx *c) { return c->q_end < c->n_seq ? c->q_end : c->n_seq; }
 
 // ---- the order ma_hit_sort leaves the hits in (hit.c:19-22): by the ORIGINAL qns of each slot's record, ties as the reference has them ----
 // A slot's original key is the qns of its input record (cuts rewrite the qs column, never the input records).
@@ -1180,33 +1233,34 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 	if (!c->soa_ready) { mahip_set_error("mahip_hits_sub: hits not indexed"); return -1; }
 	HitCols h = cols_of(c);
 	uint32_t R = c->n_seq;
+	const uint32_t q_lo = shard_lo(c), q_hi = shard_hi(c), Rr = q_hi > q_lo ? q_hi - q_lo : 1; // a shard sweeps its own reads only (everybody else's have no hits here)
 	CHK(ctr_zero(c));
 	CHK(dev_reserve(c, c->ovf, ((size_t)R + 1) * 4));
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	uint2 *sub = P<uint2>(c->sub[slot]);
 	SubFuse nofuse = {nullptr, 0, 0, 0, nullptr};
-	SubGather nog = {nullptr, nullptr, nullptr, 0, 0, sub_chunk(R)};
+	SubGather nog = {nullptr, nullptr, nullptr, 0, 0, sub_chunk(Rr), q_lo};
 	const bool fuse_gather = c->gather_pending && R && c->n_hits && !getenv("MA_NO_GATHER_FUSE");
 	if (c->gather_pending && !fuse_gather) CHK(hits_need_cols(c, "mahip_hits_sub"));
 	if (fuse_gather) { // the sweep fetches the records itself and writes the columns on the way
-		SubGather g = {(const uint64_t*)P<uint64_t>(c->key[c->gk_gen]), c->d_aos, P<uint32_t>(c->sidx), c->gk_bi, (uint32_t)c->n_hits, sub_chunk(R)};
+		SubGather g = {(const uint64_t*)P<uint64_t>(c->key[c->gk_gen]), c->d_aos, P<uint32_t>(c->sidx), c->gk_bi, (uint32_t)c->n_hits, sub_chunk(Rr), q_lo};
 		ProfScope ps(c, "k_hit_sub<gather>", (64.0 + 48.0) * (double)c->n_hits); // hit sort 64 (32 r + 32 w, counted once whatever the digit passes) + ma_hit_sub 48 B per stored hit
 		SubFork fk(c);
-		hipLaunchKernelGGL((k_hit_sub<false, 0, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(0), h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 0, true>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(0), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-		hipLaunchKernelGGL((k_hit_sub<false, 1, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(1), h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 1, true>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(1), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-		hipLaunchKernelGGL((k_hit_sub<false, 2, true>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(2), h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 2, true>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(2), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
 		fk.join();
 		c->gather_pending = false;
 	} else if (R) {
 		ProfScope ps(c, "k_hit_sub", 48.0 * (double)c->n_hits + 8.0 * R); // 32 r + 8 w events + 8 r events per stored hit
-		hipLaunchKernelGGL((k_hit_sub<false, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 0>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, nog);
-		hipLaunchKernelGGL((k_hit_sub<false, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 1>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, nog);
-		hipLaunchKernelGGL((k_hit_sub<false, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
+		hipLaunchKernelGGL((k_hit_sub<false, 2>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, c->st, h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, nog);
 	}
 	if (R) { // tier B always runs behind the register tiers on a small grid: it finds its work list (usually empty) in the device counter
@@ -1230,6 +1284,7 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
 	CHK(hits_need_cols(c, "mahip_hits_cutflt_sub"));
 	HitCols h = cols_of(c);
 	uint32_t R = c->n_seq;
+	const uint32_t q_lo = shard_lo(c), q_hi = shard_hi(c), Rr = q_hi > q_lo ? q_hi - q_lo : 1;
 	CHK(ctr_zero(c));
 	CHK(dev_reserve(c, c->ovf, ((size_t)R + 1) * 4));
 	HIPCHK(hipMemsetAsync(c->r_live.p, 0, R, c->st));
@@ -1239,12 +1294,12 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
 	if (R) {
 		ProfScope ps(c, "k_hit_sub<cut+flt>", (80.0 + 80.0 + 48.0) * (double)c->n_hits + 8.0 * R); // cut 80 + flt 80 + sub 48 B per hit
 		SubFork fk(c);
-		hipLaunchKernelGGL((k_hit_sub<true, 0>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(0), h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(R)});
-		hipLaunchKernelGGL((k_hit_sub<true, 1>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(1), h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(R)});
-		hipLaunchKernelGGL((k_hit_sub<true, 2>), dim3(grid_for(R, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(2), h, (const uint32_t*)P<uint32_t>(c->goff), R, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(R)});
+		hipLaunchKernelGGL((k_hit_sub<true, 0>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(0), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(Rr), q_lo});
+		hipLaunchKernelGGL((k_hit_sub<true, 1>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(1), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(Rr), q_lo});
+		hipLaunchKernelGGL((k_hit_sub<true, 2>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(2), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(Rr), q_lo});
 		fk.join();
 	}
 	if (R) {
@@ -1440,7 +1495,7 @@ extern "C" int mahip_copy_out(mahip_ctx_t *c, int which, void *d_dst, size_t fir
 	DevBuf *b = xbuf(c, which, &es);
 	if (!b || (first + count) * es > b->cap) { mahip_set_error("mahip_copy_out: bad buffer/range"); return -1; }
 	if (count) HIPCHK(hipMemcpyAsync(d_dst, (char*)b->p + first * es, count * es, hipMemcpyDeviceToDevice, c->st));
-	if (c->own_stream) HIPCHK(hipStreamSynchronize(c->st)); // a caller-owned stream orders the exchange itself (sharded mode: the collectives are queued on it)
+	if (xchg_needs_sync(c)) HIPCHK(hipStreamSynchronize(c->st)); // the exchange runs on somebody else's stream (mahip_internal.hpp)
 	return 0;
 }
 
@@ -1451,7 +1506,7 @@ extern "C" int mahip_copy_in(mahip_ctx_t *c, int which, const void *d_src, size_
 	DevBuf *b = xbuf(c, which, &es);
 	if (!b || (first + count) * es > b->cap) { mahip_set_error("mahip_copy_in: bad buffer/range"); return -1; }
 	if (count) HIPCHK(hipMemcpyAsync((char*)b->p + first * es, d_src, count * es, hipMemcpyDeviceToDevice, c->st));
-	if (c->own_stream) HIPCHK(hipStreamSynchronize(c->st)); // a caller-owned stream orders the exchange itself (sharded mode: the collectives are queued on it)
+	if (xchg_needs_sync(c)) HIPCHK(hipStreamSynchronize(c->st)); // the exchange runs on somebody else's stream (mahip_internal.hpp)
 	return 0;
 }
 

@@ -38,6 +38,7 @@ struct mahip_ctx {
 	size_t n_live = 0;
 	uint32_t n_seq = 0;       // reads, original numbering
 	uint32_t q_beg = 0, q_end = 0xffffffffu; // shard
+	std::vector<uint32_t> shard_bounds;      // read ranges of all ranks (mahip_hits_balance / mahip_set_shard_bounds); empty: equal read counts
 	uint32_t hint_max_qs = 0; // upper bound of the query starts (max read length), 0 = unknown
 	uint32_t paf_max_qs = 0;  // the same as found by the last mahip_paf_parse (hints are reset by every upload/adopt)
 	const ma_hit_t *d_aos = nullptr; // input records (adopted or aos_own)
@@ -123,6 +124,11 @@ struct ProfScope {
 };
 
 template <typename T> static inline T *P(DevBuf &b) { return (T*)b.p; }
+
+// The building blocks of the sharded mode hand buffers to an exchange.  When the collectives are this context's own (mahip_comm_*: queued on c->st, the C
+// orchestration of host/sharded.c) stream order is all that is needed.  When somebody else runs them on another stream (the torch-driven specification,
+// miniasm_amd/sharded.py) and the context has a private stream, the producer has to finish first.  A caller-owned stream orders the exchange itself.
+static inline bool xchg_needs_sync(const mahip_ctx *c) { return c->own_stream && !c->comm; }
 
 // counters (indices into ctx->ctr)
 enum { CT_LIVE = 0, CT_REMAIN, CT_TOTDP, CT_TOTLEN, CT_OVF, CT_NRED, CT_NMULTI, CT_NASYMM, CT_NSHORT, CT_MAXQID, CT_MAXQS, CT_TOTAL, CT_OVF2, CT_MAXLEN, CT_CUT, CT_N };

@@ -25,13 +25,26 @@
 
 #define GPU(call) do { if ((call) != 0) ma_gpu_fail(__func__); } while (0)
 
-static void shard_range(uint32_t n_seq, int world, int rank, uint32_t *per, uint32_t *q0, uint32_t *q1)
+/* rank's read range [*q0, *q1) and the length of the longest range (the slot size of the all-gathers): the context's table of hit-balanced
+ * ranges when it has one for this world size (mahip_hits_balance), else equal read counts */
+static void shard_range(mahip_ctx_t *c, uint32_t n_seq, int world, int rank, uint32_t *per, uint32_t *q0, uint32_t *q1, const uint32_t **bounds)
 {
-	uint32_t c = world > 0 ? (uint32_t)(((uint64_t)n_seq + world - 1) / world) : n_seq;
-	uint64_t b = (uint64_t)rank * c, e = b + c;
-	*per = c;
-	*q0 = (uint32_t)(b < n_seq ? b : n_seq);
-	*q1 = (uint32_t)(e < n_seq ? e : n_seq);
+	int bw = 0, r;
+	const uint32_t *b = mahip_shard_bounds(c, &bw);
+	*bounds = 0;
+	if (b && bw == world && b[world] == n_seq) {
+		uint32_t longest = 1;
+		for (r = 0; r < world; ++r) if (b[r + 1] - b[r] > longest) longest = b[r + 1] - b[r];
+		*per = longest; *q0 = b[rank]; *q1 = b[rank + 1]; *bounds = b;
+		return;
+	}
+	{
+		uint32_t cc = world > 0 ? (uint32_t)(((uint64_t)n_seq + world - 1) / world) : n_seq;
+		uint64_t lo = (uint64_t)rank * cc, hi = lo + cc;
+		*per = cc;
+		*q0 = (uint32_t)(lo < n_seq ? lo : n_seq);
+		*q1 = (uint32_t)(hi < n_seq ? hi : n_seq);
+	}
 }
 
 /* Per-phase device time of one sharded head (bench.py --gpus N reports the maximum over the ranks): a HIP event on the stream between the
@@ -45,15 +58,17 @@ const char *const ma_shard_phase_name[MA_SHARD_N_PHASES] = {
 #define MARK(k) do { if (g_phases) GPU(mahip_mark(c, (k))); } while (0)
 
 /* all-gather of the owned slices of one of the read-indexed arrays (element size es): afterwards every rank holds all n_seq entries */
-static size_t exchange_slices(mahip_ctx_t *c, int which, size_t es, uint32_t n_seq, uint32_t per, uint32_t q0, uint32_t q1, int world)
+static size_t exchange_slices(mahip_ctx_t *c, int which, size_t es, uint32_t n_seq, uint32_t per, uint32_t q0, uint32_t q1, int world, const uint32_t *bounds)
 {
-	void *loc, *all;
+	char *loc, *all;
+	int r;
 	if (!mahip_comm_active(c)) return 0;
-	GPU(mahip_xbuf(c, 0, (size_t)per * es, &loc));
-	GPU(mahip_xbuf(c, 1, (size_t)per * es * world, &all));
+	GPU(mahip_xbuf(c, 0, (size_t)per * es, (void**)&loc));
+	GPU(mahip_xbuf(c, 1, (size_t)per * es * world, (void**)&all));
 	GPU(mahip_copy_out(c, which, loc, q0, q1 - q0));
 	GPU(mahip_comm_all_gather(c, loc, all, (size_t)per * es));
-	GPU(mahip_copy_in(c, which, all, 0, n_seq));
+	if (bounds == 0) GPU(mahip_copy_in(c, which, all, 0, n_seq)); /* equal ranges: the gathered slots ARE the array */
+	else for (r = 0; r < world; ++r) GPU(mahip_copy_in(c, which, all + (size_t)r * per * es, bounds[r], bounds[r + 1] - bounds[r]));
 	return (size_t)per * es * world;
 }
 
@@ -83,8 +98,9 @@ int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq
 	uint64_t cnt[64];
 	uint32_t *counts = (uint32_t*)calloc((size_t)world + 1, 4);
 	size_t stride = 1, first = 0, tot = 0;
+	const uint32_t *bounds = 0;
 	memset(st, 0, sizeof(*st));
-	shard_range(n_seq, world, rank, &per, &q0, &q1);
+	shard_range(c, n_seq, world, rank, &per, &q0, &q1, &bounds);
 	GPU(mahip_set_full_input(c, full_input || world == 1));
 	GPU(mahip_set_shard(c, world > 1 ? q0 : 0, world > 1 ? q1 : 0xffffffffu));
 	MARK(0);
@@ -92,12 +108,12 @@ int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq
 	MARK(1);
 	GPU(mahip_hits_sub(c, opt->min_dp, opt->min_iden, 0, 0, &n_rem1));
 	MARK(2);
-	st->xchg_bytes[2] = exchange_slices(c, MAHIP_BUF_SUB0, 8, n_seq, per, q0, q1, world);
+	st->xchg_bytes[2] = exchange_slices(c, MAHIP_BUF_SUB0, 8, n_seq, per, q0, q1, world, bounds);
 	MARK(3);
 	GPU(mahip_hits_cutflt_sub(c, 0, opt->min_span, (int)(opt->max_hang * 1.5), (int)(opt->min_ovlp * .5), opt->min_dp, opt->min_iden, opt->min_span / 2,
 	                          1, &n_cut, &n_flt, &cov, &n_rem2)); /* hit.c:162-216 + the second ma_hit_sub: needs the complete first-pass intervals */
 	MARK(4);
-	st->xchg_bytes[4] = exchange_slices(c, MAHIP_BUF_SUB1, 8, n_seq, per, q0, q1, world);
+	st->xchg_bytes[4] = exchange_slices(c, MAHIP_BUF_SUB1, 8, n_seq, per, q0, q1, world, bounds);
 	MARK(5);
 	GPU(mahip_sub_merge(c)); /* on the complete arrays: identical on every rank */
 	GPU(mahip_hits_cut_contained_flags(c, 1, opt->min_span, opt));
@@ -320,6 +336,7 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 		const char *e = getenv("MA_TEST_FAIL_RANK");
 		if (e && atoi(e) == rank) { fprintf(stderr, "[E::%s] rank %d: MA_TEST_FAIL_RANK\n", __func__, rank); _exit(3); }
 	}
+	GPU(mahip_hits_balance(c, world, 0)); /* every rank holds the whole input here: the same hit-balanced read ranges everywhere */
 	ma_pipeline_head_sharded(c, opt, d->n_seq, 1, &st);
 	ma_shard_stats_reduce(c, &st); /* the log lines below want the sums */
 	if (rank == 0) {

@@ -25,6 +25,16 @@ def main():
     n_seq = ing.n_seq
     per = (n_seq + world - 1) // world
     q0, q1 = min(rank * per, n_seq), min((rank + 1) * per, n_seq)
+    bounds = None
+    if os.environ.get("MA_WORKER_BALANCE") == "1":  # read ranges with equally many hits (mahip_hits_balance, as bench.py and the command line use them)
+        L.mahip_hits_balance.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]
+        tmp = ma.Ctx(0)
+        tmp.hits_upload(ing.hits, n_seq)
+        bounds = (C.c_uint32 * (world + 1))()
+        ma._chk(L.mahip_hits_balance(tmp.h, world, bounds), "balance")
+        tmp.close()
+        q0, q1 = bounds[rank], bounds[rank + 1]
+        assert bounds[0] == 0 and bounds[world] == n_seq and all(bounds[r] <= bounds[r + 1] for r in range(world))
     qid = (ing.hits["qns"] >> np.uint64(32)).astype(np.int64)
     mine = np.ascontiguousarray(ing.hits[(qid >= q0) & (qid < q1)])  # this rank's records, input order kept
 
@@ -39,6 +49,9 @@ def main():
     ctx = ma.Ctx(0)
     ctx2 = ma.Ctx(0) if (tail_ctx and rank == 0) else None
     ma._chk(L.mahip_comm_init_shm(ctx.h, name.encode(), rank, world), "comm_init_shm")
+    if bounds is not None:
+        L.mahip_set_shard_bounds.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int]
+        ma._chk(L.mahip_set_shard_bounds(ctx.h, bounds, world), "set_shard_bounds")
     outs = []
     for step in range(3):
         ctx.hits_upload(mine, n_seq)

@@ -167,7 +167,7 @@ def test_cli_on_n_ranks_reproduces_the_reference_tie_order(world, tmpdir_s):
 
 @pytest.mark.parametrize("tail_ctx", [0, 1])
 @pytest.mark.parametrize("world", [2, 3])
-def test_ranks_that_hold_only_their_own_records(world, tail_ctx, tmpdir_s):
+def test_ranks_that_hold_only_their_own_records(world, tail_ctx, tmpdir_s, monkeypatch):
     """the shape of `bench.py --gpus N` without torch: every rank is a process that holds ONLY the records of its read range, three steps over
     the shared-memory double, rank 0 finishes each batch on its own context or (tail_ctx) on a second one (mahip_tail_handoff); every step's GFA
     equals the single-context run and the reference's"""
@@ -175,7 +175,8 @@ def test_ranks_that_hold_only_their_own_records(world, tail_ctx, tmpdir_s):
     import sys
     paf = R.pafgen(os.path.join(tmpdir_s, "own_%d.paf" % world), 2500, 70000, 55, ["-L", "uniform", "-d", "0.3"])
     out = os.path.join(tmpdir_s, "own_%d_%d.out" % (world, tail_ctx))
-    env = dict(os.environ, MA_WORKER_EMU="1" if getattr(ma, "IS_EMU", False) else "0")
+    # tail_ctx runs also use read ranges balanced by hit count (unequal ranges: the all-gathers' slots are as long as the longest one)
+    env = dict(os.environ, MA_WORKER_EMU="1" if getattr(ma, "IS_EMU", False) else "0", MA_WORKER_BALANCE="1" if tail_ctx else "0")
     env.pop("MA_GPUS", None)
     name = "ma_own_%d_%d_%d" % (os.getpid(), world, tail_ctx)
     procs = [subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "shard_step_worker.py"), paf, str(r), str(world), name, str(tail_ctx), out],
