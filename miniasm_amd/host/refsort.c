@@ -150,7 +150,7 @@ void ma_refsort_ki(ma_ki_t *a, size_t n, int n_threads)
 }
 
 /* perm[i] = input position of the record the reference's sort leaves at position i */
-typedef struct { const uint64_t *keys; ma_ki_t *a; uint64_t *pk; uint32_t *perm; size_t beg, end; int phase; rs_cfg_t cfg; uint64_t mhi, mlo; } fill_t;
+typedef struct { const uint64_t *keys; ma_ki_t *a; uint64_t *pk; uint32_t *perm; size_t beg, end; int phase; rs_cfg_t cfg; uint64_t mhi, mlo, diff, himask; uint8_t *dig; int shift_top; size_t cnt[256]; } fill_t;
 
 static void *fill_worker(void *arg)
 {
@@ -163,6 +163,16 @@ static void *fill_worker(void *arg)
 	} else if (f->phase == 1) for (i = f->beg; i < f->end; ++i) f->a[i].key = f->keys[i], f->a[i].idx = (uint32_t)i, f->a[i].pad = 0;
 	else if (f->phase == 2) for (i = f->beg; i < f->end; ++i) f->perm[i] = f->a[i].idx;
 	else if (f->phase == 3) for (i = f->beg; i < f->end; ++i) { const uint64_t k = f->keys[i]; f->pk[i] = ((k >> 32) << f->cfg.bl | (k & 0xffffffffull)) << f->cfg.bi | i; }
+	else if (f->phase == 5) { uint64_t d = 0; const uint64_t k0 = f->keys[0]; for (i = f->beg; i < f->end; ++i) d |= f->keys[i] ^ k0; f->diff = d; } /* which bits vary */
+	else if (f->phase == 6) { /* pack WITHOUT the bits the top level consumes (the bucket implies them); the top level's digits and their counts on the way */
+		memset(f->cnt, 0, sizeof(f->cnt));
+		for (i = f->beg; i < f->end; ++i) {
+			const uint64_t k = f->keys[i];
+			const unsigned d = (unsigned)(k >> f->shift_top) & 0xffu;
+			f->dig[i] = (uint8_t)d; ++f->cnt[d];
+			f->pk[i] = (((k >> 32) & f->himask) << f->cfg.bl | (k & 0xffffffffull)) << f->cfg.bi | i;
+		}
+	}
 	else { const uint64_t im = f->cfg.bi >= 64 ? ~0ull : (1ull << f->cfg.bi) - 1; for (i = f->beg; i < f->end; ++i) f->perm[i] = (uint32_t)(f->pk[i] & im); }
 	return 0;
 }
@@ -182,6 +192,8 @@ static void fill_run(fill_t *proto, size_t n, int phase, int n_threads)
 	fill_worker(&f[0]);
 	for (t = 1; t < n_threads; ++t) pthread_join(th[t], 0);
 	if (phase == 0) { proto->mhi = proto->mlo = 0; for (t = 0; t < n_threads; ++t) { if (f[t].mhi > proto->mhi) proto->mhi = f[t].mhi; if (f[t].mlo > proto->mlo) proto->mlo = f[t].mlo; } }
+	if (phase == 5) { proto->diff = 0; for (t = 0; t < n_threads; ++t) proto->diff |= f[t].diff; }
+	if (phase == 6) { int k; memset(proto->cnt, 0, sizeof(proto->cnt)); for (t = 0; t < n_threads; ++t) for (k = 0; k < 256; ++k) proto->cnt[k] += f[t].cnt[k]; }
 }
 
 static int bits_of64(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
@@ -221,6 +233,30 @@ int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm)
 		RS_LAP("unpack");
 		free(f.pk);
 		return 0;
+	}
+	/* Too wide for one word -- BASELINE configs[4]: 23 id + 14 start + 30 index bits.  Below the top level every element of a bucket has the same top digit,
+	 * so those bits need not travel: if the rest fits, the top level's digits are taken from the raw keys and the elements are packed without them. */
+	if (nt > 1 && n >= (1u << 17) && !getenv("MA_REFSORT_WIDE")) {
+		int shift = 56;
+		fill_run(&f, n, 5, nt);
+		while (shift > 0 && (f.diff >> shift & 0xff) == 0) shift -= 8;
+		if (f.diff != 0 && shift >= 32 && (shift - 32) + bl + bi <= 64) {
+			f.shift_top = shift; f.himask = shift > 32 ? (1ull << (shift - 32)) - 1 : 0;
+			f.cfg.bi = bi; f.cfg.bl = bl; f.cfg.lomask = (1ull << bl) - 1;
+			f.pk = (uint64_t*)malloc(n * sizeof(uint64_t));
+			f.dig = (uint8_t*)malloc(n + 16);
+			if (f.pk == 0 || f.dig == 0) { free(f.pk); free(f.dig); return -1; }
+			memset(f.dig + n, 0, 16);
+			fill_run(&f, n, 6, nt);
+			RS_LAP("pack (top digit apart)");
+			packed_sort_from_top(f.pk, n, &f.cfg, nt, f.cnt, f.dig, shift);
+			RS_LAP("sort");
+			free(f.dig);
+			fill_run(&f, n, 4, nt);
+			RS_LAP("unpack");
+			free(f.pk);
+			return 0;
+		}
 	}
 	f.a = (ma_ki_t*)malloc(n * sizeof(ma_ki_t));
 	if (f.a == 0) return -1;

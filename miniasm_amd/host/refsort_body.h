@@ -152,6 +152,40 @@ static void *RS_NAME(sweep_worker)(void *arg)
 static void RS_NAME(task)(rs_pool_t *pool, void *a, size_t n, int shift) { RS_NAME(level)(pool, (RS_T*)a, n, shift); }
 
 /* the whole sort of a[0..n) */
+/* the top level given its digits (dig[], one byte per element, and their counts), then the buckets below on the worker threads */
+static void RS_NAME(sort_from_top)(RS_T *a, size_t n, const rs_cfg_t *cfg, int n_threads, const size_t *cnt, const uint8_t *dig, int shift)
+{
+	rs_pool_t p;
+	pthread_t *th;
+	int t;
+	(void)n;
+	memset(&p, 0, sizeof(p));
+	p.cfg = *cfg; p.run = RS_NAME(task); p.elem = sizeof(RS_T);
+	pthread_mutex_init(&p.mu, 0);
+	pthread_cond_init(&p.cv, 0);
+	if (n_threads > 64) n_threads = 64;
+	p.n_threads = n_threads;
+	{
+		RS_T0;
+		th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
+		++p.busy; /* the top-level walk below produces tasks: workers must not leave while it runs */
+		for (t = 0; t < n_threads; ++t) pthread_create(&th[t], 0, pool_worker, &p);
+		if (dig) RS_NAME(permute_top)(&p, a, cnt, dig, shift);
+		else { size_t tail[256]; memcpy(tail, cnt, sizeof(tail)); RS_NAME(permute)(&p, a, tail, shift); }
+		RS_LAP(" top walk");
+		pthread_mutex_lock(&p.mu);
+		--p.busy;
+		pthread_cond_broadcast(&p.cv);
+		pthread_mutex_unlock(&p.mu);
+		for (t = 0; t < n_threads; ++t) pthread_join(th[t], 0);
+		RS_LAP(" buckets");
+		free(th); free(p.q);
+	}
+	pthread_mutex_destroy(&p.mu);
+	pthread_cond_destroy(&p.cv);
+}
+
+/* the whole sort of a[0..n) */
 static void RS_NAME(sort)(RS_T *a, size_t n, const rs_cfg_t *cfg, int n_threads)
 {
 	rs_pool_t p;
@@ -160,14 +194,10 @@ static void RS_NAME(sort)(RS_T *a, size_t n, const rs_cfg_t *cfg, int n_threads)
 	if (n <= RS_SMALL) { RS_NAME(insertion)(a, n, cfg); return; } /* ksort.h:182 */
 	if (n_threads <= 1 || n < (1u << 17)) { RS_NAME(level)(&p, a, n, 56); return; }
 	{
-		pthread_t *th;
 		size_t cnt[256];
-		int t, shift = 56;
+		int shift = 56;
 		uint64_t diff;
-		pthread_mutex_init(&p.mu, 0);
-		pthread_cond_init(&p.cv, 0);
 		if (n_threads > 64) n_threads = 64;
-		p.n_threads = n_threads;
 		/* the top level: its two sweeps (which bits vary; the digit counts) run on all threads, only the walk itself is sequential */
 		RS_T0;
 		diff = sweep_run(RS_NAME(sweep_worker), a, n, -1, 0, cfg, n_threads, 0);
@@ -177,22 +207,8 @@ static void RS_NAME(sort)(RS_T *a, size_t n, const rs_cfg_t *cfg, int n_threads)
 			if (dig) memset(dig + n, 0, 16);
 			sweep_run(RS_NAME(sweep_worker), a, n, shift, cnt, cfg, n_threads, dig);
 			RS_LAP(" sweeps");
-			th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
-			++p.busy; /* the top-level walk below produces tasks: workers must not leave while it runs */
-			for (t = 0; t < n_threads; ++t) pthread_create(&th[t], 0, pool_worker, &p);
-			if (dig) RS_NAME(permute_top)(&p, a, cnt, dig, shift);
-			else RS_NAME(permute)(&p, a, cnt, shift);
+			RS_NAME(sort_from_top)(a, n, cfg, n_threads, cnt, dig, shift);
 			free(dig);
-			RS_LAP(" top walk");
-			pthread_mutex_lock(&p.mu);
-			--p.busy;
-			pthread_cond_broadcast(&p.cv);
-			pthread_mutex_unlock(&p.mu);
-			for (t = 0; t < n_threads; ++t) pthread_join(th[t], 0);
-			RS_LAP(" buckets");
-			free(th); free(p.q);
 		}
-		pthread_mutex_destroy(&p.mu);
-		pthread_cond_destroy(&p.cv);
 	}
 }

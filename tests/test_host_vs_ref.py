@@ -263,6 +263,19 @@ def test_refsort_perm_matches_reference_sort(threads, monkeypatch):
         ref = hits.copy()
         LR.radix_sort_hit(ref.ctypes.data, ref.ctypes.data + n * 32)
         assert hits[perm].tobytes() == ref.tobytes(), "hit order differs for the nearly sorted input n=%d per=%d spread=%d" % (n, per, spread)
+    # keys + index too wide for one 64-bit element (BASELINE configs[4]: 23 + 14 + 30 bits): packed without the top level's digit when the rest fits
+    # (30 id bits: top byte = id >> 24, 24 + 20 + 19 bits travel), the 16-byte elements when it does not (32 + 32 + 19)
+    for n, hi_bits, lo_bits, n_hi in ((300000, 30, 20, 5000), (300000, 30, 20, 40), (400000, 32, 32, 3000)):
+        pool = rng.integers(0, 1 << hi_bits, n_hi, dtype=np.uint64)
+        hits = np.zeros(n, dtype=ma.HIT_DT)
+        hits["qns"] = (pool[rng.integers(0, n_hi, n)] << np.uint64(32)) | (rng.integers(0, 64, n).astype(np.uint64) * np.uint64(((1 << lo_bits) - 1) // 64))
+        hits["tn"] = np.arange(n)
+        perm = np.zeros(n, dtype=np.uint32)
+        keys = np.ascontiguousarray(hits["qns"])
+        assert LP.ma_refsort_perm(keys.ctypes.data, n, perm.ctypes.data) == 0
+        ref = hits.copy()
+        LR.radix_sort_hit(ref.ctypes.data, ref.ctypes.data + n * 32)
+        assert hits[perm].tobytes() == ref.tobytes(), "hit order differs for wide keys (%d id bits, %d start bits)" % (hi_bits, lo_bits)
     LR.asg_arc_sort.argtypes = [C.POINTER(ma.Asg)]
     for n, nu, nl in ((300, 8, 6), (400000, 5000, 12), (600000, 400000, 3)):
         arcs = np.zeros(n, dtype=ma.ARC_DT)
