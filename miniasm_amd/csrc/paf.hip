@@ -274,37 +274,20 @@ __device__ __forceinline__ bool name_eq(const unsigned char *__restrict__ a, con
 	return true;
 }
 
-// One thread per stored line: query name, then target name.  A slot is 32 bytes -- one memory sector:
-//   word 0  tag(32) | occurrence of the name's first inserter   (the CAS target; PAF_EMPTY = free)
-//   word 1  text offset << 24 | length of the slot's name       (PAF_EMPTY until the inserter has written it)
-//   word 2-3 the first 16 bytes of the name, zero-padded
-// tmin[slot] = smallest occurrence (2*line + column) of the name = its first appearance in the file.
-// A prober whose tag matches needs the slot's name to decide: round 2 fetched it from the TEXT, i.e. one random 64-byte fetch into a 6 GB file for
-// every one of the 200 M occurrences of a 100 M-line input (12.6 x the text itself).  With the first 16 bytes in the slot the same
-// sector that answered the probe settles every name of up to 16 bytes, and only the tail of a longer name is read where it lies.  The inserter
-// writes words 2-3, fences, then word 1; a prober that still sees word 1 empty goes the long way through the occurrence (line start, column
-// offset, length).  All of it through L2 (agent-scope atomics): a slot is written once, and nobody may keep a stale line of it in L1.
+// (Round 3 tried 32-byte slots that carry the first 16 bytes of the name, so that the sector that answers a probe also settles the comparison: with
+// agent-scope accesses to keep the eight L2s honest and a table four times the bytes it was SLOWER -- 17.0 against 11.5 ms per 100 M lines
+// (profiles/r03_experiments.txt) -- and was taken out again.)
+// One thread per stored line: query name, then target name.  Slot word = tag(32) | occurrence of the name's first
+// inserter; tmin[slot] = smallest occurrence (2*line + column) of the name = its first appearance in the file.
+// info[slot] = text offset << 24 | length of the slot's name, written by the inserter right after its CAS: a prober that finds it compares
+// the bytes after ONE dependent fetch; one that does not see it yet (the store is not ordered with the CAS, a stale L1 line) goes the
+// long way through the occurrence (line start, column offset, length: three more random fetches) -- both ways read the same bytes.
 #define PAF_INFO_LEN_BITS 24
-#define SLOT_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define SLOT_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-__device__ __forceinline__ void name_head16(const unsigned char *__restrict__ nm, uint32_t len, bool wide_ok, unsigned long long *k0, unsigned long long *k1)
-{ // the first 16 bytes of a name, zero-padded; wide_ok: 16 bytes may be read at nm (not at the very end of the text)
-	unsigned long long a = 0, b = 0;
-	if (wide_ok) {
-		__builtin_memcpy(&a, nm, 8); __builtin_memcpy(&b, nm + 8, 8);
-		if (len < 8) { a &= len ? ~0ull >> (64 - 8 * len) : 0ull; b = 0; }
-		else if (len < 16) b &= len > 8 ? ~0ull >> (64 - 8 * (len - 8)) : 0ull;
-	} else {
-		for (uint32_t k = 0; k < len && k < 16; ++k) { const unsigned long long ch = nm[k]; if (k < 8) a |= ch << (8 * k); else b |= ch << (8 * (k - 8)); }
-	}
-	*k0 = a; *k1 = b;
-}
 __global__ __launch_bounds__(256) void k_dict_insert(const unsigned char *__restrict__ text, const uint64_t *__restrict__ lstart, uint32_t L, PafCols o,
-                                                      unsigned long long *__restrict__ tab /* 4 words per slot */, uint32_t *__restrict__ tmin,
+                                                      unsigned long long *__restrict__ tab, uint32_t *__restrict__ tmin, unsigned long long *__restrict__ info,
                                                       uint32_t mask, unsigned long long *__restrict__ ctr)
 {
 	uint32_t fail = 0, fresh = 0;
-	const uint64_t tend = lstart[L];
 	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < L; i += gridDim.x * 256u) {
 		if (!(o.flags[i] & 2)) continue;
 		const uint64_t ls = lstart[i];
@@ -314,30 +297,21 @@ __global__ __launch_bounds__(256) void k_dict_insert(const unsigned char *__rest
 			const uint64_t noff = ls + (col ? o.tnoff[i] : 0u);
 			const unsigned char *nm = text + noff;
 			const uint32_t tag = (uint32_t)(h >> 32);
-			unsigned long long k0, k1;
-			name_head16(nm, len, noff + 16 <= tend, &k0, &k1);
 			uint32_t s = (uint32_t)h & mask, slot = 0xffffffffu;
 			for (uint32_t probe = 0; probe < PAF_PROBE_LIMIT; ++probe, s = (s + 1) & mask) {
-				unsigned long long *w = tab + 4 * (size_t)s;
-				unsigned long long e = SLOT_LD(&w[0]);
+				unsigned long long e = tab[s];
 				if (e == PAF_EMPTY) {
-					e = atomicCAS(&w[0], PAF_EMPTY, (unsigned long long)tag << 32 | occ);
+					e = atomicCAS(&tab[s], PAF_EMPTY, (unsigned long long)tag << 32 | occ);
 					if (e == PAF_EMPTY) {
-						if (len < (1u << PAF_INFO_LEN_BITS) && noff < (1ull << (64 - PAF_INFO_LEN_BITS))) {
-							SLOT_ST(&w[2], k0); SLOT_ST(&w[3], k1);
-							__threadfence();
-							SLOT_ST(&w[1], noff << PAF_INFO_LEN_BITS | len);
-						}
+						if (len < (1u << PAF_INFO_LEN_BITS) && noff < (1ull << (64 - PAF_INFO_LEN_BITS))) info[s] = noff << PAF_INFO_LEN_BITS | len;
 						atomicMin(&tmin[s], occ); slot = s; ++fresh; break;
 					}
 				}
 				if ((uint32_t)(e >> 32) == tag) {
-					const unsigned long long inf = SLOT_LD(&w[1]);
+					const unsigned long long inf = info[s];
 					bool same;
-					if (inf != PAF_EMPTY) {
-						same = (uint32_t)(inf & ((1u << PAF_INFO_LEN_BITS) - 1)) == len && SLOT_LD(&w[2]) == k0 && SLOT_LD(&w[3]) == k1;
-						if (same && len > 16) same = name_eq(nm + 16, text + (inf >> PAF_INFO_LEN_BITS) + 16, len - 16);
-					} else {
+					if (inf != PAF_EMPTY) same = (uint32_t)(inf & ((1u << PAF_INFO_LEN_BITS) - 1)) == len && name_eq(nm, text + (inf >> PAF_INFO_LEN_BITS), len);
+					else {
 						const uint32_t r = (uint32_t)e, rl = r >> 1;
 						const uint32_t rlen = (r & 1) ? o.tlen[rl] : o.qlen[rl];
 						same = rlen == len && name_eq(nm, text + lstart[rl] + ((r & 1) ? o.tnoff[rl] : 0u), len);
@@ -355,8 +329,6 @@ __global__ __launch_bounds__(256) void k_dict_insert(const unsigned char *__rest
 	blk_add_u64(&ctr[PC_OVERFLOW], fail);
 	blk_add_u64(&ctr[PC_DISTINCT], fresh);
 }
-#undef SLOT_LD
-#undef SLOT_ST
 
 // ---- -R (ma_hit_no_cont, hit.c:38-68) on the parsed columns: reads that are clearly contained are excluded BEFORE ids are given out
 // (hit.c:86), so the exclusion is a property of NAMES: a line's verdict flags the name's table slot, lines that touch a flagged name are
@@ -393,7 +365,7 @@ __global__ __launch_bounds__(256) void k_excl_count(const uint8_t *__restrict__ 
 __global__ __launch_bounds__(256) void k_dict_flag(const unsigned long long *__restrict__ tab, const uint32_t *__restrict__ tmin, uint32_t cap, uint32_t *__restrict__ keep)
 {
 	uint32_t s = blockIdx.x * 256u + threadIdx.x;
-	if (s < cap) keep[s] = tab[4 * (size_t)s] != PAF_EMPTY && tmin[s] != 0xffffffffu;
+	if (s < cap) keep[s] = tab[s] != PAF_EMPTY && tmin[s] != 0xffffffffu;
 }
 __global__ __launch_bounds__(256) void k_dict_collect(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ tmin, uint32_t cap,
                                                        uint64_t *__restrict__ key, uint32_t *__restrict__ val)
@@ -598,14 +570,16 @@ extern "C" int mahip_paf_parse_excl(mahip_ctx_t *c, int min_span, int min_match,
 		uint32_t cap = pow2_at_least(n_pass / 16 + 65536);
 		if (const char *e = getenv("MA_DICT_CAP_LOG2")) { int l2 = atoi(e); if (l2 >= 4 && l2 <= 31) cap = 1u << l2; } // tests: force the growth path
 		for (int attempt = 0;; ++attempt) {
-			CHK(dev_reserve(c, b->tab, (size_t)cap * 32)); CHK(dev_reserve(c, b->tmin, (size_t)cap * 4)); CHK(dev_reserve(c, b->slot_id, (size_t)cap * 4));
-			HIPCHK(hipMemsetAsync(b->tab.p, 0xff, (size_t)cap * 32, c->st));
+			CHK(dev_reserve(c, b->tab, (size_t)cap * 8)); CHK(dev_reserve(c, b->tmin, (size_t)cap * 4)); CHK(dev_reserve(c, b->slot_id, (size_t)cap * 4));
+			CHK(dev_reserve(c, b->info, (size_t)cap * 8));
+			HIPCHK(hipMemsetAsync(b->tab.p, 0xff, (size_t)cap * 8, c->st));
+			HIPCHK(hipMemsetAsync(b->info.p, 0xff, (size_t)cap * 8, c->st));
 			HIPCHK(hipMemsetAsync(b->tmin.p, 0xff, (size_t)cap * 4, c->st));
 			CHK(ctr_zero(c));
 			{
 				ProfScope ps(c, "k_dict_insert", 2.0 * 40.0 * (double)n_pass);
 				hipLaunchKernelGGL(k_dict_insert, dim3(grid_for(L, 256, 8192)), dim3(256), 0, c->st, text, (const uint64_t*)P<uint64_t>(b->lstart), L, o,
-				                   P<unsigned long long>(b->tab), P<uint32_t>(b->tmin), cap - 1, ctr);
+				                   P<unsigned long long>(b->tab), P<uint32_t>(b->tmin), P<unsigned long long>(b->info), cap - 1, ctr);
 			}
 			CHK(ctr_fetch(c));
 			const uint64_t distinct = c->h_ctr[PC_DISTINCT];

@@ -33,8 +33,7 @@ def _adversarial(path, seed=5):
     each other, self hits, no newline at the end"""
     rnd = random.Random(seed)
     names = ["r%d" % i for i in range(300)] + ["r1", "r10", "r100", "r1000", "x", "xx", "x" * 300, "read with space", "r\x001"]
-    # the dictionary keeps the first 16 bytes of a name in its table slot (csrc/paf.hip: k_dict_insert): names around that length, names that
-    # share their first 16 bytes and differ behind them, a name that IS another one's first 16 bytes
+    # names around 8 / 16 bytes (the comparison works on 8-byte words), names that share a long prefix and differ behind it, a name that IS another one's prefix
     names += ["m54119_180101_0001", "m54119_180101_0002", "m54119_180101_00", "m54119_180101_000", "abcdefghijklmnop", "abcdefghijklmnopq", "abcdefghijklmnopX",
               "abcdefghijklmno", "abcdefgh", "abcdefghi", "abcdefg", "abcdefghijklmnop" * 4, "abcdefghijklmnop" * 4 + "z"]
     lines = []
