@@ -2,12 +2,13 @@
 // Used for: radix-sort digit offsets, order-preserving compaction of hits and arcs, the squeeze map
 // (reference sdict.c:69-86), CSR offsets.
 //
-// ONE launch per scan: tiles are handed out by an atomic ticket (a tile's predecessors have therefore started and will publish without waiting
+// Arrays of up to 256 tiles (half a million elements: every scan of the graph phase, where a pass makes eleven of them on a few thousand elements
+// each) take ONE launch: tiles are handed out by an atomic ticket (a tile's predecessors have therefore started and will publish without waiting
 // for anybody behind them), a tile publishes its sum, looks back over its predecessors' published words (64 at a time, one per lane of a wave)
 // until it meets one that already knows its inclusive prefix, and publishes its own.  A published word = launch epoch | state | value in 64 bits,
-// written and read with one atomic access, so nothing has to be cleared between launches.  The round-2 form (reduce / scan of sums / downsweep,
-// recursive: five launches) cost 25 us per scan on arrays of a few thousand elements -- sixteen scans per input, a tenth of a 10 M-overlap pass.
-// HBM traffic: the input is read once and written once.
+// written and read with one relaxed agent-scope atomic, so nothing has to be cleared between launches and nothing has to be fenced.  The round-2
+// form cost five launches, 25 us, on such arrays.  Bigger arrays keep the three-phase form (reduce / scan of the tile sums / downsweep): there the
+// launches do not matter, and the input is read twice from a cache that mostly still holds it.
 #include "mahip_internal.hpp"
 
 #define SCAN_THREADS 256
@@ -35,6 +36,24 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t *s_wave
 	__syncthreads();
 	*total = tot;
 	return base + incl - x;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const uint32_t *__restrict__ in, uint32_t *__restrict__ bsum, size_t n)
+{
+	__shared__ uint32_t s_wave[SCAN_THREADS / 64];
+	size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+	uint32_t s = 0;
+	if (base + SCAN_ITEMS <= n) {
+		const uint4 *p = (const uint4*)(in + base);
+		uint4 a = p[0], b = p[1];
+		s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+	} else {
+		for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) s += in[base + i];
+	}
+	s = wv_sum_u32(s);
+	if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) bsum[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
 }
 
 // scans one tile; base comes from bbase[blockIdx.x] (exclusive prefix of block sums) or 0
@@ -127,6 +146,30 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const uint32_t *in,
 	if (d_total && base < n && base + SCAN_ITEMS >= n) *d_total = run; // grand total = exclusive prefix + value of the last element
 }
 
+static int scan_rec(mahip_ctx *c, const uint32_t *in, uint32_t *out, size_t n, uint32_t *d_total, int level)
+{
+	if (n == 0) {
+		if (d_total) HIPCHK(hipMemsetAsync(d_total, 0, 4, c->st));
+		return 0;
+	}
+	size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+	if (nb == 1) {
+		hipLaunchKernelGGL(k_scan_down, dim3(1), dim3(SCAN_THREADS), 0, c->st, in, out, (const uint32_t*)nullptr, n, d_total);
+		return 0;
+	}
+	if (level >= 2) { mahip_set_error("scan: input too large"); return -1; }
+	CHK(dev_reserve(c, c->scan_tmp[level + 1], (nb + 8) * 4));
+	uint32_t *bs = P<uint32_t>(c->scan_tmp[level + 1]);
+	hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, c->st, in, bs, n);
+	CHK(scan_rec(c, bs, bs, nb, nullptr, level + 1));
+	hipLaunchKernelGGL(k_scan_down, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, c->st, in, out, (const uint32_t*)bs, n, d_total);
+	return 0;
+}
+
+// tiles up to which the one-launch chained scan is used (MA_SCAN_CHAIN_MAX); beyond it the launches of the three-phase scan do not matter and its
+// traffic pattern is the safer one
+static size_t scan_chain_max() { static long v = -1; if (v < 0) { const char *e = getenv("MA_SCAN_CHAIN_MAX"); v = e ? atol(e) : 256; } return (size_t)v; }
+
 int scan_exclusive_u32(mahip_ctx *c, const uint32_t *in, uint32_t *out, size_t n, uint32_t *d_total)
 {
 	ProfScope ps(c, "scan_exclusive_u32", 8.0 * (double)n);
@@ -138,6 +181,11 @@ int scan_exclusive_u32(mahip_ctx *c, const uint32_t *in, uint32_t *out, size_t n
 	if (nb >= 0x40000000ull) { mahip_set_error("scan: input too large"); return -1; }
 	if (nb == 1) { // one tile: nothing to chain
 		hipLaunchKernelGGL(k_scan_down, dim3(1), dim3(SCAN_THREADS), 0, c->st, in, out, (const uint32_t*)nullptr, n, d_total);
+		HIPCHK(hipGetLastError());
+		return 0;
+	}
+	if (nb > scan_chain_max()) { // a big array: reduce / scan of the tile sums / downsweep
+		CHK(scan_rec(c, in, out, n, d_total, 0));
 		HIPCHK(hipGetLastError());
 		return 0;
 	}
