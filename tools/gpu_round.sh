@@ -120,7 +120,7 @@ sq)
   i=0
   for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE"; do
     i=$((i+1)); rm -rf gpurun_out/sq_$i; mkdir -p gpurun_out/sq_$i
-    (cd /tmp && timeout 900 rocprofv3 --pmc $set --kernel-trace -d /root/repo/gpurun_out/sq_$i -o r --output-format csv -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu --no-text --prof-steps 0 > /root/repo/gpurun_out/sq_$i/bench.json 2> /root/repo/gpurun_out/sq_$i/bench.log); echo "sq set $i rc=$?"
+    (cd /tmp && timeout 900 rocprofv3 --pmc $set --kernel-trace -d /root/repo/gpurun_out/sq_$i -o r --output-format csv -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu --no-text --no-legs --prof-steps 0 > /root/repo/gpurun_out/sq_$i/bench.json 2> /root/repo/gpurun_out/sq_$i/bench.log); echo "sq set $i rc=$?"
   done
   python tools/pmc_generic.py gpurun_out/sq_1 gpurun_out/sq_2 gpurun_out/sq_3 --filter k_hit_sub > gpurun_out/sq_summary.txt 2>&1; cat gpurun_out/sq_summary.txt | head -80
   find gpurun_out/sq_1 gpurun_out/sq_2 gpurun_out/sq_3 -name "*.csv" -size +8M -delete ;;
