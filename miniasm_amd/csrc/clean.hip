@@ -54,16 +54,17 @@ __global__ __launch_bounds__(64) void k_clean_bubble(cl_view_t g, cl_stamps_t s,
 	if (tid >= n_tab) return; // one table per working thread (the big tiers have fewer tables than a wave has lanes)
 	cl_bscratch_t b;
 	b.tab = tabs + (size_t)tid * cap; b.used = aux + (size_t)tid * 2 * cap; b.stack = b.used + cap; b.cap = cap; b.n_used = 0;
-	uint32_t pops = 0, tips = 0;
+	uint32_t pops = 0, tips = 0, back = 0;
 	for (uint32_t k = tid; k < n_src; k += n_tab) {
 		const uint32_t v0 = src[k];
 		uint32_t sink = 0, nt = 0;
 		int r = cl_bubble_probe(&g, v0, max_dist, &b, &sink, &nt);
-		if (r > 0) { cl_bubble_stamp(&g, s, v0, sink, &b); ++pops; tips += nt; }
+		if (r > 0) { back += cl_bubble_stamp(&g, s, v0, sink, &b); ++pops; tips += nt; }
 		else if (r < 0) ovf[atomicAdd(&ctr[CT_OVF], 1ull)] = v0;
 	}
 	if (pops) atomicAdd(&ctr[CT_LIVE], (unsigned long long)pops); // pops are rare: a handful of atomics per launch
 	if (tips) atomicAdd(&ctr[CT_REMAIN], (unsigned long long)tips);
+	if (back) atomicAdd(&ctr[CT_OVF2], (unsigned long long)back); // pops that would bring a dead read back (clean_core.h: ASSUMPTION)
 }
 
 __global__ __launch_bounds__(256) void k_table_init(cl_binfo_t *__restrict__ tabs, size_t n)
@@ -199,26 +200,33 @@ static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_
 		CHK(ctr_fetch(c));
 		HIPCHK(hipGetLastError());
 		if (mode == 3 && c->h_ctr[CT_OVF]) { // some probes filled their tables: those sources again, tier by tier, then the comparison once more
-			const unsigned long long pops = c->h_ctr[CT_LIVE], tips = c->h_ctr[CT_REMAIN];
-			unsigned long long more_pops = 0, more_tips = 0;
+			const unsigned long long pops = c->h_ctr[CT_LIVE], tips = c->h_ctr[CT_REMAIN], back = c->h_ctr[CT_OVF2];
+			unsigned long long more_pops = 0, more_tips = 0, more_back = 0;
 			uint32_t n_ovf = (uint32_t)c->h_ctr[CT_OVF];
 			for (int tier = 1, w = 0; n_ovf; ++tier, w ^= 1) {
 				if (tier >= BUB_TIERS) { mahip_set_error("asg_pop_bubble: a probe visits more than %u vertices", bub_cap(BUB_TIERS - 1) / 4 * 3); return -1; }
 				CHK(ctr_zero(c));
 				CHK(bubble_launch(c, b, tier, g, s, P<uint32_t>(b->ovf[w]), n_ovf, (uint32_t)param, P<uint32_t>(b->ovf[w ^ 1])));
 				CHK(ctr_fetch(c));
-				more_pops += c->h_ctr[CT_LIVE]; more_tips += c->h_ctr[CT_REMAIN];
+				more_pops += c->h_ctr[CT_LIVE]; more_tips += c->h_ctr[CT_REMAIN]; more_back += c->h_ctr[CT_OVF2];
 				n_ovf = (uint32_t)c->h_ctr[CT_OVF];
 			}
 			CHK(ctr_zero(c));
 			if (it > 0) hipLaunchKernelGGL(k_clean_diff, dim3(grid_for(W, 256, 1024)), dim3(256), 0, c->st, g.rst, (const uint32_t*)s.rst, W, ctr);
 			CHK(ctr_fetch(c));
-			c->h_ctr[CT_LIVE] = pops + more_pops; c->h_ctr[CT_REMAIN] = tips + more_tips;
+			c->h_ctr[CT_LIVE] = pops + more_pops; c->h_ctr[CT_REMAIN] = tips + more_tips; c->h_ctr[CT_OVF2] = back + more_back;
 		}
 		cur ^= 1;
 		if (n_iter) *n_iter = it + 1;
 		// fixpoint: the stamps did not change.  After the first sweep: no action means no stamp (an action may also be a no-op: counted, asg.c:296-302)
-		if (it == 0 ? c->h_ctr[CT_LIVE] == 0 : c->h_ctr[CT_TOTDP] == 0) { *cnt = (uint32_t)c->h_ctr[CT_LIVE]; *cnt2 = (uint32_t)c->h_ctr[CT_REMAIN]; break; }
+		if (it == 0 ? c->h_ctr[CT_LIVE] == 0 : c->h_ctr[CT_TOTDP] == 0) {
+			if (mode == 3 && c->h_ctr[CT_OVF2]) { // the final view: a pop of this sweep brings back a read an earlier pop deleted (clean_core.h: ASSUMPTION)
+				mahip_set_error("asg_pop_bubble: %llu pops of this sweep would resurrect a read that an earlier pop of the same sweep deleted (asg.c:352); the stamp model cannot express that",
+				                (unsigned long long)c->h_ctr[CT_OVF2]);
+				return -1;
+			}
+			*cnt = (uint32_t)c->h_ctr[CT_LIVE]; *cnt2 = (uint32_t)c->h_ctr[CT_REMAIN]; break;
+		}
 	}
 	if (*cnt) {
 		const size_t m = A > R ? A : R;

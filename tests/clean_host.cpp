@@ -46,7 +46,7 @@ extern "C" int clh_sweep(int mode, int param, uint32_t n_seq, uint32_t n_arc, ar
 		std::fill(ast[cur ^ 1].begin(), ast[cur ^ 1].end(), CL_NONE);
 		cl_stamps_t s; s.rst = rst[cur ^ 1].data(); s.ast = ast[cur ^ 1].data();
 		g.rst = rst[cur].data(); g.ast = ast[cur].data(); g.no_stamps = it == 0; // as the device does: the first sweep does not read stamps
-		uint32_t acts = 0, tips = 0, ovf = 0;
+		uint32_t acts = 0, tips = 0, ovf = 0, back = 0;
 		if (mode == 3) {
 			std::vector<cl_binfo_t> tab(cap);
 			std::vector<uint32_t> aux(2 * (size_t)cap);
@@ -56,7 +56,7 @@ extern "C" int clh_sweep(int mode, int param, uint32_t n_seq, uint32_t n_arc, ar
 				if ((uint32_t)G.idx[v0] < 2) continue;
 				uint32_t sink = 0, nt = 0;
 				int r = cl_bubble_probe(&g, v0, (uint32_t)param, &b, &sink, &nt);
-				if (r > 0) { cl_bubble_stamp(&g, s, v0, sink, &b); ++acts; tips += nt; }
+				if (r > 0) { back += cl_bubble_stamp(&g, s, v0, sink, &b); ++acts; tips += nt; }
 				else if (r < 0) ovf = 1;
 			}
 		} else {
@@ -67,7 +67,7 @@ extern "C" int clh_sweep(int mode, int param, uint32_t n_seq, uint32_t n_arc, ar
 		const bool same = rst[0] == rst[1] && ast[0] == ast[1];
 		cur ^= 1;
 		*iters = it + 1;
-		if (same) { *cnt = acts; *cnt2 = tips; break; }
+		if (same) { *cnt = acts; *cnt2 = tips; if (back) return -4; /* the pop that brings a dead read back: see clean_core.h, ASSUMPTION */ break; }
 	}
 	for (uint32_t r = 0; r < n_seq; ++r) if (rst[cur][r] != CL_NONE) seq[r] |= 0x80000000u;
 	for (uint32_t e = 0; e < n_arc; ++e) if (ast[cur][e] != CL_NONE) arc[e].ol |= 0x80000000u;

@@ -58,7 +58,8 @@ class Graph:
 
     def sweep(self, L, mode, param, cap=0):
         cnt, cnt2, it = C.c_uint32(0), C.c_uint32(0), C.c_int(0)
-        L.clh_sweep(mode, param, self.ns, len(self.arcs), self.arcs.ctypes.data, self.idx.ctypes.data, self.seq.ctypes.data, C.byref(cnt), C.byref(cnt2), C.byref(it), cap)
+        rc = L.clh_sweep(mode, param, self.ns, len(self.arcs), self.arcs.ctypes.data, self.idx.ctypes.data, self.seq.ctypes.data, C.byref(cnt), C.byref(cnt2), C.byref(it), cap)
+        assert rc == 0, "clh_sweep: %d (-4: a pop that would resurrect a read an earlier pop deleted -- clean_core.h, ASSUMPTION)" % rc
         if cnt.value:
             self.cleanup()
         return cnt.value, cnt2.value, it.value
