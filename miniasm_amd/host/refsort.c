@@ -203,7 +203,7 @@ static int refsort_threads(void)
 {
 	const char *s = getenv("MA_THREADS");
 	long n = s ? atol(s) : sysconf(_SC_NPROCESSORS_ONLN);
-	if (!s && n > 32) n = 32;
+	if (!s && n > 64) n = 64; /* (32 until round 3: at BASELINE configs[4] the buckets below the top level were 1.4 s on 32 threads of the GPU box's 256 cores) */
 	return n < 1 ? 1 : n > 64 ? 64 : (int)n;
 }
 

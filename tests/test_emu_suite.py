@@ -161,3 +161,6 @@ def test_bench_py_on_two_ranks_on_the_cpu_build(emu_built, tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["gfa_identical"] is True and d["parity"]["gfa_md5"] == one["parity"]["ref_md5"]
     assert d["config"]["global_overlaps"] == one["config"]["global_overlaps"] and d["config"]["per_gpu_hits"] < one["config"]["per_gpu_hits"]
+    ph = d["phases"]  # where a sharded step spends its time: one entry per phase of host/sharded.c, [max, min] over the ranks
+    assert set(ph["phase_ms"]) >= {"sort", "sub#1", "x:sub0", "x:arc blocks", "rank 0: cleanup+symm"} and all(len(v) == 2 and v[0] >= v[1] >= 0 for v in ph["phase_ms"].values())
+    assert ph["exchange_bytes_per_rank"]["x:sub0"] > 0 and ph["head_wall_ms_max"] >= ph["head_wall_ms_min"] > 0 and ph["rank0_tail_wall_ms"] > 0
