@@ -283,47 +283,78 @@ __device__ __forceinline__ bool name_eq(const unsigned char *__restrict__ a, con
 // the bytes after ONE dependent fetch; one that does not see it yet (the store is not ordered with the CAS, a stale L1 line) goes the
 // long way through the occurrence (line start, column offset, length: three more random fetches) -- both ways read the same bytes.
 #define PAF_INFO_LEN_BITS 24
+// the slot of one name occurrence (probe, insert if new); 0xffffffff: the probe sequence ran out
+__device__ __forceinline__ uint32_t dict_probe(const unsigned char *__restrict__ text, const uint64_t *__restrict__ lstart, const PafCols &o,
+                                               unsigned long long *__restrict__ tab, uint32_t *__restrict__ tmin, unsigned long long *__restrict__ info, uint32_t mask,
+                                               uint64_t h, uint32_t len, uint32_t occ, uint64_t noff, uint32_t *fresh)
+{
+	const unsigned char *nm = text + noff;
+	const uint32_t tag = (uint32_t)(h >> 32);
+	uint32_t s = (uint32_t)h & mask;
+	for (uint32_t probe = 0; probe < PAF_PROBE_LIMIT; ++probe, s = (s + 1) & mask) {
+		unsigned long long e = tab[s];
+		if (e == PAF_EMPTY) {
+			e = atomicCAS(&tab[s], PAF_EMPTY, (unsigned long long)tag << 32 | occ);
+			if (e == PAF_EMPTY) {
+				if (len < (1u << PAF_INFO_LEN_BITS) && noff < (1ull << (64 - PAF_INFO_LEN_BITS))) info[s] = noff << PAF_INFO_LEN_BITS | len;
+				atomicMin(&tmin[s], occ); ++*fresh;
+				return s;
+			}
+		}
+		if ((uint32_t)(e >> 32) == tag) {
+			const unsigned long long inf = info[s];
+			bool same;
+			if (inf != PAF_EMPTY) same = (uint32_t)(inf & ((1u << PAF_INFO_LEN_BITS) - 1)) == len && name_eq(nm, text + (inf >> PAF_INFO_LEN_BITS), len);
+			else {
+				const uint32_t r = (uint32_t)e, rl = r >> 1;
+				const uint32_t rlen = (r & 1) ? o.tlen[rl] : o.qlen[rl];
+				same = rlen == len && name_eq(nm, text + lstart[rl] + ((r & 1) ? o.tnoff[rl] : 0u), len);
+			}
+			if (same) {
+				if (tmin[s] > occ) atomicMin(&tmin[s], occ);
+				return s;
+			}
+		}
+	}
+	return 0xffffffffu;
+}
+
+// A PAF file lists a query's overlaps together (the reference's own all-vs-all pipeline writes them so; so does every overlapper that works query by
+// query): the QUERY name of a line is, 49 times in 50 at BASELINE coverage, the previous line's.  A wave holds 64 consecutive lines; a lane whose query
+// name equals its left neighbour's (same hash, same length, same bytes) does not probe but takes the slot of the nearest lane to its left that did (the
+// head of its run: its occurrence number is the run's smallest, so tmin is right as well).  Round 2 probed once per name occurrence: 200 M probes and
+// 68 GB of fetches for 100 M lines; the query column now costs one probe per run and wave.  Target names change from line to line and probe as before.
 __global__ __launch_bounds__(256) void k_dict_insert(const unsigned char *__restrict__ text, const uint64_t *__restrict__ lstart, uint32_t L, PafCols o,
                                                       unsigned long long *__restrict__ tab, uint32_t *__restrict__ tmin, unsigned long long *__restrict__ info,
                                                       uint32_t mask, unsigned long long *__restrict__ ctr)
 {
 	uint32_t fail = 0, fresh = 0;
-	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < L; i += gridDim.x * 256u) {
-		if (!(o.flags[i] & 2)) continue;
-		const uint64_t ls = lstart[i];
-		for (uint32_t col = 0; col < 2; ++col) {
-			const uint64_t h = col ? o.ht[i] : o.hq[i];
-			const uint32_t len = col ? o.tlen[i] : o.qlen[i], occ = i * 2u + col;
-			const uint64_t noff = ls + (col ? o.tnoff[i] : 0u);
-			const unsigned char *nm = text + noff;
-			const uint32_t tag = (uint32_t)(h >> 32);
-			uint32_t s = (uint32_t)h & mask, slot = 0xffffffffu;
-			for (uint32_t probe = 0; probe < PAF_PROBE_LIMIT; ++probe, s = (s + 1) & mask) {
-				unsigned long long e = tab[s];
-				if (e == PAF_EMPTY) {
-					e = atomicCAS(&tab[s], PAF_EMPTY, (unsigned long long)tag << 32 | occ);
-					if (e == PAF_EMPTY) {
-						if (len < (1u << PAF_INFO_LEN_BITS) && noff < (1ull << (64 - PAF_INFO_LEN_BITS))) info[s] = noff << PAF_INFO_LEN_BITS | len;
-						atomicMin(&tmin[s], occ); slot = s; ++fresh; break;
-					}
-				}
-				if ((uint32_t)(e >> 32) == tag) {
-					const unsigned long long inf = info[s];
-					bool same;
-					if (inf != PAF_EMPTY) same = (uint32_t)(inf & ((1u << PAF_INFO_LEN_BITS) - 1)) == len && name_eq(nm, text + (inf >> PAF_INFO_LEN_BITS), len);
-					else {
-						const uint32_t r = (uint32_t)e, rl = r >> 1;
-						const uint32_t rlen = (r & 1) ? o.tlen[rl] : o.qlen[rl];
-						same = rlen == len && name_eq(nm, text + lstart[rl] + ((r & 1) ? o.tnoff[rl] : 0u), len);
-					}
-					if (same) {
-						if (tmin[s] > occ) atomicMin(&tmin[s], occ);
-						slot = s; break;
-					}
-				}
-			}
-			if (slot == 0xffffffffu) fail = 1;
-			if (col) o.tslot[i] = slot; else o.qslot[i] = slot;
+	const unsigned lane = threadIdx.x & 63;
+	for (uint32_t base = blockIdx.x * 256u; base < L; base += gridDim.x * 256u) { // wave-uniform: the lanes talk to each other below
+		const uint32_t i = base + threadIdx.x;
+		const bool stored = i < L && (o.flags[i] & 2);
+		const uint64_t ls = stored ? lstart[i] : 0;
+		const uint64_t hq = stored ? o.hq[i] : 0;
+		const uint32_t qlen = stored ? o.qlen[i] : 0;
+		// does this line continue its left neighbour's run of one query name?
+		const uint64_t hq_l = (uint64_t)__shfl_up((uint32_t)(hq >> 32), 1, 64) << 32 | __shfl_up((uint32_t)hq, 1, 64);
+		const uint32_t qlen_l = __shfl_up(qlen, 1, 64);
+		const uint64_t ls_l = (uint64_t)__shfl_up((uint32_t)(ls >> 32), 1, 64) << 32 | __shfl_up((uint32_t)ls, 1, 64);
+		const int stored_l = __shfl_up((int)stored, 1, 64);
+		const bool cont = stored && lane > 0 && stored_l && hq_l == hq && qlen_l == qlen && name_eq(text + ls, text + ls_l, qlen);
+		uint32_t qslot = 0xffffffffu;
+		if (stored && !cont) qslot = dict_probe(text, lstart, o, tab, tmin, info, mask, hq, qlen, i * 2u, ls, &fresh);
+		const unsigned long long heads = __ballot(stored && !cont);
+		{ // a continuing lane: the slot of the nearest head to its left (there is one: lane 0 never continues)
+			const unsigned long long left = heads & ((1ull << lane) - 1ull);
+			const int src = left ? 63 - __builtin_clzll(left) : (int)lane;
+			const uint32_t got = __shfl(qslot, src, 64);
+			if (cont) qslot = got;
+		}
+		if (stored) {
+			const uint32_t tslot = dict_probe(text, lstart, o, tab, tmin, info, mask, o.ht[i], o.tlen[i], i * 2u + 1u, ls + o.tnoff[i], &fresh);
+			if (qslot == 0xffffffffu || tslot == 0xffffffffu) fail = 1;
+			o.qslot[i] = qslot; o.tslot[i] = tslot;
 		}
 	}
 	blk_add_u64(&ctr[PC_OVERFLOW], fail);
