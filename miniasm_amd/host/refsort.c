@@ -33,6 +33,7 @@ static int rs_timing = -1;
  * new cache line of a bucket used to be a miss on the walk's dependent chain; each store now asks for the line a few ahead of its head. */
 #define RS_PREFETCH(p) __builtin_prefetch((const char*)(p) + 256, 1, 3)
 #define TASK_MIN (1u << 11)   /* buckets smaller than this are finished by the thread that made them */
+#define RS_DIG_MIN ((size_t)1 << 20) /* ranges at least this long below the top level also walk on a byte array of their digits (refsort_body.h) */
 
 /* Element layouts.  wide: {key, index} (16 bytes).  packed: when the bits of the key's high word (bh), of its low word (bl) and of the
  * index (bi) fit into 64, one word (hi << bl | lo) << bi | index -- half the memory traffic of a walk that is bound by it.  The reference

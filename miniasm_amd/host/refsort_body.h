@@ -55,7 +55,22 @@ static void RS_NAME(permute_top)(rs_pool_t *pool, RS_T *a, const size_t *cnt, co
 		unsigned d;
 		if (b[k].head == start[k + 1]) { ++k; continue; }
 		d = b[k].nd;
-		if (d == (unsigned)k) { b[k].nd = dig[++b[k].head]; continue; }
+		if (d == (unsigned)k) { /* already home -- and so, in a PAF-ordered input, are most of its neighbours: the whole stretch at once, eight digits per step */
+			size_t p = b[k].head + 1;
+			const size_t lim = start[k + 1];
+			const uint64_t pat = 0x0101010101010101ull * (unsigned)k;
+			while (p + 8 <= lim) {
+				uint64_t x;
+				memcpy(&x, dig + p, 8);
+				x ^= pat;
+				if (x) { p += (size_t)__builtin_ctzll(x) >> 3; goto stretch_done; }
+				p += 8;
+			}
+			while (p < lim && dig[p] == (unsigned)k) ++p;
+		stretch_done:
+			b[k].head = p; b[k].nd = dig[p];
+			continue;
+		}
 		{
 			RS_T carry = a[b[k].head];
 			do {
@@ -113,6 +128,7 @@ static void RS_NAME(level)(rs_pool_t *pool, RS_T *a, size_t n, int shift)
 	size_t tail[256], i;
 	/* A level on which the digit does not vary leaves the range untouched and recurses into the same range (n > 64
 	 * here).  One sweep gives the varying bits and, optimistically, the histogram of the current digit. */
+	uint8_t *dig = n >= RS_DIG_MIN ? (uint8_t*)malloc(n + 16) : 0; /* a big range (the 65 536-read buckets below the top level of a 10^9-hit input): the digit walk */
 	for (;;) {
 		uint64_t diff = 0;
 		const uint64_t k0 = RS_ORIG(a[0], cfg);
@@ -120,12 +136,14 @@ static void RS_NAME(level)(rs_pool_t *pool, RS_T *a, size_t n, int shift)
 		unsigned m;
 		RS_LEVEL(cfg, shift, sh, m);
 		memset(tail, 0, sizeof(tail));
-		for (i = 0; i < n; ++i) diff |= RS_ORIG(a[i], cfg) ^ k0, ++tail[RS_WORD(a[i]) >> sh & m];
-		if (diff == 0) return; /* all keys equal: every remaining level is the identity */
+		if (dig) for (i = 0; i < n; ++i) { const unsigned dg = (unsigned)(RS_WORD(a[i]) >> sh & m); diff |= RS_ORIG(a[i], cfg) ^ k0; dig[i] = (uint8_t)dg; ++tail[dg]; }
+		else for (i = 0; i < n; ++i) diff |= RS_ORIG(a[i], cfg) ^ k0, ++tail[RS_WORD(a[i]) >> sh & m];
+		if (diff == 0) { free(dig); return; } /* all keys equal: every remaining level is the identity */
 		if ((diff >> shift & 0xff) != 0) break;
 		while (shift > 0 && (diff >> shift & 0xff) == 0) shift -= 8;
 	}
-	RS_NAME(permute)(pool, a, tail, shift);
+	if (dig) { memset(dig + n, 0, 16); RS_NAME(permute_top)(pool, a, tail, dig, shift); free(dig); }
+	else RS_NAME(permute)(pool, a, tail, shift);
 }
 
 /* parallel sweeps over a big range: OR of (key ^ key[0]) and, with shift >= 0, the histogram of one digit */

@@ -248,7 +248,8 @@ def test_refsort_perm_matches_reference_sort(threads, monkeypatch):
     # the shape of a PAF file: keys that are almost sorted already (a query's overlaps are listed together, the mirrored records point at reads
     # nearby): the top-level walk (host/refsort_body.h: permute_top) then runs over long stretches of elements that are already home -- identity at
     # the bucket it works on, shifted by one everywhere else, recorded as segments when long
-    for n, per, spread in ((300000, 3, 40), (1500000, 20, 3), (1500000, 20, 70000), (2000000, 7, 1)):
+    # (the 2.6 M-element cases leave ranges of more than a million elements below the top level: those walk on a byte array of their digits too)
+    for n, per, spread in ((300000, 3, 40), (1500000, 20, 3), (1500000, 20, 70000), (2000000, 7, 1), (2600000, 20, 500), (2600000, 13, 100000)):
         nr = n // per
         q = np.sort(rng.integers(0, nr, n // 2)).astype(np.int64)
         t = np.clip(q + rng.integers(-spread, spread + 1, n // 2), 0, nr - 1)
