@@ -32,6 +32,7 @@ static int rs_timing = -1;
 /* The walk touches the 256 bucket heads in an order the hardware prefetchers cannot follow (they track a few dozen streams), so every
  * new cache line of a bucket used to be a miss on the walk's dependent chain; each store now asks for the line a few ahead of its head. */
 #define RS_PREFETCH(p) __builtin_prefetch((const char*)(p) + 256, 1, 3)
+#define RS_SHORT 4096u        /* ranges up to this length take the short-range form of a level (refsort_body.h: level_small) */
 #define TASK_MIN (1u << 11)   /* buckets smaller than this are finished by the thread that made them */
 #define RS_DIG_MIN ((size_t)1 << 20) /* ranges at least this long below the top level also walk on a byte array of their digits (refsort_body.h) */
 

@@ -121,11 +121,59 @@ static void RS_NAME(permute)(rs_pool_t *pool, RS_T *a, size_t *tail, int shift)
 	RS_NAME(dispatch)(pool, a, start, shift);
 }
 
+/* A short range -- the hits of one read, the arcs of one vertex: most of the ranges there are, a hundred elements each.  Same procedure, but what a
+ * level costs must not be the 256 buckets it could have: one pass says which bits vary (and with that which level is the next that moves anything
+ * and which digits can occur there: lo | any subset of the varying bits), and counting, walk and hand-over only look at the digits lo..hi. */
+static void RS_NAME(level_small)(rs_pool_t *pool, RS_T *a, size_t n, int shift)
+{
+	const rs_cfg_t *cfg = &pool->cfg;
+	uint32_t head[256], tail[256], start[257];
+	const uint64_t k0 = RS_ORIG(a[0], cfg);
+	uint64_t diff = 0;
+	size_t i;
+	int sh, k, lo, hi, next;
+	unsigned m, vb;
+	for (i = 1; i < n; ++i) diff |= RS_ORIG(a[i], cfg) ^ k0;
+	if (diff == 0) return; /* all keys equal: every remaining level is the identity */
+	while (shift > 0 && (diff >> shift & 0xff) == 0) shift -= 8; /* levels on which the digit does not vary leave the range as it is */
+	RS_LEVEL(cfg, shift, sh, m);
+	vb = (unsigned)(diff >> shift & 0xff) & m;
+	lo = (int)((unsigned)(RS_WORD(a[0]) >> sh & m) & ~vb); hi = lo | (int)vb;
+	for (k = lo; k <= hi; ++k) tail[k] = 0;
+	for (i = 0; i < n; ++i) ++tail[RS_WORD(a[i]) >> sh & m];
+	start[lo] = 0;
+	for (k = lo; k <= hi; ++k) start[k + 1] = start[k] + tail[k], head[k] = start[k], tail[k] = start[k + 1];
+	for (k = lo; k <= hi;) { /* ksort.h:160-172 */
+		int dst;
+		if (head[k] == tail[k]) { ++k; continue; }
+		dst = (int)(RS_WORD(a[head[k]]) >> sh & m);
+		if (dst == k) { ++head[k]; continue; }
+		{
+			RS_T carry = a[head[k]];
+			do {
+				RS_T evicted = a[head[dst]];
+				a[head[dst]++] = carry;
+				carry = evicted;
+				dst = (int)(RS_WORD(carry) >> sh & m);
+			} while (dst != k);
+			a[head[k]++] = carry;
+		}
+	}
+	if (!shift) return;
+	next = shift > 8 ? shift - 8 : 0;
+	for (k = lo; k <= hi; ++k) { /* ksort.h:177-182 */
+		const size_t cnt = start[k + 1] - start[k];
+		if (cnt > RS_SMALL) RS_NAME(level_small)(pool, a + start[k], cnt, next);
+		else if (cnt > 1) RS_NAME(insertion)(a + start[k], cnt, cfg);
+	}
+}
+
 /* one level of ksort.h:153-179 on a[0..n) */
 static void RS_NAME(level)(rs_pool_t *pool, RS_T *a, size_t n, int shift)
 {
 	const rs_cfg_t *cfg = &pool->cfg;
 	size_t tail[256], i;
+	if (n <= RS_SHORT) { RS_NAME(level_small)(pool, a, n, shift); return; }
 	/* A level on which the digit does not vary leaves the range untouched and recurses into the same range (n > 64
 	 * here).  One sweep gives the varying bits and, optimistically, the histogram of the current digit. */
 	uint8_t *dig = n >= RS_DIG_MIN ? (uint8_t*)malloc(n + 16) : 0; /* a big range (the 65 536-read buckets below the top level of a 10^9-hit input): the digit walk */
