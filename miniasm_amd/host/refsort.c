@@ -34,7 +34,7 @@ static int rs_timing = -1;
 #define RS_PREFETCH(p) __builtin_prefetch((const char*)(p) + 256, 1, 3)
 #define RS_SHORT 4096u        /* ranges up to this length take the short-range form of a level (refsort_body.h: level_small) */
 #define TASK_MIN (1u << 11)   /* buckets smaller than this are finished by the thread that made them */
-#define RS_DIG_MIN ((size_t)1 << 20) /* ranges at least this long below the top level also walk on a byte array of their digits (refsort_body.h) */
+#define RS_DIG_MIN ((size_t)RS_SHORT + 1) /* ranges at least this long below the top level also walk on a byte array of their digits (refsort_body.h) */
 
 /* Element layouts.  wide: {key, index} (16 bytes).  packed: when the bits of the key's high word (bh), of its low word (bl) and of the
  * index (bi) fit into 64, one word (hi << bl | lo) << bi | index -- half the memory traffic of a walk that is bound by it.  The reference

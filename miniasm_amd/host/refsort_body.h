@@ -43,6 +43,45 @@ static void RS_NAME(dispatch)(rs_pool_t *pool, RS_T *a, const size_t *start, int
  * by all threads: 0.62 s against 0.32 s for this form on the 50 M-overlap noisy input, 8.0 s against 2.8 s at BASELINE configs[4] on the EPYC of the
  * GPU box (profiles/r03_tiewalk.txt): noisy PAFs have few long runs, and a separate 4-byte permutation plus a gather is more memory traffic than
  * moving 8-byte elements once.  Dropped. */
+/* The walk as ONE loop without a data-dependent branch.  ksort.h:160-172 is a token that moves from bucket to bucket: at bucket d it takes the element at
+ * d's head (that element's digit says where the token goes next) and leaves the element it carries.  For every bucket but the scanned one k the slot read
+ * and the slot written are the same; for k the element carried away at the start of a chain came from the slot the chain's last element will fill, so k
+ * reads one slot ahead of where it writes (an element of k that is already home is written back to its own slot).  With a read and a write position per
+ * bucket every step is the same few instructions, `while (l != k)` and `if (l != k)` of the reference disappear, and the only branch left is taken when
+ * the scanned bucket is full (256 times).  The literal form mispredicted once per chain: 2 x slower with the 4 top-level buckets of a 250 k-read input,
+ * 1.3 x with 16 (1 M reads), the same with 77 (profiles/r03_tiewalk.txt). */
+typedef struct { size_t r, w; } RS_NAME(rw_t);
+static void RS_NAME(permute_uniform)(RS_T *a, const size_t *start, const uint8_t *dig /* n + 1 bytes */, int lo, int hi /* the digits that occur: start[lo .. hi + 1] are set */)
+{
+	RS_NAME(rw_t) b[256];
+	uint8_t nd[256];
+	const size_t last = start[hi + 1] - 1;
+	size_t left;
+	RS_T carry;
+	unsigned d;
+	int k;
+	for (k = lo; k <= hi; ++k) b[k].r = b[k].w = start[k], nd[k] = dig[start[k]];
+	for (k = lo; k <= hi && start[k + 1] == start[k]; ++k) {}
+	if (k > hi) return;
+	left = start[k + 1] - b[k].w; carry = a[b[k].w]; d = nd[k]; b[k].r = b[k].w + 1; nd[k] = dig[b[k].r];
+	for (;;) { /* carry = the element taken from the scanned bucket's write slot or evicted on the way; d = its digit */
+		const size_t rd = b[d].r, wd = b[d].w;
+		const unsigned dn = nd[d];
+		const RS_T evicted = a[rd < last ? rd : last]; /* (the scanned bucket reads one slot ahead: at most one past the range, and that element is dropped) */
+		a[wd] = carry;
+		b[d].r = rd + 1; b[d].w = wd + 1; nd[d] = dig[rd + 1];
+		RS_PREFETCH(&a[rd]);
+		carry = evicted;
+		left -= d == (unsigned)k;
+		d = dn;
+		if (left == 0) { /* bucket k is full (what was read beyond its end is dropped): scan the next bucket that has free slots */
+			do ++k; while (k <= hi && b[k].w == start[k + 1]);
+			if (k > hi) break;
+			left = start[k + 1] - b[k].w; carry = a[b[k].w]; d = nd[k]; b[k].r = b[k].w + 1; nd[k] = dig[b[k].r];
+		}
+	}
+}
+
 typedef struct { size_t head; uint32_t nd; uint32_t pad; } RS_NAME(bk_t);
 static void RS_NAME(permute_top)(rs_pool_t *pool, RS_T *a, const size_t *cnt, const uint8_t *dig /* n + 1 bytes */, int shift)
 {
@@ -50,7 +89,15 @@ static void RS_NAME(permute_top)(rs_pool_t *pool, RS_T *a, const size_t *cnt, co
 	size_t start[257];
 	int k;
 	start[0] = 0;
-	for (k = 0; k < 256; ++k) start[k + 1] = start[k] + cnt[k], b[k].head = start[k], b[k].nd = dig[start[k]], b[k].pad = 0;
+	for (k = 0; k < 256; ++k) start[k + 1] = start[k] + cnt[k];
+	{ /* a sample says which form of the walk: few elements at home (a PAF as the mapper writes it: ids in order of first appearance, queries in any order) -> the
+	   * uniform walk below; mostly at home (arcs, a PAF sorted by query) -> the form that takes a stretch of home elements eight at a time */
+		const size_t n = start[256], step = n / 4096 + 1;
+		size_t p, home = 0, seen = 0;
+		for (p = 0, k = 0; p < n; p += step, ++seen) { while (start[k + 1] <= p) ++k; home += dig[p] == (unsigned)k; }
+		if (home * 2 < seen) { RS_NAME(permute_uniform)(a, start, dig, 0, 255); RS_NAME(dispatch)(pool, a, start, shift); return; }
+	}
+	for (k = 0; k < 256; ++k) b[k].head = start[k], b[k].nd = dig[start[k]], b[k].pad = 0;
 	for (k = 0; k < 256;) {
 		unsigned d;
 		if (b[k].head == start[k + 1]) { ++k; continue; }
@@ -127,7 +174,8 @@ static void RS_NAME(permute)(rs_pool_t *pool, RS_T *a, size_t *tail, int shift)
 static void RS_NAME(level_small)(rs_pool_t *pool, RS_T *a, size_t n, int shift)
 {
 	const rs_cfg_t *cfg = &pool->cfg;
-	uint32_t head[256], tail[256], start[257];
+	size_t start[257], cnt[256];
+	uint8_t dig[RS_SHORT + 16];
 	const uint64_t k0 = RS_ORIG(a[0], cfg);
 	uint64_t diff = 0;
 	size_t i;
@@ -139,32 +187,18 @@ static void RS_NAME(level_small)(rs_pool_t *pool, RS_T *a, size_t n, int shift)
 	RS_LEVEL(cfg, shift, sh, m);
 	vb = (unsigned)(diff >> shift & 0xff) & m;
 	lo = (int)((unsigned)(RS_WORD(a[0]) >> sh & m) & ~vb); hi = lo | (int)vb;
-	for (k = lo; k <= hi; ++k) tail[k] = 0;
-	for (i = 0; i < n; ++i) ++tail[RS_WORD(a[i]) >> sh & m];
+	for (k = lo; k <= hi; ++k) cnt[k] = 0;
+	for (i = 0; i < n; ++i) { const unsigned dg = (unsigned)(RS_WORD(a[i]) >> sh & m); dig[i] = (uint8_t)dg; ++cnt[dg]; }
+	dig[n] = dig[n + 1] = 0;
 	start[lo] = 0;
-	for (k = lo; k <= hi; ++k) start[k + 1] = start[k] + tail[k], head[k] = start[k], tail[k] = start[k + 1];
-	for (k = lo; k <= hi;) { /* ksort.h:160-172 */
-		int dst;
-		if (head[k] == tail[k]) { ++k; continue; }
-		dst = (int)(RS_WORD(a[head[k]]) >> sh & m);
-		if (dst == k) { ++head[k]; continue; }
-		{
-			RS_T carry = a[head[k]];
-			do {
-				RS_T evicted = a[head[dst]];
-				a[head[dst]++] = carry;
-				carry = evicted;
-				dst = (int)(RS_WORD(carry) >> sh & m);
-			} while (dst != k);
-			a[head[k]++] = carry;
-		}
-	}
+	for (k = lo; k <= hi; ++k) start[k + 1] = start[k] + cnt[k];
+	RS_NAME(permute_uniform)(a, start, dig, lo, hi); /* ksort.h:160-172 */
 	if (!shift) return;
 	next = shift > 8 ? shift - 8 : 0;
 	for (k = lo; k <= hi; ++k) { /* ksort.h:177-182 */
-		const size_t cnt = start[k + 1] - start[k];
-		if (cnt > RS_SMALL) RS_NAME(level_small)(pool, a + start[k], cnt, next);
-		else if (cnt > 1) RS_NAME(insertion)(a + start[k], cnt, cfg);
+		const size_t c = cnt[k];
+		if (c > RS_SMALL) RS_NAME(level_small)(pool, a + start[k], c, next);
+		else if (c > 1) RS_NAME(insertion)(a + start[k], c, cfg);
 	}
 }
 
