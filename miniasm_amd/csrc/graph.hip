@@ -574,7 +574,9 @@ static int push_stable_order(mahip_ctx *c, size_t m, int *gen, uint64_t *conflic
 static int push_order(mahip_ctx *c, size_t m, bool exact, int *gen)
 {
 	uint64_t conf = 0;
+	TieLaps tl(c);
 	CHK(push_stable_order(c, m, gen, &conf));
+	tl.lap("stable push order + conflicts");
 	c->tie.push_conflicts = conf;
 	if (exact && conf) {
 		CHK(hits_reference_rank(c)); // uses key[]/val[] as scratch
@@ -638,6 +640,7 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 		unsigned long long *ctr = P<unsigned long long>(c->ctr);
 		const int32_t *map = c->has_map ? (const int32_t*)P<int32_t>(c->map) : (const int32_t*)nullptr;
 		int gen = 0, need_walk = c->tie_mode == 1 && !sharded;
+		TieLaps tl(c);
 		if (c->tie_mode == 0 && want_slots) { // the documented stable order: the stable sort of the stable push order
 			int g0 = 0;
 			CHK(push_order(c, m, false, &g0));
@@ -660,6 +663,7 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 				c->tie.arc_tie_groups = c->h_ctr[ST_ARC_TIE_GROUPS]; c->tie.arc_tie_arcs = c->h_ctr[ST_ARC_TIE_ARCS];
 				need_walk = c->tie.arc_tie_groups > 0;
 			}
+			tl.lap("stable arc sort + census");
 		}
 		if (need_walk) {
 			// (1) the push order: arcs leave ma_sg_gen in the order ma_hit_sort left the hits in (asm.c:18-35)
@@ -669,6 +673,7 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 				hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, (const uint32_t*)P<uint32_t>(c->val[g2]), out);
 				c->ag ^= 1; // `out` now holds the arcs in the reference's push order
 				in = arcs_of(c, c->ag); out = arcs_of(c, c->ag ^ 1);
+				tl.lap("push order (all of it)");
 			}
 			// (2) the reference's sort of that sequence (ksort.h:134-183 on ul with squeezed ids): permutation from the host walk
 			hipLaunchKernelGGL(k_arc_keys_ref, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, map, P<uint64_t>(c->key[0]));
@@ -678,6 +683,7 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 				hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, (const uint32_t*)P<uint32_t>(c->val[1]), out);
 			}
 			c->tie.arc_walk = 1;
+			tl.lap("arc walk (all of it)");
 		}
 		c->ag ^= 1;
 	}

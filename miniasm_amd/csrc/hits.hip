@@ -1042,13 +1042,17 @@ int hits_reference_rank(mahip_ctx *c)
 	CHK(dev_reserve(c, c->hrank, (n + 1) * 4));
 	if (n == 0) { c->hrank_ready = true; return 0; }
 	// the walk runs over ALL input records (on a shard: every rank repeats it and keeps the ranks of its own slots; sidx holds global positions)
+	TieLaps tl0(c);
 	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (N + 1) * 8)); CHK(dev_reserve(c, c->val[k], (N + 1) * 4)); }
 	hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(N, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, N, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
 	                   (uint32_t*)nullptr, P<unsigned long long>(c->ctr), 0u, 0xffffffffu, 0, 1); // key = qid<<32 | qs, input order
+	tl0.lap("hit keys (+ buffers)");
 	CHK(reference_order(c, P<uint64_t>(c->key[0]), N, P<uint32_t>(c->val[1])));
+	TieLaps tl(c);
 	hipLaunchKernelGGL(k_perm_invert, dim3(grid_for(N, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->val[1]), N, P<uint32_t>(c->val[0]));
 	hipLaunchKernelGGL(k_hit_rank, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->sidx), (const uint32_t*)P<uint32_t>(c->val[0]), n, P<uint32_t>(c->hrank));
 	HIPCHK(hipGetLastError());
+	tl.lap("hit ranks on the device");
 	c->hrank_ready = true;
 	c->tie.hit_walk = 1;
 	return 0;

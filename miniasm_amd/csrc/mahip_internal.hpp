@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <vector>
 #include <string>
 #include "mahip.h"
@@ -121,6 +122,14 @@ struct ProfScope {
 	mahip_ctx *c;
 	ProfScope(mahip_ctx *c_, const char *name, double alg_bytes) : c(c_) { if (c->prof) prof_begin(c, name, alg_bytes); }
 	~ProfScope() { if (c->prof) prof_end(c); }
+};
+
+// MA_PIPE_TIMING >= 2: wall time of the steps of the tie repair (a stream sync per lap), `[T::ties]   <step> <ms>` on stderr
+struct TieLaps {
+	mahip_ctx *c; bool on; double t0 = 0;
+	static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+	explicit TieLaps(mahip_ctx *c_) : c(c_) { const char *s = getenv("MA_PIPE_TIMING"); on = s && atoi(s) >= 2; if (on) { (void)hipStreamSynchronize(c->st); t0 = now(); } }
+	void lap(const char *what) { if (!on) return; (void)hipStreamSynchronize(c->st); const double t1 = now(); fprintf(stderr, "[T::ties]   %-34s %9.3f ms\n", what, (t1 - t0) * 1e3); t0 = t1; }
 };
 
 template <typename T> static inline T *P(DevBuf &b) { return (T*)b.p; }

@@ -221,14 +221,19 @@ extern "C" int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm);
 int reference_order(mahip_ctx *c, const uint64_t *d_keys, size_t n, uint32_t *d_perm)
 {
 	if (n == 0) return 0;
+	TieLaps tl(c);
 	uint64_t *hk = (uint64_t*)malloc(n * 8);
 	uint32_t *hp = (uint32_t*)malloc(n * 4);
 	if (!hk || !hp) { free(hk); free(hp); mahip_set_error("reference_order: out of host memory"); return -1; }
 	int rc = 0;
 	if (xfer_copy(c, (void*)d_keys, hk, n * 8, 0) != 0) rc = -1;
+	tl.lap("walk: keys to the host");
 	if (rc == 0 && ma_refsort_perm(hk, n, hp) != 0) rc = -1;
+	tl.lap("walk: host");
 	if (rc == 0 && xfer_copy(c, d_perm, hp, n * 4, 1) != 0) rc = -1;
+	tl.lap("walk: permutation to the device");
 	free(hk); free(hp);
+	tl.lap("walk: free");
 	if (rc) mahip_set_error("reference_order: copy or host sort failed");
 	return rc;
 }
