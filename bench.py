@@ -168,7 +168,11 @@ class Workload:
         ma._chk(L.mahip_hits_raw_extract(ctx.h, q0, q1, None, C.byref(n_my)), "raw_extract")
         self.n_my = n_my.value
         self.hits_dev = torch.empty(max(self.n_my, 1) * 32, dtype=torch.uint8, device="cuda")
-        ma._chk(L.mahip_hits_raw_extract(ctx.h, q0, q1, C.c_void_p(self.hits_dev.data_ptr()), C.byref(n_my)), "raw_extract")
+        # N > 1: where this rank's records stood in the input -- a rank that only holds its read range needs it to restore the reference's order of tied hits
+        self.pos_dev = torch.empty(max(self.n_my, 1) * 4, dtype=torch.uint8, device="cuda") if world > 1 else None
+        L.mahip_hits_raw_extract_pos.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+        L.mahip_hits_set_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]
+        ma._chk(L.mahip_hits_raw_extract_pos(ctx.h, q0, q1, C.c_void_p(self.hits_dev.data_ptr()), C.c_void_p(self.pos_dev.data_ptr()) if world > 1 else None, C.byref(n_my)), "raw_extract")
         L.mahip_sync(ctx.h)
         self.size = os.path.getsize(paf)
 
@@ -177,6 +181,7 @@ class Workload:
             L.sd_destroy(self.d)
             self.d = None
         self.hits_dev = None
+        self.pos_dev = None
 
 
 def main():
@@ -336,6 +341,8 @@ def main():
             W = self.W
             ma._chk(L.mahip_hits_adopt(self.hctx.h, W.hits_dev.data_ptr(), W.n_my, W.n_seq), "adopt")
             L.mahip_set_hints(self.hctx.h, W.max_qs)
+            if W.pos_dev is not None:
+                ma._chk(L.mahip_hits_set_positions(self.hctx.h, C.c_void_p(W.pos_dev.data_ptr()), 1, W.n_all), "set_positions")
             st = (C.c_uint32 * 4)(0, 0, 0, 0)
             if world == 1:  # single GPU: the C pipeline's device half
                 assert L.ma_pipeline_head(self.hctx.h, C.byref(opt), W.d, b"ug", 100, 0, C.byref(st)) == 0

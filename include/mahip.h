@@ -68,6 +68,15 @@ int mahip_hits_raw_download(mahip_ctx_t *c, ma_hit_t *out);                 /* t
 /* device-to-device: the unsorted records whose query id lies in [q_beg,q_end), in input order, into d_dst (NULL: only count
  * them); *n_out = their number.  Lets a caller keep the records of one read-range shard (bench.py, multi-GPU set-up). */
 int mahip_hits_raw_extract(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end, void *d_dst, size_t *n_out);
+/* the same, and (d_pos != NULL, device) the position each extracted record had in this context's input */
+int mahip_hits_raw_extract_pos(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end, void *d_dst, uint32_t *d_pos, size_t *n_out);
+/* A context that holds only the records of its read range (mahip_set_full_input(c, 0)) can take part in the repair of the reference's HIT order
+ * (hit.c:19-22: an unstable in-place sort -- the order of tied records is a function of the order of ALL records) only if it knows where its records
+ * stood in the whole input: pos[i] < n_total (the records of all ranks), distinct over the ranks, increasing on a rank.  The ranks then put the keys of
+ * the whole input together (two all-gathers, only when the tie census asks for it) and every rank runs the walk.  Copied (host or device array); like
+ * the hints it describes one upload/adopt.  Without positions such a context leaves tied hits in the stable order and reports `unrepaired`. */
+int mahip_hits_set_positions(mahip_ctx_t *c, const uint32_t *pos, int on_device, uint64_t n_total);
+int mahip_hits_have_positions(mahip_ctx_t *c);
 
 /* optional: an upper bound of the query starts (e.g. the longest read) lets the on-demand (qid,qs) sorts (hit dumps, push order
  * of the arcs) plan their digits without a sweep over the records; 0 = unknown */

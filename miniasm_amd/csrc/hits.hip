@@ -859,6 +859,7 @@ static int hits_common_setup(mahip_ctx *c, size_t n, uint32_t n_seq)
 	c->hint_max_qs = 0; // hints describe one upload: set them again after every upload/adopt
 	c->lazy_squeeze = false;
 	c->sorted_here = false; c->hrank_ready = false; c->orank_ready = false;
+	c->n_total = 0; // positions describe one upload, like the hints
 	memset(&c->tie, 0, sizeof(c->tie));
 	CHK(reserve_read_arrays(c));
 	for (int k = 0; k < 8; ++k) CHK(dev_reserve(c, c->col[k], (n + 128) * 4)); // + spare slots (k_hit_sub gather mode: lanes without a slot)
@@ -903,7 +904,16 @@ __global__ __launch_bounds__(256) void k_rec_compact(const ma_hit_t *__restrict_
 	if (i < n && keep[i]) { const uint4 *p = (const uint4*)(h + i); uint4 *o = (uint4*)(out + pos[i]); o[0] = p[0]; o[1] = p[1]; }
 }
 
-extern "C" int mahip_hits_raw_extract(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end, void *d_dst, size_t *n_out)
+__global__ __launch_bounds__(256) void k_rec_positions(size_t n, const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, uint32_t *__restrict__ out)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n && keep[i]) out[pos[i]] = (uint32_t)i;
+}
+
+extern "C" int mahip_hits_raw_extract_pos(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end, void *d_dst, uint32_t *d_pos, size_t *n_out);
+extern "C" int mahip_hits_raw_extract(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end, void *d_dst, size_t *n_out) { return mahip_hits_raw_extract_pos(c, q_beg, q_end, d_dst, nullptr, n_out); }
+// d_pos (optional, device): where each extracted record stood in this context's input -- what mahip_hits_set_positions of the shard's own context wants
+extern "C" int mahip_hits_raw_extract_pos(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end, void *d_dst, uint32_t *d_pos, size_t *n_out)
 {
 	HIPCHK(hipSetDevice(c->dev));
 	const size_t n = c->n_hits;
@@ -915,6 +925,7 @@ extern "C" int mahip_hits_raw_extract(mahip_ctx_t *c, uint32_t q_beg, uint32_t q
 	hipLaunchKernelGGL(k_rec_keep, dim3(grid_for(n, 256)), dim3(256), 0, c->st, c->d_aos, n, q_beg, q_end, P<uint32_t>(c->keep));
 	CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), n, d_tot));
 	if (d_dst) hipLaunchKernelGGL(k_rec_compact, dim3(grid_for(n, 256)), dim3(256), 0, c->st, c->d_aos, n, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (ma_hit_t*)d_dst);
+	if (d_pos) hipLaunchKernelGGL(k_rec_positions, dim3(grid_for(n, 256)), dim3(256), 0, c->st, n, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), d_pos);
 	CHK(ctr_fetch(c));
 	HIPCHK(hipGetLastError());
 	if (n_out) *n_out = (size_t)(c->h_ctr[CT_TOTAL] & 0xffffffffu);
@@ -985,6 +996,24 @@ extern "C" int mahip_set_full_input(mahip_ctx_t *c, int full)
 }
 
 
+// Own-records shards (mahip_set_full_input(c, 0)): where this context's records stood in the whole input.  The reference's hit order is a function of
+// the order of ALL records (hit.c:19-22 sorts them in place with an unstable sort), so a rank that only holds its read range can take part in the tie
+// repair only if it knows these positions: the ranks then put the keys of the whole input together (hits_reference_rank).  pos[i] < n_total, all distinct
+// over the ranks, increasing on a rank (the records keep their input order).  Copied; set again after every upload/adopt.
+extern "C" int mahip_hits_set_positions(mahip_ctx_t *c, const uint32_t *pos, int on_device, uint64_t n_total)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	if (pos == nullptr || n_total == 0) { c->n_total = 0; return 0; }
+	if (n_total >= 0xffffffffull || n_total < c->n_in) { mahip_set_error("mahip_hits_set_positions: n_total out of range"); return -1; }
+	CHK(dev_reserve(c, c->gpos, (c->n_in + 1) * 4));
+	if (c->n_in) HIPCHK(hipMemcpyAsync(c->gpos.p, pos, c->n_in * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->st));
+	if (!on_device) HIPCHK(hipStreamSynchronize(c->st)); // the caller's array may go away
+	c->n_total = n_total;
+	c->hrank_ready = false;
+	return 0;
+}
+extern "C" int mahip_hits_have_positions(mahip_ctx_t *c) { return c->n_total != 0; }
+
 extern "C" int mahip_set_hints(mahip_ctx_t *c, uint32_t max_qs)
 {
 	c->hint_max_qs = max_qs;
@@ -1031,6 +1060,59 @@ __global__ __launch_bounds__(256) void k_hit_rank(const uint32_t *__restrict__ s
 	if (i < n) hrank[i] = inv[sidx[i]];
 }
 
+__global__ __launch_bounds__(256) void k_gkey_scatter(const uint64_t *__restrict__ key, const uint32_t *__restrict__ pos, size_t n, size_t n_total, uint64_t *__restrict__ gkey,
+                                                       unsigned long long *__restrict__ ctr)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) {
+		const uint32_t p = pos[i];
+		if (p < n_total) gkey[p] = key[i]; else atomicAdd(&ctr[CT_OVF2], 1ull);
+	}
+}
+__global__ __launch_bounds__(256) void k_hit_rank_pos(const uint32_t *__restrict__ sidx, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ inv, size_t n, uint32_t *__restrict__ hrank)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) hrank[i] = inv[pos[sidx[i]]];
+}
+
+// Own-records shards: the keys of the WHOLE input, in input order, put together from every rank's (key, position) pairs (two all-gathers padded to the
+// longest rank); then the same walk on every rank, and hrank[slot] = place of the slot's record among all records of the input.
+static int hits_reference_rank_global(mahip_ctx *c)
+{
+	const size_t n = c->n_hits, N = c->n_in, T = (size_t)c->n_total;
+	const int world = mahip_comm_world(c), rank = mahip_comm_rank(c);
+	if (world > 32) { mahip_set_error("hits_reference_rank: at most 32 ranks"); return -1; }
+	uint64_t cnt[32];
+	memset(cnt, 0, sizeof(cnt));
+	cnt[rank] = N;
+	CHK(mahip_comm_all_reduce_sum_u64(c, cnt, (size_t)world));
+	size_t stride = 1, tot = 0;
+	for (int r = 0; r < world; ++r) { if (cnt[r] > stride) stride = cnt[r]; tot += cnt[r]; }
+	if (tot != T) { mahip_set_error("hits_reference_rank: the ranks hold %zu records, mahip_hits_set_positions said %zu", tot, T); return -1; }
+	CHK(dev_reserve(c, c->key[0], (stride + 1) * 8));
+	CHK(dev_reserve(c, c->key[1], (T + 1) * 8));
+	for (int k = 0; k < 2; ++k) CHK(dev_reserve(c, c->val[k], (T + 1) * 4));
+	CHK(dev_reserve(c, c->xb[0], stride * 8 * world + 256));
+	CHK(dev_reserve(c, c->xb[1], stride * 4 * world + 256));
+	if (N) hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(N, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, N, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
+	                          (uint32_t*)nullptr, P<unsigned long long>(c->ctr), 0u, 0xffffffffu, 0, 1); // key = qid<<32 | qs, input order
+	CHK(mahip_comm_all_gather(c, c->key[0].p, c->xb[0].p, stride * 8));
+	if (N) HIPCHK(hipMemcpyAsync(c->val[1].p, c->gpos.p, N * 4, hipMemcpyDeviceToDevice, c->st)); // (a send slot as long as the longest rank's)
+	CHK(mahip_comm_all_gather(c, c->val[1].p, c->xb[1].p, stride * 4));
+	CHK(ctr_zero(c));
+	for (int r = 0; r < world; ++r)
+		if (cnt[r]) hipLaunchKernelGGL(k_gkey_scatter, dim3(grid_for(cnt[r], 256)), dim3(256), 0, c->st, (const uint64_t*)c->xb[0].p + (size_t)r * stride,
+		                               (const uint32_t*)c->xb[1].p + (size_t)r * stride, (size_t)cnt[r], T, P<uint64_t>(c->key[1]), P<unsigned long long>(c->ctr));
+	CHK(ctr_fetch(c));
+	if (c->h_ctr[CT_OVF2]) { mahip_set_error("hits_reference_rank: %llu record positions are not below the number of records", (unsigned long long)c->h_ctr[CT_OVF2]); return -1; }
+	CHK(reference_order(c, P<uint64_t>(c->key[1]), T, P<uint32_t>(c->val[1])));
+	hipLaunchKernelGGL(k_perm_invert, dim3(grid_for(T, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->val[1]), T, P<uint32_t>(c->val[0]));
+	if (n) hipLaunchKernelGGL(k_hit_rank_pos, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->sidx), (const uint32_t*)P<uint32_t>(c->gpos),
+	                          (const uint32_t*)P<uint32_t>(c->val[0]), n, P<uint32_t>(c->hrank));
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
 // c->hrank[slot] = position of the slot's record in the order the reference's ma_hit_sort (hit.c:19-22) leaves the input in.
 // Both orders are sorted by key, so hrank is the identity outside runs of equal keys.
 int hits_reference_rank(mahip_ctx *c)
@@ -1038,7 +1120,14 @@ int hits_reference_rank(mahip_ctx *c)
 	if (c->hrank_ready) return 0;
 	const size_t n = c->n_hits, N = c->n_in; // slots of this context / records of the input
 	if (!c->sorted_here || !c->sidx.p || !c->d_aos) { mahip_set_error("hits_reference_rank: the hits were not sorted by this context"); return -1; }
-	if (ctx_sharded(c) && !c->full_input) { mahip_set_error("hits_reference_rank: the reference's tie order is a function of the whole input; this context only holds a shard of it"); return -1; }
+	if (ctx_sharded(c) && !c->full_input) {
+		if (c->n_total == 0 || !c->comm) { mahip_set_error("hits_reference_rank: the reference's tie order is a function of the whole input; this context only holds a shard of it (and no positions: mahip_hits_set_positions)"); return -1; }
+		CHK(dev_reserve(c, c->hrank, (n + 1) * 4));
+		CHK(hits_reference_rank_global(c)); // collective: every rank gets here together (host/sharded.c decides on all-reduced counters)
+		c->hrank_ready = true;
+		c->tie.hit_walk = 1;
+		return 0;
+	}
 	CHK(dev_reserve(c, c->hrank, (n + 1) * 4));
 	if (n == 0) { c->hrank_ready = true; return 0; }
 	// the walk runs over ALL input records (on a shard: every rank repeats it and keeps the ranks of its own slots; sidx holds global positions)

@@ -36,6 +36,8 @@ struct mahip_ctx {
 	size_t n_hits = 0;        // slots (live + dead)
 	size_t n_in = 0;          // records at d_aos (= n_hits unless a shard range dropped some at the sort)
 	bool full_input = true;   // d_aos holds the WHOLE input (false: the caller handed over this rank's records only)
+	DevBuf gpos;              // u32 [n_in] own-records shards: position of each of this context's records in the whole input (mahip_hits_set_positions)
+	uint64_t n_total = 0;     //   records of the whole input; 0 = no positions known
 	size_t n_live = 0;
 	uint32_t n_seq = 0;       // reads, original numbering
 	uint32_t q_beg = 0, q_end = 0xffffffffu; // shard

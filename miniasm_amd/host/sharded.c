@@ -150,13 +150,15 @@ int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq
 		mahip_tie_stats(c, &ti);
 		st->tie_groups = ti.arc_tie_groups;
 		if (ti.unrepaired) {
-			uint64_t conf = 0;
+			uint64_t conf = 0, two[2];
 			GPU(mahip_sg_push_conflicts(c, &conf));
-			GPU(mahip_comm_all_reduce_sum_u64(c, &conf, 1));
+			two[0] = conf; two[1] = mahip_hits_have_positions(c) ? 1 : 0;
+			GPU(mahip_comm_all_reduce_sum_u64(c, two, 2));
+			conf = two[0];
 			st->push_conflicts = conf;
-			if (conf == 0 || full_input || world == 1) {
+			if (conf == 0 || full_input || world == 1 || two[1] == (uint64_t)world) { /* own-records shards: only when EVERY rank knows where its records stood in the input */
 				void *rows, *all;
-				if (conf) GPU(mahip_sg_push_fix(c)); /* every rank walks the hit keys of the whole input and keeps the ranks of its own hits */
+				if (conf) GPU(mahip_sg_push_fix(c)); /* every rank walks the hit keys of the whole input (own-records shards: gathered from all ranks) and keeps the ranks of its own hits */
 				GPU(mahip_xbuf(c, 0, stride * 16, &rows));
 				GPU(mahip_xbuf(c, 1, stride * 16 * world, &all));
 				GPU(mahip_asg_export_rows_push(c, rows));

@@ -36,7 +36,9 @@ def main():
         q0, q1 = bounds[rank], bounds[rank + 1]
         assert bounds[0] == 0 and bounds[world] == n_seq and all(bounds[r] <= bounds[r + 1] for r in range(world))
     qid = (ing.hits["qns"] >> np.uint64(32)).astype(np.int64)
-    mine = np.ascontiguousarray(ing.hits[(qid >= q0) & (qid < q1)])  # this rank's records, input order kept
+    sel = (qid >= q0) & (qid < q1)
+    mine = np.ascontiguousarray(ing.hits[sel])  # this rank's records, input order kept
+    pos = np.ascontiguousarray(np.nonzero(sel)[0].astype(np.uint32)) if os.environ.get("MA_WORKER_POS") == "1" else None  # ... and where they stood
 
     ShardStats = ma.ShardStats
     L.ma_pipeline_head_sharded.restype = C.c_int
@@ -55,8 +57,13 @@ def main():
     outs = []
     for step in range(3):
         ctx.hits_upload(mine, n_seq)
+        if pos is not None:  # positions describe one upload: with them the ranks can restore the reference's order of tied hits (mahip_hits_set_positions)
+            L.mahip_hits_set_positions.argtypes = [vp, C.c_void_p, C.c_int, C.c_uint64]
+            ma._chk(L.mahip_hits_set_positions(ctx.h, pos.ctypes.data, 0, len(ing.hits)), "set_positions")
         stats = ShardStats()
         assert L.ma_pipeline_head_sharded(ctx.h, C.byref(opt), n_seq, 0, C.byref(stats)) == 0
+        if pos is not None:
+            assert stats.tie_groups == 0 or stats.tie_repaired == 1, "tie groups left unrepaired although every rank knows its positions"
         if rank != 0:
             continue
         st = (C.c_uint32 * 4)(1, 1, stats.n_red, 1)

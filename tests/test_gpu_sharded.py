@@ -197,6 +197,36 @@ def test_ranks_that_hold_only_their_own_records(world, tail_ctx, tmpdir_s, monke
             assert data[3:] == R.run_cli(R.REF_BIN, [], paf)[0]
 
 
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_with_their_own_records_restore_the_reference_tie_order(world, tmpdir_s):
+    """own-records shards on a tie-rich input: each rank knows where its records stood in the input (mahip_hits_set_positions), the ranks put the hit keys
+    of the whole input together, every rank runs the walk (hit.c:19-22 is a function of ALL records) and orders its own pushed arcs by it; the GFA of every
+    step is the reference's, byte for byte -- without positions the same run reports the groups as unrepaired"""
+    import subprocess
+    import sys
+    paf = R.pafgen(os.path.join(tmpdir_s, "own_ties_%d.paf" % world), 3000, 80000, 5, ["-q", "16", "-L", "uniform", "-d", "0.3", "-x", "0.03"])
+    ref_sg, _ = R.run_cli(R.REF_BIN, ["-p", "sg", "-S5"], paf)
+    assert R.arc_tie_groups(ref_sg) >= 5
+    out = os.path.join(tmpdir_s, "own_ties_%d.out" % world)
+    env = dict(os.environ, MA_WORKER_EMU="1" if getattr(ma, "IS_EMU", False) else "0", MA_WORKER_BALANCE="1" if world == 3 else "0", MA_WORKER_POS="1")
+    env.pop("MA_GPUS", None)
+    name = "ma_ownt_%d_%d" % (os.getpid(), world)
+    procs = [subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "shard_step_worker.py"), paf, str(r), str(world), name, "0", out],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(world)]
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, err.decode()[-2000:]
+    data = open(out, "rb").read()
+    assert data.startswith(b"OK\n"), "a step's GFA differs from the single-context run"
+    assert data[3:] == R.run_cli(R.REF_BIN, [], paf)[0]
+
+
 @pytest.mark.parametrize("who", ["one_gpu", "child", "parent"])
 def test_cli_on_n_ranks_never_leaves_a_rank_waiting(who, tmpdir_s):
     """no rank is ever left waiting: a request the sharded head does not serve (hit dumps, early -S stages, -1 / -2) is decided before the ranks
