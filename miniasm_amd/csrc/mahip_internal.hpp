@@ -89,6 +89,7 @@ struct mahip_ctx {
 
 	// ---- scratch ----
 	DevBuf keep, pos;         // u32 flags / scanned positions
+	DevBuf tdig;              // u8 [n] tie walk: the keys' top digit when it does not fit into the packed element (radix.hip: reference_order)
 	DevBuf key[2], val[2];    // radix sort ping-pong
 	DevBuf hist;              // radix block histograms
 	DevBuf scan_tmp[3];       // scan levels
@@ -161,7 +162,7 @@ int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen, bool first
 void radix_first_digit(int lo, int hi, int *shift, int *bits, unsigned *tile);
 int radix_reserve_hist(mahip_ctx *c, size_t n);
 // the permutation the reference's (unstable) sort applies to d_keys[0..n) (input order), written to d_perm
-int reference_order(mahip_ctx *c, const uint64_t *d_keys, size_t n, uint32_t *d_perm);
+int reference_order(mahip_ctx *c, uint64_t *d_keys /* overwritten */, size_t n, uint32_t *d_perm);
 // position of every hit slot in the reference's order -> c->hrank (hits.hip)
 int hits_reference_rank(mahip_ctx *c);
 // bits of the largest query start of the input records

@@ -214,26 +214,94 @@ int radix_reserve_hist(mahip_ctx *c, size_t n)
 }
 
 // ---- exact-tie mode (include/mahip.h: mahip_set_exact_ties) ----
-// The order the reference's in-place MSD radix sort gives to equal keys is a sequential function of the whole
-// input; the host computes it from the keys (host/refsort.c) and the device gathers through the permutation.
+// The order the reference's in-place MSD radix sort gives to equal keys is a sequential function of the whole input: the host walks it
+// (host/refsort.c) on 8-byte elements -- the key squeezed to the bits it has, above the record's input position -- that the DEVICE packs on the
+// way out and takes apart on the way back: one 8-byte array travels each way and the host allocates nothing but that array (until round 3 the
+// raw keys went down, the host looked for their bounds, packed, sorted, unpacked, and a 4-byte permutation went up: at BASELINE configs[4] 0.4 s of
+// packing, 0.2 s of unpacking and 20 GB of freshly faulted host memory around a 3 s walk).
 extern "C" int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm);
+extern "C" int ma_refsort_packed(uint64_t *pk, size_t n, int bl, int bi, int shift_top, const uint8_t *dig_top);
 
-int reference_order(mahip_ctx *c, const uint64_t *d_keys, size_t n, uint32_t *d_perm)
+__global__ __launch_bounds__(256) void k_key_bounds(const uint64_t *__restrict__ key, size_t n, unsigned long long *__restrict__ ctr)
+{
+	uint32_t mh = 0, ml = 0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+		const uint64_t k = key[i];
+		const uint32_t h = (uint32_t)(k >> 32), l = (uint32_t)k;
+		mh = h > mh ? h : mh; ml = l > ml ? l : ml;
+	}
+	blk_max_u64(&ctr[CT_MAXQID], mh);
+	blk_max_u64(&ctr[CT_MAXQS], ml);
+}
+// in place: key[i] -> (hi & himask) << bl | lo) << bi | i; dig (optional): the key's digit at shift_top, which the packed element no longer holds
+__global__ __launch_bounds__(256) void k_pack_keys(uint64_t *__restrict__ key, size_t n, int bl, int bi, uint64_t himask, int shift_top, uint8_t *__restrict__ dig)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) {
+		const uint64_t k = key[i];
+		key[i] = ((((k >> 32) & himask) << bl) | (k & 0xffffffffull)) << bi | (uint64_t)i;
+		if (dig) dig[i] = (uint8_t)(k >> shift_top);
+	}
+}
+__global__ __launch_bounds__(256) void k_perm_from_packed(const uint64_t *__restrict__ pk, size_t n, uint64_t mask, uint32_t *__restrict__ perm)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) perm[i] = (uint32_t)(pk[i] & mask);
+}
+
+static int bitlen64(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
+
+// d_perm[j] <- input position of the j-th record in the reference's order.  d_keys is overwritten.
+int reference_order(mahip_ctx *c, uint64_t *d_keys, size_t n, uint32_t *d_perm)
 {
 	if (n == 0) return 0;
 	TieLaps tl(c);
-	uint64_t *hk = (uint64_t*)malloc(n * 8);
-	uint32_t *hp = (uint32_t*)malloc(n * 4);
-	if (!hk || !hp) { free(hk); free(hp); mahip_set_error("reference_order: out of host memory"); return -1; }
+	unsigned long long *ctr = P<unsigned long long>(c->ctr);
+	HIPCHK(hipMemsetAsync(ctr + CT_MAXQID, 0, 16, c->st)); // (CT_MAXQID, CT_MAXQS: adjacent)
+	hipLaunchKernelGGL(k_key_bounds, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)d_keys, n, ctr);
+	CHK(ctr_fetch(c));
+	int bh = bitlen64(c->h_ctr[CT_MAXQID]), bl = bitlen64(c->h_ctr[CT_MAXQS]), bi = bitlen64(n - 1), shift_top = -1;
+	if (bh == 0) bh = 1;
+	if (bl == 0) bl = 1;
+	if (bi == 0) bi = 1;
+	uint64_t himask = 0xffffffffull;
+	const bool force_apart = getenv("MA_REFSORT_TOP_APART") != nullptr; // tests: the wide-key form on inputs of any size
+	bool packed = !force_apart && bh + bl + bi <= 64;
+	if (!packed && (n > (1u << 17) || (force_apart && n > 64))) { // too wide for one word: without the top level's digit (it goes down as a byte array of its own) if the rest fits
+		shift_top = (32 + bh - 1) & ~7;
+		if ((shift_top - 32) + bl + bi <= 64) { packed = true; himask = shift_top > 32 ? (1ull << (shift_top - 32)) - 1 : 0; }
+		else shift_top = -1;
+	}
 	int rc = 0;
-	if (xfer_copy(c, (void*)d_keys, hk, n * 8, 0) != 0) rc = -1;
-	tl.lap("walk: keys to the host");
-	if (rc == 0 && ma_refsort_perm(hk, n, hp) != 0) rc = -1;
-	tl.lap("walk: host");
-	if (rc == 0 && xfer_copy(c, d_perm, hp, n * 4, 1) != 0) rc = -1;
-	tl.lap("walk: permutation to the device");
-	free(hk); free(hp);
-	tl.lap("walk: free");
+	if (packed && !getenv("MA_REFSORT_KEYS")) {
+		uint64_t *hk = (uint64_t*)malloc(n * 8);
+		uint8_t *hd = shift_top >= 0 ? (uint8_t*)malloc(n + 16) : nullptr;
+		if (!hk || (shift_top >= 0 && !hd)) { free(hk); free(hd); mahip_set_error("reference_order: out of host memory"); return -1; }
+		if (shift_top >= 0) CHK(dev_reserve(c, c->tdig, n + 16));
+		hipLaunchKernelGGL(k_pack_keys, dim3(grid_for(n, 256)), dim3(256), 0, c->st, d_keys, n, bl, bi, himask, shift_top, shift_top >= 0 ? P<uint8_t>(c->tdig) : (uint8_t*)nullptr);
+		if (xfer_copy(c, d_keys, hk, n * 8, 0) != 0) rc = -1;
+		if (rc == 0 && hd) { if (xfer_copy(c, c->tdig.p, hd, n, 0) != 0) rc = -1; memset(hd + n, 0, 16); }
+		tl.lap("walk: packed keys to the host");
+		if (rc == 0 && ma_refsort_packed(hk, n, bl, bi, shift_top, hd) != 0) rc = -1;
+		tl.lap("walk: host");
+		if (rc == 0 && xfer_copy(c, d_keys, hk, n * 8, 1) != 0) rc = -1;
+		if (rc == 0) hipLaunchKernelGGL(k_perm_from_packed, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint64_t*)d_keys, n, bi >= 64 ? ~0ull : (1ull << bi) - 1, d_perm);
+		tl.lap("walk: order to the device");
+		free(hk); free(hd);
+		tl.lap("walk: free");
+	} else { // keys too wide (or MA_REFSORT_KEYS, for the tests): the raw keys go down, the host packs what it can
+		uint64_t *hk = (uint64_t*)malloc(n * 8);
+		uint32_t *hp = (uint32_t*)malloc(n * 4);
+		if (!hk || !hp) { free(hk); free(hp); mahip_set_error("reference_order: out of host memory"); return -1; }
+		if (xfer_copy(c, d_keys, hk, n * 8, 0) != 0) rc = -1;
+		tl.lap("walk: keys to the host");
+		if (rc == 0 && ma_refsort_perm(hk, n, hp) != 0) rc = -1;
+		tl.lap("walk: host");
+		if (rc == 0 && xfer_copy(c, d_perm, hp, n * 4, 1) != 0) rc = -1;
+		tl.lap("walk: permutation to the device");
+		free(hk); free(hp);
+	}
+	HIPCHK(hipGetLastError());
 	if (rc) mahip_set_error("reference_order: copy or host sort failed");
 	return rc;
 }

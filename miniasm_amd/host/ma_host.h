@@ -73,6 +73,7 @@ void ma_refsort_arcs(asg_arc_t *beg, asg_arc_t *end);
 typedef struct { uint64_t key; uint32_t idx, pad; } ma_ki_t;
 void ma_refsort_ki(ma_ki_t *a, size_t n, int n_threads);
 int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm); /* perm[i] = input position of the i-th record in reference order */
+int ma_refsort_packed(uint64_t *pk, size_t n, int bl, int bi, int shift_top, const uint8_t *dig_top); /* the same on elements the caller packed (key above input position), in place */
 
 #ifdef __cplusplus
 }

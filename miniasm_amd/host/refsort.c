@@ -175,6 +175,7 @@ static void *fill_worker(void *arg)
 			f->pk[i] = (((k >> 32) & f->himask) << f->cfg.bl | (k & 0xffffffffull)) << f->cfg.bi | i;
 		}
 	}
+	else if (f->phase == 7) { memset(f->cnt, 0, sizeof(f->cnt)); for (i = f->beg; i < f->end; ++i) ++f->cnt[f->dig[i]]; }
 	else { const uint64_t im = f->cfg.bi >= 64 ? ~0ull : (1ull << f->cfg.bi) - 1; for (i = f->beg; i < f->end; ++i) f->perm[i] = (uint32_t)(f->pk[i] & im); }
 	return 0;
 }
@@ -195,7 +196,7 @@ static void fill_run(fill_t *proto, size_t n, int phase, int n_threads)
 	for (t = 1; t < n_threads; ++t) pthread_join(th[t], 0);
 	if (phase == 0) { proto->mhi = proto->mlo = 0; for (t = 0; t < n_threads; ++t) { if (f[t].mhi > proto->mhi) proto->mhi = f[t].mhi; if (f[t].mlo > proto->mlo) proto->mlo = f[t].mlo; } }
 	if (phase == 5) { proto->diff = 0; for (t = 0; t < n_threads; ++t) proto->diff |= f[t].diff; }
-	if (phase == 6) { int k; memset(proto->cnt, 0, sizeof(proto->cnt)); for (t = 0; t < n_threads; ++t) for (k = 0; k < 256; ++k) proto->cnt[k] += f[t].cnt[k]; }
+	if (phase == 6 || phase == 7) { int k; memset(proto->cnt, 0, sizeof(proto->cnt)); for (t = 0; t < n_threads; ++t) for (k = 0; k < 256; ++k) proto->cnt[k] += f[t].cnt[k]; }
 }
 
 static int bits_of64(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
@@ -266,5 +267,40 @@ int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm)
 	ma_refsort_ki(f.a, n, nt);
 	fill_run(&f, n, 2, nt);
 	free(f.a);
+	return 0;
+}
+
+/* The same sort on elements the CALLER packed (the device does it on the way out, csrc/radix.hip): pk[i] = (hi << bl | lo) << bi | i, with hi = the key's high
+ * word, lo its low word (lo < 2^bl), i < 2^bi the input position; sorted in place, so that afterwards pk[j] & (2^bi - 1) is the input position of the j-th
+ * record in the reference's order.  shift_top >= 32: keys too wide for that -- hi is stored WITHOUT its bits at and above (shift_top - 32), dig_top[i] (n + 16
+ * bytes, the last 16 zero) is the key's digit at shift_top, which is the first level that can move anything (every key is < 2^(shift_top + 8)); the caller
+ * guarantees (shift_top - 32) + bl + bi <= 64.  shift_top < 0: the whole key is in the word (bits of hi + bl + bi <= 64). */
+int ma_refsort_packed(uint64_t *pk, size_t n, int bl, int bi, int shift_top, const uint8_t *dig_top)
+{
+	const int nt = refsort_threads();
+	rs_cfg_t cfg;
+	if (n < 2) return 0;
+	if (bl < 1 || bl > 32 || bi < 1 || bi > 32) return -1;
+	cfg.bi = bi; cfg.bl = bl; cfg.lomask = (1ull << bl) - 1;
+	{
+		RS_T0;
+		if (shift_top < 0) packed_sort(pk, n, &cfg, nt);
+		else {
+			fill_t f;
+			if (shift_top < 32 || (shift_top & 7) || (shift_top - 32) + bl + bi > 64 || dig_top == 0 || n <= RS_SMALL) return -1; /* (<= 64 records: ksort.h:182 sorts by insertion -- the caller uses ma_refsort_perm) */
+			if (nt > 1 && n >= (1u << 17)) {
+				memset(&f, 0, sizeof(f));
+				f.dig = (uint8_t*)dig_top;
+				fill_run(&f, n, 7, nt); /* the counts of the top level's digits */
+				packed_sort_from_top(pk, n, &cfg, nt, f.cnt, dig_top, shift_top);
+			} else { /* small: one thread does everything; the top level from its digit array like any other */
+				size_t cnt[256], i;
+				memset(cnt, 0, sizeof(cnt));
+				for (i = 0; i < n; ++i) ++cnt[dig_top[i]];
+				packed_sort_from_top(pk, n, &cfg, 1, cnt, dig_top, shift_top);
+			}
+		}
+		RS_LAP("sort");
+	}
 	return 0;
 }

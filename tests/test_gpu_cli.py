@@ -193,6 +193,21 @@ def test_tie_rich_input_is_byte_identical(name, mode, tmpdir_s, monkeypatch):
 
 
 @pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("form", ["MA_REFSORT_TOP_APART", "MA_REFSORT_KEYS"])
+def test_tie_walk_transport_forms(form, tmpdir_s, monkeypatch):
+    """how the keys travel to the host walk and back (csrc/radix.hip: reference_order): packed on the device into one word (the default, covered by every
+    tie test), packed WITHOUT the digit of the top level, which goes down as a byte array (keys too wide for a word: BASELINE configs[4]; forced here), or
+    as raw keys that the host packs (wider still).  Same bytes as the reference in every form, hit dump included."""
+    monkeypatch.setenv(form, "1")
+    cfg = TIE_INPUTS["short_reads"] if "short_reads" in TIE_INPUTS else list(TIE_INPUTS.values())[0]
+    paf = R.pafgen(os.path.join(tmpdir_s, "tie_form.paf"), cfg["reads"], cfg["lines"], cfg["seed"], cfg["extra"])
+    for args in ([], ["-p", "paf"], ["-p", "sg", "-S5"]):
+        ref_out, _ = R.run_cli(R.REF_BIN, args, paf)
+        out, _ = R.run_cli(ma.CLI_PATH, args, paf)
+        assert out == ref_out, "%s=1, cli %s: bytes differ from the reference" % (form, " ".join(args))
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
 def test_tie_census_and_walks_are_reported(tmpdir_s):
     """the C ABI reports what the automatic mode found and did (mahip_tie_stats): tie groups -> arc walk (and the hit walk
     only when two arcs were pushed from hits with equal keys); a tie-free input -> nothing to do"""

@@ -221,6 +221,28 @@ def test_refsort_emulation_matches_reference_on_ties():
         assert res[0] == res[1], "tie order differs for n=%d" % n
 
 
+def packed_order(LP, keys):
+    """the order through ma_refsort_packed -- elements packed by the caller the way the device does it (csrc/radix.hip: k_pack_keys); None: keys too wide"""
+    n = len(keys)
+    LP.ma_refsort_packed.restype = C.c_int
+    LP.ma_refsort_packed.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    hi, lo = keys >> np.uint64(32), keys & np.uint64(0xffffffff)
+    bh, bl, bi = max(int(hi.max()).bit_length(), 1), max(int(lo.max()).bit_length(), 1), max((n - 1).bit_length(), 1)
+    idx = np.arange(n, dtype=np.uint64)
+    if bh + bl + bi <= 64:
+        pk = np.ascontiguousarray(((hi << np.uint64(bl) | lo) << np.uint64(bi)) | idx)
+        assert LP.ma_refsort_packed(pk.ctypes.data, n, bl, bi, -1, None) == 0
+    else:
+        st = (32 + bh - 1) & ~7
+        if (st - 32) + bl + bi > 64 or n <= 64:
+            return None
+        pk = np.ascontiguousarray((((hi & np.uint64((1 << (st - 32)) - 1)) << np.uint64(bl) | lo) << np.uint64(bi)) | idx)
+        dig = np.zeros(n + 16, dtype=np.uint8)
+        dig[:n] = ((keys >> np.uint64(st)) & np.uint64(0xff)).astype(np.uint8)
+        assert LP.ma_refsort_packed(pk.ctypes.data, n, bl, bi, st, dig.ctypes.data) == 0
+    return (pk & np.uint64((1 << bi) - 1)).astype(np.uint32)
+
+
 @needs_ref
 @pytest.mark.parametrize("threads", ["1", "8"])
 def test_refsort_perm_matches_reference_sort(threads, monkeypatch):
@@ -245,6 +267,8 @@ def test_refsort_perm_matches_reference_sort(threads, monkeypatch):
         LR.radix_sort_hit(ref.ctypes.data, ref.ctypes.data + n * 32)
         assert (np.diff(ref["qns"].astype(np.int64)) >= 0).all()
         assert hits[perm].tobytes() == ref.tobytes(), "hit order differs for n=%d" % n
+        pp = packed_order(LP, keys)
+        assert pp is not None and (pp == perm).all(), "caller-packed elements: different order for n=%d" % n
     # the shape of a PAF file: keys that are almost sorted already (a query's overlaps are listed together, the mirrored records point at reads
     # nearby): the top-level walk (host/refsort_body.h: permute_top) then runs over long stretches of elements that are already home -- identity at
     # the bucket it works on, shifted by one everywhere else, recorded as segments when long
@@ -264,6 +288,8 @@ def test_refsort_perm_matches_reference_sort(threads, monkeypatch):
         ref = hits.copy()
         LR.radix_sort_hit(ref.ctypes.data, ref.ctypes.data + n * 32)
         assert hits[perm].tobytes() == ref.tobytes(), "hit order differs for the nearly sorted input n=%d per=%d spread=%d" % (n, per, spread)
+        pp = packed_order(LP, keys)
+        assert pp is not None and (pp == perm).all(), "caller-packed elements: different order for the nearly sorted input n=%d" % n
     # keys + index too wide for one 64-bit element (BASELINE configs[4]: 23 + 14 + 30 bits): packed without the top level's digit when the rest fits
     # (30 id bits: top byte = id >> 24, 24 + 20 + 19 bits travel), the 16-byte elements when it does not (32 + 32 + 19)
     for n, hi_bits, lo_bits, n_hi in ((300000, 30, 20, 5000), (300000, 30, 20, 40), (400000, 32, 32, 3000)):
@@ -277,6 +303,8 @@ def test_refsort_perm_matches_reference_sort(threads, monkeypatch):
         ref = hits.copy()
         LR.radix_sort_hit(ref.ctypes.data, ref.ctypes.data + n * 32)
         assert hits[perm].tobytes() == ref.tobytes(), "hit order differs for wide keys (%d id bits, %d start bits)" % (hi_bits, lo_bits)
+        pp = packed_order(LP, keys)
+        assert (pp is None) == (hi_bits == 32) and (pp is None or (pp == perm).all()), "caller-packed wide keys (%d id bits): different order" % hi_bits
     LR.asg_arc_sort.argtypes = [C.POINTER(ma.Asg)]
     for n, nu, nl in ((300, 8, 6), (400000, 5000, 12), (600000, 400000, 3)):
         arcs = np.zeros(n, dtype=ma.ARC_DT)
@@ -290,6 +318,8 @@ def test_refsort_perm_matches_reference_sort(threads, monkeypatch):
         g.arc, g.n_arc_srt, g.m_arc = ref.ctypes.data, n, n
         LR.asg_arc_sort(C.byref(g))
         assert arcs[perm].tobytes() == ref.tobytes(), "arc order differs for n=%d" % n
+        pp = packed_order(LP, keys)
+        assert pp is not None and (pp == perm).all(), "caller-packed arc keys: different order for n=%d" % n
 
 
 @needs_ref
