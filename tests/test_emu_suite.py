@@ -76,7 +76,7 @@ def test_cli_suite_on_cpu(emu_built):
 def test_sharded_suite_on_cpu(emu_built):
     """tests/test_gpu_sharded.py: `MA_GPUS=N miniasm` -- host/sharded.c, N forked ranks over the shared-memory double of the collectives --
     against the single-rank run and the reference binary (tie-rich input included).  The torch-driven virtual-rank test needs a real device."""
-    sel = "not rccl and not virtual_ranks" + ("" if FULL else " and (2-lognormal or 3-noisy or tie_order or hold_only or never_leaves)")
+    sel = "not rccl and not virtual_ranks" + ("" if FULL else " and (2-lognormal or 3-noisy or tie_order or hold_only or their_own_records or never_leaves)")
     run_gpu_tests(["tests/test_gpu_sharded.py", "-k", sel], 5000)
 
 
