@@ -251,6 +251,25 @@ __global__ __launch_bounds__(256) void k_perm_from_packed(const uint64_t *__rest
 
 static int bitlen64(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
 
+// The walk's array: gigabytes that are written once by the copy, walked along up to 256 heads and dropped.  On 4 KB pages that is a page fault per page on the
+// way in, a TLB miss at every head and a long munmap on the way out; MA_HOST_THP=1 asks for transparent huge pages (measured per round, profiles/).
+#include <sys/mman.h>
+struct BigHost {
+	void *p = nullptr; size_t bytes = 0; bool mapped = false;
+	bool get(size_t n) {
+		static int thp = -1;
+		if (thp < 0) { const char *s = getenv("MA_HOST_THP"); thp = s && atoi(s) != 0; }
+		if (thp && n >= ((size_t)64 << 20)) {
+			bytes = (n + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+			void *q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+			if (q != MAP_FAILED) { (void)madvise(q, bytes, MADV_HUGEPAGE); p = q; mapped = true; return true; }
+		}
+		p = malloc(n); bytes = n; mapped = false;
+		return p != nullptr;
+	}
+	void drop() { if (p) { if (mapped) munmap(p, bytes); else free(p); } p = nullptr; }
+};
+
 // d_perm[j] <- input position of the j-th record in the reference's order.  d_keys is overwritten.
 int reference_order(mahip_ctx *c, uint64_t *d_keys, size_t n, uint32_t *d_perm)
 {
@@ -274,9 +293,10 @@ int reference_order(mahip_ctx *c, uint64_t *d_keys, size_t n, uint32_t *d_perm)
 	}
 	int rc = 0;
 	if (packed && !getenv("MA_REFSORT_KEYS")) {
-		uint64_t *hk = (uint64_t*)malloc(n * 8);
-		uint8_t *hd = shift_top >= 0 ? (uint8_t*)malloc(n + 16) : nullptr;
-		if (!hk || (shift_top >= 0 && !hd)) { free(hk); free(hd); mahip_set_error("reference_order: out of host memory"); return -1; }
+		BigHost bk, bd;
+		if (!bk.get(n * 8) || (shift_top >= 0 && !bd.get(n + 16))) { bk.drop(); bd.drop(); mahip_set_error("reference_order: out of host memory"); return -1; }
+		uint64_t *hk = (uint64_t*)bk.p;
+		uint8_t *hd = (uint8_t*)bd.p;
 		if (shift_top >= 0) CHK(dev_reserve(c, c->tdig, n + 16));
 		hipLaunchKernelGGL(k_pack_keys, dim3(grid_for(n, 256)), dim3(256), 0, c->st, d_keys, n, bl, bi, himask, shift_top, shift_top >= 0 ? P<uint8_t>(c->tdig) : (uint8_t*)nullptr);
 		if (xfer_copy(c, d_keys, hk, n * 8, 0) != 0) rc = -1;
@@ -287,7 +307,7 @@ int reference_order(mahip_ctx *c, uint64_t *d_keys, size_t n, uint32_t *d_perm)
 		if (rc == 0 && xfer_copy(c, d_keys, hk, n * 8, 1) != 0) rc = -1;
 		if (rc == 0) hipLaunchKernelGGL(k_perm_from_packed, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint64_t*)d_keys, n, bi >= 64 ? ~0ull : (1ull << bi) - 1, d_perm);
 		tl.lap("walk: order to the device");
-		free(hk); free(hd);
+		bk.drop(); bd.drop();
 		tl.lap("walk: free");
 	} else { // keys too wide (or MA_REFSORT_KEYS, for the tests): the raw keys go down, the host packs what it can
 		uint64_t *hk = (uint64_t*)malloc(n * 8);

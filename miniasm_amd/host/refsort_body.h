@@ -95,7 +95,7 @@ static void RS_NAME(permute_top)(rs_pool_t *pool, RS_T *a, const size_t *cnt, co
 		const size_t n = start[256], step = n / 4096 + 1;
 		size_t p, home = 0, seen = 0;
 		for (p = 0, k = 0; p < n; p += step, ++seen) { while (start[k + 1] <= p) ++k; home += dig[p] == (unsigned)k; }
-		if (home * 2 < seen) { RS_NAME(permute_uniform)(a, start, dig, 0, 255); RS_NAME(dispatch)(pool, a, start, shift); return; }
+		if (home * 2 < seen && !rs_literal_top()) { RS_NAME(permute_uniform)(a, start, dig, 0, 255); RS_NAME(dispatch)(pool, a, start, shift); return; }
 	}
 	for (k = 0; k < 256; ++k) b[k].head = start[k], b[k].nd = dig[start[k]], b[k].pad = 0;
 	for (k = 0; k < 256;) {

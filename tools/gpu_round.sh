@@ -46,6 +46,25 @@ tiewalk)
     grep -E "T::refsort|T::ties|T::head\\] sg_gen|Real time|T::xfer.*HBM->host" gpurun_out/tiewalk5.log | head -40
     echo "(reference md5 of this input, profiles/r03_e2e_cfg5_500M.txt: fa9c76984d44526d1a9a9e70132d01da)"
   fi ;;
+tiewalk2)
+  # A/B on one box: the top-level walk in its two forms, the walk's array on huge pages or not (50 M noisy; TIEWALK_CFG5=1: BASELINE configs[4], default and THP)
+  miniasm_amd/bin/pafgen -r 1000000 -n 50000000 -s 3 -L uniform -d 0.35 -x 0.03 -o /tmp/tw50.paf 2>/dev/null
+  for v in "" "MA_REFSORT_LITERAL_TOP=1" "MA_HOST_THP=1" ""; do
+    echo "## 50 M noisy [${v:-default}]"
+    env $v MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm /tmp/tw50.paf 2> gpurun_out/tiewalk50_ab.log | md5sum
+    grep -E "top walk|buckets|walk: (packed|order|free|host)|T::head\] sg_gen|Real time" gpurun_out/tiewalk50_ab.log | head -8
+  done
+  if [ -n "$TIEWALK_CFG5" ]; then
+    miniasm_amd/bin/pafgen -r 5000000 -n 500000000 -s 3 -L uniform -d 0.35 -x 0.03 -o /tmp/tw5.paf 2>/dev/null
+    for v in "" "MA_HOST_THP=1"; do
+      echo "## BASELINE configs[4] [${v:-default}]"
+      env $v MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 900 miniasm_amd/bin/miniasm /tmp/tw5.paf 2> gpurun_out/tiewalk5_ab.log | md5sum
+      grep -E "top walk|buckets|walk: (packed|order|free|host)|T::head\] sg_gen|Real time" gpurun_out/tiewalk5_ab.log | head -8
+    done
+  fi ;;
+walkprobe)
+  # the walk's dependent chain alone on this box's CPU (tools/probes/walk_probe.c): forms x bucket counts x page size
+  gcc -O2 -o /tmp/walk_probe tools/probes/walk_probe.c && for nb in 4 16 77; do for form in 0 3 5 1; do for thp in 0 1; do /tmp/walk_probe 100000000 $nb $form $thp; done; done; done 2>&1 | tee gpurun_out/walk_probe.txt ;;
 parseprof)
   # per-kernel times of the text-resident leg (device parse + dictionary inside the step)
   rm -rf gpurun_out/parseprof; mkdir -p gpurun_out/parseprof
