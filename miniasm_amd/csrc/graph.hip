@@ -684,6 +684,7 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 			}
 			c->tie.arc_walk = 1;
 			tl.lap("arc walk (all of it)");
+			walk_scratch_release(c);
 		}
 		c->ag ^= 1;
 	}
@@ -814,6 +815,7 @@ extern "C" int mahip_asg_import_push_rows(mahip_ctx_t *c, const void *d_src, con
 		c->ag = 1;
 	}
 	CHK(arc_reindex(c));
+	walk_scratch_release(c);
 	c->tie.arc_walk = 1; c->tie.unrepaired = 0;
 	c->graph_ready = true;
 	return 0;

@@ -1682,5 +1682,6 @@ extern "C" int mahip_hits_download(mahip_ctx_t *c, ma_hit_t *out, size_t *n_out)
 	hipLaunchKernelGGL(k_hit_export, dim3(grid_for(n, 256)), dim3(256), 0, c->st, h, n, (const uint32_t*)P<uint32_t>(c->pos),
 	                   c->has_map ? (const int32_t*)P<int32_t>(c->map) : (const int32_t*)nullptr, (ma_hit_t*)c->key[0].p, rank);
 	CHK(xfer_copy(c, c->key[0].p, out, c->n_live * sizeof(ma_hit_t), 0));
+	walk_scratch_release(c);
 	return 0;
 }

@@ -165,6 +165,7 @@ extern "C" void mahip_destroy(mahip_ctx_t *c)
 		&c->ctr, &c->ovf, &c->big0, &c->big1, &c->marks, &c->sgmask, &c->sidx, &c->hrank, &c->orank, &c->aslot, &c->pushrows[0], &c->pushrows[1], &c->xb[0], &c->xb[1], &c->gpos, &c->tdig };
 	for (DevBuf *b : all) dev_free(c, *b);
 	for (int k = 0; k < 8; ++k) dev_free(c, c->col[k]);
+	c->hwalk.drop(); c->hdig.drop();
 	mahip_comm_destroy(c);
 	paf_free(c);
 	clean_free(c);

@@ -26,6 +26,9 @@ struct DevBuf {
 struct ProfEvent { const char *name; hipEvent_t a, b; double alg_bytes; };
 struct ProfAcc { const char *name; uint64_t launches; double ms; double alg_bytes; };
 
+// big pageable host arrays of the tie walk (radix.hip)
+struct BigHost { void *p = nullptr; size_t bytes = 0; bool mapped = false; bool reserve(size_t n); void drop(); };
+
 struct mahip_ctx {
 	int dev = 0;
 	hipStream_t st = nullptr;
@@ -89,6 +92,7 @@ struct mahip_ctx {
 
 	// ---- scratch ----
 	DevBuf keep, pos;         // u32 flags / scanned positions
+	BigHost hwalk, hdig;      // host side of the tie walk: the packed elements and, when they do not hold it, the top level's digits; dropped by walk_scratch_release()
 	DevBuf tdig;              // u8 [n] tie walk: the keys' top digit when it does not fit into the packed element (radix.hip: reference_order)
 	DevBuf key[2], val[2];    // radix sort ping-pong
 	DevBuf hist;              // radix block histograms
@@ -163,6 +167,7 @@ void radix_first_digit(int lo, int hi, int *shift, int *bits, unsigned *tile);
 int radix_reserve_hist(mahip_ctx *c, size_t n);
 // the permutation the reference's (unstable) sort applies to d_keys[0..n) (input order), written to d_perm
 int reference_order(mahip_ctx *c, uint64_t *d_keys /* overwritten */, size_t n, uint32_t *d_perm);
+void walk_scratch_release(mahip_ctx *c); // the host arrays of the walks go away (on a thread of their own when they are big)
 // position of every hit slot in the reference's order -> c->hrank (hits.hip)
 int hits_reference_rank(mahip_ctx *c);
 // bits of the largest query start of the input records

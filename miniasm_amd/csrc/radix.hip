@@ -13,6 +13,8 @@
 //   * tiles of 4096 keys (256 threads x 16): ranks come from wave ballots (stable multi-split), the tile is
 //     reordered through LDS so that consecutive lanes write consecutive addresses of a digit's run.
 #include "mahip_internal.hpp"
+#include <sys/mman.h>
+#include <thread>
 
 #define RS_THREADS 256
 #ifndef RS_ITEMS
@@ -251,24 +253,33 @@ __global__ __launch_bounds__(256) void k_perm_from_packed(const uint64_t *__rest
 
 static int bitlen64(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
 
-// The walk's array: gigabytes that are written once by the copy, walked along up to 256 heads and dropped.  On 4 KB pages that is a page fault per page on the
-// way in, a TLB miss at every head and a long munmap on the way out; MA_HOST_THP=1 asks for transparent huge pages (measured per round, profiles/).
-#include <sys/mman.h>
-struct BigHost {
-	void *p = nullptr; size_t bytes = 0; bool mapped = false;
-	bool get(size_t n) {
-		static int thp = -1;
-		if (thp < 0) { const char *s = getenv("MA_HOST_THP"); thp = s && atoi(s) != 0; }
-		if (thp && n >= ((size_t)64 << 20)) {
-			bytes = (n + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-			void *q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-			if (q != MAP_FAILED) { (void)madvise(q, bytes, MADV_HUGEPAGE); p = q; mapped = true; return true; }
-		}
-		p = malloc(n); bytes = n; mapped = false;
-		return p != nullptr;
+// The walk's arrays (c->hwalk, c->hdig) stay with the context between the hit walk and the arc walk that follows it and are dropped by a thread of their
+// own when the repair is over (walk_scratch_release): unmapping 9 GB took 0.5 s of the 5.8 s of BASELINE configs[4], 60 ms of the 1.1 s of the 50 M-overlap
+// noisy input, while the device was waiting for its next kernel.
+bool BigHost::reserve(size_t n)
+{
+	static int thp = -1;
+	if (n <= bytes && p) return true;
+	drop();
+	if (thp < 0) { const char *s = getenv("MA_HOST_THP"); thp = s && atoi(s) != 0; }
+	if (thp && n >= ((size_t)64 << 20)) { // transparent huge pages, on request: a fault per 2 MB instead of per 4 KB, fewer TLB misses at the walk's heads, a shorter munmap
+		const size_t b = (n + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+		void *q = mmap(nullptr, b, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+		if (q != MAP_FAILED) { (void)madvise(q, b, MADV_HUGEPAGE); p = q; bytes = b; mapped = true; return true; }
 	}
-	void drop() { if (p) { if (mapped) munmap(p, bytes); else free(p); } p = nullptr; }
-};
+	p = malloc(n); bytes = p ? n : 0; mapped = false;
+	return p != nullptr;
+}
+void BigHost::drop() { if (p) { if (mapped) munmap(p, bytes); else free(p); } p = nullptr; bytes = 0; mapped = false; }
+
+void walk_scratch_release(mahip_ctx *c)
+{
+	if (!c->hwalk.p && !c->hdig.p) return;
+	BigHost a = c->hwalk, b = c->hdig;
+	c->hwalk = BigHost(); c->hdig = BigHost();
+	if (a.bytes + b.bytes < ((size_t)32 << 20)) { a.drop(); b.drop(); return; }
+	std::thread([a, b]() mutable { a.drop(); b.drop(); }).detach();
+}
 
 // d_perm[j] <- input position of the j-th record in the reference's order.  d_keys is overwritten.
 int reference_order(mahip_ctx *c, uint64_t *d_keys, size_t n, uint32_t *d_perm)
@@ -293,10 +304,9 @@ int reference_order(mahip_ctx *c, uint64_t *d_keys, size_t n, uint32_t *d_perm)
 	}
 	int rc = 0;
 	if (packed && !getenv("MA_REFSORT_KEYS")) {
-		BigHost bk, bd;
-		if (!bk.get(n * 8) || (shift_top >= 0 && !bd.get(n + 16))) { bk.drop(); bd.drop(); mahip_set_error("reference_order: out of host memory"); return -1; }
-		uint64_t *hk = (uint64_t*)bk.p;
-		uint8_t *hd = (uint8_t*)bd.p;
+		if (!c->hwalk.reserve(n * 8) || (shift_top >= 0 && !c->hdig.reserve(n + 16))) { mahip_set_error("reference_order: out of host memory"); return -1; }
+		uint64_t *hk = (uint64_t*)c->hwalk.p;
+		uint8_t *hd = shift_top >= 0 ? (uint8_t*)c->hdig.p : nullptr;
 		if (shift_top >= 0) CHK(dev_reserve(c, c->tdig, n + 16));
 		hipLaunchKernelGGL(k_pack_keys, dim3(grid_for(n, 256)), dim3(256), 0, c->st, d_keys, n, bl, bi, himask, shift_top, shift_top >= 0 ? P<uint8_t>(c->tdig) : (uint8_t*)nullptr);
 		if (xfer_copy(c, d_keys, hk, n * 8, 0) != 0) rc = -1;
@@ -307,8 +317,6 @@ int reference_order(mahip_ctx *c, uint64_t *d_keys, size_t n, uint32_t *d_perm)
 		if (rc == 0 && xfer_copy(c, d_keys, hk, n * 8, 1) != 0) rc = -1;
 		if (rc == 0) hipLaunchKernelGGL(k_perm_from_packed, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint64_t*)d_keys, n, bi >= 64 ? ~0ull : (1ull << bi) - 1, d_perm);
 		tl.lap("walk: order to the device");
-		bk.drop(); bd.drop();
-		tl.lap("walk: free");
 	} else { // keys too wide (or MA_REFSORT_KEYS, for the tests): the raw keys go down, the host packs what it can
 		uint64_t *hk = (uint64_t*)malloc(n * 8);
 		uint32_t *hp = (uint32_t*)malloc(n * 4);

@@ -70,6 +70,7 @@ static void RS_NAME(permute_uniform)(RS_T *a, const size_t *start, const uint8_t
 		const RS_T evicted = a[rd < last ? rd : last]; /* (the scanned bucket reads one slot ahead: at most one past the range, and that element is dropped) */
 		a[wd] = carry;
 		b[d].r = rd + 1; b[d].w = wd + 1; nd[d] = dig[rd + 1];
+		__builtin_prefetch(dig + rd + 129); /* the digit has to be in L1 when this bucket comes round again: on the EPYC of the GPU box 2.6 -> 1.9 ns per element with 77 buckets (tools/probes/walk_probe.c) */
 		RS_PREFETCH(&a[rd]);
 		carry = evicted;
 		left -= d == (unsigned)k;

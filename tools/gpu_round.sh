@@ -49,6 +49,12 @@ tiewalk)
 tiewalk2)
   # A/B on one box: the top-level walk in its two forms, the walk's array on huge pages or not (50 M noisy; TIEWALK_CFG5=1: BASELINE configs[4], default and THP)
   miniasm_amd/bin/pafgen -r 1000000 -n 50000000 -s 3 -L uniform -d 0.35 -x 0.03 -o /tmp/tw50.paf 2>/dev/null
+  miniasm_amd/bin/pafgen -r 250000 -n 5000000 -s 5 -q 16 -L uniform -d 0.3 -x 0.03 -o /tmp/twrich.paf 2>/dev/null
+  for v in "" "MA_REFSORT_LITERAL_TOP=1" ""; do
+    echo "## tie-rich 5 M (bench.py legs.tie_rich's input) [${v:-default}]"
+    env $v MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm /tmp/twrich.paf 2> gpurun_out/tiewalkrich_ab.log | md5sum
+    grep -E "top walk|buckets|walk: (packed|order|free|host)|T::head\\] sg_gen|Real time" gpurun_out/tiewalkrich_ab.log | head -6
+  done
   for v in "" "MA_REFSORT_LITERAL_TOP=1" "MA_HOST_THP=1" ""; do
     echo "## 50 M noisy [${v:-default}]"
     env $v MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm /tmp/tw50.paf 2> gpurun_out/tiewalk50_ab.log | md5sum
