@@ -28,8 +28,6 @@ static int rs_timing = -1;
 #define RS_T0 double t0_ = rs_now()
 #define RS_LAP(what) do { if (rs_timing < 0) rs_timing = getenv("MA_REFSORT_TIMING") != 0; if (rs_timing) { double t1_ = rs_now(); fprintf(stderr, "[T::refsort] %-12s %.3f s\n", what, t1_ - t0_); t0_ = t1_; } } while (0)
 
-static int rs_lit_top = -1;
-static int rs_literal_top(void) { if (rs_lit_top < 0) rs_lit_top = getenv("MA_REFSORT_LITERAL_TOP") != 0; return rs_lit_top; } /* timing: the walk with ksort.h's two loops instead of the uniform one */
 #define RS_SMALL 64           /* RS_MIN_SIZE ksort.h:132 */
 /* The walk touches the 256 bucket heads in an order the hardware prefetchers cannot follow (they track a few dozen streams), so every
  * new cache line of a bucket used to be a miss on the walk's dependent chain; each store now asks for the line a few ahead of its head. */

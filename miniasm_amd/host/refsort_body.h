@@ -48,8 +48,11 @@ static void RS_NAME(dispatch)(rs_pool_t *pool, RS_T *a, const size_t *start, int
  * and the slot written are the same; for k the element carried away at the start of a chain came from the slot the chain's last element will fill, so k
  * reads one slot ahead of where it writes (an element of k that is already home is written back to its own slot).  With a read and a write position per
  * bucket every step is the same few instructions, `while (l != k)` and `if (l != k)` of the reference disappear, and the only branch left is taken when
- * the scanned bucket is full (256 times).  The literal form mispredicted once per chain: 2 x slower with the 4 top-level buckets of a 250 k-read input,
- * 1.3 x with 16 (1 M reads), the same with 77 (profiles/r03_tiewalk.txt). */
+ * the scanned bucket is full.  Used for the short ranges (level_small), where it saves the set-up of the other form.  For the long walks it was measured
+ * against permute_top below on the EPYC 9575F of the GPU box and lost on real inputs (0.34-0.36 s against 0.31 s at the top level of the 50 M-overlap noisy
+ * input, 46 against 37 ms on the tie-rich one) although it wins on random digits (tools/probes/walk_probe.c: 2.4 against 3.2 ns per element with 4 buckets,
+ * 1.9 against 2.0 with 77): a PAF lists a query's overlaps together, so every other element of a stretch goes to the same bucket, and the literal form's
+ * inner loop keeps that bucket's state in flight (profiles/r03_tiewalk.txt). */
 typedef struct { size_t r, w; } RS_NAME(rw_t);
 static void RS_NAME(permute_uniform)(RS_T *a, const size_t *start, const uint8_t *dig /* n + 1 bytes */, int lo, int hi /* the digits that occur: start[lo .. hi + 1] are set */)
 {
@@ -91,13 +94,6 @@ static void RS_NAME(permute_top)(rs_pool_t *pool, RS_T *a, const size_t *cnt, co
 	int k;
 	start[0] = 0;
 	for (k = 0; k < 256; ++k) start[k + 1] = start[k] + cnt[k];
-	{ /* a sample says which form of the walk: few elements at home (a PAF as the mapper writes it: ids in order of first appearance, queries in any order) -> the
-	   * uniform walk below; mostly at home (arcs, a PAF sorted by query) -> the form that takes a stretch of home elements eight at a time */
-		const size_t n = start[256], step = n / 4096 + 1;
-		size_t p, home = 0, seen = 0;
-		for (p = 0, k = 0; p < n; p += step, ++seen) { while (start[k + 1] <= p) ++k; home += dig[p] == (unsigned)k; }
-		if (home * 2 < seen && !rs_literal_top()) { RS_NAME(permute_uniform)(a, start, dig, 0, 255); RS_NAME(dispatch)(pool, a, start, shift); return; }
-	}
 	for (k = 0; k < 256; ++k) b[k].head = start[k], b[k].nd = dig[start[k]], b[k].pad = 0;
 	for (k = 0; k < 256;) {
 		unsigned d;

@@ -38,24 +38,26 @@ inflight)
 tiewalk)
   # the host walk that reproduces the reference's tie order: laps of host/refsort.c on the 50 M noisy input and (TIEWALK_CFG5=1) on BASELINE configs[4]
   miniasm_amd/bin/pafgen -r 1000000 -n 50000000 -s 3 -L uniform -d 0.35 -x 0.03 -o /tmp/tw50.paf 2>/dev/null
+  for k in 1 2; do t0=$(date +%s.%N); timeout 600 miniasm_amd/bin/miniasm /tmp/tw50.paf 2> gpurun_out/tiewalk50_plain.log | md5sum; t1=$(date +%s.%N); python3 -c "print(\"plain run: %.3f s wall\" % ($t1 - $t0))"; grep "Real time" gpurun_out/tiewalk50_plain.log; done
   MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm /tmp/tw50.paf 2> gpurun_out/tiewalk50.log | md5sum
   grep -E "T::refsort|T::ties|T::head\\] sg_gen|Real time|T::xfer.*HBM->host" gpurun_out/tiewalk50.log | head -30
   if [ -n "$TIEWALK_CFG5" ]; then
     miniasm_amd/bin/pafgen -r 5000000 -n 500000000 -s 3 -L uniform -d 0.35 -x 0.03 -o /tmp/tw5.paf 2>/dev/null
+    t0=$(date +%s.%N); timeout 900 miniasm_amd/bin/miniasm /tmp/tw5.paf 2> gpurun_out/tiewalk5_plain.log | md5sum; t1=$(date +%s.%N); python3 -c "print(\"plain run: %.3f s wall\" % ($t1 - $t0))"; grep "Real time" gpurun_out/tiewalk5_plain.log
     MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 900 miniasm_amd/bin/miniasm /tmp/tw5.paf 2> gpurun_out/tiewalk5.log | md5sum
     grep -E "T::refsort|T::ties|T::head\\] sg_gen|Real time|T::xfer.*HBM->host" gpurun_out/tiewalk5.log | head -40
     echo "(reference md5 of this input, profiles/r03_e2e_cfg5_500M.txt: fa9c76984d44526d1a9a9e70132d01da)"
   fi ;;
 tiewalk2)
-  # A/B on one box: the top-level walk in its two forms, the walk's array on huge pages or not (50 M noisy; TIEWALK_CFG5=1: BASELINE configs[4], default and THP)
+  # A/B on one box: the walk's array on huge pages or not (50 M noisy; TIEWALK_CFG5=1: BASELINE configs[4], default and THP)
   miniasm_amd/bin/pafgen -r 1000000 -n 50000000 -s 3 -L uniform -d 0.35 -x 0.03 -o /tmp/tw50.paf 2>/dev/null
   miniasm_amd/bin/pafgen -r 250000 -n 5000000 -s 5 -q 16 -L uniform -d 0.3 -x 0.03 -o /tmp/twrich.paf 2>/dev/null
-  for v in "" "MA_REFSORT_LITERAL_TOP=1" ""; do
+  for v in "" "MA_HOST_THP=1"; do
     echo "## tie-rich 5 M (bench.py legs.tie_rich's input) [${v:-default}]"
     env $v MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm /tmp/twrich.paf 2> gpurun_out/tiewalkrich_ab.log | md5sum
     grep -E "top walk|buckets|walk: (packed|order|free|host)|T::head\\] sg_gen|Real time" gpurun_out/tiewalkrich_ab.log | head -6
   done
-  for v in "" "MA_REFSORT_LITERAL_TOP=1" "MA_HOST_THP=1" ""; do
+  for v in "" "MA_HOST_THP=1" ""; do
     echo "## 50 M noisy [${v:-default}]"
     env $v MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm /tmp/tw50.paf 2> gpurun_out/tiewalk50_ab.log | md5sum
     grep -E "top walk|buckets|walk: (packed|order|free|host)|T::head\] sg_gen|Real time" gpurun_out/tiewalk50_ab.log | head -8
