@@ -70,6 +70,14 @@ tiewalk2)
       grep -E "top walk|buckets|walk: (packed|order|free|host)|T::head\] sg_gen|Real time" gpurun_out/tiewalk5_ab.log | head -8
     done
   fi ;;
+cleanprof)
+  # per-kernel times of one CLI run on the 50 M noisy input (where the cleaners and the tie repair are what is left of the device time)
+  [ -f /tmp/tw50.paf ] || miniasm_amd/bin/pafgen -r 1000000 -n 50000000 -s 3 -L uniform -d 0.35 -x 0.03 -o /tmp/tw50.paf 2>/dev/null
+  rm -rf gpurun_out/cleanprof; mkdir -p gpurun_out/cleanprof
+  (cd /tmp && MA_PIPE_TIMING=2 timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/cleanprof -o r --output-format csv -- /root/repo/miniasm_amd/bin/miniasm /tmp/tw50.paf > /dev/null 2> /root/repo/gpurun_out/cleanprof/run.log); echo "rc=$?"
+  f=$(find gpurun_out/cleanprof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "$f" | cut -c1-150
+  grep -E "T::tail|T::clean" gpurun_out/cleanprof/run.log | head -20
+  find gpurun_out/cleanprof -name "*trace*.csv" -size +8M -delete ;;
 walkprobe)
   # the walk's dependent chain alone on this box's CPU (tools/probes/walk_probe.c): forms x bucket counts x page size
   gcc -O2 -o /tmp/walk_probe tools/probes/walk_probe.c && for nb in 4 16 77; do for form in 0 3 5 1; do for thp in 0 1; do /tmp/walk_probe 100000000 $nb $form $thp; done; done; done 2>&1 | tee gpurun_out/walk_probe.txt ;;
