@@ -67,6 +67,111 @@ __global__ __launch_bounds__(64) void k_clean_bubble(cl_view_t g, cl_stamps_t s,
 	if (back) atomicAdd(&ctr[CT_OVF2], (unsigned long long)back); // pops that would bring a dead read back (clean_core.h: ASSUMPTION)
 }
 
+// The tiers above the first: ONE WAVE per source.  A probe that needs a big table is a long chain of dependent look-ups -- per expanded vertex its arcs, per
+// arc the target's record and, for a target seen for the first time, the live arcs of its complement (asg.c:388: the in-degree): some 15 loads in a row per
+// vertex, 2.3 ms for the longest probe of the 50 M-overlap noisy input, and a launch lasts as long as its longest probe.  Here the lanes fetch what lane 0 is
+// going to need -- lane i takes arc i of the vertex: target, length, dead or not, and the in-degree of a target that is not in the table yet -- into LDS, and lane 0
+// replays cl_bubble_probe's loop over the staged values (same order, same rules: the table it builds is the one a single thread builds).  The table itself sits in
+// LDS while it fits (1 024 slots; the tiers above keep theirs in HBM).  Per vertex: three rounds of loads instead of fifteen.
+enum { BW_LDS_CAP = 1024 };
+__global__ __launch_bounds__(64) void k_clean_bubble_wave(cl_view_t g, cl_stamps_t s, const uint32_t *__restrict__ src, uint32_t n_src, uint32_t max_dist,
+                                                           cl_binfo_t *__restrict__ tabs, uint32_t *__restrict__ aux, uint32_t cap, int in_lds, uint32_t *__restrict__ ovf,
+                                                           unsigned long long *__restrict__ ctr)
+{
+	__shared__ cl_binfo_t l_tab[BW_LDS_CAP];
+	__shared__ uint32_t l_used[BW_LDS_CAP], l_stack[BW_LDS_CAP];
+	__shared__ uint32_t st_w[64], st_l[64], st_live[64], st_dead[64];
+	__shared__ uint32_t sh_v, sh_first, sh_nv, sh_state, sh_n; // sh_state: 0 = walking, 1 = a bubble, 2 = none, 3 = the table is full
+	const uint32_t lane = threadIdx.x;
+	cl_bscratch_t b;
+	if (in_lds) {
+		b.tab = l_tab; b.used = l_used; b.stack = l_stack;
+		for (uint32_t i = lane; i < cap; i += 64) l_tab[i].key = CL_NONE;
+	} else { b.tab = tabs + (size_t)blockIdx.x * cap; b.used = aux + (size_t)blockIdx.x * 2 * cap; b.stack = b.used + cap; } // (kept empty by the probes, initialised once: k_table_init)
+	b.cap = cap; b.n_used = 0;
+	uint32_t pops = 0, tips_all = 0, back = 0;
+	__syncthreads();
+	for (uint32_t k = blockIdx.x; k < n_src; k += gridDim.x) {
+		const uint32_t v0 = src[k];
+		uint32_t n_stack = 0, n_pending = 0, tips = 0, d = 0, c = 0; // lane 0's
+		if (lane == 0) {
+			const int go = !cl_seq_dead(&g, v0 >> 1, v0) && cl_count(&g, v0) >= 2 && cl_live_out(&g, v0, v0) >= 2; /* asg.c:421-427 */
+			if (go) b.stack[n_stack++] = v0;
+			sh_state = go ? 0u : 2u;
+		}
+		__syncthreads();
+		while (sh_state == 0) {
+			if (lane == 0) {
+				const uint32_t v = b.stack[--n_stack];
+				d = c = 0;
+				if (v != v0) { cl_binfo_t *tv = cl_bfind(&b, v); d = tv->d; c = tv->c; tv->fl |= CL_B_EXPANDED; }
+				sh_v = v; sh_first = cl_first(&g, v); sh_nv = cl_count(&g, v);
+			}
+			__syncthreads();
+			const uint32_t v = sh_v, first = sh_first, nv = sh_nv;
+			for (uint32_t base = 0; base < nv; base += 64) {
+				const uint32_t i = base + lane;
+				if (i < nv) { // what lane 0 is going to ask about arc i
+					const uint32_t e = first + i, w = g.av[e];
+					const uint32_t dead = (uint32_t)cl_arc_dead(&g, e, v0);
+					uint32_t live = 0;
+					if (w != v0 && !dead && cl_bfind(&b, w) == 0) live = cl_live_out(&g, w ^ 1, v0);
+					st_w[lane] = w; st_l[lane] = g.alen[e]; st_dead[lane] = dead; st_live[lane] = live;
+				}
+				__syncthreads();
+				if (lane == 0) {
+					const uint32_t m = nv - base < 64 ? nv - base : 64;
+					for (uint32_t j = 0; j < m; ++j) { // cl_bubble_probe's loop body on the staged values
+						const uint32_t w = st_w[j], l = st_l[j];
+						cl_binfo_t *t;
+						int fresh = 0;
+						if (w == v0) { sh_state = 2; break; }
+						if (st_dead[j]) continue;
+						if (d + l > max_dist) { sh_state = 2; break; }
+						t = cl_bget(&b, w, &fresh);
+						if (t == 0) { sh_state = 3; break; }
+						if (fresh) {
+							t->p = v; t->d = d + l;
+							t->r = st_live[j];
+							++n_pending;
+						} else {
+							if (c + 1 > t->c || (c + 1 == t->c && d + l > t->d)) t->p = v;
+							if (c + 1 > t->c) t->c = c + 1;
+							if (d + l < t->d) t->d = d + l;
+						}
+						if (--t->r == 0) {
+							if (cl_count(&g, w)) b.stack[n_stack++] = w;
+							else t->fl |= CL_B_TIP, ++tips;
+							--n_pending;
+						}
+					}
+				}
+				__syncthreads();
+				if (sh_state != 0) break;
+			}
+			if (lane == 0 && sh_state == 0) {
+				if (n_stack == 0) sh_state = 2;
+				else if (!(n_stack > 1 || n_pending)) sh_state = 1;
+			}
+			__syncthreads();
+		}
+		const uint32_t state = sh_state;
+		if (state == 1) {
+			if (lane == 0) { back += cl_bubble_stamp(&g, s, v0, b.stack[0], &b); ++pops; tips_all += tips; } // (leaves the table empty)
+		} else {
+			if (lane == 0) { sh_n = b.n_used; b.n_used = 0; if (state == 3) ovf[atomicAdd(&ctr[CT_OVF], 1ull)] = v0; }
+			__syncthreads();
+			for (uint32_t i = lane; i < sh_n; i += 64) b.tab[b.used[i]].key = CL_NONE;
+		}
+		__syncthreads();
+	}
+	if (lane == 0) {
+		if (pops) atomicAdd(&ctr[CT_LIVE], (unsigned long long)pops);
+		if (tips_all) atomicAdd(&ctr[CT_REMAIN], (unsigned long long)tips_all);
+		if (back) atomicAdd(&ctr[CT_OVF2], (unsigned long long)back);
+	}
+}
+
 __global__ __launch_bounds__(256) void k_table_init(cl_binfo_t *__restrict__ tabs, size_t n)
 {
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -118,6 +223,8 @@ static inline uint32_t bub_cap(int tier)
 	if (!base) { const char *e = getenv("MA_BUBBLE_CAP0"); base = e && atoi(e) >= 4 && !(atoi(e) & (atoi(e) - 1)) ? (uint32_t)atoi(e) : (uint32_t)BUB_CAP0; }
 	return base << (4 * tier);
 }
+static inline bool bub_thread_tiers() { static int v = -1; if (v < 0) v = getenv("MA_BUBBLE_THREAD_TIERS") != nullptr; return v != 0; } // measurements / tests: a thread per source in every tier
+static inline uint32_t bub_lds_cap() { static long v = -1; if (v < 0) { const char *e = getenv("MA_BUBBLE_LDS_CAP"); v = e ? atol(e) : (long)BW_LDS_CAP; if (v > (long)BW_LDS_CAP) v = BW_LDS_CAP; } return (uint32_t)v; } // tests: smaller, so that small inputs reach the tables in HBM
 static inline unsigned bub_threads(int tier, uint32_t n_src)
 {
 	const unsigned most = (unsigned)BUB_THREADS0 >> (4 * tier) ? (unsigned)BUB_THREADS0 >> (4 * tier) : 1u; // 65536, 4096, 256, 16, 1
@@ -129,20 +236,23 @@ static int bubble_launch(mahip_ctx *c, CleanBufs *b, int tier, const cl_view_t &
 {
 	BubTier &t = b->tier[tier];
 	const uint32_t cap = bub_cap(tier);
-	const unsigned threads = bub_threads(tier, n_src);
-	const size_t slots = (size_t)threads * cap;
+	const bool wave = tier > 0 && !bub_thread_tiers(); // a wave per source (k_clean_bubble_wave); its table in LDS while it fits
+	const bool lds = wave && cap <= bub_lds_cap();
+	const unsigned threads = lds ? (n_src < 8192u ? n_src : 8192u) : bub_threads(tier, n_src); // = tables = (wave form) blocks
+	const size_t slots = lds ? 0 : (size_t)threads * cap;
 	if (t.tabs.cap < slots * sizeof(cl_binfo_t)) {
 		CHK(dev_reserve(c, t.tabs, slots * sizeof(cl_binfo_t)));
 		CHK(dev_reserve(c, t.aux, slots * 2 * 4));
 		t.ready = false;
 	}
-	if (!t.ready) { // probes leave their table empty (also the ones that give up): initialise once per allocation
+	if (!t.ready && slots) { // probes leave their table empty (also the ones that give up): initialise once per allocation
 		const size_t all = t.tabs.cap / sizeof(cl_binfo_t);
 		hipLaunchKernelGGL(k_table_init, dim3(grid_for(all, 256)), dim3(256), 0, c->st, (cl_binfo_t*)t.tabs.p, all);
 		t.ready = true;
 	}
 	ProfScope ps(c, "k_clean_bubble", 0);
-	hipLaunchKernelGGL(k_clean_bubble, dim3((threads + 63) / 64), dim3(64), 0, c->st, g, s, src, n_src, max_dist, (cl_binfo_t*)t.tabs.p, P<uint32_t>(t.aux), cap, threads, ovf, P<unsigned long long>(c->ctr));
+	if (wave) hipLaunchKernelGGL(k_clean_bubble_wave, dim3(threads), dim3(64), 0, c->st, g, s, src, n_src, max_dist, (cl_binfo_t*)t.tabs.p, P<uint32_t>(t.aux), cap, lds ? 1 : 0, ovf, P<unsigned long long>(c->ctr));
+	else hipLaunchKernelGGL(k_clean_bubble, dim3((threads + 63) / 64), dim3(64), 0, c->st, g, s, src, n_src, max_dist, (cl_binfo_t*)t.tabs.p, P<uint32_t>(t.aux), cap, threads, ovf, P<unsigned long long>(c->ctr));
 	if ((uint32_t)tier > b->max_tier) b->max_tier = tier;
 	return 0;
 }

@@ -298,8 +298,15 @@ def test_bubble_probes_that_outgrow_their_tables(tmpdir_s, monkeypatch):
     paf = _gen(tmpdir_s, "noisy")
     monkeypatch.setenv("MA_BUBBLE_CAP0", "4")
     monkeypatch.setenv("MA_PIPE_TIMING", "2")
-    for args in ([], ["-p", "sg"]):
-        ref_out, _ = R.run_cli(R.REF_BIN, args, paf)
-        out, log = R.run_cli(ma.CLI_PATH, args, paf)
-        assert out == ref_out
-        assert "(tier 2)" in log, "the input was supposed to reach the third tier of probe tables"
+    # the tiers above the first probe with a wave per source, the table in LDS while it fits (default) or in HBM (forced here by a tiny limit);
+    # MA_BUBBLE_THREAD_TIERS: a thread per source in every tier, the form of round 2
+    for extra in ({}, {"MA_BUBBLE_LDS_CAP": "16"}, {"MA_BUBBLE_THREAD_TIERS": "1"}):
+        for k in ("MA_BUBBLE_LDS_CAP", "MA_BUBBLE_THREAD_TIERS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
+        for args in ([], ["-p", "sg"]):
+            ref_out, _ = R.run_cli(R.REF_BIN, args, paf)
+            out, log = R.run_cli(ma.CLI_PATH, args, paf)
+            assert out == ref_out, "%r %r" % (extra, args)
+            assert "(tier 2)" in log, "the input was supposed to reach the third tier of probe tables"
