@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_clean_apply(const uint32_t *__restrict_
 
 // bubble tables: tier 0 = one small table per thread of the full-width launch; tiers above (16x the slots, 1/16 of the threads: the same
 // bytes) only ever see the sources that overflowed the tier below
-enum { BUB_CAP0 = 64, BUB_THREADS0 = 65536, BUB_TIERS = 5 }; // 64 .. 4 M slots; 32 B per slot: 128 MiB per tier that is ever needed
+enum { BUB_CAP0 = 16, BUB_THREADS0 = 524288, BUB_TIERS = 5 }; // 16, 1 024, 16 384 .. 4 M slots; 32 B per slot: 256 MiB per tier that is ever needed (tier 1: LDS)
 struct BubTier { DevBuf tabs, aux; bool ready = false; };
 struct CleanBufs { DevBuf st[2], src, ovf[2]; BubTier tier[BUB_TIERS]; uint32_t max_tier = 0; }; // st[k]: read stamps [R rounded up] then arc stamps [A]
 
@@ -219,15 +219,24 @@ void clean_free(mahip_ctx *c)
 
 static inline uint32_t bub_cap(int tier)
 {
-	static uint32_t base = 0; // MA_BUBBLE_CAP0 (a power of two >= 4): the tests shrink tier 0 so that small graphs reach the tiers above
-	if (!base) { const char *e = getenv("MA_BUBBLE_CAP0"); base = e && atoi(e) >= 4 && !(atoi(e) & (atoi(e) - 1)) ? (uint32_t)atoi(e) : (uint32_t)BUB_CAP0; }
-	return base << (4 * tier);
+	// Tier 0 is small (most probes see a handful of vertices) and wide; tier 1 is what fits into LDS (the wave form); above it 16 x per tier.
+	// MA_BUBBLE_CAP0 (a power of two >= 4; MA_BUBBLE_CAP1 likewise): measurements, and the tests shrink the tiers so that small graphs reach the ones above.
+	static uint32_t base = 0, one = 0;
+	if (!base) {
+		const char *e = getenv("MA_BUBBLE_CAP0"), *f = getenv("MA_BUBBLE_CAP1");
+		base = e && atoi(e) >= 4 && !(atoi(e) & (atoi(e) - 1)) ? (uint32_t)atoi(e) : (uint32_t)BUB_CAP0;
+		one = f && atoi(f) >= 8 && !(atoi(f) & (atoi(f) - 1)) ? (uint32_t)atoi(f) : e ? base << 4 : (uint32_t)BW_LDS_CAP;
+		if (one <= base) one = base << 1;
+	}
+	return tier == 0 ? base : one << (4 * (tier - 1));
 }
 static inline bool bub_thread_tiers() { static int v = -1; if (v < 0) v = getenv("MA_BUBBLE_THREAD_TIERS") != nullptr; return v != 0; } // measurements / tests: a thread per source in every tier
 static inline uint32_t bub_lds_cap() { static long v = -1; if (v < 0) { const char *e = getenv("MA_BUBBLE_LDS_CAP"); v = e ? atol(e) : (long)BW_LDS_CAP; if (v > (long)BW_LDS_CAP) v = BW_LDS_CAP; } return (uint32_t)v; } // tests: smaller, so that small inputs reach the tables in HBM
 static inline unsigned bub_threads(int tier, uint32_t n_src)
 {
-	const unsigned most = (unsigned)BUB_THREADS0 >> (4 * tier) ? (unsigned)BUB_THREADS0 >> (4 * tier) : 1u; // 65536, 4096, 256, 16, 1
+	static unsigned base = 0; // MA_BUBBLE_THREADS0: tier 0's launch width (measurements)
+	if (!base) { const char *e = getenv("MA_BUBBLE_THREADS0"); base = e && atoi(e) >= 64 ? (unsigned)atoi(e) : (unsigned)BUB_THREADS0; }
+	const unsigned most = base >> (4 * tier) ? base >> (4 * tier) : 1u; // 65536, 4096, 256, 16, 1
 	return n_src < most ? n_src : most;
 }
 

@@ -84,6 +84,14 @@ bubwave)
   [ -f /tmp/twrich.paf ] || miniasm_amd/bin/pafgen -r 250000 -n 5000000 -s 5 -q 16 -L uniform -d 0.3 -x 0.03 -o /tmp/twrich.paf 2>/dev/null
   for f in /tmp/tw50.paf /tmp/twrich.paf; do for v in "" "MA_BUBBLE_THREAD_TIERS=1" "" "MA_BUBBLE_THREAD_TIERS=1"; do
     echo "## $f [${v:-wave per source}]"; env $v MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm $f 2> gpurun_out/bubwave.log | md5sum; grep -E "device cleaners" gpurun_out/bubwave.log; done; done ;;
+bubtune)
+  # tier 0 of the bubble probes: table size (MA_BUBBLE_CAP0) and launch width (MA_BUBBLE_THREADS0) against the device time of the cleaners
+  [ -f /tmp/tw50.paf ] || miniasm_amd/bin/pafgen -r 1000000 -n 50000000 -s 3 -L uniform -d 0.35 -x 0.03 -o /tmp/tw50.paf 2>/dev/null
+  [ -f /tmp/twrich.paf ] || miniasm_amd/bin/pafgen -r 250000 -n 5000000 -s 5 -q 16 -L uniform -d 0.3 -x 0.03 -o /tmp/twrich.paf 2>/dev/null
+  for v in "" "MA_BUBBLE_THREADS0=131072" "MA_BUBBLE_THREADS0=524288" "MA_BUBBLE_CAP0=16 MA_BUBBLE_CAP1=1024 MA_BUBBLE_THREADS0=524288" "MA_BUBBLE_CAP0=64 MA_BUBBLE_CAP1=1024"; do
+    echo "## tie-rich [${v:-default}]"; env $v MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm /tmp/twrich.paf 2> gpurun_out/bubtune.log | md5sum; grep -E "device cleaners" gpurun_out/bubtune.log; done
+  for v in "" "MA_BUBBLE_THREADS0=131072" "MA_BUBBLE_THREADS0=524288" "MA_BUBBLE_CAP0=16 MA_BUBBLE_CAP1=1024 MA_BUBBLE_THREADS0=524288" "MA_BUBBLE_CAP0=64 MA_BUBBLE_CAP1=1024" ""; do
+    echo "## [${v:-default}]"; env $v MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm /tmp/tw50.paf 2> gpurun_out/bubtune.log | md5sum; grep -E "device cleaners" gpurun_out/bubtune.log; done ;;
 walkprobe)
   # the walk's dependent chain alone on this box's CPU (tools/probes/walk_probe.c): forms x bucket counts x page size
   gcc -O2 -o /tmp/walk_probe tools/probes/walk_probe.c && for nb in 4 16 77; do for form in 0 3 5 1; do for thp in 0 1; do /tmp/walk_probe 100000000 $nb $form $thp; done; done; done 2>&1 | tee gpurun_out/walk_probe.txt ;;
