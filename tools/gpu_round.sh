@@ -45,6 +45,7 @@ tiewalk)
     miniasm_amd/bin/pafgen -r 5000000 -n 500000000 -s 3 -L uniform -d 0.35 -x 0.03 -o /tmp/tw5.paf 2>/dev/null
     t0=$(date +%s.%N); timeout 900 miniasm_amd/bin/miniasm /tmp/tw5.paf 2> gpurun_out/tiewalk5_plain.log | md5sum; t1=$(date +%s.%N); python3 -c "print(\"plain run: %.3f s wall\" % ($t1 - $t0))"; grep "Real time" gpurun_out/tiewalk5_plain.log
     MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 900 miniasm_amd/bin/miniasm /tmp/tw5.paf 2> gpurun_out/tiewalk5.log | md5sum
+    echo "## MA_XFER_THREADS=16"; MA_XFER_THREADS=16 MA_PIPE_TIMING=2 timeout 900 miniasm_amd/bin/miniasm /tmp/tw5.paf 2>&1 >/dev/null | grep -E "T::xfer|walk: (packed|order)|Real time" | head -12
     grep -E "T::refsort|T::ties|T::head\\] sg_gen|Real time|T::xfer.*HBM->host" gpurun_out/tiewalk5.log | head -40
     echo "(reference md5 of this input, profiles/r03_e2e_cfg5_500M.txt: fa9c76984d44526d1a9a9e70132d01da)"
   fi ;;
