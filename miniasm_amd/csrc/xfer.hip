@@ -72,12 +72,15 @@ static void *xfer_worker(void *arg)
 	return 0;
 }
 
-static int xfer_workers()
+static int xfer_workers(int to_device)
 {
 	const char *s = getenv("MA_XFER_THREADS");
 	long n = s ? atol(s) : sysconf(_SC_NPROCESSORS_ONLN) / 2;
+	// device -> host ends in a memcpy into pageable memory that is usually fresh (a page fault and a cleared page per 4 KB): 8 workers reach 21 GB/s, 16 reach 31
+	// (8 GB of tie-walk keys, BASELINE configs[4], profiles/r03_tiewalk.txt); host -> device is at 45 GB/s with 8 and no faster with 16
+	const long most = to_device ? 8 : 16;
 	if (n < 1) n = 1;
-	if (n > 8 && !s) n = 8;
+	if (n > most && !s) n = most;
 	if (n > XF_MAX_WORKERS) n = XF_MAX_WORKERS;
 	return (int)n;
 }
@@ -111,7 +114,7 @@ static int xfer_run(mahip_ctx *c, void *dev_ptr, void *host_ptr, int fd, size_t 
 		HIPCHK(hipStreamSynchronize(c->st));
 		return 0;
 	}
-	int W = xfer_workers();
+	int W = xfer_workers(to_device);
 	const size_t n_slices = (bytes + XF_SLOT - 1) / XF_SLOT;
 	if ((size_t)W > n_slices) W = (int)n_slices;
 	CHK(xfer_pool_init(c, W));
