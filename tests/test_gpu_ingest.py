@@ -242,6 +242,19 @@ def test_bench_shaped_steps_from_resident_records(case, tmpdir_s):
     qid = (host.hits["qns"] >> np.uint64(32)).astype(np.int64)
     for r, p in enumerate(parts):
         assert p.tobytes() == host.hits[(qid >= r * per) & (qid < (r + 1) * per)].tobytes()
+    # ... and mahip_hits_raw_extract_pos also says where each record of a range stood in the input (what an own-records rank hands to mahip_hits_set_positions)
+    L.mahip_hits_raw_extract_pos.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_size_t)]
+    for r in range(3):
+        sel = (qid >= r * per) & (qid < (r + 1) * per)
+        n = C.c_size_t(0)
+        keep_r, ptr_r = _dev_buffer(max(int(sel.sum()), 1) * 32)
+        keep_p, ptr_p = _dev_buffer(max(int(sel.sum()), 1) * 4)
+        ma._chk(L.mahip_hits_raw_extract_pos(ctx.h, min(r * per, n_seq), min((r + 1) * per, n_seq), vp(ptr_r), vp(ptr_p), C.byref(n)), "raw_extract_pos")
+        L.mahip_sync(ctx.h)
+        pos = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            ma._chk(L.mahip_memcpy_d2h(ctx.h, pos.ctypes.data, vp(ptr_p), n.value * 4), "d2h")
+        assert n.value == int(sel.sum()) and (pos == np.nonzero(sel)[0]).all()
     want, _ = R.run_cli(ma.CLI_PATH, [], paf)
     for step in range(3):
         ma._chk(L.mahip_hits_adopt(ctx.h, vp(ptr_all), len(all_recs), n_seq), "adopt")
