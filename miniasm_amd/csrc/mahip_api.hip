@@ -21,21 +21,103 @@ extern "C" int mahip_device_count(void)
 	return n;
 }
 
+// ---- device memory of a context ----
+// Freed buffers are kept and handed out again (first the smallest piece that fits, split when much is left over; neighbours of one allocation grow together
+// again) instead of going back to the driver: on part of the MI355X pool an allocation that reuses memory freed a moment ago waits for the driver to clear it at
+// ~8 GB/s -- the CLI releases the text and the parser's columns (60 GB at BASELINE configs[4]) and allocates the pipeline's buffers right after: 2 s in the first
+// coverage pass there, 0.2 s at 50 M overlaps, half of cfg4's 1.2 s end-to-end (profiles/r03_tiewalk.txt, tools/probes/alloc_probe.hip).  Everything runs on the
+// context's one stream, so a piece that changes hands is safe in stream order.  MA_DEV_POOL=0: plain hipMalloc / hipFree (the guard-page run of the CPU build).
+static bool pool_on() { static int v = -1; if (v < 0) { const char *e = getenv("MA_DEV_POOL"); v = !(e && atoi(e) == 0); } return v != 0; }
+
+static DevPool::Base *pool_base_of(DevPool &P, const char *p)
+{
+	for (DevPool::Base &b : P.bases) if (p >= b.p && p < b.p + b.bytes) return &b;
+	return nullptr;
+}
+
+static void pool_give_back(mahip_ctx *c, char *p, size_t cap)
+{
+	DevPool &P = c->pool;
+	DevPool::Base *base = pool_base_of(P, p);
+	if (!base) { (void)hipFree(p); return; } // (not from the pool: cannot happen)
+	DevPool::Piece nw = { p, cap, base->p };
+	for (size_t i = 0; i < P.free_pieces.size();) { // grow together with free neighbours of the same allocation
+		DevPool::Piece &f = P.free_pieces[i];
+		if (f.base == nw.base && (f.p + f.cap == nw.p || nw.p + nw.cap == f.p)) {
+			if (f.p < nw.p) nw.p = f.p;
+			nw.cap += f.cap;
+			P.free_pieces[i] = P.free_pieces.back(); P.free_pieces.pop_back();
+			i = 0; // the grown piece may now touch another one
+		} else ++i;
+	}
+	P.free_pieces.push_back(nw);
+}
+
+// whole allocations that are free go back to the driver (when the driver has nothing left to give)
+static void pool_trim(mahip_ctx *c)
+{
+	DevPool &P = c->pool;
+	for (size_t i = 0; i < P.free_pieces.size();) {
+		const DevPool::Piece f = P.free_pieces[i];
+		DevPool::Base *b = pool_base_of(P, f.p);
+		if (b && f.p == b->p && f.cap == b->bytes) {
+			(void)hipFree(b->p);
+			*b = P.bases.back(); P.bases.pop_back();
+			P.free_pieces[i] = P.free_pieces.back(); P.free_pieces.pop_back();
+		} else ++i;
+	}
+}
+
+static int pool_take(mahip_ctx *c, size_t want, void **out, size_t *cap)
+{
+	DevPool &P = c->pool;
+	size_t best = (size_t)-1;
+	for (size_t i = 0; i < P.free_pieces.size(); ++i)
+		if (P.free_pieces[i].cap >= want && (best == (size_t)-1 || P.free_pieces[i].cap < P.free_pieces[best].cap)) best = i;
+	if (best != (size_t)-1) {
+		DevPool::Piece &f = P.free_pieces[best];
+		*out = f.p;
+		if (f.cap - want >= ((size_t)1 << 20)) { *cap = want; f.p += want; f.cap -= want; }
+		else { *cap = f.cap; P.free_pieces[best] = P.free_pieces.back(); P.free_pieces.pop_back(); }
+		return 0;
+	}
+	void *p = nullptr;
+	hipError_t e = hipMalloc(&p, want);
+	if (e != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->st); pool_trim(c); e = hipMalloc(&p, want); }
+	if (e != hipSuccess) { mahip_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e)); return -1; }
+	P.bases.push_back({ (char*)p, want });
+	*out = p; *cap = want;
+	return 0;
+}
+
+void dev_pool_destroy(mahip_ctx *c)
+{
+	for (DevPool::Base &b : c->pool.bases) (void)hipFree(b.p);
+	c->pool.bases.clear(); c->pool.free_pieces.clear();
+}
+
 int dev_reserve(mahip_ctx *c, DevBuf &b, size_t bytes)
 {
 	if (bytes <= b.cap) return 0;
-	if (b.p) { HIPCHK(hipStreamSynchronize(c->st)); HIPCHK(hipFree(b.p)); c->mem_bytes -= b.cap; b.p = nullptr; b.cap = 0; }
+	if (b.p) { HIPCHK(hipStreamSynchronize(c->st)); dev_free(c, b); }
 	size_t want = (bytes + 255) & ~(size_t)255;
-	hipError_t e = hipMalloc(&b.p, want);
-	if (e != hipSuccess) { b.p = nullptr; mahip_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e)); return -1; }
-	b.cap = want;
-	c->mem_bytes += want;
+	if (pool_on()) {
+		if (pool_take(c, want, &b.p, &b.cap) != 0) { b.p = nullptr; b.cap = 0; return -1; }
+	} else {
+		hipError_t e = hipMalloc(&b.p, want);
+		if (e != hipSuccess) { b.p = nullptr; mahip_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e)); return -1; }
+		b.cap = want;
+	}
+	c->mem_bytes += b.cap;
 	return 0;
 }
 
 void dev_free(mahip_ctx *c, DevBuf &b)
 {
-	if (b.p) { (void)hipFree(b.p); c->mem_bytes -= b.cap; }
+	if (b.p) {
+		c->mem_bytes -= b.cap;
+		if (pool_on()) pool_give_back(c, (char*)b.p, b.cap); else (void)hipFree(b.p);
+	}
 	b.p = nullptr; b.cap = 0;
 }
 
@@ -172,6 +254,7 @@ extern "C" void mahip_destroy(mahip_ctx_t *c)
 	ug_free(c);
 	useq_free(c);
 	xfer_pool_free(c);
+	dev_pool_destroy(c); // after everybody gave its buffers back
 	if (c->h_ctr) (void)hipHostFree(c->h_ctr);
 	if (c->own_stream) (void)hipStreamDestroy(c->st);
 	delete c;

@@ -26,6 +26,14 @@ struct DevBuf {
 struct ProfEvent { const char *name; hipEvent_t a, b; double alg_bytes; };
 struct ProfAcc { const char *name; uint64_t launches; double ms; double alg_bytes; };
 
+// device memory that DevBufs gave back, kept for the next one that asks (mahip_api.hip: dev_reserve / dev_free)
+struct DevPool {
+	struct Base { char *p; size_t bytes; };             // what hipMalloc returned
+	struct Piece { char *p; size_t cap; char *base; };  // a free stretch of one of them
+	std::vector<Base> bases;
+	std::vector<Piece> free_pieces;
+};
+
 // big pageable host arrays of the tie walk (radix.hip)
 struct BigHost { void *p = nullptr; size_t bytes = 0; bool mapped = false; bool reserve(size_t n); void drop(); };
 
@@ -34,6 +42,7 @@ struct mahip_ctx {
 	hipStream_t st = nullptr;
 	bool own_stream = false;
 	size_t mem_bytes = 0;
+	DevPool pool;
 
 	// ---- hits ----
 	size_t n_hits = 0;        // slots (live + dead)

@@ -54,7 +54,7 @@ def test_kernels_with_reversed_schedule_and_guard_pages(emu_built):
     """the same kernels with lanes, waves and blocks executed in DESCENDING order (code that leans on lock-step execution or on launch order
     without a barrier breaks) and every device allocation ending at a faulting page (an out-of-bounds access crashes)"""
     run_gpu_tests(["tests/test_gpu_parity.py", "-k", "noisy or deep_groups or sort_random", "tests/test_gpu_ingest.py"], 3000,
-                  {"EMU_ORDER": "reverse", "EMU_GUARD": "1"})
+                  {"EMU_ORDER": "reverse", "EMU_GUARD": "1", "MA_DEV_POOL": "0"})  # (the pool hands out pieces of bigger allocations: no guard page behind them)
 
 
 def test_kernels_graph_api_on_cpu(emu_built):

@@ -93,6 +93,13 @@ bubtune)
     echo "## tie-rich [${v:-default}]"; env $v MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm /tmp/twrich.paf 2> gpurun_out/bubtune.log | md5sum; grep -E "device cleaners" gpurun_out/bubtune.log; done
   for v in "" "MA_BUBBLE_THREADS0=131072" "MA_BUBBLE_THREADS0=524288" "MA_BUBBLE_CAP0=16 MA_BUBBLE_CAP1=1024 MA_BUBBLE_THREADS0=524288" "MA_BUBBLE_CAP0=64 MA_BUBBLE_CAP1=1024" ""; do
     echo "## [${v:-default}]"; env $v MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm /tmp/tw50.paf 2> gpurun_out/bubtune.log | md5sum; grep -E "device cleaners" gpurun_out/bubtune.log; done ;;
+poolab)
+  # the context's device-memory pool (freed buffers handed out again) against plain hipMalloc / hipFree: CLI runs, wall and the phases that allocate
+  miniasm_amd/bin/pafgen -r 2000000 -n 100000000 -s 2 -o /tmp/cfg4.paf 2>/dev/null
+  [ -f /tmp/tw50.paf ] || miniasm_amd/bin/pafgen -r 1000000 -n 50000000 -s 3 -L uniform -d 0.35 -x 0.03 -o /tmp/tw50.paf 2>/dev/null
+  for f in /tmp/cfg4.paf /tmp/tw50.paf; do for v in 1 0 1 0; do
+    t0=$(date +%s.%N); MA_DEV_POOL=$v MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm $f 2> gpurun_out/poolab.log | md5sum | cut -c1-12; t1=$(date +%s.%N)
+    python3 -c "print(\"## $f MA_DEV_POOL=$v: %.3f s wall\" % ($t1 - $t0))"; grep -E "hipMalloc of the text|T::head\] (sort|sub #1) |Real time" gpurun_out/poolab.log | tr '\n' ' '; echo; done; done ;;
 walkprobe)
   # the walk's dependent chain alone on this box's CPU (tools/probes/walk_probe.c): forms x bucket counts x page size
   gcc -O2 -o /tmp/walk_probe tools/probes/walk_probe.c && for nb in 4 16 77; do for form in 0 3 5 1; do for thp in 0 1; do /tmp/walk_probe 100000000 $nb $form $thp; done; done; done 2>&1 | tee gpurun_out/walk_probe.txt ;;
