@@ -292,7 +292,8 @@ void walk_scratch_release(mahip_ctx *c)
 	BigHost a = c->hwalk, b = c->hdig;
 	c->hwalk = BigHost(); c->hdig = BigHost();
 	if (a.bytes + b.bytes < ((size_t)32 << 20)) { a.drop(); b.drop(); return; }
-	std::thread([a, b]() mutable { a.drop(); b.drop(); }).detach();
+	try { std::thread([a, b]() mutable { a.drop(); b.drop(); }).detach(); }
+	catch (...) { a.drop(); b.drop(); } // no thread to be had: here and now
 }
 
 // d_perm[j] <- input position of the j-th record in the reference's order.  d_keys is overwritten.
