@@ -28,6 +28,7 @@ static int rs_timing = -1;
 #define RS_T0 double t0_ = rs_now()
 #define RS_LAP(what) do { if (rs_timing < 0) rs_timing = getenv("MA_REFSORT_TIMING") != 0; if (rs_timing) { double t1_ = rs_now(); fprintf(stderr, "[T::refsort] %-12s %.3f s\n", what, t1_ - t0_); t0_ = t1_; } } while (0)
 
+#define RS_MAX_THREADS 128
 #define RS_SMALL 64           /* RS_MIN_SIZE ksort.h:132 */
 /* The walk touches the 256 bucket heads in an order the hardware prefetchers cannot follow (they track a few dozen streams), so every
  * new cache line of a bucket used to be a miss on the walk's dependent chain; each store now asks for the line a few ahead of its head. */
@@ -92,10 +93,10 @@ typedef struct { const void *a; const rs_cfg_t *cfg; size_t beg, end; int shift;
 static uint64_t sweep_run(void *(*worker)(void*), const void *a, size_t n, int shift, size_t *cnt, const rs_cfg_t *cfg, int n_threads, uint8_t *dig)
 {
 	sweep_t *w;
-	pthread_t th[64];
+	pthread_t th[RS_MAX_THREADS];
 	uint64_t diff = 0;
 	int t, k;
-	if (n_threads > 64) n_threads = 64;
+	if (n_threads > RS_MAX_THREADS) n_threads = RS_MAX_THREADS;
 	if (n_threads < 1) n_threads = 1;
 	w = (sweep_t*)malloc(sizeof(sweep_t) * n_threads);
 	for (t = 0; t < n_threads; ++t) w[t].a = a, w[t].cfg = cfg, w[t].shift = shift, w[t].dig = dig, w[t].diff = 0, w[t].beg = n / n_threads * t, w[t].end = t == n_threads - 1 ? n : n / n_threads * (t + 1);
@@ -182,10 +183,10 @@ static void *fill_worker(void *arg)
 
 static void fill_run(fill_t *proto, size_t n, int phase, int n_threads)
 {
-	fill_t f[64];
-	pthread_t th[64];
+	fill_t *f = (fill_t*)malloc(sizeof(fill_t) * RS_MAX_THREADS); /* (2 KB each) */
+	pthread_t th[RS_MAX_THREADS];
 	int t;
-	if (n_threads > 64) n_threads = 64;
+	if (n_threads > RS_MAX_THREADS) n_threads = RS_MAX_THREADS;
 	if (n < (1u << 20) || n_threads < 2) n_threads = 1;
 	for (t = 0; t < n_threads; ++t) {
 		f[t] = *proto; f[t].phase = phase;
@@ -197,6 +198,7 @@ static void fill_run(fill_t *proto, size_t n, int phase, int n_threads)
 	if (phase == 0) { proto->mhi = proto->mlo = 0; for (t = 0; t < n_threads; ++t) { if (f[t].mhi > proto->mhi) proto->mhi = f[t].mhi; if (f[t].mlo > proto->mlo) proto->mlo = f[t].mlo; } }
 	if (phase == 5) { proto->diff = 0; for (t = 0; t < n_threads; ++t) proto->diff |= f[t].diff; }
 	if (phase == 6 || phase == 7) { int k; memset(proto->cnt, 0, sizeof(proto->cnt)); for (t = 0; t < n_threads; ++t) for (k = 0; k < 256; ++k) proto->cnt[k] += f[t].cnt[k]; }
+	free(f);
 }
 
 static int bits_of64(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
@@ -207,7 +209,7 @@ static int refsort_threads(void)
 	const char *s = getenv("MA_THREADS");
 	long n = s ? atol(s) : sysconf(_SC_NPROCESSORS_ONLN);
 	if (!s && n > 64) n = 64; /* (32 until round 3: at BASELINE configs[4] the buckets below the top level were 1.4 s on 32 threads of the GPU box's 256 cores) */
-	return n < 1 ? 1 : n > 64 ? 64 : (int)n;
+	return n < 1 ? 1 : n > RS_MAX_THREADS ? RS_MAX_THREADS : (int)n;
 }
 
 int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm)

@@ -260,7 +260,7 @@ static void RS_NAME(sort_from_top)(RS_T *a, size_t n, const rs_cfg_t *cfg, int n
 	p.cfg = *cfg; p.run = RS_NAME(task); p.elem = sizeof(RS_T);
 	pthread_mutex_init(&p.mu, 0);
 	pthread_cond_init(&p.cv, 0);
-	if (n_threads > 64) n_threads = 64;
+	if (n_threads > RS_MAX_THREADS) n_threads = RS_MAX_THREADS;
 	p.n_threads = n_threads;
 	{
 		RS_T0;
@@ -294,7 +294,7 @@ static void RS_NAME(sort)(RS_T *a, size_t n, const rs_cfg_t *cfg, int n_threads)
 		size_t cnt[256];
 		int shift = 56;
 		uint64_t diff;
-		if (n_threads > 64) n_threads = 64;
+		if (n_threads > RS_MAX_THREADS) n_threads = RS_MAX_THREADS;
 		/* the top level: its two sweeps (which bits vary; the digit counts) run on all threads, only the walk itself is sequential */
 		RS_T0;
 		diff = sweep_run(RS_NAME(sweep_worker), a, n, -1, 0, cfg, n_threads, 0);

@@ -100,6 +100,12 @@ poolab)
   for f in /tmp/cfg4.paf /tmp/tw50.paf; do for v in 1 0 1 0; do
     t0=$(date +%s.%N); MA_DEV_POOL=$v MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm $f 2> gpurun_out/poolab.log | md5sum | cut -c1-12; t1=$(date +%s.%N)
     python3 -c "print(\"## $f MA_DEV_POOL=$v: %.3f s wall\" % ($t1 - $t0))"; grep -E "hipMalloc of the text|T::head\] (sort|sub #1) |Real time" gpurun_out/poolab.log | tr '\n' ' '; echo; done; done ;;
+walkthreads)
+  # threads of the tie walk's lower levels (MA_THREADS; default min(cores, 64)) against the `buckets` lap, 50 M noisy and (TIEWALK_CFG5=1) BASELINE configs[4]
+  [ -f /tmp/tw50.paf ] || miniasm_amd/bin/pafgen -r 1000000 -n 50000000 -s 3 -L uniform -d 0.35 -x 0.03 -o /tmp/tw50.paf 2>/dev/null
+  [ -z "$TIEWALK_CFG5" ] || [ -f /tmp/tw5.paf ] || miniasm_amd/bin/pafgen -r 5000000 -n 500000000 -s 3 -L uniform -d 0.35 -x 0.03 -o /tmp/tw5.paf 2>/dev/null
+  for f in /tmp/tw50.paf ${TIEWALK_CFG5:+/tmp/tw5.paf}; do for t in 64 128 96 64; do
+    echo "## $f MA_THREADS=$t"; MA_THREADS=$t MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 900 miniasm_amd/bin/miniasm $f 2>&1 >/dev/null | grep -E "top walk|buckets|sg_gen|Real time" | head -4 | tr '\n' ' '; echo; done; done ;;
 walkprobe)
   # the walk's dependent chain alone on this box's CPU (tools/probes/walk_probe.c): forms x bucket counts x page size
   gcc -O2 -o /tmp/walk_probe tools/probes/walk_probe.c && for nb in 4 16 77; do for form in 0 3 5 1; do for thp in 0 1; do /tmp/walk_probe 100000000 $nb $form $thp; done; done; done 2>&1 | tee gpurun_out/walk_probe.txt ;;
