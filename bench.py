@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--lines", type=int, default=100000000)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--model", default="lognormal", choices=["lognormal", "fixed", "uniform"])
+    ap.add_argument("--grid", type=int, default=0, help="pafgen -q: coordinates on a grid -> equal sort keys (tie-rich input; not the BASELINE workload)")
     ap.add_argument("--workdir", default=os.environ.get("MA_BENCH_DIR", "/tmp/ma_bench"))
     ap.add_argument("--no-cpu", action="store_true", help="skip the reference run (no cpu_baseline, no gfa_identical)")
     ap.add_argument("--no-text", action="store_true", help="skip the text-resident leg (device-side parse inside the step)")
@@ -205,7 +206,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=1, help="experiment: batches in flight on the one GPU (each on its own context and host thread)")
     args = ap.parse_args()
     args.tail_ctx = not args.no_tail_ctx
-    args.gen_extra = [] if args.model == "lognormal" else ["-L", args.model]
+    args.gen_extra = ([] if args.model == "lognormal" else ["-L", args.model]) + (["-q", str(args.grid), "-d", "0.3", "-x", "0.03"] if args.grid else [])
     cfg_name = {(2000000, 100000000, 2, "lognormal"): "cfg4", (200000, 10000000, 1, "lognormal"): "cfg2"}.get((args.reads, args.lines, args.seed, args.model), "custom")
 
     import torch
@@ -239,7 +240,7 @@ def main():
     L.sys_init()
 
     t0 = time.perf_counter()
-    paf = os.path.join(args.workdir, "w_%s_r%d_n%d_s%d.paf" % (args.model, args.reads, args.lines, args.seed))
+    paf = os.path.join(args.workdir, "w_%s%s_r%d_n%d_s%d.paf" % (args.model, "_q%d" % args.grid if args.grid else "", args.reads, args.lines, args.seed))
     if rank == 0:
         gen_paf(paf, args.reads, args.lines, args.seed, args.gen_extra)
     if world > 1:

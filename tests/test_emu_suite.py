@@ -124,7 +124,8 @@ def test_bench_py_runs_on_the_cpu_build(mode, emu_built, tmp_path):
     assert all(k["alg_GBs"] is None for k in d["kernels"] if k["name"] in ("k_hit_keys", "k_radix_scatter", "k_radix_hist", "k_hit_goff"))
 
 
-def test_bench_py_on_two_ranks_on_the_cpu_build(emu_built, tmp_path):
+@pytest.mark.parametrize("grid", [0, 16])
+def test_bench_py_on_two_ranks_on_the_cpu_build(grid, emu_built, tmp_path):
     """`bench.py --gpus 2` as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* in the environment), on the CPU build:
     the control plane is a file-based stand-in for torch.distributed, the collectives go through the shared-memory double
     (MA_BENCH_ONE_GPU_DEBUG, the hook bench.py has for one-GPU boxes), rank 0 runs its tail on a second context.  A one-rank run first leaves
@@ -137,10 +138,13 @@ def test_bench_py_on_two_ranks_on_the_cpu_build(emu_built, tmp_path):
     env["MINIASM_AMD_LIB"] = os.path.join(EMU, "_build", "libminiasm_amd_emu.so")
     env["MA_BENCH_DIR"] = str(tmp_path)
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "2500", "--lines", "70000", "--seed", "5", "--steps", "2", "--warmup", "1"]
+    if grid:  # a tie-rich input: the ranks (which hold only their own records, and say where they stood in the input) have to restore the reference's order of tied hits
+        base += ["--grid", str(grid), "--model", "uniform", "--reads", "3000", "--lines", "80000"]
     r = subprocess.run(base + ["--no-legs", "--no-text"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
     assert r.returncode == 0, r.stderr[-3000:]
     one = json.loads(r.stdout.strip().splitlines()[-1])
     assert one["gfa_identical"] is True
+    assert (one["tie_groups"] > 0) == bool(grid)
     procs = []
     for rank in range(2):
         e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(20000 + os.getpid() % 20000),
@@ -160,6 +164,7 @@ def test_bench_py_on_two_ranks_on_the_cpu_build(emu_built, tmp_path):
     d = json.loads(outs[0].strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["gfa_identical"] is True and d["parity"]["gfa_md5"] == one["parity"]["ref_md5"]
+    assert d["tie_groups"] == one["tie_groups"] and (not grid or "hit walk" in d["tie_path"])  # tie-rich: both walks ran on the shards too
     assert d["config"]["global_overlaps"] == one["config"]["global_overlaps"] and d["config"]["per_gpu_hits"] < one["config"]["per_gpu_hits"]
     ph = d["phases"]  # where a sharded step spends its time: one entry per phase of host/sharded.c, [max, min] over the ranks
     assert set(ph["phase_ms"]) >= {"sort", "sub#1", "x:sub0", "x:arc blocks", "rank 0: cleanup+symm"} and all(len(v) == 2 and v[0] >= v[1] >= 0 for v in ph["phase_ms"].values())
