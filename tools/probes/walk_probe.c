@@ -1,7 +1,7 @@
 /* walk_probe.c -- the dependent chain of host/refsort_body.h's top-level walk, alone: ns per element for a few forms of the loop, bucket counts
  * and page sizes, on the host CPU of the box (gcc -O2 -o walk_probe walk_probe.c; tools/gpu_round.sh walkprobe).
  * forms: 0 = ksort.h's two loops with the next digit kept per bucket (permute_top), 1 = the same without moving elements (the chain alone),
- *        3 = one loop, read + write position per bucket (permute_uniform), 5 = 3 + software prefetch of the digit stream. */
+ *        3 = one loop, read + write position per bucket (permute_uniform), 5 = 3 + software prefetch of the digit stream, 6 = 0 + that prefetch. */
 #define _GNU_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
@@ -39,7 +39,7 @@ int main(int argc, char **argv)
 	start[0] = 0;
 	for (k = 0; k < 256; ++k) { start[k + 1] = start[k] + cnt[k]; b[k].head = start[k]; b[k].nd = dig[start[k]]; }
 	t0 = now();
-	if (form == 0 || form == 1) {
+	if (form == 0 || form == 1 || form == 6) {
 		for (k = 0; k < 256;) {
 			unsigned d;
 			if (b[k].head == start[k + 1]) { ++k; continue; }
@@ -50,10 +50,11 @@ int main(int argc, char **argv)
 				do {
 					const size_t slot = b[d].head; const unsigned dn = b[d].nd;
 					b[d].head = slot + 1; b[d].nd = dig[slot + 1];
-					if (form == 0) { const T ev = a[slot]; a[slot] = carry; __builtin_prefetch((char*)&a[slot] + 256, 1, 3); carry = ev; }
+					if (form == 6) __builtin_prefetch(dig + slot + 129, 0, 3);
+					if (form != 1) { const T ev = a[slot]; a[slot] = carry; __builtin_prefetch((char*)&a[slot] + 256, 1, 3); carry = ev; }
 					d = dn; ++steps;
 				} while (d != (unsigned)k);
-				if (form == 0) a[b[k].head] = carry;
+				if (form != 1) a[b[k].head] = carry;
 				b[k].nd = dig[++b[k].head];
 			}
 		}
