@@ -123,6 +123,7 @@ static void RS_NAME(permute_top)(rs_pool_t *pool, RS_T *a, const size_t *cnt, co
 				const RS_T evicted = a[slot];
 				b[d].head = slot + 1;
 				b[d].nd = dig[slot + 1];
+				__builtin_prefetch(dig + slot + 129); /* (2.37 -> 2.17 ns per element with 16 buckets on the GPU box's EPYC, tools/probes/walk_probe.c forms 0 / 6) */
 				a[slot] = carry;
 				RS_PREFETCH(&a[slot]);
 				carry = evicted;
