@@ -243,6 +243,26 @@ def packed_order(LP, keys):
     return (pk & np.uint64((1 << bi) - 1)).astype(np.uint32)
 
 
+def test_refsort_packed_rejects_what_it_cannot_sort():
+    """ma_refsort_packed's contract (host/refsort.c): bit counts in range, the top digit apart only with its digit array, at a multiple of 8 at or above
+    bit 32, with room for the rest in the word, and never for <= 64 records (the reference sorts those by insertion: ksort.h:182)"""
+    LP = ma.lib()
+    LP.ma_refsort_packed.restype = C.c_int
+    LP.ma_refsort_packed.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    pk = np.arange(1000, dtype=np.uint64)[::-1].copy()
+    dig = np.zeros(1016, dtype=np.uint8)
+    assert LP.ma_refsort_packed(pk.ctypes.data, 1, 10, 10, -1, None) == 0 and LP.ma_refsort_packed(pk.ctypes.data, 0, 10, 10, -1, None) == 0
+    for bl, bi, st, d in ((0, 10, -1, None), (33, 10, -1, None), (10, 0, -1, None), (10, 33, -1, None),  # bit counts
+                          (10, 10, 40, None), (10, 10, 24, dig), (10, 10, 36, dig), (32, 32, 40, dig)):  # no digits / below bit 32 / not a multiple of 8 / no room
+        assert LP.ma_refsort_packed(pk.ctypes.data, 1000, bl, bi, st, d.ctypes.data if d is not None else None) == -1, (bl, bi, st)
+    assert LP.ma_refsort_packed(pk.ctypes.data, 64, 10, 10, 40, dig.ctypes.data) == -1
+    assert (pk == np.arange(1000, dtype=np.uint64)[::-1]).all(), "a rejected call must not touch the array"
+    keys = np.arange(1000, dtype=np.uint64)[::-1].copy()  # (and one that is accepted: key above position, 10 + 10 bits)
+    pk = (keys << np.uint64(10)) | np.arange(1000, dtype=np.uint64)
+    assert LP.ma_refsort_packed(pk.ctypes.data, 1000, 10, 10, -1, None) == 0
+    assert ((pk >> np.uint64(10)) == np.arange(1000, dtype=np.uint64)).all()
+
+
 @needs_ref
 @pytest.mark.parametrize("threads", ["1", "8"])
 def test_refsort_perm_matches_reference_sort(threads, monkeypatch):
