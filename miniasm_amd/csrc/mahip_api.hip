@@ -162,16 +162,6 @@ int ctr_fetch(mahip_ctx *c)
 #include <sched.h>
 #include <ctype.h>
 #include <dirent.h>
-static cpu_set_t g_cpus_before_pin;
-static int g_cpus_before_pin_valid = 0;
-// The CPUs the process could use before it was narrowed to the GPU's NUMA node: host work that is compute, not staging -- the lower levels of the tie walk
-// (host/refsort.c) -- spreads over them again (on the GPU box the GPU's node is 16 cores of 128).  0 = the affinity was never narrowed.
-extern "C" int mahip_cpus_before_pin(void *set, size_t bytes)
-{
-	if (!g_cpus_before_pin_valid || bytes < sizeof(cpu_set_t)) return 0;
-	memcpy(set, &g_cpus_before_pin, sizeof(cpu_set_t));
-	return CPU_COUNT(&g_cpus_before_pin);
-}
 static void pin_to_gpu_node(int device)
 {
 	static int done = 0;
@@ -207,7 +197,6 @@ static void pin_to_gpu_node(int device)
 	if (n_set == 0 || sched_getaffinity(0, sizeof(have), &have) != 0) return;
 	CPU_AND(&want, &want, &have); // never widen what the launcher allowed
 	if (CPU_COUNT(&want) == 0) return;
-	if (CPU_COUNT(&want) < CPU_COUNT(&have)) { g_cpus_before_pin = have; g_cpus_before_pin_valid = 1; }
 	DIR *dp = opendir("/proc/self/task"); // every thread that exists now (the context may be created on a helper thread); later ones inherit
 	if (!dp) { (void)sched_setaffinity(0, sizeof(want), &want); return; }
 	for (struct dirent *de; (de = readdir(dp)) != nullptr;) {

@@ -16,8 +16,6 @@
  * at the bits that vary in the range.  Own implementation (index based); pinned against the reference build by
  * tests/test_host_vs_ref.py::test_refsort_perm_matches_reference_sort.
  */
-#define _GNU_SOURCE
-#include <sched.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -51,7 +49,7 @@ typedef struct rs_pool_s {
 	pthread_cond_t cv;
 	rs_task_t *q;
 	size_t nq, mq, elem;
-	int busy, n_threads, spread;
+	int busy, n_threads;
 	rs_cfg_t cfg;
 	void (*run)(struct rs_pool_s*, void*, size_t, int);
 } rs_pool_t;
@@ -69,20 +67,9 @@ static void pool_push(rs_pool_t *p, void *a, size_t n, int shift)
 	pthread_mutex_unlock(&p->mu);
 }
 
-/* The process is kept on the GPU's NUMA node for the staging copies (csrc/mahip_api.hip); the levels below the top of a big walk are compute on independent
- * ranges and want every core there is: their workers go back to the CPUs the process had before.  MA_REFSORT_SPREAD=0: stay on the node. */
-extern int mahip_cpus_before_pin(void *set, size_t bytes);
-static int rs_spread_cpus(cpu_set_t *set)
-{
-	static int on = -1;
-	if (on < 0) { const char *e = getenv("MA_REFSORT_SPREAD"); on = !(e && atoi(e) == 0); }
-	return on ? mahip_cpus_before_pin(set, sizeof(*set)) : 0;
-}
-
 static void *pool_worker(void *arg)
 {
 	rs_pool_t *p = (rs_pool_t*)arg;
-	if (p->spread) { cpu_set_t all; if (rs_spread_cpus(&all) > 0) (void)sched_setaffinity(0, sizeof(all), &all); }
 	pthread_mutex_lock(&p->mu);
 	for (;;) {
 		while (p->nq == 0 && p->busy > 0) pthread_cond_wait(&p->cv, &p->mu);
@@ -221,12 +208,7 @@ static int refsort_threads(void)
 {
 	const char *s = getenv("MA_THREADS");
 	long n = s ? atol(s) : sysconf(_SC_NPROCESSORS_ONLN);
-	if (!s) {
-		cpu_set_t all;
-		const int wide = rs_spread_cpus(&all);
-		if (wide >= 128) n = wide / 2; /* the workers spread over the machine again: about a thread per core */
-		else if (n > 64) n = 64;
-	} /* (32 until round 3: at BASELINE configs[4] the buckets below the top level were 1.4 s on 32 threads of the GPU box's 256 cores) */
+	if (!s && n > 64) n = 64; /* (32 until round 3: at BASELINE configs[4] the buckets below the top level were 1.4 s on 32 threads of the GPU box's 256 cores) */
 	return n < 1 ? 1 : n > RS_MAX_THREADS ? RS_MAX_THREADS : (int)n;
 }
 

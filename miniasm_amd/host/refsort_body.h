@@ -262,7 +262,7 @@ static void RS_NAME(sort_from_top)(RS_T *a, size_t n, const rs_cfg_t *cfg, int n
 	pthread_mutex_init(&p.mu, 0);
 	pthread_cond_init(&p.cv, 0);
 	if (n_threads > RS_MAX_THREADS) n_threads = RS_MAX_THREADS;
-	p.n_threads = n_threads; p.spread = 1;
+	p.n_threads = n_threads;
 	{
 		RS_T0;
 		th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
