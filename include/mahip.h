@@ -268,8 +268,13 @@ int mahip_prof_get(mahip_ctx_t *c, mahip_prof_t *out, int max);
 /* phase marks: an event on the stream per slot (0..63); after a sync, ms[i] = time from mark first+i to mark first+i+1 (0 if either is missing) */
 int mahip_mark(mahip_ctx_t *c, int slot);
 int mahip_marks_ms(mahip_ctx_t *c, int first, int n, float *ms);
-/* bytes of HBM currently held by the context */
+/* bytes of HBM currently held by the context: buffers in use + what its pool keeps idle for the next request */
 size_t mahip_mem_bytes(mahip_ctx_t *c);
+/* the idle part alone, and a way to hand it back to the driver (whole free allocations; waits for the context's stream).  A context whose
+ * allocation fails trims itself and the process's other contexts on the same GPU on its own; other PROCESSES that share the GPU
+ * (MA_COMM=shm ranks) are what this call is for: the sharded head calls it at its end.  released (optional) = bytes returned. */
+size_t mahip_mem_pool_bytes(mahip_ctx_t *c);
+int mahip_mem_trim(mahip_ctx_t *c, size_t *released);
 /* device pointers for multi-GPU exchanges done outside (RCCL via torch.distributed): which = MAHIP_PTR_* */
 #define MAHIP_PTR_SUB0    0
 #define MAHIP_PTR_SUB1    1

@@ -38,6 +38,7 @@ void     sd_destroy(sdict_t *d);                                /* sdict.h:22 */
 int32_t  sd_put(sdict_t *d, const char *name, uint32_t len);    /* sdict.h:23 : ids dense, in first-appearance order */
 int32_t  sd_get(const sdict_t *d, const char *name);            /* sdict.h:24 : -1 if absent */
 int32_t *sd_squeeze(sdict_t *d);                                /* sdict.h:25 : returns calloc'ed old->new map (-1 dropped) */
+void sd_hash(sdict_t *d);                                       /* sdict.c:55 (no header declares it): build the name index if it is not there */
 
 /* ------------------------------------------------------------------ PAF reader (paf.h:20-32) */
 
@@ -52,6 +53,7 @@ typedef struct {                                                /* paf.h:20-24 *
 paf_file_t *paf_open(const char *fn);                           /* paf.h:30 : plain, gz, or "-" for stdin */
 int paf_close(paf_file_t *pf);                                  /* paf.h:31 */
 int paf_read(paf_file_t *pf, paf_rec_t *r);                     /* paf.h:32 : <0 at EOF; lines with <10 fields skipped */
+int paf_parse(int l, char *s, paf_rec_t *pr);                   /* paf.c:34 (no header declares it): one NUL-terminated line, split in place; <0 = fewer than 10 columns */
 
 /* ------------------------------------------------------------------ timers (sys.h:8-11) */
 
@@ -59,6 +61,7 @@ double sys_cputime(void);
 double sys_realtime(void);
 void   sys_init(void);
 const char *sys_timestamp(void);
+void   sys_liftrlimit(void);                                    /* sys.c:22 (no header declares it): RLIMIT_AS soft limit := hard limit */
 
 /* ------------------------------------------------------------------ string graph (asg.h:7-42) */
 

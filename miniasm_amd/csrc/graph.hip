@@ -579,7 +579,7 @@ static int push_order(mahip_ctx *c, size_t m, bool exact, int *gen)
 	tl.lap("stable push order + conflicts");
 	c->tie.push_conflicts = conf;
 	if (exact && conf) {
-		CHK(hits_reference_rank(c)); // uses key[]/val[] as scratch
+		CHK(hits_reference_rank(c, false)); // uses key[]/val[] as scratch
 		for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }
 		hipLaunchKernelGGL(k_arc_push_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->aslot), (const uint32_t*)P<uint32_t>(c->hrank), m,
 		                   P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
@@ -770,7 +770,7 @@ extern "C" int mahip_sg_push_fix(mahip_ctx_t *c)
 	HIPCHK(hipSetDevice(c->dev));
 	const size_t m = c->n_push;
 	if (m < 2) return 0;
-	CHK(hits_reference_rank(c));
+	CHK(hits_reference_rank(c, true)); // the one entry that may run the ranks' collective form
 	for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }
 	CHK(dev_reserve(c, c->pushrows[1], (m + 1) * 16));
 	hipLaunchKernelGGL(k_arc_push_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->aslot), (const uint32_t*)P<uint32_t>(c->hrank), m, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));

@@ -860,6 +860,7 @@ static int hits_common_setup(mahip_ctx *c, size_t n, uint32_t n_seq)
 	c->lazy_squeeze = false;
 	c->sorted_here = false; c->hrank_ready = false; c->orank_ready = false;
 	c->n_total = 0; // positions describe one upload, like the hints
+	if (!c->shard_bounds.empty() && c->shard_bounds.back() != n_seq) c->shard_bounds.clear(); // a table of read ranges made for another dictionary (the same input adopted again keeps it)
 	memset(&c->tie, 0, sizeof(c->tie));
 	CHK(reserve_read_arrays(c));
 	for (int k = 0; k < 8; ++k) CHK(dev_reserve(c, c->col[k], (n + 128) * 4)); // + spare slots (k_hit_sub gather mode: lanes without a slot)
@@ -1115,13 +1116,14 @@ static int hits_reference_rank_global(mahip_ctx *c)
 
 // c->hrank[slot] = position of the slot's record in the order the reference's ma_hit_sort (hit.c:19-22) leaves the input in.
 // Both orders are sorted by key, so hrank is the identity outside runs of equal keys.
-int hits_reference_rank(mahip_ctx *c)
-{
+int hits_reference_rank(mahip_ctx *c, bool collective_ok)
+{ // collective_ok: the caller is the orchestrated tie repair (mahip_sg_push_fix, which host/sharded.c enters on ALL ranks after an all-reduce);
+	// any other way in must not start a collective one rank alone would wait in for ever
 	if (c->hrank_ready) return 0;
 	const size_t n = c->n_hits, N = c->n_in; // slots of this context / records of the input
 	if (!c->sorted_here || !c->sidx.p || !c->d_aos) { mahip_set_error("hits_reference_rank: the hits were not sorted by this context"); return -1; }
 	if (ctx_sharded(c) && !c->full_input) {
-		if (c->n_total == 0 || !c->comm) { mahip_set_error("hits_reference_rank: the reference's tie order is a function of the whole input; this context only holds a shard of it (and no positions: mahip_hits_set_positions)"); return -1; }
+		if (c->n_total == 0 || !c->comm || !collective_ok) { mahip_set_error("hits_reference_rank: the reference's tie order is a function of the whole input; this context only holds a shard of it (%s)", c->n_total == 0 || !c->comm ? "and no positions: mahip_hits_set_positions" : "the ranks put their keys together only inside the sharded head's tie repair"); return -1; }
 		CHK(dev_reserve(c, c->hrank, (n + 1) * 4));
 		CHK(hits_reference_rank_global(c)); // collective: every rank gets here together (host/sharded.c decides on all-reduced counters)
 		c->hrank_ready = true;
@@ -1191,7 +1193,7 @@ static int hits_order_rank(mahip_ctx *c, const uint32_t **rank)
 			if (c->tie_mode == 1) { mahip_set_error("mahip_hits_download: exact tie order is not available on a shard"); return -1; }
 			c->tie.unrepaired = 1;
 		} else {
-			CHK(hits_reference_rank(c));
+			CHK(hits_reference_rank(c, false));
 			*rank = P<uint32_t>(c->hrank);
 			return 0;
 		}
@@ -1249,6 +1251,12 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	if (sharded) { // this context only keeps the hits whose query read lies in its range
 		CHK(ctr_fetch(c));
 		size_t n_in = (size_t)c->h_ctr[CT_LIVE];
+		if (n_in < n && c->n_total) { // a rank that was handed "its own records" (mahip_hits_set_positions) holds records of somebody else's reads: the read
+			// range is not the one the records were selected by -- e.g. a table of bounds left in the context by an earlier input.  Dropping them
+			// silently would lose hits on every rank.
+			mahip_set_error("mahip_hits_sort: %zu of the %zu records handed to this rank as its own lie outside its read range [%u, %u): stale shard bounds?", n - n_in, n, c->q_beg, c->q_end);
+			return -1;
+		}
 		if (n_in < n) {
 			CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), n, nullptr));
 			hipLaunchKernelGGL(k_key_compact, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[0]), (const uint32_t*)nullptr,
@@ -1311,7 +1319,18 @@ struct SubFork {
 	hipStream_t side[2]; hipEvent_t start, done[2];
 	SubFork(mahip_ctx *c_) : c(c_), on(true) {
 		if (!on) return;
-		if (!c->sub_side[0]) { for (int k = 0; k < 2; ++k) (void)hipStreamCreateWithFlags(&c->sub_side[k], hipStreamNonBlocking); for (int k = 0; k < 3; ++k) (void)hipEventCreateWithFlags(&c->sub_ev[k], hipEventDisableTiming); }
+		if (!c->sub_side[0] && !c->sub_fork_failed) { // streams and events are made once per context; if any of them cannot be had, all three size classes run on the context's stream
+			bool ok = true;
+			for (int k = 0; k < 2 && ok; ++k) ok = hipStreamCreateWithFlags(&c->sub_side[k], hipStreamNonBlocking) == hipSuccess;
+			for (int k = 0; k < 3 && ok; ++k) ok = hipEventCreateWithFlags(&c->sub_ev[k], hipEventDisableTiming) == hipSuccess;
+			if (!ok) {
+				(void)hipGetLastError();
+				for (int k = 0; k < 2; ++k) if (c->sub_side[k]) { (void)hipStreamDestroy(c->sub_side[k]); c->sub_side[k] = nullptr; }
+				for (int k = 0; k < 3; ++k) if (c->sub_ev[k]) { (void)hipEventDestroy(c->sub_ev[k]); c->sub_ev[k] = nullptr; }
+				c->sub_fork_failed = true;
+			}
+		}
+		if (c->sub_fork_failed) { on = false; return; }
 		side[0] = c->sub_side[0]; side[1] = c->sub_side[1]; start = c->sub_ev[0]; done[0] = c->sub_ev[1]; done[1] = c->sub_ev[2];
 		(void)hipEventRecord(start, c->st);
 		for (int k = 0; k < 2; ++k) (void)hipStreamWaitEvent(side[k], start, 0);

@@ -29,6 +29,18 @@ extern "C" int mahip_device_count(void)
 // context's one stream, so a piece that changes hands is safe in stream order.  MA_DEV_POOL=0: plain hipMalloc / hipFree (the guard-page run of the CPU build).
 static bool pool_on() { static int v = -1; if (v < 0) { const char *e = getenv("MA_DEV_POOL"); v = !(e && atoi(e) == 0); } return v != 0; }
 
+// The contexts of this process (bench.py's second context for the tail, several batches in flight): a context whose hipMalloc fails asks the
+// others to let go of what their pools hold idle.  Other PROCESSES on the same GPU (the shared-memory ranks of a one-GPU test) cannot be asked;
+// for them the orchestration trims at the phase boundaries (mahip_mem_trim).
+static std::mutex g_reg_mu;
+static std::vector<mahip_ctx*> g_ctxs;
+static void ctx_register(mahip_ctx *c) { std::lock_guard<std::mutex> g(g_reg_mu); g_ctxs.push_back(c); }
+static void ctx_unregister(mahip_ctx *c)
+{
+	std::lock_guard<std::mutex> g(g_reg_mu);
+	for (size_t i = 0; i < g_ctxs.size(); ++i) if (g_ctxs[i] == c) { g_ctxs[i] = g_ctxs.back(); g_ctxs.pop_back(); break; }
+}
+
 static DevPool::Base *pool_base_of(DevPool &P, const char *p)
 {
 	for (DevPool::Base &b : P.bases) if (p >= b.p && p < b.p + b.bytes) return &b;
@@ -38,6 +50,7 @@ static DevPool::Base *pool_base_of(DevPool &P, const char *p)
 static void pool_give_back(mahip_ctx *c, char *p, size_t cap)
 {
 	DevPool &P = c->pool;
+	std::lock_guard<std::mutex> g(P.mu);
 	DevPool::Base *base = pool_base_of(P, p);
 	if (!base) { (void)hipFree(p); return; } // (not from the pool: cannot happen)
 	DevPool::Piece nw = { p, cap, base->p };
@@ -53,38 +66,61 @@ static void pool_give_back(mahip_ctx *c, char *p, size_t cap)
 	P.free_pieces.push_back(nw);
 }
 
-// whole allocations that are free go back to the driver (when the driver has nothing left to give)
-static void pool_trim(mahip_ctx *c)
+// Whole allocations that are free go back to the driver.  A piece may still be read by kernels queued before it was given up (stream order is
+// all that protects a piece inside the pool); hipFree waits for the device, so handing it to the driver is safe from any thread.
+// Returns the bytes released.  A partly used allocation cannot be returned -- which is why pool_take never splits an allocation it makes
+// for a request (a base = one buffer's worth) and the pool therefore fragments only inside recycled bases.
+static size_t pool_trim_locked(DevPool &P)
 {
-	DevPool &P = c->pool;
+	size_t freed = 0;
 	for (size_t i = 0; i < P.free_pieces.size();) {
 		const DevPool::Piece f = P.free_pieces[i];
 		DevPool::Base *b = pool_base_of(P, f.p);
 		if (b && f.p == b->p && f.cap == b->bytes) {
 			(void)hipFree(b->p);
+			freed += b->bytes;
 			*b = P.bases.back(); P.bases.pop_back();
 			P.free_pieces[i] = P.free_pieces.back(); P.free_pieces.pop_back();
 		} else ++i;
 	}
+	return freed;
+}
+static size_t pool_trim(mahip_ctx *c) { std::lock_guard<std::mutex> g(c->pool.mu); return pool_trim_locked(c->pool); }
+static void pool_trim_siblings(mahip_ctx *c)
+{
+	std::lock_guard<std::mutex> g(g_reg_mu);
+	for (mahip_ctx *o : g_ctxs) if (o != c && o->dev == c->dev) (void)pool_trim(o);
+}
+static size_t pool_idle_bytes(mahip_ctx *c)
+{
+	std::lock_guard<std::mutex> g(c->pool.mu);
+	size_t n = 0;
+	for (const DevPool::Piece &f : c->pool.free_pieces) n += f.cap;
+	return n;
 }
 
 static int pool_take(mahip_ctx *c, size_t want, void **out, size_t *cap)
 {
 	DevPool &P = c->pool;
-	size_t best = (size_t)-1;
-	for (size_t i = 0; i < P.free_pieces.size(); ++i)
-		if (P.free_pieces[i].cap >= want && (best == (size_t)-1 || P.free_pieces[i].cap < P.free_pieces[best].cap)) best = i;
-	if (best != (size_t)-1) {
-		DevPool::Piece &f = P.free_pieces[best];
-		*out = f.p;
-		if (f.cap - want >= ((size_t)1 << 20)) { *cap = want; f.p += want; f.cap -= want; }
-		else { *cap = f.cap; P.free_pieces[best] = P.free_pieces.back(); P.free_pieces.pop_back(); }
-		return 0;
+	{
+		std::lock_guard<std::mutex> g(P.mu);
+		size_t best = (size_t)-1;
+		for (size_t i = 0; i < P.free_pieces.size(); ++i)
+			if (P.free_pieces[i].cap >= want && (best == (size_t)-1 || P.free_pieces[i].cap < P.free_pieces[best].cap)) best = i;
+		if (best != (size_t)-1) {
+			DevPool::Piece &f = P.free_pieces[best];
+			*out = f.p;
+			if (f.cap - want >= ((size_t)1 << 20)) { *cap = want; f.p += want; f.cap -= want; }
+			else { *cap = f.cap; P.free_pieces[best] = P.free_pieces.back(); P.free_pieces.pop_back(); }
+			return 0;
+		}
 	}
 	void *p = nullptr;
 	hipError_t e = hipMalloc(&p, want);
-	if (e != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->st); pool_trim(c); e = hipMalloc(&p, want); }
-	if (e != hipSuccess) { mahip_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e)); return -1; }
+	if (e != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->st); (void)pool_trim(c); e = hipMalloc(&p, want); }   // what this context holds idle
+	if (e != hipSuccess) { (void)hipGetLastError(); pool_trim_siblings(c); e = hipMalloc(&p, want); }                                    // what the process's other contexts on this GPU hold idle
+	if (e != hipSuccess) { (void)hipGetLastError(); mahip_set_error("hipMalloc(%zu bytes) failed: %s (%zu bytes in use by this context)", want, hipGetErrorString(e), c->mem_bytes); return -1; }
+	std::lock_guard<std::mutex> g(P.mu);
 	P.bases.push_back({ (char*)p, want });
 	*out = p; *cap = want;
 	return 0;
@@ -92,6 +128,7 @@ static int pool_take(mahip_ctx *c, size_t want, void **out, size_t *cap)
 
 void dev_pool_destroy(mahip_ctx *c)
 {
+	std::lock_guard<std::mutex> g(c->pool.mu);
 	for (DevPool::Base &b : c->pool.bases) (void)hipFree(b.p);
 	c->pool.bases.clear(); c->pool.free_pieces.clear();
 }
@@ -116,10 +153,26 @@ void dev_free(mahip_ctx *c, DevBuf &b)
 {
 	if (b.p) {
 		c->mem_bytes -= b.cap;
-		if (pool_on()) pool_give_back(c, (char*)b.p, b.cap); else (void)hipFree(b.p);
+		if (pool_on()) {
+			// a buffer whose address left the library may be in use on a stream this context knows nothing about (collectives run by the
+			// caller): stream order does not cover it, so it changes hands only after the device is idle -- what hipFree did implicitly
+			if (b.ext) (void)hipDeviceSynchronize();
+			pool_give_back(c, (char*)b.p, b.cap);
+		} else (void)hipFree(b.p);
 	}
-	b.p = nullptr; b.cap = 0;
+	b.p = nullptr; b.cap = 0; b.ext = false;
 }
+
+// give the idle part of the pool back to the driver (phase boundaries of a run that shares its GPU with other processes; callers that are done for now)
+extern "C" int mahip_mem_trim(mahip_ctx_t *c, size_t *released)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	HIPCHK(hipStreamSynchronize(c->st));
+	const size_t n = pool_trim(c);
+	if (released) *released = n;
+	return 0;
+}
+extern "C" size_t mahip_mem_pool_bytes(mahip_ctx_t *c) { return pool_idle_bytes(c); }
 
 int ctr_zero(mahip_ctx *c)
 {
@@ -140,14 +193,24 @@ __global__ __launch_bounds__(64) void k_ctr_publish(const unsigned long long *__
 	if (threadIdx.x == 0) { h[64] = seq; __threadfence_system(); }
 }
 
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+	__builtin_ia32_pause();
+#elif defined(__aarch64__)
+	__asm__ __volatile__("yield");
+#endif
+}
+
 int ctr_fetch(mahip_ctx *c)
 {
 	const unsigned long long seq = ++c->ctr_seq;
 	hipLaunchKernelGGL(k_ctr_publish, dim3(1), dim3(64), 0, c->st, (const unsigned long long*)c->ctr.p, (volatile unsigned long long*)c->h_ctr, seq);
+	{ hipError_t le = hipGetLastError(); if (le != hipSuccess) { mahip_set_error("ctr_fetch: launch failed: %s", hipGetErrorString(le)); return -1; } } // (a launch that never ran would leave the spin below waiting for the stream query)
 	volatile unsigned long long *flag = (volatile unsigned long long*)c->h_ctr + 64;
 	for (unsigned long spins = 0;; ++spins) {
 		if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
-		__builtin_ia32_pause();
+		cpu_relax();
 		if ((spins & 0xffff) == 0xffff) { // every few hundred microseconds: has the stream ended without the word (a fault)?
 			hipError_t e = hipStreamQuery(c->st);
 			if (e == hipSuccess) { if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0; HIPCHK(hipStreamSynchronize(c->st)); if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0; mahip_set_error("ctr_fetch: the stream is idle but the counters never arrived"); return -1; }
@@ -219,15 +282,16 @@ extern "C" mahip_ctx_t *mahip_create(int device, void *stream)
 	pin_to_gpu_node(device);
 	mahip_ctx *c = new mahip_ctx();
 	c->dev = device;
+	ctx_register(c);
 	if (stream) c->st = (hipStream_t)stream, c->own_stream = false;
 	else {
-		if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { mahip_set_error("mahip_create: hipStreamCreate failed"); delete c; return nullptr; }
+		if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { mahip_set_error("mahip_create: hipStreamCreate failed"); ctx_unregister(c); delete c; return nullptr; }
 		c->own_stream = true;
 	}
-	if (dev_reserve(c, c->ctr, 64 * 8) != 0) { delete c; return nullptr; }
-	if (hipHostMalloc((void**)&c->h_ctr, 72 * 8, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { mahip_set_error("mahip_create: hipHostMalloc failed"); delete c; return nullptr; }
+	if (dev_reserve(c, c->ctr, 64 * 8) != 0) { ctx_unregister(c); delete c; return nullptr; }
+	if (hipHostMalloc((void**)&c->h_ctr, 72 * 8, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { mahip_set_error("mahip_create: hipHostMalloc failed"); ctx_unregister(c); delete c; return nullptr; }
 	memset(c->h_ctr, 0, 72 * 8);
-	if (hipMemsetAsync(c->ctr.p, 0, 64 * 8, c->st) != hipSuccess) { mahip_set_error("mahip_create: memset failed"); delete c; return nullptr; }
+	if (hipMemsetAsync(c->ctr.p, 0, 64 * 8, c->st) != hipSuccess) { mahip_set_error("mahip_create: memset failed"); ctx_unregister(c); delete c; return nullptr; }
 	{ const char *s = getenv("MA_EXACT_TIES"); c->tie_mode = s == 0 || *s == 0 ? 2 : atoi(s) != 0 ? 1 : 0; } // unset: automatic
 	return c;
 }
@@ -235,6 +299,7 @@ extern "C" mahip_ctx_t *mahip_create(int device, void *stream)
 extern "C" void mahip_destroy(mahip_ctx_t *c)
 {
 	if (!c) return;
+	ctx_unregister(c); // nobody trims a pool that is being taken down
 	(void)hipSetDevice(c->dev);
 	(void)hipStreamSynchronize(c->st);
 	for (auto &e : c->pev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -266,6 +331,7 @@ extern "C" int mahip_xbuf(mahip_ctx_t *c, int slot, size_t bytes, void **d_ptr)
 	if (slot < 0 || slot > 1) { mahip_set_error("mahip_xbuf: bad slot"); return -1; }
 	HIPCHK(hipSetDevice(c->dev));
 	CHK(dev_reserve(c, c->xb[slot], bytes + 256));
+	c->xb[slot].ext = true;
 	*d_ptr = c->xb[slot].p;
 	return 0;
 }
@@ -277,12 +343,13 @@ extern "C" int mahip_sync(mahip_ctx_t *c)
 	return 0;
 }
 
-extern "C" size_t mahip_mem_bytes(mahip_ctx_t *c) { return c->mem_bytes; }
+extern "C" size_t mahip_mem_bytes(mahip_ctx_t *c) { return c->mem_bytes + pool_idle_bytes(c); } // in use + kept idle by the pool: what the driver sees
 
 extern "C" void *mahip_devptr(mahip_ctx_t *c, int which, size_t *bytes)
 {
 	DevBuf *b = which == MAHIP_PTR_SUB0 ? &c->sub[0] : which == MAHIP_PTR_SUB1 ? &c->sub[1] : which == MAHIP_PTR_RDFLAG ? &c->r_del : nullptr;
 	if (!b) return nullptr;
+	b->ext = true;
 	if (bytes) *bytes = which == MAHIP_PTR_RDFLAG ? (size_t)c->n_seq : (size_t)c->n_seq * 8;
 	return b->p;
 }

@@ -7,6 +7,7 @@
 #include <string.h>
 #include <time.h>
 #include <vector>
+#include <mutex>
 #include <string>
 #include "mahip.h"
 #include "ma_core.h"
@@ -21,6 +22,7 @@ void mahip_set_error(const char *fmt, ...);
 struct DevBuf {
 	void *p = nullptr;
 	size_t cap = 0;
+	bool ext = false; // its address was handed to the caller (mahip_xbuf / mahip_devptr): streams this context does not know may be using it
 };
 
 struct ProfEvent { const char *name; hipEvent_t a, b; double alg_bytes; };
@@ -32,6 +34,7 @@ struct DevPool {
 	struct Piece { char *p; size_t cap; char *base; };  // a free stretch of one of them
 	std::vector<Base> bases;
 	std::vector<Piece> free_pieces;
+	std::mutex mu; // a sibling context of the process that runs out of memory trims this pool from ITS thread
 };
 
 // big pageable host arrays of the tie walk (radix.hip)
@@ -119,6 +122,7 @@ struct mahip_ctx {
 
 	hipEvent_t mark_ev[64] = {}; // phase marks (mahip_mark)
 	hipStream_t sub_side[2] = {}; hipEvent_t sub_ev[3] = {}; // side streams of the coverage passes' size classes (hits.hip: SubFork)
+	bool sub_fork_failed = false;                           // they could not be created: every size class on the context's stream
 	unsigned long long mark_set = 0;
 	// ---- profiling ----
 	bool prof = false;
@@ -178,7 +182,7 @@ int radix_reserve_hist(mahip_ctx *c, size_t n);
 int reference_order(mahip_ctx *c, uint64_t *d_keys /* overwritten */, size_t n, uint32_t *d_perm);
 void walk_scratch_release(mahip_ctx *c); // the host arrays of the walks go away (on a thread of their own when they are big)
 // position of every hit slot in the reference's order -> c->hrank (hits.hip)
-int hits_reference_rank(mahip_ctx *c);
+int hits_reference_rank(mahip_ctx *c, bool collective_ok);
 // bits of the largest query start of the input records
 int hits_qs_bits(mahip_ctx *c);
 // make sure the SoA columns exist (the gather after mahip_hits_sort is lazy)

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "ma_host.h"
+#include "ma_core.h"
 
 int ma_verbose = 3; /* reference common.c:3 */
 
@@ -67,33 +68,39 @@ static uint32_t max_read_id(size_t n, const ma_hit_t *a)
 
 /* ---------------------------------------------------------------------------------------------- ingest */
 
-sdict_t *ma_hit_no_cont(const char *fn, int min_span, int min_match, int max_hang, float int_frac) /* hit.c:38-68 */
+/* the span / match gate every reader applies to a line before anything else (hit.c:52,85) */
+static inline int line_passes(const paf_rec_t *r, int min_span, int min_match)
+{
+	return r->qe - r->qs >= (uint32_t)min_span && r->te - r->ts >= (uint32_t)min_span && (int)r->ml >= min_match;
+}
+
+static paf_file_t *open_or_die(const char *fn, const char *who)
 {
 	paf_file_t *fp = paf_open(fn);
+	if (fp) return fp;
+	fprintf(stderr, "[E::%s] could not open PAF file %s\n", who, fn);
+	exit(1);
+}
+
+/* hit.c:38-68 behind the per-symbol ABI (and MA_HOST_PARSE=1): the names of reads that some line shows clearly inside a read more than
+ * twice their length.  The per-line verdict is mc_no_cont (csrc/ma_core.h) -- the same function the device parser's k_paf_nocont runs --
+ * so there is ONE statement of the rule; this loop only feeds it lines and collects names in order of first appearance. */
+sdict_t *ma_hit_no_cont(const char *fn, int min_span, int min_match, int max_hang, float int_frac)
+{
+	paf_file_t *fp = open_or_die(fn, __func__);
+	sdict_t *excl = sd_init();
 	paf_rec_t r;
-	sdict_t *d;
-	if (!fp) {
-		fprintf(stderr, "[E::%s] could not open PAF file %s\n", __func__, fn);
-		exit(1);
-	}
 	memset(&r, 0, sizeof(r));
-	d = sd_init();
 	while (paf_read(fp, &r) >= 0) {
-		int l5, l3;
-		if (r.qe - r.qs < (uint32_t)min_span || r.te - r.ts < (uint32_t)min_span || (int)r.ml < min_match) continue;
-		l5 = r.rev ? r.tl - r.te : r.ts;
-		l3 = r.rev ? r.ts : r.tl - r.te;
-		if (r.ql >> 1 > r.tl) { /* the query is more than twice the target: is the target clearly inside it? */
-			if (l5 > max_hang >> 2 || l3 > max_hang >> 2 || (float)(r.te - r.ts) < (float)r.tl * int_frac) continue;
-			if ((int)r.qs - l5 > max_hang << 1 && (int)(r.ql - r.qe) - l3 > max_hang << 1) sd_put(d, r.tn, r.tl);
-		} else if (r.ql < r.tl >> 1) {
-			if (r.qs > (uint32_t)(max_hang >> 2) || r.ql - r.qe > (uint32_t)(max_hang >> 2) || (float)(r.qe - r.qs) < (float)r.ql * int_frac) continue;
-			if (l5 - (int)r.qs > max_hang << 1 && l3 - (int)(r.ql - r.qe) > max_hang << 1) sd_put(d, r.qn, r.ql);
-		}
+		int who;
+		if (!line_passes(&r, min_span, min_match)) continue;
+		who = mc_no_cont(r.ql, r.qs, r.qe, r.tl, r.ts, r.te, r.rev, max_hang, int_frac); /* 1: the target is inside the query, 2: the query inside the target */
+		if (who == 1) sd_put(excl, r.tn, r.tl);
+		else if (who == 2) sd_put(excl, r.qn, r.ql);
 	}
 	paf_close(fp);
-	if (ma_verbose >= 3) fprintf(MA_LOG, "[M::%s::%s] dropped %d contained reads\n", __func__, sys_timestamp(), d->n_seq);
-	return d;
+	if (ma_verbose >= 3) fprintf(MA_LOG, "[M::%s::%s] dropped %d contained reads\n", __func__, sys_timestamp(), excl->n_seq);
+	return excl;
 }
 
 static uint32_t g_ingest_max_qs; /* largest query start stored by the last ingest: lets the device sort plan its digits */
@@ -108,33 +115,27 @@ ma_hit_t *ma_hit_ingest(const char *fn, int min_span, int min_match, sdict_t *d,
 	size_t na = 0, ma = 0, i, tot = 0, tot_len = 0;
 	a = ma_hit_ingest_mt(fn, min_span, min_match, d, &na, bi_dir, excl, &tot, &max_qs); /* plain files: chunk-parallel parse */
 	if (a) goto done;
-	fp = paf_open(fn);
-	if (!fp) {
-		fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn);
-		exit(1);
-	}
+	fp = open_or_die(fn, "ma_hit_read"); /* gzip / stdin: one line at a time */
 	memset(&r, 0, sizeof(r));
-	while (paf_read(fp, &r) >= 0) {
-		ma_hit_t *p;
-		uint32_t qid, tid;
-		++tot;
-		if (r.qe - r.qs < (uint32_t)min_span || r.te - r.ts < (uint32_t)min_span || (int)r.ml < min_match) continue;
+	for (; paf_read(fp, &r) >= 0; ++tot) {
+		uint32_t id[2];
+		int k, n_rec;
+		if (!line_passes(&r, min_span, min_match)) continue;
 		if (excl && (sd_get(excl, r.qn) >= 0 || sd_get(excl, r.tn) >= 0)) continue;
+		id[0] = (uint32_t)sd_put(d, r.qn, r.ql); /* ids in order of first appearance, the query column first (sdict.c:27-45) */
+		id[1] = (uint32_t)sd_put(d, r.tn, r.tl);
+		n_rec = bi_dir && id[0] != id[1] ? 2 : 1;   /* the line as it stands, then seen from the target (hit.c:87-98) */
 		if (na + 2 > ma) {
 			ma = ma ? ma << 1 : 1u << 16;
 			a = (ma_hit_t*)realloc(a, ma * sizeof(ma_hit_t));
 		}
-		qid = (uint32_t)sd_put(d, r.qn, r.ql);
-		tid = (uint32_t)sd_put(d, r.tn, r.tl);
-		p = &a[na++];
-		p->qns = (uint64_t)qid << 32 | r.qs; p->qe = r.qe; p->tn = tid; p->ts = r.ts; p->te = r.te;
-		p->rev = r.rev; p->ml = r.ml; p->bl = r.bl; p->del = 0;
-		if (r.qs > max_qs) max_qs = r.qs;
-		if (bi_dir && qid != tid) {
-			if (r.ts > max_qs) max_qs = r.ts;
-			p = &a[na++];
-			p->qns = (uint64_t)tid << 32 | r.ts; p->qe = r.te; p->tn = qid; p->ts = r.qs; p->te = r.qe;
+		for (k = 0; k < n_rec; ++k) {
+			const uint32_t beg[2] = { r.qs, r.ts }, end[2] = { r.qe, r.te };
+			ma_hit_t *p = &a[na++];
+			p->qns = (uint64_t)id[k] << 32 | beg[k]; p->qe = end[k];
+			p->tn = id[k ^ 1]; p->ts = beg[k ^ 1]; p->te = end[k ^ 1];
 			p->rev = r.rev; p->ml = r.ml; p->bl = r.bl; p->del = 0;
+			if (beg[k] > max_qs) max_qs = beg[k];
 		}
 	}
 	paf_close(fp);

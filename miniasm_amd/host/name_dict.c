@@ -101,6 +101,13 @@ void ma_sd_reindex(sdict_t *d)
 	for (i = 0; i < d->n_seq; ++i) ix_insert_raw(ix, sd_hash_str(d->seq[i].name), i);
 }
 
+/* reference sdict.c:55-66: "make sure the index exists" (sd_squeeze calls it there; non-static, so exported here too) */
+void sd_hash(sdict_t *d)
+{
+	const sd_index_t *ix = (const sd_index_t*)d->h;
+	if (ix == 0 || ix->n_slot == 0) ma_sd_reindex(d);
+}
+
 /* forget the index (it is rebuilt on the first sd_get / sd_put); the name arena, if any, stays */
 void ma_sd_drop_index(sdict_t *d)
 {

@@ -89,6 +89,9 @@ int ma_paf_parse_line(int l, char *s, paf_rec_t *pr)
 	return t < 10 ? -1 : 0;
 }
 
+/* the reference's own name for it (paf.c:34; non-static there, so an object written against paf.o may bind it) */
+int paf_parse(int l, char *s, paf_rec_t *pr) { return ma_paf_parse_line(l, s, pr); }
+
 /* next raw line: returns its length (>=0) and a pointer valid until the next call, or -1 at end of input */
 static int next_line(paf_file_t *pf, char **line)
 {

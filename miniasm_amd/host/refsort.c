@@ -183,11 +183,11 @@ static void *fill_worker(void *arg)
 
 static void fill_run(fill_t *proto, size_t n, int phase, int n_threads)
 {
-	fill_t *f = (fill_t*)malloc(sizeof(fill_t) * RS_MAX_THREADS); /* (2 KB each) */
+	fill_t one, *heap = (fill_t*)malloc(sizeof(fill_t) * RS_MAX_THREADS), *f = heap ? heap : &one; /* (2 KB each; without the block: one thread, its state on the stack) */
 	pthread_t th[RS_MAX_THREADS];
 	int t;
 	if (n_threads > RS_MAX_THREADS) n_threads = RS_MAX_THREADS;
-	if (n < (1u << 20) || n_threads < 2) n_threads = 1;
+	if (n < (1u << 20) || n_threads < 2 || heap == 0) n_threads = 1;
 	for (t = 0; t < n_threads; ++t) {
 		f[t] = *proto; f[t].phase = phase;
 		f[t].beg = n / n_threads * t, f[t].end = t == n_threads - 1 ? n : n / n_threads * (t + 1);
@@ -198,7 +198,7 @@ static void fill_run(fill_t *proto, size_t n, int phase, int n_threads)
 	if (phase == 0) { proto->mhi = proto->mlo = 0; for (t = 0; t < n_threads; ++t) { if (f[t].mhi > proto->mhi) proto->mhi = f[t].mhi; if (f[t].mlo > proto->mlo) proto->mlo = f[t].mlo; } }
 	if (phase == 5) { proto->diff = 0; for (t = 0; t < n_threads; ++t) proto->diff |= f[t].diff; }
 	if (phase == 6 || phase == 7) { int k; memset(proto->cnt, 0, sizeof(proto->cnt)); for (t = 0; t < n_threads; ++t) for (k = 0; k < 256; ++k) proto->cnt[k] += f[t].cnt[k]; }
-	free(f);
+	free(heap);
 }
 
 static int bits_of64(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }

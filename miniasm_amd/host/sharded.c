@@ -215,7 +215,15 @@ int ma_shard_stats_reduce(mahip_ctx_t *c, ma_shard_stats_t *st)
 	if (st->reduced) return 0;
 	sums[0] = st->n_rem1; sums[1] = st->n_rem2; sums[2] = st->n_hits; sums[3] = st->n_red_local;
 	GPU(mahip_comm_all_reduce_sum_u64(c, sums, 4));
-	st->n_rem1 = sums[0]; st->n_rem2 = sums[1]; st->n_hits = sums[2]; st->n_red = (uint32_t)sums[3]; /* (= what rank 0's cleanup removed) */
+	st->n_rem1 = sums[0]; st->n_rem2 = sums[1]; st->n_hits = sums[2];
+	/* n_red has ONE meaning: the arcs the reduction deleted.  Rank 0 measured it as what its cleanup removed (it holds every rank's del flags), the ranks as the sum of
+	 * what each deleted among its own vertices; the two must agree -- an arc deleted twice, or deleted by something else before the cleanup, would make the log line and
+	 * the later "anything reduced?" gate disagree with what rank 0 did */
+	if (mahip_comm_rank(c) == 0 && mahip_comm_world(c) > 1 && st->n_red != (uint32_t)sums[3]) {
+		fprintf(stderr, "[E::%s] the ranks reduced %lu arcs, rank 0's cleanup removed %u\n", __func__, (unsigned long)sums[3], st->n_red);
+		return -1;
+	}
+	st->n_red = (uint32_t)sums[3];
 	st->reduced = 1;
 	return 0;
 }
@@ -340,7 +348,8 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 	}
 	GPU(mahip_hits_balance(c, world, 0)); /* every rank holds the whole input here: the same hit-balanced read ranges everywhere */
 	ma_pipeline_head_sharded(c, opt, d->n_seq, 1, &st);
-	ma_shard_stats_reduce(c, &st); /* the log lines below want the sums */
+	if (ma_shard_stats_reduce(c, &st) != 0) exit(1); /* the log lines below want the sums */
+	if (use_shm) GPU(mahip_mem_trim(c, 0)); /* the ranks share ONE GPU here: what this rank's pool keeps idle (the text, the parser's columns) is memory rank 0's tail cannot have */
 	if (rank == 0) {
 		fprintf(lg, "[M::%s] ===> Step 2: 1-pass (crude) read selection <===\n", "main");
 		if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)st.n_rem1);

@@ -23,10 +23,15 @@ double sys_cputime(void)
 
 double sys_realtime(void) { return wall_now() - t_origin; }
 
+void sys_liftrlimit(void)
+{ /* reference sys.c:22-30: the address-space soft limit goes up to the hard limit */
+	struct rlimit rl;
+	if (getrlimit(RLIMIT_AS, &rl) == 0) { rl.rlim_cur = rl.rlim_max; setrlimit(RLIMIT_AS, &rl); }
+}
+
 void sys_init(void)
 {
-	struct rlimit rl; /* lift the address-space soft limit like the reference (sys.c:22-30) */
-	if (getrlimit(RLIMIT_AS, &rl) == 0) { rl.rlim_cur = rl.rlim_max; setrlimit(RLIMIT_AS, &rl); }
+	sys_liftrlimit();
 	t_origin = 0.;
 	t_origin = wall_now();
 }

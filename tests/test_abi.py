@@ -49,6 +49,59 @@ def test_reference_externals_for_the_dropin_link():
     assert not [s for s in und if not hasattr(L, s)]
 
 
+def test_every_external_function_of_the_reference_objects_is_exported():
+    """an object written against the reference's .o files may bind ANY of their non-static functions, declared in a header
+    or not (paf_parse paf.c:34, sd_hash sdict.c:55, sys_liftrlimit sys.c:22 are not): all of them must resolve here"""
+    ref = os.path.join(ma.ROOT, "oracle", "_ref", "libminiasm_ref.so")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/libminiasm_ref.so not built")
+    out = subprocess.run(["nm", "-D", "--defined-only", ref], stdout=subprocess.PIPE, text=True).stdout
+    syms = [l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in "TDB"]
+    # klib macro instances (ks_*/kh_*/radix_sort_*/kdq_*) are static-inline-like helpers of the reference's containers, not its interface
+    syms = [x for x in syms if x.startswith(PREFIXES) or x == "ma_verbose"]
+    L = C.CDLL(ma.LIB_PATH)
+    assert {"paf_parse", "sd_hash", "sys_liftrlimit"} <= set(syms)
+    assert not [x for x in syms if not hasattr(L, x)]
+
+
+def test_undeclared_reference_externals_behave_like_the_reference():
+    L = C.CDLL(ma.LIB_PATH)
+
+    class PafRec(C.Structure):  # paf.h:20-24
+        _fields_ = [("qn", C.c_char_p), ("tn", C.c_char_p), ("ql", C.c_uint32), ("qs", C.c_uint32), ("qe", C.c_uint32),
+                    ("tl", C.c_uint32), ("ts", C.c_uint32), ("te", C.c_uint32), ("ml_rev", C.c_uint32), ("bl", C.c_uint32)]
+    libs = [L]
+    ref = os.path.join(ma.ROOT, "oracle", "_ref", "libminiasm_ref.so")
+    if os.path.exists(ref):
+        libs.append(C.CDLL(ref))
+    lines = [b"a\t9000\t10\t5000\t-\tb\t8000\t20\t5010\t800\t4990\t255", b"a\t9000\t10\t5000\t+\tb\t8000\t20\t5010\t800",
+             b"a\t1\t2", b"q\t-5\t 7\t9x\t+\tt\t99999999999\t0\t0\t0\t0"]
+    res = []
+    for lib in libs:
+        got = []
+        for ln in lines:
+            buf = C.create_string_buffer(ln, len(ln) + 1)
+            r = PafRec(); r.bl = 77
+            rc = lib.paf_parse(len(ln), buf, C.byref(r))
+            got.append((rc, r.qn, r.tn, r.ql, r.qs, r.qe, r.tl, r.ts, r.te, r.ml_rev, r.bl) if rc >= 0 else (rc,))
+        res.append(got)
+    assert res[0][0] == (0, b"a", b"b", 9000, 10, 5000, 8000, 20, 5010, 800 | 1 << 31, 4990)
+    assert res[0][1][-1] == 77 and res[0][2] == (-1,)  # 10 columns: bl untouched; 3 columns: refused
+    assert all(r == res[0] for r in res)
+    # sd_hash: the index exists afterwards, lookups work, a second call changes nothing
+    L.sd_init.restype = C.c_void_p
+    L.sd_put.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+    L.sd_get.argtypes = [C.c_void_p, C.c_char_p]
+    L.sd_hash.argtypes = [C.c_void_p]
+    L.sd_destroy.argtypes = [C.c_void_p]
+    d = L.sd_init()
+    assert [L.sd_put(d, n, 5) for n in (b"x", b"y", b"x")] == [0, 1, 0]
+    L.sd_hash(d); L.sd_hash(d)
+    assert L.sd_get(d, b"y") == 1 and L.sd_get(d, b"z") == -1
+    L.sd_destroy(d)
+    L.sys_liftrlimit()
+
+
 def test_record_layouts():
     assert C.sizeof(ma.MaOpt) == 56 and C.sizeof(ma.SdSeq) == 16 and C.sizeof(ma.Asg) == 40
     assert ma.HIT_DT.itemsize == 32 and ma.ARC_DT.itemsize == 16 and ma.SUB_DT.itemsize == 8
