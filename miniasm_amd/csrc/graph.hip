@@ -215,17 +215,108 @@ __global__ __launch_bounds__(256) void k_arc_keys_ref(ArcCols a, size_t n, const
 	}
 }
 
-// asg.c:27-36 asg_arc_index_core on a zeroed idx
+// asg.c:27-36 asg_arc_index_core on a zeroed idx: idx[u] = first<<32 | count.  The first arc of a run contributes first<<32 - first, the last one
+// its end: the sum is first<<32 | (end - first) (the borrow of the first term is paid back by the carry of the second).  Round 3 let the first arc's
+// thread count its run in a loop -- one dependent load per arc of the run, 2.2 ms per launch at 200 M arcs; this form is one streaming read of the u column.
 __global__ __launch_bounds__(256) void k_arc_index(const uint32_t *__restrict__ au, size_t n, unsigned long long *__restrict__ idx)
 {
-	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (i >= n) return;
-	uint32_t u = au[i];
-	if (i == 0 || au[i - 1] != u) { // first arc of u: count the run
-		size_t j = i + 1;
-		while (j < n && au[j] == u) ++j;
-		idx[u] = (unsigned long long)i << 32 | (unsigned long long)(j - i);
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+		const uint32_t u = au[i];
+		const bool first = i == 0 || au[i - 1] != u, last = i + 1 == n || au[i + 1] != u;
+		if (first && last) idx[u] = (unsigned long long)i << 32 | 1ull; // a run of one: nobody else writes the word
+		else if (first) atomicAdd(&idx[u], ((unsigned long long)i << 32) - (unsigned long long)i);
+		else if (last) atomicAdd(&idx[u], (unsigned long long)(i + 1));
 	}
+}
+
+// ---- asg_arc_sort + asg_arc_index (asg.c:22-42) for arcs that arrive GROUPED BY READ ----
+// ma_sg_gen pushes the arcs in hit order and the hit slots are grouped by query id, so the arcs of read q -- the lists of its two vertices 2q and 2q+1
+// -- are one contiguous stretch of the push sequence.  Sorting by (u, len) is then a sort INSIDE each stretch: one wave per read, the (strand, len,
+// position in the stretch) keys in registers, the network of the coverage sweeps (wave_sort_regs), the rows fetched through the sorted positions.
+// One read and one write of every arc ("arc sort 32 B per arc") instead of keys + four 12-byte radix passes + a permutation, and the
+// wave that has a read's sorted keys in registers also writes the two CSR words (asg_arc_index) and counts the equal (u,len) keys (the tie census).
+// The position rides in the low bits, so the order is total and equal keys stay in push order -- the stable order radix.hip gave.
+#define AG_IB 9        // bits of an arc's position inside its read's stretch
+#define AG_MAX 512u    // arcs per read the register network takes; longer stretches (or lengths of more than 21 bits) send the whole sort to the radix path
+
+// grp[q] = {first arc, one past the last arc} of read q (zeroed before: reads without arcs).  CT_OVF2 counts what the fast path cannot take: a read id
+// that DEcreases along the sequence (the arcs are not grouped) or a stretch longer than AG_MAX.
+__global__ __launch_bounds__(256) void k_arc_groups(const uint32_t *__restrict__ au, size_t n, uint2 *__restrict__ grp, unsigned long long *__restrict__ ctr)
+{
+	uint32_t bad = 0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+		const uint32_t q = au[i] >> 1;
+		if (i == 0 || (au[i - 1] >> 1) != q) { grp[q].x = (uint32_t)i; if (i && (au[i - 1] >> 1) > q) ++bad; }
+		if (i + 1 == n || (au[i + 1] >> 1) != q) grp[q].y = (uint32_t)(i + 1);
+	}
+	blk_add_u64(&ctr[CT_OVF2], bad);
+}
+
+template <int ITEMS>
+__device__ __forceinline__ void arc_group_sort_regs(const ArcCols &in, const ArcCols &out, uint32_t q, uint32_t beg, uint32_t n, int bl, unsigned lane,
+                                                    unsigned long long *__restrict__ idx, uint32_t &tie_groups, uint32_t &tie_arcs)
+{
+	uint32_t x[ITEMS];
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) { // any arrangement will do on the way in: the position is part of the key
+		const uint32_t i = (uint32_t)r * 64u + lane;
+		x[r] = 0xffffffffu;
+		if (i < n) x[r] = (in.u[beg + i] & 1u) << (bl + AG_IB) | in.len[beg + i] << AG_IB | i;
+	}
+	wave_sort_regs<ITEMS>(x, lane); // sorted element p sits in lane p / ITEMS, register p % ITEMS
+	const uint32_t lmask = (1u << bl) - 1u;
+	uint32_t n0 = 0;
+	const uint32_t up = __shfl_up(x[ITEMS - 1], 1, 64), down = __shfl_down(x[0], 1, 64); // the neighbours across the lane borders
+#pragma unroll
+	for (int r = 0; r < ITEMS; ++r) {
+		const uint32_t p = lane * ITEMS + (uint32_t)r;
+		if (p < n) {
+			const uint32_t k = x[r], src = beg + (k & ((1u << AG_IB) - 1u)), strand = k >> (bl + AG_IB) & 1u;
+			out.u[beg + p] = q << 1 | strand; out.v[beg + p] = in.v[src]; out.len[beg + p] = (k >> AG_IB) & lmask; out.ol[beg + p] = in.ol[src];
+			n0 += strand ^ 1u;
+			// tie census: runs of equal (u,len) among neighbours in sorted order
+			const uint32_t kp = r > 0 ? x[r > 0 ? r - 1 : 0] : up, kn = r + 1 < ITEMS ? x[r + 1 < ITEMS ? r + 1 : 0] : down;
+			const bool eq_prev = p > 0 && (kp >> AG_IB) == (k >> AG_IB), eq_next = p + 1 < n && (kn >> AG_IB) == (k >> AG_IB);
+			tie_groups += eq_next && !eq_prev;
+			tie_arcs += eq_prev || eq_next;
+		}
+	}
+	n0 = wv_sum_u32(n0);
+	if (lane == 0) { // asg_arc_index: vertices without arcs keep the zero of the cleared array (asg.c:29)
+		if (n0) idx[2 * (size_t)q] = (unsigned long long)beg << 32 | n0;
+		if (n - n0) idx[2 * (size_t)q + 1] = (unsigned long long)(beg + n0) << 32 | (n - n0);
+	}
+}
+
+// one wave per read with arcs; a wave takes 64 consecutive reads at a time (their bounds: one coalesced load) and visits the ones that have arcs --
+// after containment most reads have none.  SMALL: stretches of <= 128 arcs (2 keys per lane: most of them); !SMALL: 129 .. AG_MAX.
+template <bool SMALL>
+__global__ __launch_bounds__(256) void k_arc_group_sort(ArcCols in, ArcCols out, const uint2 *__restrict__ grp, uint32_t q_lo, uint32_t q_hi, int bl,
+                                                         unsigned long long *__restrict__ idx, unsigned long long *__restrict__ ctr)
+{
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t tg = 0, ta = 0, big = 0;
+	for (uint64_t qb = (uint64_t)q_lo + (uint64_t)(blockIdx.x * 4 + wave) * 64; qb < q_hi; qb += (uint64_t)gridDim.x * 256) {
+		const uint2 g = qb + lane < q_hi ? grp[qb + lane] : make_uint2(0, 0);
+		const uint32_t n_l = g.y - g.x;
+		if (SMALL) big += n_l > AG_MAX; // counted once (by the SMALL launch)
+		unsigned long long todo = wv_ballot(SMALL ? (n_l != 0 && n_l <= 128u) : (n_l > 128u && n_l <= AG_MAX));
+		while (todo) {
+			const int b = __ffsll((long long)todo) - 1;
+			todo &= todo - 1;
+			const uint32_t q = (uint32_t)qb + (uint32_t)b, beg = __shfl(g.x, b, 64), n = __shfl(n_l, b, 64);
+			if (SMALL) {
+				if (n <= 64) arc_group_sort_regs<1>(in, out, q, beg, n, bl, lane, idx, tg, ta);
+				else arc_group_sort_regs<2>(in, out, q, beg, n, bl, lane, idx, tg, ta);
+			} else {
+				if (n <= 256) arc_group_sort_regs<4>(in, out, q, beg, n, bl, lane, idx, tg, ta);
+				else arc_group_sort_regs<8>(in, out, q, beg, n, bl, lane, idx, tg, ta);
+			}
+		}
+	}
+	blk_add_u64(&ctr[ST_ARC_TIE_GROUPS], tg);
+	blk_add_u64(&ctr[ST_ARC_TIE_ARCS], ta);
+	if (SMALL) blk_add_u64(&ctr[CT_OVF2], big);
 }
 
 // ------------------------------------------------------------------------------------------------ asg_arc_del_trans
@@ -648,9 +739,44 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 			c->ag ^= 1;
 			in = arcs_of(c, c->ag); out = arcs_of(c, c->ag ^ 1);
 		}
+		bool idx_done = false;
 		if (c->tie_mode != 1 || sharded) { // stable sort (asg.c:24 up to the order of equal keys), then the census (on a shard: after the exchange, sharded.c)
+			// fast path: the arcs are grouped by read (push order): one in-register sort per read that also writes the CSR index and takes the census
+			bool fast = blen + AG_IB + 1 <= 31 && !getenv("MA_ARC_RADIX");
+			if (fast) {
+				const size_t V = 2 * (size_t)R;
+				const uint32_t q_lo = sharded ? c->q_beg : 0u, q_hi = sharded && c->q_end < R ? c->q_end : R, Rr = q_hi > q_lo ? q_hi - q_lo : 1;
+				CHK(dev_reserve(c, c->agrp, ((size_t)R + 1) * 8));
+				CHK(dev_reserve(c, c->idx, (V + 2) * 8));
+				HIPCHK(hipMemsetAsync(c->agrp.p, 0, (size_t)R * 8, c->st));
+				HIPCHK(hipMemsetAsync(c->idx.p, 0, V * 8, c->st));
+				HIPCHK(hipMemsetAsync(ctr + CT_OVF2, 0, 8, c->st));
+				HIPCHK(hipMemsetAsync(ctr + CT_STICKY, 0, (64 - CT_STICKY) * 8, c->st));
+				{
+					ProfScope ps(c, "k_arc_groups", 4.0 * (double)m);
+					hipLaunchKernelGGL(k_arc_groups, dim3(grid_for(m, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)in.u, m, (uint2*)c->agrp.p, ctr);
+				}
+				{
+					ProfScope ps(c, "k_arc_group_sort", 48.0 * (double)m); // arc sort 32 + index 16 B per arc
+					const unsigned grid = grid_for(((size_t)Rr + 63) / 64, 4, MA_STREAM_BLOCKS);
+					hipLaunchKernelGGL(k_arc_group_sort<true>, dim3(grid), dim3(256), 0, c->st, in, out, (const uint2*)c->agrp.p, q_lo, q_hi, blen ? blen : 1, P<unsigned long long>(c->idx), ctr);
+					hipLaunchKernelGGL(k_arc_group_sort<false>, dim3(grid), dim3(256), 0, c->st, in, out, (const uint2*)c->agrp.p, q_lo, q_hi, blen ? blen : 1, P<unsigned long long>(c->idx), ctr);
+				}
+				CHK(ctr_fetch(c));
+				if (c->h_ctr[CT_OVF2]) fast = false; // a read with more than AG_MAX arcs (or arcs that are not grouped): the general sort below
+				else {
+					idx_done = true;
+					if (c->tie_mode == 2 && !sharded) {
+						c->tie.arc_tie_groups = c->h_ctr[ST_ARC_TIE_GROUPS]; c->tie.arc_tie_arcs = c->h_ctr[ST_ARC_TIE_ARCS];
+						need_walk = c->tie.arc_tie_groups > 0;
+					}
+				}
+			}
+			if (!fast) {
 			hipLaunchKernelGGL(k_arc_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
+			c->radix_arcs = true; // (profile names: the arc sort's digit passes apart from the hit sort's)
 			CHK(radix_sort_pairs(c, m, 0, blen, 32, 32 + bitlen_u64(2ull * R), &gen));
+			c->radix_arcs = false;
 			{
 				ProfScope ps(c, "k_arc_permute", 36.0 * (double)m);
 				hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, (const uint32_t*)P<uint32_t>(c->val[gen]), out);
@@ -662,6 +788,7 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 				CHK(ctr_fetch(c));
 				c->tie.arc_tie_groups = c->h_ctr[ST_ARC_TIE_GROUPS]; c->tie.arc_tie_arcs = c->h_ctr[ST_ARC_TIE_ARCS];
 				need_walk = c->tie.arc_tie_groups > 0;
+			}
 			}
 			tl.lap("stable arc sort + census");
 		}
@@ -685,10 +812,11 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 			c->tie.arc_walk = 1;
 			tl.lap("arc walk (all of it)");
 			walk_scratch_release(c);
+			idx_done = false; // the walk's order moved arcs inside their lists: same runs, but index them from what is there now
 		}
 		c->ag ^= 1;
-	}
-	CHK(arc_reindex(c));
+		if (!idx_done) CHK(arc_reindex(c));
+	} else CHK(arc_reindex(c));
 	HIPCHK(hipGetLastError());
 	c->graph_ready = true;
 	if (n_arc) *n_arc = c->n_arc;

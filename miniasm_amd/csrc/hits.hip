@@ -176,71 +176,7 @@ static uint32_t sub_chunk(uint32_t R) { uint64_t waves = 4ull * grid_for(R, 4, M
 #define SUB_CHUNK 16u // most reads whose bounds a wave of the larger size classes fetches at once
 #define SUB_LDS_EVENTS 8192u
 
-#define MA_CE(a, b) do { uint32_t lo_ = (a) < (b) ? (a) : (b), hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
-
-// what a lane keeps of a compare-exchange with its partner's value y: the smaller one in the lower lane, the larger one in the upper;
-// min / max take the DPP operand themselves and the select reads the lane mask from scalar registers (round 3: -5 % on the fused pass
-// against mov_dpp + compare + xor on vcc + select)
-#define MA_KEEP(x, y, lower) ((lower) ? ((x) < (y) ? (x) : (y)) : ((x) < (y) ? (y) : (x)))
-// Value of lane (lane ^ M) for a compile-time M.  Exchanges inside a row of 16 lanes are DPP modifiers of a VALU move
-// (quad_perm, row_half_mirror, row_mirror, row_ror, banked row_shl/shr): no LDS crossbar round trip, no s_waitcnt.
-// Only the exchanges across rows (16, 31, 63) go through ds_bpermute.
-__device__ __forceinline__ uint32_t lane_xor(uint32_t x, int m)
-{
-	const int v = (int)x;
-	switch (m) {
-	case 1: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
-	case 2: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
-	case 3: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x1B, 0xf, 0xf, true);  // quad_perm [3,2,1,0]
-	case 7: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true); // row_half_mirror
-	case 15: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true); // row_mirror
-	case 8: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true);  // row_ror:8
-	case 4: { // banks with lane bit 2 clear read lane+4 (row_shl:4), the others lane-4 (row_shr:4)
-		int t = __builtin_amdgcn_mov_dpp(v, 0x104, 0xf, 0x5, true);
-		return (uint32_t)__builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xa, false);
-	}
-	default: return __shfl_xor(x, m, 64);
-	}
-}
-
-// ascending sort of the 64*ITEMS values held blocked (element lane*ITEMS + r) across one wave
-template <int ITEMS>
-__device__ __forceinline__ void wave_sort_regs(uint32_t (&x)[ITEMS], unsigned lane)
-{
-#pragma unroll
-	for (int k = 2; k <= ITEMS; k <<= 1) { // inside a lane
-#pragma unroll
-		for (int r = 0; r < ITEMS; ++r) { int p = r ^ (k - 1); if (p > r) MA_CE(x[r], x[p]); }
-#pragma unroll
-		for (int j = k >> 2; j > 0; j >>= 1)
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r) if ((r & j) == 0) MA_CE(x[r], x[r | j]);
-	}
-#pragma unroll
-	for (int L = 2; L <= 64; L <<= 1) { // merge blocks of L lanes
-		{ // flip step: element e pairs with e ^ (L*ITEMS - 1) = (lane ^ (L-1), ITEMS-1-r)
-			const bool lower = (lane & (L >> 1)) == 0;
-			uint32_t y[ITEMS];
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r) y[r] = lane_xor(x[ITEMS - 1 - r], L - 1);
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r) x[r] = MA_KEEP(x[r], y[r], lower); // lower half keeps the min, upper the max
-		}
-#pragma unroll
-		for (int m = L >> 2; m > 0; m >>= 1) { // half cleaners across lanes
-			const bool lower = (lane & m) == 0;
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r) {
-				uint32_t y = lane_xor(x[r], m);
-				x[r] = MA_KEEP(x[r], y, lower);
-			}
-		}
-#pragma unroll
-		for (int j = ITEMS >> 1; j > 0; j >>= 1) // half cleaners inside a lane
-#pragma unroll
-			for (int r = 0; r < ITEMS; ++r) if ((r & j) == 0) MA_CE(x[r], x[r | j]);
-	}
-}
+// (MA_CE, MA_KEEP, lane_xor, wave_sort_regs: mahip_internal.hpp -- the arc sort of graph.hip uses the same network)
 
 // Optional fusion (resident pipeline): while a hit sits in registers on its way into the coverage events of the
 // SECOND pass, first apply ma_hit_cut against the first-pass intervals (hit.c:162-193) and ma_hit_flt

@@ -79,6 +79,7 @@ struct mahip_ctx {
 	DevBuf hrank;             // u32 [n_hits] position of each slot's record in the order the reference's ma_hit_sort gives the input (host walk)
 	DevBuf orank;             // u32 [n_hits] position of each slot in the stable (qid, qs, input position) order (device sort, on demand)
 	DevBuf aslot;             // u32 [n_arc]  hit slot every pushed arc came from
+	DevBuf agrp;              // uint2 [n_seq] the stretch of the push sequence that holds a read's arcs (graph.hip: k_arc_groups)
 	DevBuf pushrows[2];       // sharded mode: this rank's arcs in push order as packed rows (the arc arrays are overwritten by the exchange)
 	uint32_t n_push = 0;
 	bool sorted_here = false, hrank_ready = false, orank_ready = false; // hits grouped by mahip_hits_sort (d_aos = the unsorted input) / hrank valid / orank valid
@@ -122,6 +123,7 @@ struct mahip_ctx {
 
 	hipEvent_t mark_ev[64] = {}; // phase marks (mahip_mark)
 	hipStream_t sub_side[2] = {}; hipEvent_t sub_ev[3] = {}; // side streams of the coverage passes' size classes (hits.hip: SubFork)
+	bool radix_arcs = false;                                // the radix passes running now sort arcs (profile names)
 	bool sub_fork_failed = false;                           // they could not be created: every size class on the context's stream
 	unsigned long long mark_set = 0;
 	// ---- profiling ----
@@ -343,6 +345,73 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t x, uint32_t *s_
 	*total = tot;
 	return base + incl - x;
 }
+// ---- the wave's register sorting network (coverage sweeps of hits.hip, arc groups of graph.hip) ----
+#define MA_CE(a, b) do { uint32_t lo_ = (a) < (b) ? (a) : (b), hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)
+
+// what a lane keeps of a compare-exchange with its partner's value y: the smaller one in the lower lane, the larger one in the upper;
+// min / max take the DPP operand themselves and the select reads the lane mask from scalar registers (round 3: -5 % on the fused pass
+// against mov_dpp + compare + xor on vcc + select)
+#define MA_KEEP(x, y, lower) ((lower) ? ((x) < (y) ? (x) : (y)) : ((x) < (y) ? (y) : (x)))
+// Value of lane (lane ^ M) for a compile-time M.  Exchanges inside a row of 16 lanes are DPP modifiers of a VALU move
+// (quad_perm, row_half_mirror, row_mirror, row_ror, banked row_shl/shr): no LDS crossbar round trip, no s_waitcnt.
+// Only the exchanges across rows (16, 31, 63) go through ds_bpermute.
+__device__ __forceinline__ uint32_t lane_xor(uint32_t x, int m)
+{
+	const int v = (int)x;
+	switch (m) {
+	case 1: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+	case 2: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+	case 3: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x1B, 0xf, 0xf, true);  // quad_perm [3,2,1,0]
+	case 7: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true); // row_half_mirror
+	case 15: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true); // row_mirror
+	case 8: return (uint32_t)__builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true);  // row_ror:8
+	case 4: { // banks with lane bit 2 clear read lane+4 (row_shl:4), the others lane-4 (row_shr:4)
+		int t = __builtin_amdgcn_mov_dpp(v, 0x104, 0xf, 0x5, true);
+		return (uint32_t)__builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xa, false);
+	}
+	default: return __shfl_xor(x, m, 64);
+	}
+}
+
+// ascending sort of the 64*ITEMS values held blocked (element lane*ITEMS + r) across one wave
+template <int ITEMS>
+__device__ __forceinline__ void wave_sort_regs(uint32_t (&x)[ITEMS], unsigned lane)
+{
+#pragma unroll
+	for (int k = 2; k <= ITEMS; k <<= 1) { // inside a lane
+#pragma unroll
+		for (int r = 0; r < ITEMS; ++r) { int p = r ^ (k - 1); if (p > r) MA_CE(x[r], x[p]); }
+#pragma unroll
+		for (int j = k >> 2; j > 0; j >>= 1)
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) if ((r & j) == 0) MA_CE(x[r], x[r | j]);
+	}
+#pragma unroll
+	for (int L = 2; L <= 64; L <<= 1) { // merge blocks of L lanes
+		{ // flip step: element e pairs with e ^ (L*ITEMS - 1) = (lane ^ (L-1), ITEMS-1-r)
+			const bool lower = (lane & (L >> 1)) == 0;
+			uint32_t y[ITEMS];
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) y[r] = lane_xor(x[ITEMS - 1 - r], L - 1);
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) x[r] = MA_KEEP(x[r], y[r], lower); // lower half keeps the min, upper the max
+		}
+#pragma unroll
+		for (int m = L >> 2; m > 0; m >>= 1) { // half cleaners across lanes
+			const bool lower = (lane & m) == 0;
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) {
+				uint32_t y = lane_xor(x[r], m);
+				x[r] = MA_KEEP(x[r], y, lower);
+			}
+		}
+#pragma unroll
+		for (int j = ITEMS >> 1; j > 0; j >>= 1) // half cleaners inside a lane
+#pragma unroll
+			for (int r = 0; r < ITEMS; ++r) if ((r & j) == 0) MA_CE(x[r], x[r | j]);
+	}
+}
+
 #define MA_STREAM_BLOCKS 2048u // 256 CUs x 8 blocks of 256 threads: full occupancy for streaming passes
 
 // All-ascending bitonic network on a[0..n) (n need not be a power of two: indices >= n act as +inf).

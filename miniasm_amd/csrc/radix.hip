@@ -183,12 +183,12 @@ static int radix_sort_impl(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, in
 		uint32_t *vin = P<uint32_t>(c->val[g]), *vout = P<uint32_t>(c->val[g ^ 1]);
 		uint32_t *hist = P<uint32_t>(c->hist);
 		if (!(p == 0 && first_hist_ready)) {
-			ProfScope ps(c, "k_radix_hist", 8.0 * (double)n);
+			ProfScope ps(c, c->radix_arcs ? "k_arc_radix_hist" : "k_radix_hist", 8.0 * (double)n);
 			hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(RS_THREADS), 0, c->st, kin, hist, n, nb, shift[p], mask);
 		}
 		CHK(scan_exclusive_u32(c, hist, hist, (size_t)(mask + 1) * nb, nullptr));
 		{
-			ProfScope ps(c, "k_radix_scatter", (has_val ? 24.0 : 16.0) * (double)n);
+			ProfScope ps(c, c->radix_arcs ? "k_arc_radix_scatter" : "k_radix_scatter", (has_val ? 24.0 : 16.0) * (double)n);
 			if (has_val) hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(RS_THREADS), 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p]);
 			else hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nb), dim3(RS_THREADS), 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p]);
 		}
