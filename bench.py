@@ -95,7 +95,7 @@ def pmc_profile(workload):
     FETCH_SIZE and WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md's HBM section prescribes).  PMC counters cannot be
     read from inside this process: the figures are attached only when the workload is the profiled one, and are labelled with the file
     and the commit the profile was taken at (its `_meta`)."""
-    for rnd in ("r03", "r03a", "r02", "r01"):  # the newest profile of this workload
+    for rnd in ("r04", "r03", "r03a", "r02", "r01"):  # the newest profile of this workload
         path = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, workload))
         try:
             d = json.load(open(path))
@@ -128,6 +128,42 @@ def pmc_traffic(names, kernel):
 # key / digit / offset kernels report is the traffic of this design (keys 16, a digit pass 8 + 16, offsets 8 B per hit): `design_GBs`.
 DESIGN_ONLY = ("k_hit_keys", "k_radix_hist", "k_radix_scatter", "k_hit_goff", "scan_exclusive_u32", "k_arc_keys", "k_arc_permute")
 SORT_GROUP = ("k_hit_keys", "k_radix_hist", "k_radix_scatter", "k_hit_goff", "k_hit_sub<gather>")
+# the "reduce" half of north_star's roofline target (per arc): arc sort 32 + index 16 + del_trans 16 (A + I)/A + del_multi 16 +
+# del_asymm 16 + 16 x entries probed + asg_arc_rm 32.  The timed scopes that do that work (graph.hip); the *_radix_* / permute / census scopes only
+# run when the in-register arc sort hands a sort to the radix path.
+REDUCE_GROUP = ("k_arc_groups", "k_arc_group_sort", "k_arc_radix_hist", "k_arc_radix_scatter", "k_arc_permute", "k_arc_tie_census", "k_arc_index",
+                "k_asg_trans", "k_asg_trans_big", "k_asg_multi", "k_asg_asymm", "k_arc_rm")
+REDUCE_DESIGN_ONLY = ("k_arc_groups", "k_arc_radix_hist", "k_arc_radix_scatter", "k_arc_permute", "k_arc_tie_census")  # their bytes are this design's, not 8(d) rows
+
+
+def kernel_table(recs, prof_steps, design_only=DESIGN_ONLY + ("k_arc_groups", "k_arc_radix_hist", "k_arc_radix_scatter", "k_arc_tie_census")):
+    """per timed scope: launches per step, HIP-event time per launch, share, algorithmic GB/s"""
+    tot_ms = sum(r["total_ms"] for r in recs) or 1.0
+    out = []
+    for r in sorted(recs, key=lambda r: -r["total_ms"]):
+        per = r["total_ms"] / max(r["launches"], 1)
+        gbs = round(r["alg_bytes"] / max(r["launches"], 1) / (per * 1e-3) / 1e9, 1) if per > 0 and r["alg_bytes"] > 0 else None
+        design = r["name"] in design_only
+        out.append({"name": r["name"], "launches_per_step": r["launches"] / max(prof_steps, 1), "avg_ms": round(per, 5), "share": round(r["total_ms"] / tot_ms, 4),
+                    "alg_GBs": None if design else gbs, "design_GBs": gbs if design else None, "alg_bytes_per_step": r["alg_bytes"] / max(prof_steps, 1)})
+    return out
+
+
+def reduce_group(ktab, n_arc, n_inner):
+    """SURVEY 8(d)'s per-arc rows of the graph phase over the HIP-event time of the scopes that do them"""
+    grp = [k for k in ktab if k["name"] in REDUCE_GROUP]
+    ms = sum(k["avg_ms"] * k["launches_per_step"] for k in grp)
+    alg = sum(k["alg_bytes_per_step"] for k in grp if k["name"] not in REDUCE_DESIGN_ONLY)
+    if ms <= 0 or alg <= 0:
+        return None
+    worst = min((k for k in grp if k["alg_GBs"] and k["avg_ms"] * k["launches_per_step"] > 0.02 * ms), key=lambda k: k["alg_GBs"], default=None)  # furthest below the roofline among those that matter
+    return {"kernels": [{"name": k["name"], "launches_per_step": k["launches_per_step"], "avg_ms": k["avg_ms"], "alg_GBs": k["alg_GBs"], "design_GBs": k["design_GBs"]} for k in grp],
+            "arcs_into_the_reduction": n_arc, "inner_iterations_I": n_inner, "ms_per_step": round(ms, 4), "alg_bytes_per_step": alg,
+            "bytes_per_arc": round(alg / max(n_arc, 1), 1), "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "slowest_by_8d": worst and worst["name"],
+            "note": "sum of SURVEY 8(d)'s per-arc rows (arc sort 32, index 16, del_trans 16 (A + I) with I counted on the device, del_multi 16, del_asymm 16 + 16 x probed entries, "
+                    "asg_arc_rm 32; each row x the arcs its launch saw) / HIP-event time of the scopes that do them"}
 
 
 class Workload:
@@ -203,9 +239,12 @@ def main():
                     "Default: it moves to a second context on the same GPU and runs beside the next batch's hit passes (mahip_tail_handoff; round 3, measured: "
                     "cfg4 20.0 -> 19.2 ms per step, cfg2 3.23 -> 2.79 ms)")
     ap.add_argument("--prof-steps", type=int, default=3)
+    ap.add_argument("--legs", default="cfg2,tie_rich,graph_heavy,latency,e2e", help="which secondary legs to run (comma list)")
+    ap.add_argument("--graph-heavy-lines", type=int, default=100000000, help="overlaps of the graph-heavy leg (pafgen -L fixed, 50 lines per read); 0 = skip it")
     ap.add_argument("--inflight", type=int, default=1, help="experiment: batches in flight on the one GPU (each on its own context and host thread)")
     args = ap.parse_args()
     args.tail_ctx = not args.no_tail_ctx
+    want_leg = lambda name: not args.no_legs and name in args.legs.split(",")
     args.gen_extra = ([] if args.model == "lognormal" else ["-L", args.model]) + (["-q", str(args.grid), "-d", "0.3", "-x", "0.03"] if args.grid else [])
     cfg_name = {(2000000, 100000000, 2, "lognormal"): "cfg4", (200000, 10000000, 1, "lognormal"): "cfg2"}.get((args.reads, args.lines, args.seed, args.model), "custom")
 
@@ -291,7 +330,7 @@ def main():
     class Runner:
         """the timed step over one workload"""
 
-        def __init__(self, W, hctx=None):
+        def __init__(self, W, hctx=None, overlap=overlap):
             self.W = W
             self.hctx = hctx or ctx  # the context the hit passes run on
             self.out = {"n": 0, "rc": 0, "buf": None}
@@ -473,17 +512,12 @@ def main():
     if rank == 0:
         recs = ctx.prof_get()
         ctx.prof_enable(False)
-        tot_ms = sum(r["total_ms"] for r in recs) or 1.0
         pmc, pmc_src = pmc_profile(cfg_name)
-        for r in sorted(recs, key=lambda r: -r["total_ms"]):
-            per = r["total_ms"] / max(r["launches"], 1)
-            gbs = round(r["alg_bytes"] / max(r["launches"], 1) / (per * 1e-3) / 1e9, 1) if per > 0 and r["alg_bytes"] > 0 else None
-            design = r["name"] in DESIGN_ONLY
-            tr = pmc_traffic(pmc, r["name"])
-            kernels.append({"name": r["name"], "launches_per_step": r["launches"] / max(args.prof_steps, 1), "avg_ms": round(per, 5),
-                            "share": round(r["total_ms"] / tot_ms, 4), "alg_GBs": None if design else gbs, "design_GBs": gbs if design else None,
-                            # the bytes the launch really moved (rocprofv3 PMC profile of this command) / this run's launch time: cannot exceed the peak
-                            "counter_GBs": round(tr / (per * 1e-3) / 1e9, 1) if tr and per > 0 else None})
+        kernels = kernel_table(recs, args.prof_steps)
+        for k in kernels:
+            tr = pmc_traffic(pmc, k["name"])
+            # the bytes the launch really moved (rocprofv3 PMC profile of this command) / this run's launch time: cannot exceed the peak
+            k["counter_GBs"] = round(tr / (k["avg_ms"] * 1e-3) / 1e9, 1) if tr and k["avg_ms"] > 0 else None
         dom = next((k for k in kernels if k["alg_GBs"]), None)
         if dom:
             traffic = pmc_traffic(pmc, dom["name"])
@@ -510,6 +544,24 @@ def main():
                                  "frac": round(chain_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
                                  "note": "584 B per stored hit (SURVEY 8(d), sum over the reference's passes) x hits of this rank / measured step time"}
     run.close()
+
+    # ---- one input at a time: device + host latency of a single batch (no second context, no overlap with a neighbour): `ms_per_step` above is a
+    # throughput figure with two inputs in flight
+    latency = None
+    if rank == 0 and world == 1 and want_leg("latency"):
+        try:
+            solo = Runner(W, overlap=False)
+            solo.step(); solo.fence()
+            lat = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                solo.step(); solo.fence()
+                lat.append((time.perf_counter() - t0) * 1e3)
+            assert solo.output() == gfa
+            solo.close()
+            latency = {"ms": round(min(lat), 4), "ms_all": [round(x, 4) for x in lat], "what": "one input, records resident in HBM -> GFA text in host memory, nothing else in flight (best of 3)"}
+        except Exception as e:
+            log("latency leg failed:", e)
 
     # ---- the same job started one stage earlier: PAF TEXT resident in HBM -> device-side parse + dictionary -> ... -> GFA
     from_text = None
@@ -545,7 +597,7 @@ def main():
     # ---- secondary legs (rank 0, one GPU)
     legs = {}
     if rank == 0 and world == 1 and not args.no_legs:
-        def leg(name, reads, lines, seed, extra, steps, with_ref):
+        def leg(name, reads, lines, seed, extra, steps, with_ref, prof_steps=0):
             try:
                 p = gen_paf(os.path.join(args.workdir, "leg_%s_r%d_n%d_s%d.paf" % (name, reads, lines, seed)), reads, lines, seed, extra)
                 w = Workload(ma, L, ctx, p, opt, 1, 0)
@@ -553,9 +605,26 @@ def main():
                 t = r.timed(1, steps)
                 out = r.output()
                 ti = ctx.tie_stats()
-                res = {"value": w.n_lines * steps / t, "unit": "overlaps/s", "ms_per_step": t / steps * 1e3, "overlaps": w.n_lines, "reads": w.n_seq,
+                res = {"value": w.n_lines * steps / t, "unit": "overlaps/s", "ms_per_step": t / steps * 1e3, "overlaps": w.n_lines, "reads": w.n_seq, "stored_hits": w.n_all,
                        "gfa_bytes": len(out), "tie_groups": ti["arc_tie_groups"],
                        "tie_path": "arc walk%s" % (" + hit walk" if ti["hit_walk"] else "") if ti["arc_walk"] else "stable order (no arc ties)"}
+                if prof_steps:  # HIP events around every timed scope of a few extra steps: where this input's time goes, and the reduce group's roofline
+                    ctx.prof_enable(True)
+                    ctx.prof_reset()
+                    for _ in range(prof_steps):
+                        r.step()
+                    r.fence()
+                    recs = ctx.prof_get()
+                    ctx.prof_enable(False)
+                    kt = kernel_table(recs, prof_steps)
+                    L.mahip_asg_trans_inner.restype = C.c_uint64
+                    L.mahip_asg_trans_inner.argtypes = [C.c_void_p]
+                    n_inner = int(L.mahip_asg_trans_inner(ctx.h))
+                    srt = next((k for k in kt if k["name"] == "k_arc_group_sort"), None) or next((k for k in kt if k["name"] == "k_asg_trans"), None)
+                    n_arc = int(round(srt["alg_bytes_per_step"] / 48.0)) if srt and srt["name"] == "k_arc_group_sort" else None
+                    res["arcs"] = n_arc
+                    res["kernels"] = [{kk: k[kk] for kk in ("name", "launches_per_step", "avg_ms", "share", "alg_GBs", "design_GBs")} for k in kt[:16]]
+                    res["reduce_group"] = reduce_group(kt, n_arc or 0, n_inner)
                 if with_ref:
                     ref = run_reference(p, os.path.join(args.workdir, "leg_%s.ref.gfa" % name))
                     if ref:
@@ -566,11 +635,19 @@ def main():
                 legs[name] = res
             except Exception as e:
                 log("leg %s failed:" % name, e)
-        if cfg_name != "cfg2":
+        if cfg_name != "cfg2" and want_leg("cfg2"):
             leg("cfg2", 200000, 10000000, 1, [], 10, False)  # BASELINE configs[1]
         # coordinates on a 16-bp grid, 30 % dropout, 3 % false overlaps: thousands of equal (u,len) arc keys -- the default
         # mode finds them by census and reproduces the reference's (unstable-sort) order
-        leg("tie_rich", 250000, 5000000, 5, ["-q", "16", "-L", "uniform", "-d", "0.3", "-x", "0.03"], 3, not args.no_cpu)
+        if want_leg("tie_rich"):
+            leg("tie_rich", 250000, 5000000, 5, ["-q", "16", "-L", "uniform", "-d", "0.3", "-x", "0.03"], 3, not args.no_cpu)
+        # graph-heavy ("always also run a graph-heavy fixed-length variant"): reads of ONE length, nothing is contained, every stored hit becomes an
+        # arc -- the input on which arc sort, index, transitive reduction, symm and asg_arc_rm have work (at cfg4 containment leaves 1 M arcs of 200 M hits)
+        if args.graph_heavy_lines > 0 and want_leg("graph_heavy"):
+            leg("graph_heavy", max(args.graph_heavy_lines // 50, 100), args.graph_heavy_lines, 4, ["-L", "fixed"], 5, not args.no_cpu, prof_steps=2)
+            if legs.get("graph_heavy", {}).get("reduce_group") and roof is not None:
+                roof["reduce_group"] = dict(legs["graph_heavy"]["reduce_group"], input="legs.graph_heavy: pafgen -L fixed, %d overlaps, %d reads, %s arcs" % (
+                    legs["graph_heavy"]["overlaps"], legs["graph_heavy"]["reads"], legs["graph_heavy"]["arcs"]))
 
     # ---- the reference on the same file: CPU baseline + the GFA every output above is compared with
     cpu, parity, e2e = None, None, None
@@ -598,7 +675,7 @@ def main():
                           "ref_from": "the reference's GFA of this file, kept by the N = 1 run in the work directory"}
         except Exception as e:
             log("parity against the cached reference GFA failed:", e)
-    if rank == 0 and world == 1 and not args.no_legs:
+    if rank == 0 and world == 1 and want_leg("e2e"):
         try:  # the command line, process start -> GFA on disk (north_star's ">= 10x reference wall-clock" is about this)
             outp = os.path.join(args.workdir, "cli_%s.gfa" % cfg_name)
             best = None
@@ -632,7 +709,7 @@ def main():
             "gfa_identical": parity["gfa_identical"] if parity else None, "parity": parity,
             "tie_groups": tie["arc_tie_groups"] if tie else None,
             "tie_path": None if not tie else ("arc walk%s" % (" + hit walk" if tie["hit_walk"] else "") if tie["arc_walk"] else "unrepaired" if tie["unrepaired"] else "stable order (census: no arc ties => provably the reference's order)"),
-            "phases": phases, "roofline": roof, "cpu_baseline": cpu, "e2e": e2e, "from_text": from_text, "legs": legs, "kernels": kernels[:14],
+            "phases": phases, "roofline": roof, "cpu_baseline": cpu, "latency": latency, "e2e": e2e, "from_text": from_text, "legs": legs, "kernels": kernels[:14],
             "setup": {"gen_s": t_gen, "file_to_hbm_s": W.t_load, "file_to_hbm_GBs": W.size / W.t_load / 1e9, "parse_dictionary_s": W.t_parse, "hbm_bytes_held": ctx.mem_bytes()},
         }
         print(json.dumps(out), flush=True)

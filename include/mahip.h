@@ -196,6 +196,9 @@ int mahip_useq_begin(mahip_ctx_t *c, size_t arena_bytes);          /* arena of a
 int mahip_useq_batch(mahip_ctx_t *c, const char *h_seq, size_t seq_bytes, const mahip_useq_job_t *h_jobs, size_t n_jobs);
 int mahip_useq_end(mahip_ctx_t *c, char *h_arena);                 /* the arena back to the host */
 uint32_t mahip_asg_n_arc(mahip_ctx_t *c);
+/* iterations of the inner loop of asg_arc_del_trans (asg.c:169) in the last reduction this context ran, counted on the device: SURVEY 8(d) prices the
+ * reduction at 16 (A + I) bytes (bench.py: roofline.reduce_group) */
+uint64_t mahip_asg_trans_inner(mahip_ctx_t *c);
 /* fills g (arc/seq/idx malloc'ed, is_srt=1) in the squeezed numbering */
 int mahip_asg_download(mahip_ctx_t *c, asg_t *g);
 

@@ -110,31 +110,68 @@ __global__ __launch_bounds__(256) void k_sg_arcs(HitColsG h, size_t n, const uin
 // passes B (out.u == nullptr: count per tile) and C (write): one thread per 64-slot word of the candidate mask, tile b = the words
 // [b*256, (b+1)*256) = SG_TILE consecutive hits.  Candidates are rare (a handful per tile): a thread walks the set bits of its word
 // and recomputes those arcs; threads, and the bits inside a word, are in hit order, so the dense slots are too.
+// A word with many candidates (graph-heavy inputs: reads of one length, nothing contained -- every hit becomes an arc) is taken by the whole WAVE, a slot
+// per lane: eight coalesced column loads per word instead of eight cache lines per candidate of a lane that walks its word alone (SG_DENSE: from how many
+// candidates on).  Which form handles a word changes nothing about where its arcs go: the owner lane's count and offset are the same.
+#ifndef SG_DENSE
+#define SG_DENSE 6
+#endif
+__device__ __forceinline__ unsigned long long wv_bcast_u64(unsigned long long x, int src) { return (unsigned long long)__shfl((uint32_t)(x >> 32), src, 64) << 32 | __shfl((uint32_t)x, src, 64); }
+
 __global__ __launch_bounds__(256) void k_sg_emit(HitColsG h, size_t n, const uint32_t *__restrict__ slen, const uint8_t *__restrict__ sdel,
                                                   int max_hang, float int_frac, int min_ovlp, const unsigned long long *__restrict__ cmask,
                                                   uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off, ArcCols out, uint32_t *__restrict__ aslot)
 { // aslot (optional, pass C): the hit slot each pushed arc comes from (push order, tie-order repair)
 	__shared__ uint32_t s_w[4];
-	const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x, n_words = (n + 63) >> 6;
+	const unsigned lane = threadIdx.x & 63;
+	const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x, n_words = (n + 63) >> 6, w0 = w - lane;
 	unsigned long long m = w < n_words ? cmask[w] : 0ull, kept = 0;
 	uint32_t cnt = 0;
-	for (unsigned long long rest = m; rest; rest &= rest - 1) { // which candidates survive asg_arc_rm on the fresh arcs (asg.c:57-70): endpoints must be alive
-		const int b = __ffsll((long long)rest) - 1;
-		const size_t i = (w << 6) + (size_t)b;
-		if (i < n && !sdel[h.qid[i]] && !sdel[h.tn[i]]) kept |= 1ull << b, ++cnt;
+	const bool dense = __popcll(m) >= SG_DENSE;
+	const unsigned long long dense_lanes = wv_ballot(dense);
+	// which candidates survive asg_arc_rm on the fresh arcs (asg.c:57-70): endpoints must be alive
+	for (unsigned long long dl = dense_lanes; dl; dl &= dl - 1) {
+		const int l = __ffsll((long long)dl) - 1;
+		const unsigned long long ml = wv_bcast_u64(m, l);
+		const size_t i = ((w0 + (size_t)l) << 6) + lane;
+		const int k = (ml >> lane & 1ull) && i < n && !sdel[h.qid[i]] && !sdel[h.tn[i]];
+		const unsigned long long kb = wv_ballot(k);
+		if ((int)lane == l) kept = kb, cnt = (uint32_t)__popcll(kb);
 	}
+	if (!dense)
+		for (unsigned long long rest = m; rest; rest &= rest - 1) {
+			const int b = __ffsll((long long)rest) - 1;
+			const size_t i = (w << 6) + (size_t)b;
+			if (i < n && !sdel[h.qid[i]] && !sdel[h.tn[i]]) kept |= 1ull << b, ++cnt;
+		}
 	uint32_t tot, ex = block_excl_scan_256(cnt, s_w, &tot);
 	if (!out.u) { if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot; return; }
 	uint32_t p = tile_off[blockIdx.x] + ex;
-	for (; kept; kept &= kept - 1, ++p) {
-		const size_t i = (w << 6) + (size_t)(__ffsll((long long)kept) - 1);
-		mc_arc_t x;
-		uint32_t q = 0, t = 0;
-		int self_rc = 0;
-		sg_candidate(h, i, slen, max_hang, int_frac, min_ovlp, nullptr, &x, &q, &t, &self_rc);
-		out.u[p] = x.u; out.v[p] = x.v; out.len[p] = x.len; out.ol[p] = x.ol;
-		if (aslot) aslot[p] = (uint32_t)i;
+	for (unsigned long long dl = dense_lanes; dl; dl &= dl - 1) {
+		const int l = __ffsll((long long)dl) - 1;
+		const unsigned long long kl = wv_bcast_u64(kept, l);
+		const uint32_t pl = __shfl(p, l, 64);
+		if (kl >> lane & 1ull) {
+			const size_t i = ((w0 + (size_t)l) << 6) + lane;
+			const uint32_t pp = pl + (uint32_t)__popcll(kl & wv_lt(lane));
+			mc_arc_t x;
+			uint32_t q = 0, t = 0;
+			int self_rc = 0;
+			sg_candidate(h, i, slen, max_hang, int_frac, min_ovlp, nullptr, &x, &q, &t, &self_rc);
+			out.u[pp] = x.u; out.v[pp] = x.v; out.len[pp] = x.len; out.ol[pp] = x.ol;
+			if (aslot) aslot[pp] = (uint32_t)i;
+		}
 	}
+	if (!dense)
+		for (; kept; kept &= kept - 1, ++p) {
+			const size_t i = (w << 6) + (size_t)(__ffsll((long long)kept) - 1);
+			mc_arc_t x;
+			uint32_t q = 0, t = 0;
+			int self_rc = 0;
+			sg_candidate(h, i, slen, max_hang, int_frac, min_ovlp, nullptr, &x, &q, &t, &self_rc);
+			out.u[p] = x.u; out.v[p] = x.v; out.len[p] = x.len; out.ol[p] = x.ol;
+			if (aslot) aslot[p] = (uint32_t)i;
+		}
 }
 
 __global__ __launch_bounds__(256) void k_arc_keep(ArcCols a, size_t n, const uint8_t *__restrict__ sdel, uint32_t *__restrict__ keep, int use_keep_in)
@@ -153,6 +190,54 @@ __global__ __launch_bounds__(256) void k_arc_compact(ArcCols in, size_t n, const
 		uint32_t p = pos[i];
 		out.u[p] = in.u[i]; out.v[p] = in.v[i]; out.len[p] = in.len[i]; out.ol[p] = in.ol[i];
 	}
+}
+
+// asg_arc_rm (asg.c:57-70) in ONE pass: a tile of RM_TILE consecutive arcs decides what stays (not deleted, both reads alive), learns where its
+// survivors go from the tiles before it (chained look-back, mahip_internal.hpp: sc_look_back) and writes them -- every arc read once, the survivors
+// written once (32 B per arc), no flag and position arrays in between.  The three-launch form above (flags, scan, compact) moves 70 B per
+// arc and is kept for MA_ARC_RM_OLD=1 (A/B on the GPU) only.
+#define RM_ITEMS 8
+#define RM_TILE (256 * RM_ITEMS)
+__global__ __launch_bounds__(256) void k_arc_rm_chain(ArcCols in, size_t n, const uint8_t *__restrict__ sdel, ArcCols out, uint32_t *__restrict__ d_total,
+                                                       unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
+{
+	__shared__ uint32_t s_wave[4];
+	__shared__ uint32_t s_tile, s_prefix;
+	if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+	__syncthreads();
+	const uint32_t tile = s_tile;
+	const size_t base = (size_t)tile * RM_TILE + (size_t)threadIdx.x * RM_ITEMS;
+	uint32_t u[RM_ITEMS], v[RM_ITEMS], ol[RM_ITEMS], keep = 0;
+	if (base + RM_ITEMS <= n) {
+		const uint4 *pu = (const uint4*)(in.u + base), *pv = (const uint4*)(in.v + base), *po = (const uint4*)(in.ol + base);
+		const uint4 a0 = pu[0], a1 = pu[1], b0 = pv[0], b1 = pv[1], c0 = po[0], c1 = po[1];
+		u[0] = a0.x, u[1] = a0.y, u[2] = a0.z, u[3] = a0.w, u[4] = a1.x, u[5] = a1.y, u[6] = a1.z, u[7] = a1.w;
+		v[0] = b0.x, v[1] = b0.y, v[2] = b0.z, v[3] = b0.w, v[4] = b1.x, v[5] = b1.y, v[6] = b1.z, v[7] = b1.w;
+		ol[0] = c0.x, ol[1] = c0.y, ol[2] = c0.z, ol[3] = c0.w, ol[4] = c1.x, ol[5] = c1.y, ol[6] = c1.z, ol[7] = c1.w;
+	} else {
+#pragma unroll
+		for (int i = 0; i < RM_ITEMS; ++i) { const bool in_r = base + i < n; u[i] = in_r ? in.u[base + i] : 0; v[i] = in_r ? in.v[base + i] : 0; ol[i] = in_r ? in.ol[base + i] : ADEL; }
+	}
+#pragma unroll
+	for (int i = 0; i < RM_ITEMS; ++i)
+		if (base + i < n && !(ol[i] & ADEL) && !sdel[u[i] >> 1] && !sdel[v[i] >> 1]) keep |= 1u << i;
+	const uint32_t cnt = (uint32_t)__popc(keep);
+	uint32_t tot;
+	const uint32_t ex = block_excl_scan_256(cnt, s_wave, &tot);
+	if (threadIdx.x == 0) {
+		SC_PUBLISH(&state[tile], sc_pack(epoch, tile == 0 ? SC_INCL : SC_AGG, tot));
+		if (tile == 0) s_prefix = 0;
+	}
+	if (tile > 0 && threadIdx.x < 64) {
+		const uint32_t prefix = sc_look_back(state, tile, epoch, threadIdx.x);
+		if (threadIdx.x == 0) { s_prefix = prefix; SC_PUBLISH(&state[tile], sc_pack(epoch, SC_INCL, prefix + tot)); }
+	}
+	__syncthreads();
+	uint32_t p = s_prefix + ex;
+#pragma unroll
+	for (int i = 0; i < RM_ITEMS; ++i)
+		if (keep >> i & 1u) { out.u[p] = u[i]; out.v[p] = v[i]; out.len[p] = in.len[base + i]; out.ol[p] = ol[i]; ++p; }
+	if (base < n && base + RM_ITEMS >= n) *d_total = p; // the last thread with arcs: its end is the total
 }
 
 __global__ __launch_bounds__(256) void k_arc_keys(ArcCols a, size_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
@@ -354,7 +439,7 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 	__shared__ uint32_t s_ws[4][SMALL ? CAP : 1], s_nw[4][SMALL ? CAP : 1];
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t *lv = s_v[wave], *ll = s_l[wave], *slot = s_slot[wave], *hk = s_hk[wave], *hm = s_hm[wave];
-	uint32_t n_red = 0;
+	uint32_t n_red = 0, n_inner = 0; // n_inner: bodies of the loop at asg.c:169 this lane executed (SURVEY 8(d) prices the reduction at 16 (A + I) bytes)
 	// a wave takes 64 consecutive vertices at a time: one coalesced load of their CSR entries, then only the vertices that have arcs (of this
 	// instantiation's size class) are visited -- after containment most vertices have none, and a dependent load per vertex is pure latency
 	for (uint64_t vb = (uint64_t)v_beg + (uint64_t)(blockIdx.x * 4 + wave) * 64; vb < n_vtx; vb += (uint64_t)gridDim.x * 256) {
@@ -413,6 +498,7 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 					uint64_t fail = wv_ballot(ok && !cond);
 					if (fail) cond = cond && lane < (unsigned)(__ffsll((long long)fail) - 1);
 					if (cond) {
+						++n_inner;
 						int sx = tr_find(hk, av[ws + j], hbits);
 						if (sx >= 0) hm[sx] = (hm[sx] & ~3u) | 2u; // every writer stores the same word
 					}
@@ -429,6 +515,7 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 	}
 	}
 	blk_add_u64(&ctr[CT_NRED], n_red);
+	blk_add_u64(&ctr[CT_TRINNER], n_inner);
 }
 
 // second tier: vertices with more than TR_CAP arcs; one block per vertex with a private global mark array
@@ -489,14 +576,17 @@ __global__ __launch_bounds__(256) void k_asg_multi(ArcCols a, size_t n, const un
 __global__ __launch_bounds__(256) void k_asg_asymm(ArcCols a, size_t n, const unsigned long long *__restrict__ idx, unsigned long long *__restrict__ ctr)
 {
 	uint32_t cnt = 0;
+	uint64_t probed = 0;
 	for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
 		uint32_t v = a.v[e] ^ 1, u = a.u[e] ^ 1;
 		unsigned long long x = idx[v];
 		uint32_t st = (uint32_t)(x >> 32), nv = (uint32_t)x, i;
 		for (i = 0; i < nv; ++i) if (a.v[st + i] == u) break;
+		probed += i < nv ? i + 1 : nv;
 		if (i == nv) a.ol[e] |= ADEL, ++cnt; // only the ol column is written; the v column read above is never modified
 	}
 	blk_add_u64(&ctr[CT_NASYMM], cnt);
+	blk_add_u64(&ctr[CT_PROBED], probed);
 }
 
 // asg.c:83-101
@@ -591,7 +681,14 @@ static int arc_cleanup(mahip_ctx *c, size_t n_in, int keep_in, int index_mode)
 	uint32_t *d_tot = (uint32_t*)(P<unsigned long long>(c->ctr) + CT_TOTAL);
 	if (n_in == 0) { c->n_arc = 0; return index_mode < 0 ? 0 : arc_reindex(c); }
 	ArcCols in = arcs_of(c, c->ag), out = arcs_of(c, c->ag ^ 1);
-	{
+	static const bool old_form = getenv("MA_ARC_RM_OLD") != nullptr;
+	if (!keep_in && !old_form) {
+		const size_t nb = (n_in + RM_TILE - 1) / RM_TILE;
+		uint32_t *ticket; unsigned long long *state; uint32_t ticket_base, epoch;
+		CHK(scan_chain_begin(c, nb, &state, &ticket, &ticket_base, &epoch));
+		ProfScope ps(c, "k_arc_rm", 32.0 * (double)n_in); // asg_arc_rm 32 B per arc
+		hipLaunchKernelGGL(k_arc_rm_chain, dim3((unsigned)nb), dim3(256), 0, c->st, in, n_in, (const uint8_t*)P<uint8_t>(c->sdel), out, d_tot, state, ticket, ticket_base, epoch);
+	} else {
 		ProfScope ps(c, "k_arc_rm", 32.0 * (double)n_in); // asg_arc_rm 32 B per arc
 		hipLaunchKernelGGL(k_arc_keep, dim3(grid_for(n_in, 256)), dim3(256), 0, c->st, in, n_in, (const uint8_t*)P<uint8_t>(c->sdel), P<uint32_t>(c->keep), keep_in);
 		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), n_in, d_tot));
@@ -1115,6 +1212,8 @@ extern "C" int mahip_asg_del_trans_range(mahip_ctx_t *c, int fuzz, uint32_t v_be
 		                   (const unsigned long long*)P<unsigned long long>(c->idx), (const uint8_t*)P<uint8_t>(c->sdel), v_beg, v_end, (uint32_t)fuzz, P<uint32_t>(c->ovf), ctr);
 	}
 	CHK(ctr_fetch(c));
+	c->tr_inner = c->h_ctr[CT_TRINNER];
+	if (c->prof && c->n_arc) prof_patch_last(c, "k_asg_trans", 16.0 * ((double)c->n_arc + (double)c->tr_inner)); // 16 (A + I) with the I this launch really ran
 	uint32_t n_ovf = (uint32_t)c->h_ctr[CT_OVF2];
 	if (n_ovf) {
 		unsigned nblk = n_ovf < 64 ? n_ovf : 64;
@@ -1169,6 +1268,7 @@ extern "C" int mahip_asg_del_asymm(mahip_ctx_t *c, uint32_t *n_asymm)
 		                   (const unsigned long long*)P<unsigned long long>(c->idx), P<unsigned long long>(c->ctr));
 	}
 	CHK(ctr_fetch(c));
+	if (c->prof && c->n_arc) prof_patch_last(c, "k_asg_asymm", 16.0 * (double)c->n_arc + 16.0 * (double)c->h_ctr[CT_PROBED]); // 16 + 16 x list entries probed
 	const uint32_t na = (uint32_t)c->h_ctr[CT_NASYMM];
 	if (na) CHK(arc_cleanup(c, c->n_arc, 0, 0));
 	if (n_asymm) *n_asymm = na;
@@ -1196,6 +1296,8 @@ extern "C" int mahip_asg_del_short(mahip_ctx_t *c, float drop_ratio, uint32_t *n
 }
 
 extern "C" uint32_t mahip_asg_n_arc(mahip_ctx_t *c) { return c->n_arc; }
+// iterations of the loop at asg.c:169 the last reduction on this context ran (the reduction moves 16 (A + I) bytes)
+extern "C" uint64_t mahip_asg_trans_inner(mahip_ctx_t *c) { return c->tr_inner; }
 
 extern "C" int mahip_asg_download(mahip_ctx_t *c, asg_t *g)
 {

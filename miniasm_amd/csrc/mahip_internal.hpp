@@ -123,6 +123,7 @@ struct mahip_ctx {
 
 	hipEvent_t mark_ev[64] = {}; // phase marks (mahip_mark)
 	hipStream_t sub_side[2] = {}; hipEvent_t sub_ev[3] = {}; // side streams of the coverage passes' size classes (hits.hip: SubFork)
+	uint64_t tr_inner = 0;                                  // iterations of asg.c:169's loop in the last reduction (mahip_asg_trans_inner)
 	bool radix_arcs = false;                                // the radix passes running now sort arcs (profile names)
 	bool sub_fork_failed = false;                           // they could not be created: every size class on the context's stream
 	unsigned long long mark_set = 0;
@@ -162,7 +163,7 @@ template <typename T> static inline T *P(DevBuf &b) { return (T*)b.p; }
 static inline bool xchg_needs_sync(const mahip_ctx *c) { return c->own_stream && !c->comm; }
 
 // counters (indices into ctx->ctr)
-enum { CT_LIVE = 0, CT_REMAIN, CT_TOTDP, CT_TOTLEN, CT_OVF, CT_NRED, CT_NMULTI, CT_NASYMM, CT_NSHORT, CT_MAXQID, CT_MAXQS, CT_TOTAL, CT_OVF2, CT_MAXLEN, CT_CUT, CT_N };
+enum { CT_LIVE = 0, CT_REMAIN, CT_TOTDP, CT_TOTLEN, CT_OVF, CT_NRED, CT_NMULTI, CT_NASYMM, CT_NSHORT, CT_MAXQID, CT_MAXQS, CT_TOTAL, CT_OVF2, CT_MAXLEN, CT_CUT, CT_TRINNER /* iterations of asg.c:169's loop */, CT_PROBED /* list entries asg.c:131 looked at */, CT_N };
 // slots [CT_STICKY, 64) are not touched by ctr_zero: the tie census keeps its results there until they are read
 enum { CT_STICKY = 48, ST_ARC_TIE_GROUPS = 48, ST_ARC_TIE_ARCS, ST_PUSH_CONFLICTS, ST_HIT_TIES };
 int ctr_zero(mahip_ctx *c);
@@ -180,6 +181,7 @@ int radix_sort_pairs(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1,
 int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen, bool first_hist_ready = false);
 void radix_first_digit(int lo, int hi, int *shift, int *bits, unsigned *tile);
 int radix_reserve_hist(mahip_ctx *c, size_t n);
+int scan_chain_begin(mahip_ctx *c, size_t nb, unsigned long long **state, uint32_t **ticket, uint32_t *ticket_base, uint32_t *epoch);
 // the permutation the reference's (unstable) sort applies to d_keys[0..n) (input order), written to d_perm
 int reference_order(mahip_ctx *c, uint64_t *d_keys /* overwritten */, size_t n, uint32_t *d_perm);
 void walk_scratch_release(mahip_ctx *c); // the host arrays of the walks go away (on a thread of their own when they are big)
@@ -344,6 +346,32 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t x, uint32_t *s_
 	__syncthreads();
 	*total = tot;
 	return base + incl - x;
+}
+// ---- chained tiles (scan.hip: k_scan_chain; graph.hip: k_arc_rm_chain) ----
+#define SC_AGG 1ull
+#define SC_INCL 2ull
+__device__ __forceinline__ unsigned long long sc_pack(uint32_t epoch, unsigned long long st, uint32_t v) { return (unsigned long long)epoch << 34 | st << 32 | v; }
+// A published word carries its own flag, so nothing has to be ordered against it: RELAXED atomics at AGENT scope (served where the eight XCDs' L2s meet).
+// The first version used __atomic_store_n(RELEASE) / __atomic_load_n(ACQUIRE), i.e. SYSTEM scope: on this chip a release writes the XCD's L2 back and an
+// acquire invalidates it -- per tile, and per spin of a waiting lane.  A 100 M-element scan took 11.4 ms instead of 0.4 (round 3, visit E).
+#define SC_PUBLISH(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SC_PEEK(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// exclusive prefix of tile `tile` (> 0) from the words its predecessors published: one wave, 64 predecessors per step (one per lane), until one of them
+// knows its inclusive prefix.  Tiles take their numbers from an atomic ticket, so every predecessor has started and publishes without waiting for anybody.
+__device__ __forceinline__ uint32_t sc_look_back(const unsigned long long *state, uint32_t tile, uint32_t epoch, unsigned lane)
+{
+	uint32_t prefix = 0;
+	for (long look = (long)tile - 1;; look -= 64) {
+		const long idx = look - (long)lane;
+		unsigned long long w = sc_pack(epoch, SC_INCL, 0); // in front of tile 0: an inclusive prefix of zero
+		if (idx >= 0) do { w = SC_PEEK(&state[idx]); } while ((uint32_t)(w >> 34) != epoch || ((w >> 32) & 3ull) == 0);
+		const unsigned long long incl = wv_ballot(((w >> 32) & 3ull) == SC_INCL);
+		const int first = incl ? __ffsll((long long)incl) - 1 : 63; // the nearest predecessor that knows its inclusive prefix
+		prefix += wv_sum_u32(lane <= (unsigned)first ? (uint32_t)w : 0u);
+		if (incl) break;
+	}
+	return prefix;
 }
 // ---- the wave's register sorting network (coverage sweeps of hits.hip, arc groups of graph.hip) ----
 #define MA_CE(a, b) do { uint32_t lo_ = (a) < (b) ? (a) : (b), hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; } while (0)

@@ -86,15 +86,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const uint32_t *in, 
 	if (d_total && base < n && base + SCAN_ITEMS >= n) *d_total = run;
 }
 
-#define SC_AGG 1ull
-#define SC_INCL 2ull
-__device__ __forceinline__ unsigned long long sc_pack(uint32_t epoch, unsigned long long st, uint32_t v) { return (unsigned long long)epoch << 34 | st << 32 | v; }
-// A published word carries its own flag, so nothing has to be ordered against it: RELAXED atomics at AGENT scope (served where the eight XCDs' L2s meet).
-// The first version used __atomic_store_n(RELEASE) / __atomic_load_n(ACQUIRE), i.e. SYSTEM scope: on this chip a release writes the XCD's L2 back and an
-// acquire invalidates it -- per tile, and per spin of a waiting lane.  A 100 M-element scan took 11.4 ms instead of 0.4 (round 3, visit E).
-#define SC_PUBLISH(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define SC_PEEK(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-
+// (SC_AGG / SC_INCL / sc_pack / SC_PUBLISH / SC_PEEK and the look-back itself, sc_look_back: mahip_internal.hpp -- graph.hip's one-pass arc compaction chains its tiles the same way)
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const uint32_t *in, uint32_t *out, // may alias (in-place)
                                                               size_t n, uint32_t *d_total, unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
 {
@@ -119,18 +111,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chain(const uint32_t *in,
 		if (tile == 0) s_prefix = 0;
 	}
 	if (tile > 0 && threadIdx.x < 64) { // look back
-		const unsigned lane = threadIdx.x;
-		uint32_t prefix = 0;
-		for (long look = (long)tile - 1;; look -= 64) {
-			const long idx = look - (long)lane;
-			unsigned long long w = sc_pack(epoch, SC_INCL, 0); // in front of tile 0: an inclusive prefix of zero
-			if (idx >= 0) do { w = SC_PEEK(&state[idx]); } while ((uint32_t)(w >> 34) != epoch || ((w >> 32) & 3ull) == 0);
-			const unsigned long long incl = wv_ballot(((w >> 32) & 3ull) == SC_INCL);
-			const int first = incl ? __ffsll((long long)incl) - 1 : 63; // the nearest predecessor that knows its inclusive prefix
-			prefix += wv_sum_u32(lane <= (unsigned)first ? (uint32_t)w : 0u);
-			if (incl) break;
-		}
-		if (lane == 0) { s_prefix = prefix; SC_PUBLISH(&state[tile], sc_pack(epoch, SC_INCL, prefix + tot)); }
+		const uint32_t prefix = sc_look_back(state, tile, epoch, threadIdx.x);
+		if (threadIdx.x == 0) { s_prefix = prefix; SC_PUBLISH(&state[tile], sc_pack(epoch, SC_INCL, prefix + tot)); }
 	}
 	__syncthreads();
 	uint32_t run = ex + s_prefix;
@@ -170,6 +152,23 @@ static int scan_rec(mahip_ctx *c, const uint32_t *in, uint32_t *out, size_t n, u
 // traffic pattern is the safer one
 static size_t scan_chain_max() { static long v = -1; if (v < 0) { const char *e = getenv("MA_SCAN_CHAIN_MAX"); v = e ? atol(e) : 256; } return (size_t)v; }
 
+// the published words + ticket of ONE chained launch of nb tiles (k_scan_chain, graph.hip: k_arc_rm_chain): the tiles behind one ticket word; fresh memory
+// is cleared once, afterwards the launch epoch tells this launch's words from older ones
+int scan_chain_begin(mahip_ctx *c, size_t nb, unsigned long long **state, uint32_t **ticket, uint32_t *ticket_base, uint32_t *epoch)
+{
+	if (c->scan_tmp[0].cap < (nb + 8) * 8 + 64) { // epoch 0 is never used
+		CHK(dev_reserve(c, c->scan_tmp[0], (nb + 8) * 8 * 2 + 64));
+		HIPCHK(hipMemsetAsync(c->scan_tmp[0].p, 0, c->scan_tmp[0].cap, c->st));
+		c->scan_ticket = 0; c->scan_epoch = 0;
+	}
+	*ticket = P<uint32_t>(c->scan_tmp[0]);
+	*state = (unsigned long long*)((char*)c->scan_tmp[0].p + 64);
+	if (++c->scan_epoch >= (1u << 30)) { HIPCHK(hipMemsetAsync(*state, 0, c->scan_tmp[0].cap - 64, c->st)); c->scan_epoch = 1; } // (after 2^30 launches)
+	*ticket_base = c->scan_ticket; *epoch = c->scan_epoch;
+	c->scan_ticket += (uint32_t)nb;
+	return 0;
+}
+
 int scan_exclusive_u32(mahip_ctx *c, const uint32_t *in, uint32_t *out, size_t n, uint32_t *d_total)
 {
 	ProfScope ps(c, "scan_exclusive_u32", 8.0 * (double)n);
@@ -189,16 +188,9 @@ int scan_exclusive_u32(mahip_ctx *c, const uint32_t *in, uint32_t *out, size_t n
 		HIPCHK(hipGetLastError());
 		return 0;
 	}
-	if (c->scan_tmp[0].cap < (nb + 8) * 8 + 64) { // published words of the tiles behind one ticket word; fresh memory: epoch 0 is never used
-		CHK(dev_reserve(c, c->scan_tmp[0], (nb + 8) * 8 * 2 + 64));
-		HIPCHK(hipMemsetAsync(c->scan_tmp[0].p, 0, c->scan_tmp[0].cap, c->st));
-		c->scan_ticket = 0; c->scan_epoch = 0;
-	}
-	uint32_t *ticket = P<uint32_t>(c->scan_tmp[0]);
-	unsigned long long *state = (unsigned long long*)((char*)c->scan_tmp[0].p + 64);
-	if (++c->scan_epoch >= (1u << 30)) { HIPCHK(hipMemsetAsync(state, 0, c->scan_tmp[0].cap - 64, c->st)); c->scan_epoch = 1; } // (after 2^30 scans)
-	hipLaunchKernelGGL(k_scan_chain, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, c->st, in, out, n, d_total, state, ticket, c->scan_ticket, c->scan_epoch);
-	c->scan_ticket += (uint32_t)nb;
+	uint32_t *ticket; unsigned long long *state; uint32_t ticket_base, epoch;
+	CHK(scan_chain_begin(c, nb, &state, &ticket, &ticket_base, &epoch));
+	hipLaunchKernelGGL(k_scan_chain, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, c->st, in, out, n, d_total, state, ticket, ticket_base, epoch);
 	HIPCHK(hipGetLastError());
 	return 0;
 }

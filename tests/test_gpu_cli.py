@@ -291,6 +291,42 @@ def test_cli_matches_reference_at_baseline_scale(name, tmpdir_s):
     os.remove(paf)
 
 
+# ---- the largest BASELINE configurations (configs[2] stand-in: 40 M overlaps; configs[4]: 500 M overlaps, high-repeat; a 100 M-overlap graph-heavy
+# input with 200 M arcs).  Opt-in (MA_TEST_BIG=1): the reference alone needs 36 s / 7 minutes / 3 minutes on them and the 500 M file is 30 GB of text;
+# round 3 ran them by hand (profiles/r03_e2e_*.txt) -- here a driver can.  MA_TEST_BIG=cfg3,graph selects.
+HUGE_INPUTS = {
+    "cfg3": dict(reads=1200000, lines=40000000, seed=7, extra=[]),
+    "graph": dict(reads=2000000, lines=100000000, seed=4, extra=["-L", "fixed"]),
+    "cfg5": dict(reads=5000000, lines=500000000, seed=3, extra=["-L", "uniform", "-d", "0.35", "-x", "0.03"]),
+}
+_BIG = os.environ.get("MA_TEST_BIG", "")
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.skipif(not _BIG, reason="MA_TEST_BIG=1 (or a comma list of cfg3,graph,cfg5) runs the 40 M / 100 M graph-heavy / 500 M inputs against the reference")
+@pytest.mark.parametrize("name", list(HUGE_INPUTS))
+def test_cli_matches_reference_on_the_largest_configurations(name, tmpdir_s):
+    import hashlib
+    import subprocess
+    if _BIG != "1" and name not in _BIG.split(","):
+        pytest.skip("not selected by MA_TEST_BIG")
+    cfg = HUGE_INPUTS[name]
+    paf = R.pafgen(os.path.join(os.environ.get("MA_TEST_BIG_DIR", tmpdir_s), "huge_%s.paf" % name), cfg["reads"], cfg["lines"], cfg["seed"], cfg["extra"])
+    try:
+        digests = []
+        for binary in (ma.CLI_PATH, R.REF_BIN):
+            h, n = hashlib.md5(), 0
+            with subprocess.Popen([binary, paf], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) as pr:
+                for blk in iter(lambda: pr.stdout.read(1 << 24), b""):
+                    h.update(blk); n += len(blk)
+            assert pr.returncode == 0, binary
+            digests.append((h.hexdigest(), n))
+        assert digests[0] == digests[1], "%s: bytes differ from the reference (raw md5, no normalisation)" % name
+        assert digests[0][1] > 1000
+    finally:
+        os.remove(paf)
+
+
 @pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
 def test_bubble_probes_that_outgrow_their_tables(tmpdir_s, monkeypatch):
     """a bubble probe that fills its table hands its source to a launch with bigger tables (csrc/clean.hip, tiers); with tier 0
