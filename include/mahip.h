@@ -182,6 +182,9 @@ int mahip_asg_cut_tip(mahip_ctx_t *c, int max_ext, uint32_t *n_cut);            
 int mahip_asg_cut_internal(mahip_ctx_t *c, int max_ext, uint32_t *n_cut);                  /* asg.c:256-272 */
 int mahip_asg_cut_biloop(mahip_ctx_t *c, int max_ext, uint32_t *n_cut);                    /* asg.c:274-306 */
 int mahip_asg_pop_bubble(mahip_ctx_t *c, int max_dist, uint32_t *n_pop, uint32_t *n_tips); /* asg.c:412-433 (the graph must be symmetric) */
+/* how many asg_pop_bubble calls of this context were run as the reference's sequential sweep on one lane (graphs that are not symmetric or not clean:
+ * csrc/clean_core.h, ASSUMPTION; MA_BUBBLE_SEQ=1 forces it) */
+uint32_t mahip_bubble_seq_sweeps(mahip_ctx_t *c);
 /* asm.c:121-210 ma_ug_gen on the device (csrc/ug.hip): unitigs of the current graph.  Counts: unitigs, reads on them, arcs
  * between unitig ends.  mahip_ug_download: per unitig {reads, length, start, end} (start == end == 0xffffffff: circular) and the
  * offset of its members; members = vertex << 32 | length to the next read; uarcs = the unitig arcs in push order (the

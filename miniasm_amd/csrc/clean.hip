@@ -194,11 +194,21 @@ __global__ __launch_bounds__(256) void k_clean_apply(const uint32_t *__restrict_
 	if (i < n_arc && ast[i] != CL_NONE) aol[i] |= CL_ADEL;
 }
 
+// the reference's own sweep on ONE lane (clean_core.h: cl_bubble_sweep_seq): for graphs outside the fixpoint's contract, and for MA_BUBBLE_SEQ=1
+__global__ __launch_bounds__(64) void k_clean_bubble_seq(const uint32_t *au, const uint32_t *av, const uint32_t *alen, uint32_t *aol, const unsigned long long *idx, uint8_t *sdel, uint32_t n_vtx,
+                                                          uint32_t max_dist, cl_seqinfo_t *info, uint32_t *stk, uint32_t *seen, uint32_t *walked, unsigned long long *ctr)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	unsigned long long pops = 0, tips = 0;
+	const int rc = cl_bubble_sweep_seq(au, av, alen, aol, idx, sdel, n_vtx, max_dist, info, stk, seen, walked, &pops, &tips);
+	ctr[CT_LIVE] = pops; ctr[CT_REMAIN] = tips; ctr[CT_OVF] = rc != 0;
+}
+
 // bubble tables: tier 0 = one small table per thread of the full-width launch; tiers above (16x the slots, 1/16 of the threads: the same
 // bytes) only ever see the sources that overflowed the tier below
 enum { BUB_CAP0 = 16, BUB_THREADS0 = 524288, BUB_TIERS = 5 }; // 16, 1 024, 16 384 .. 4 M slots; 32 B per slot: 256 MiB per tier that is ever needed (tier 1: LDS)
 struct BubTier { DevBuf tabs, aux; bool ready = false; };
-struct CleanBufs { DevBuf st[2], src, ovf[2]; BubTier tier[BUB_TIERS]; uint32_t max_tier = 0; }; // st[k]: read stamps [R rounded up] then arc stamps [A]
+struct CleanBufs { DevBuf st[2], src, ovf[2], seq; BubTier tier[BUB_TIERS]; uint32_t max_tier = 0; uint32_t n_seq_sweeps = 0; }; // st[k]: read stamps [R rounded up] then arc stamps [A]
 
 static CleanBufs *clean_bufs(mahip_ctx *c)
 {
@@ -210,7 +220,7 @@ void clean_free(mahip_ctx *c)
 {
 	CleanBufs *b = (CleanBufs*)c->clean;
 	if (!b) return;
-	DevBuf *all[] = { &b->st[0], &b->st[1], &b->src, &b->ovf[0], &b->ovf[1] };
+	DevBuf *all[] = { &b->st[0], &b->st[1], &b->src, &b->ovf[0], &b->ovf[1], &b->seq };
 	for (DevBuf *x : all) dev_free(c, *x);
 	for (BubTier &t : b->tier) { dev_free(c, t.tabs); dev_free(c, t.aux); }
 	delete b;
@@ -266,6 +276,32 @@ static int bubble_launch(mahip_ctx *c, CleanBufs *b, int tier, const cl_view_t &
 	return 0;
 }
 
+// asg_pop_bubble exactly as the reference runs it, on one lane, on the base flags (no stamps): *cnt / *cnt2 as clean_sweep
+static int bubble_sweep_seq(mahip_ctx *c, CleanBufs *b, uint32_t max_dist, uint32_t *cnt, uint32_t *cnt2)
+{
+	const uint32_t V = 2 * graph_nseq(c);
+	const size_t A = c->n_arc, words = (size_t)V * 4 + (size_t)V * 2 + A + 16;
+	CHK(dev_reserve(c, b->seq, words * 4));
+	HIPCHK(hipMemsetAsync(b->seq.p, 0, (size_t)V * 16, c->st)); // info[]: nothing visited
+	cl_seqinfo_t *info = (cl_seqinfo_t*)b->seq.p;
+	uint32_t *stk = (uint32_t*)b->seq.p + (size_t)V * 4, *seen = stk + V, *walked = seen + V;
+	const int ag = c->ag;
+	CHK(ctr_zero(c));
+	{
+		ProfScope ps(c, "k_clean_bubble_seq", 0);
+		hipLaunchKernelGGL(k_clean_bubble_seq, dim3(1), dim3(64), 0, c->st, (const uint32_t*)P<uint32_t>(c->au[ag]), (const uint32_t*)P<uint32_t>(c->av[ag]), (const uint32_t*)P<uint32_t>(c->alen[ag]),
+		                   P<uint32_t>(c->aol[ag]), (const unsigned long long*)P<unsigned long long>(c->idx), P<uint8_t>(c->sdel), V, max_dist, info, stk, seen, walked, P<unsigned long long>(c->ctr));
+	}
+	CHK(ctr_fetch(c));
+	HIPCHK(hipGetLastError());
+	++b->n_seq_sweeps;
+	if (c->h_ctr[CT_OVF]) { mahip_set_error("asg_pop_bubble: more walks into a vertex than it has arcs in -- the graph is not symmetric, and the reference's assertion (asg.c:391) ends its run here too"); return -1; }
+	*cnt = (uint32_t)c->h_ctr[CT_LIVE]; *cnt2 = (uint32_t)c->h_ctr[CT_REMAIN];
+	if (*cnt) { CHK(ctr_zero(c)); CHK(graph_cleanup(c)); } // asg.c:430
+	return 0;
+}
+extern "C" uint32_t mahip_bubble_seq_sweeps(mahip_ctx_t *c) { return c->clean ? ((CleanBufs*)c->clean)->n_seq_sweeps : 0; } // tests: did a call take the sequential road?
+
 // mode 0..2: the short-unitig rules with param = max_ext; mode 3: bubbles with param = max_dist.
 // *cnt = actions of the sweep (tips cut / internal sequences / bi-loops / bubbles), *cnt2 = tips trimmed by bubble pops.
 static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_t *cnt2, int *n_iter)
@@ -293,6 +329,8 @@ static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_
 		CHK(ctr_fetch(c));
 		n_src = (uint32_t)(c->h_ctr[CT_TOTAL] & 0xffffffffu);
 		if (n_src == 0) return 0;
+		static const bool force_seq = getenv("MA_BUBBLE_SEQ") != nullptr;
+		if (force_seq) { if (n_iter) *n_iter = 1; return bubble_sweep_seq(c, b, (uint32_t)param, cnt, cnt2); }
 	}
 	cl_view_t g;
 	const int ag = c->ag;
@@ -339,11 +377,8 @@ static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_
 		if (n_iter) *n_iter = it + 1;
 		// fixpoint: the stamps did not change.  After the first sweep: no action means no stamp (an action may also be a no-op: counted, asg.c:296-302)
 		if (it == 0 ? c->h_ctr[CT_LIVE] == 0 : c->h_ctr[CT_TOTDP] == 0) {
-			if (mode == 3 && c->h_ctr[CT_OVF2]) { // the final view: a pop of this sweep brings back a read an earlier pop deleted (clean_core.h: ASSUMPTION)
-				mahip_set_error("asg_pop_bubble: %llu pops of this sweep would resurrect a read that an earlier pop of the same sweep deleted (asg.c:352); the stamp model cannot express that",
-				                (unsigned long long)c->h_ctr[CT_OVF2]);
-				return -1;
-			}
+			if (mode == 3 && c->h_ctr[CT_OVF2]) // the final view holds a pop that brings a dead read back (clean_core.h: ASSUMPTION): outside the fixpoint's contract --
+				return bubble_sweep_seq(c, b, (uint32_t)param, cnt, cnt2); // the base flags are untouched so far: the reference's sequential sweep, on one lane
 			*cnt = (uint32_t)c->h_ctr[CT_LIVE]; *cnt2 = (uint32_t)c->h_ctr[CT_REMAIN]; break;
 		}
 	}

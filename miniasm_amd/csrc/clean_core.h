@@ -17,11 +17,29 @@
  * The per-vertex rules (what is a tip, how far a unitig end is extended, what a bubble pop deletes and resurrects)
  * are the reference's definitions -- they are the specification -- re-expressed over the view.
  *
- * ASSUMPTION (ADVICE r2): a cell deleted by a smaller vertex stays deleted -- stamps only ever decrease.  One action of the reference can break it:
- * asg_bub_backtrack sets seq.del = 0 for every vertex of the best path (asg.c:352), also for a read an EARLIER pop of the same sweep flagged deleted
- * (such a read keeps the arcs that enter it from outside that bubble until the sweep's asg_cleanup, so it can be the sink of a later bubble).  That
- * resurrection cannot be written as a stamp.  cl_bubble_stamp reports it (a path vertex whose read is already dead in the popper's view) and the
- * sweep fails loudly instead of diverging silently; it has not occurred in any input or in the ~20 000 random graphs of the fuzz tests.
+ * ASSUMPTION: a cell deleted by a smaller vertex stays deleted -- stamps only ever decrease.  One action of the reference can break it:
+ * asg_bub_backtrack sets seq.del = 0 for every vertex of the best path (asg.c:352) whatever the read's state was.  "Dead, then alive again from v0 on"
+ * is not a stamp.  When can a probe put a dead read on its path?  It only follows live arcs (asg.c:377), so the read must be dead AND own a live arc.
+ *
+ *   CLAIM.  On a graph that is symmetric (u->v live  <=>  v'->u' live) and clean (no live arc touches a read with seq.del set) at the start of the sweep
+ *   -- what asg_symm + asg_cleanup leave, i.e. every call the pipeline makes (main.c:160-187; asg_arc_del_short re-establishes both, asg.c:95-98) --
+ *   no probe of the sweep ever meets a dead read: the situation cannot arise.
+ *   PROOF.  Induction over the successful pops of the sweep, invariant: the live arcs are symmetric and none touches a dead read.  Let the pop from v0
+ *   succeed and let w be a visited vertex that is not on the best path.  (i) Arcs INTO w: a fresh visit sets r(w) = live arcs out of w' (asg.c:383), by
+ *   symmetry the number of live arcs into w; the probe succeeds only when no vertex is pending (asg.c:400), i.e. r(w) went to 0, one decrement per arc
+ *   walked into w from an expanded vertex: EVERY live arc u->w was walked, sits in b->e, and is deleted together with w'->u' (asg.c:345-348).
+ *   (ii) Arcs OUT of w: either w was expanded -- then all its live arcs were walked (a walk that stops early, asg.c:379, makes the probe fail) and are
+ *   deleted with their mirrors x'->w' -- or w is a tip with no arcs at all (asg.c:393 counts deleted arcs too), and then w' has no arc into it.
+ *   So after the pop every arc with an end in w's read, on either strand, is deleted; the arcs it brings back (asg.c:353-354) join path vertices, whose
+ *   reads it revives -- both ends alive; every deletion and revival is done to an arc and its mirror.  The invariant holds again, and under it a probe
+ *   that follows live arcs reaches live reads only.  (The rules of cut_tip / cut_internal / cut_biloop delete reads with asg_seq_del, which deletes all
+ *   their arcs and mirrors; nothing else in a sweep revives anything.)  QED.
+ *
+ * Outside that contract the reference still answers, and so must the drop-in: the per-symbol asg_pop_bubble can be handed a graph whose is_symm flag is
+ * set although it is not symmetric (the extra arc into a popped read survives and a later pop can walk it), or one that was never cleaned (a read with
+ * seq.del set and live arcs lies on a path).  cl_bubble_stamp reports a path vertex that is dead in the popper's view; if the FINAL view still holds
+ * such a pop the fixpoint's answer is void and the call is run again as the reference's own sequential sweep on one lane (cl_bubble_sweep_seq below,
+ * csrc/clean.hip: k_clean_bubble_seq) -- slow and exact.  tests/test_gpu_graph_api.py holds a witness of either kind.
  */
 #ifndef CLEAN_CORE_H
 #define CLEAN_CORE_H
@@ -302,6 +320,93 @@ CL_HD int cl_bubble_stamp(const cl_view_t *g, cl_stamps_t s, uint32_t v0, uint32
 	}
 	cl_bclear(b);
 	return resurrects;
+}
+
+
+/* ---- asg_pop_bubble as the reference runs it (asg.c:360-433): one sweep over the vertices that MUTATES the base flags as it goes.  The fallback for graphs
+ * outside the fixpoint's contract (see the ASSUMPTION at the top); also what MA_BUBBLE_SEQ=1 forces, so that the tests can hold it against the reference
+ * on every graph they have.  info[n_vtx] zeroed by the caller; stk / seen: n_vtx words each, walked: one word per arc.
+ * Returns 0, or -1 where the reference's own assertion (asg.c:391: more walks into a vertex than it has arcs in) would end the process. */
+typedef struct { uint32_t p, d, c, r; } cl_seqinfo_t; /* best parent, shortest distance, most reads, arcs still to come in | visited << 31 */
+
+CL_HD void cl_seq_arc_set(const uint32_t *av, uint32_t *aol, const unsigned long long *idx, uint32_t v, uint32_t w, int del)
+{ /* asg_arc_del (asg.h:53-60): every arc v -> w */
+	const uint32_t st = (uint32_t)(idx[v] >> 32), n = (uint32_t)idx[v];
+	uint32_t i;
+	for (i = 0; i < n; ++i)
+		if (av[st + i] == w) aol[st + i] = del ? aol[st + i] | CL_ADEL : aol[st + i] & ~CL_ADEL;
+}
+CL_HD uint32_t cl_seq_live_out(const uint32_t *aol, const unsigned long long *idx, uint32_t v)
+{
+	const uint32_t st = (uint32_t)(idx[v] >> 32), n = (uint32_t)idx[v];
+	uint32_t i, live = 0;
+	for (i = 0; i < n; ++i) live += !(aol[st + i] >> 31);
+	return live;
+}
+
+CL_HD int cl_bubble_sweep_seq(const uint32_t *au, const uint32_t *av, const uint32_t *alen, uint32_t *aol, const unsigned long long *idx, uint8_t *sdel, uint32_t n_vtx,
+                              uint32_t max_dist, cl_seqinfo_t *info, uint32_t *stk, uint32_t *seen, uint32_t *walked, unsigned long long *n_pop, unsigned long long *n_tips)
+{
+	uint32_t v0;
+	*n_pop = *n_tips = 0;
+	for (v0 = 0; v0 < n_vtx; ++v0) {
+		uint32_t n_stk = 0, n_seen = 0, n_walk = 0, pending = 0, tips = 0, k;
+		int popped = 0;
+		if ((uint32_t)idx[v0] < 2 || sdel[v0 >> 1] || cl_seq_live_out(aol, idx, v0) < 2) continue; /* asg.c:421-427, 365-366 */
+		info[v0].c = info[v0].d = 0;
+		stk[n_stk++] = v0;
+		for (;;) {
+			const uint32_t v = stk[--n_stk], d = info[v].d, c = info[v].c, st = (uint32_t)(idx[v] >> 32), nv = (uint32_t)idx[v];
+			uint32_t i;
+			for (i = 0; i < nv; ++i) {
+				const uint32_t w = av[st + i], l = alen[st + i];
+				cl_seqinfo_t *t = &info[w];
+				if (w == v0) goto reset;
+				if (aol[st + i] >> 31) continue;
+				walked[n_walk++] = st + i;
+				if (d + l > max_dist) break;
+				if (!(t->r >> 31)) { /* first visit; c keeps the zero it was reset to */
+					seen[n_seen++] = w;
+					t->p = v; t->d = d + l;
+					t->r = 0x80000000u | cl_seq_live_out(aol, idx, w ^ 1);
+					++pending;
+				} else {
+					if (c + 1 > t->c || (c + 1 == t->c && d + l > t->d)) t->p = v;
+					if (c + 1 > t->c) t->c = c + 1;
+					if (d + l < t->d) t->d = d + l;
+				}
+				if ((t->r & 0x7fffffffu) == 0) return -1; /* asg.c:391 */
+				if ((--t->r & 0x7fffffffu) == 0) {
+					if ((uint32_t)idx[w]) stk[n_stk++] = w; else ++tips; /* deleted arcs count here too (asg.c:393) */
+					--pending;
+				}
+			}
+			if (i < nv || n_stk == 0) goto reset;
+			if (!(n_stk > 1 || pending)) break;
+		}
+		/* asg_bub_backtrack (asg.c:338-357): everything touched goes, the best path comes back */
+		for (k = 0; k < n_seen; ++k) sdel[seen[k] >> 1] = 1;
+		for (k = 0; k < n_walk; ++k) {
+			const uint32_t e = walked[k];
+			aol[e] |= CL_ADEL;
+			cl_seq_arc_set(av, aol, idx, av[e] ^ 1, au[e] ^ 1, 1);
+		}
+		{
+			uint32_t v = stk[0];
+			do {
+				const uint32_t u = info[v].p;
+				sdel[v >> 1] = 0;
+				cl_seq_arc_set(av, aol, idx, u, v, 0);
+				cl_seq_arc_set(av, aol, idx, v ^ 1, u ^ 1, 0);
+				v = u;
+			} while (v != v0);
+		}
+		popped = 1;
+reset:
+		for (k = 0; k < n_seen; ++k) { cl_seqinfo_t *t = &info[seen[k]]; t->r = t->c = t->d = 0; }
+		if (popped) { ++*n_pop; *n_tips += tips; }
+	}
+	return 0;
 }
 
 #endif

@@ -27,6 +27,23 @@ static void to_soa(uint32_t n_seq, uint32_t n_arc, const arc_t *arc, const uint6
 	g.idx.push_back(0);
 }
 
+// asg_pop_bubble as the reference runs it (clean_core.h: cl_bubble_sweep_seq; csrc/clean.hip: k_clean_bubble_seq): sets / clears the del bits in arc[] / seq[] (no cleanup)
+extern "C" int clh_bubble_seq(int max_dist, uint32_t n_seq, uint32_t n_arc, arc_t *arc, const uint64_t *idx, uint32_t *seq, uint32_t *cnt, uint32_t *cnt2)
+{
+	Soa G;
+	to_soa(n_seq, n_arc, arc, idx, seq, G);
+	const uint32_t V = 2 * n_seq;
+	std::vector<cl_seqinfo_t> info(V + 1);
+	memset(info.data(), 0, info.size() * sizeof(cl_seqinfo_t));
+	std::vector<uint32_t> stk(V + 1), seen(V + 1), walked(n_arc + 1);
+	unsigned long long pops = 0, tips = 0;
+	if (cl_bubble_sweep_seq(G.au.data(), G.av.data(), G.alen.data(), G.aol.data(), G.idx.data(), G.sdel.data(), V, (uint32_t)max_dist, info.data(), stk.data(), seen.data(), walked.data(), &pops, &tips) != 0) return -1;
+	*cnt = (uint32_t)pops; *cnt2 = (uint32_t)tips;
+	for (uint32_t r = 0; r < n_seq; ++r) seq[r] = (seq[r] & 0x7fffffffu) | (uint32_t)G.sdel[r] << 31;
+	for (uint32_t e = 0; e < n_arc; ++e) arc[e].ol = G.aol[e];
+	return 0;
+}
+
 // mode 0 tip, 1 internal, 2 bi-loop (param = max_ext), 3 bubbles (param = max_dist).  Sets the del bits in arc[] / seq[] (no cleanup).
 extern "C" int clh_sweep(int mode, int param, uint32_t n_seq, uint32_t n_arc, arc_t *arc, const uint64_t *idx, uint32_t *seq,
                          uint32_t *cnt, uint32_t *cnt2, int *iters, uint32_t bubble_cap)
@@ -67,7 +84,11 @@ extern "C" int clh_sweep(int mode, int param, uint32_t n_seq, uint32_t n_arc, ar
 		const bool same = rst[0] == rst[1] && ast[0] == ast[1];
 		cur ^= 1;
 		*iters = it + 1;
-		if (same) { *cnt = acts; *cnt2 = tips; if (back) return -4; /* the pop that brings a dead read back: see clean_core.h, ASSUMPTION */ break; }
+		if (same) {
+			*cnt = acts; *cnt2 = tips;
+			if (back) return clh_bubble_seq(param, n_seq, n_arc, arc, idx, seq, cnt, cnt2) == 0 ? 1 : -4; /* a pop brings a dead read back (clean_core.h, ASSUMPTION): the sequential sweep, as the device does; 1 = that road was taken */
+			break;
+		}
 	}
 	for (uint32_t r = 0; r < n_seq; ++r) if (rst[cur][r] != CL_NONE) seq[r] |= 0x80000000u;
 	for (uint32_t e = 0; e < n_arc; ++e) if (ast[cur][e] != CL_NONE) arc[e].ol |= 0x80000000u;

@@ -172,6 +172,90 @@ def test_fixpoint_cleaners_and_unitigs_match_reference(name, reads, lines, seed,
     LR.asg_destroy(g_ref)
 
 
+def _ref_pop_bubble(a, seq, idx, max_dist):
+    """reference asg_pop_bubble on a libc-heap copy of the graph (it frees and rebuilds the index); is_symm set: the graph is taken as it is"""
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    LR = R.ref()
+    LR.asg_pop_bubble.restype = C.c_int
+    LR.asg_pop_bubble.argtypes = [C.POINTER(ma.Asg), C.c_int]
+    g = ma.Asg()
+    for field, arr in (("arc", a), ("seq", seq), ("idx", idx)):
+        p = libc.malloc(max(arr.nbytes, 16))
+        C.memmove(p, arr.ctypes.data, arr.nbytes)
+        setattr(g, field, p)
+    g.m_arc, g.n_arc_srt, g.m_seq, g.n_seq_symm = max(len(a), 1), len(a) | 1 << 31, len(seq), len(seq) | 1 << 31
+    n = LR.asg_pop_bubble(C.byref(g), max_dist)
+    return n, tuple(x.tobytes() for x in R.asg_arrays(g))
+
+
+@needs_ref
+@pytest.mark.parametrize("which", ["unclean", "asymmetric"])
+def test_pops_that_revive_a_dead_read_take_the_sequential_sweep(which):
+    """clean_core.h, ASSUMPTION: on these two graphs (tests/bubble_witness.py) a pop sets seq.del = 0 for a read that is dead when it happens.  The fixpoint
+    notices (its final view holds such a pop) and the call is run again as the reference's sequential sweep: same graph as the reference's, no abort."""
+    import bubble_witness as BW
+    (a, seq, idx), why = BW.WITNESSES[which]()
+    n_ref, want = _ref_pop_bubble(a, seq, idx, 50000)
+    L = host()
+    G = Graph.__new__(Graph)
+    G.arcs, G.seq, G.idx, G.ns = a.copy(), seq.copy(), idx.copy(), len(seq)
+    cnt, cnt2, it = C.c_uint32(0), C.c_uint32(0), C.c_int(0)
+    rc = L.clh_sweep(3, 50000, G.ns, len(G.arcs), G.arcs.ctypes.data, G.idx.ctypes.data, G.seq.ctypes.data, C.byref(cnt), C.byref(cnt2), C.byref(it), 0)
+    assert rc == 1, "%s: expected the fixpoint to hand the call to the sequential sweep (rc %d): %s" % (which, rc, why)
+    assert (cnt.value, cnt2.value) == (n_ref & 0xffffffff, 0) or cnt.value == (n_ref & 0xffffffff)
+    G.cleanup()
+    if which == "unclean":
+        assert not (G.seq[3] >> 31), "the reference leaves read 3 alive"
+    else:
+        assert cnt.value == 2 and not (G.seq[2] >> 31) and (G.seq[3] >> 31), "read 2 comes back, its tip (read 3) stays deleted"
+    assert G.snapshot() == want, which
+
+
+@needs_ref
+@pytest.mark.parametrize("name,reads,lines,seed,extra", GRAPH_CASES[:5], ids=[c[0] for c in GRAPH_CASES[:5]])
+def test_sequential_bubble_sweep_matches_reference(name, reads, lines, seed, extra, tmpdir_s):
+    """cl_bubble_sweep_seq (the one-lane fallback of asg_pop_bubble, csrc/clean.hip: k_clean_bubble_seq) on ordinary graphs: every asg_pop_bubble of the
+    cleaning script through it, the other calls through the fixpoint; graph equal to the reference's after every call"""
+    paf = R.pafgen(os.path.join(tmpdir_s, "cs_%s.paf" % name), reads, lines, seed, extra)
+    opt = ma.default_opt()
+    S = ST.ref_stages(paf, opt)
+    LR, L = R.ref(), host()
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+    L.clh_bubble_seq.argtypes = [i32, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(u32)]
+    g_ref = S["g"]
+    G = Graph(g_ref)
+    n_pops = 0
+
+    def one(fn, arg):
+        nonlocal n_pops
+        r0 = getattr(LR, fn)(g_ref, arg)
+        if fn == "asg_pop_bubble":
+            cnt, cnt2 = C.c_uint32(0), C.c_uint32(0)
+            assert L.clh_bubble_seq(arg, G.ns, len(G.arcs), G.arcs.ctypes.data, G.idx.ctypes.data, G.seq.ctypes.data, C.byref(cnt), C.byref(cnt2)) == 0
+            assert cnt.value == r0 & 0xffffffff, (r0, cnt.value, cnt2.value)  # (the tips are in the upper half of a count the reference returns as an int)
+            n_pops += cnt.value
+            if cnt.value:
+                G.cleanup()
+        else:
+            assert G.sweep(L, MODE[fn], arg)[0] == r0
+        assert G.snapshot() == tuple(x.tobytes() for x in R.asg_arrays(g_ref)), "graph differs after %s(%r)" % (fn, arg)
+
+    for fn, arg in cleaning_script(opt):
+        if fn == "short":
+            r0 = LR.asg_arc_del_short(g_ref, arg)
+            assert G.del_short(arg) == r0
+            if r0:
+                one("asg_cut_tip", opt.max_ext)
+                one("asg_pop_bubble", opt.bub_dist)
+        else:
+            one(fn, arg)
+    if name.startswith("noisy"):
+        assert n_pops > 0
+    LR.asg_destroy(g_ref)
+
+
 @needs_ref
 def test_circular_unitigs_and_isolated_reads():
     """hand-made graphs: a ring of reads (circular unitig entered at its smallest vertex), a ring plus a linear piece, reads without arcs"""
