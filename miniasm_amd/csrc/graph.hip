@@ -339,14 +339,14 @@ __global__ __launch_bounds__(256) void k_arc_groups(const uint32_t *__restrict__
 
 template <int ITEMS>
 __device__ __forceinline__ void arc_group_sort_regs(const ArcCols &in, const ArcCols &out, uint32_t q, uint32_t beg, uint32_t n, int bl, unsigned lane,
-                                                    unsigned long long *__restrict__ idx, uint32_t &tie_groups, uint32_t &tie_arcs)
-{
+                                                    unsigned long long *__restrict__ idx, uint32_t &tie_groups, uint32_t &tie_arcs, const uint32_t *pu, const uint32_t *pl)
+{ // pu / pl (SMALL tier): the u and len columns of the read's arcs, arc r * 64 + lane in slot r, fetched a read ahead; else loaded here
 	uint32_t x[ITEMS];
 #pragma unroll
 	for (int r = 0; r < ITEMS; ++r) { // any arrangement will do on the way in: the position is part of the key
 		const uint32_t i = (uint32_t)r * 64u + lane;
 		x[r] = 0xffffffffu;
-		if (i < n) x[r] = (in.u[beg + i] & 1u) << (bl + AG_IB) | in.len[beg + i] << AG_IB | i;
+		if (i < n) x[r] = ((pu ? pu[r < 2 ? r : 0] : in.u[beg + i]) & 1u) << (bl + AG_IB) | (pl ? pl[r < 2 ? r : 0] : in.len[beg + i]) << AG_IB | i;
 	}
 	wave_sort_regs<ITEMS>(x, lane); // sorted element p sits in lane p / ITEMS, register p % ITEMS
 	const uint32_t lmask = (1u << bl) - 1u;
@@ -374,7 +374,9 @@ __device__ __forceinline__ void arc_group_sort_regs(const ArcCols &in, const Arc
 }
 
 // one wave per read with arcs; a wave takes 64 consecutive reads at a time (their bounds: one coalesced load) and visits the ones that have arcs --
-// after containment most reads have none.  SMALL: stretches of <= 128 arcs (2 keys per lane: most of them); !SMALL: 129 .. AG_MAX.
+// after containment most reads have none.  SMALL: stretches of <= 128 arcs (2 keys per lane: most of them), the next read's two key columns in flight
+// while the current one is sorted (a read is a chain load -> sort -> gather -> store; round 4, visit A: 2.4 ms per 200 M arcs without);
+// !SMALL: 129 .. AG_MAX.
 template <bool SMALL>
 __global__ __launch_bounds__(256) void k_arc_group_sort(ArcCols in, ArcCols out, const uint2 *__restrict__ grp, uint32_t q_lo, uint32_t q_hi, int bl,
                                                          unsigned long long *__restrict__ idx, unsigned long long *__restrict__ ctr)
@@ -386,17 +388,37 @@ __global__ __launch_bounds__(256) void k_arc_group_sort(ArcCols in, ArcCols out,
 		const uint32_t n_l = g.y - g.x;
 		if (SMALL) big += n_l > AG_MAX; // counted once (by the SMALL launch)
 		unsigned long long todo = wv_ballot(SMALL ? (n_l != 0 && n_l <= 128u) : (n_l > 128u && n_l <= AG_MAX));
+		if (SMALL) {
+			uint32_t cu[2] = {0, 0}, cl[2] = {0, 0}, nu[2] = {0, 0}, nl[2] = {0, 0};
+			int b = todo ? __ffsll((long long)todo) - 1 : -1;
+			uint32_t beg = 0, n = 0;
+			if (b >= 0) {
+				beg = __shfl(g.x, b, 64); n = __shfl(n_l, b, 64);
+#pragma unroll
+				for (int r = 0; r < 2; ++r) { const uint32_t i = (uint32_t)r * 64u + lane; if (i < n) cu[r] = in.u[beg + i], cl[r] = in.len[beg + i]; }
+			}
+			while (b >= 0) {
+				todo &= todo - 1;
+				const int bn = todo ? __ffsll((long long)todo) - 1 : -1;
+				uint32_t begn = 0, nn = 0;
+				if (bn >= 0) { // the next read's columns first: they are in flight while this one is sorted
+					begn = __shfl(g.x, bn, 64); nn = __shfl(n_l, bn, 64);
+#pragma unroll
+					for (int r = 0; r < 2; ++r) { const uint32_t i = (uint32_t)r * 64u + lane; if (i < nn) nu[r] = in.u[begn + i], nl[r] = in.len[begn + i]; }
+				}
+				const uint32_t q = (uint32_t)qb + (uint32_t)b;
+				if (n <= 64) arc_group_sort_regs<1>(in, out, q, beg, n, bl, lane, idx, tg, ta, cu, cl);
+				else arc_group_sort_regs<2>(in, out, q, beg, n, bl, lane, idx, tg, ta, cu, cl);
+				b = bn; beg = begn; n = nn;
+				cu[0] = nu[0]; cu[1] = nu[1]; cl[0] = nl[0]; cl[1] = nl[1];
+			}
+		} else
 		while (todo) {
 			const int b = __ffsll((long long)todo) - 1;
 			todo &= todo - 1;
 			const uint32_t q = (uint32_t)qb + (uint32_t)b, beg = __shfl(g.x, b, 64), n = __shfl(n_l, b, 64);
-			if (SMALL) {
-				if (n <= 64) arc_group_sort_regs<1>(in, out, q, beg, n, bl, lane, idx, tg, ta);
-				else arc_group_sort_regs<2>(in, out, q, beg, n, bl, lane, idx, tg, ta);
-			} else {
-				if (n <= 256) arc_group_sort_regs<4>(in, out, q, beg, n, bl, lane, idx, tg, ta);
-				else arc_group_sort_regs<8>(in, out, q, beg, n, bl, lane, idx, tg, ta);
-			}
+			if (n <= 256) arc_group_sort_regs<4>(in, out, q, beg, n, bl, lane, idx, tg, ta, nullptr, nullptr);
+			else arc_group_sort_regs<8>(in, out, q, beg, n, bl, lane, idx, tg, ta, nullptr, nullptr);
 		}
 	}
 	blk_add_u64(&ctr[ST_ARC_TIE_GROUPS], tg);
@@ -405,6 +427,9 @@ __global__ __launch_bounds__(256) void k_arc_group_sort(ArcCols in, ArcCols out,
 }
 
 // ------------------------------------------------------------------------------------------------ asg_arc_del_trans
+#ifndef TR_PRE
+#define TR_PRE 128u // neighbours whose CSR words are fetched with the vertex's own list (SMALL); the rest wait until they are expanded.  128 = all of them
+#endif
 #define TR_CAP 512
 #define TR_HASH 1024
 #define TR_EMPTY 0xffffffffu
@@ -462,7 +487,7 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 		for (uint32_t i = lane; i < nv; i += 64) {
 			uint32_t w = av[st + i];
 			lv[i] = w, ll[i] = alen[st + i];
-			if (SMALL) { unsigned long long xw = idx[w]; s_ws[wave][i] = (uint32_t)(xw >> 32); s_nw[wave][i] = (uint32_t)xw; }
+			if (SMALL && i < TR_PRE) { unsigned long long xw = idx[w]; s_ws[wave][i] = (uint32_t)(xw >> 32); s_nw[wave][i] = (uint32_t)xw; }
 		}
 		// hm[slot] = (index of the FIRST arc to this target) << 2 | mark
 		for (uint32_t s = lane; s < hsize; s += 64) hk[s] = TR_EMPTY, hm[s] = 0xffffffffu;
@@ -488,7 +513,7 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 				passed |= l0 == 63 ? ~0ull : ((2ull << l0) - 1ull);
 				const uint32_t i0 = base + l0, li = ll[i0];
 				uint32_t ws, nw;
-				if (SMALL) ws = s_ws[wave][i0], nw = s_nw[wave][i0];
+				if (SMALL && i0 < TR_PRE) ws = s_ws[wave][i0], nw = s_nw[wave][i0];
 				else { unsigned long long xw = idx[lv[i0]]; ws = (uint32_t)(xw >> 32); nw = (uint32_t)xw; }
 				for (uint32_t j0 = 0; j0 < nw; j0 += 64) { // lanes over w's arcs; sorted by len => the loop of asg.c:169 is a prefix
 					uint32_t j = j0 + lane;
