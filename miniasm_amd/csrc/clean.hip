@@ -297,7 +297,7 @@ static int bubble_sweep_seq(mahip_ctx *c, CleanBufs *b, uint32_t max_dist, uint3
 	++b->n_seq_sweeps;
 	if (c->h_ctr[CT_OVF]) { mahip_set_error("asg_pop_bubble: more walks into a vertex than it has arcs in -- the graph is not symmetric, and the reference's assertion (asg.c:391) ends its run here too"); return -1; }
 	*cnt = (uint32_t)c->h_ctr[CT_LIVE]; *cnt2 = (uint32_t)c->h_ctr[CT_REMAIN];
-	if (*cnt) { CHK(ctr_zero(c)); CHK(graph_cleanup(c)); } // asg.c:430
+	if (*cnt) { c->arcs_clean = false; CHK(ctr_zero(c)); CHK(graph_cleanup(c)); } // asg.c:430 (reads were deleted: the cleanup looks at seq.del again)
 	return 0;
 }
 extern "C" uint32_t mahip_bubble_seq_sweeps(mahip_ctx_t *c) { return c->clean ? ((CleanBufs*)c->clean)->n_seq_sweeps : 0; } // tests: did a call take the sequential road?
@@ -386,6 +386,7 @@ static int clean_sweep(mahip_ctx *c, int mode, int param, uint32_t *cnt, uint32_
 		const size_t m = A > R ? A : R;
 		const uint32_t *fin = P<uint32_t>(b->st[cur]);
 		hipLaunchKernelGGL(k_clean_apply, dim3(grid_for(m, 256)), dim3(256), 0, c->st, fin, R, P<uint8_t>(c->sdel), fin + Rp, A, P<uint32_t>(c->aol[ag]));
+		c->arcs_clean = false; // reads were deleted: the cleanup has to look at seq.del again
 		CHK(ctr_zero(c));
 		CHK(graph_cleanup(c)); // asg.c:251, 269, 303, 430: asg_cleanup when something was cut
 	}

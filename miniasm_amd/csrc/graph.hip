@@ -120,8 +120,11 @@ __device__ __forceinline__ unsigned long long wv_bcast_u64(unsigned long long x,
 
 __global__ __launch_bounds__(256) void k_sg_emit(HitColsG h, size_t n, const uint32_t *__restrict__ slen, const uint8_t *__restrict__ sdel,
                                                   int max_hang, float int_frac, int min_ovlp, const unsigned long long *__restrict__ cmask,
-                                                  uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off, ArcCols out, uint32_t *__restrict__ aslot)
+                                                  uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off, ArcCols out, uint32_t *__restrict__ aslot,
+                                                  uint32_t *__restrict__ wpos, unsigned long long *__restrict__ kmask)
 { // aslot (optional, pass C): the hit slot each pushed arc comes from (push order, tie-order repair)
+  // wpos / kmask (optional, pass C): per 64-slot word the position of its first arc in the push sequence and the slots that yielded one -- the arc sort finds the
+  // stretch of a read's arcs from them and the read's hit slots (arc_pos_of_slot) instead of a sweep over the arcs (k_arc_groups: 0.55 ms per 200 M arcs)
 	__shared__ uint32_t s_w[4];
 	const unsigned lane = threadIdx.x & 63;
 	const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x, n_words = (n + 63) >> 6, w0 = w - lane;
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(256) void k_sg_emit(HitColsG h, size_t n, const uin
 	uint32_t tot, ex = block_excl_scan_256(cnt, s_w, &tot);
 	if (!out.u) { if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot; return; }
 	uint32_t p = tile_off[blockIdx.x] + ex;
+	if (wpos && w < n_words) { wpos[w] = p; kmask[w] = kept; }
 	for (unsigned long long dl = dense_lanes; dl; dl &= dl - 1) {
 		const int l = __ffsll((long long)dl) - 1;
 		const unsigned long long kl = wv_bcast_u64(kept, l);
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256) void k_arc_rm_chain(ArcCols in, size_t n, cons
 	}
 #pragma unroll
 	for (int i = 0; i < RM_ITEMS; ++i)
-		if (base + i < n && !(ol[i] & ADEL) && !sdel[u[i] >> 1] && !sdel[v[i] >> 1]) keep |= 1u << i;
+		if (base + i < n && !(ol[i] & ADEL) && (!sdel || (!sdel[u[i] >> 1] && !sdel[v[i] >> 1]))) keep |= 1u << i; // sdel == nullptr: no arc can touch a deleted read (arcs_clean)
 	const uint32_t cnt = (uint32_t)__popc(keep);
 	uint32_t tot;
 	const uint32_t ex = block_excl_scan_256(cnt, s_wave, &tot);
@@ -324,29 +328,25 @@ __global__ __launch_bounds__(256) void k_arc_index(const uint32_t *__restrict__ 
 #define AG_IB 9        // bits of an arc's position inside its read's stretch
 #define AG_MAX 512u    // arcs per read the register network takes; longer stretches (or lengths of more than 21 bits) send the whole sort to the radix path
 
-// grp[q] = {first arc, one past the last arc} of read q (zeroed before: reads without arcs).  CT_OVF2 counts what the fast path cannot take: a read id
-// that DEcreases along the sequence (the arcs are not grouped) or a stretch longer than AG_MAX.
-__global__ __launch_bounds__(256) void k_arc_groups(const uint32_t *__restrict__ au, size_t n, uint2 *__restrict__ grp, unsigned long long *__restrict__ ctr)
+// position in the push sequence of the first arc that comes from hit slot s or a later one (k_sg_emit, pass C, left wpos / kmask behind); s = n_slots: all of them
+__device__ __forceinline__ uint32_t arc_pos_of_slot(const uint32_t *__restrict__ wpos, const unsigned long long *__restrict__ kmask, uint32_t s, uint32_t n_slots, uint32_t n_arc)
 {
-	uint32_t bad = 0;
-	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-		const uint32_t q = au[i] >> 1;
-		if (i == 0 || (au[i - 1] >> 1) != q) { grp[q].x = (uint32_t)i; if (i && (au[i - 1] >> 1) > q) ++bad; }
-		if (i + 1 == n || (au[i + 1] >> 1) != q) grp[q].y = (uint32_t)(i + 1);
-	}
-	blk_add_u64(&ctr[CT_OVF2], bad);
+	if (s >= n_slots) return n_arc;
+	return wpos[s >> 6] + (uint32_t)__popcll(kmask[s >> 6] & ((1ull << (s & 63u)) - 1ull));
 }
+
+struct ArcPre { uint32_t u[2], len[2], v[2], ol[2]; }; // the four columns of a read's (up to 128) arcs, arc r * 64 + lane in slot r
 
 template <int ITEMS>
 __device__ __forceinline__ void arc_group_sort_regs(const ArcCols &in, const ArcCols &out, uint32_t q, uint32_t beg, uint32_t n, int bl, unsigned lane,
-                                                    unsigned long long *__restrict__ idx, uint32_t &tie_groups, uint32_t &tie_arcs, const uint32_t *pu, const uint32_t *pl)
-{ // pu / pl (SMALL tier): the u and len columns of the read's arcs, arc r * 64 + lane in slot r, fetched a read ahead; else loaded here
+                                                    unsigned long long *__restrict__ idx, uint32_t &tie_groups, uint32_t &tie_arcs, const ArcPre *pre)
+{ // pre (SMALL tier): the read's rows, fetched a read ahead; else loaded here
 	uint32_t x[ITEMS];
 #pragma unroll
 	for (int r = 0; r < ITEMS; ++r) { // any arrangement will do on the way in: the position is part of the key
 		const uint32_t i = (uint32_t)r * 64u + lane;
 		x[r] = 0xffffffffu;
-		if (i < n) x[r] = ((pu ? pu[r < 2 ? r : 0] : in.u[beg + i]) & 1u) << (bl + AG_IB) | (pl ? pl[r < 2 ? r : 0] : in.len[beg + i]) << AG_IB | i;
+		if (i < n) x[r] = ((pre ? pre->u[r < 2 ? r : 0] : in.u[beg + i]) & 1u) << (bl + AG_IB) | (pre ? pre->len[r < 2 ? r : 0] : in.len[beg + i]) << AG_IB | i;
 	}
 	wave_sort_regs<ITEMS>(x, lane); // sorted element p sits in lane p / ITEMS, register p % ITEMS
 	const uint32_t lmask = (1u << bl) - 1u;
@@ -355,9 +355,16 @@ __device__ __forceinline__ void arc_group_sort_regs(const ArcCols &in, const Arc
 #pragma unroll
 	for (int r = 0; r < ITEMS; ++r) {
 		const uint32_t p = lane * ITEMS + (uint32_t)r;
+		const uint32_t k = x[r], at = k & ((1u << AG_IB) - 1u), strand = k >> (bl + AG_IB) & 1u;
+		uint32_t v, ol;
+		if (pre) { // the row's other two columns sit in lane (at & 63), slot (at >> 6) of the prefetched registers: through the LDS crossbar, no second trip to memory
+			const uint32_t v0 = __shfl(pre->v[0], (int)(at & 63u), 64), o0 = __shfl(pre->ol[0], (int)(at & 63u), 64);
+			v = v0; ol = o0;
+			if (ITEMS > 1) { const uint32_t v1 = __shfl(pre->v[1], (int)(at & 63u), 64), o1 = __shfl(pre->ol[1], (int)(at & 63u), 64); if (at >> 6) v = v1, ol = o1; }
+		}
 		if (p < n) {
-			const uint32_t k = x[r], src = beg + (k & ((1u << AG_IB) - 1u)), strand = k >> (bl + AG_IB) & 1u;
-			out.u[beg + p] = q << 1 | strand; out.v[beg + p] = in.v[src]; out.len[beg + p] = (k >> AG_IB) & lmask; out.ol[beg + p] = in.ol[src];
+			if (!pre) { v = in.v[beg + at]; ol = in.ol[beg + at]; }
+			out.u[beg + p] = q << 1 | strand; out.v[beg + p] = v; out.len[beg + p] = (k >> AG_IB) & lmask; out.ol[beg + p] = ol;
 			n0 += strand ^ 1u;
 			// tie census: runs of equal (u,len) among neighbours in sorted order
 			const uint32_t kp = r > 0 ? x[r > 0 ? r - 1 : 0] : up, kn = r + 1 < ITEMS ? x[r + 1 < ITEMS ? r + 1 : 0] : down;
@@ -373,52 +380,61 @@ __device__ __forceinline__ void arc_group_sort_regs(const ArcCols &in, const Arc
 	}
 }
 
+__device__ __forceinline__ void arc_prefetch(const ArcCols &in, uint32_t beg, uint32_t n, unsigned lane, ArcPre &p)
+{
+#pragma unroll
+	for (int r = 0; r < 2; ++r) {
+		const uint32_t i = (uint32_t)r * 64u + lane;
+		p.u[r] = p.len[r] = p.v[r] = p.ol[r] = 0;
+		if (i < n) { p.u[r] = in.u[beg + i]; p.len[r] = in.len[beg + i]; p.v[r] = in.v[beg + i]; p.ol[r] = in.ol[beg + i]; }
+	}
+}
+
 // one wave per read with arcs; a wave takes 64 consecutive reads at a time (their bounds: one coalesced load) and visits the ones that have arcs --
-// after containment most reads have none.  SMALL: stretches of <= 128 arcs (2 keys per lane: most of them), the next read's two key columns in flight
-// while the current one is sorted (a read is a chain load -> sort -> gather -> store; round 4, visit A: 2.4 ms per 200 M arcs without);
-// !SMALL: 129 .. AG_MAX.
+// after containment most reads have none.  SMALL: stretches of <= 128 arcs (2 rows per lane: most of them).  A read is a chain load -> sort -> rows through
+// the sorted positions -> store; the rows of the NEXT read are in flight while the current one is sorted, and the rows follow the sorted positions through the
+// LDS crossbar instead of a second, dependent trip to memory (round 4: the key columns alone a read ahead changed nothing, 2.5 ms per 200 M arcs either way).
+// !SMALL: 129 .. AG_MAX arcs, loaded where they are needed.
 template <bool SMALL>
-__global__ __launch_bounds__(256) void k_arc_group_sort(ArcCols in, ArcCols out, const uint2 *__restrict__ grp, uint32_t q_lo, uint32_t q_hi, int bl,
+__global__ __launch_bounds__(256) void k_arc_group_sort(ArcCols in, ArcCols out, const uint32_t *__restrict__ goff, const uint32_t *__restrict__ wpos, const unsigned long long *__restrict__ kmask,
+                                                         uint32_t n_slots, uint32_t n_arc, uint32_t q_lo, uint32_t q_hi, int bl,
                                                          unsigned long long *__restrict__ idx, unsigned long long *__restrict__ ctr)
 {
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t tg = 0, ta = 0, big = 0;
 	for (uint64_t qb = (uint64_t)q_lo + (uint64_t)(blockIdx.x * 4 + wave) * 64; qb < q_hi; qb += (uint64_t)gridDim.x * 256) {
-		const uint2 g = qb + lane < q_hi ? grp[qb + lane] : make_uint2(0, 0);
+		// the arcs of read q come from its hit slots goff[q] .. goff[q+1]: lane l holds the start of read qb + l; its end is the next read's start
+		const bool have = qb + lane < q_hi;
+		const uint32_t a0 = have ? arc_pos_of_slot(wpos, kmask, goff[qb + lane], n_slots, n_arc) : 0u;
+		uint32_t a1 = __shfl_down(a0, 1, 64);
+		const uint32_t last = (uint32_t)((qb + 64 < q_hi ? qb + 64 : q_hi) - qb) - 1u; // the chunk's last read: its end is not in a neighbour lane
+		if (lane == last) a1 = arc_pos_of_slot(wpos, kmask, goff[qb + lane + 1], n_slots, n_arc);
+		const uint2 g = have ? make_uint2(a0, a1) : make_uint2(0, 0);
 		const uint32_t n_l = g.y - g.x;
 		if (SMALL) big += n_l > AG_MAX; // counted once (by the SMALL launch)
 		unsigned long long todo = wv_ballot(SMALL ? (n_l != 0 && n_l <= 128u) : (n_l > 128u && n_l <= AG_MAX));
 		if (SMALL) {
-			uint32_t cu[2] = {0, 0}, cl[2] = {0, 0}, nu[2] = {0, 0}, nl[2] = {0, 0};
+			ArcPre cur, nxt;
 			int b = todo ? __ffsll((long long)todo) - 1 : -1;
 			uint32_t beg = 0, n = 0;
-			if (b >= 0) {
-				beg = __shfl(g.x, b, 64); n = __shfl(n_l, b, 64);
-#pragma unroll
-				for (int r = 0; r < 2; ++r) { const uint32_t i = (uint32_t)r * 64u + lane; if (i < n) cu[r] = in.u[beg + i], cl[r] = in.len[beg + i]; }
-			}
+			if (b >= 0) { beg = __shfl(g.x, b, 64); n = __shfl(n_l, b, 64); arc_prefetch(in, beg, n, lane, cur); }
 			while (b >= 0) {
 				todo &= todo - 1;
 				const int bn = todo ? __ffsll((long long)todo) - 1 : -1;
 				uint32_t begn = 0, nn = 0;
-				if (bn >= 0) { // the next read's columns first: they are in flight while this one is sorted
-					begn = __shfl(g.x, bn, 64); nn = __shfl(n_l, bn, 64);
-#pragma unroll
-					for (int r = 0; r < 2; ++r) { const uint32_t i = (uint32_t)r * 64u + lane; if (i < nn) nu[r] = in.u[begn + i], nl[r] = in.len[begn + i]; }
-				}
+				if (bn >= 0) { begn = __shfl(g.x, bn, 64); nn = __shfl(n_l, bn, 64); arc_prefetch(in, begn, nn, lane, nxt); } // first: in flight while this read is sorted
 				const uint32_t q = (uint32_t)qb + (uint32_t)b;
-				if (n <= 64) arc_group_sort_regs<1>(in, out, q, beg, n, bl, lane, idx, tg, ta, cu, cl);
-				else arc_group_sort_regs<2>(in, out, q, beg, n, bl, lane, idx, tg, ta, cu, cl);
-				b = bn; beg = begn; n = nn;
-				cu[0] = nu[0]; cu[1] = nu[1]; cl[0] = nl[0]; cl[1] = nl[1];
+				if (n <= 64) arc_group_sort_regs<1>(in, out, q, beg, n, bl, lane, idx, tg, ta, &cur);
+				else arc_group_sort_regs<2>(in, out, q, beg, n, bl, lane, idx, tg, ta, &cur);
+				b = bn; beg = begn; n = nn; cur = nxt;
 			}
 		} else
 		while (todo) {
 			const int b = __ffsll((long long)todo) - 1;
 			todo &= todo - 1;
 			const uint32_t q = (uint32_t)qb + (uint32_t)b, beg = __shfl(g.x, b, 64), n = __shfl(n_l, b, 64);
-			if (n <= 256) arc_group_sort_regs<4>(in, out, q, beg, n, bl, lane, idx, tg, ta, nullptr, nullptr);
-			else arc_group_sort_regs<8>(in, out, q, beg, n, bl, lane, idx, tg, ta, nullptr, nullptr);
+			if (n <= 256) arc_group_sort_regs<4>(in, out, q, beg, n, bl, lane, idx, tg, ta, nullptr);
+			else arc_group_sort_regs<8>(in, out, q, beg, n, bl, lane, idx, tg, ta, nullptr);
 		}
 	}
 	blk_add_u64(&ctr[ST_ARC_TIE_GROUPS], tg);
@@ -455,6 +471,8 @@ __device__ __forceinline__ int tr_find(const uint32_t *hk, uint32_t x, uint32_t 
 // only ever go 1 -> 2, so "the next arc to expand" is simply the lowest not-yet-passed arc whose target is still
 // marked 1 NOW: each lane watches the mark of its own arc and a ballot finds that arc -- the serial walk shrinks from
 // one step per arc to one step per expansion (about one per vertex on clean data).
+struct TrPre { uint32_t v[2], l[2], o[2]; uint32_t dead; }; // a vertex's (up to 128) arcs -- target, length, overlap word -- and its read's seq.del, a vertex ahead
+
 template <int CAP, int HASH, bool SMALL>
 __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ av, const uint32_t *__restrict__ alen, uint32_t *__restrict__ aol,
                                                     const unsigned long long *__restrict__ idx, const uint8_t *__restrict__ sdel, uint32_t v_beg, uint32_t n_vtx,
@@ -466,28 +484,61 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 	uint32_t *lv = s_v[wave], *ll = s_l[wave], *slot = s_slot[wave], *hk = s_hk[wave], *hm = s_hm[wave];
 	uint32_t n_red = 0, n_inner = 0; // n_inner: bodies of the loop at asg.c:169 this lane executed (SURVEY 8(d) prices the reduction at 16 (A + I) bytes)
 	// a wave takes 64 consecutive vertices at a time: one coalesced load of their CSR entries, then only the vertices that have arcs (of this
-	// instantiation's size class) are visited -- after containment most vertices have none, and a dependent load per vertex is pure latency
+	// instantiation's size class) are visited -- after containment most vertices have none, and a dependent load per vertex is pure latency.
+	// A vertex is a chain of dependent trips to memory (own list -> the neighbours' CSR words -> a neighbour's list -> the overlap words to flag): at 200 M
+	// arcs, where every vertex has work, the chain is what a launch costs (round 4, visit A: 3.8 ms, 0.21 of the roofline).  SMALL therefore fetches the NEXT
+	// vertex's rows (with the overlap words, so that a flag is a plain store) and its read's seq.del while the current vertex is reduced, and a neighbour's
+	// targets travel with its lengths: two trips per vertex are left.
 	for (uint64_t vb = (uint64_t)v_beg + (uint64_t)(blockIdx.x * 4 + wave) * 64; vb < n_vtx; vb += (uint64_t)gridDim.x * 256) {
 	const unsigned long long xl = vb + lane < n_vtx ? idx[vb + lane] : 0ull;
 	const uint32_t nvl = (uint32_t)xl;
 	unsigned long long todo = wv_ballot(nvl != 0 && !(SMALL ? nvl > (uint32_t)CAP : nvl <= 128u));
-	while (todo) {
-		const int vbit = __ffsll((long long)todo) - 1;
+	TrPre cur, nxt;
+	int vbit = todo ? __ffsll((long long)todo) - 1 : -1;
+	auto preload = [&](int bit, TrPre &p) {
+		const unsigned long long x = __shfl(xl, bit, 64);
+		const uint32_t st = (uint32_t)(x >> 32), nv = (uint32_t)x;
+#pragma unroll
+		for (int r = 0; r < 2; ++r) {
+			const uint32_t i = (uint32_t)r * 64u + lane;
+			p.v[r] = p.l[r] = p.o[r] = 0;
+			if (i < nv) { p.v[r] = av[st + i]; p.l[r] = alen[st + i]; p.o[r] = aol[st + i]; }
+		}
+		p.dead = sdel[((uint32_t)vb + (uint32_t)bit) >> 1];
+	};
+	if (SMALL && vbit >= 0) preload(vbit, cur);
+	while (vbit >= 0) {
 		todo &= todo - 1;
+		const int vnext = todo ? __ffsll((long long)todo) - 1 : -1;
+		if (SMALL && vnext >= 0) preload(vnext, nxt);
 		const uint32_t v = (uint32_t)vb + (uint32_t)vbit;
 		const unsigned long long x = __shfl(xl, vbit, 64);
 		uint32_t st = (uint32_t)(x >> 32), nv = (uint32_t)x;
-		if (sdel[v >> 1]) { // asg.c:158-161
-			for (uint32_t i = lane; i < nv; i += 64) aol[st + i] |= ADEL, ++n_red;
+		if (SMALL ? cur.dead != 0 : sdel[v >> 1] != 0) { // asg.c:158-161
+			if (SMALL) {
+#pragma unroll
+				for (int r = 0; r < 2; ++r) { const uint32_t i = (uint32_t)r * 64u + lane; if (i < nv) aol[st + i] = cur.o[r] | ADEL, ++n_red; }
+			} else for (uint32_t i = lane; i < nv; i += 64) aol[st + i] |= ADEL, ++n_red;
+			vbit = vnext; cur = nxt;
 			continue;
 		}
-		if (nv > (uint32_t)CAP) { if (lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF2], 1ull); ovf[k] = v; } continue; }
+		if (nv > (uint32_t)CAP) { if (lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF2], 1ull); ovf[k] = v; } vbit = vnext; cur = nxt; continue; }
 		uint32_t hbits = 6; while ((1u << hbits) < 2 * nv) ++hbits;
 		uint32_t hsize = 1u << hbits, hmask = hsize - 1;
+		if (SMALL) {
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const uint32_t i = (uint32_t)r * 64u + lane;
+				if (i < nv) {
+					const uint32_t w = cur.v[r];
+					lv[i] = w, ll[i] = cur.l[r];
+					if (i < TR_PRE) { unsigned long long xw = idx[w]; s_ws[wave][i] = (uint32_t)(xw >> 32); s_nw[wave][i] = (uint32_t)xw; }
+				}
+			}
+		} else
 		for (uint32_t i = lane; i < nv; i += 64) {
 			uint32_t w = av[st + i];
 			lv[i] = w, ll[i] = alen[st + i];
-			if (SMALL && i < TR_PRE) { unsigned long long xw = idx[w]; s_ws[wave][i] = (uint32_t)(xw >> 32); s_nw[wave][i] = (uint32_t)xw; }
 		}
 		// hm[slot] = (index of the FIRST arc to this target) << 2 | mark
 		for (uint32_t s = lane; s < hsize; s += 64) hk[s] = TR_EMPTY, hm[s] = 0xffffffffu;
@@ -518,13 +569,13 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 				for (uint32_t j0 = 0; j0 < nw; j0 += 64) { // lanes over w's arcs; sorted by len => the loop of asg.c:169 is a prefix
 					uint32_t j = j0 + lane;
 					int ok = j < nw;
-					uint32_t lx = ok ? alen[ws + j] : 0;
+					const uint32_t lx = ok ? alen[ws + j] : 0, y = ok ? av[ws + j] : 0; // both columns at once: the target is wanted by (almost) every lane that has a length
 					int cond = ok && lx + li <= L;
 					uint64_t fail = wv_ballot(ok && !cond);
 					if (fail) cond = cond && lane < (unsigned)(__ffsll((long long)fail) - 1);
 					if (cond) {
 						++n_inner;
-						int sx = tr_find(hk, av[ws + j], hbits);
+						int sx = tr_find(hk, y, hbits);
 						if (sx >= 0) hm[sx] = (hm[sx] & ~3u) | 2u; // every writer stores the same word
 					}
 					if (fail) break;
@@ -534,9 +585,14 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 		}
 		// asg.c:181-184: the sweep resets mark[target] at the first arc to a target, so of several arcs to one
 		// reduced target (multi-arcs are still present here) only the first is deleted
+		if (SMALL) {
+#pragma unroll
+			for (int r = 0; r < 2; ++r) { const uint32_t i = (uint32_t)r * 64u + lane; if (i < nv && hm[slot[i]] == (i << 2 | 2u)) aol[st + i] = cur.o[r] | ADEL, ++n_red; }
+		} else
 		for (uint32_t i = lane; i < nv; i += 64)
 			if (hm[slot[i]] == (i << 2 | 2u)) aol[st + i] |= ADEL, ++n_red;
 		wv_sync();
+		vbit = vnext; cur = nxt;
 	}
 	}
 	blk_add_u64(&ctr[CT_NRED], n_red);
@@ -712,7 +768,9 @@ static int arc_cleanup(mahip_ctx *c, size_t n_in, int keep_in, int index_mode)
 		uint32_t *ticket; unsigned long long *state; uint32_t ticket_base, epoch;
 		CHK(scan_chain_begin(c, nb, &state, &ticket, &ticket_base, &epoch));
 		ProfScope ps(c, "k_arc_rm", 32.0 * (double)n_in); // asg_arc_rm 32 B per arc
-		hipLaunchKernelGGL(k_arc_rm_chain, dim3((unsigned)nb), dim3(256), 0, c->st, in, n_in, (const uint8_t*)P<uint8_t>(c->sdel), out, d_tot, state, ticket, ticket_base, epoch);
+		// arcs_clean: nothing has deleted a read since the arcs were last checked against seq.del (ma_sg_gen's own asg_arc_rm, an earlier cleanup): only the arcs'
+		// del bits can have changed -- the cleanup behind the transitive reduction and behind asg_symm -- and the two look-ups per arc (1.45 -> ms at 200 M arcs) are moot
+		hipLaunchKernelGGL(k_arc_rm_chain, dim3((unsigned)nb), dim3(256), 0, c->st, in, n_in, c->arcs_clean ? (const uint8_t*)nullptr : (const uint8_t*)P<uint8_t>(c->sdel), out, d_tot, state, ticket, ticket_base, epoch);
 	} else {
 		ProfScope ps(c, "k_arc_rm", 32.0 * (double)n_in); // asg_arc_rm 32 B per arc
 		hipLaunchKernelGGL(k_arc_keep, dim3(grid_for(n_in, 256)), dim3(256), 0, c->st, in, n_in, (const uint8_t*)P<uint8_t>(c->sdel), P<uint32_t>(c->keep), keep_in);
@@ -724,6 +782,7 @@ static int arc_cleanup(mahip_ctx *c, size_t n_in, int keep_in, int index_mode)
 	c->ag ^= 1;
 	int changed = n_out != n_in;
 	c->n_arc = n_out;
+	c->arcs_clean = true;
 	if (index_mode > 0 || (index_mode == 0 && changed)) CHK(arc_reindex(c));
 	return 0;
 }
@@ -738,7 +797,7 @@ extern "C" int mahip_sg_flags(mahip_ctx_t *c, const ma_opt_t *opt, int use_sub, 
 	uint32_t R = c->n_seq;
 	CHK(dev_reserve(c, c->slen, ((size_t)R + 4) * 4)); CHK(dev_reserve(c, c->sdel, (size_t)R + 16));
 	c->sg_max_hang = opt->max_hang; c->sg_int_frac = opt->int_frac; c->sg_min_ovlp = opt->min_ovlp;
-	c->gsq = false;
+	c->gsq = false; c->arcs_clean = false;
 	CHK(ctr_zero(c));
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	// host-side per-read arrays (per-symbol path) go through the scratch buffers
@@ -826,7 +885,7 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 		{
 			ProfScope ps(c, "k_sg_emit", 4.0 * (double)n + 64.0 * (double)c->n_live);
 			hipLaunchKernelGGL(k_sg_emit, dim3((unsigned)n_tiles), dim3(256), 0, c->st, gcols_of(c), n, (const uint32_t*)P<uint32_t>(c->slen), (const uint8_t*)P<uint8_t>(c->sdel),
-			                   c->sg_max_hang, c->sg_int_frac, c->sg_min_ovlp, lazy, P<uint32_t>(c->keep), (const uint32_t*)nullptr, none, (uint32_t*)nullptr);
+			                   c->sg_max_hang, c->sg_int_frac, c->sg_min_ovlp, lazy, P<uint32_t>(c->keep), (const uint32_t*)nullptr, none, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr);
 		}
 		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), n_tiles, d_tot));
 		CHK(ctr_fetch(c));
@@ -837,7 +896,7 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 			ProfScope ps(c, "k_sg_emit", 4.0 * (double)n + 64.0 * (double)c->n_live + 16.0 * (double)c->n_arc);
 			hipLaunchKernelGGL(k_sg_emit, dim3((unsigned)n_tiles), dim3(256), 0, c->st, gcols_of(c), n, (const uint32_t*)P<uint32_t>(c->slen), (const uint8_t*)P<uint8_t>(c->sdel),
 			                   c->sg_max_hang, c->sg_int_frac, c->sg_min_ovlp, lazy, (uint32_t*)nullptr, (const uint32_t*)P<uint32_t>(c->pos), arcs_of(c, 0),
-			                   want_slots ? P<uint32_t>(c->aslot) : (uint32_t*)nullptr);
+			                   want_slots ? P<uint32_t>(c->aslot) : (uint32_t*)nullptr, P<uint32_t>(c->apos), P<unsigned long long>(c->sgmask)); // (the candidate bits become "kept" bits in place: every thread owns its word)
 		}
 	} else CHK(reserve_arcs(c, 0));
 	c->n_push = 0; c->push_ordered = false;
@@ -868,21 +927,17 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 			if (fast) {
 				const size_t V = 2 * (size_t)R;
 				const uint32_t q_lo = sharded ? c->q_beg : 0u, q_hi = sharded && c->q_end < R ? c->q_end : R, Rr = q_hi > q_lo ? q_hi - q_lo : 1;
-				CHK(dev_reserve(c, c->agrp, ((size_t)R + 1) * 8));
 				CHK(dev_reserve(c, c->idx, (V + 2) * 8));
-				HIPCHK(hipMemsetAsync(c->agrp.p, 0, (size_t)R * 8, c->st));
 				HIPCHK(hipMemsetAsync(c->idx.p, 0, V * 8, c->st));
 				HIPCHK(hipMemsetAsync(ctr + CT_OVF2, 0, 8, c->st));
 				HIPCHK(hipMemsetAsync(ctr + CT_STICKY, 0, (64 - CT_STICKY) * 8, c->st));
 				{
-					ProfScope ps(c, "k_arc_groups", 4.0 * (double)m);
-					hipLaunchKernelGGL(k_arc_groups, dim3(grid_for(m, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)in.u, m, (uint2*)c->agrp.p, ctr);
-				}
-				{
 					ProfScope ps(c, "k_arc_group_sort", 48.0 * (double)m); // arc sort 32 + index 16 B per arc
 					const unsigned grid = grid_for(((size_t)Rr + 63) / 64, 4, MA_STREAM_BLOCKS);
-					hipLaunchKernelGGL(k_arc_group_sort<true>, dim3(grid), dim3(256), 0, c->st, in, out, (const uint2*)c->agrp.p, q_lo, q_hi, blen ? blen : 1, P<unsigned long long>(c->idx), ctr);
-					hipLaunchKernelGGL(k_arc_group_sort<false>, dim3(grid), dim3(256), 0, c->st, in, out, (const uint2*)c->agrp.p, q_lo, q_hi, blen ? blen : 1, P<unsigned long long>(c->idx), ctr);
+					const uint32_t *goff = (const uint32_t*)P<uint32_t>(c->goff), *wpos = (const uint32_t*)P<uint32_t>(c->apos);
+					const unsigned long long *km = (const unsigned long long*)P<unsigned long long>(c->sgmask);
+					hipLaunchKernelGGL(k_arc_group_sort<true>, dim3(grid), dim3(256), 0, c->st, in, out, goff, wpos, km, (uint32_t)n, (uint32_t)m, q_lo, q_hi, blen ? blen : 1, P<unsigned long long>(c->idx), ctr);
+					hipLaunchKernelGGL(k_arc_group_sort<false>, dim3(grid), dim3(256), 0, c->st, in, out, goff, wpos, km, (uint32_t)n, (uint32_t)m, q_lo, q_hi, blen ? blen : 1, P<unsigned long long>(c->idx), ctr);
 				}
 				CHK(ctr_fetch(c));
 				if (c->h_ctr[CT_OVF2]) fast = false; // a read with more than AG_MAX arcs (or arcs that are not grouped): the general sort below
@@ -941,6 +996,7 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 	} else CHK(arc_reindex(c));
 	HIPCHK(hipGetLastError());
 	c->graph_ready = true;
+	c->arcs_clean = true; // k_sg_emit kept only arcs between live reads (asg.c:57-70 on the fresh arcs)
 	if (n_arc) *n_arc = c->n_arc;
 	return 0;
 }
@@ -967,7 +1023,7 @@ extern "C" int mahip_asg_import_rows(mahip_ctx_t *c, const void *d_src, const ui
 	for (int r = 0; r < n_ranks; ++r) tot += counts[r];
 	if (tot >= 0x7fffffffull) { mahip_set_error("mahip_asg_import_rows: too many arcs"); return -1; }
 	CHK(reserve_arcs(c, tot));
-	c->ag = 0; c->gsq = false;
+	c->ag = 0; c->gsq = false; c->arcs_clean = false;
 	ArcCols a = arcs_of(c, 0);
 	size_t off = 0;
 	for (int r = 0; r < n_ranks; ++r) {
@@ -1049,7 +1105,7 @@ extern "C" int mahip_asg_import_push_rows(mahip_ctx_t *c, const void *d_src, con
 	for (int r = 0; r < n_ranks; ++r) tot += counts[r];
 	if (tot >= 0x7fffffffull) { mahip_set_error("mahip_asg_import_push_rows: too many arcs"); return -1; }
 	CHK(reserve_arcs(c, tot));
-	c->ag = 0; c->gsq = false;
+	c->ag = 0; c->gsq = false; c->arcs_clean = false;
 	ArcCols in = arcs_of(c, 0), out = arcs_of(c, 1);
 	size_t off = 0;
 	for (int r = 0; r < n_ranks; ++r) {
@@ -1197,7 +1253,7 @@ extern "C" int mahip_asg_upload(mahip_ctx_t *c, const asg_t *g)
 	HIPCHK(hipSetDevice(c->dev));
 	size_t n = g->n_arc;
 	uint32_t R = g->n_seq;
-	c->n_seq = R; c->n_seq_new = R; c->has_map = false; c->surv_ready = false; c->soa_ready = false; c->gather_pending = false; c->gsq = false;
+	c->n_seq = R; c->n_seq_new = R; c->has_map = false; c->surv_ready = false; c->soa_ready = false; c->gather_pending = false; c->gsq = false; c->arcs_clean = false;
 	CHK(reserve_arcs(c, n));
 	CHK(dev_reserve(c, c->slen, ((size_t)R + 4) * 4)); CHK(dev_reserve(c, c->sdel, (size_t)R + 16));
 	CHK(dev_reserve(c, c->idx, (2 * (size_t)R + 2) * 8));

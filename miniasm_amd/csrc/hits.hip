@@ -1580,7 +1580,7 @@ static DevBuf *xbuf(mahip_ctx *c, int which, size_t *elem)
 	case MAHIP_BUF_SUB1: *elem = 8; return &c->sub[1];
 	case MAHIP_BUF_RCONT: *elem = 1; return &c->r_cont;
 	case MAHIP_BUF_RUSED: *elem = 1; return &c->r_used;
-	case MAHIP_BUF_SDEL: *elem = 1; return &c->sdel;
+	case MAHIP_BUF_SDEL: *elem = 1; c->arcs_clean = false; return &c->sdel; // (handed out for an exchange: assume it changes)
 	default: return nullptr;
 	}
 }

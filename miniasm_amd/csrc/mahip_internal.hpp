@@ -79,7 +79,7 @@ struct mahip_ctx {
 	DevBuf hrank;             // u32 [n_hits] position of each slot's record in the order the reference's ma_hit_sort gives the input (host walk)
 	DevBuf orank;             // u32 [n_hits] position of each slot in the stable (qid, qs, input position) order (device sort, on demand)
 	DevBuf aslot;             // u32 [n_arc]  hit slot every pushed arc came from
-	DevBuf agrp;              // uint2 [n_seq] the stretch of the push sequence that holds a read's arcs (graph.hip: k_arc_groups)
+	DevBuf apos;              // u32 [n_hits / 64] position in the push sequence of the first arc of every 64-slot word (graph.hip: k_sg_emit -> k_arc_group_sort)
 	DevBuf pushrows[2];       // sharded mode: this rank's arcs in push order as packed rows (the arc arrays are overwritten by the exchange)
 	uint32_t n_push = 0;
 	bool sorted_here = false, hrank_ready = false, orank_ready = false; // hits grouped by mahip_hits_sort (d_aos = the unsorted input) / hrank valid / orank valid
@@ -124,6 +124,7 @@ struct mahip_ctx {
 	hipEvent_t mark_ev[64] = {}; // phase marks (mahip_mark)
 	hipStream_t sub_side[2] = {}; hipEvent_t sub_ev[3] = {}; // side streams of the coverage passes' size classes (hits.hip: SubFork)
 	uint64_t tr_inner = 0;                                  // iterations of asg.c:169's loop in the last reduction (mahip_asg_trans_inner)
+	bool arcs_clean = false;                                // no arc touches a read with seq.del set (checked when the arcs were made / last cleaned, no read deleted since): asg_arc_rm need not look
 	bool radix_arcs = false;                                // the radix passes running now sort arcs (profile names)
 	bool sub_fork_failed = false;                           // they could not be created: every size class on the context's stream
 	unsigned long long mark_set = 0;
@@ -379,10 +380,11 @@ __device__ __forceinline__ uint32_t sc_look_back(const unsigned long long *state
 // what a lane keeps of a compare-exchange with its partner's value y: the smaller one in the lower lane, the larger one in the upper;
 // min / max take the DPP operand themselves and the select reads the lane mask from scalar registers (round 3: -5 % on the fused pass
 // against mov_dpp + compare + xor on vcc + select)
-#ifndef SORT_MED3
+#ifdef SORT_MINMAX // the form of round 3 (min + max with the DPP operand folded in, then a select): kept for A/B builds
 #define MA_KEEP(x, y, lower) ((lower) ? ((x) < (y) ? (x) : (y)) : ((x) < (y) ? (y) : (x)))
 #else
-// Round 4: ONE instruction instead of min + max + select: the median of (x, y, 0) is min(x, y), the median of (x, y, ~0) is max(x, y) -- v_med3_u32 with the
+// Round 4 (measured on one box: the fused coverage pass 3.37 -> 3.26 ms at BASELINE configs[3], 2.75 -> 2.50 ms on the graph-heavy input; profiles/r04_experiments.txt):
+// ONE instruction instead of min + max + select: the median of (x, y, 0) is min(x, y), the median of (x, y, ~0) is max(x, y) -- v_med3_u32 with the
 // lane's role (0 in the lower lane of a pair, ~0 in the upper) as its third operand.  gfx9 has no DPP form of a three-operand instruction, so the partner's
 // value arrives through a v_mov_b32 dpp (or ds_bpermute across rows): 2 VALU per compare-exchange instead of 3.
 __device__ __forceinline__ uint32_t ma_med3_u32(uint32_t a, uint32_t b, uint32_t c)
