@@ -892,6 +892,7 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 		c->n_arc = (uint32_t)(c->h_ctr[CT_TOTAL] & 0xffffffffu);
 		CHK(reserve_arcs(c, c->n_arc));
 		if (want_slots) CHK(dev_reserve(c, c->aslot, ((size_t)c->n_arc + 4) * 4));
+		CHK(dev_reserve(c, c->apos, (n / 64 + 8) * 4)); // first arc of every 64-slot word (pass C -> k_arc_group_sort)
 		if (c->n_arc) {
 			ProfScope ps(c, "k_sg_emit", 4.0 * (double)n + 64.0 * (double)c->n_live + 16.0 * (double)c->n_arc);
 			hipLaunchKernelGGL(k_sg_emit, dim3((unsigned)n_tiles), dim3(256), 0, c->st, gcols_of(c), n, (const uint32_t*)P<uint32_t>(c->slen), (const uint8_t*)P<uint8_t>(c->sdel),
