@@ -260,6 +260,11 @@ int mahip_comm_active(mahip_ctx_t *c);   /* more than one rank -- or one RCCL ra
 int mahip_comm_all_gather(mahip_ctx_t *c, const void *d_send, void *d_recv, size_t bytes_per_rank);  /* d_recv: world x bytes, rank-major */
 int mahip_comm_all_reduce_max_u8(mahip_ctx_t *c, void *d_buf, size_t n);                               /* OR of 0/1 flag bytes */
 int mahip_comm_all_reduce_sum_u64(mahip_ctx_t *c, uint64_t *h_vals, size_t n);                         /* <= 32 host counters */
+/* for the ranks' own text ranges (host/ingest_sharded.c): a device-side sum of u32 words, a personalised exchange (bytes[i * world + j] = what rank i sends
+ * to rank j, pieces back to back in destination order on the way out and in source order on the way in), and an all-gather of a few host words */
+int mahip_comm_all_reduce_sum_u32(mahip_ctx_t *c, void *d_buf, size_t n);
+int mahip_comm_all_to_all_v(mahip_ctx_t *c, const void *d_send, void *d_recv, const uint64_t *bytes);
+int mahip_comm_all_gather_u64(mahip_ctx_t *c, const uint64_t *h_vals, size_t n, uint64_t *h_out);
 int mahip_comm_barrier(mahip_ctx_t *c);
 int mahip_xbuf(mahip_ctx_t *c, int slot, size_t bytes, void **d_ptr);                                  /* exchange buffers (slot 0 / 1) */
 

@@ -21,6 +21,10 @@ struct RcclApi {
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
 	ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*GroupStart)(void) = nullptr;
+	ncclResult_t (*GroupEnd)(void) = nullptr;
 	const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -39,6 +43,7 @@ static int rccl_load(void)
 #define SYM(field, name) do { *(void**)&g_rccl.field = dlsym(g_rccl.dl, name); if (!g_rccl.field) { mahip_set_error("librccl has no %s", name); g_rccl.dl = nullptr; return -1; } } while (0)
 	SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
 	SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
+	SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd");
 #undef SYM
 	return 0;
 }
@@ -224,6 +229,84 @@ extern "C" int mahip_comm_all_reduce_sum_u64(mahip_ctx_t *c, uint64_t *h_vals, s
 	shm_barrier(m);
 	memcpy(h_vals, acc, n * 8);
 	shm_turn_take(m);
+	return 0;
+}
+
+// element-wise sum of n u32 words over the ranks, in place on the device (per-read hit counts of the ranks' text ranges: host/ingest_sharded.c)
+extern "C" int mahip_comm_all_reduce_sum_u32(mahip_ctx_t *c, void *d_buf, size_t n)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	Comm *m = (Comm*)c->comm;
+	if (!comm_live(m) || n == 0) return 0;
+	if (m->kind == 1) { NCCLCHK(g_rccl.AllReduce(d_buf, d_buf, n, ncclUint32, ncclSum, m->nccl, c->st)); return 0; }
+	if (n * 4 > SHM_SLOT_BYTES) { mahip_set_error("shm all-reduce: %zu bytes exceed the slot", n * 4); return -1; }
+	uint32_t *mine = (uint32_t*)(m->slots + (size_t)m->rank * SHM_SLOT_BYTES);
+	HIPCHK(hipMemcpyAsync(mine, d_buf, n * 4, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	shm_turn_give(m);
+	shm_barrier(m);
+	uint32_t *acc = (uint32_t*)malloc(n * 4);
+	memcpy(acc, m->slots, n * 4);
+	for (int r = 1; r < m->world; ++r) { const uint32_t *s = (const uint32_t*)(m->slots + (size_t)r * SHM_SLOT_BYTES); for (size_t i = 0; i < n; ++i) acc[i] += s[i]; }
+	shm_barrier(m);
+	HIPCHK(hipMemcpyAsync(d_buf, acc, n * 4, hipMemcpyHostToDevice, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	free(acc);
+	shm_turn_take(m);
+	return 0;
+}
+
+// Personalised exchange: bytes[i * world + j] = what rank i sends to rank j (the same table on every rank: all-gathered counts).  d_send holds this rank's
+// pieces back to back in destination order, d_recv receives the pieces meant for this rank back to back in SOURCE order -- for contiguous, ordered text
+// ranges that is the order of the input.  RCCL: one group of ncclSend / ncclRecv pairs (every pair its own xGMI link, 7 per GPU); shm: through the segment.
+extern "C" int mahip_comm_all_to_all_v(mahip_ctx_t *c, const void *d_send, void *d_recv, const uint64_t *bytes)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	Comm *m = (Comm*)c->comm;
+	const int W = m ? m->world : 1, me = m ? m->rank : 0;
+	if (!comm_live(m)) { if (bytes[0] && d_recv != d_send) HIPCHK(hipMemcpyAsync(d_recv, d_send, bytes[0], hipMemcpyDeviceToDevice, c->st)); return 0; }
+	size_t soff = 0, roff = 0;
+	if (m->kind == 1) {
+		NCCLCHK(g_rccl.GroupStart());
+		for (int r = 0; r < W; ++r) {
+			const size_t sb = bytes[(size_t)me * W + r], rb = bytes[(size_t)r * W + me];
+			if (sb) NCCLCHK(g_rccl.Send((const char*)d_send + soff, sb, ncclUint8, r, m->nccl, c->st));
+			if (rb) NCCLCHK(g_rccl.Recv((char*)d_recv + roff, rb, ncclUint8, r, m->nccl, c->st));
+			soff += sb; roff += rb;
+		}
+		NCCLCHK(g_rccl.GroupEnd());
+		return 0;
+	}
+	size_t mine = 0;
+	for (int r = 0; r < W; ++r) mine += bytes[(size_t)me * W + r];
+	if (mine > SHM_SLOT_BYTES) { mahip_set_error("shm all-to-all: %zu bytes from one rank exceed the slot", mine); return -1; }
+	if (mine) HIPCHK(hipMemcpyAsync(m->slots + (size_t)me * SHM_SLOT_BYTES, d_send, mine, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	shm_turn_give(m);
+	shm_barrier(m);
+	for (int r = 0; r < W; ++r) { // the piece rank r holds for me starts behind its pieces for the ranks before me
+		size_t off = 0;
+		for (int j = 0; j < me; ++j) off += bytes[(size_t)r * W + j];
+		const size_t rb = bytes[(size_t)r * W + me];
+		if (rb) HIPCHK(hipMemcpyAsync((char*)d_recv + roff, m->slots + (size_t)r * SHM_SLOT_BYTES + off, rb, hipMemcpyHostToDevice, c->st));
+		roff += rb;
+	}
+	HIPCHK(hipStreamSynchronize(c->st));
+	shm_barrier(m);
+	shm_turn_take(m);
+	return 0;
+}
+
+// the same u64 words from every rank (host values): out[r * n + k] = rank r's vals[k]
+extern "C" int mahip_comm_all_gather_u64(mahip_ctx_t *c, const uint64_t *h_vals, size_t n, uint64_t *h_out)
+{
+	Comm *m = (Comm*)c->comm;
+	const int W = m ? m->world : 1, me = m ? m->rank : 0;
+	if (!comm_live(m)) { memcpy(h_out, h_vals, n * 8); return 0; }
+	const size_t tot = n * (size_t)W;
+	memset(h_out, 0, tot * 8);
+	memcpy(h_out + (size_t)me * n, h_vals, n * 8);
+	for (size_t k = 0; k < tot; k += 32) CHK(mahip_comm_all_reduce_sum_u64(c, h_out + k, tot - k < 32 ? tot - k : 32)); // every word has one contributor: the sum IS the gather
 	return 0;
 }
 

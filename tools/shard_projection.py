@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--lines", type=int, default=100000000)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--ranks", default="1,2,4,8")
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--workdir", default=os.environ.get("MA_BENCH_DIR", "/tmp/ma_bench"))
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "shard_projection.json"))
     ap.add_argument("--worker", action="store_true")
@@ -107,9 +107,12 @@ def main():
             print("N=%d: a rank failed (%r)" % (n, rc), file=sys.stderr)
             continue
         ranks = [json.load(open(o)) for o in outs]
+        # per rank and phase: the best of the steps behind the first (the ranks take turns on one GPU; a turn that collides with another process's work on the box
+        # shows as one slow phase on one rank of one step -- round 4, visit C: "sort" 1.85 ms on one rank of eight, 0.82 on the others); then the slowest rank
         last = [rk["steps"][-1] for rk in ranks]
-        pmax = [max(l["phase_ms"][i] for l in last) for i in range(len(names))]
-        pmin = [min(l["phase_ms"][i] for l in last) for i in range(len(names))]
+        best = [[min(st["phase_ms"][i] for st in rk["steps"][1:] or rk["steps"]) for i in range(len(names))] for rk in ranks]
+        pmax = [max(b[i] for b in best) for i in range(len(names))]
+        pmin = [min(b[i] for b in best) for i in range(len(names))]
         xb = [max(l["xchg_bytes"][i] for l in last) for i in range(len(names))]
         compute = sum(pmax[i] for i, nm in enumerate(names) if not nm.startswith("x:"))
         n_coll = sum(1 for i, nm in enumerate(names) if nm.startswith("x:")) if n > 1 else 0
