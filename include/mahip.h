@@ -59,6 +59,17 @@ int mahip_paf_parse(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, mah
 /* the same with the -R pre-filter folded in (hit.c:38-68 ma_hit_no_cont + the exclusion test of hit.c:86): names of reads that some line shows
  * to be clearly contained are excluded before ids are given out; lines touching them are dropped */
 int mahip_paf_parse_excl(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, int no_cont, int max_hang, float int_frac, mahip_paf_info_t *info);
+/* Sharded ingest ("ingest routing option B"; host/ingest_sharded.c): every rank loads and parses ITS byte range of the text (ranges in rank order,
+ * cut at line starts) and the ranks exchange what the reference's sequential reader carries across a range border: line counts (occurrence numbers count lines
+ * of the whole file), the `bl` a 10-column line inherits (paf.c:54), and the distinct names of every range with their first appearances, merged into ONE
+ * dictionary with the reference's ids on every rank (sdict.c:27-45).  Afterwards the context holds the records of its own lines (global ids); info: line /
+ * record counts are totals over the ranks, n_hits is this rank's.  Collective: needs a communicator (mahip_comm_init*); -R is not served in this mode. */
+int mahip_paf_load_fd_range(mahip_ctx_t *c, int fd, size_t off, size_t nbytes);
+int mahip_paf_parse_sharded(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, mahip_paf_info_t *info);
+/* after mahip_paf_parse_sharded: every record to the rank that owns its query read (read ranges with equally many hits, from the ranks' summed per-read
+ * counts: kept as the context's shard bounds), with its position in the record sequence of the whole input.  The context then holds its own records in input
+ * order, as ma_pipeline_head_sharded(full_input = 0) wants them.  *n_total = records of all ranks; *bytes_sent = what this rank sent away. */
+int mahip_hits_route(mahip_ctx_t *c, uint64_t *n_total, uint64_t *bytes_sent);
 int mahip_paf_names(mahip_ctx_t *c, char *names, uint32_t *lens);
 /* the same as ready-made sd_seq_t records (sdict.h:6-10) whose name pointers point into `names` (a host block of name_bytes): seqs16[n_seq * 16 bytes] */
 int mahip_paf_seqs(mahip_ctx_t *c, char *names, void *seqs16, uint64_t *tot_len);          /* names[name_bytes], lens[n_seq] = first-seen read lengths */

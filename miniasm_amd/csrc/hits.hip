@@ -948,6 +948,88 @@ extern "C" int mahip_hits_balance(mahip_ctx_t *c, int world, uint32_t *bounds)
 	if (bounds) memcpy(bounds, b.data(), b.size() * 4);
 	return 0;
 }
+// ---- sharded ingest: the records of a rank's own LINES to the ranks that own their QUERY reads ("one all-to-all of 32-byte hits") ----
+__global__ __launch_bounds__(256) void k_add_u32(uint32_t *__restrict__ x, size_t n, uint32_t a)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) x[i] += a;
+}
+// The context holds the records its own text range yielded (mahip_paf_parse_sharded: ids of the merged dictionary).  Read ranges with equally many hits are
+// made from the ranks' summed per-read counts, every record travels to the owner of its query read -- with its position in the record sequence of the WHOLE
+// input, which the tie repair of a rank that holds only its own records needs (mahip_hits_set_positions) -- and the context ends as a rank of the sharded
+// head wants it: its own records in input order (source ranks hold consecutive ranges: pieces in source order ARE input order), bounds in shard_bounds.
+extern "C" int mahip_hits_route(mahip_ctx_t *c, uint64_t *n_total_out, uint64_t *bytes_sent)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	const int W = mahip_comm_world(c), me = mahip_comm_rank(c);
+	const uint32_t R = c->n_seq;
+	const size_t n = c->n_hits;
+	if (W > 32) { mahip_set_error("mahip_hits_route: at most 32 ranks"); return -1; }
+	if (n_total_out) *n_total_out = n;
+	if (bytes_sent) *bytes_sent = 0;
+	if (!mahip_comm_active(c)) { std::vector<uint32_t> b2(2); b2[0] = 0; b2[1] = R; c->shard_bounds = b2; return 0; }
+	// (1) hits per read over all ranks -> the same hit-balanced read ranges everywhere
+	uint64_t mine = n, every[32], total = 0, base = 0;
+	CHK(mahip_comm_all_gather_u64(c, &mine, 1, every));
+	for (int r = 0; r < W; ++r) { if (r < me) base += every[r]; total += every[r]; }
+	if (total >= 0xffffffffull) { mahip_set_error("mahip_hits_route: too many hits"); return -1; }
+	std::vector<uint32_t> b((size_t)W + 1, R);
+	b[0] = 0;
+	if (R) {
+		CHK(dev_reserve(c, c->keep, ((size_t)R + 16) * 4));
+		HIPCHK(hipMemsetAsync(c->keep.p, 0, (size_t)R * 4, c->st));
+		if (n) hipLaunchKernelGGL(k_qid_count, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, R, P<uint32_t>(c->keep));
+		CHK(mahip_comm_all_reduce_sum_u32(c, c->keep.p, R));
+		std::vector<uint32_t> cnt(R);
+		HIPCHK(hipMemcpyAsync(cnt.data(), c->keep.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));
+		unsigned long long run = 0;
+		int r = 1;
+		for (uint32_t q = 0; q < R && r < W; ++q) { // as mahip_hits_balance: rank r starts behind the read that completes r/W of the hits
+			run += cnt[q];
+			while (r < W && run * (unsigned long long)W >= (unsigned long long)total * (unsigned long long)r) b[r++] = q + 1;
+		}
+	}
+	// (2) my records by destination, each with its position in the whole input
+	DevBuf send_rec, send_pos, recv_rec, recv_pos;
+	uint64_t row[32], mat[32 * 32], by[32 * 32];
+	int rc = 0;
+	do {
+		if ((rc = dev_reserve(c, send_rec, (n + 1) * sizeof(ma_hit_t))) != 0 || (rc = dev_reserve(c, send_pos, (n + 1) * 4)) != 0) break;
+		size_t off = 0;
+		for (int h = 0; h < W && rc == 0; ++h) {
+			size_t k = 0;
+			rc = mahip_hits_raw_extract_pos(c, b[h], b[h + 1], (char*)send_rec.p + off * sizeof(ma_hit_t), (uint32_t*)send_pos.p + off, &k);
+			row[h] = k; off += k;
+		}
+		if (rc) break;
+		if (off != n) { mahip_set_error("mahip_hits_route: %zu of %zu records have a query id inside the dictionary", off, n); rc = -1; break; }
+		if (n && base) hipLaunchKernelGGL(k_add_u32, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (uint32_t*)send_pos.p, n, (uint32_t)base);
+		if ((rc = mahip_comm_all_gather_u64(c, row, (size_t)W, mat)) != 0) break; // mat[i * W + j]: records rank i holds for rank j
+		size_t n_my = 0;
+		for (int r = 0; r < W; ++r) n_my += mat[(size_t)r * W + me];
+		if ((rc = dev_reserve(c, recv_rec, (n_my + 1) * sizeof(ma_hit_t))) != 0 || (rc = dev_reserve(c, recv_pos, (n_my + 1) * 4)) != 0) break;
+		for (int k = 0; k < W * W; ++k) by[k] = mat[k] * sizeof(ma_hit_t);
+		if ((rc = mahip_comm_all_to_all_v(c, send_rec.p, recv_rec.p, by)) != 0) break;
+		for (int k = 0; k < W * W; ++k) by[k] = mat[k] * 4;
+		if ((rc = mahip_comm_all_to_all_v(c, send_pos.p, recv_pos.p, by)) != 0) break;
+		HIPCHK(hipStreamSynchronize(c->st));
+		if (bytes_sent) *bytes_sent = (uint64_t)(n - row[me]) * (sizeof(ma_hit_t) + 4);
+		// (3) the context as a rank of the sharded head wants it
+		const uint32_t max_qs = c->paf_max_qs;
+		dev_free(c, c->aos_own);
+		c->aos_own = recv_rec; recv_rec = DevBuf();
+		if ((rc = mahip_hits_adopt(c, c->aos_own.p, n_my, R)) != 0) break;
+		c->hint_max_qs = max_qs;
+		if ((rc = mahip_hits_set_positions(c, (const uint32_t*)recv_pos.p, 1, total)) != 0) break;
+		HIPCHK(hipStreamSynchronize(c->st));
+		c->shard_bounds = b;
+		if (n_total_out) *n_total_out = total;
+	} while (0);
+	dev_free(c, send_rec); dev_free(c, send_pos); dev_free(c, recv_rec); dev_free(c, recv_pos);
+	return rc;
+}
+
 extern "C" int mahip_set_shard_bounds(mahip_ctx_t *c, const uint32_t *bounds, int world)
 {
 	if (!bounds || world < 1) { c->shard_bounds.clear(); return 0; }

@@ -196,6 +196,7 @@ int hits_need_cols(mahip_ctx *c, const char *who);
 int xfer_copy(mahip_ctx *c, void *dev_ptr, void *host_ptr, size_t bytes, int to_device);
 void xfer_pool_free(mahip_ctx *c);
 int xfer_from_fd(mahip_ctx *c, void *dev_ptr, int fd, size_t bytes);
+int xfer_from_fd_at(mahip_ctx *c, void *dev_ptr, int fd, size_t off, size_t bytes);
 void paf_free(mahip_ctx *c);
 void clean_free(mahip_ctx *c);
 void ug_free(mahip_ctx *c);

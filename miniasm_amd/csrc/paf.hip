@@ -431,6 +431,96 @@ __global__ __launch_bounds__(256) void k_dict_names(const unsigned char *__restr
 	d[len] = 0;
 }
 
+// ------------------------------------------------------------------------------------------------ the ranks' name tables -> one dictionary
+// Sharded ingest (host/ingest_sharded.c, SURVEY 8e "ingest routing, option B"): every rank parses its own byte range of the text and holds the distinct names
+// of that range with the GLOBAL occurrence number (2 x line in the whole file + column) of their first appearance there.  The tables of all ranks are gathered
+// (rows + name bytes), every rank inserts all of them into one table -- minimum occurrence per name, first-seen length riding in the low word -- and sorts the
+// distinct names by that minimum: the same ids on every rank, the ids the reference's sequential reader hands out (sdict.c:27-45).
+struct NameRow { uint32_t occ, seq_len, name_len, name_pos; }; // one distinct name of one rank's range; name_pos: offset in that rank's block of name bytes
+
+__device__ __forceinline__ uint64_t fnv_bytes(const unsigned char *__restrict__ p, uint32_t len)
+{
+	uint64_t h = FNV_OFF;
+	for (uint32_t k = 0; k < len; ++k) h = (h ^ p[k]) * FNV_PRIME;
+	return h;
+}
+// row t = rank (t / stride_rows), index (t % stride_rows); its bytes: blobs + rank * stride_bytes + name_pos
+__global__ __launch_bounds__(256) void k_dict_merge(const NameRow *__restrict__ rows, const unsigned char *__restrict__ blobs, const uint32_t *__restrict__ n_rows /* per rank */, int world,
+                                                     uint32_t stride_rows, size_t stride_bytes, unsigned long long *__restrict__ tab, unsigned long long *__restrict__ gkey, uint32_t mask,
+                                                     uint32_t *__restrict__ slot_of, unsigned long long *__restrict__ ctr)
+{
+	uint32_t fail = 0;
+	for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < (size_t)world * stride_rows; t += (size_t)gridDim.x * 256) {
+		const uint32_t rk = (uint32_t)(t / stride_rows), j = (uint32_t)(t % stride_rows);
+		if (j >= n_rows[rk]) continue;
+		const NameRow r = rows[t];
+		const unsigned char *nm = blobs + (size_t)rk * stride_bytes + r.name_pos;
+		const uint64_t h = fnv_bytes(nm, r.name_len);
+		const uint32_t tag = (uint32_t)(h >> 32);
+		uint32_t s = (uint32_t)h & mask, got = 0xffffffffu;
+		for (uint32_t probe = 0; probe < PAF_PROBE_LIMIT; ++probe, s = (s + 1) & mask) {
+			unsigned long long e = tab[s];
+			if (e == PAF_EMPTY) {
+				e = atomicCAS(&tab[s], PAF_EMPTY, (unsigned long long)tag << 32 | (uint32_t)t);
+				if (e == PAF_EMPTY) { got = s; break; }
+			}
+			if ((uint32_t)(e >> 32) == tag) { // the claimant's row is part of the gathered (read-only) input: comparable at once
+				const uint32_t t2 = (uint32_t)e, rk2 = t2 / stride_rows;
+				const NameRow r2 = rows[t2];
+				if (r2.name_len == r.name_len && name_eq(nm, blobs + (size_t)rk2 * stride_bytes + r2.name_pos, r.name_len)) { got = s; break; }
+			}
+		}
+		if (got == 0xffffffffu) { fail = 1; continue; }
+		atomicMin(&gkey[got], (unsigned long long)r.occ << 32 | r.seq_len); // first appearance in the whole file, and the length seen there
+		slot_of[t] = got;
+	}
+	blk_add_u64(&ctr[PC_OVERFLOW], fail);
+}
+__global__ __launch_bounds__(256) void k_merge_flag(const unsigned long long *__restrict__ tab, uint32_t cap, uint32_t *__restrict__ keep)
+{
+	uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s < cap) keep[s] = tab[s] != PAF_EMPTY;
+}
+__global__ __launch_bounds__(256) void k_merge_collect(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, const unsigned long long *__restrict__ gkey, uint32_t cap,
+                                                        uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+	uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s < cap && keep[s]) { key[pos[s]] = gkey[s] >> 32; val[pos[s]] = s; }
+}
+// id i = the i-th name by first appearance: its table slot, length, where its bytes are, how long they are
+__global__ __launch_bounds__(256) void k_merge_assign(const uint32_t *__restrict__ val, uint32_t R, const unsigned long long *__restrict__ tab, const unsigned long long *__restrict__ gkey,
+                                                       const NameRow *__restrict__ rows, uint32_t stride_rows, size_t stride_bytes, uint32_t *__restrict__ gid_of_slot,
+                                                       uint32_t *__restrict__ seq_len, uint64_t *__restrict__ name_off, uint32_t *__restrict__ name_len, uint32_t *__restrict__ keep)
+{
+	uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= R) return;
+	const uint32_t s = val[i], t = (uint32_t)tab[s];
+	const NameRow r = rows[t];
+	gid_of_slot[s] = i;
+	seq_len[i] = (uint32_t)gkey[s];
+	name_off[i] = (uint64_t)(t / stride_rows) * stride_bytes + r.name_pos;
+	name_len[i] = r.name_len;
+	keep[i] = r.name_len + 1;
+}
+// this rank's table slot -> global id, through the slot's local id and the row it became
+__global__ __launch_bounds__(256) void k_merge_map(const uint32_t *__restrict__ keep_local /* slot in use */, const uint32_t *__restrict__ slot_id /* slot -> local id */, uint32_t cap,
+                                                    const uint32_t *__restrict__ slot_of, uint32_t row0, const uint32_t *__restrict__ gid_of_slot, uint32_t *__restrict__ out)
+{
+	uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s < cap && keep_local[s]) out[s] = gid_of_slot[slot_of[row0 + slot_id[s]]];
+}
+__global__ __launch_bounds__(256) void k_name_rows(const uint64_t *__restrict__ key /* sorted local first appearances */, uint32_t R, uint32_t occ_base, const uint32_t *__restrict__ seq_len,
+                                                    const uint32_t *__restrict__ name_len, const uint32_t *__restrict__ name_pos, NameRow *__restrict__ out)
+{
+	uint32_t j = blockIdx.x * 256u + threadIdx.x;
+	if (j < R) { NameRow r; r.occ = (uint32_t)key[j] + occ_base; r.seq_len = seq_len[j]; r.name_len = name_len[j]; r.name_pos = name_pos[j]; out[j] = r; }
+}
+__global__ __launch_bounds__(256) void k_bl_fill_from(const uint32_t *__restrict__ f_hasbl, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ blv, uint32_t L, uint32_t *__restrict__ bl, uint32_t before)
+{ // k_paf_bl_fill for a text range that does not start the file: lines in front of the range's first 11-column line inherit `before`, the previous ranges' last bl
+	uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < L && !f_hasbl[i]) bl[i] = pos[i] ? blv[pos[i] - 1] : before;
+}
+
 // ------------------------------------------------------------------------------------------------ records
 
 __global__ __launch_bounds__(256) void k_paf_ids(PafCols o, const uint32_t *__restrict__ slot_id, uint32_t L, int bi_dir, uint32_t *__restrict__ keep)
@@ -501,6 +591,15 @@ extern "C" int mahip_paf_load_fd(mahip_ctx_t *c, int fd, size_t nbytes)
 	return 0;
 }
 
+extern "C" int mahip_paf_load_fd_range(mahip_ctx_t *c, int fd, size_t off, size_t nbytes)
+{ // bytes [off, off + nbytes) of an open plain file: a rank's own range of the text (cut at line starts by the caller)
+	HIPCHK(hipSetDevice(c->dev));
+	CHK(paf_reserve_text(c, nbytes));
+	if (nbytes) CHK(xfer_from_fd_at(c, paf_of(c)->text.p, fd, off, nbytes));
+	paf_of(c)->loaded = true;
+	return 0;
+}
+
 static uint32_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p > 0x80000000ull ? 0x80000000u : (uint32_t)p; }
 static int bits_of(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
 
@@ -509,10 +608,18 @@ extern "C" int mahip_paf_parse(mahip_ctx_t *c, int min_span, int min_match, int 
 	return mahip_paf_parse_excl(c, min_span, min_match, bi_dir, 0, 0, 0.f, info);
 }
 
-extern "C" int mahip_paf_parse_excl(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, int no_cont, int max_hang, float int_frac, mahip_paf_info_t *info)
+// sharded: the text in the context is THIS RANK'S byte range of the file (cut at line starts, ranges in rank order); the context has a communicator.  The ranks
+// exchange what the sequential semantics need across range borders -- line counts (occurrence numbers count lines of the whole file), the last `bl` a range
+// leaves behind, the distinct names of every range with their first appearances -- and every rank ends with the records of ITS lines carrying the ids the
+// reference would give (the same dictionary on every rank).  info: n_lines / n_records / n_stored_lines are totals over the ranks, n_hits is this rank's.
+static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, int no_cont, int max_hang, float int_frac, mahip_paf_info_t *info, bool sharded)
 {
 	HIPCHK(hipSetDevice(c->dev));
 	PafBufs *b = paf_of(c);
+	const int W = sharded ? mahip_comm_world(c) : 1, me = sharded ? mahip_comm_rank(c) : 0;
+	if (sharded && no_cont) { mahip_set_error("mahip_paf_parse_sharded: the -R pre-filter needs the whole text on one rank"); return -1; }
+	if (sharded && W > 32) { mahip_set_error("mahip_paf_parse_sharded: at most 32 ranks"); return -1; }
+	uint64_t line_base = 0, lines_total = 0, valid_total = 0, pass_total = 0;
 	if (!b->loaded) { mahip_set_error("mahip_paf_parse: no text loaded"); return -1; }
 	const size_t n = b->nbytes;
 	const unsigned char *text = P<unsigned char>(b->text);
@@ -583,16 +690,47 @@ extern "C" int mahip_paf_parse_excl(mahip_ctx_t *c, int min_span, int min_match,
 		CHK(ctr_fetch(c));
 		n_valid = (size_t)c->h_ctr[PC_VALID]; n_pass = (size_t)c->h_ctr[PC_PASS]; n_nobl = (size_t)c->h_ctr[PC_NOBL];
 		max_qs = (uint32_t)c->h_ctr[PC_MAXQS];
-		if (n_nobl) { // stale bl: rare (PAF writers emit 12+ columns)
+		if (n_nobl && !sharded) { // stale bl: rare (PAF writers emit 12+ columns)
 			CHK(dev_reserve(c, b->blv, ((size_t)L + 4) * 4));
 			CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), L, nullptr));
 			hipLaunchKernelGGL(k_paf_bl_compact, dim3(grid_for(L, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (const uint32_t*)o.bl, L, P<uint32_t>(b->blv));
 			hipLaunchKernelGGL(k_paf_bl_fill, dim3(grid_for(L, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (const uint32_t*)P<uint32_t>(b->blv), L, o.bl);
 		}
 	}
+	uint64_t nobl_total = n_nobl;
+	if (sharded) { // what the ranges have to know of each other before names and records can be numbered
+		uint64_t mine[5] = { L, n_valid, n_pass, n_nobl, max_qs }, all[5 * 32];
+		CHK(mahip_comm_all_gather_u64(c, mine, 5, all));
+		nobl_total = 0;
+		for (int r = 0; r < W; ++r) {
+			if (r < me) line_base += all[5 * r];
+			lines_total += all[5 * r]; valid_total += all[5 * r + 1]; pass_total += all[5 * r + 2]; nobl_total += all[5 * r + 3];
+			if (all[5 * r + 4] > max_qs) max_qs = (uint32_t)all[5 * r + 4];
+		}
+		if (lines_total + 1 >= 0x7fffffffull) { mahip_set_error("mahip_paf_parse_sharded: more than 2^31 lines"); return -1; }
+		if (nobl_total) { // somebody has a 10-column line: every range says what `bl` it leaves behind (the bl of its last 11-column line), and a line in front of
+			// a range's first 11-column line inherits from the nearest range before it that has one (paf.c:54: the field is simply not written)
+			uint64_t two[2] = { 0, 0 }, every[2 * 32];
+			uint32_t n_has = 0, last_bl = 0;
+			if (L) {
+				CHK(dev_reserve(c, b->blv, ((size_t)L + 4) * 4));
+				CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), L, P<uint32_t>(b->scal)));
+				hipLaunchKernelGGL(k_paf_bl_compact, dim3(grid_for(L, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (const uint32_t*)o.bl, L, P<uint32_t>(b->blv));
+				HIPCHK(hipMemcpyAsync(&n_has, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
+				HIPCHK(hipStreamSynchronize(c->st));
+				if (n_has) { HIPCHK(hipMemcpyAsync(&last_bl, P<uint32_t>(b->blv) + (n_has - 1), 4, hipMemcpyDeviceToHost, c->st)); HIPCHK(hipStreamSynchronize(c->st)); }
+			}
+			two[0] = n_has ? 1 : 0; two[1] = last_bl;
+			CHK(mahip_comm_all_gather_u64(c, two, 2, every));
+			uint32_t before = 0;
+			for (int r = 0; r < me; ++r) if (every[2 * r]) before = (uint32_t)every[2 * r + 1];
+			if (L && n_nobl) hipLaunchKernelGGL(k_bl_fill_from, dim3(grid_for(L, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (const uint32_t*)P<uint32_t>(b->blv), L, o.bl, before);
+		}
+	}
 
 	// ---- dictionary: distinct names, ids in order of first appearance
-	uint32_t R = 0;
+	uint32_t R = 0, cap_used = 0;
+	int gen_local = 0;
 	if (n_pass) {
 		// The number of distinct names is not known before the pass (<= 2 per stored line; in overlap files a read has tens of lines).  Start with a
 		// table sized for 16 lines per name -- 8x smaller than the safe size, it stays in the last-level cache -- count the names as they go in, and
@@ -641,7 +779,9 @@ extern "C" int mahip_paf_parse_excl(mahip_ctx_t *c, int min_span, int min_match,
 		hipLaunchKernelGGL(k_dict_collect, dim3(grid_for(cap, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (const uint32_t*)P<uint32_t>(b->tmin), cap,
 		                   P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
 		int gen = 0;
+		cap_used = cap;
 		CHK(radix_sort_pairs(c, R, 0, bits_of(2ull * L), 0, 0, &gen));
+		gen_local = gen;
 		CHK(dev_reserve(c, b->seq_len, ((size_t)R + 4) * 4)); CHK(dev_reserve(c, b->name_off, ((size_t)R + 4) * 8));
 		CHK(dev_reserve(c, b->name_len, ((size_t)R + 4) * 4)); CHK(dev_reserve(c, b->name_pos, ((size_t)R + 4) * 4));
 		hipLaunchKernelGGL(k_dict_assign, dim3(grid_for(R, 256)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[gen]), (const uint32_t*)P<uint32_t>(c->val[gen]), R,
@@ -656,12 +796,100 @@ extern "C" int mahip_paf_parse_excl(mahip_ctx_t *c, int min_span, int min_match,
 		b->name_bytes = nb;
 	}
 	b->n_seq = R;
+	const uint32_t *slot_to_id = P<uint32_t>(b->slot_id); // table slot -> id, for the records
+	if (sharded) { // ---- the ranks' name tables -> one dictionary (kernels above)
+		const uint32_t R_loc = R;
+		const size_t nb_loc = b->name_bytes;
+		uint64_t mine[2] = { R_loc, nb_loc }, all[2 * 32];
+		CHK(mahip_comm_all_gather_u64(c, mine, 2, all));
+		uint32_t stride_rows = 1, h_rows[32];
+		size_t stride_bytes = 16, sum_rows = 0;
+		for (int r = 0; r < W; ++r) { h_rows[r] = (uint32_t)all[2 * r]; sum_rows += all[2 * r]; if (all[2 * r] > stride_rows) stride_rows = (uint32_t)all[2 * r]; if (all[2 * r + 1] > stride_bytes) stride_bytes = (size_t)all[2 * r + 1]; }
+		stride_bytes = (stride_bytes + 15) & ~(size_t)15;
+		if ((uint64_t)stride_rows * (uint64_t)W >= 0xffffffffull) { mahip_set_error("mahip_paf_parse_sharded: too many names"); return -1; }
+		// my rows and name bytes into exchange buffers, gathered with the stride of the largest range
+		DevBuf rows_all, blobs_all, aux;
+		void *xr = nullptr, *xb = nullptr;
+		CHK(mahip_xbuf(c, 0, (size_t)stride_rows * sizeof(NameRow) + stride_bytes, &xr));
+		xb = (char*)xr + (size_t)stride_rows * sizeof(NameRow);
+		if (R_loc) {
+			hipLaunchKernelGGL(k_name_rows, dim3(grid_for(R_loc, 256)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[gen_local]), R_loc, (uint32_t)(2 * line_base), (const uint32_t*)P<uint32_t>(b->seq_len),
+			                   (const uint32_t*)P<uint32_t>(b->name_len), (const uint32_t*)P<uint32_t>(b->name_pos), (NameRow*)xr);
+			HIPCHK(hipMemcpyAsync(xb, b->names.p, nb_loc, hipMemcpyDeviceToDevice, c->st));
+		}
+		int rc = 0;
+		do {
+			if ((rc = dev_reserve(c, rows_all, (size_t)W * stride_rows * sizeof(NameRow) + 64)) != 0) break;
+			if ((rc = dev_reserve(c, blobs_all, (size_t)W * stride_bytes + 64)) != 0) break;
+			if ((rc = mahip_comm_all_gather(c, xr, rows_all.p, (size_t)stride_rows * sizeof(NameRow))) != 0) break;
+			if ((rc = mahip_comm_all_gather(c, xb, blobs_all.p, stride_bytes)) != 0) break;
+			// one table for all of them: at most sum_rows distinct names
+			const uint32_t gcap = pow2_at_least(2 * (uint64_t)sum_rows + 1024);
+			const size_t total_rows = (size_t)W * stride_rows;
+			// aux: tab[gcap] u64 | gkey[gcap] u64 | slot_of[total_rows] u32 | gid_of_slot[gcap] u32 | n_rows[32] u32
+			const size_t o_key = (size_t)gcap * 8, o_slot = o_key + (size_t)gcap * 8, o_gid = o_slot + ((total_rows * 4 + 7) & ~(size_t)7), o_n = o_gid + (size_t)gcap * 4;
+			if ((rc = dev_reserve(c, aux, o_n + 32 * 4 + 64)) != 0) break;
+			unsigned long long *gtab = (unsigned long long*)aux.p, *gkey = (unsigned long long*)((char*)aux.p + o_key);
+			uint32_t *slot_of = (uint32_t*)((char*)aux.p + o_slot), *gid_of_slot = (uint32_t*)((char*)aux.p + o_gid), *d_rows = (uint32_t*)((char*)aux.p + o_n);
+			HIPCHK(hipMemsetAsync(aux.p, 0xff, o_slot, c->st));
+			HIPCHK(hipMemcpyAsync(d_rows, h_rows, (size_t)W * 4, hipMemcpyHostToDevice, c->st));
+			CHK(ctr_zero(c));
+			if (sum_rows) hipLaunchKernelGGL(k_dict_merge, dim3(grid_for(total_rows, 256, 8192)), dim3(256), 0, c->st, (const NameRow*)rows_all.p, (const unsigned char*)blobs_all.p, (const uint32_t*)d_rows, W,
+			                                 stride_rows, stride_bytes, gtab, gkey, gcap - 1, slot_of, ctr);
+			CHK(ctr_fetch(c));
+			if (c->h_ctr[PC_OVERFLOW]) { mahip_set_error("mahip_paf_parse_sharded: name table overflow"); rc = -1; break; }
+			// distinct names sorted by first appearance = ids
+			if ((rc = dev_reserve(c, c->keep, ((size_t)gcap + 16) * 4)) != 0 || (rc = dev_reserve(c, c->pos, ((size_t)gcap + 16) * 4)) != 0) break;
+			hipLaunchKernelGGL(k_merge_flag, dim3(grid_for(gcap, 256)), dim3(256), 0, c->st, (const unsigned long long*)gtab, gcap, P<uint32_t>(c->keep));
+			if ((rc = scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), gcap, P<uint32_t>(b->scal))) != 0) break;
+			uint32_t Rg = 0;
+			HIPCHK(hipMemcpyAsync(&Rg, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
+			HIPCHK(hipStreamSynchronize(c->st));
+			for (int k = 0; k < 2 && rc == 0; ++k) { rc = dev_reserve(c, c->key[k], ((size_t)Rg + 1) * 8); if (rc == 0) rc = dev_reserve(c, c->val[k], ((size_t)Rg + 1) * 4); }
+			if (rc) break;
+			hipLaunchKernelGGL(k_merge_collect, dim3(grid_for(gcap, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (const unsigned long long*)gkey, gcap,
+			                   P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));
+			int gen = 0;
+			if ((rc = radix_sort_pairs(c, Rg, 0, bits_of(2ull * lines_total), 0, 0, &gen)) != 0) break;
+			// the map for this rank's records BEFORE the local arrays are overwritten: local slot -> global id (k_merge_map needs the local "slot in use" flags)
+			if (cap_used) {
+				if ((rc = dev_reserve(c, b->excl, (size_t)cap_used * 4 + 16)) != 0) break; // (the -R flag array is free in this mode: the map lives there)
+			}
+			if ((rc = dev_reserve(c, b->seq_len, ((size_t)Rg + 4) * 4)) != 0 || (rc = dev_reserve(c, b->name_off, ((size_t)Rg + 4) * 8)) != 0 ||
+			    (rc = dev_reserve(c, b->name_len, ((size_t)Rg + 4) * 4)) != 0 || (rc = dev_reserve(c, b->name_pos, ((size_t)Rg + 4) * 4)) != 0) break;
+			// keep / pos are about to be reused for the name lengths: the local flags first
+			DevBuf used_local;
+			if (cap_used) {
+				if ((rc = dev_reserve(c, used_local, (size_t)cap_used * 4 + 16)) != 0) break;
+				hipLaunchKernelGGL(k_dict_flag, dim3(grid_for(cap_used, 256)), dim3(256), 0, c->st, (const unsigned long long*)P<unsigned long long>(b->tab), (const uint32_t*)P<uint32_t>(b->tmin), cap_used, (uint32_t*)used_local.p);
+			}
+			if ((rc = dev_reserve(c, c->keep, ((size_t)Rg + 16) * 4)) != 0) { dev_free(c, used_local); break; }
+			if (Rg) hipLaunchKernelGGL(k_merge_assign, dim3(grid_for(Rg, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->val[gen]), Rg, (const unsigned long long*)gtab, (const unsigned long long*)gkey,
+			                           (const NameRow*)rows_all.p, stride_rows, stride_bytes, gid_of_slot, P<uint32_t>(b->seq_len), P<uint64_t>(b->name_off), P<uint32_t>(b->name_len), P<uint32_t>(c->keep));
+			if (cap_used) hipLaunchKernelGGL(k_merge_map, dim3(grid_for(cap_used, 256)), dim3(256), 0, c->st, (const uint32_t*)used_local.p, (const uint32_t*)P<uint32_t>(b->slot_id), cap_used,
+			                                 (const uint32_t*)slot_of, (uint32_t)((size_t)me * stride_rows), (const uint32_t*)gid_of_slot, P<uint32_t>(b->excl));
+			uint32_t nb = 0;
+			if ((rc = scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(b->name_pos), Rg, P<uint32_t>(b->scal))) != 0) { dev_free(c, used_local); break; }
+			HIPCHK(hipMemcpyAsync(&nb, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
+			HIPCHK(hipStreamSynchronize(c->st));
+			dev_free(c, used_local);
+			if ((rc = dev_reserve(c, b->names, (size_t)nb + 16)) != 0) break;
+			if (Rg) hipLaunchKernelGGL(k_dict_names, dim3(grid_for(Rg, 256)), dim3(256), 0, c->st, (const unsigned char*)blobs_all.p, (const uint64_t*)P<uint64_t>(b->name_off), (const uint32_t*)P<uint32_t>(b->name_len),
+			                           (const uint32_t*)P<uint32_t>(b->name_pos), Rg, P<char>(b->names));
+			HIPCHK(hipStreamSynchronize(c->st)); // (the gathered blocks are released below)
+			b->name_bytes = nb;
+			R = Rg; b->n_seq = Rg;
+			slot_to_id = (const uint32_t*)P<uint32_t>(b->excl);
+		} while (0);
+		dev_free(c, rows_all); dev_free(c, blobs_all); dev_free(c, aux);
+		if (rc) return -1;
+	}
 
 	// ---- records: hit (+ mirrored hit) per stored line, in line order
 	size_t n_hits = 0;
 	if (n_pass) {
 		CHK(dev_reserve(c, c->keep, ((size_t)L + 16) * 4)); CHK(dev_reserve(c, c->pos, ((size_t)L + 16) * 4));
-		hipLaunchKernelGGL(k_paf_ids, dim3(grid_for(L, 256)), dim3(256), 0, c->st, o, (const uint32_t*)P<uint32_t>(b->slot_id), L, bi_dir, P<uint32_t>(c->keep));
+		hipLaunchKernelGGL(k_paf_ids, dim3(grid_for(L, 256)), dim3(256), 0, c->st, o, slot_to_id, L, bi_dir, P<uint32_t>(c->keep));
 		uint32_t nh = 0;
 		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), L, P<uint32_t>(b->scal)));
 		HIPCHK(hipMemcpyAsync(&nh, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
@@ -679,7 +907,17 @@ extern "C" int mahip_paf_parse_excl(mahip_ctx_t *c, int min_span, int min_match,
 	HIPCHK(hipStreamSynchronize(c->st));
 	c->hint_max_qs = c->paf_max_qs = max_qs;
 	info->n_records = n_valid; info->n_stored_lines = n_pass; info->n_hits = n_hits; info->n_seq = R; info->max_qs = max_qs; info->name_bytes = b->name_bytes; info->n_lines = L;
+	if (sharded) { info->n_records = valid_total; info->n_stored_lines = pass_total; info->n_lines = lines_total; }
 	return 0;
+}
+
+extern "C" int mahip_paf_parse_excl(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, int no_cont, int max_hang, float int_frac, mahip_paf_info_t *info)
+{
+	return paf_parse_impl(c, min_span, min_match, bi_dir, no_cont, max_hang, int_frac, info, false);
+}
+extern "C" int mahip_paf_parse_sharded(mahip_ctx_t *c, int min_span, int min_match, int bi_dir, mahip_paf_info_t *info)
+{
+	return paf_parse_impl(c, min_span, min_match, bi_dir, 0, 0, 0.f, info, mahip_comm_active(c) != 0);
 }
 
 extern "C" int mahip_paf_names(mahip_ctx_t *c, char *names, uint32_t *lens)

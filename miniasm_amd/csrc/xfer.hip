@@ -20,7 +20,7 @@ struct XferPool {
 	hipEvent_t ev[XF_MAX_WORKERS][2] = {};
 };
 
-struct XferJob { XferPool *p; hipStream_t st; int w, n_workers, dev, to_device, rc, fd; char *dev_ptr; char *host_ptr; size_t bytes; }; // fd >= 0: the source is a file (pread)
+struct XferJob { XferPool *p; hipStream_t st; int w, n_workers, dev, to_device, rc, fd; char *dev_ptr; char *host_ptr; size_t bytes, fd_off; }; // fd >= 0: the source is a file (pread)
 
 static void *xfer_worker(void *arg)
 {
@@ -46,7 +46,7 @@ static void *xfer_worker(void *arg)
 			if (j->fd >= 0) { // file -> pinned slot directly: no pageable intermediate copy
 				size_t got = 0;
 				while (got < len) {
-					ssize_t r = pread(j->fd, p->slot[w][b] + got, len - got, (off_t)(off + got));
+					ssize_t r = pread(j->fd, p->slot[w][b] + got, len - got, (off_t)(j->fd_off + off + got));
 					if (r <= 0) { j->rc = -1; return 0; }
 					got += (size_t)r;
 				}
@@ -105,7 +105,7 @@ void xfer_pool_free(mahip_ctx *c)
 }
 
 // synchronous with respect to the host; ordered after everything already queued on the context's stream
-static int xfer_run(mahip_ctx *c, void *dev_ptr, void *host_ptr, int fd, size_t bytes, int to_device)
+static int xfer_run(mahip_ctx *c, void *dev_ptr, void *host_ptr, int fd, size_t bytes, int to_device, size_t fd_off = 0)
 {
 	if (bytes == 0) return 0;
 	HIPCHK(hipSetDevice(c->dev));
@@ -123,7 +123,7 @@ static int xfer_run(mahip_ctx *c, void *dev_ptr, void *host_ptr, int fd, size_t 
 	bool started[XF_MAX_WORKERS];
 	for (int w = 0; w < W; ++w) {
 		job[w].p = (XferPool*)c->xfer; job[w].st = c->st; job[w].w = w; job[w].n_workers = W; job[w].dev = c->dev; job[w].to_device = to_device; job[w].rc = 0;
-		job[w].dev_ptr = (char*)dev_ptr; job[w].host_ptr = (char*)host_ptr; job[w].bytes = bytes; job[w].fd = fd;
+		job[w].dev_ptr = (char*)dev_ptr; job[w].host_ptr = (char*)host_ptr; job[w].bytes = bytes; job[w].fd = fd; job[w].fd_off = fd_off;
 		started[w] = pthread_create(&th[w], 0, xfer_worker, &job[w]) == 0;
 		if (!started[w]) xfer_worker(&job[w]); // no thread: do this worker's slices here
 	}
@@ -147,6 +147,8 @@ static int xfer_run(mahip_ctx *c, void *dev_ptr, void *host_ptr, int fd, size_t 
 int xfer_copy(mahip_ctx *c, void *dev_ptr, void *host_ptr, size_t bytes, int to_device) { return xfer_run(c, dev_ptr, host_ptr, -1, bytes, to_device); }
 // bytes [0, bytes) of an open file -> device memory
 int xfer_from_fd(mahip_ctx *c, void *dev_ptr, int fd, size_t bytes) { return xfer_run(c, dev_ptr, nullptr, fd, bytes, 1); }
+// bytes [off, off + bytes) of an open file -> device memory (a rank's own range of the text: host/ingest_sharded.c)
+int xfer_from_fd_at(mahip_ctx *c, void *dev_ptr, int fd, size_t off, size_t bytes) { return xfer_run(c, dev_ptr, nullptr, fd, bytes, 1, off); }
 
 extern "C" int mahip_memcpy_h2d(mahip_ctx_t *c, void *d_dst, const void *h_src, size_t bytes) { return xfer_copy(c, d_dst, (void*)h_src, bytes, 1); }
 extern "C" int mahip_memcpy_d2h(mahip_ctx_t *c, void *h_dst, const void *d_src, size_t bytes) { return xfer_copy(c, (void*)d_src, h_dst, bytes, 0); }

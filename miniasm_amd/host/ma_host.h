@@ -60,6 +60,10 @@ ma_hit_t *ma_hit_ingest_mt(const char *fn, int min_span, int min_match, sdict_t 
 /* the same on the device (ingest_gpu.c + csrc/paf.hip): records stay in the context; 0 ok, -1 cannot open */
 int ma_hit_ingest_gpu(mahip_ctx_t *c, const char *fn, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir);
 int ma_hit_ingest_gpu_excl(mahip_ctx_t *c, const char *fn, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir, int no_cont, int max_hang, float int_frac);
+/* the same on N ranks, every rank on its own byte range of a plain file (ingest_sharded.c): collective; -2 = not possible for this file (same verdict on every rank) */
+typedef struct { uint64_t bytes_own, bytes_file, n_lines, n_records, n_hits_total, bytes_routed, tot_len; uint32_t max_qs; } ma_ingest_shard_info_t;
+int ma_ingest_sharded_possible(const char *fn);
+int ma_hit_ingest_sharded(mahip_ctx_t *c, const char *fn, int min_span, int min_match, sdict_t *d, size_t *n_hits_total, int bi_dir, ma_ingest_shard_info_t *si);
 int ma_hit_ingest_loaded_excl(mahip_ctx_t *c, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir, int release, int no_cont, int max_hang, float int_frac);
 int ma_paf_load_file(mahip_ctx_t *c, const char *fn); /* plain / gzip / "-": text into HBM */
 int ma_hit_ingest_loaded(mahip_ctx_t *c, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir, int release);

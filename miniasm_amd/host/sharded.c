@@ -267,7 +267,7 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 {
 	const char *kind = getenv("MA_COMM");
 	const int use_shm = kind && strcmp(kind, "shm") == 0;
-	int rank = 0, r, (*pipes)[2] = (int(*)[2])calloc((size_t)world, sizeof(int[2]));
+	int rank = 0, r, own_records = 0, (*pipes)[2] = (int(*)[2])calloc((size_t)world, sizeof(int[2]));
 	pid_t *kids = (pid_t*)calloc((size_t)world, sizeof(pid_t));
 	char id[128], shm_name[64];
 	mahip_ctx_t *c;
@@ -339,15 +339,29 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 	else GPU(mahip_comm_init(c, id, rank, world));
 	lg = MA_LOG;
 	fprintf(lg, "[M::%s] ===> Step %d: %s <===\n", "main", (flags & 8) ? 0 : 1, (flags & 8) ? "removing contained reads" : "reading read mappings");
+	/* Ingest.  A plain file without -R: every rank loads and parses its own byte range, the ranks merge their name tables and route the records to the owners
+	 * of their query reads (ingest_sharded.c) -- 1/N of the text per rank.  Otherwise (gzip, stdin, -R, MA_INGEST_WHOLE=1): every rank parses the whole text
+	 * and keeps the hits of its read range, as in round 3.  The choice depends on the file and the options alone: every rank makes the same one. */
+	own_records = !(flags & 8) && !(getenv("MA_INGEST_WHOLE") && atoi(getenv("MA_INGEST_WHOLE"))) && ma_ingest_sharded_possible(fn);
+	if (own_records) {
+		ma_ingest_shard_info_t si;
+		memset(&si, 0, sizeof(si));
+		r = ma_hit_ingest_sharded(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), &si);
+		if (r == -1) { fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn); exit(1); }
+		if (r != 0) { fprintf(stderr, "[E::%s] rank %d: the ranges of the text could not be ingested\n", __func__, rank); exit(1); }
+		if (ma_verbose >= 3)
+			fprintf(lg, "[M::%s::%s] read %ld hits; stored %ld hits and %d sequences (%ld bp)\n", "ma_hit_read", sys_timestamp(), (long)si.n_records, (long)si.n_hits_total, d->n_seq, (long)si.tot_len);
+	} else {
 	r = ma_hit_ingest_gpu_excl(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), (flags & 8) != 0, opt->max_hang, opt->int_frac);
 	if (r == -1) { fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn); exit(1); }
 	if (r != 0) { fprintf(stderr, "[E::%s] the text does not fit the device stage; MA_GPUS > 1 needs the device parser\n", __func__); exit(1); }
+	}
 	{ /* test hook: a rank that dies in the middle of a run (tests/test_gpu_sharded.py checks that nobody is left waiting) */
 		const char *e = getenv("MA_TEST_FAIL_RANK");
 		if (e && atoi(e) == rank) { fprintf(stderr, "[E::%s] rank %d: MA_TEST_FAIL_RANK\n", __func__, rank); _exit(3); }
 	}
-	GPU(mahip_hits_balance(c, world, 0)); /* every rank holds the whole input here: the same hit-balanced read ranges everywhere */
-	ma_pipeline_head_sharded(c, opt, d->n_seq, 1, &st);
+	if (!own_records) GPU(mahip_hits_balance(c, world, 0)); /* every rank holds the whole input here: the same hit-balanced read ranges everywhere (own records: mahip_hits_route made them) */
+	ma_pipeline_head_sharded(c, opt, d->n_seq, !own_records, &st);
 	if (ma_shard_stats_reduce(c, &st) != 0) exit(1); /* the log lines below want the sums */
 	if (use_shm) GPU(mahip_mem_trim(c, 0)); /* the ranks share ONE GPU here: what this rank's pool keeps idle (the text, the parser's columns) is memory rank 0's tail cannot have */
 	if (rank == 0) {
