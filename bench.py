@@ -172,7 +172,6 @@ class Workload:
 
     def __init__(self, ma, L, ctx, paf, opt, world, rank, keep_text=False):
         import torch
-        from miniasm_amd.sharded import shard_range
         self.paf, self.n_lines = paf, count_lines(paf)
         L.ma_paf_load_file.argtypes = [C.c_void_p, C.c_char_p]
         L.ma_hit_ingest_loaded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(ma.Sdict), C.POINTER(C.c_size_t), C.c_int, C.c_int]
@@ -192,7 +191,7 @@ class Workload:
         L.mahip_paf_max_qs.restype = C.c_uint32
         L.mahip_paf_max_qs.argtypes = [C.c_void_p]
         self.max_qs = L.mahip_paf_max_qs(ctx.h)
-        _, q0, q1 = shard_range(self.n_seq, world, rank)
+        q0, q1 = 0, 0xffffffff
         if world == 1:
             q0, q1 = 0, 0xffffffff
         else:  # read ranges with equally many hits; the table stays in the context for the sharded head (host/sharded.c)

@@ -219,7 +219,7 @@ int mahip_asg_download(mahip_ctx_t *c, asg_t *g);
 /* ---- building blocks of the sharded multi-GPU mode ---------------------------------------------------
  * One context per GPU owns the hits whose query id lies in its read range (mahip_set_shard).  Passes that read
  * another read's sub/flags need the complete read-indexed arrays, so the caller exchanges them between the
- * split halves below (RCCL all-gather / max all-reduce through torch.distributed in miniasm_amd/sharded.py);
+ * split halves below (host/sharded.c: RCCL all-gather / max all-reduce on the context's stream);
  * the arcs are exchanged once, before the transitive reduction. */
 #define MAHIP_BUF_SUB0  0   /* uint2 [n_seq] */
 #define MAHIP_BUF_SUB1  1
@@ -271,6 +271,18 @@ int mahip_comm_active(mahip_ctx_t *c);   /* more than one rank -- or one RCCL ra
 int mahip_comm_all_gather(mahip_ctx_t *c, const void *d_send, void *d_recv, size_t bytes_per_rank);  /* d_recv: world x bytes, rank-major */
 int mahip_comm_all_reduce_max_u8(mahip_ctx_t *c, void *d_buf, size_t n);                               /* OR of 0/1 flag bytes */
 int mahip_comm_all_reduce_sum_u64(mahip_ctx_t *c, uint64_t *h_vals, size_t n);                         /* <= 32 host counters */
+/* A transport of the caller's own instead of RCCL / the shared-memory double: five callbacks on HOST buffers (0 = ok); the library stages the device buffers
+ * through the host around them.  all_gather: every rank's `bytes` from send into recv, rank-major; all_to_all_v: as mahip_comm_all_to_all_v below (bytes[i *
+ * world + j] from rank i to rank j, pieces back to back).  tests/test_dist_gloo.py: host/sharded.c over torch.distributed's gloo backend on the CPU build. */
+typedef struct {
+	void *user;
+	int (*all_gather)(void *user, const void *send, void *recv, size_t bytes);
+	int (*all_reduce_max_u8)(void *user, void *buf, size_t n);
+	int (*all_reduce_sum_u64)(void *user, uint64_t *vals, size_t n);
+	int (*all_reduce_sum_u32)(void *user, void *buf, size_t n);
+	int (*all_to_all_v)(void *user, const void *send, void *recv, const uint64_t *bytes);
+} mahip_comm_ext_t;
+int mahip_comm_init_ext(mahip_ctx_t *c, int rank, int world, const mahip_comm_ext_t *ext);
 /* for the ranks' own text ranges (host/ingest_sharded.c): a device-side sum of u32 words, a personalised exchange (bytes[i * world + j] = what rank i sends
  * to rank j, pieces back to back in destination order on the way out and in source order on the way in), and an all-gather of a few host words */
 int mahip_comm_all_reduce_sum_u32(mahip_ctx_t *c, void *d_buf, size_t n);

@@ -6,6 +6,8 @@
 //   shm   : the same three operations staged through a POSIX shared-memory segment by the host -- a test double for boxes with
 //           ONE GPU (RCCL refuses two ranks on one device): N processes, one context each on the same device, exercise the
 //           orchestration code (host/sharded.c) end to end.  Never the production path.
+//   ext   : the caller's own transport over HOST buffers (mahip_comm_init_ext): five callbacks.  tests/test_dist_gloo.py runs host/sharded.c over
+//           torch.distributed's gloo backend this way -- the product's orchestration on the CPU build of the kernels, no second copy of the sequence.
 #include "mahip_internal.hpp"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
@@ -64,7 +66,9 @@ struct ShmHeader { volatile unsigned arrive, sense; unsigned world; size_t slot;
 #define SHM_SLOT_BYTES ((size_t)1 << 30) // per rank, sparse: pages exist only where a collective wrote
 
 struct Comm {
-	int kind = 0, rank = 0, world = 1; // kind 1 = RCCL, 2 = shm
+	int kind = 0, rank = 0, world = 1; // kind 1 = RCCL, 2 = shm, 3 = the caller's own transport (host buffers: mahip_comm_init_ext)
+	mahip_comm_ext_t ext = {};
+	std::vector<char> hbuf[2]; // kind 3: host staging
 	ncclComm_t nccl = nullptr;
 	ShmHeader *hdr = nullptr;
 	char *slots = nullptr;
@@ -153,6 +157,30 @@ extern "C" int mahip_comm_init_shm(mahip_ctx_t *c, const char *name, int rank, i
 	return 0;
 }
 
+extern "C" int mahip_comm_init_ext(mahip_ctx_t *c, int rank, int world, const mahip_comm_ext_t *ext)
+{
+	if (!ext || !ext->all_gather || !ext->all_reduce_max_u8 || !ext->all_reduce_sum_u64 || !ext->all_reduce_sum_u32 || !ext->all_to_all_v) { mahip_set_error("mahip_comm_init_ext: a callback is missing"); return -1; }
+	mahip_comm_destroy(c);
+	Comm *m = new Comm();
+	m->kind = 3; m->rank = rank; m->world = world; m->ext = *ext;
+	c->comm = m;
+	return 0;
+}
+// kind 3: a device buffer through the host and the caller's callback
+static int ext_stage_out(mahip_ctx *c, Comm *m, int k, const void *d_src, size_t bytes)
+{
+	if (m->hbuf[k].size() < bytes + 16) m->hbuf[k].resize(bytes + 16);
+	if (bytes) { HIPCHK(hipMemcpyAsync(m->hbuf[k].data(), d_src, bytes, hipMemcpyDeviceToHost, c->st)); }
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}
+static int ext_stage_in(mahip_ctx *c, Comm *m, int k, void *d_dst, size_t bytes)
+{
+	if (bytes) { HIPCHK(hipMemcpyAsync(d_dst, m->hbuf[k].data(), bytes, hipMemcpyHostToDevice, c->st)); HIPCHK(hipStreamSynchronize(c->st)); }
+	return 0;
+}
+#define EXTCHK(call, what) do { if ((call) != 0) { mahip_set_error("the caller's %s callback failed", what); return -1; } } while (0)
+
 // MA_RCCL_ONE_RANK=1: a one-rank RCCL communicator still goes through ncclAllGather / ncclAllReduce (symbol binding, datatypes, in-place
 // conventions and stream ordering run on hardware wherever a single GPU is all there is); default: one rank = plain copies
 static bool one_rank_forced() { static int v = -1; if (v < 0) { const char *e = getenv("MA_RCCL_ONE_RANK"); v = e && atoi(e) != 0; } return v != 0; }
@@ -169,6 +197,12 @@ extern "C" int mahip_comm_all_gather(mahip_ctx_t *c, const void *d_send, void *d
 	if (!comm_live(m)) { if (bytes && d_recv != d_send) HIPCHK(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, c->st)); return 0; }
 	if (bytes == 0) return 0;
 	if (m->kind == 1) { NCCLCHK(g_rccl.AllGather(d_send, d_recv, bytes, ncclUint8, m->nccl, c->st)); return 0; }
+	if (m->kind == 3) {
+		CHK(ext_stage_out(c, m, 0, d_send, bytes));
+		if (m->hbuf[1].size() < bytes * (size_t)m->world + 16) m->hbuf[1].resize(bytes * (size_t)m->world + 16);
+		EXTCHK(m->ext.all_gather(m->ext.user, m->hbuf[0].data(), m->hbuf[1].data(), bytes), "all_gather");
+		return ext_stage_in(c, m, 1, d_recv, bytes * (size_t)m->world);
+	}
 	if (bytes > SHM_SLOT_BYTES) { mahip_set_error("shm all-gather: %zu bytes per rank exceed the slot", bytes); return -1; }
 	HIPCHK(hipMemcpyAsync(m->slots + (size_t)m->rank * SHM_SLOT_BYTES, d_send, bytes, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipStreamSynchronize(c->st));
@@ -188,6 +222,11 @@ extern "C" int mahip_comm_all_reduce_max_u8(mahip_ctx_t *c, void *d_buf, size_t 
 	Comm *m = (Comm*)c->comm;
 	if (!comm_live(m) || n == 0) return 0;
 	if (m->kind == 1) { NCCLCHK(g_rccl.AllReduce(d_buf, d_buf, n, ncclUint8, ncclMax, m->nccl, c->st)); return 0; }
+	if (m->kind == 3) {
+		CHK(ext_stage_out(c, m, 0, d_buf, n));
+		EXTCHK(m->ext.all_reduce_max_u8(m->ext.user, m->hbuf[0].data(), n), "all_reduce_max_u8");
+		return ext_stage_in(c, m, 0, d_buf, n);
+	}
 	if (n > SHM_SLOT_BYTES) { mahip_set_error("shm all-reduce: %zu bytes exceed the slot", n); return -1; }
 	uint8_t *mine = (uint8_t*)(m->slots + (size_t)m->rank * SHM_SLOT_BYTES);
 	HIPCHK(hipMemcpyAsync(mine, d_buf, n, hipMemcpyDeviceToHost, c->st));
@@ -212,6 +251,7 @@ extern "C" int mahip_comm_all_reduce_sum_u64(mahip_ctx_t *c, uint64_t *h_vals, s
 	Comm *m = (Comm*)c->comm;
 	if (!comm_live(m) || n == 0) return 0;
 	if (n > 32) { mahip_set_error("mahip_comm_all_reduce_sum_u64: at most 32 counters"); return -1; }
+	if (m->kind == 3) { HIPCHK(hipStreamSynchronize(c->st)); EXTCHK(m->ext.all_reduce_sum_u64(m->ext.user, h_vals, n), "all_reduce_sum_u64"); return 0; }
 	if (m->kind == 1) {
 		unsigned long long *d = P<unsigned long long>(c->ctr) + 16; // scratch words of the counter block (not sticky, not in use between passes)
 		HIPCHK(hipMemcpyAsync(d, h_vals, n * 8, hipMemcpyHostToDevice, c->st));
@@ -239,6 +279,11 @@ extern "C" int mahip_comm_all_reduce_sum_u32(mahip_ctx_t *c, void *d_buf, size_t
 	Comm *m = (Comm*)c->comm;
 	if (!comm_live(m) || n == 0) return 0;
 	if (m->kind == 1) { NCCLCHK(g_rccl.AllReduce(d_buf, d_buf, n, ncclUint32, ncclSum, m->nccl, c->st)); return 0; }
+	if (m->kind == 3) {
+		CHK(ext_stage_out(c, m, 0, d_buf, n * 4));
+		EXTCHK(m->ext.all_reduce_sum_u32(m->ext.user, m->hbuf[0].data(), n), "all_reduce_sum_u32");
+		return ext_stage_in(c, m, 0, d_buf, n * 4);
+	}
 	if (n * 4 > SHM_SLOT_BYTES) { mahip_set_error("shm all-reduce: %zu bytes exceed the slot", n * 4); return -1; }
 	uint32_t *mine = (uint32_t*)(m->slots + (size_t)m->rank * SHM_SLOT_BYTES);
 	HIPCHK(hipMemcpyAsync(mine, d_buf, n * 4, hipMemcpyDeviceToHost, c->st));
@@ -279,6 +324,14 @@ extern "C" int mahip_comm_all_to_all_v(mahip_ctx_t *c, const void *d_send, void 
 	}
 	size_t mine = 0;
 	for (int r = 0; r < W; ++r) mine += bytes[(size_t)me * W + r];
+	if (m->kind == 3) {
+		size_t in = 0;
+		for (int r = 0; r < W; ++r) in += bytes[(size_t)r * W + me];
+		CHK(ext_stage_out(c, m, 0, d_send, mine));
+		if (m->hbuf[1].size() < in + 16) m->hbuf[1].resize(in + 16);
+		EXTCHK(m->ext.all_to_all_v(m->ext.user, m->hbuf[0].data(), m->hbuf[1].data(), bytes), "all_to_all_v");
+		return ext_stage_in(c, m, 1, d_recv, in);
+	}
 	if (mine > SHM_SLOT_BYTES) { mahip_set_error("shm all-to-all: %zu bytes from one rank exceed the slot", mine); return -1; }
 	if (mine) HIPCHK(hipMemcpyAsync(m->slots + (size_t)me * SHM_SLOT_BYTES, d_send, mine, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipStreamSynchronize(c->st));

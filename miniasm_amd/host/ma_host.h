@@ -40,6 +40,8 @@ void ma_shard_phases(int on);
 int ma_pipeline_head_sharded(mahip_ctx_t *c, const ma_opt_t *opt, uint32_t n_seq, int full_input, ma_shard_stats_t *st);
 int ma_shard_stats_reduce(mahip_ctx_t *c, ma_shard_stats_t *st);
 int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *outfmt, int stage, int flags, FILE *out, int world);
+/* one rank's part of it, for a context that already has a communicator of any kind (collective; rank 0 writes `out`) */
+int ma_pipeline_run_rank(mahip_ctx_t *c, const ma_opt_t *opt, const char *fn, const char *outfmt, int stage, int flags, FILE *out, int share_gpu);
 ma_ug_t *ma_ug_from_device(mahip_ctx_t *c); /* unitigs of the graph resident in c (unitig_gfa.c over csrc/ug.hip) */
 void ma_sd_reindex(sdict_t *d);    /* build the name index from seq[] (for dictionaries assembled by hand) */
 void ma_sd_drop_index(sdict_t *d);

@@ -7,7 +7,7 @@
  *
  *   ma_pipeline_device() = ma_pipeline_head() (device passes) + ma_pipeline_tail() (host part); bench.py times
  *   ma_pipeline_device with the unsorted hit records already in HBM.  In the sharded multi-GPU mode the head is
- *   replaced by miniasm_amd/sharded.py (same passes + RCCL exchanges) and rank 0 runs the tail.
+ *   replaced by ma_pipeline_head_sharded (sharded.c: same passes + RCCL exchanges) and rank 0 runs the tail.
  */
 #define _GNU_SOURCE
 #include <stdio.h>

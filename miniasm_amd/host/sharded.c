@@ -10,8 +10,8 @@
  *   | transitive reduction of the own vertices | ALL-GATHER of the del flags | rank 0: cleanup, symm
  *
  * The collectives are RCCL calls queued on the context's stream (csrc/comm.hip); nothing but the few per-pass counters and
- * the arc-block sizes comes back to the host in between.  The same sequence is kept as an executable specification in
- * miniasm_amd/sharded.py (driven over gloo with an oracle-backed stand-in in tests/test_dist_gloo.py).
+ * the arc-block sizes comes back to the host in between.  This file is the ONE statement of the sequence: tests/test_dist_gloo.py
+ * runs it over torch.distributed's gloo backend (mahip_comm_init_ext + miniasm_amd/dist_transport.py) on the CPU build of the kernels.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -228,6 +228,73 @@ int ma_shard_stats_reduce(mahip_ctx_t *c, ma_shard_stats_t *st)
 	return 0;
 }
 
+/* What ONE rank of an N-rank run does once its context has a communicator (RCCL, the shared-memory double, or a transport of the caller's:
+ * mahip_comm_init_ext): ingest -- its own byte range of a plain file, else the whole text --, the sharded head, and on rank 0 the tail into `out`.
+ * Collective.  ma_pipeline_run_sharded() below calls it in every process it forked; tests/test_dist_gloo.py calls it on ranks that torch.distributed
+ * started, over gloo.  share_gpu: the ranks sit on one device (test set-ups): idle pool memory goes back to the driver before the tail. */
+int ma_pipeline_run_rank(mahip_ctx_t *c, const ma_opt_t *opt, const char *fn, const char *outfmt, int stage, int flags, FILE *out, int share_gpu)
+{
+	const int world = mahip_comm_world(c), rank = mahip_comm_rank(c);
+	int r, own_records = 0;
+	sdict_t *d = sd_init();
+	size_t n_hits = 0;
+	ma_shard_stats_t st;
+	uint32_t pst[4];
+	FILE *lg;
+	lg = MA_LOG;
+	fprintf(lg, "[M::%s] ===> Step %d: %s <===\n", "main", (flags & 8) ? 0 : 1, (flags & 8) ? "removing contained reads" : "reading read mappings");
+	/* Ingest.  A plain file without -R: every rank loads and parses its own byte range, the ranks merge their name tables and route the records to the owners
+	 * of their query reads (ingest_sharded.c) -- 1/N of the text per rank.  Otherwise (gzip, stdin, -R, MA_INGEST_WHOLE=1): every rank parses the whole text
+	 * and keeps the hits of its read range, as in round 3.  The choice depends on the file and the options alone: every rank makes the same one. */
+	own_records = !(flags & 8) && !(getenv("MA_INGEST_WHOLE") && atoi(getenv("MA_INGEST_WHOLE"))) && ma_ingest_sharded_possible(fn);
+	if (own_records) {
+		ma_ingest_shard_info_t si;
+		memset(&si, 0, sizeof(si));
+		r = ma_hit_ingest_sharded(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), &si);
+		if (r == -1) { fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn); exit(1); }
+		if (r != 0) { fprintf(stderr, "[E::%s] rank %d: the ranges of the text could not be ingested\n", "ma_pipeline_run_sharded", rank); exit(1); }
+		if (ma_verbose >= 3)
+			fprintf(lg, "[M::%s::%s] read %ld hits; stored %ld hits and %d sequences (%ld bp)\n", "ma_hit_read", sys_timestamp(), (long)si.n_records, (long)si.n_hits_total, d->n_seq, (long)si.tot_len);
+	} else {
+	r = ma_hit_ingest_gpu_excl(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), (flags & 8) != 0, opt->max_hang, opt->int_frac);
+	if (r == -1) { fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn); exit(1); }
+	if (r != 0) { fprintf(stderr, "[E::%s] the text does not fit the device stage; MA_GPUS > 1 needs the device parser\n", "ma_pipeline_run_sharded"); exit(1); }
+	}
+	{ /* test hook: a rank that dies in the middle of a run (tests/test_gpu_sharded.py checks that nobody is left waiting) */
+		const char *e = getenv("MA_TEST_FAIL_RANK");
+		if (e && atoi(e) == rank) { fprintf(stderr, "[E::%s] rank %d: MA_TEST_FAIL_RANK\n", "ma_pipeline_run_sharded", rank); _exit(3); }
+	}
+	if (!own_records) GPU(mahip_hits_balance(c, world, 0)); /* every rank holds the whole input here: the same hit-balanced read ranges everywhere (own records: mahip_hits_route made them) */
+	ma_pipeline_head_sharded(c, opt, d->n_seq, !own_records, &st);
+	if (ma_shard_stats_reduce(c, &st) != 0) exit(1); /* the log lines below want the sums */
+	if (share_gpu) GPU(mahip_mem_trim(c, 0)); /* the ranks share ONE GPU here: what this rank's pool keeps idle (the text, the parser's columns) is memory rank 0's tail cannot have */
+	if (rank == 0) {
+		fprintf(lg, "[M::%s] ===> Step 2: 1-pass (crude) read selection <===\n", "main");
+		if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)st.n_rem1);
+		fprintf(lg, "[M::%s] ===> Step 3: 2-pass (fine) read selection <===\n", "main");
+		if (ma_verbose >= 3) {
+			fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)st.n_rem2);
+			fprintf(lg, "[M::%s::%s] %d sequences and %ld hits remain after containment removal\n", "ma_hit_contained", sys_timestamp(), st.n_seq_new, (long)st.n_hits);
+		}
+		fprintf(lg, "[M::%s] ===> Step 4: graph cleaning <===\n", "main");
+		fprintf(lg, "[M::%s] read %d arcs\n", "ma_sg_gen", st.n_arc);
+		if (st.tie_groups && !st.tie_repaired)
+			fprintf(stderr, "[W::%s] %llu groups of arcs with equal (u,len) keys were left in the stable order: the output may differ from the reference's inside those groups\n",
+			        "ma_pipeline_run_sharded", (unsigned long long)st.tie_groups);
+		fprintf(lg, "[M::%s] ===> Step 4.1: transitive reduction <===\n", "main");
+		fprintf(lg, "[M::%s] transitively reduced %d arcs\n", "asg_arc_del_trans", st.n_red);
+		if (st.n_red) {
+			fprintf(lg, "[M::%s] removed %d multi-arcs\n", "asg_arc_del_multi", st.n_multi);
+			fprintf(lg, "[M::%s] removed %d asymmetric arcs\n", "asg_arc_del_asymm", st.n_asymm);
+		}
+		pst[0] = 1; pst[1] = 1; pst[2] = st.n_red; pst[3] = 1;
+		ma_pipeline_tail(c, opt, d, outfmt, stage, pst, out);
+	}
+	GPU(mahip_comm_barrier(c));
+	sd_destroy(d);
+	return 0;
+}
+
 /* ---- the command line on N GPUs: MA_GPUS=N miniasm in.paf > out.gfa ------------------------------------------------------
  * The parent is rank 0; it forks N-1 children BEFORE any HIP call and hands them the RCCL id through pipes.  Every rank loads
  * and parses the whole text on its own GPU (its own PCIe link; the device parser makes this cheaper than routing records:
@@ -267,20 +334,15 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 {
 	const char *kind = getenv("MA_COMM");
 	const int use_shm = kind && strcmp(kind, "shm") == 0;
-	int rank = 0, r, own_records = 0, (*pipes)[2] = (int(*)[2])calloc((size_t)world, sizeof(int[2]));
+	int rank = 0, r, (*pipes)[2] = (int(*)[2])calloc((size_t)world, sizeof(int[2]));
 	pid_t *kids = (pid_t*)calloc((size_t)world, sizeof(pid_t));
 	char id[128], shm_name[64];
 	mahip_ctx_t *c;
-	sdict_t *d = sd_init();
-	size_t n_hits = 0;
-	ma_shard_stats_t st;
-	uint32_t pst[4];
-	FILE *lg;
 	/* The sharded head is the full graph path (both read selections, containment, graph, reduction).  Any other request -- a hit dump, an
 	 * early -S stage, -1 / -2 -- is decided BEFORE the ranks exist and runs on one GPU: the output is the same, only not spread out. */
 	if ((strcmp(outfmt, "ug") != 0 && strcmp(outfmt, "sg") != 0) || (flags & 3) || stage < 6) {
 		fprintf(stderr, "[W::%s] MA_GPUS=%d serves -p ug / -p sg with both read selections and -S >= 6; this request runs on one GPU\n", __func__, world);
-		free(pipes); free(kids); sd_destroy(d);
+		free(pipes); free(kids);
 		return ma_pipeline_run(opt, fn, outfmt, stage, flags, out);
 	}
 	if (world > 32) { fprintf(stderr, "[E::%s] at most 32 ranks\n", __func__); exit(1); }
@@ -337,58 +399,8 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 	c = ma_gpu();
 	if (use_shm) GPU(mahip_comm_init_shm(c, shm_name, rank, world));
 	else GPU(mahip_comm_init(c, id, rank, world));
-	lg = MA_LOG;
-	fprintf(lg, "[M::%s] ===> Step %d: %s <===\n", "main", (flags & 8) ? 0 : 1, (flags & 8) ? "removing contained reads" : "reading read mappings");
-	/* Ingest.  A plain file without -R: every rank loads and parses its own byte range, the ranks merge their name tables and route the records to the owners
-	 * of their query reads (ingest_sharded.c) -- 1/N of the text per rank.  Otherwise (gzip, stdin, -R, MA_INGEST_WHOLE=1): every rank parses the whole text
-	 * and keeps the hits of its read range, as in round 3.  The choice depends on the file and the options alone: every rank makes the same one. */
-	own_records = !(flags & 8) && !(getenv("MA_INGEST_WHOLE") && atoi(getenv("MA_INGEST_WHOLE"))) && ma_ingest_sharded_possible(fn);
-	if (own_records) {
-		ma_ingest_shard_info_t si;
-		memset(&si, 0, sizeof(si));
-		r = ma_hit_ingest_sharded(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), &si);
-		if (r == -1) { fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn); exit(1); }
-		if (r != 0) { fprintf(stderr, "[E::%s] rank %d: the ranges of the text could not be ingested\n", __func__, rank); exit(1); }
-		if (ma_verbose >= 3)
-			fprintf(lg, "[M::%s::%s] read %ld hits; stored %ld hits and %d sequences (%ld bp)\n", "ma_hit_read", sys_timestamp(), (long)si.n_records, (long)si.n_hits_total, d->n_seq, (long)si.tot_len);
-	} else {
-	r = ma_hit_ingest_gpu_excl(c, fn, opt->min_span, opt->min_match, d, &n_hits, !(flags & 4), (flags & 8) != 0, opt->max_hang, opt->int_frac);
-	if (r == -1) { fprintf(stderr, "[E::%s] could not open PAF file %s\n", "ma_hit_read", fn); exit(1); }
-	if (r != 0) { fprintf(stderr, "[E::%s] the text does not fit the device stage; MA_GPUS > 1 needs the device parser\n", __func__); exit(1); }
-	}
-	{ /* test hook: a rank that dies in the middle of a run (tests/test_gpu_sharded.py checks that nobody is left waiting) */
-		const char *e = getenv("MA_TEST_FAIL_RANK");
-		if (e && atoi(e) == rank) { fprintf(stderr, "[E::%s] rank %d: MA_TEST_FAIL_RANK\n", __func__, rank); _exit(3); }
-	}
-	if (!own_records) GPU(mahip_hits_balance(c, world, 0)); /* every rank holds the whole input here: the same hit-balanced read ranges everywhere (own records: mahip_hits_route made them) */
-	ma_pipeline_head_sharded(c, opt, d->n_seq, !own_records, &st);
-	if (ma_shard_stats_reduce(c, &st) != 0) exit(1); /* the log lines below want the sums */
-	if (use_shm) GPU(mahip_mem_trim(c, 0)); /* the ranks share ONE GPU here: what this rank's pool keeps idle (the text, the parser's columns) is memory rank 0's tail cannot have */
-	if (rank == 0) {
-		fprintf(lg, "[M::%s] ===> Step 2: 1-pass (crude) read selection <===\n", "main");
-		if (ma_verbose >= 3) fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)st.n_rem1);
-		fprintf(lg, "[M::%s] ===> Step 3: 2-pass (fine) read selection <===\n", "main");
-		if (ma_verbose >= 3) {
-			fprintf(lg, "[M::%s::%s] %ld query sequences remain after sub\n", "ma_hit_sub", sys_timestamp(), (long)st.n_rem2);
-			fprintf(lg, "[M::%s::%s] %d sequences and %ld hits remain after containment removal\n", "ma_hit_contained", sys_timestamp(), st.n_seq_new, (long)st.n_hits);
-		}
-		fprintf(lg, "[M::%s] ===> Step 4: graph cleaning <===\n", "main");
-		fprintf(lg, "[M::%s] read %d arcs\n", "ma_sg_gen", st.n_arc);
-		if (st.tie_groups && !st.tie_repaired)
-			fprintf(stderr, "[W::%s] %llu groups of arcs with equal (u,len) keys were left in the stable order: the output may differ from the reference's inside those groups\n",
-			        __func__, (unsigned long long)st.tie_groups);
-		fprintf(lg, "[M::%s] ===> Step 4.1: transitive reduction <===\n", "main");
-		fprintf(lg, "[M::%s] transitively reduced %d arcs\n", "asg_arc_del_trans", st.n_red);
-		if (st.n_red) {
-			fprintf(lg, "[M::%s] removed %d multi-arcs\n", "asg_arc_del_multi", st.n_multi);
-			fprintf(lg, "[M::%s] removed %d asymmetric arcs\n", "asg_arc_del_asymm", st.n_asymm);
-		}
-		pst[0] = 1; pst[1] = 1; pst[2] = st.n_red; pst[3] = 1;
-		ma_pipeline_tail(c, opt, d, outfmt, stage, pst, out);
-	}
-	GPU(mahip_comm_barrier(c));
+	ma_pipeline_run_rank(c, opt, fn, outfmt, stage, flags, out, use_shm);
 	mahip_comm_destroy(c);
-	sd_destroy(d);
 	if (rank != 0) exit(0); /* orderly: the context's atexit teardown runs */
 	g_kids_done = 1; /* the work is done: from here a rank's exit status is only reported */
 	for (r = 1; r < world; ++r) {

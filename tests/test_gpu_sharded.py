@@ -1,10 +1,9 @@
-"""GPU: the sharded multi-GPU mode on real hardware.  One box has one GPU, so N virtual ranks run as threads of one
-process, each with its own mahip context on device 0, exchanging through an in-process stand-in for the RCCL
-collectives (same call pattern as miniasm_amd/sharded.Comm).  Everything else is the production path: GpuBackend,
-run_sharded, mahip_set_shard, the split contained / sg passes, arc row import/export, ranged transitive reduction."""
+"""GPU: the sharded multi-GPU mode on real hardware.  One box has one GPU, and RCCL refuses two ranks on one device, so N ranks run as N processes
+that share the GPU and exchange through the shared-memory double of the collectives (MA_COMM=shm).  Everything else is the production path: host/sharded.c,
+host/ingest_sharded.c, mahip_set_shard, the split contained / sg passes, arc row import/export, ranged transitive reduction.  (Until round 3 this module
+also ran N virtual ranks as threads through a Python copy of the exchange sequence; that copy is gone -- tests/test_dist_gloo.py runs the C code over gloo.)"""
 import ctypes as C
 import os
-import threading
 
 import numpy as np
 import pytest
@@ -13,112 +12,8 @@ import torch
 import miniasm_amd as ma
 import refapi as R
 import stages as ST
-from miniasm_amd.sharded import GpuBackend, run_sharded, shard_range
 
 pytestmark = pytest.mark.gpu
-
-
-class _Shared:
-    def __init__(self, world):
-        self.world, self.slots, self.barrier = world, [None] * world, threading.Barrier(world)
-
-
-class ThreadComm:
-    def __init__(self, shared, rank):
-        self.sh, self.rank, self.world = shared, rank, shared.world
-
-    def _exchange(self, obj):
-        torch.cuda.synchronize()  # the stand-in hands tensors across threads/streams: make them complete first
-        self.sh.slots[self.rank] = obj
-        self.sh.barrier.wait()
-        res = list(self.sh.slots)
-        self.sh.barrier.wait()
-        return res
-
-    def all_gather_bytes(self, local):
-        return torch.cat(self._exchange(local)) if self.world > 1 else local
-
-    def all_reduce_max_bytes(self, t):
-        if self.world > 1:
-            parts = self._exchange(t.clone())
-            t.copy_(torch.stack(parts).max(0).values)
-        return t
-
-    def all_gather_int(self, x, device):
-        return [int(v) for v in self._exchange(int(x))]
-
-    def sum_int(self, x, device):
-        return sum(self.all_gather_int(x, device))
-
-    def sum_ints(self, xs, device):
-        parts = self._exchange([int(x) for x in xs])
-        return [sum(p[k] for p in parts) for k in range(len(xs))]
-
-
-def _run_virtual_ranks(world, hits, n_seq, opt, ing):
-    shared = _Shared(world)
-    out, errs = {}, []
-
-    def work(rank):
-        try:
-            be = GpuBackend.create(0, n_seq)
-            ctx = be.ctx
-            _, q0, q1 = shard_range(n_seq, world, rank)
-            q = (hits["qns"] >> 32).astype(np.int64)
-            mine = hits[(q >= q0) & (q < q1)]
-            ctx.hits_upload(mine, n_seq)
-            stats = run_sharded(be, ThreadComm(shared, rank), opt, n_seq)
-            if rank == 0:
-                out["stats"] = stats
-                out["graph"] = ctx.asg_download()
-                L = ma.lib()
-                L.ma_pipeline_tail_mem.restype = C.c_int
-                L.ma_pipeline_tail_mem.argtypes = [C.c_void_p, C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_char_p, C.c_int, C.POINTER(C.c_uint32 * 4),
-                                                   C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
-                st = (C.c_uint32 * 4)(1, 1, stats["n_red"], 1)
-                buf, ln = C.c_void_p(0), C.c_size_t(0)
-                assert L.ma_pipeline_tail_mem(ctx.h, C.byref(opt), ing.d, b"ug", 100, C.byref(st), C.byref(buf), C.byref(ln)) == 0
-                out["gfa"] = C.string_at(buf, ln.value)
-                L.free_buf(buf)
-            shared.barrier.wait()
-            ctx.close()
-        except Exception as e:  # pragma: no cover
-            errs.append(e)
-            shared.barrier.abort()
-
-    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    if errs:
-        raise errs[0]
-    return out
-
-
-@pytest.mark.parametrize("world", [1, 2, 4])
-@pytest.mark.parametrize("case", ["lognormal", "noisy", "fixed"])
-def test_virtual_ranks_match_single_gpu_and_oracle(world, case, tmpdir_s):
-    extra = {"lognormal": [], "noisy": ["-L", "uniform", "-d", "0.35", "-x", "0.03"], "fixed": ["-L", "fixed"]}[case]
-    paf = R.pafgen(os.path.join(tmpdir_s, "sh_%s.paf" % case), 3001, 80000, 81, extra)
-    opt = ma.default_opt()
-    ma.lib().ma_set_log_path(b"/dev/null")
-    ing = ma.Ingest(paf, opt)
-    got = _run_virtual_ranks(world, ing.hits, ing.n_seq, opt, ing)
-    one = ST.orc_stages(ing.hits, ing.n_seq, opt)
-    s = got["stats"]
-    assert (s["n_rem1"], s["n_rem2"], s["n_seq_new"], s["n_hits"]) == (one["n_rem1"], one["n_rem2"], one["n_seq_new"], len(one["cont"]))
-    assert (s["n_arc"], s["n_red"], s["n_multi"], s["n_asymm"]) == (len(one["sg_arcs"]), one["tr_cnt"]["n_red"], one["tr_cnt"]["n_multi"], one["tr_cnt"]["n_asymm"])
-    arcs, seq, idx = got["graph"]
-    assert arcs.tobytes() == one["tr_arcs"].tobytes(), "reduced graph differs from the oracle"
-    assert idx.tobytes() == one["tr_idx"].tobytes()
-    # GFA from the sharded run == GFA from the ordinary single-GPU resident pipeline
-    ctx = ma.Ctx(0)
-    ctx.hits_upload(ing.hits, ing.n_seq)
-    assert got["gfa"] == ma.run_resident(ctx, opt, ing, "ug")
-    ctx.close()
-    ma.lib().ma_set_log_path(b"")
-    ing.close()
 
 
 # ---- the product path: orchestration in C (host/sharded.c), collectives from C (csrc/comm.hip) ----
