@@ -117,9 +117,11 @@ def pmc_traffic(names, kernel):
         parts = [v for k, v in names.items() if k.startswith(scope[0]) and (scope[1] is None or k.endswith(", true>") == scope[1])]
         return round(sum(per_launch(v) for v in parts)) if parts else None
     base = kernel.split("<")[0]
-    hits = [v for k, v in names.items() if k.split("<")[0] in (base, {"k_hit_keys": "k_hit_keys_tiled"}.get(base, base))]
+    hits = [v for k, v in names.items() if k.split("<")[0] in (base, {"k_hit_keys": "k_hit_keys_tiled", "k_arc_rm": "k_arc_rm_chain"}.get(base, base))]
     if not hits:
         return None
+    if base in ("k_arc_group_sort", "k_asg_trans"):  # a timed scope = one launch of each size-class instantiation: their bytes add up
+        return round(sum(per_launch(v) for v in hits))
     return round(sum(per_launch(v) * v["launches"] for v in hits) / max(sum(v["launches"] for v in hits), 1))
 
 
@@ -624,6 +626,16 @@ def main():
                     res["arcs"] = n_arc
                     res["kernels"] = [{kk: k[kk] for kk in ("name", "launches_per_step", "avg_ms", "share", "alg_GBs", "design_GBs")} for k in kt[:16]]
                     res["reduce_group"] = reduce_group(kt, n_arc or 0, n_inner)
+                    pmc_g, pmc_g_src = pmc_profile("gh" if name == "graph_heavy" else name)  # counter traffic of this input's kernels, if a profile of it is committed
+                    if pmc_g and res["reduce_group"]:
+                        tr = 0.0
+                        for k in res["reduce_group"]["kernels"]:
+                            t = pmc_traffic(pmc_g, k["name"])
+                            k["counter_GBs"] = round(t / (k["avg_ms"] * 1e-3) / 1e9, 1) if t and k["avg_ms"] > 0 else None
+                            tr += (t or 0) * k["launches_per_step"]
+                        res["reduce_group"]["traffic"] = round(tr)
+                        res["reduce_group"]["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py on this input; not measured in this run)" % pmc_g_src
+                        res["reduce_group"]["frac_counter"] = round(tr / (res["reduce_group"]["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 if with_ref:
                     ref = run_reference(p, os.path.join(args.workdir, "leg_%s.ref.gfa" % name))
                     if ref:

@@ -341,6 +341,34 @@ __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q,
 	int live_any = 0, ev_any = 0;
 	uint2 rq = make_uint2(0, 0);
 	if (FUSE) rq = pre ? pre->rq : f.cut_sub[q];
+	if (GATHER && !pre) { // (the two larger size classes in gather mode) the records through the sorted keys, the columns written on the way.  Round 4: ALL keys of the read
+		// first, then ALL records, then the stores -- four slots a lane at a time.  Round 3 went key -> record -> stores slot by slot: with stores between
+		// them the compiler keeps the loads in program order, and a read of 256 hits was eight dependent trips to memory instead of two.
+		constexpr int HB = 4; // slots per lane per batch: 4 x 9 registers
+#pragma unroll
+		for (int h0 = 0; h0 < ITEMS / 2; h0 += HB) {
+			uint32_t jj[HB];
+			uint4 aa[HB], bb[HB];
+#pragma unroll
+			for (int k = 0; k < HB; ++k) { const uint32_t i = beg + (h0 + k) * 64 + lane; jj[k] = (h0 + k < ITEMS / 2 && i < end) ? gather_pos(*g, i) : 0u; }
+#pragma unroll
+			for (int k = 0; k < HB; ++k) { const uint4 *p = (const uint4*)(g->aos + jj[k]); aa[k] = p[0]; bb[k] = p[1]; } // (lanes without a slot fetch record 0: no branch between the loads)
+#pragma unroll
+			for (int k = 0; k < HB; ++k) {
+				const int h = h0 + k;
+				const uint32_t i = beg + h * 64 + lane;
+				if (h < ITEMS / 2) {
+					x[2 * h] = x[2 * h + 1] = EV_PAD;
+					if (i < end) {
+						uint32_t es, ee;
+						gather_store(c, *g, i, jj[k], aa[k], bb[k]);
+						live_any = 1;
+						if (mc_sub_ok(q, aa[k].x, aa[k].z, aa[k].w, (int32_t)(bb[k].z & 0x7fffffffu), (int32_t)(bb[k].w & ~DEAD), min_iden, end_clip, &es, &ee)) x[2 * h] = es, x[2 * h + 1] = ee, ev_any = 1;
+					}
+				}
+			}
+		}
+	} else
 #pragma unroll
 	for (int h = 0; h < ITEMS / 2; ++h) {
 		uint32_t i = beg + h * 64 + lane;
@@ -431,7 +459,13 @@ __device__ __forceinline__ unsigned sub_block_id()
 #else
 #define SUB_WPE_ATTR(F, C, G)
 #endif
-constexpr unsigned sub_wpe(bool fuse, int cls, bool gather) { return gather && cls == 0 ? 6 : fuse && cls == 1 ? 5 : 0; }
+#ifndef SUB_WPE_G0
+#define SUB_WPE_G0 6
+#endif
+#ifndef SUB_WPE_F0
+#define SUB_WPE_F0 0
+#endif
+constexpr unsigned sub_wpe(bool fuse, int cls, bool gather) { return gather && cls == 0 ? SUB_WPE_G0 : fuse && cls == 1 ? 5 : fuse && cls == 0 ? SUB_WPE_F0 : 0; }
 template <bool FUSE, int CLS, bool GATHER = false>
 __global__ __launch_bounds__(256) SUB_WPE_ATTR(FUSE, CLS, GATHER) void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
                                                   int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
