@@ -63,7 +63,9 @@ struct StdoutToStderr {
 
 // ---- shared-memory test double ----
 struct ShmHeader { volatile unsigned arrive, sense; unsigned world; size_t slot; volatile unsigned turn_lock; };
-#define SHM_SLOT_BYTES ((size_t)1 << 30) // per rank, sparse: pages exist only where a collective wrote
+// per rank, sparse: pages exist only where a collective wrote.  MA_SHM_SLOT_LOG2 (tests): a smaller slot, so that small inputs take the chunked rounds of the personalised exchange
+static size_t shm_slot_bytes() { static size_t v = 0; if (!v) { const char *e = getenv("MA_SHM_SLOT_LOG2"); int l2 = e ? atoi(e) : 30; if (l2 < 12) l2 = 12; if (l2 > 34) l2 = 34; v = (size_t)1 << l2; } return v; }
+#define SHM_SLOT_BYTES shm_slot_bytes()
 
 struct Comm {
 	int kind = 0, rank = 0, world = 1; // kind 1 = RCCL, 2 = shm, 3 = the caller's own transport (host buffers: mahip_comm_init_ext)
@@ -332,21 +334,33 @@ extern "C" int mahip_comm_all_to_all_v(mahip_ctx_t *c, const void *d_send, void 
 		EXTCHK(m->ext.all_to_all_v(m->ext.user, m->hbuf[0].data(), m->hbuf[1].data(), bytes), "all_to_all_v");
 		return ext_stage_in(c, m, 1, d_recv, in);
 	}
-	if (mine > SHM_SLOT_BYTES) { mahip_set_error("shm all-to-all: %zu bytes from one rank exceed the slot", mine); return -1; }
-	if (mine) HIPCHK(hipMemcpyAsync(m->slots + (size_t)me * SHM_SLOT_BYTES, d_send, mine, hipMemcpyDeviceToHost, c->st));
+	// through the segment, destination by destination, a slot's worth of every rank's piece at a time (a rank's pieces for ALL destinations need not fit its slot:
+	// BASELINE configs[3] on two ranks sends 3.2 GB from each)
 	HIPCHK(hipStreamSynchronize(c->st));
 	shm_turn_give(m);
-	shm_barrier(m);
-	for (int r = 0; r < W; ++r) { // the piece rank r holds for me starts behind its pieces for the ranks before me
-		size_t off = 0;
-		for (int j = 0; j < me; ++j) off += bytes[(size_t)r * W + j];
-		const size_t rb = bytes[(size_t)r * W + me];
-		if (rb) HIPCHK(hipMemcpyAsync((char*)d_recv + roff, m->slots + (size_t)r * SHM_SLOT_BYTES + off, rb, hipMemcpyHostToDevice, c->st));
-		roff += rb;
+	for (int dst = 0; dst < W; ++dst) {
+		size_t longest = 0, my_off = 0;
+		for (int r = 0; r < W; ++r) if (bytes[(size_t)r * W + dst] > longest) longest = bytes[(size_t)r * W + dst];
+		for (int j = 0; j < dst; ++j) my_off += bytes[(size_t)me * W + j]; // where my piece for `dst` starts in d_send
+		const size_t my_len = bytes[(size_t)me * W + dst];
+		for (size_t c0 = 0; c0 < longest; c0 += SHM_SLOT_BYTES) { // every rank runs the same number of rounds
+			const size_t part = c0 < my_len ? (my_len - c0 < SHM_SLOT_BYTES ? my_len - c0 : SHM_SLOT_BYTES) : 0;
+			if (part) { HIPCHK(hipMemcpyAsync(m->slots + (size_t)me * SHM_SLOT_BYTES, (const char*)d_send + my_off + c0, part, hipMemcpyDeviceToHost, c->st)); HIPCHK(hipStreamSynchronize(c->st)); }
+			shm_barrier(m);
+			if (me == dst) {
+				size_t ro = 0;
+				for (int r = 0; r < W; ++r) {
+					const size_t len = bytes[(size_t)r * W + me], p2 = c0 < len ? (len - c0 < SHM_SLOT_BYTES ? len - c0 : SHM_SLOT_BYTES) : 0;
+					if (p2) HIPCHK(hipMemcpyAsync((char*)d_recv + ro + c0, m->slots + (size_t)r * SHM_SLOT_BYTES, p2, hipMemcpyHostToDevice, c->st));
+					ro += len;
+				}
+				HIPCHK(hipStreamSynchronize(c->st));
+			}
+			shm_barrier(m);
+		}
 	}
-	HIPCHK(hipStreamSynchronize(c->st));
-	shm_barrier(m);
 	shm_turn_take(m);
+	(void)roff; (void)mine;
 	return 0;
 }
 

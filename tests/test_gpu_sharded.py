@@ -163,6 +163,9 @@ def test_every_rank_ingests_its_own_byte_range(world, tmpdir_s):
     for sg_args in (["-p", "sg"], ["-p", "sg", "-S6"]):
         r2 = subprocess.run([ma.CLI_PATH] + sg_args + [paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
         assert r2.returncode == 0 and r2.stdout == R.run_cli(R.REF_BIN, sg_args, paf)[0], sg_args
+    if world == 2:  # the shared-memory double moves a rank's pieces a slot's worth at a time (BASELINE configs[3] on two ranks: 3.2 GB from each through 1 GB slots): here with 512 KB slots
+        small = subprocess.run([ma.CLI_PATH, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(env, MA_SHM_SLOT_LOG2="19"), timeout=900)
+        assert small.returncode == 0 and small.stdout == ref, small.stderr.decode()[-500:]
     whole = subprocess.run([ma.CLI_PATH, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(env, MA_INGEST_WHOLE="1"), timeout=900)
     assert whole.returncode == 0 and whole.stdout == ref and b"bytes [" not in whole.stderr
     with open(paf, "rb") as fi, gzip.open(paf + ".gz", "wb") as fo:

@@ -37,6 +37,8 @@ def worker(a):
         fcntl.flock(lk, fcntl.LOCK_EX)
         W = bench.Workload(ma, L, ctx, a.paf, opt, a.world, a.rank)
         L.mahip_paf_release(ctx.h)
+        L.mahip_mem_trim.argtypes = [C.c_void_p, C.c_void_p]
+        L.mahip_mem_trim(ctx.h, None)  # the ranks share ONE GPU here: the text and the parser's columns (20 GB at cfg4) must not sit idle in N pools
         L.mahip_sync(ctx.h)
         fcntl.flock(lk, fcntl.LOCK_UN)
     L.ma_pipeline_head_sharded.restype = C.c_int
@@ -81,6 +83,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--workdir", default=os.environ.get("MA_BENCH_DIR", "/tmp/ma_bench"))
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "shard_projection.json"))
+    ap.add_argument("--per-n-timeout", type=float, default=240.0, help="seconds one N may take before its ranks are killed")
     ap.add_argument("--worker", action="store_true")
     ap.add_argument("--paf"); ap.add_argument("--rank", type=int); ap.add_argument("--world", type=int); ap.add_argument("--name")
     a = ap.parse_args()
@@ -102,7 +105,15 @@ def main():
             outs.append(o)
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", "--paf", paf, "--rank", str(r), "--world", str(n),
                                            "--name", "ma_proj_%d_%d" % (os.getpid(), n), "--steps", str(a.steps), "--out", o], env=env))
-        rc = [p.wait() for p in procs]
+        rc = []
+        t_end = time.time() + a.per_n_timeout
+        for p in procs:  # a run that does not come back (round 4, visit D: N = 8 sat until the visit's time limit) is ended here, not by the caller's budget
+            try:
+                rc.append(p.wait(timeout=max(1.0, t_end - time.time())))
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                rc.append(-9)
         if any(rc):
             print("N=%d: a rank failed (%r)" % (n, rc), file=sys.stderr)
             continue
