@@ -460,10 +460,10 @@ __device__ __forceinline__ unsigned sub_block_id()
 #define SUB_WPE_ATTR(F, C, G)
 #endif
 #ifndef SUB_WPE_G0
-#define SUB_WPE_G0 6
+#define SUB_WPE_G0 7 // round 4, visit F (one box, base 6.60 / 6.70 ms): 5 waves 6.86, 6 waves (round 3) 6.6 - 6.7, 7 waves 6.42 ms although 18 registers spill
 #endif
 #ifndef SUB_WPE_F0
-#define SUB_WPE_F0 0
+#define SUB_WPE_F0 6 // the fused first tier: the compiler's own choice (82 registers, 6 waves by count but no target) 3.26 ms, target 6: 3.11, target 8 (29 spills): 3.15
 #endif
 constexpr unsigned sub_wpe(bool fuse, int cls, bool gather) { return gather && cls == 0 ? SUB_WPE_G0 : fuse && cls == 1 ? 5 : fuse && cls == 0 ? SUB_WPE_F0 : 0; }
 template <bool FUSE, int CLS, bool GATHER = false>
