@@ -626,7 +626,8 @@ def main():
                     res["arcs"] = n_arc
                     res["kernels"] = [{kk: k[kk] for kk in ("name", "launches_per_step", "avg_ms", "share", "alg_GBs", "design_GBs")} for k in kt[:16]]
                     res["reduce_group"] = reduce_group(kt, n_arc or 0, n_inner)
-                    pmc_g, pmc_g_src = pmc_profile("gh" if name == "graph_heavy" else name)  # counter traffic of this input's kernels, if a profile of it is committed
+                    # counter traffic of this input's kernels, if a profile of THIS input is committed (the profile is of the default size: 100 M overlaps)
+                    pmc_g, pmc_g_src = pmc_profile("gh") if (name == "graph_heavy" and lines == 100000000 and reads == 2000000) else (None, None)
                     if pmc_g and res["reduce_group"]:
                         tr = 0.0
                         for k in res["reduce_group"]["kernels"]:
