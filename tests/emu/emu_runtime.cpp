@@ -496,6 +496,8 @@ hipError_t hipMemset(void *dst, int v, size_t bytes) { if (bytes) memset(dst, v,
 hipError_t hipMemsetAsync(void *dst, int v, size_t bytes, hipStream_t st) { (void)st; if (bytes) memset(dst, v, bytes); return hipSuccess; }
 hipError_t hipStreamCreate(hipStream_t *st) { *st = new emu_stream{0}; return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned flags) { *st = new emu_stream{(int)flags}; return hipSuccess; }
+hipError_t hipStreamCreateWithPriority(hipStream_t *st, unsigned flags, int) { return hipStreamCreateWithFlags(st, flags); }
+hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = -1; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t st) { delete st; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t st)
 {
