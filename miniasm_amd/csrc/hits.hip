@@ -1414,8 +1414,8 @@ struct SubFork {
 		if (!c->sub_side[0] && !c->sub_fork_failed) { // streams and events are made once per context; if any of them cannot be had, all three size classes run on the context's stream
 			bool ok = true;
 			// the two larger size classes hold few, heavy reads and finish LAST when all three launches share the chip evenly (round 4, visit E: first tier 4.2 ms, the others 5.3;
-			// fused pass 2.1 against 3.1): their streams get the device's highest priority, so that their blocks are placed first and the first tier fills what is left (MA_SUB_PRIO=0: plain streams)
-			static const bool prio = !(getenv("MA_SUB_PRIO") && atoi(getenv("MA_SUB_PRIO")) == 0);
+			// fused pass 2.1 against 3.1): MA_SUB_PRIO=1 gives their streams the device's highest priority -- measured: no effect; the three launches pack the chip as it is (the first tier alone needs about 3.9 ms of it, the other two about 1.5)
+			static const bool prio = getenv("MA_SUB_PRIO") && atoi(getenv("MA_SUB_PRIO")) != 0; // (visit G: 5.47 / 5.47 ms without, 5.43 / 5.88 with: nothing; off)
 			int lo = 0, hi = 0;
 			if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
 			for (int k = 0; k < 2 && ok; ++k) ok = (prio && hi != lo ? hipStreamCreateWithPriority(&c->sub_side[k], hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&c->sub_side[k], hipStreamNonBlocking)) == hipSuccess;
