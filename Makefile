@@ -16,7 +16,7 @@ B         = build/obj
 HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function -Iinclude -I$(CSRC) $(EXTRA)
 CFLAGS    = -O2 -g -Wall -fPIC -Iinclude -I$(HOST) -I$(CSRC)
 
-HIP_SRC   = scan radix hits graph clean ug useq comm paf mahip_api xfer
+HIP_SRC   = scan radix hits graph clean ug useq comm paf mahip_api xfer diag
 HOST_SRC  = timers name_dict paf_reader ingest_mt ingest_gpu ingest_sharded hits_host graph_host refsort unitig_gfa pipeline sharded
 HIP_OBJ   = $(addprefix $(B)/,$(addsuffix .hip.o,$(HIP_SRC)))
 HOST_OBJ  = $(addprefix $(B)/,$(addsuffix .o,$(HOST_SRC)))

@@ -309,6 +309,15 @@ size_t mahip_mem_bytes(mahip_ctx_t *c);
  * (MA_COMM=shm ranks) are what this call is for: the sharded head calls it at its end.  released (optional) = bytes returned. */
 size_t mahip_mem_pool_bytes(mahip_ctx_t *c);
 int mahip_mem_trim(mahip_ctx_t *c, size_t *released);
+
+/* Measurement hooks (csrc/diag.hip; tools/pmc_calibrate.py) -- NOT part of the pipeline: plain access patterns with a known byte count (a 16-byte
+ * stream, 8 bytes of every 32-byte record, a random 32-byte fetch, the run-wise scatter of a radix pass, ...), timed with HIP events on the context's
+ * stream.  They give the rate this GPU sustains for the patterns the hot path is made of, and a known byte count per pattern to calibrate rocprofv3's
+ * FETCH_SIZE / WRITE_SIZE against.  mahip_diag_run: `reps` launches of `pattern` over `bytes` of data; *best_ms = the fastest, *moved = bytes read +
+ * written by construction.  0 on success. */
+int mahip_diag_patterns(void);
+const char *mahip_diag_name(int pattern);
+int mahip_diag_run(mahip_ctx_t *c, int pattern, size_t bytes, int reps, double *best_ms, double *moved);
 /* device pointers for multi-GPU exchanges done outside (RCCL via torch.distributed): which = MAHIP_PTR_* */
 #define MAHIP_PTR_SUB0    0
 #define MAHIP_PTR_SUB1    1

@@ -61,19 +61,23 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint64_t *__res
 }
 
 // Element order inside a tile is (wave, item, lane): element index = tile + wave*64*ITEMS + item*64 + lane.
-template <bool HAS_VAL>
+// NBITS > 0: the digit's width at compile time (the hit sort's three digits of 7 bits at BASELINE configs[4]): the ballot loop unrolls, and the block keeps
+// 2^NBITS bins instead of RS_BINS (35 KB of LDS against 42: four blocks per CU).  NBITS = 0: any width up to RS_MAXBITS.
+template <bool HAS_VAL, int NBITS>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                                uint64_t *__restrict__ kout, uint32_t *__restrict__ vout,
-                                                               const uint32_t *__restrict__ gofs, size_t n, unsigned nb, int shift, unsigned mask, int nbits)
+                                                               const uint32_t *__restrict__ gofs, size_t n, unsigned nb, int shift, unsigned mask, int nbits_rt)
 {
-	__shared__ uint32_t s_cnt[RS_WAVES][RS_BINS]; // per-wave digit counts, then the wave's first local slot per digit
-	__shared__ uint32_t s_gb[RS_BINS];            // global offset of the digit's run minus its first local slot
+	constexpr int NB = NBITS ? (1 << NBITS) : RS_BINS;
+	const int nbits = nbits_rt;
+	__shared__ uint32_t s_cnt[RS_WAVES][NB]; // per-wave digit counts, then the wave's first local slot per digit
+	__shared__ uint32_t s_gb[NB];            // global offset of the digit's run minus its first local slot
 	__shared__ uint32_t s_scan[RS_WAVES];
 	__shared__ uint64_t s_key[RS_TILE];
 	__shared__ uint32_t s_val[HAS_VAL ? RS_TILE : 1];
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint64_t lt = wv_lt(lane);
-	for (unsigned d = threadIdx.x; d < RS_WAVES * RS_BINS; d += RS_THREADS) (&s_cnt[0][0])[d] = 0;
+	for (unsigned d = threadIdx.x; d < RS_WAVES * NB; d += RS_THREADS) (&s_cnt[0][0])[d] = 0;
 	__syncthreads();
 	const unsigned tid_ = rs_tile_id();
 	const size_t tile = (size_t)tid_ * RS_TILE, wbase = tile + (size_t)wave * 64 * RS_ITEMS;
@@ -92,10 +96,21 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
 		int valid = i < n;
 		unsigned d = (unsigned)(k[it] >> shift) & mask;
 		uint64_t peers = wv_ballot(valid);
-		for (int b = 0; b < nbits; ++b) {
-			uint64_t bal = wv_ballot((d >> b) & 1);
-			peers &= ((d >> b) & 1) ? bal : ~bal;
-		}
+		uint32_t p_lo = (uint32_t)peers, p_hi = (uint32_t)(peers >> 32); // the lanes with my digit, in halves: a step is one three-input bit operation per half
+		auto split = [&](int b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+			const uint32_t same = (uint32_t)__builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u); // all ones where my bit is set (v_bfe_i32)
+#else
+			const uint32_t same = 0u - ((d >> b) & 1u);
+#endif
+			const uint64_t bal = wv_ballot(same != 0u);
+			p_lo &= ~((uint32_t)bal ^ same); p_hi &= ~((uint32_t)(bal >> 32) ^ same); // lanes whose bit b equals mine
+		};
+		if constexpr (NBITS > 0) {
+#pragma unroll
+			for (int b = 0; b < NBITS; ++b) split(b);
+		} else for (int b = 0; b < nbits; ++b) split(b);
+		peers = (uint64_t)p_hi << 32 | p_lo;
 		uint32_t prev = s_cnt[wave][d];
 		wv_sync();
 		if (valid && (peers & lt) == 0) s_cnt[wave][d] = prev + (uint32_t)__popcll(peers);
@@ -103,21 +118,24 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
 		r[it] = prev + (uint32_t)__popcll(peers & lt);
 	}
 	__syncthreads();
-	{ // thread t owns RS_DPT consecutive digits: waves' counts -> exclusive over waves; tile counts -> exclusive over digits
-		constexpr int RS_DPT = RS_BINS / RS_THREADS;
+	{ // thread t owns RS_DPT consecutive digits (the first NB threads one each when there are fewer bins than threads): waves' counts -> exclusive over
+		// waves; tile counts -> exclusive over digits
+		constexpr int RS_DPT = NB >= RS_THREADS ? NB / RS_THREADS : 1;
 		const unsigned d0 = RS_DPT * threadIdx.x;
 		uint32_t cd[RS_DPT], wo[RS_DPT][RS_WAVES], sum = 0;
 #pragma unroll
 		for (int k = 0; k < RS_DPT; ++k) {
 			uint32_t cc = 0;
-			for (int w = 0; w < RS_WAVES; ++w) { wo[k][w] = cc; cc += s_cnt[w][d0 + k]; }
+			if (d0 + k < (unsigned)NB) for (int w = 0; w < RS_WAVES; ++w) { wo[k][w] = cc; cc += s_cnt[w][d0 + k]; }
 			cd[k] = cc; sum += cc;
 		}
 		uint32_t tot, ex = block_excl_scan_256(sum, s_scan, &tot);
 #pragma unroll
 		for (int k = 0; k < RS_DPT; ++k) {
-			for (int w = 0; w < RS_WAVES; ++w) s_cnt[w][d0 + k] = ex + wo[k][w];
-			if (d0 + k <= mask) s_gb[d0 + k] = gofs[(size_t)(d0 + k) * nb + tid_] - ex;
+			if (d0 + k < (unsigned)NB) {
+				for (int w = 0; w < RS_WAVES; ++w) s_cnt[w][d0 + k] = ex + wo[k][w];
+				if (d0 + k <= mask) s_gb[d0 + k] = gofs[(size_t)(d0 + k) * nb + tid_] - ex;
+			}
 			ex += cd[k];
 		}
 	}
@@ -189,8 +207,11 @@ static int radix_sort_impl(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, in
 		CHK(scan_exclusive_u32(c, hist, hist, (size_t)(mask + 1) * nb, nullptr));
 		{
 			ProfScope ps(c, c->radix_arcs ? "k_arc_radix_scatter" : "k_radix_scatter", (has_val ? 24.0 : 16.0) * (double)n);
-			if (has_val) hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(RS_THREADS), 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p]);
-			else hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nb), dim3(RS_THREADS), 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p]);
+			const dim3 gr(nb), bl(RS_THREADS);
+			if (has_val && bits[p] == 7) hipLaunchKernelGGL((k_radix_scatter<true, 7>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p]);
+			else if (has_val) hipLaunchKernelGGL((k_radix_scatter<true, 0>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p]);
+			else if (bits[p] == 7) hipLaunchKernelGGL((k_radix_scatter<false, 7>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p]);
+			else hipLaunchKernelGGL((k_radix_scatter<false, 0>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p]);
 		}
 		g ^= 1;
 	}

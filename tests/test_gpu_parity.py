@@ -61,7 +61,8 @@ def test_stages_match_oracle_and_reference(name, reads, lines, seed, extra, tmpd
 def test_sort_random_keys_and_ties(gpu_ctx):
     """radix sort on adversarial keys: heavy ties, wide query ids, zero starts, sizes around tile boundaries"""
     rng = np.random.default_rng(9)
-    for n, nq, ns in ((1, 1, 1), (2, 1, 1), (63, 5, 3), (2048, 7, 2), (2049, 300, 50), (100000, 70000, 60000), (300001, 17, 5), (50000, 1 << 24, 1 << 20)):
+    for n, nq, ns in ((1, 1, 1), (2, 1, 1), (63, 5, 3), (2048, 7, 2), (2049, 300, 50), (100000, 70000, 60000), (300001, 17, 5), (50000, 1 << 24, 1 << 20),
+                      (5000, 100, 100), (200000, 16000, 16000), (70000, 2000000, 1000)):  # digits of exactly 7 bits: the scatter's compile-time width
         h = np.zeros(n, dtype=ma.HIT_DT)
         h["qns"] = (rng.integers(0, nq, n).astype(np.uint64) << 32) | rng.integers(0, ns, n).astype(np.uint64)
         h["qe"] = np.arange(n)  # distinguishes tied records: stability is observable
