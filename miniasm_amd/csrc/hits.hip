@@ -1363,12 +1363,18 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 		c->soa_ready = true;
 		return 0;
 	}
+	static const int fuse_goff = getenv("MA_GOFF_FUSE") ? atoi(getenv("MA_GOFF_FUSE")) : 1;
+	if (!sharded && fuse_goff && c->n_seq) { // the group offsets come out of the sort's last pass (ids are < n_seq by contract, checked by the kernel)
+		const RadixGroups grp = {P<uint32_t>(c->goff), bi, c->n_seq};
+		CHK(radix_sort_keys(c, n, bi, bi + bq, &gen, first_hist, &grp));
+	} else {
 	CHK(radix_sort_keys(c, n, bi, bi + bq, &gen, first_hist));
 	{ // the records stay where they are for now: the first consumer moves them (hits_need_cols), ma_hit_sub while it sweeps them
 		ProfScope ps(c, "k_hit_goff", 8.0 * (double)n);
 		const uint32_t q_lo = sharded ? c->q_beg : 0u, q_hi = sharded && c->q_end < c->n_seq ? c->q_end : c->n_seq;
 		if (sharded) hipLaunchKernelGGL(k_goff_outside, dim3(grid_for((size_t)c->n_seq + 1, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, P<uint32_t>(c->goff), q_lo, q_hi, c->n_seq, (uint32_t)n);
 		hipLaunchKernelGGL(k_hit_goff, dim3(grid_for(n + 1, 512, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[gen]), bi, n, c->n_seq, P<uint32_t>(c->goff), q_lo, q_hi);
+	}
 	}
 	HIPCHK(hipGetLastError());
 	c->gather_pending = true; c->gk_gen = gen; c->gk_bi = bi;

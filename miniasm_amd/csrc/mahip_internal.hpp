@@ -110,6 +110,7 @@ struct mahip_ctx {
 	DevBuf key[2], val[2];    // radix sort ping-pong
 	DevBuf hist;              // radix block histograms
 	DevBuf scan_tmp[3];       // scan levels
+	DevBuf gs_tmp;            // radix.hip: tile minima of the group starts
 	DevBuf ctr;               // u64 [64] device counters
 	DevBuf ovf;               // overflow lists
 	DevBuf big0, big1;        // lazily allocated global scratch for oversized groups
@@ -179,7 +180,10 @@ int scan_exclusive_u32(mahip_ctx *c, const uint32_t *in, uint32_t *out, size_t n
 #endif
 int radix_sort_pairs(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1, int *gen);
 // same for bare u64 keys (a payload such as the record index may ride in the bits below lo): key bits [lo,hi)
-int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen, bool first_hist_ready = false);
+// groups (optional): the sorted bits [lo, hi) are a group id in [0, n_id) whose lowest bit is key bit groups->lo (= lo): the last pass also leaves the CSR offsets of
+// the groups in groups->start[0 .. n_id] (start[id] = first slot of the id's keys, empty groups closed, start[n_id] = n) -- no sweep over the sorted keys for them
+struct RadixGroups { uint32_t *start; int lo; uint32_t n_id; };
+int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen, bool first_hist_ready = false, const RadixGroups *groups = nullptr);
 void radix_first_digit(int lo, int hi, int *shift, int *bits, unsigned *tile);
 int radix_reserve_hist(mahip_ctx *c, size_t n);
 int scan_chain_begin(mahip_ctx *c, size_t nb, unsigned long long **state, uint32_t **ticket, uint32_t *ticket_base, uint32_t *epoch);

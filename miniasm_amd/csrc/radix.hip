@@ -63,10 +63,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint64_t *__res
 // Element order inside a tile is (wave, item, lane): element index = tile + wave*64*ITEMS + item*64 + lane.
 // NBITS > 0: the digit's width at compile time (the hit sort's three digits of 7 bits at BASELINE configs[4]): the ballot loop unrolls, and the block keeps
 // 2^NBITS bins instead of RS_BINS (35 KB of LDS against 42: four blocks per CU).  NBITS = 0: any width up to RS_MAXBITS.
-template <bool HAS_VAL, int NBITS>
+// GROUPS (the LAST pass of a key sort whose sorted bits [gr.lo, ..) are a group id, e.g. the hits' read id): the pass also notes where every group starts in the
+// output, gr.start[id] = smallest output slot of a key with that id -- the sweep over the sorted keys that looked for the boundaries (k_hit_goff) is not needed.
+// The keys of a tile arrive ordered by the bits below this pass's digit, so inside one of the tile's runs the ids do not decrease: a key whose id differs from
+// its predecessor's in the run is the first of its id anywhere; the first key of a run may continue an id of the tile before: atomicMin settles both.
+// Ids without keys keep the initial ~0 (radix_group_starts_finish closes them).
+struct RsGroups { uint32_t *start; int lo; uint32_t n_id; };
+template <bool HAS_VAL, int NBITS, bool GROUPS = false>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                                uint64_t *__restrict__ kout, uint32_t *__restrict__ vout,
-                                                               const uint32_t *__restrict__ gofs, size_t n, unsigned nb, int shift, unsigned mask, int nbits_rt)
+                                                               const uint32_t *__restrict__ gofs, size_t n, unsigned nb, int shift, unsigned mask, int nbits_rt, RsGroups gr)
 {
 	constexpr int NB = NBITS ? (1 << NBITS) : RS_BINS;
 	const int nbits = nbits_rt;
@@ -159,6 +165,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
 			uint32_t g = s_gb[(unsigned)(kk >> shift) & mask] + p;
 			kout[g] = kk;
 			if (HAS_VAL) vout[g] = s_val[p];
+			if (GROUPS) {
+				const uint64_t kp = p ? s_key[p - 1] : 0;
+				const uint32_t id = (uint32_t)(kk >> gr.lo);
+				const bool run_first = p == 0 || ((unsigned)(kp >> shift) & mask) != ((unsigned)(kk >> shift) & mask);
+				if (run_first || id != (uint32_t)(kp >> gr.lo)) atomicMin(&gr.start[id < gr.n_id ? id : gr.n_id], g); // (ids out of range, a caller's error: in front of the sentinel, as k_hit_goff has them)
+			}
 		}
 	}
 }
@@ -186,7 +198,68 @@ void radix_first_digit(int lo, int hi, int *shift, int *bits, unsigned *tile)
 	if (plan_digits(lo, hi, sh, bt) > 0) *shift = sh[0], *bits = bt[0];
 }
 
-static int radix_sort_impl(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1, int *gen, bool has_val, bool first_hist_ready = false)
+// ---- group starts from the last pass (RsGroups) ----
+// start[id] = first slot of the id's keys, ~0 for ids without keys, on entry; on exit every id without keys points at the next id's first slot (an empty group) and
+// start[n_id] = n: the offsets of a CSR over the sorted keys.  Two small launches over the n_id + 1 entries (a suffix minimum).
+#define GS_TILE 2048u
+__global__ __launch_bounds__(256) void k_group_tile_min(const uint32_t *__restrict__ start, uint32_t n_ent, uint32_t *__restrict__ tmin)
+{
+	__shared__ uint32_t s_w[4];
+	uint32_t m = 0xffffffffu;
+	for (uint32_t i = blockIdx.x * GS_TILE + threadIdx.x; i < n_ent && i < (blockIdx.x + 1) * GS_TILE; i += 256) { const uint32_t v = start[i]; m = v < m ? v : m; }
+	for (int o = 32; o; o >>= 1) { const uint32_t y = __shfl_xor(m, o, 64); m = y < m ? y : m; }
+	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = m;
+	__syncthreads();
+	if (threadIdx.x == 0) { for (int w = 1; w < 4; ++w) m = s_w[w] < m ? s_w[w] : m; tmin[blockIdx.x] = m; }
+}
+__global__ __launch_bounds__(256) void k_group_close(uint32_t *__restrict__ start, uint32_t n_ent, const uint32_t *__restrict__ tmin, uint32_t n_tiles)
+{
+	__shared__ uint32_t s_w[4], s_v[GS_TILE];
+	uint32_t m = 0xffffffffu; // the smallest start in the tiles behind this one
+	for (uint32_t t = blockIdx.x + 1 + threadIdx.x; t < n_tiles; t += 256) { const uint32_t v = tmin[t]; m = v < m ? v : m; }
+	for (int o = 32; o; o >>= 1) { const uint32_t y = __shfl_xor(m, o, 64); m = y < m ? y : m; }
+	if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = m;
+	const uint32_t base = blockIdx.x * GS_TILE;
+	for (uint32_t j = threadIdx.x; j < GS_TILE; j += 256) s_v[j] = base + j < n_ent ? start[base + j] : 0xffffffffu;
+	__syncthreads();
+	uint32_t behind = s_w[0];
+	for (int w = 1; w < 4; ++w) behind = s_w[w] < behind ? s_w[w] : behind;
+	// thread t owns 8 consecutive entries: the suffix minimum inside them, then over the threads behind it (a wave scan from the right, then the waves behind)
+	const uint32_t j0 = threadIdx.x * 8u;
+	uint32_t v[8], run = 0xffffffffu;
+#pragma unroll
+	for (int k = 7; k >= 0; --k) { run = s_v[j0 + k] < run ? s_v[j0 + k] : run; v[k] = run; }
+	uint32_t suf = run; // min over this thread's entries and those of the threads behind it in the wave
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_down(suf, o, 64); if (lane + o < 64) suf = y < suf ? y : suf; }
+	__syncthreads(); // (everybody has read the tiles' minimum from s_w)
+	if (lane == 0) s_w[wave] = suf;
+	__syncthreads();
+	uint32_t after = behind; // everything behind this thread's wave
+	for (unsigned w = wave + 1; w < 4; ++w) after = s_w[w] < after ? s_w[w] : after;
+	const uint32_t nxt = __shfl_down(suf, 1, 64);
+	const uint32_t right = lane < 63 ? (nxt < after ? nxt : after) : after; // min over everything behind this thread
+#pragma unroll
+	for (int k = 0; k < 8; ++k) if (base + j0 + k < n_ent) start[base + j0 + k] = v[k] < right ? v[k] : right;
+}
+int radix_group_starts_begin(mahip_ctx *c, uint32_t *start, uint32_t n_id, uint32_t n)
+{
+	HIPCHK(hipMemsetAsync(start, 0xff, (size_t)n_id * 4, c->st));
+	HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(start + n_id), (int)n, 1, c->st)); // the sentinel that closes the last groups
+	return 0;
+}
+int radix_group_starts_finish(mahip_ctx *c, uint32_t *start, uint32_t n_id)
+{
+	const uint32_t n_ent = n_id + 1, n_tiles = (n_ent + GS_TILE - 1) / GS_TILE;
+	CHK(dev_reserve(c, c->gs_tmp, ((size_t)n_tiles + 8) * 4));
+	ProfScope ps(c, "k_group_close", 12.0 * (double)n_ent);
+	hipLaunchKernelGGL(k_group_tile_min, dim3(n_tiles), dim3(256), 0, c->st, (const uint32_t*)start, n_ent, P<uint32_t>(c->gs_tmp));
+	hipLaunchKernelGGL(k_group_close, dim3(n_tiles), dim3(256), 0, c->st, start, n_ent, (const uint32_t*)P<uint32_t>(c->gs_tmp), n_tiles);
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+static int radix_sort_impl(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1, int *gen, bool has_val, bool first_hist_ready = false, const RadixGroups *groups = nullptr)
 {
 	int g = *gen, shift[16], bits[16], np;
 	if (n == 0) return 0;
@@ -208,10 +281,16 @@ static int radix_sort_impl(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, in
 		{
 			ProfScope ps(c, c->radix_arcs ? "k_arc_radix_scatter" : "k_radix_scatter", (has_val ? 24.0 : 16.0) * (double)n);
 			const dim3 gr(nb), bl(RS_THREADS);
-			if (has_val && bits[p] == 7) hipLaunchKernelGGL((k_radix_scatter<true, 7>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p]);
-			else if (has_val) hipLaunchKernelGGL((k_radix_scatter<true, 0>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p]);
-			else if (bits[p] == 7) hipLaunchKernelGGL((k_radix_scatter<false, 7>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p]);
-			else hipLaunchKernelGGL((k_radix_scatter<false, 0>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p]);
+			const RsGroups nog = {nullptr, 0, 0};
+			if (groups && p == np - 1) { // the last pass notes the group starts
+				const RsGroups gg = {groups->start, groups->lo, groups->n_id};
+				if (bits[p] == 7) hipLaunchKernelGGL((k_radix_scatter<false, 7, true>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p], gg);
+				else hipLaunchKernelGGL((k_radix_scatter<false, 0, true>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p], gg);
+			}
+			else if (has_val && bits[p] == 7) hipLaunchKernelGGL((k_radix_scatter<true, 7>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p], nog);
+			else if (has_val) hipLaunchKernelGGL((k_radix_scatter<true, 0>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p], nog);
+			else if (bits[p] == 7) hipLaunchKernelGGL((k_radix_scatter<false, 7>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p], nog);
+			else hipLaunchKernelGGL((k_radix_scatter<false, 0>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p], nog);
 		}
 		g ^= 1;
 	}
@@ -225,9 +304,12 @@ int radix_sort_pairs(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, int hi1,
 	return radix_sort_impl(c, n, lo0, hi0, lo1, hi1, gen, true);
 }
 
-int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen, bool first_hist_ready)
+int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen, bool first_hist_ready, const RadixGroups *groups)
 {
-	return radix_sort_impl(c, n, lo, hi, 0, 0, gen, false, first_hist_ready);
+	if (groups) CHK(radix_group_starts_begin(c, groups->start, groups->n_id, (uint32_t)n));
+	CHK(radix_sort_impl(c, n, lo, hi, 0, 0, gen, false, first_hist_ready, groups));
+	if (groups) CHK(radix_group_starts_finish(c, groups->start, groups->n_id));
+	return 0;
 }
 
 int radix_reserve_hist(mahip_ctx *c, size_t n)

@@ -494,6 +494,7 @@ hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kin
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st) { (void)st; if (kind == hipMemcpyDeviceToHost) ++g_d2h; else if (kind == hipMemcpyHostToDevice) ++g_h2d; if (bytes) memmove(dst, src, bytes); return hipSuccess; }
 hipError_t hipMemset(void *dst, int v, size_t bytes) { if (bytes) memset(dst, v, bytes); return hipSuccess; }
 hipError_t hipMemsetAsync(void *dst, int v, size_t bytes, hipStream_t st) { (void)st; if (bytes) memset(dst, v, bytes); return hipSuccess; }
+hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int v, size_t count, hipStream_t st) { (void)st; for (size_t i = 0; i < count; ++i) ((int*)dst)[i] = v; return hipSuccess; }
 hipError_t hipStreamCreate(hipStream_t *st) { *st = new emu_stream{0}; return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned flags) { *st = new emu_stream{(int)flags}; return hipSuccess; }
 hipError_t hipStreamCreateWithPriority(hipStream_t *st, unsigned flags, int) { return hipStreamCreateWithFlags(st, flags); }

@@ -280,6 +280,8 @@ hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kin
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st);
 hipError_t hipMemset(void *dst, int v, size_t bytes);
 hipError_t hipMemsetAsync(void *dst, int v, size_t bytes, hipStream_t st);
+typedef void *hipDeviceptr_t;
+hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int v, size_t count, hipStream_t st);
 hipError_t hipStreamCreate(hipStream_t *st);
 hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned flags);
 hipError_t hipStreamCreateWithPriority(hipStream_t *st, unsigned flags, int priority);

@@ -240,3 +240,33 @@ def test_random_hit_arrays_match_the_oracle_at_every_stage(block, gpu_ctx):
         orc = ST.orc_stages(h, n_seq, opt)
         gpu = ST.gpu_stages(gpu_ctx, h, n_seq, opt)
         ST.compare(orc, gpu, "random hits, seed %d" % seed, exact_order=True, graph=True)
+
+
+@pytest.mark.parametrize("n_seq,n,where", [(2048, 1, "last"), (2049, 100, "first"), (6000, 300, "middle"), (6000, 5000, "ends"), (70000, 20000, "sparse"), (70000, 3, "last")])
+def test_group_offsets_when_most_reads_have_no_hits(n_seq, n, where, gpu_ctx):
+    """the group offsets come out of the sort's last pass (radix.hip: RsGroups) and the reads without hits are closed afterwards, tile of 2048 ids by tile:
+    ids in use only at one end, in one tile of several, or thinly spread -- every stage behind the sort sees wrong groups if one offset is off"""
+    rng = np.random.default_rng(n_seq + n)
+    if where == "last":
+        q = np.full(n, n_seq - 1)
+    elif where == "first":
+        q = np.zeros(n, dtype=np.int64)
+    elif where == "middle":
+        q = rng.integers(2500, 2600, n)
+    elif where == "ends":
+        q = np.where(rng.integers(0, 2, n) == 0, rng.integers(0, 3, n), n_seq - 1 - rng.integers(0, 3, n))
+    else:
+        q = rng.choice(n_seq, 40, replace=False)[rng.integers(0, 40, n)]
+    t = rng.integers(0, n_seq, n)
+    qs = rng.integers(0, 5000, n); qe = qs + rng.integers(1, 5000, n)
+    ts = rng.integers(0, 5000, n); te = ts + rng.integers(1, 5000, n)
+    bl = rng.integers(1, 6000, n)
+    h = np.zeros(n, dtype=ma.HIT_DT)
+    h["qns"] = (q.astype(np.uint64) << np.uint64(32)) | qs.astype(np.uint64)
+    h["qe"] = qe.astype(np.uint32); h["tn"] = t.astype(np.uint32); h["ts"] = ts.astype(np.uint32); h["te"] = te.astype(np.uint32)
+    h["mlrev"] = (bl * 9 // 10).astype(np.uint32); h["bldel"] = bl.astype(np.uint32)
+    opt = ma.default_opt()
+    opt.min_dp = 1
+    orc = ST.orc_stages(h, n_seq, opt)
+    gpu = ST.gpu_stages(gpu_ctx, h, n_seq, opt)
+    ST.compare(orc, gpu, "sparse ids: %d reads, %d hits, %s" % (n_seq, n, where), exact_order=True, graph=True)
