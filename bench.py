@@ -125,11 +125,30 @@ def pmc_traffic(names, kernel):
     return round(sum(per_launch(v) * v["launches"] for v in hits) / max(sum(v["launches"] for v in hits), 1))
 
 
+def achievable_rates():
+    """profiles/r0N_diag_patterns.json (a committed measurement, not taken in this run): GB/s of the largest size per pattern"""
+    for fn in ("profiles/r04_diag_patterns.json",):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), fn)
+        if os.path.exists(path):
+            try:
+                rows = json.load(open(path))["rows"]
+                top = max(r["source_MB"] for r in rows)
+                pick = {"read16_flat": "stream_read", "write16": "stream_write", "copy16": "copy", "read8_of32+write8": "keys_from_records", "scatter_runs32": "radix_scatter_runs",
+                        "gather32+cols": "gather_32B_records_to_columns_useful_bytes"}
+                out = {v: round(r["TB_per_s"] * 1e3, 0) for r in rows for k, v in pick.items() if r["pattern"] == k and r["source_MB"] == top}
+                out.update(unit="GB/s", source="%s: csrc/diag.hip patterns over %d MB, fastest of 5 launches, HIP events (visit I of round 4); a random 32-byte fetch moves a 128-byte line, "
+                           "so the gather's 64 useful bytes per record stand for 160 moved" % (fn, top))
+                return out
+            except Exception:
+                return None
+    return None
+
+
 # Timed scopes whose byte figure is NOT a SURVEY 8(d) row of its own: 8(d) prices the hit sort at 64 B per hit "counted once regardless of
 # digit passes" and that row is billed to the scope that moves the records (k_hit_sub<gather>: sort 64 + ma_hit_sub 48 B per hit); what the
 # key / digit / offset kernels report is the traffic of this design (keys 16, a digit pass 8 + 16, offsets 8 B per hit): `design_GBs`.
-DESIGN_ONLY = ("k_hit_keys", "k_radix_hist", "k_radix_scatter", "k_hit_goff", "scan_exclusive_u32", "k_arc_keys", "k_arc_permute")
-SORT_GROUP = ("k_hit_keys", "k_radix_hist", "k_radix_scatter", "k_hit_goff", "k_hit_sub<gather>")
+DESIGN_ONLY = ("k_hit_keys", "k_radix_hist", "k_radix_scatter", "k_hit_goff", "k_group_close", "scan_exclusive_u32", "k_arc_keys", "k_arc_permute")
+SORT_GROUP = ("k_hit_keys", "k_radix_hist", "k_radix_scatter", "k_hit_goff", "k_group_close", "k_hit_sub<gather>")
 # the "reduce" half of north_star's roofline target (SURVEY 8(d), per arc): arc sort 32 + index 16 + del_trans 16 (A + I)/A + del_multi 16 +
 # del_asymm 16 + 16 x entries probed + asg_arc_rm 32.  The timed scopes that do that work (graph.hip); the *_radix_* / permute / census scopes only
 # run when the in-register arc sort hands a sort to the radix path.
@@ -538,6 +557,10 @@ def main():
                 roof["sort_group"] = {"kernels": [k["name"] for k in grp], "ms_per_step": round(grp_ms, 4), "alg_bytes_per_step": grp_bytes,
                                       "achieved": round(grp_bytes / (grp_ms * 1e-3) / 1e9, 1), "frac": round(grp_bytes / (grp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                       "traffic": round(sum(t * k["launches_per_step"] for t, k in zip(grp_tr, grp))) if all(grp_tr) else None}
+            # what this GPU sustained for plain access patterns with known byte counts (csrc/diag.hip, tools/pmc_calibrate.py): the rate `frac_counter` is to be read against
+            ach = achievable_rates()
+            if ach:
+                roof["achievable"] = ach
             # the whole hit chain by the same accounting: SURVEY 8(d) sums the reference's passes to 584 B per stored hit
             chain_bytes = 584.0 * float(W.n_my)
             step_s = dt / args.steps

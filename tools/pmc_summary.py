@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Aggregate rocprofv3 --pmc counter_collection CSVs per kernel: mean FETCH_SIZE / WRITE_SIZE (KB) per launch.
 usage: pmc_summary.py <dir with FETCH_SIZE run> <dir with WRITE_SIZE run>   -> JSON on stdout
-gfx950 note (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B request for wide coalesced
-streams, i.e. HALF the bytes; `fetch_bytes_x2` applies that correction, `fetch_bytes_raw` is the counter as is."""
+gfx950 note (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B request, i.e. HALF the bytes of a stream; `fetch_bytes_x2` applies that correction,
+`fetch_bytes_raw` is the counter as is.  Calibrated in round 4 against byte counts known by construction (tools/pmc_calibrate.py, profiles/r04_pmc_calibration.json):
+the factor 2 holds for every streaming pattern of the hot path (16 and 8 bytes per lane, 8 bytes of every 32-byte record), a random 32-byte fetch shows as 64 B
+(x2 = the 128-byte line it moves), WRITE_SIZE is exact for all of them."""
 import csv, glob, json, os, sys, collections
 
 def load(d, want):
