@@ -117,6 +117,9 @@ def pmc_traffic(names, kernel):
         parts = [v for k, v in names.items() if k.startswith(scope[0]) and (scope[1] is None or k.endswith(", true>") == scope[1])]
         return round(sum(per_launch(v) for v in parts)) if parts else None
     base = kernel.split("<")[0]
+    if base == "k_group_close":  # the scope = the two launches that close the empty groups
+        parts = [names.get(k) for k in ("k_group_tile_min", "k_group_close")]
+        return round(sum(per_launch(v) for v in parts)) if all(parts) else None
     hits = [v for k, v in names.items() if k.split("<")[0] in (base, {"k_hit_keys": "k_hit_keys_tiled", "k_arc_rm": "k_arc_rm_chain"}.get(base, base))]
     if not hits:
         return None
