@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void k_arc_compact(ArcCols in, size_t n, const
 // asg_arc_rm (asg.c:57-70) in ONE pass: a tile of RM_TILE consecutive arcs decides what stays (not deleted, both reads alive), learns where its
 // survivors go from the tiles before it (chained look-back, mahip_internal.hpp: sc_look_back) and writes them -- every arc read once, the survivors
 // written once (32 B per arc), no flag and position arrays in between.  The three-launch form above (flags, scan, compact) moves 70 B per
-// arc and is kept for MA_ARC_RM_OLD=1 (A/B on the GPU) only.
+// arc (round 4, visit A: 1.25 against 3.6 ms at 200 M arcs) and serves the callers that bring a pre-filter of their own (keep_in).
 #define RM_ITEMS 8
 #define RM_TILE (256 * RM_ITEMS)
 __global__ __launch_bounds__(256) void k_arc_rm_chain(ArcCols in, size_t n, const uint8_t *__restrict__ sdel, ArcCols out, uint32_t *__restrict__ d_total,
@@ -762,8 +762,7 @@ static int arc_cleanup(mahip_ctx *c, size_t n_in, int keep_in, int index_mode)
 	uint32_t *d_tot = (uint32_t*)(P<unsigned long long>(c->ctr) + CT_TOTAL);
 	if (n_in == 0) { c->n_arc = 0; return index_mode < 0 ? 0 : arc_reindex(c); }
 	ArcCols in = arcs_of(c, c->ag), out = arcs_of(c, c->ag ^ 1);
-	static const bool old_form = getenv("MA_ARC_RM_OLD") != nullptr;
-	if (!keep_in && !old_form) {
+	if (!keep_in) {
 		const size_t nb = (n_in + RM_TILE - 1) / RM_TILE;
 		uint32_t *ticket; unsigned long long *state; uint32_t ticket_base, epoch;
 		CHK(scan_chain_begin(c, nb, &state, &ticket, &ticket_base, &epoch));

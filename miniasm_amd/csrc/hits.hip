@@ -129,40 +129,6 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 	}
 }
 
-// The same for the slots of reads with MORE than min_h hits only (MA_GATHER_APART): the register tiers above the first one sweep such reads from the columns,
-// and their records come through this slot-parallel form (every lane a chain of its own, 2 per lane) instead of through the sweeping wave -- which, outside the
-// first tier, fetches a read's records without anything else in flight.  The read of a slot is in the key; its size is two look-ups in the group offsets that
-// neighbouring lanes share.
-__global__ __launch_bounds__(256) void k_hit_gather_sel(const ma_hit_t *__restrict__ h, const uint64_t *__restrict__ skey, int bi, size_t n, HitCols c,
-                                                         const uint32_t *__restrict__ goff, uint32_t *__restrict__ sidx, uint32_t min_h)
-{
-	size_t i[GATHER_ILP], j[GATHER_ILP];
-	uint4 a[GATHER_ILP], b[GATHER_ILP];
-	bool act[GATHER_ILP];
-#pragma unroll
-	for (int u = 0; u < GATHER_ILP; ++u) {
-		i[u] = ((size_t)blockIdx.x * GATHER_ILP + u) * 256 + threadIdx.x;
-		act[u] = false; j[u] = 0;
-		if (i[u] < n) {
-			const uint64_t k = skey[i[u]];
-			const uint32_t q = (uint32_t)(k >> bi);
-			act[u] = goff[q + 1] - goff[q] > min_h;
-			j[u] = (size_t)(k & ((1ull << bi) - 1));
-		}
-	}
-#pragma unroll
-	for (int u = 0; u < GATHER_ILP; ++u)
-		if (act[u]) { const uint4 *p = (const uint4*)(h + j[u]); a[u] = p[0]; b[u] = p[1]; }
-#pragma unroll
-	for (int u = 0; u < GATHER_ILP; ++u)
-		if (act[u]) {
-			const size_t s = i[u];
-			sidx[s] = (uint32_t)j[u];
-			c.qid[s] = a[u].y; c.qs[s] = a[u].x; c.qe[s] = a[u].z; c.tn[s] = a[u].w;
-			c.ts[s] = b[u].x; c.te[s] = b[u].y; c.ml[s] = b[u].z; c.bl[s] = b[u].w & ~DEAD;
-		}
-}
-
 // group offsets alone, from the sorted keys (the gather itself is left to the first coverage pass: k_hit_sub<false,*,true>)
 // On a shard the reads below q_lo and above q_hi have no hits here: their (empty) groups are written by k_goff_outside, all lanes at once -- left to the
 // thread that meets the first hit / the sentinel they were one serial loop over up to 7/8 of the reads (found by the round-3 projection: 17 - 29 ms per pass
@@ -319,15 +285,9 @@ __device__ __forceinline__ void gather_recs(const SubGather &g, const GKeys &k, 
 }
 __device__ __forceinline__ void gather_store(const HitCols &c, const SubGather &g, uint32_t i, uint32_t j, uint4 a, uint4 b)
 {
-#ifdef GATHER_NT // experiment: the columns are written once and read a pass later (7.2 GB, far more than the caches hold): stores that do not claim L2 lines leave them to the record sectors two reads share
-	__builtin_nontemporal_store(a.y, &c.qid[i]); __builtin_nontemporal_store(a.x, &c.qs[i]); __builtin_nontemporal_store(a.z, &c.qe[i]); __builtin_nontemporal_store(a.w, &c.tn[i]);
-	__builtin_nontemporal_store(b.x, &c.ts[i]); __builtin_nontemporal_store(b.y, &c.te[i]); __builtin_nontemporal_store(b.z, &c.ml[i]); __builtin_nontemporal_store(b.w & ~DEAD, &c.bl[i]);
-	__builtin_nontemporal_store(j, &g.sidx[i]);
-#else
 	c.qid[i] = a.y; c.qs[i] = a.x; c.qe[i] = a.z; c.tn[i] = a.w;
 	c.ts[i] = b.x; c.te[i] = b.y; c.ml[i] = b.z; c.bl[i] = b.w & ~DEAD;
 	g.sidx[i] = j;
-#endif
 }
 
 // one read in registers; returns 1 if the read keeps an interval (value identical on all lanes).  pre != nullptr: the
@@ -1419,12 +1379,8 @@ struct SubFork {
 		if (!on) return;
 		if (!c->sub_side[0] && !c->sub_fork_failed) { // streams and events are made once per context; if any of them cannot be had, all three size classes run on the context's stream
 			bool ok = true;
-			// the two larger size classes hold few, heavy reads and finish LAST when all three launches share the chip evenly (round 4, visit E: first tier 4.2 ms, the others 5.3;
-			// fused pass 2.1 against 3.1): MA_SUB_PRIO=1 gives their streams the device's highest priority -- measured: no effect; the three launches pack the chip as it is (the first tier alone needs about 3.9 ms of it, the other two about 1.5)
-			static const bool prio = getenv("MA_SUB_PRIO") && atoi(getenv("MA_SUB_PRIO")) != 0; // (visit G: 5.47 / 5.47 ms without, 5.43 / 5.88 with: nothing; off)
-			int lo = 0, hi = 0;
-			if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
-			for (int k = 0; k < 2 && ok; ++k) ok = (prio && hi != lo ? hipStreamCreateWithPriority(&c->sub_side[k], hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&c->sub_side[k], hipStreamNonBlocking)) == hipSuccess;
+			// (the side streams at the device's highest priority -- the larger classes finish last -- were measured in round 4, visit G: no effect)
+			for (int k = 0; k < 2 && ok; ++k) ok = hipStreamCreateWithFlags(&c->sub_side[k], hipStreamNonBlocking) == hipSuccess;
 			for (int k = 0; k < 3 && ok; ++k) ok = hipEventCreateWithFlags(&c->sub_ev[k], hipEventDisableTiming) == hipSuccess;
 			if (!ok) {
 				(void)hipGetLastError();
@@ -1463,19 +1419,10 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 		SubFork fk(c);
 		hipLaunchKernelGGL((k_hit_sub<false, 0, true>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(0), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-		static const int apart = getenv("MA_GATHER_APART") ? atoi(getenv("MA_GATHER_APART")) : 0;
-		if (apart) { // reads of more than 128 hits: records -> columns by the slot-parallel gather, then the column sweeps of the two larger classes behind it (one side stream)
-			hipLaunchKernelGGL(k_hit_gather_sel, dim3(grid_for(c->n_hits, 256 * GATHER_ILP)), dim3(256), 0, fk.st(1), c->d_aos, g.skey, g.bi, c->n_hits, h, (const uint32_t*)P<uint32_t>(c->goff), g.sidx, 128u);
-			hipLaunchKernelGGL((k_hit_sub<false, 1>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(1), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
-			                   sub, P<uint32_t>(c->ovf), ctr, nofuse, nog);
-			hipLaunchKernelGGL((k_hit_sub<false, 2>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(1), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
-			                   sub, P<uint32_t>(c->ovf), ctr, nofuse, nog);
-		} else {
 		hipLaunchKernelGGL((k_hit_sub<false, 1, true>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(1), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
 		hipLaunchKernelGGL((k_hit_sub<false, 2, true>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(2), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
 		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-		}
 		fk.join();
 		c->gather_pending = false;
 	} else if (R) {

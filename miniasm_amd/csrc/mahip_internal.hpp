@@ -385,10 +385,7 @@ __device__ __forceinline__ uint32_t sc_look_back(const unsigned long long *state
 // what a lane keeps of a compare-exchange with its partner's value y: the smaller one in the lower lane, the larger one in the upper;
 // min / max take the DPP operand themselves and the select reads the lane mask from scalar registers (round 3: -5 % on the fused pass
 // against mov_dpp + compare + xor on vcc + select)
-#ifdef SORT_MINMAX // the form of round 3 (min + max with the DPP operand folded in, then a select): kept for A/B builds
-#define MA_KEEP(x, y, lower) ((lower) ? ((x) < (y) ? (x) : (y)) : ((x) < (y) ? (y) : (x)))
-#else
-// Round 4 (measured on one box: the fused coverage pass 3.37 -> 3.26 ms at BASELINE configs[3], 2.75 -> 2.50 ms on the graph-heavy input; profiles/r04_experiments.txt):
+// (Round 3: min + max with the DPP operand folded in, then a select -- 3 VALU.)  Round 4 (measured on one box: the fused coverage pass 3.37 -> 3.26 ms at BASELINE configs[3], 2.75 -> 2.50 ms on the graph-heavy input; profiles/r04_experiments.txt):
 // ONE instruction instead of min + max + select: the median of (x, y, 0) is min(x, y), the median of (x, y, ~0) is max(x, y) -- v_med3_u32 with the
 // lane's role (0 in the lower lane of a pair, ~0 in the upper) as its third operand.  gfx9 has no DPP form of a three-operand instruction, so the partner's
 // value arrives through a v_mov_b32 dpp (or ds_bpermute across rows): 2 VALU per compare-exchange instead of 3.
@@ -404,7 +401,6 @@ __device__ __forceinline__ uint32_t ma_med3_u32(uint32_t a, uint32_t b, uint32_t
 #endif
 }
 #define MA_KEEP(x, y, lower) ma_med3_u32((x), (y), (lower) ? 0u : 0xffffffffu)
-#endif
 // Value of lane (lane ^ M) for a compile-time M.  Exchanges inside a row of 16 lanes are DPP modifiers of a VALU move
 // (quad_perm, row_half_mirror, row_mirror, row_ror, banked row_shl/shr): no LDS crossbar round trip, no s_waitcnt.
 // Only the exchanges across rows (16, 31, 63) go through ds_bpermute.

@@ -497,8 +497,6 @@ hipError_t hipMemsetAsync(void *dst, int v, size_t bytes, hipStream_t st) { (voi
 hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int v, size_t count, hipStream_t st) { (void)st; for (size_t i = 0; i < count; ++i) ((int*)dst)[i] = v; return hipSuccess; }
 hipError_t hipStreamCreate(hipStream_t *st) { *st = new emu_stream{0}; return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned flags) { *st = new emu_stream{(int)flags}; return hipSuccess; }
-hipError_t hipStreamCreateWithPriority(hipStream_t *st, unsigned flags, int) { return hipStreamCreateWithFlags(st, flags); }
-hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = -1; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t st) { delete st; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t st)
 {

@@ -284,8 +284,6 @@ typedef void *hipDeviceptr_t;
 hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int v, size_t count, hipStream_t st);
 hipError_t hipStreamCreate(hipStream_t *st);
 hipError_t hipStreamCreateWithFlags(hipStream_t *st, unsigned flags);
-hipError_t hipStreamCreateWithPriority(hipStream_t *st, unsigned flags, int priority);
-hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest);
 hipError_t hipStreamDestroy(hipStream_t st);
 hipError_t hipStreamSynchronize(hipStream_t st);
 static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; } /* launches are synchronous here */
