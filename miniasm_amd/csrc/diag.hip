@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void k_diag_read16_flat(const uint4 *__restric
 }
 
 // 8 x 16-byte loads of a thread in flight together, one block per 32 KB (the shape of k_radix_hist); ATOM: + that kernel's LDS atomics (1 = once, 2 = twice)
-template <int ATOM>
+// ROWS: the block's 128 counts leave as one row of 512 bytes (tile-major) instead of 128 words a tile-count apart (digit-major, what k_radix_hist writes)
+template <int ATOM, bool ROWS = false>
 __global__ __launch_bounds__(256) void k_diag_read16_x8(const ulonglong2 *__restrict__ src, size_t n16, uint32_t *__restrict__ out, int shift)
 {
 	__shared__ uint32_t s_cnt[ATOM > 1 ? 2 : 1][DG_BINS];
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void k_diag_read16_x8(const ulonglong2 *__rest
 	}
 	if (ATOM) {
 		__syncthreads();
-		if (threadIdx.x < DG_BINS) out[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_cnt[0][threadIdx.x] + (ATOM > 1 ? s_cnt[1][threadIdx.x] : 0u);
+		if (threadIdx.x < DG_BINS) out[ROWS ? (size_t)blockIdx.x * DG_BINS + threadIdx.x : (size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_cnt[0][threadIdx.x] + (ATOM > 1 ? s_cnt[1][threadIdx.x] : 0u);
 	} else {
 		x = wv_sum_u32(x);
 		if ((threadIdx.x & 63) == 0 && x == 0x9e3779b9u) out[blockIdx.x & 1023u] = x;
@@ -164,6 +165,7 @@ static const char *const dg_names[] = {
 	"read16_flat", "read16_x8", "read16_x8+lds_atomics", "read16_x8+lds_atomics_x2", "read8_of32", "read8_of32+write8", "write16", "write8", "copy16", "copy8",
 	"gather32", "gather32_ilp4", "gather32+cols", "gather32_ilp4+cols", "scatter_runs32",
 	"gather32+cols_win32MB", "gather32+cols_win64MB", "gather32+cols_win128MB", "gather32+cols_win256MB", "gather32+cols_win512MB",
+	"read16_x8+lds_atomics+rows_out",
 };
 extern "C" int mahip_diag_patterns(void) { return (int)(sizeof(dg_names) / sizeof(dg_names[0])); }
 extern "C" const char *mahip_diag_name(int pattern) { return pattern >= 0 && pattern < mahip_diag_patterns() ? dg_names[pattern] : nullptr; }
@@ -209,6 +211,7 @@ extern "C" int mahip_diag_run(mahip_ctx_t *c, int pattern, size_t bytes, int rep
 		case 13: hipLaunchKernelGGL((k_diag_gather32<true, 4>), dim3((unsigned)(n_g / 1024)), dim3(256), 0, c->st, (const uint4*)src, bits, (uint32_t*)dst, n_g, bits); mv = 64.0 * (double)n_g; break;
 		case 15: case 16: case 17: case 18: case 19:
 			hipLaunchKernelGGL((k_diag_gather32<true, 1>), dim3((unsigned)(n_g / 256)), dim3(256), 0, c->st, (const uint4*)src, bits, (uint32_t*)dst, n_g, 20 + (pattern - 15)); mv = 64.0 * (double)n_g; break;
+		case 20: hipLaunchKernelGGL((k_diag_read16_x8<1, true>), dim3((unsigned)(n16 / 2048)), dim3(256), 0, c->st, (const ulonglong2*)src, n16, out, 27); mv = (double)bytes; break;
 		case 14: hipLaunchKernelGGL(k_diag_scatter_runs, dim3((unsigned)(n8 / 4096)), dim3(256), 0, c->st, (const uint64_t*)src, (uint64_t*)dst, n8 / 4096); mv = 2.0 * (double)bytes; break;
 		}
 		HIPCHK(hipEventRecord(e1, c->st));

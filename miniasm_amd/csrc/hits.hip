@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_hit_keys_tiled(const ma_hit_t *__restri
 		}
 	}
 	__syncthreads();
-	for (unsigned d = threadIdx.x; d <= mask; d += 256) hist[(size_t)d * nb + blockIdx.x] = s_cnt[d];
+	for (unsigned d = threadIdx.x; d <= mask; d += 256) hist[(size_t)blockIdx.x * (mask + 1u) + d] = s_cnt[d]; // the tile's row (radix.hip: RsOffsets)
 }
 
 // largest query id / query start (only when the caller gave no hints: the per-symbol ma_hit_sort)

@@ -9,7 +9,7 @@
 //     (hits: 16 bits of start + 18..21 bits of read id = 4 passes of <= 10 bits instead of 8 byte-passes over 64 bits);
 //   * when the record index fits below the key bits the index rides in the low bits of the key itself
 //     (8-byte elements, no value array): a pass reads 8 B twice and writes 8 B per record;
-//   * per pass: k_radix_hist (per-tile digit counts, digit-major) -> exclusive scan -> k_radix_scatter;
+//   * per pass: k_radix_hist (per-tile digit counts, one ROW per tile) -> scan down the columns (k_radix_colscan_*) -> k_radix_scatter;
 //   * tiles of 4096 keys (256 threads x 16): ranks come from wave ballots (stable multi-split), the tile is
 //     reordered through LDS so that consecutive lanes write consecutive addresses of a digit's run.
 #include "mahip_internal.hpp"
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint64_t *__res
 		}
 	}
 	__syncthreads();
-	for (unsigned d = threadIdx.x; d <= mask; d += RS_THREADS) hist[(size_t)d * nb + tid_] = s_cnt[d];
+	for (unsigned d = threadIdx.x; d <= mask; d += RS_THREADS) hist[(size_t)tid_ * (mask + 1u) + d] = s_cnt[d]; // the tile's row (radix_hist_layout)
 }
 
 // Element order inside a tile is (wave, item, lane): element index = tile + wave*64*ITEMS + item*64 + lane.
@@ -69,10 +69,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint64_t *__res
 // its predecessor's in the run is the first of its id anywhere; the first key of a run may continue an id of the tile before: atomicMin settles both.
 // Ids without keys keep the initial ~0 (radix_group_starts_finish closes them).
 struct RsGroups { uint32_t *start; int lo; uint32_t n_id; };
+// Where a tile's runs start.  The per-tile digit counts are ROWS of (mask + 1) words -- a tile writes and reads its counts with one coalesced access; round 4 until
+// visit R kept them digit-major, 128 words a tile-count apart: every 4-byte store a 32-byte sector of its own, and k_radix_hist at 4.6 TB/s where the same read with a
+// row written runs at 5.9 (profiles/r04_experiments.txt).  The scan runs DOWN the columns in chunks of RS_CHUNK tiles: cnt[t][d] becomes the count of digit d in the
+// chunk's tiles in front of t, pre[c][d] the count in the chunks in front of c, tot[d] the digit's total; a run starts at sum(tot[< d]) + pre + cnt.
+struct RsOffsets { const uint32_t *cnt, *pre, *tot; };
+#define RS_CHUNK 64u
 template <bool HAS_VAL, int NBITS, bool GROUPS = false>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                                uint64_t *__restrict__ kout, uint32_t *__restrict__ vout,
-                                                               const uint32_t *__restrict__ gofs, size_t n, unsigned nb, int shift, unsigned mask, int nbits_rt, RsGroups gr)
+                                                               RsOffsets go, size_t n, unsigned nb, int shift, unsigned mask, int nbits_rt, RsGroups gr)
 {
 	constexpr int NB = NBITS ? (1 << NBITS) : RS_BINS;
 	const int nbits = nbits_rt;
@@ -135,14 +141,22 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const uint64_t *__
 			if (d0 + k < (unsigned)NB) for (int w = 0; w < RS_WAVES; ++w) { wo[k][w] = cc; cc += s_cnt[w][d0 + k]; }
 			cd[k] = cc; sum += cc;
 		}
+		uint32_t gt[RS_DPT], gsum = 0, goff[RS_DPT]; // the digits' totals and this tile's offsets inside them: asked for before the barriers of the scans below
+#pragma unroll
+		for (int k = 0; k < RS_DPT; ++k) {
+			const bool in = d0 + k <= mask;
+			gt[k] = in ? go.tot[d0 + k] : 0u; gsum += gt[k];
+			goff[k] = in ? go.pre[(size_t)(tid_ / RS_CHUNK) * (mask + 1u) + d0 + k] + go.cnt[(size_t)tid_ * (mask + 1u) + d0 + k] : 0u;
+		}
 		uint32_t tot, ex = block_excl_scan_256(sum, s_scan, &tot);
+		uint32_t gtot, gb = block_excl_scan_256(gsum, s_scan, &gtot); // where the digit's run starts in the output: exclusive over the totals
 #pragma unroll
 		for (int k = 0; k < RS_DPT; ++k) {
 			if (d0 + k < (unsigned)NB) {
 				for (int w = 0; w < RS_WAVES; ++w) s_cnt[w][d0 + k] = ex + wo[k][w];
-				if (d0 + k <= mask) s_gb[d0 + k] = gofs[(size_t)(d0 + k) * nb + tid_] - ex;
+				if (d0 + k <= mask) s_gb[d0 + k] = gb + goff[k] - ex;
 			}
-			ex += cd[k];
+			ex += cd[k]; gb += gt[k];
 		}
 	}
 	__syncthreads();
@@ -189,13 +203,62 @@ static int plan_digits(int lo, int hi, int *shift, int *bits)
 }
 
 // sort key[*gen] (and val[*gen] if has_val) on key bits [lo0,hi0) then [lo1,hi1); result in generation *gen
-// the first digit of a key sort on bits [lo,hi) and the histogram layout (digit-major, one column per RS_TILE keys), for a
+// the first digit of a key sort on bits [lo,hi) and the histogram layout (a row of 2^bits words per RS_TILE keys at the start of c->hist), for a
 // producer of the keys that counts the first digit on the fly (k_hit_keys_tiled) and so saves the first histogram pass
 void radix_first_digit(int lo, int hi, int *shift, int *bits, unsigned *tile)
 {
 	int sh[16], bt[16];
 	*shift = lo; *bits = 0; *tile = RS_TILE;
 	if (plan_digits(lo, hi, sh, bt) > 0) *shift = sh[0], *bits = bt[0];
+}
+
+// ---- the scan down the columns of the count rows (RsOffsets) ----
+// a chunk of RS_CHUNK tiles: every column's counts become exclusive prefixes inside the chunk (in place), the column's sum goes to pre[chunk][d]
+__global__ __launch_bounds__(256) void k_radix_colscan_chunk(uint32_t *__restrict__ cnt, unsigned nb, unsigned nbd, uint32_t *__restrict__ pre)
+{
+	const size_t t0 = (size_t)blockIdx.x * RS_CHUNK;
+	for (unsigned d = threadIdx.x; d < nbd; d += 256) {
+		uint32_t run = 0;
+		for (unsigned r = 0; r < RS_CHUNK; r += 16) { // 16 rows in flight
+			uint32_t v[16];
+#pragma unroll
+			for (int k = 0; k < 16; ++k) v[k] = t0 + r + k < nb ? cnt[(t0 + r + k) * nbd + d] : 0u;
+#pragma unroll
+			for (int k = 0; k < 16; ++k) { if (t0 + r + k < nb) cnt[(t0 + r + k) * nbd + d] = run; run += v[k]; }
+		}
+		pre[(size_t)blockIdx.x * nbd + d] = run;
+	}
+}
+// one block per digit: the chunks' sums of its column become exclusive prefixes (in place), the column's total goes to tot[d]
+__global__ __launch_bounds__(256) void k_radix_colscan_top(uint32_t *__restrict__ pre, unsigned n_chunk, unsigned nbd, uint32_t *__restrict__ tot)
+{
+	__shared__ uint32_t s_w[4];
+	const unsigned d = blockIdx.x, per = (n_chunk + 255) / 256, c0 = threadIdx.x * per;
+	uint32_t sum = 0;
+	for (unsigned c = c0; c < c0 + per && c < n_chunk; ++c) sum += pre[(size_t)c * nbd + d];
+	uint32_t total, ex = block_excl_scan_256(sum, s_w, &total);
+	for (unsigned c = c0; c < c0 + per && c < n_chunk; ++c) { const uint32_t v = pre[(size_t)c * nbd + d]; pre[(size_t)c * nbd + d] = ex; ex += v; }
+	if (threadIdx.x == 0) tot[d] = total;
+}
+// the layout of c->hist for nb tiles of nbd bins: rows, then the chunks' prefixes, then the totals
+static RsOffsets radix_hist_layout(mahip_ctx *c, unsigned nb, unsigned nbd, uint32_t **cnt, uint32_t **pre, uint32_t **tot)
+{
+	const unsigned n_chunk = (nb + RS_CHUNK - 1) / RS_CHUNK;
+	*cnt = P<uint32_t>(c->hist); *pre = *cnt + (size_t)nb * nbd; *tot = *pre + (size_t)n_chunk * nbd;
+	RsOffsets o = {*cnt, *pre, *tot};
+	return o;
+}
+static size_t radix_hist_words(unsigned nb) { return ((size_t)nb + (nb + RS_CHUNK - 1) / RS_CHUNK + 1) * RS_BINS + 8; }
+static int radix_colscan(mahip_ctx *c, unsigned nb, unsigned nbd)
+{
+	uint32_t *cnt, *pre, *tot;
+	(void)radix_hist_layout(c, nb, nbd, &cnt, &pre, &tot);
+	const unsigned n_chunk = (nb + RS_CHUNK - 1) / RS_CHUNK;
+	ProfScope ps(c, "k_radix_colscan", 8.0 * (double)nb * nbd);
+	hipLaunchKernelGGL(k_radix_colscan_chunk, dim3(n_chunk), dim3(256), 0, c->st, cnt, nb, nbd, pre);
+	hipLaunchKernelGGL(k_radix_colscan_top, dim3(nbd), dim3(256), 0, c->st, pre, n_chunk, nbd, tot);
+	HIPCHK(hipGetLastError());
+	return 0;
 }
 
 // ---- group starts from the last pass (RsGroups) ----
@@ -267,30 +330,31 @@ static int radix_sort_impl(mahip_ctx *c, size_t n, int lo0, int hi0, int lo1, in
 	np = plan_digits(lo0, hi0, shift, bits);
 	np += plan_digits(lo1, hi1, shift + np, bits + np);
 	unsigned nb = (unsigned)((n + RS_TILE - 1) / RS_TILE);
-	CHK(dev_reserve(c, c->hist, ((size_t)RS_BINS * nb + 8) * 4));
+	CHK(dev_reserve(c, c->hist, radix_hist_words(nb) * 4));
 	for (int p = 0; p < np; ++p) {
 		unsigned mask = (1u << bits[p]) - 1;
 		uint64_t *kin = P<uint64_t>(c->key[g]), *kout = P<uint64_t>(c->key[g ^ 1]);
 		uint32_t *vin = P<uint32_t>(c->val[g]), *vout = P<uint32_t>(c->val[g ^ 1]);
-		uint32_t *hist = P<uint32_t>(c->hist);
+		uint32_t *hist, *hpre, *htot;
+		const RsOffsets ro = radix_hist_layout(c, nb, mask + 1u, &hist, &hpre, &htot);
 		if (!(p == 0 && first_hist_ready)) {
 			ProfScope ps(c, c->radix_arcs ? "k_arc_radix_hist" : "k_radix_hist", 8.0 * (double)n);
 			hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(RS_THREADS), 0, c->st, kin, hist, n, nb, shift[p], mask);
 		}
-		CHK(scan_exclusive_u32(c, hist, hist, (size_t)(mask + 1) * nb, nullptr));
+		CHK(radix_colscan(c, nb, mask + 1u));
 		{
 			ProfScope ps(c, c->radix_arcs ? "k_arc_radix_scatter" : "k_radix_scatter", (has_val ? 24.0 : 16.0) * (double)n);
 			const dim3 gr(nb), bl(RS_THREADS);
 			const RsGroups nog = {nullptr, 0, 0};
 			if (groups && p == np - 1) { // the last pass notes the group starts
 				const RsGroups gg = {groups->start, groups->lo, groups->n_id};
-				if (bits[p] == 7) hipLaunchKernelGGL((k_radix_scatter<false, 7, true>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p], gg);
-				else hipLaunchKernelGGL((k_radix_scatter<false, 0, true>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p], gg);
+				if (bits[p] == 7) hipLaunchKernelGGL((k_radix_scatter<false, 7, true>), gr, bl, 0, c->st, kin, vin, kout, vout, ro, n, nb, shift[p], mask, bits[p], gg);
+				else hipLaunchKernelGGL((k_radix_scatter<false, 0, true>), gr, bl, 0, c->st, kin, vin, kout, vout, ro, n, nb, shift[p], mask, bits[p], gg);
 			}
-			else if (has_val && bits[p] == 7) hipLaunchKernelGGL((k_radix_scatter<true, 7>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p], nog);
-			else if (has_val) hipLaunchKernelGGL((k_radix_scatter<true, 0>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p], nog);
-			else if (bits[p] == 7) hipLaunchKernelGGL((k_radix_scatter<false, 7>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p], nog);
-			else hipLaunchKernelGGL((k_radix_scatter<false, 0>), gr, bl, 0, c->st, kin, vin, kout, vout, hist, n, nb, shift[p], mask, bits[p], nog);
+			else if (has_val && bits[p] == 7) hipLaunchKernelGGL((k_radix_scatter<true, 7>), gr, bl, 0, c->st, kin, vin, kout, vout, ro, n, nb, shift[p], mask, bits[p], nog);
+			else if (has_val) hipLaunchKernelGGL((k_radix_scatter<true, 0>), gr, bl, 0, c->st, kin, vin, kout, vout, ro, n, nb, shift[p], mask, bits[p], nog);
+			else if (bits[p] == 7) hipLaunchKernelGGL((k_radix_scatter<false, 7>), gr, bl, 0, c->st, kin, vin, kout, vout, ro, n, nb, shift[p], mask, bits[p], nog);
+			else hipLaunchKernelGGL((k_radix_scatter<false, 0>), gr, bl, 0, c->st, kin, vin, kout, vout, ro, n, nb, shift[p], mask, bits[p], nog);
 		}
 		g ^= 1;
 	}
@@ -315,7 +379,7 @@ int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen, bool first
 int radix_reserve_hist(mahip_ctx *c, size_t n)
 {
 	unsigned nb = (unsigned)((n + RS_TILE - 1) / RS_TILE);
-	return dev_reserve(c, c->hist, ((size_t)RS_BINS * nb + 8) * 4);
+	return dev_reserve(c, c->hist, radix_hist_words(nb) * 4);
 }
 
 // ---- exact-tie mode (include/mahip.h: mahip_set_exact_ties) ----

@@ -17,6 +17,7 @@ KERNEL_OF = {  # pattern name -> the kernel's name as the trace shows it (prefix
     "gather32": "void k_diag_gather32<false, 1>", "gather32_ilp4": "void k_diag_gather32<false, 4>", "gather32+cols": "void k_diag_gather32<true, 1>",
     "gather32_ilp4+cols": "void k_diag_gather32<true, 4>", "scatter_runs32": "k_diag_scatter_runs",
     "gather32+cols_win32MB": None, "gather32+cols_win64MB": None, "gather32+cols_win128MB": None, "gather32+cols_win256MB": None, "gather32+cols_win512MB": None,  # (same kernel as gather32+cols: timing only)
+    "read16_x8+lds_atomics+rows_out": "void k_diag_read16_x8<1, true>",
 }
 
 
