@@ -117,8 +117,11 @@ def pmc_traffic(names, kernel):
         parts = [v for k, v in names.items() if k.startswith(scope[0]) and (scope[1] is None or k.endswith(", true>") == scope[1])]
         return round(sum(per_launch(v) for v in parts)) if parts else None
     base = kernel.split("<")[0]
-    if base == "k_group_close":  # the scope = the two launches that close the empty groups
-        parts = [names.get(k) for k in ("k_group_tile_min", "k_group_close")]
+    two = {"k_group_close": ("k_group_tile_min", "k_group_close"), "k_radix_colscan": ("k_radix_colscan_chunk", "k_radix_colscan_top")}.get(base)
+    if two:  # a scope of two small launches
+        parts = [names.get(k) for k in two]
+        if not all(parts) and base == "k_radix_colscan":
+            return 0  # (a counter profile from before these kernels existed: 50 MB per pass, nothing against the group's 46 GB)
         return round(sum(per_launch(v) for v in parts)) if all(parts) else None
     hits = [v for k, v in names.items() if k.split("<")[0] in (base, {"k_hit_keys": "k_hit_keys_tiled", "k_arc_rm": "k_arc_rm_chain"}.get(base, base))]
     if not hits:
@@ -150,8 +153,8 @@ def achievable_rates():
 # Timed scopes whose byte figure is NOT a SURVEY 8(d) row of its own: 8(d) prices the hit sort at 64 B per hit "counted once regardless of
 # digit passes" and that row is billed to the scope that moves the records (k_hit_sub<gather>: sort 64 + ma_hit_sub 48 B per hit); what the
 # key / digit / offset kernels report is the traffic of this design (keys 16, a digit pass 8 + 16, offsets 8 B per hit): `design_GBs`.
-DESIGN_ONLY = ("k_hit_keys", "k_radix_hist", "k_radix_scatter", "k_hit_goff", "k_group_close", "scan_exclusive_u32", "k_arc_keys", "k_arc_permute")
-SORT_GROUP = ("k_hit_keys", "k_radix_hist", "k_radix_scatter", "k_hit_goff", "k_group_close", "k_hit_sub<gather>")
+DESIGN_ONLY = ("k_hit_keys", "k_radix_hist", "k_radix_colscan", "k_radix_scatter", "k_hit_goff", "k_group_close", "scan_exclusive_u32", "k_arc_keys", "k_arc_permute")
+SORT_GROUP = ("k_hit_keys", "k_radix_hist", "k_radix_colscan", "k_radix_scatter", "k_hit_goff", "k_group_close", "k_hit_sub<gather>")
 # the "reduce" half of north_star's roofline target (per arc): arc sort 32 + index 16 + del_trans 16 (A + I)/A + del_multi 16 +
 # del_asymm 16 + 16 x entries probed + asg_arc_rm 32.  The timed scopes that do that work (graph.hip); the *_radix_* / permute / census scopes only
 # run when the in-register arc sort hands a sort to the radix path.
@@ -559,7 +562,7 @@ def main():
                 grp_bytes = 112.0 * float(W.n_my)
                 roof["sort_group"] = {"kernels": [k["name"] for k in grp], "ms_per_step": round(grp_ms, 4), "alg_bytes_per_step": grp_bytes,
                                       "achieved": round(grp_bytes / (grp_ms * 1e-3) / 1e9, 1), "frac": round(grp_bytes / (grp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                      "traffic": round(sum(t * k["launches_per_step"] for t, k in zip(grp_tr, grp))) if all(grp_tr) else None}
+                                      "traffic": round(sum(t * k["launches_per_step"] for t, k in zip(grp_tr, grp))) if all(t is not None for t in grp_tr) else None}
             # what this GPU sustained for plain access patterns with known byte counts (csrc/diag.hip, tools/pmc_calibrate.py): the rate `frac_counter` is to be read against
             ach = achievable_rates()
             if ach:
