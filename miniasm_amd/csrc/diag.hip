@@ -186,8 +186,12 @@ extern "C" int mahip_diag_run(mahip_ctx_t *c, int pattern, size_t bytes, int rep
 	const void *src = c->key[0].p;
 	void *dst = c->key[1].p;
 	uint32_t *out = P<uint32_t>(c->hist);
-	hipEvent_t e0, e1;
-	HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+	struct Events { // (destroyed on every way out)
+		hipEvent_t e0 = nullptr, e1 = nullptr;
+		~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+	} ev;
+	HIPCHK(hipEventCreate(&ev.e0)); HIPCHK(hipEventCreate(&ev.e1));
+	const hipEvent_t e0 = ev.e0, e1 = ev.e1;
 	double best = 1e30, mv = 0;
 	for (int r = 0; r < reps; ++r) {
 		HIPCHK(hipEventRecord(e0, c->st));
@@ -220,7 +224,6 @@ extern "C" int mahip_diag_run(mahip_ctx_t *c, int pattern, size_t bytes, int rep
 		HIPCHK(hipEventElapsedTime(&ms, e0, e1));
 		if (ms < best) best = ms;
 	}
-	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	HIPCHK(hipGetLastError());
 	if (best_ms) *best_ms = best;
 	if (moved) *moved = mv;
