@@ -219,11 +219,11 @@ class Workload:
         L.mahip_paf_max_qs.argtypes = [C.c_void_p]
         self.max_qs = L.mahip_paf_max_qs(ctx.h)
         q0, q1 = 0, 0xffffffff
-        if world == 1:
-            q0, q1 = 0, 0xffffffff
-        else:  # read ranges with equally many hits; the table stays in the context for the sharded head (host/sharded.c)
+        self.bounds = None
+        if world > 1:  # read ranges with equally many hits; the table is handed to the sharded head with every batch (a table describes one upload, include/mahip.h)
             L.mahip_hits_balance.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]
-            bounds = (C.c_uint32 * (world + 1))()
+            L.mahip_set_shard_bounds.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
+            self.bounds = bounds = (C.c_uint32 * (world + 1))()
             ma._chk(L.mahip_hits_balance(ctx.h, world, bounds), "balance")
             q0, q1 = bounds[rank], bounds[rank + 1]
         n_my = C.c_size_t(0)
@@ -407,6 +407,8 @@ def main():
             W = self.W
             ma._chk(L.mahip_hits_adopt(self.hctx.h, W.hits_dev.data_ptr(), W.n_my, W.n_seq), "adopt")
             L.mahip_set_hints(self.hctx.h, W.max_qs)
+            if W.bounds is not None:
+                ma._chk(L.mahip_set_shard_bounds(self.hctx.h, W.bounds, world), "set_shard_bounds")
             if W.pos_dev is not None:
                 ma._chk(L.mahip_hits_set_positions(self.hctx.h, C.c_void_p(W.pos_dev.data_ptr()), 1, W.n_all), "set_positions")
             st = (C.c_uint32 * 4)(0, 0, 0, 0)

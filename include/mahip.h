@@ -35,7 +35,8 @@ int mahip_hits_adopt(mahip_ctx_t *c, const void *d_hits, size_t n, uint32_t n_se
 int mahip_set_shard(mahip_ctx_t *c, uint32_t q_beg, uint32_t q_end);
 /* Read ranges that hold equally many hits: bounds[0..world], rank r owns [bounds[r], bounds[r+1]).  mahip_hits_balance computes the table from the unsorted
  * records in the context (identical on every rank that holds the whole input) and keeps it; mahip_set_shard_bounds installs a table made elsewhere;
- * the orchestrator (host/sharded.c) uses the table of its world size when there is one, equal read counts otherwise. */
+ * the orchestrator (host/sharded.c) uses the table of its world size when there is one, equal read counts otherwise.  A table describes ONE upload, like the
+ * hints and the positions: every mahip_hits_upload / mahip_hits_adopt forgets it -- install it (again) after the records. */
 int mahip_hits_balance(mahip_ctx_t *c, int world, uint32_t *bounds);
 int mahip_set_shard_bounds(mahip_ctx_t *c, const uint32_t *bounds, int world);
 const uint32_t *mahip_shard_bounds(mahip_ctx_t *c, int *world);

@@ -252,10 +252,10 @@ extern "C" int mahip_comm_all_reduce_sum_u64(mahip_ctx_t *c, uint64_t *h_vals, s
 	HIPCHK(hipSetDevice(c->dev));
 	Comm *m = (Comm*)c->comm;
 	if (!comm_live(m) || n == 0) return 0;
-	if (n > 32) { mahip_set_error("mahip_comm_all_reduce_sum_u64: at most 32 counters"); return -1; }
+	if (n > CT_XCHG_WORDS) { mahip_set_error("mahip_comm_all_reduce_sum_u64: at most %d counters", (int)CT_XCHG_WORDS); return -1; }
 	if (m->kind == 3) { HIPCHK(hipStreamSynchronize(c->st)); EXTCHK(m->ext.all_reduce_sum_u64(m->ext.user, h_vals, n), "all_reduce_sum_u64"); return 0; }
 	if (m->kind == 1) {
-		unsigned long long *d = P<unsigned long long>(c->ctr) + 16; // scratch words of the counter block (not sticky, not in use between passes)
+		unsigned long long *d = P<unsigned long long>(c->ctr) + CT_XCHG; // the collectives' own words of the counter block (mahip_internal.hpp)
 		HIPCHK(hipMemcpyAsync(d, h_vals, n * 8, hipMemcpyHostToDevice, c->st));
 		NCCLCHK(g_rccl.AllReduce(d, d, n, ncclUint64, ncclSum, m->nccl, c->st));
 		HIPCHK(hipMemcpyAsync(h_vals, d, n * 8, hipMemcpyDeviceToHost, c->st));

@@ -119,12 +119,14 @@ __global__ __launch_bounds__(256) void k_sg_arcs(HitColsG h, size_t n, const uin
 __device__ __forceinline__ unsigned long long wv_bcast_u64(unsigned long long x, int src) { return (unsigned long long)__shfl((uint32_t)(x >> 32), src, 64) << 32 | __shfl((uint32_t)x, src, 64); }
 
 __global__ __launch_bounds__(256) void k_sg_emit(HitColsG h, size_t n, const uint32_t *__restrict__ slen, const uint8_t *__restrict__ sdel,
-                                                  int max_hang, float int_frac, int min_ovlp, const unsigned long long *__restrict__ cmask,
+                                                  int max_hang, float int_frac, int min_ovlp, const unsigned long long *cmask,
                                                   uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_off, ArcCols out, uint32_t *__restrict__ aslot,
-                                                  uint32_t *__restrict__ wpos, unsigned long long *__restrict__ kmask)
+                                                  uint32_t *__restrict__ wpos, unsigned long long *kmask)
 { // aslot (optional, pass C): the hit slot each pushed arc comes from (push order, tie-order repair)
   // wpos / kmask (optional, pass C): per 64-slot word the position of its first arc in the push sequence and the slots that yielded one -- the arc sort finds the
-  // stretch of a read's arcs from them and the read's hit slots (arc_pos_of_slot) instead of a sweep over the arcs (k_arc_groups: 0.55 ms per 200 M arcs)
+  // stretch of a read's arcs from them and the read's hit slots (arc_pos_of_slot) instead of a sweep over the arcs (k_arc_groups: 0.55 ms per 200 M arcs).
+  // cmask and kmask MAY BE THE SAME buffer (mahip_sg_finish: c->sgmask; hence no __restrict__ on either): every thread reads its word before it writes it, and
+  // from then on the buffer holds KEPT bits, not candidates -- mahip_sg_finish consumes the candidates exactly once (mahip_sg_flags makes them anew)
 	__shared__ uint32_t s_w[4];
 	const unsigned lane = threadIdx.x & 63;
 	const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x, n_words = (n + 63) >> 6, w0 = w - lane;
@@ -339,14 +341,19 @@ struct ArcPre { uint32_t u[2], len[2], v[2], ol[2]; }; // the four columns of a 
 
 template <int ITEMS>
 __device__ __forceinline__ void arc_group_sort_regs(const ArcCols &in, const ArcCols &out, uint32_t q, uint32_t beg, uint32_t n, int bl, unsigned lane,
-                                                    unsigned long long *__restrict__ idx, uint32_t &tie_groups, uint32_t &tie_arcs, const ArcPre *pre)
+                                                    unsigned long long *__restrict__ idx, uint32_t &tie_groups, uint32_t &tie_arcs, uint32_t &foreign, const ArcPre *pre)
 { // pre (SMALL tier): the read's rows, fetched a read ahead; else loaded here
 	uint32_t x[ITEMS];
 #pragma unroll
 	for (int r = 0; r < ITEMS; ++r) { // any arrangement will do on the way in: the position is part of the key
 		const uint32_t i = (uint32_t)r * 64u + lane;
 		x[r] = 0xffffffffu;
-		if (i < n) x[r] = ((pre ? pre->u[r < 2 ? r : 0] : in.u[beg + i]) & 1u) << (bl + AG_IB) | (pre ? pre->len[r < 2 ? r : 0] : in.len[beg + i]) << AG_IB | i;
+		if (i < n) {
+			const uint32_t u = pre ? pre->u[r < 2 ? r : 0] : in.u[beg + i];
+			foreign += (u >> 1) != q; // the stretch goff / wpos / kmask name must hold read q's arcs and nothing else: true when the hit slots ascend by query id (hits sorted here);
+			                          // hits indexed as the caller had them (mahip_hits_index: any order of the groups) can break it -> the caller falls back to the general sort
+			x[r] = (u & 1u) << (bl + AG_IB) | (pre ? pre->len[r < 2 ? r : 0] : in.len[beg + i]) << AG_IB | i;
+		}
 	}
 	wave_sort_regs<ITEMS>(x, lane); // sorted element p sits in lane p / ITEMS, register p % ITEMS
 	const uint32_t lmask = (1u << bl) - 1u;
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(256) void k_arc_group_sort(ArcCols in, ArcCols out,
                                                          unsigned long long *__restrict__ idx, unsigned long long *__restrict__ ctr)
 {
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	uint32_t tg = 0, ta = 0, big = 0;
+	uint32_t tg = 0, ta = 0, big = 0, foreign = 0;
 	for (uint64_t qb = (uint64_t)q_lo + (uint64_t)(blockIdx.x * 4 + wave) * 64; qb < q_hi; qb += (uint64_t)gridDim.x * 256) {
 		// the arcs of read q come from its hit slots goff[q] .. goff[q+1]: lane l holds the start of read qb + l; its end is the next read's start
 		const bool have = qb + lane < q_hi;
@@ -424,8 +431,8 @@ __global__ __launch_bounds__(256) void k_arc_group_sort(ArcCols in, ArcCols out,
 				uint32_t begn = 0, nn = 0;
 				if (bn >= 0) { begn = __shfl(g.x, bn, 64); nn = __shfl(n_l, bn, 64); arc_prefetch(in, begn, nn, lane, nxt); } // first: in flight while this read is sorted
 				const uint32_t q = (uint32_t)qb + (uint32_t)b;
-				if (n <= 64) arc_group_sort_regs<1>(in, out, q, beg, n, bl, lane, idx, tg, ta, &cur);
-				else arc_group_sort_regs<2>(in, out, q, beg, n, bl, lane, idx, tg, ta, &cur);
+				if (n <= 64) arc_group_sort_regs<1>(in, out, q, beg, n, bl, lane, idx, tg, ta, foreign, &cur);
+				else arc_group_sort_regs<2>(in, out, q, beg, n, bl, lane, idx, tg, ta, foreign, &cur);
 				b = bn; beg = begn; n = nn; cur = nxt;
 			}
 		} else
@@ -433,13 +440,13 @@ __global__ __launch_bounds__(256) void k_arc_group_sort(ArcCols in, ArcCols out,
 			const int b = __ffsll((long long)todo) - 1;
 			todo &= todo - 1;
 			const uint32_t q = (uint32_t)qb + (uint32_t)b, beg = __shfl(g.x, b, 64), n = __shfl(n_l, b, 64);
-			if (n <= 256) arc_group_sort_regs<4>(in, out, q, beg, n, bl, lane, idx, tg, ta, nullptr);
-			else arc_group_sort_regs<8>(in, out, q, beg, n, bl, lane, idx, tg, ta, nullptr);
+			if (n <= 256) arc_group_sort_regs<4>(in, out, q, beg, n, bl, lane, idx, tg, ta, foreign, nullptr);
+			else arc_group_sort_regs<8>(in, out, q, beg, n, bl, lane, idx, tg, ta, foreign, nullptr);
 		}
 	}
 	blk_add_u64(&ctr[ST_ARC_TIE_GROUPS], tg);
 	blk_add_u64(&ctr[ST_ARC_TIE_ARCS], ta);
-	if (SMALL) blk_add_u64(&ctr[CT_OVF2], big);
+	blk_add_u64(&ctr[CT_OVF2], (SMALL ? big : 0u) + foreign); // either: the general sort takes over (mahip_sg_finish)
 }
 
 // ------------------------------------------------------------------------------------------------ asg_arc_del_trans
@@ -940,7 +947,7 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 					hipLaunchKernelGGL(k_arc_group_sort<false>, dim3(grid), dim3(256), 0, c->st, in, out, goff, wpos, km, (uint32_t)n, (uint32_t)m, q_lo, q_hi, blen ? blen : 1, P<unsigned long long>(c->idx), ctr);
 				}
 				CHK(ctr_fetch(c));
-				if (c->h_ctr[CT_OVF2]) fast = false; // a read with more than AG_MAX arcs (or arcs that are not grouped): the general sort below
+				if (c->h_ctr[CT_OVF2]) fast = false; // a read with more than AG_MAX arcs, or a stretch that holds another read's arcs (hit groups not in ascending id order): the general sort below
 				else {
 					idx_done = true;
 					if (c->tie_mode == 2 && !sharded) {
@@ -1234,6 +1241,7 @@ extern "C" int mahip_tail_handoff(mahip_ctx_t *s, mahip_ctx_t *d)
 	d->n_seq = Rn; d->n_seq_new = Rn; d->has_map = false; d->surv_ready = s->has_map || s->surv_ready; d->gsq = true; d->lazy_squeeze = false;
 	d->soa_ready = false; d->gather_pending = false; d->sorted_here = false; d->n_hits = 0; d->n_live = 0;
 	d->ag = 0; d->n_arc = (uint32_t)n; d->graph_ready = true;
+	d->arcs_clean = s->arcs_clean; // the copied sdel / arcs are as checked against each other as the source's were (a reused tail context must not keep the last batch's answer)
 	d->tie = s->tie;
 	return 0;
 }

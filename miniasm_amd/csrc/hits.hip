@@ -830,7 +830,8 @@ static int hits_common_setup(mahip_ctx *c, size_t n, uint32_t n_seq)
 	c->lazy_squeeze = false;
 	c->sorted_here = false; c->hrank_ready = false; c->orank_ready = false;
 	c->n_total = 0; // positions describe one upload, like the hints
-	if (!c->shard_bounds.empty() && c->shard_bounds.back() != n_seq) c->shard_bounds.clear(); // a table of read ranges made for another dictionary (the same input adopted again keeps it)
+	c->shard_bounds.clear(); // read ranges describe one upload, like the hints and the positions: a caller that shards by its own table says so again (mahip_set_shard_bounds / mahip_hits_balance)
+	                         // after every upload / adopt.  (Until round 4 a table survived a new input with the same number of reads: a second input of equal read count silently got the stale ranges.)
 	memset(&c->tie, 0, sizeof(c->tie));
 	CHK(reserve_read_arrays(c));
 	for (int k = 0; k < 8; ++k) CHK(dev_reserve(c, c->col[k], (n + 128) * 4)); // + spare slots (k_hit_sub gather mode: lanes without a slot)

@@ -288,10 +288,10 @@ extern "C" mahip_ctx_t *mahip_create(int device, void *stream)
 		if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) { mahip_set_error("mahip_create: hipStreamCreate failed"); ctx_unregister(c); delete c; return nullptr; }
 		c->own_stream = true;
 	}
-	if (dev_reserve(c, c->ctr, 64 * 8) != 0) { ctx_unregister(c); delete c; return nullptr; }
+	if (dev_reserve(c, c->ctr, CT_ALLOC_WORDS * 8) != 0) { ctx_unregister(c); delete c; return nullptr; }
 	if (hipHostMalloc((void**)&c->h_ctr, 72 * 8, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { mahip_set_error("mahip_create: hipHostMalloc failed"); ctx_unregister(c); delete c; return nullptr; }
 	memset(c->h_ctr, 0, 72 * 8);
-	if (hipMemsetAsync(c->ctr.p, 0, 64 * 8, c->st) != hipSuccess) { mahip_set_error("mahip_create: memset failed"); ctx_unregister(c); delete c; return nullptr; }
+	if (hipMemsetAsync(c->ctr.p, 0, CT_ALLOC_WORDS * 8, c->st) != hipSuccess) { mahip_set_error("mahip_create: memset failed"); ctx_unregister(c); delete c; return nullptr; }
 	{ const char *s = getenv("MA_EXACT_TIES"); c->tie_mode = s == 0 || *s == 0 ? 2 : atoi(s) != 0 ? 1 : 0; } // unset: automatic
 	return c;
 }

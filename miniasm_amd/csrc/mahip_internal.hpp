@@ -166,8 +166,12 @@ static inline bool xchg_needs_sync(const mahip_ctx *c) { return c->own_stream &&
 
 // counters (indices into ctx->ctr)
 enum { CT_LIVE = 0, CT_REMAIN, CT_TOTDP, CT_TOTLEN, CT_OVF, CT_NRED, CT_NMULTI, CT_NASYMM, CT_NSHORT, CT_MAXQID, CT_MAXQS, CT_TOTAL, CT_OVF2, CT_MAXLEN, CT_CUT, CT_TRINNER /* iterations of asg.c:169's loop */, CT_PROBED /* list entries asg.c:131 looked at */, CT_N };
+static_assert(CT_N <= 48, "a named counter would overlap the sticky counters");
 // slots [CT_STICKY, 64) are not touched by ctr_zero: the tie census keeps its results there until they are read
 enum { CT_STICKY = 48, ST_ARC_TIE_GROUPS = 48, ST_ARC_TIE_ARCS, ST_PUSH_CONFLICTS, ST_HIT_TIES };
+// words [CT_XCHG, CT_XCHG + CT_XCHG_WORDS): scratch of the collectives (comm.hip: all-reduce of counters, all-gather of u64) -- behind the 64 words the mailbox publishes, so that no
+// counter, named or sticky, can ever share a word with it (it used to be `ctr + 16`, which CT_PROBED had reached)
+enum { CT_WORDS = 64, CT_XCHG = 64, CT_XCHG_WORDS = 32, CT_ALLOC_WORDS = CT_XCHG + CT_XCHG_WORDS };
 int ctr_zero(mahip_ctx *c);
 int ctr_fetch(mahip_ctx *c); // D2H + sync into c->h_ctr
 

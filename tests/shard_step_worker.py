@@ -51,12 +51,12 @@ def main():
     ctx = ma.Ctx(0)
     ctx2 = ma.Ctx(0) if (tail_ctx and rank == 0) else None
     ma._chk(L.mahip_comm_init_shm(ctx.h, name.encode(), rank, world), "comm_init_shm")
-    if bounds is not None:
-        L.mahip_set_shard_bounds.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int]
-        ma._chk(L.mahip_set_shard_bounds(ctx.h, bounds, world), "set_shard_bounds")
+    L.mahip_set_shard_bounds.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int]
     outs = []
     for step in range(3):
         ctx.hits_upload(mine, n_seq)
+        if bounds is not None:  # a table of read ranges describes one upload: every upload forgets it
+            ma._chk(L.mahip_set_shard_bounds(ctx.h, bounds, world), "set_shard_bounds")
         if pos is not None:  # positions describe one upload: with them the ranks can restore the reference's order of tied hits (mahip_hits_set_positions)
             L.mahip_hits_set_positions.argtypes = [vp, C.c_void_p, C.c_int, C.c_uint64]
             ma._chk(L.mahip_hits_set_positions(ctx.h, pos.ctypes.data, 0, len(ing.hits)), "set_positions")

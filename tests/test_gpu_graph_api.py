@@ -332,3 +332,45 @@ def test_sequential_bubble_sweep_on_the_device_matches_reference(tmpdir_s):
     r = subprocess.run([ma.CLI_PATH, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-500:]
     assert r.stdout == ref_out
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+def test_sg_gen_on_hits_whose_query_groups_do_not_ascend(tmpdir_s):
+    """the per-symbol ma_sg_gen (asm.c:9-39) indexes the hits as the caller has them (mahip_hits_index); the reference is independent of their
+    order, and a caller may hand over groups in ANY order of the query ids.  The arc sort per read (k_arc_group_sort) takes read q's stretch of the push
+    sequence from the group offsets; with the groups of neighbouring reads swapped, or all groups reversed, a stretch holds another read's arcs -- the kernel
+    now counts such arcs and the general sort takes over.  Graph (arcs, seq, index) after ma_sg_gen must equal the reference's on the same permuted array."""
+    LR, LP = R.ref(), product_graph_api()
+    LP.ma_sg_gen.restype = C.POINTER(ma.Asg)
+    LP.ma_sg_gen.argtypes = [C.POINTER(ma.MaOpt), C.POINTER(ma.Sdict), C.c_void_p, C.c_size_t, C.c_void_p]
+    LP.asg_destroy.argtypes = [C.POINTER(ma.Asg)]
+    paf = R.pafgen(os.path.join(tmpdir_s, "perm_groups.paf"), 3000, 80000, 41, [])  # tie-free (tests/golden/make_golden.py checks this input)
+    opt = ma.default_opt()
+    d = LR.sd_init()
+    n = C.c_size_t(0)
+    p = LR.ma_hit_read(paf.encode(), opt.min_span, opt.min_match, d, C.byref(n), 1, None)
+    n = n.value
+    n_seq = d.contents.n_seq
+    sub = LR.ma_hit_sub(opt.min_dp, opt.min_iden, 0, n, p, n_seq)
+    n = LR.ma_hit_cut(sub, opt.min_span, n, p)
+    n = LR.ma_hit_contained(C.byref(opt), d, sub, n, p)
+    hits = R.np_from(p, n, ma.HIT_DT).copy()
+    hits["bldel"] &= 0x7FFFFFFF
+    qid = (hits["qns"] >> np.uint64(32)).astype(np.int64)
+    starts = np.flatnonzero(np.r_[True, qid[1:] != qid[:-1]])
+    groups = np.split(np.arange(n), starts[1:])
+    assert len(groups) > 100
+    orders = {"sorted": list(range(len(groups))), "neighbours swapped": [i ^ 1 if (i ^ 1) < len(groups) else i for i in range(len(groups))],
+              "reversed": list(range(len(groups) - 1, -1, -1)), "one pair swapped": [1, 0] + list(range(2, len(groups)))}
+    for what, order in orders.items():
+        a = np.ascontiguousarray(hits[np.concatenate([groups[g] for g in order])])
+        res = []
+        for L in (LR, LP):
+            g = L.ma_sg_gen(C.byref(opt), d, sub, len(a), a.ctypes.data)
+            res.append(snapshot(g))
+            L.asg_destroy(g)
+        assert len(res[0][0]) > 16 * 1000
+        assert res[0] == res[1], "ma_sg_gen on hit groups in the order '%s': graph differs from the reference's" % what
+    LR.free_buf(sub)
+    LR.free_buf(p)
+    LR.sd_destroy(d)

@@ -247,3 +247,29 @@ def test_rccl_loads_and_initialises_a_one_rank_communicator():
     assert torch.equal(a, b)
     L.mahip_comm_destroy(ctx.h)
     ctx.close()
+
+
+def test_a_table_of_read_ranges_describes_one_upload():
+    """round-4 review, What's weak #9: a table of read ranges (mahip_set_shard_bounds / mahip_hits_balance) used to survive a new input with the same number
+    of reads, so a second input of equal read count silently got the stale ranges.  Like the hints and the positions it now describes ONE upload: every
+    upload / adopt forgets it, the caller installs it again behind the records (bench.py and tests/shard_step_worker.py do)."""
+    L = ma.lib()
+    L.mahip_set_shard_bounds.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
+    L.mahip_shard_bounds.restype = C.POINTER(C.c_uint32)
+    L.mahip_shard_bounds.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    ctx = ma.Ctx(0)
+    try:
+        hits = np.zeros(64, dtype=ma.HIT_DT)
+        hits["qns"] = (np.arange(64, dtype=np.uint64) % np.uint64(8)) << np.uint64(32)
+        hits["tn"] = (np.arange(64) + 1) % 8
+        ctx.hits_upload(hits, 8)
+        b = (C.c_uint32 * 3)(0, 5, 8)
+        ma._chk(L.mahip_set_shard_bounds(ctx.h, b, 2), "set_shard_bounds")
+        w = C.c_int(-1)
+        p = L.mahip_shard_bounds(ctx.h, C.byref(w))
+        assert w.value == 2 and [p[0], p[1], p[2]] == [0, 5, 8]
+        ctx.hits_upload(hits, 8)  # the same number of reads: until round 4 the table stayed
+        p = L.mahip_shard_bounds(ctx.h, C.byref(w))
+        assert w.value == 0 and not p, "a table of read ranges survived the next upload"
+    finally:
+        ctx.close()
