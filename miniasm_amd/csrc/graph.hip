@@ -606,6 +606,179 @@ __global__ __launch_bounds__(256) void k_asg_trans(const uint32_t *__restrict__ 
 	blk_add_u64(&ctr[CT_TRINNER], n_inner);
 }
 
+// ---- the first tier (1 .. 128 arcs) as a four-stage software pipeline (round 5) ----
+// A vertex is a chain of dependent trips to memory: its own rows -> its neighbours' CSR words -> the list of the first neighbour (which asg.c:168 ALWAYS expands:
+// nothing has been marked 2 yet) -> the lists of the neighbours that are still marked 1 after that.  Round 4 fetched the rows a vertex ahead and paid the other trips per
+// vertex: at 200 M arcs, where every vertex has work, a wave spent 6 us per vertex, nearly all of it waiting (2.95 ms per launch, 0.27 of the roofline).  Here every trip but
+// the last is issued for a LATER vertex of the wave's chunk: stage 1 loads the rows of vertex t+3, stage 2 the CSR words of the neighbours of t+2, stage 3 the first
+// neighbour's list of t+1, while vertex t is reduced from registers and LDS.  What is left on the critical path are the expansions after the first one, and those are
+// batched: the lists of up to FOUR pending candidates are fetched at once, 16 entries each (a quarter of the wave per candidate; the far neighbours that survive the first
+// expansion have short prefixes inside L), and then replayed in the reference's order -- a candidate that an earlier one of its batch marked is skipped, as asg.c:168 would.
+// The overlap words are not carried through the pipeline: they are fetched when a vertex is taken up and used when its flags are written.
+struct TrItem { uint32_t st, nv, nvp; uint32_t v[2], l[2], dead; uint32_t ws[2], nw[2]; uint32_t el[2], ev[2], n0; }; // nvp: arcs this kernel will expand from (0: dead read, no vertex)
+
+__global__ __launch_bounds__(256) void k_asg_trans_pipe(const uint32_t *__restrict__ av, const uint32_t *__restrict__ alen, uint32_t *__restrict__ aol,
+                                                         const unsigned long long *__restrict__ idx, const uint8_t *__restrict__ sdel, uint32_t v_beg, uint32_t n_vtx,
+                                                         uint32_t fuzz, unsigned long long *__restrict__ ctr)
+{
+	constexpr int CAP = 128, HASH = 256;
+	__shared__ uint32_t s_l[4][CAP], s_slot[4][CAP], s_hk[4][HASH], s_hm[4][HASH], s_ws[4][CAP], s_nw[4][CAP];
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t *ll = s_l[wave], *slot = s_slot[wave], *hk = s_hk[wave], *hm = s_hm[wave], *lws = s_ws[wave], *lnw = s_nw[wave];
+	uint32_t n_red = 0, n_inner = 0;
+	for (uint64_t vb = (uint64_t)v_beg + (uint64_t)(blockIdx.x * 4 + wave) * 64; vb < n_vtx; vb += (uint64_t)gridDim.x * 256) {
+		const unsigned long long xl = vb + lane < n_vtx ? idx[vb + lane] : 0ull;
+		const uint32_t nvl = (uint32_t)xl;
+		unsigned long long todo = wv_ballot(nvl != 0 && nvl <= (uint32_t)CAP);
+		// the stages; an item without a vertex (bit < 0) has nv = 0 and issues nothing -- no branch around the loads, so that the waits stay counted
+		auto stage1 = [&](int bit, TrItem &p) {
+			const unsigned long long x = __shfl(xl, bit < 0 ? 0 : bit, 64);
+			p.st = (uint32_t)(x >> 32); p.nv = bit < 0 ? 0u : (uint32_t)x;
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const uint32_t i = (uint32_t)r * 64u + lane;
+				p.v[r] = p.l[r] = 0;
+				if (i < p.nv) { p.v[r] = av[p.st + i]; p.l[r] = alen[p.st + i]; }
+			}
+			p.dead = bit < 0 ? 0u : sdel[((uint32_t)vb + (uint32_t)bit) >> 1];
+		};
+		auto stage2 = [&](TrItem &p) { // the rows have arrived: the CSR words of the neighbours
+			p.nvp = p.dead ? 0u : p.nv;
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const uint32_t i = (uint32_t)r * 64u + lane;
+				p.ws[r] = p.nw[r] = 0;
+				if (i < p.nvp) { const unsigned long long xw = idx[p.v[r]]; p.ws[r] = (uint32_t)(xw >> 32); p.nw[r] = (uint32_t)xw; }
+			}
+		};
+		auto stage3 = [&](TrItem &p) { // the CSR words have arrived: the list of the first neighbour (lane 0, row 0), up to 128 entries of it
+			const uint32_t ws0 = __shfl(p.ws[0], 0, 64);
+			p.n0 = p.nvp ? __shfl(p.nw[0], 0, 64) : 0u;
+			const uint32_t m = p.n0 < 128u ? p.n0 : 128u;
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const uint32_t j = (uint32_t)r * 64u + lane;
+				p.el[r] = p.ev[r] = 0;
+				if (j < m) { p.el[r] = alen[ws0 + j]; p.ev[r] = av[ws0 + j]; }
+			}
+		};
+		auto next_bit = [&]() { int b = -1; if (todo) { b = __ffsll((long long)todo) - 1; todo &= todo - 1; } return b; };
+		TrItem c0, c1, c2, c3; // c0: being reduced; c1: stage 3 issued; c2: stage 2 issued; c3: stage 1 issued
+		int b0 = next_bit(), b1 = next_bit(), b2 = next_bit(), b3;
+		stage1(b0, c0); stage1(b1, c1); stage1(b2, c2);
+		stage2(c0); stage2(c1);
+		stage3(c0);
+		while (b0 >= 0) {
+			b3 = next_bit();
+			stage1(b3, c3); stage2(c2); stage3(c1);
+			__builtin_amdgcn_sched_barrier(0);
+			const uint32_t st = c0.st, nv = c0.nv;
+			if (c0.dead) { // asg.c:158-161: all arcs of a deleted read go
+				for (uint32_t i = lane; i < nv; i += 64) aol[st + i] |= ADEL, ++n_red;
+			} else {
+				uint32_t o[2];
+#pragma unroll
+				for (int r = 0; r < 2; ++r) { const uint32_t i = (uint32_t)r * 64u + lane; o[r] = i < nv ? aol[st + i] : 0u; } // used when the flags are written
+				uint32_t hbits = 6; while ((1u << hbits) < 2 * nv) ++hbits;
+				const uint32_t hsize = 1u << hbits, hmask = hsize - 1;
+#pragma unroll
+				for (int r = 0; r < 2; ++r) {
+					const uint32_t i = (uint32_t)r * 64u + lane;
+					if (i < nv) { ll[i] = c0.l[r]; lws[i] = c0.ws[r]; lnw[i] = c0.nw[r]; }
+				}
+				for (uint32_t s = lane; s < hsize; s += 64) hk[s] = TR_EMPTY, hm[s] = 0xffffffffu; // hm[slot] = (index of the FIRST arc to this target) << 2 | mark
+				wv_sync();
+#pragma unroll
+				for (int r = 0; r < 2; ++r) { // mark all neighbours 1 (asg.c:162); duplicates share a slot
+					const uint32_t i = (uint32_t)r * 64u + lane;
+					if (i < nv) {
+						const uint32_t key = c0.v[r];
+						uint32_t s = tr_hash(key, hbits);
+						for (;;) {
+							const uint32_t old = atomicCAS(&hk[s], TR_EMPTY, key);
+							if (old == TR_EMPTY || old == key) { atomicMin(&hm[s], i << 2 | 1u); slot[i] = s; break; }
+							s = (s + 1) & hmask;
+						}
+					}
+				}
+				wv_sync();
+				const uint32_t L = ll[nv - 1] + fuzz; // asg.c:163
+				auto expand_rest = [&](uint32_t ws, uint32_t nw, uint32_t li, uint32_t from) { // lanes over w's arcs from entry `from` on; sorted by len => the loop of asg.c:169 is a prefix
+					for (uint32_t j0 = from; j0 < nw; j0 += 64) {
+						const uint32_t j = j0 + lane;
+						const int ok = j < nw;
+						const uint32_t lx = ok ? alen[ws + j] : 0, y = ok ? av[ws + j] : 0;
+						int cond = ok && lx + li <= L;
+						const uint64_t fail = wv_ballot(ok && !cond);
+						if (fail) cond = cond && lane < (unsigned)(__ffsll((long long)fail) - 1);
+						if (cond) { ++n_inner; const int sx = tr_find(hk, y, hbits); if (sx >= 0) hm[sx] = (hm[sx] & ~3u) | 2u; } // every writer stores the same word
+						if (fail) break;
+					}
+				};
+				{ // the first neighbour: always expanded (asg.c:168: its mark is still 1), its list is in registers
+					const uint32_t li = ll[0], n0 = c0.n0;
+					bool more = true;
+#pragma unroll
+					for (int r = 0; r < 2; ++r) {
+						const uint32_t j = (uint32_t)r * 64u + lane;
+						const int ok = more && j < n0 && j < 128u;
+						int cond = ok && c0.el[r] + li <= L;
+						const uint64_t fail = wv_ballot(ok && !cond);
+						if (fail) cond = cond && lane < (unsigned)(__ffsll((long long)fail) - 1);
+						if (cond) { ++n_inner; const int sx = tr_find(hk, c0.ev[r], hbits); if (sx >= 0) hm[sx] = (hm[sx] & ~3u) | 2u; }
+						if (fail) more = false;
+					}
+					if (more && n0 > 128u) expand_rest(lws[0], n0, li, 128u);
+					wv_sync();
+				}
+				for (uint32_t base = 0; base < nv; base += 64) {
+					const uint32_t i = base + lane;
+					const uint32_t myslot = i < nv ? slot[i] : 0;
+					uint64_t passed = base == 0 ? 1ull : 0ull; // lanes of this chunk the walk has gone past
+					for (;;) {
+						uint64_t cand = wv_ballot(i < nv && (hm[myslot] & 3u) == 1u) & ~passed;
+						if (!cand) break;
+						// up to four pending candidates, a quarter of the wave each: 16 entries of each list in ONE trip
+						int cb[4];
+#pragma unroll
+						for (int k = 0; k < 4; ++k) { cb[k] = cand ? __ffsll((long long)cand) - 1 : -1; cand &= cand - 1; }
+						const unsigned g = lane >> 4, sub = lane & 15u;
+						const int mine = g == 0 ? cb[0] : g == 1 ? cb[1] : g == 2 ? cb[2] : cb[3];
+						const uint32_t i0 = base + (uint32_t)(mine < 0 ? 0 : mine);
+						const uint32_t li_g = ll[i0], ws_g = lws[i0], nw_g = mine < 0 ? 0u : lnw[i0];
+						const int ok = sub < nw_g;
+						const uint32_t lx = ok ? alen[ws_g + sub] : 0, y = ok ? av[ws_g + sub] : 0;
+#pragma unroll
+						for (int k = 0; k < 4; ++k) {
+							if (cb[k] < 0) break; // (uniform)
+							const uint32_t ik = base + (uint32_t)cb[k];
+							passed |= cb[k] == 63 ? ~0ull : ((2ull << cb[k]) - 1ull);
+							if ((hm[slot[ik]] & 3u) != 1u) continue; // an earlier candidate of this batch marked it: asg.c:168 skips it (uniform: every lane reads the same word)
+							const int in = g == (unsigned)k;
+							int cond = in && ok && lx + li_g <= L;
+							const uint64_t fail = wv_ballot(in && ok && !cond);
+							if (fail) cond = cond && lane < (unsigned)(__ffsll((long long)fail) - 1);
+							if (cond) { ++n_inner; const int sx = tr_find(hk, y, hbits); if (sx >= 0) hm[sx] = (hm[sx] & ~3u) | 2u; }
+							const uint32_t nwk = lnw[ik];
+							if (!fail && nwk > 16u) expand_rest(lws[ik], nwk, ll[ik], 16u); // a long prefix: the rest of the list, the whole wave over it
+							wv_sync();
+						}
+					}
+				}
+				// asg.c:181-184: the sweep resets mark[target] at the first arc to a target, so of several arcs to one
+				// reduced target (multi-arcs are still present here) only the first is deleted
+#pragma unroll
+				for (int r = 0; r < 2; ++r) { const uint32_t i = (uint32_t)r * 64u + lane; if (i < nv && hm[slot[i]] == (i << 2 | 2u)) aol[st + i] = o[r] | ADEL, ++n_red; }
+				wv_sync();
+			}
+			b0 = b1; b1 = b2; b2 = b3;
+			c0 = c1; c1 = c2; c2 = c3;
+		}
+	}
+	blk_add_u64(&ctr[CT_NRED], n_red);
+	blk_add_u64(&ctr[CT_TRINNER], n_inner);
+}
+
 // second tier: vertices with more than TR_CAP arcs; one block per vertex with a private global mark array
 // (the reference's own data structure, asg.c:153), lanes over the inner loop.
 __global__ __launch_bounds__(256) void k_asg_trans_big(const uint32_t *__restrict__ av, const uint32_t *__restrict__ alen, uint32_t *__restrict__ aol,
@@ -1295,8 +1468,13 @@ extern "C" int mahip_asg_del_trans_range(mahip_ctx_t *c, int fuzz, uint32_t v_be
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	if (v_end > v_beg && c->n_arc) {
 		ProfScope ps(c, "k_asg_trans", 32.0 * (double)c->n_arc); // 16*(A+I)/A per arc, I ~ A on clean data
+		static const bool old_small = getenv("MA_TRANS_OLD") != nullptr; // A/B handle: round 4's first tier (rows a vertex ahead, every other trip paid per vertex)
+		if (old_small)
 		hipLaunchKernelGGL((k_asg_trans<128, 256, true>), dim3(grid_for(((size_t)(v_end - v_beg) + 63) / 64, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
 		                   (const unsigned long long*)P<unsigned long long>(c->idx), (const uint8_t*)P<uint8_t>(c->sdel), v_beg, v_end, (uint32_t)fuzz, P<uint32_t>(c->ovf), ctr);
+		else
+		hipLaunchKernelGGL(k_asg_trans_pipe, dim3(grid_for(((size_t)(v_end - v_beg) + 63) / 64, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
+		                   (const unsigned long long*)P<unsigned long long>(c->idx), (const uint8_t*)P<uint8_t>(c->sdel), v_beg, v_end, (uint32_t)fuzz, ctr);
 		hipLaunchKernelGGL((k_asg_trans<TR_CAP, TR_HASH, false>), dim3(grid_for(((size_t)(v_end - v_beg) + 63) / 64, 4, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint32_t*)a.v, (const uint32_t*)a.len, a.ol,
 		                   (const unsigned long long*)P<unsigned long long>(c->idx), (const uint8_t*)P<uint8_t>(c->sdel), v_beg, v_end, (uint32_t)fuzz, P<uint32_t>(c->ovf), ctr);
 	}

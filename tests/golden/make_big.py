@@ -47,6 +47,19 @@ def md5_file(path):
     return h.hexdigest(), n
 
 
+def head_tail_md5(path, span=16 << 20):
+    """md5 over the first and the last `span` bytes + the size: what the GPU-side checks use to recognise the regenerated PAF without hashing 30 GB"""
+    n = os.path.getsize(path)
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        h.update(f.read(min(span, n)))
+        if n > span:
+            f.seek(max(span, n - span))
+            h.update(f.read())
+    h.update(str(n).encode())
+    return h.hexdigest()
+
+
 def md5_stdout(cmd):
     """run cmd, digest its stdout while it runs; returns (md5, bytes, wall seconds, max RSS in MB)"""
     h, n, t0 = hashlib.md5(), 0, time.time()
@@ -62,14 +75,15 @@ def md5_stdout(cmd):
 
 
 def main():
-    names = sys.argv[1:] or list(CONFIGS)
+    names = [a for a in sys.argv[1:] if not a.startswith("--")] or list(CONFIGS)
     if not os.path.exists(REF_BIN):
         sys.exit("oracle/_ref/miniasm_ref is missing: run `make -C oracle ref` where /root/reference exists")
     gold = json.load(open(OUT)) if os.path.exists(OUT) else {"reference_version": "0.3-r179", "what": __doc__.split("\n\n")[2], "inputs": {}}
     tmp = os.environ.get("MA_BIG_DIR", "/tmp")
     for name in names:
         cfg = CONFIGS[name]
-        if name in gold["inputs"] and gold["inputs"][name]["pafgen"] == cfg and "--force" not in sys.argv:
+        have = gold["inputs"].get(name)
+        if have and have["pafgen"] == cfg and "--force" not in sys.argv and "paf_head_tail_md5" in have:
             print("[make_big] %s: already recorded" % name)
             continue
         paf = os.path.join(tmp, "make_big_%s.paf" % name)
@@ -78,10 +92,18 @@ def main():
         t_gen = time.time() - t0
         try:
             paf_md5, paf_bytes = md5_file(paf)
+            ht = head_tail_md5(paf)
+            if have and have["pafgen"] == cfg and "--force" not in sys.argv:  # recorded before the head/tail digest existed: the text must be the recorded one, the reference need not run again
+                assert (have["paf_md5"], have["paf_bytes"]) == (paf_md5, paf_bytes), "%s: the generator no longer writes the recorded text" % name
+                have["paf_head_tail_md5"] = ht
+                with open(OUT, "w") as f:
+                    json.dump(gold, f, indent=1, sort_keys=True)
+                print("[make_big] %s: head/tail digest added" % name)
+                continue
             gfa_md5, gfa_bytes, wall, rss = md5_stdout(["taskset", "-c", "0", REF_BIN, paf])
         finally:
             os.remove(paf)
-        gold["inputs"][name] = dict(pafgen=cfg, paf_md5=paf_md5, paf_bytes=paf_bytes, gfa_md5=gfa_md5, gfa_bytes=gfa_bytes,
+        gold["inputs"][name] = dict(pafgen=cfg, paf_md5=paf_md5, paf_bytes=paf_bytes, paf_head_tail_md5=ht, gfa_md5=gfa_md5, gfa_bytes=gfa_bytes,
                                     reference_wall_s=round(wall, 1), reference_max_rss_mb=rss, pafgen_s=round(t_gen, 1),
                                     host="%s, %d cores" % (next((l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?"), os.cpu_count()))
         with open(OUT, "w") as f:
