@@ -25,6 +25,8 @@ mahip_ctx_t *mahip_create(int device, void *stream);
 void mahip_destroy(mahip_ctx_t *c);
 const char *mahip_strerror(void);
 int mahip_sync(mahip_ctx_t *c);
+/* one trivial kernel launch + wait (start-up timing: the first launch of a process loads the code object) */
+int mahip_first_launch(mahip_ctx_t *c);
 
 /* ---- hits ------------------------------------------------------------------------------------------ */
 /* n unsorted (or sorted) 32-byte ma_hit_t records, reads numbered [0,n_seq).  upload = H2D copy of a host

@@ -336,6 +336,13 @@ extern "C" int mahip_xbuf(mahip_ctx_t *c, int slot, size_t bytes, void **d_ptr)
 	return 0;
 }
 
+// one trivial launch + wait: the first launch of a process loads the library's code object onto the device; callers that time their start-up make that cost visible with this
+extern "C" int mahip_first_launch(mahip_ctx_t *c)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	return ctr_fetch(c);
+}
+
 extern "C" int mahip_sync(mahip_ctx_t *c)
 {
 	HIPCHK(hipSetDevice(c->dev));

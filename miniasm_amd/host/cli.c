@@ -101,5 +101,14 @@ int main(int argc, char *argv[])
 	fprintf(stderr, "[M::%s] CMD:", __func__);
 	for (i = 0; i < argc; ++i) fprintf(stderr, " %s", argv[i]);
 	fprintf(stderr, "\n[M::%s] Real time: %.3f sec; CPU: %.3f sec\n", __func__, sys_realtime(), sys_cputime());
+	/* The result is complete.  What a normal return would still do -- hand every device buffer back one hipFree at a time (tens of GB at BASELINE configs[3]: each unmaps),
+	 * then the HIP runtime's own exit handlers -- is 0.1 s and more of a 0.5 s run and produces nothing: the driver reclaims a process's memory when it is gone.
+	 * So: flush, report a failed write as the exit status, and leave.  MA_CLEAN_EXIT=1 takes the long road (leak checks, tools that want the teardown exercised). */
+	{
+		int bad = fflush(stdout) != 0 || ferror(stdout);
+		fflush(stderr);
+		if (bad) { fprintf(stderr, "[E::%s] could not write the output\n", __func__); _exit(1); }
+		if (getenv("MA_CLEAN_EXIT") == 0) _exit(0);
+	}
 	return 0;
 }

@@ -45,8 +45,18 @@ mahip_ctx_t *ma_gpu(void)
 	if (g_ctx == 0) {
 		const char *s = getenv("MA_GPU_DEVICE");
 		if (s == 0) s = getenv("LOCAL_RANK");
+		const int timing = getenv("MA_PIPE_TIMING") != 0;
+		double t0 = sys_realtime(), t1, t2, t3;
+		int n_dev = mahip_device_count(); /* the first HIP call: the runtime comes up here (driver, queues, the code objects are registered) */
+		t1 = sys_realtime();
 		g_ctx = mahip_create(s ? atoi(s) : 0, 0);
 		if (g_ctx == 0) ma_gpu_fail("ma_gpu");
+		t2 = sys_realtime();
+		if (timing) { /* the first launch loads the library's code object onto the device: made visible here, otherwise it hides in the first pass that launches */
+			mahip_first_launch(g_ctx);
+			t3 = sys_realtime();
+			fprintf(stderr, "[T::init] at %.3f s after main: HIP runtime %.3f s (%d devices)  context (stream, counters, pinned mailbox) %.3f s  first launch + sync %.3f s\n", t0, t1 - t0, n_dev, t2 - t1, t3 - t2);
+		}
 		atexit(ma_gpu_shutdown);
 	}
 	return g_ctx;

@@ -178,3 +178,40 @@ def arc_tie_groups(sg_text):
         k = (f[1], f[2], f[6])
         seen[k] = seen.get(k, 0) + 1
     return sum(1 for v in seen.values() if v > 1)
+
+
+# ---- reference digests of the large configurations (tests/golden/big.json, written by tests/golden/make_big.py from the unmodified reference binary)
+def big_golden():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "big.json")) as f:
+        return json.load(f)["inputs"]
+
+
+def head_tail_md5(path, span=16 << 20):
+    """the digest make_big.py records to recognise a regenerated PAF without hashing all of it: first + last 16 MiB + size"""
+    n = os.path.getsize(path)
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        h.update(f.read(min(span, n)))
+        if n > span:
+            f.seek(max(span, n - span))
+            h.update(f.read())
+    h.update(str(n).encode())
+    return h.hexdigest()
+
+
+def md5_of_stdout(cmd, env=None, timeout=None):
+    """run cmd, digest its stdout while it runs (a 500 M-overlap GFA need not be held): (md5, bytes, stderr tail)"""
+    h, n = hashlib.md5(), 0
+    with subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) as pr:
+        import threading
+        err = []
+        t = threading.Thread(target=lambda: err.append(pr.stderr.read()))
+        t.start()
+        for blk in iter(lambda: pr.stdout.read(1 << 24), b""):
+            h.update(blk)
+            n += len(blk)
+        pr.wait(timeout=timeout)
+        t.join()
+    assert pr.returncode == 0, "%s: exit %d: %s" % (cmd[0], pr.returncode, (err[0] if err else b"")[-2000:].decode(errors="replace"))
+    return h.hexdigest(), n, (err[0] if err else b"").decode(errors="replace")

@@ -202,5 +202,40 @@ pmc)
     find gpurun_out/pmc_$ctr -name "*.csv" | head -5
   done
   python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_summary.json 2> gpurun_out/pmc_summary.log; tail -3 gpurun_out/pmc_summary.log; head -c 3000 gpurun_out/pmc_summary.json ;;
+evidence)
+  # the round's evidence at the current commit (what tools/gpu_r4z.sh did in round 4): rocprofv3 kernel stats and PMC traffic of the bench command at BASELINE configs[3] and on
+  # the graph-heavy input -> gpurun_out/ev/{rocprofv3_kernel_stats,pmc_traffic}_{cfg4,gh}.*; copy them to profiles/rNN_* afterwards
+  O=gpurun_out/ev; mkdir -p $O
+  GH="--reads 2000000 --lines 100000000 --seed 4 --model fixed"
+  for wl in ${EVIDENCE_WORKLOADS:-cfg4 gh}; do
+    case $wl in cfg4) A="";; gh) A="$GH";; esac
+    rm -rf $O/prof_$wl; mkdir -p $O/prof_$wl
+    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /root/repo/$O/prof_$wl -o r --output-format csv -- python /root/repo/bench.py $A --steps 5 --warmup 1 --no-cpu --no-legs --no-text --prof-steps 0 > /root/repo/$O/prof_$wl/bench.json 2> /root/repo/$O/prof_$wl/bench.log); echo "rocprof $wl rc=$?"
+    f=$(find $O/prof_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/rocprofv3_kernel_stats_$wl.csv && head -12 $f | cut -c1-140
+    find $O/prof_$wl -name "*.csv" ! -name "*stats*" -delete 2>/dev/null
+    for ctr in FETCH_SIZE WRITE_SIZE; do
+      rm -rf $O/pmc_${wl}_$ctr; mkdir -p $O/pmc_${wl}_$ctr
+      (cd /tmp && timeout 900 rocprofv3 --pmc $ctr --kernel-trace -d /root/repo/$O/pmc_${wl}_$ctr -o r --output-format csv -- python /root/repo/bench.py $A --steps 2 --warmup 1 --no-cpu --no-legs --no-text --prof-steps 0 > /root/repo/$O/pmc_${wl}_$ctr/bench.json 2> /root/repo/$O/pmc_${wl}_$ctr/bench.log); echo "pmc $wl $ctr rc=$?"
+    done
+    python tools/pmc_summary.py $O/pmc_${wl}_FETCH_SIZE $O/pmc_${wl}_WRITE_SIZE > $O/pmc_traffic_$wl.json 2> $O/pmc_$wl.log; tail -1 $O/pmc_$wl.log
+    find $O/pmc_${wl}_FETCH_SIZE $O/pmc_${wl}_WRITE_SIZE -name "*.csv" -size +1M -delete 2>/dev/null
+  done ;;
+benchsum)
+  # the default bench line (as the driver runs it) + a one-screen summary
+  timeout 1700 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.log; echo "bench rc=$?"
+  python3 - <<'PY'
+import json
+try:
+    d = json.load(open("gpurun_out/bench_default.json"))
+    print("ms_per_step %.3f  value %.4g  gfa_identical %s  latency %s  e2e %s  from_text %s" % (d["ms_per_step"], d["value"], d["gfa_identical"], d.get("latency") and d["latency"]["ms"], d.get("e2e") and round(d["e2e"]["wall_s"], 3), d.get("from_text") and round(d["from_text"]["ms_per_step"], 2)))
+    r = d["roofline"]; print("roofline (sort group): %.3f ms frac %.3f | dominant %s %.3f ms frac %.3f | hit_chain %.3f" % (r["avg_launch_ms"], r["frac"], r["dominant_kernel"]["kernel"], r["dominant_kernel"]["avg_launch_ms"], r["dominant_kernel"]["frac"], r["hit_chain"]["frac"]))
+    rg = r.get("reduce_group"); print("reduce_group:", rg and (rg["ms_per_step"], rg["frac"], rg["slowest_by_8d"]), rg and [(k["name"], k["avg_ms"]) for k in rg["kernels"]])
+    for n, l in d["legs"].items(): print("leg %-12s %s  identical %s / %s" % (n, ("%.3f ms/step" % l["ms_per_step"]) if "ms_per_step" in l else ("%.3f s wall" % l["wall_s"]), l.get("gfa_identical"), l.get("gfa_md5_matches_reference", l.get("gfa_md5_matches_recorded_reference"))))
+    print("cpu_baseline", d["cpu_baseline"] and d["cpu_baseline"]["value"])
+    for k in d["kernels"][:12]: print("  %-28s x%-4g %.3f ms" % (k["name"], k["launches_per_step"], k["avg_ms"]))
+except Exception as e:
+    print("bench summary failed:", e)
+PY
+  ;;
 esac
 done
