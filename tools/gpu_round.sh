@@ -202,6 +202,27 @@ pmc)
     find gpurun_out/pmc_$ctr -name "*.csv" | head -5
   done
   python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_summary.json 2> gpurun_out/pmc_summary.log; tail -3 gpurun_out/pmc_summary.log; head -c 3000 gpurun_out/pmc_summary.json ;;
+transab)
+  # asg_arc_del_trans, first tier: round 5's pipelined kernel (default) against round 4's (MA_TRANS_OLD=1) on the graph-heavy input (100 M overlaps, 200 M arcs): HIP-event kernel times of bench.py
+  GH="--reads 2000000 --lines 100000000 --seed 4 --model fixed"
+  for v in "" "MA_TRANS_OLD=1" ""; do
+    env $v timeout 900 python bench.py $GH --steps 4 --warmup 1 --prof-steps 3 --no-cpu --no-legs --no-text > gpurun_out/bench_transab.json 2> gpurun_out/bench_transab.log; echo "[${v:-pipelined}] rc=$?"
+    python3 -c "
+import json; d=json.load(open('gpurun_out/bench_transab.json')); print('   ms_per_step %.3f' % d['ms_per_step']); [print('   %-26s x%-4g %.3f ms' % (k['name'], k['launches_per_step'], k['avg_ms'])) for k in d['kernels'] if k['name'] in ('k_asg_trans','k_arc_group_sort','k_arc_rm','k_arc_index','k_asg_symm')]"
+  done ;;
+initlaps)
+  # where a command-line run spends its start and its end: [T::init] laps, wall with the fast exit (default) and with the full teardown (MA_CLEAN_EXIT=1); configs[2] stand-in (40 M) and configs[3] (100 M)
+  miniasm_amd/bin/pafgen -r 1200000 -n 40000000 -s 4 -o /tmp/il40.paf 2>/dev/null
+  miniasm_amd/bin/pafgen -r 2000000 -n 100000000 -s 2 -o /tmp/il100.paf 2>/dev/null
+  for f in /tmp/il40.paf /tmp/il100.paf; do
+    cat $f > /dev/null
+    for v in "" "MA_CLEAN_EXIT=1" "" "MA_CLEAN_EXIT=1"; do
+      t0=$(date +%s.%N); env $v timeout 600 miniasm_amd/bin/miniasm $f 2> gpurun_out/initlaps.log | md5sum | cut -c1-12; t1=$(date +%s.%N)
+      python3 -c "print(\"## $f [${v:-fast exit}]: %.3f s wall\" % ($t1 - $t0))"; grep "Real time" gpurun_out/initlaps.log
+    done
+    MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm $f 2>&1 >/dev/null | grep -E "T::init|T::paf|T::xfer|T::ingest|T::head|T::pipeline|T::tail|ma_hit_read|Real time" | head -30
+    LD_DEBUG=statistics miniasm_amd/bin/miniasm -V 2>&1 | grep -E "total startup|relocation|load" | head -4
+  done ;;
 evidence)
   # the round's evidence at the current commit (what tools/gpu_r4z.sh did in round 4): rocprofv3 kernel stats and PMC traffic of the bench command at BASELINE configs[3] and on
   # the graph-heavy input -> gpurun_out/ev/{rocprofv3_kernel_stats,pmc_traffic}_{cfg4,gh}.*; copy them to profiles/rNN_* afterwards
