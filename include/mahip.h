@@ -95,6 +95,12 @@ int mahip_hits_have_positions(mahip_ctx_t *c);
 /* optional: an upper bound of the query starts (e.g. the longest read) lets the on-demand (qid,qs) sorts (hit dumps, push order
  * of the arcs) plan their digits without a sweep over the records; 0 = unknown */
 int mahip_set_hints(mahip_ctx_t *c, uint32_t max_qs);
+/* optional: how the records of one query's own PAF lines stand in the array: 2 = record and mirror side by side (what ma_hit_read stores with bi_dir, hit.c:87-98),
+ * 1 = no mirrored records, 0 = unknown (default).  With 1 or 2 mahip_hits_sort sorts RUNS of records (about half as many keys at stride 2) and expands them
+ * afterwards; the result is the same grouping in input order, and it falls back to sorting records by itself when the hint does not fit the data.  Describes one
+ * upload/adopt, like the other hints. */
+int mahip_set_run_stride(mahip_ctx_t *c, int stride);
+uint64_t mahip_hits_sorted_runs(mahip_ctx_t *c); /* elements of the last mahip_hits_sort if it sorted runs, else 0 */
 /* Bulk copies between pageable host memory and device memory at PCIe speed: worker threads stage slices through
  * pinned slots while their DMAs run (a plain hipMemcpy of pageable memory is staged by one runtime thread).
  * Synchronous; ordered after the work already queued on the context's stream.  MA_XFER_THREADS sets the workers. */

@@ -104,6 +104,7 @@ def lib():
         L.mahip_hits_adopt.argtypes = [vp, vp, sz, u32]
         L.mahip_set_shard.argtypes = [vp, u32, u32]
         L.mahip_set_hints.argtypes = [vp, u32]
+        L.mahip_set_run_stride.argtypes = [vp, i32]
         L.mahip_set_exact_ties.argtypes = [vp, i32]
         L.mahip_tie_stats.argtypes = [vp, C.POINTER(TieInfo)]
         L.mahip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
@@ -203,6 +204,10 @@ class Ctx:
         self._keep = hits
         _chk(lib().mahip_hits_upload(self.h, hits.ctypes.data, len(hits), n_seq), "hits_upload")
         _chk(lib().mahip_sync(self.h), "sync")
+
+    def set_run_stride(self, stride):
+        """hint for the sort (include/mahip.h): 2 = records and mirrors side by side, 1 = no mirrors, 0 = unknown; describes one upload"""
+        _chk(lib().mahip_set_run_stride(self.h, int(stride)), "set_run_stride")
 
     def hits_adopt(self, dptr, n, n_seq):
         _chk(lib().mahip_hits_adopt(self.h, dptr, n, n_seq), "hits_adopt")

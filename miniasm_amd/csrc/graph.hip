@@ -12,6 +12,7 @@
 //   mahip_asg_symm     : reference asg.c:104-145 asg_arc_del_multi + asg_arc_del_asymm
 //   mahip_asg_del_short: reference asg.c:83-101
 #include "mahip_internal.hpp"
+#include <type_traits>
 
 #define DEAD 0x80000000u
 #define ADEL 0x80000000u
@@ -676,20 +677,25 @@ __global__ __launch_bounds__(256) void k_asg_trans_pipe(const uint32_t *__restri
 			if (c0.dead) { // asg.c:158-161: all arcs of a deleted read go
 				for (uint32_t i = lane; i < nv; i += 64) aol[st + i] |= ADEL, ++n_red;
 			} else {
-				uint32_t o[2];
+				// ROWS = 1: the vertex AND its first neighbour have at most 64 arcs (most vertices: ~ 50 arcs at BASELINE coverage): everything that runs over "two rows
+				// of 64" runs over one -- the kernel is bound by the instructions it issues (round 5, visit 1: 2.75 ms per 200 M arcs with every trip to memory but one
+				// off the critical path, 2.95 with all of them on it), and the second row of a 50-arc vertex is all instructions and no work
+				auto reduce = [&](auto rows_tag) {
+				constexpr int ROWS = decltype(rows_tag)::value;
+				uint32_t o[ROWS];
 #pragma unroll
-				for (int r = 0; r < 2; ++r) { const uint32_t i = (uint32_t)r * 64u + lane; o[r] = i < nv ? aol[st + i] : 0u; } // used when the flags are written
+				for (int r = 0; r < ROWS; ++r) { const uint32_t i = (uint32_t)r * 64u + lane; o[r] = i < nv ? aol[st + i] : 0u; } // used when the flags are written
 				uint32_t hbits = 6; while ((1u << hbits) < 2 * nv) ++hbits;
 				const uint32_t hsize = 1u << hbits, hmask = hsize - 1;
 #pragma unroll
-				for (int r = 0; r < 2; ++r) {
+				for (int r = 0; r < ROWS; ++r) {
 					const uint32_t i = (uint32_t)r * 64u + lane;
 					if (i < nv) { ll[i] = c0.l[r]; lws[i] = c0.ws[r]; lnw[i] = c0.nw[r]; }
 				}
 				for (uint32_t s = lane; s < hsize; s += 64) hk[s] = TR_EMPTY, hm[s] = 0xffffffffu; // hm[slot] = (index of the FIRST arc to this target) << 2 | mark
 				wv_sync();
 #pragma unroll
-				for (int r = 0; r < 2; ++r) { // mark all neighbours 1 (asg.c:162); duplicates share a slot
+				for (int r = 0; r < ROWS; ++r) { // mark all neighbours 1 (asg.c:162); duplicates share a slot
 					const uint32_t i = (uint32_t)r * 64u + lane;
 					if (i < nv) {
 						const uint32_t key = c0.v[r];
@@ -719,7 +725,7 @@ __global__ __launch_bounds__(256) void k_asg_trans_pipe(const uint32_t *__restri
 					const uint32_t li = ll[0], n0 = c0.n0;
 					bool more = true;
 #pragma unroll
-					for (int r = 0; r < 2; ++r) {
+					for (int r = 0; r < ROWS; ++r) {
 						const uint32_t j = (uint32_t)r * 64u + lane;
 						const int ok = more && j < n0 && j < 128u;
 						int cond = ok && c0.el[r] + li <= L;
@@ -731,7 +737,7 @@ __global__ __launch_bounds__(256) void k_asg_trans_pipe(const uint32_t *__restri
 					if (more && n0 > 128u) expand_rest(lws[0], n0, li, 128u);
 					wv_sync();
 				}
-				for (uint32_t base = 0; base < nv; base += 64) {
+				for (uint32_t base = 0; base < (uint32_t)ROWS * 64u && base < nv; base += 64) {
 					const uint32_t i = base + lane;
 					const uint32_t myslot = i < nv ? slot[i] : 0;
 					uint64_t passed = base == 0 ? 1ull : 0ull; // lanes of this chunk the walk has gone past
@@ -768,8 +774,10 @@ __global__ __launch_bounds__(256) void k_asg_trans_pipe(const uint32_t *__restri
 				// asg.c:181-184: the sweep resets mark[target] at the first arc to a target, so of several arcs to one
 				// reduced target (multi-arcs are still present here) only the first is deleted
 #pragma unroll
-				for (int r = 0; r < 2; ++r) { const uint32_t i = (uint32_t)r * 64u + lane; if (i < nv && hm[slot[i]] == (i << 2 | 2u)) aol[st + i] = o[r] | ADEL, ++n_red; }
+				for (int r = 0; r < ROWS; ++r) { const uint32_t i = (uint32_t)r * 64u + lane; if (i < nv && hm[slot[i]] == (i << 2 | 2u)) aol[st + i] = o[r] | ADEL, ++n_red; }
 				wv_sync();
+				};
+				if (nv <= 64u && c0.n0 <= 64u) reduce(std::integral_constant<int, 1>()); else reduce(std::integral_constant<int, 2>());
 			}
 			b0 = b1; b1 = b2; b2 = b3;
 			c0 = c1; c1 = c2; c2 = c3;

@@ -85,6 +85,142 @@ __global__ __launch_bounds__(256) void k_key_compact(const uint64_t *__restrict_
 	if (i < n && keep[i]) { kout[pos[i]] = kin[i]; if (vin) vout[pos[i]] = vin[i]; }
 }
 
+// ---- sorting RUNS of records instead of records (round 5) ----
+// ma_hit_read stores a PAF line's record and its mirror side by side (hit.c:87-98), and an overlapper lists a query's overlaps together: the records of one
+// query's own lines stand in the input at stride 2 (stride 1 without mirrors, `-b`), a RUN of ~ 50 with one query id.  A run is one element of the sort:
+//   key = qid << (bi + bl) | position of its first record << bl | (length - 1)
+// -- the mirrored records, whose ids are spread over the whole dictionary, stay runs of one.  At BASELINE configs[3] that is 102 M keys through the three digit
+// passes instead of 200 M.  The stable sort on the id bits keeps a read's runs in the order of their first positions = input order, as long as no two runs of one
+// read interleave (two runs of one id at the two parities over the same stretch: consecutive records of ONE query id at stride 1 under a stride-2 reading, e.g. a
+// row of self hits): k_runs_expand counts such pairs and the caller then sorts records as before.  k_runs_expand turns the sorted runs back into what every
+// consumer wants -- sidx[slot] = input position of the record in each slot, goff[id] = first slot of a read -- so the gather reads 4 bytes per slot instead of an
+// 8-byte key and does not write sidx itself.
+// k_hit_keys_runs: a wave takes 1024 consecutive records (16 x 64), a run never crosses that border (cut there: 0.2 % more runs); heads by comparing with the
+// record STRIDE before; lengths from the head masks, walking the 16 rounds backwards; the keys leave in input order at the tile's offset in the run sequence
+// (chained look-back, mahip_internal.hpp: sc_look_back).
+#define RUN_SLAB 1024u
+#define RUN_TILE (4u * RUN_SLAB)
+#define RUN_MIN_LEN_BITS 10 // a run has at most RUN_SLAB records
+template <int STRIDE>
+__global__ __launch_bounds__(256) void k_hit_keys_runs(const ma_hit_t *__restrict__ h, size_t n, uint64_t *__restrict__ key, int bi, int bl, unsigned long long *__restrict__ d_total,
+                                                        unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
+{
+	__shared__ uint32_t s_wave[4];
+	__shared__ uint32_t s_tile, s_prefix;
+	if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+	__syncthreads();
+	const uint32_t tile = s_tile;
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const size_t wbase = (size_t)tile * RUN_TILE + (size_t)wave * RUN_SLAB;
+	const uint32_t nvalid = wbase >= n ? 0u : (uint32_t)(n - wbase < RUN_SLAB ? n - wbase : RUN_SLAB);
+	uint32_t q[16];
+	unsigned long long hm[16];
+#pragma unroll
+	for (int it = 0; it < 16; ++it) { const uint32_t p = (uint32_t)it * 64u + lane; q[it] = p < nvalid ? (uint32_t)(h[wbase + p].qns >> 32) : 0u; }
+	uint32_t cnt = 0, pre[16]; // pre[it]: heads of the wave in front of round it
+#pragma unroll
+	for (int it = 0; it < 16; ++it) {
+		const uint32_t p = (uint32_t)it * 64u + lane;
+		uint32_t pred = __shfl_up(q[it], STRIDE, 64);
+		if (it > 0) { const uint32_t carry = __shfl(q[it > 0 ? it - 1 : 0], (int)((lane + 64u - STRIDE) & 63u), 64); if (lane < (unsigned)STRIDE) pred = carry; }
+		const bool has_pred = it > 0 || lane >= (unsigned)STRIDE;
+		hm[it] = wv_ballot(p < nvalid && (!has_pred || pred != q[it]));
+		pre[it] = cnt; cnt += (uint32_t)__popcll(hm[it]);
+	}
+	if (lane == 0) s_wave[wave] = cnt;
+	__syncthreads();
+	uint32_t wex = 0, tot = 0;
+	for (unsigned w = 0; w < 4; ++w) { const uint32_t v = s_wave[w]; if (w < wave) wex += v; tot += v; }
+	if (threadIdx.x == 0) {
+		SC_PUBLISH(&state[tile], sc_pack(epoch, tile == 0 ? SC_INCL : SC_AGG, tot));
+		if (tile == 0) s_prefix = 0;
+	}
+	if (tile > 0 && threadIdx.x < 64) {
+		const uint32_t prefix = sc_look_back(state, tile, epoch, threadIdx.x);
+		if (threadIdx.x == 0) { s_prefix = prefix; SC_PUBLISH(&state[tile], sc_pack(epoch, SC_INCL, prefix + tot)); }
+	}
+	__syncthreads();
+	const uint32_t out0 = s_prefix + wex;
+	if ((size_t)tile * RUN_TILE < n && (size_t)(tile + 1) * RUN_TILE >= n && threadIdx.x == 0) *d_total = (unsigned long long)s_prefix + tot; // the last tile
+	// lengths, last round first: nxt[par] = the nearest head of the parity class behind the current round (or the slab's end, rounded up to the class)
+	const unsigned par = STRIDE == 1 ? 0u : (lane & 1u);
+	const unsigned long long cls = STRIDE == 1 ? ~0ull : (par ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull);
+	uint32_t nxt = STRIDE == 1 ? nvalid : nvalid + ((par - nvalid) & 1u); // (per lane: its own class)
+#pragma unroll
+	for (int it = 15; it >= 0; --it) {
+		const uint32_t p = (uint32_t)it * 64u + lane;
+		const unsigned long long same = hm[it] & cls, above = same & ~wv_le(lane);
+		const uint32_t np = above ? (uint32_t)it * 64u + (uint32_t)(__ffsll((long long)above) - 1) : nxt;
+		if (hm[it] >> lane & 1ull) {
+			const uint32_t len = (np - p) / (uint32_t)STRIDE;
+			key[out0 + pre[it] + (uint32_t)__popcll(hm[it] & wv_lt(lane))] = (uint64_t)q[it] << (bi + bl) | (uint64_t)(wbase + p) << bl | (uint64_t)(len - 1u);
+		}
+		if (same) nxt = (uint32_t)it * 64u + (uint32_t)(__ffsll((long long)same) - 1);
+	}
+}
+
+// sorted runs -> sidx (input position of the record in every slot) + goff (first slot of every read with records; the others: radix_group_starts_finish).
+// A tile of RX_TILE consecutive runs covers a contiguous stretch of slots: the runs' lengths are scanned in the block, the tile's first slot comes from the tiles
+// before it (chained look-back), and the stretch is written by all threads, a slot each, through a binary search over the runs' offsets in LDS -- coalesced.
+#define RX_ITEMS 8
+#define RX_TILE (256 * RX_ITEMS)
+template <int STRIDE>
+__global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict__ rkey, uint32_t n_runs, int bi, int bl, uint32_t n_seq, uint32_t n_slots,
+                                                      uint32_t *__restrict__ sidx, uint32_t *__restrict__ goff, unsigned long long *__restrict__ ctr,
+                                                      unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
+{
+	__shared__ uint32_t s_wave[4], s_off[RX_TILE + 1], s_pos[RX_TILE];
+	__shared__ uint32_t s_tile, s_prefix;
+	if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+	__syncthreads();
+	const uint32_t tile = s_tile, r0 = tile * RX_TILE + threadIdx.x * RX_ITEMS;
+	const uint64_t lmask = (1ull << bl) - 1ull, pmask = bi >= 64 ? ~0ull : (1ull << bi) - 1ull;
+	uint64_t k[RX_ITEMS];
+	uint32_t sum = 0, bad = 0;
+#pragma unroll
+	for (int j = 0; j < RX_ITEMS; ++j) { k[j] = r0 + j < n_runs ? rkey[r0 + j] : 0ull; sum += r0 + j < n_runs ? (uint32_t)(k[j] & lmask) + 1u : 0u; }
+	uint64_t kprev = r0 > 0 && r0 <= n_runs ? rkey[r0 - 1] : 0ull; // (r0 == n_runs: nothing of this thread's is looked at)
+	uint32_t tot;
+	uint32_t ex = block_excl_scan_256(sum, s_wave, &tot);
+	if (threadIdx.x == 0) {
+		SC_PUBLISH(&state[tile], sc_pack(epoch, tile == 0 ? SC_INCL : SC_AGG, tot));
+		if (tile == 0) s_prefix = 0;
+	}
+	if (tile > 0 && threadIdx.x < 64) {
+		const uint32_t prefix = sc_look_back(state, tile, epoch, threadIdx.x);
+		if (threadIdx.x == 0) { s_prefix = prefix; SC_PUBLISH(&state[tile], sc_pack(epoch, SC_INCL, prefix + tot)); }
+	}
+#pragma unroll
+	for (int j = 0; j < RX_ITEMS; ++j) {
+		s_off[threadIdx.x * RX_ITEMS + j] = ex; s_pos[threadIdx.x * RX_ITEMS + j] = (uint32_t)(k[j] >> bl & pmask);
+		ex += r0 + j < n_runs ? (uint32_t)(k[j] & lmask) + 1u : 0u;
+	}
+	if (threadIdx.x == 255) s_off[RX_TILE] = ex;
+	__syncthreads();
+	const uint32_t S0 = s_prefix;
+#pragma unroll
+	for (int j = 0; j < RX_ITEMS; ++j) {
+		if (r0 + j < n_runs) {
+			const uint32_t qid = (uint32_t)(k[j] >> (bi + bl));
+			const bool first = r0 + j == 0;
+			const uint32_t qp = (uint32_t)(kprev >> (bi + bl));
+			if (first || qp != qid) { if (qid < n_seq) goff[qid] = S0 + s_off[threadIdx.x * RX_ITEMS + j]; else ++bad; } // ids are < n_seq by contract
+			else { // the read's previous run: it must end in front of this one (no interleaving, see above)
+				const uint64_t pend = (kprev >> bl & pmask) + (uint64_t)STRIDE * (kprev & lmask);
+				bad += (k[j] >> bl & pmask) <= pend;
+			}
+			kprev = k[j];
+		}
+	}
+	for (uint32_t j = threadIdx.x; j < tot; j += 256) { // slot S0 + j belongs to the last run whose offset is <= j
+		uint32_t lo = 0, hi = RX_TILE; // s_off[lo] <= j < s_off[hi]
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_off[mid] <= j) lo = mid; else hi = mid; }
+		if (S0 + j < n_slots) sidx[S0 + j] = s_pos[lo] + (uint32_t)STRIDE * (j - s_off[lo]);
+	}
+	if (r0 < n_runs && r0 + RX_ITEMS >= n_runs) bad += S0 + s_off[RX_TILE] != n_slots; // the last thread with runs: the slots must add up to the records
+	blk_add_u64(&ctr[CT_OVF2], bad);
+}
+
 struct HitCols { uint32_t *qid, *qs, *qe, *tn, *ts, *te, *ml, *bl; };
 
 // AoS (input order) -> SoA (grouped by query id): one 32-byte record per lane as 2 x dwordx4 through the permutation held
@@ -95,8 +231,9 @@ struct HitCols { uint32_t *qid, *qs, *qe, *tn, *ts, *te, *ml, *bl; };
 #endif
 // GATHER_ILP slots per thread: two independent request chains in flight per lane (the record fetch is a dependent chain: key -> record)
 __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__ h, const uint64_t *__restrict__ skey, int bi, size_t n, uint32_t n_seq,
-                                                     HitCols c, uint32_t *__restrict__ goff, uint32_t *__restrict__ sidx)
+                                                     HitCols c, uint32_t *__restrict__ goff, uint32_t *__restrict__ sidx, const uint32_t *__restrict__ spos = nullptr)
 { // sidx (optional): input position of the record in every slot -- how the order inside a group is re-established (hits_order_rank, push_stable_order)
+  // spos (hits sorted as runs): the positions are there already (k_runs_expand), with the group offsets; skey, goff and sidx are then null
 	size_t i[GATHER_ILP], j[GATHER_ILP];
 	uint4 a[GATHER_ILP], b[GATHER_ILP];
 	bool act[GATHER_ILP];
@@ -104,7 +241,8 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 	for (int u = 0; u < GATHER_ILP; ++u) { // keys of all slots first
 		i[u] = ((size_t)blockIdx.x * GATHER_ILP + u) * 256 + threadIdx.x;
 		act[u] = i[u] < n; j[u] = i[u];
-		if (act[u] && skey) j[u] = (size_t)(skey[i[u]] & ((1ull << bi) - 1));
+		if (act[u] && spos) j[u] = spos[i[u]];
+		else if (act[u] && skey) j[u] = (size_t)(skey[i[u]] & ((1ull << bi) - 1));
 	}
 #pragma unroll
 	for (int u = 0; u < GATHER_ILP; ++u)
@@ -121,7 +259,7 @@ __global__ __launch_bounds__(256) void k_hit_gather(const ma_hit_t *__restrict__
 			c.qid[s] = a[u].y; c.qs[s] = a[u].x; c.qe[s] = a[u].z; c.tn[s] = a[u].w;
 			c.ts[s] = b[u].x; c.te[s] = b[u].y; c.ml[s] = b[u].z; c.bl[s] = b[u].w & ~DEAD;
 		}
-		if (!first) qprev = skey ? (uint32_t)(skey[i[u] - 1] >> bi) : (uint32_t)(h[i[u] - 1].qns >> 32);
+		if (!first && goff) qprev = skey ? (uint32_t)(skey[i[u] - 1] >> bi) : (uint32_t)(h[i[u] - 1].qns >> 32);
 		// reads qprev+1 .. q start at slot i (reads without hits get empty groups)
 		const uint32_t r0 = first ? 0 : qprev + 1;
 		if (q > n_seq) q = n_seq;
@@ -243,15 +381,14 @@ __device__ __forceinline__ void sub_preload(const HitCols &c, const uint32_t *__
 // fetches the read's records itself -- through the permutation in the low bits of the sorted keys -- and writes the SoA columns on the way.
 // The gather is a chain of dependent random fetches (memory latency), the sweep is a register sort (VALU): in one kernel the two overlap
 // across the waves of a SIMD instead of adding up as two launches.
-struct SubGather { const uint64_t *skey; const ma_hit_t *aos; uint32_t *sidx; int bi; uint32_t n, chunk, q_lo; }; // n = slots; chunk = reads per bounds fetch of the larger tiers; q_lo = first read to visit (a shard: its own range only; the kernel's n_seq argument is then the range's end)
+struct SubGather { const uint32_t *pos; uint32_t pstride, pmask; const ma_hit_t *aos; uint32_t *sidx; uint32_t n, chunk, q_lo; }; // pos[i * pstride] & pmask = input position of the record of slot i: the low words of the sorted keys (pstride 2, the position bits) or sidx itself (pstride 1, all bits: hits sorted as runs, k_runs_expand) // n = slots; chunk = reads per bounds fetch of the larger tiers; q_lo = first read to visit (a shard: its own range only; the kernel's n_seq argument is then the range's end)
 struct GBounds { uint32_t beg, end; };                     // a read's slots
 struct GKeys { uint32_t beg, end, j[2]; };                 // + low words of the sorted keys of its (up to 128) slots, two slots per lane
 struct GRecs { uint32_t beg, end, j[2]; uint4 a[2], b[2]; }; // + input positions and records: a = {qs, qid, qe, tn}, b = {ts, te, ml|rev, bl|del}
 
 __device__ __forceinline__ uint32_t gather_pos(const SubGather &g, size_t i)
-{ // little endian: the low word of key i; the input position sits in its low bi bits (bi <= 32)
-	const uint32_t lo = ((const uint32_t*)g.skey)[2 * i];
-	return g.bi >= 32 ? lo : lo & ((1u << g.bi) - 1u);
+{ // (little endian: the low word of key i holds the input position in its low bits)
+	return g.pos[i * g.pstride] & g.pmask;
 }
 // The three stages of the pipelined chain.  All loads are UNCONDITIONAL (indices clamped into range, lanes without a slot fetch
 // record 0): straight-line code lets the compiler count the outstanding loads (s_waitcnt vmcnt(N)) instead of draining the queue at
@@ -267,14 +404,14 @@ __device__ __forceinline__ void gather_keys(const SubGather &g, const GBounds &b
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint32_t i = b.beg + h * 64 + lane, ic = i < g.n ? i : g.n - 1;
-		k.j[h] = ((const uint32_t*)g.skey)[2 * (size_t)ic];
+		k.j[h] = g.pos[(size_t)ic * g.pstride];
 	}
 }
 __device__ __forceinline__ void gather_recs(const SubGather &g, const GKeys &k, unsigned lane, GRecs &r)
 {
 	r.beg = k.beg; r.end = k.end;
 	const bool mine = k.end - k.beg <= 128u;
-	const uint32_t mask = g.bi >= 32 ? 0xffffffffu : (1u << g.bi) - 1u;
+	const uint32_t mask = g.pmask;
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint32_t i = k.beg + h * 64 + lane;
@@ -283,16 +420,17 @@ __device__ __forceinline__ void gather_recs(const SubGather &g, const GKeys &k, 
 		r.a[h] = p[0]; r.b[h] = p[1];
 	}
 }
+template <int GATHER>
 __device__ __forceinline__ void gather_store(const HitCols &c, const SubGather &g, uint32_t i, uint32_t j, uint4 a, uint4 b)
-{
+{ // GATHER 1: positions from the sorted keys, sidx is written here; 2: positions read from sidx (k_runs_expand wrote it)
 	c.qid[i] = a.y; c.qs[i] = a.x; c.qe[i] = a.z; c.tn[i] = a.w;
 	c.ts[i] = b.x; c.te[i] = b.y; c.ml[i] = b.z; c.bl[i] = b.w & ~DEAD;
-	g.sidx[i] = j;
+	if (GATHER == 1) g.sidx[i] = j;
 }
 
 // one read in registers; returns 1 if the read keeps an interval (value identical on all lanes).  pre != nullptr: the
 // columns of the (at most 128) hits are already in registers
-template <int ITEMS, bool FUSE, bool GATHER = false>
+template <int ITEMS, bool FUSE, int GATHER = 0>
 __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q, uint32_t beg, uint32_t end, int min_dp, float min_iden,
                                                    int end_clip, uint2 *__restrict__ sub, unsigned lane, const SubFuse &f, SubAcc &acc, const SubPre *pre = nullptr,
                                                    const SubGather *g = nullptr)
@@ -321,7 +459,7 @@ __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q,
 					x[2 * h] = x[2 * h + 1] = EV_PAD;
 					if (i < end) {
 						uint32_t es, ee;
-						gather_store(c, *g, i, jj[k], aa[k], bb[k]);
+						gather_store<GATHER>(c, *g, i, jj[k], aa[k], bb[k]);
 						live_any = 1;
 						if (mc_sub_ok(q, aa[k].x, aa[k].z, aa[k].w, (int32_t)(bb[k].z & 0x7fffffffu), (int32_t)(bb[k].w & ~DEAD), min_iden, end_clip, &es, &ee)) x[2 * h] = es, x[2 * h + 1] = ee, ev_any = 1;
 					}
@@ -343,7 +481,7 @@ __device__ __forceinline__ uint32_t sub_group_regs(const HitCols &c, uint32_t q,
 				const uint32_t j = gather_pos(*g, i);
 				const uint4 *p = (const uint4*)(g->aos + j);
 				const uint4 a = p[0], b = p[1];
-				gather_store(c, *g, i, j, a, b);
+				gather_store<GATHER>(c, *g, i, j, a, b);
 				bl = b.w & ~DEAD; ml = b.z; qs = a.x; qe = a.z; tn = a.w;
 				alive = 1;
 			} else {
@@ -425,8 +563,8 @@ __device__ __forceinline__ unsigned sub_block_id()
 #ifndef SUB_WPE_F0
 #define SUB_WPE_F0 6 // the fused first tier: the compiler's own choice (82 registers, 6 waves by count but no target) 3.26 ms, target 6: 3.11, target 8 (29 spills): 3.15
 #endif
-constexpr unsigned sub_wpe(bool fuse, int cls, bool gather) { return gather && cls == 0 ? SUB_WPE_G0 : fuse && cls == 1 ? 5 : fuse && cls == 0 ? SUB_WPE_F0 : 0; }
-template <bool FUSE, int CLS, bool GATHER = false>
+constexpr unsigned sub_wpe(bool fuse, int cls, int gather) { return gather && cls == 0 ? SUB_WPE_G0 : fuse && cls == 1 ? 5 : fuse && cls == 0 ? SUB_WPE_F0 : 0; }
+template <bool FUSE, int CLS, int GATHER = 0>
 __global__ __launch_bounds__(256) SUB_WPE_ATTR(FUSE, CLS, GATHER) void k_hit_sub(HitCols c, const uint32_t *__restrict__ goff, uint32_t n_seq,
                                                   int min_dp, float min_iden, int end_clip, uint2 *__restrict__ sub,
                                                   uint32_t *__restrict__ ovf, unsigned long long *__restrict__ ctr, SubFuse f, SubGather g)
@@ -455,7 +593,7 @@ __global__ __launch_bounds__(256) SUB_WPE_ATTR(FUSE, CLS, GATHER) void k_hit_sub
 #pragma unroll
 			for (int h = 0; h < 2; ++h) {
 				const uint32_t i = beg + h * 64 + lane;
-				gather_store(c, g, (H <= 128u && i < end) ? i : g.n + lane, cur.j[h], cur.a[h], cur.b[h]);
+				gather_store<GATHER>(c, g, (H <= 128u && i < end) ? i : g.n + lane, cur.j[h], cur.a[h], cur.b[h]);
 			}
 			__builtin_amdgcn_sched_barrier(0);
 			// (2) the fetches of the reads behind it
@@ -519,7 +657,7 @@ __global__ __launch_bounds__(256) SUB_WPE_ATTR(FUSE, CLS, GATHER) void k_hit_sub
 					for (uint32_t i = beg + lane; i < end; i += 64) {
 						const uint32_t j = gather_pos(g, i);
 						const uint4 *p = (const uint4*)(g.aos + j);
-						gather_store(c, g, i, j, p[0], p[1]);
+						gather_store<GATHER>(c, g, i, j, p[0], p[1]);
 					}
 				if (lane == 0) { unsigned long long k = atomicAdd(&ctr[CT_OVF], 1ull); ovf[k] = q; }
 			}
@@ -826,7 +964,7 @@ static int hits_common_setup(mahip_ctx *c, size_t n, uint32_t n_seq)
 {
 	c->n_hits = n; c->n_in = n; c->n_live = n; c->n_seq = n_seq; c->n_seq_new = n_seq;
 	c->soa_ready = false; c->has_map = false; c->surv_ready = false; c->graph_ready = false; c->gather_pending = false;
-	c->hint_max_qs = 0; // hints describe one upload: set them again after every upload/adopt
+	c->hint_max_qs = 0; c->run_stride = 0; c->gk_runs = false; c->n_runs = 0; // hints describe one upload: set them again after every upload/adopt
 	c->lazy_squeeze = false;
 	c->sorted_here = false; c->hrank_ready = false; c->orank_ready = false;
 	c->n_total = 0; // positions describe one upload, like the hints
@@ -1074,6 +1212,15 @@ extern "C" int mahip_set_hints(mahip_ctx_t *c, uint32_t max_qs)
 	return 0;
 }
 
+extern "C" int mahip_set_run_stride(mahip_ctx_t *c, int stride)
+{ // how the records of one query's own PAF lines stand in the input: 2 = record + mirror side by side (ma_hit_read with bi_dir, hit.c:87-98), 1 = no mirrors, 0 = unknown
+	c->run_stride = stride == 1 || stride == 2 ? stride : 0;
+	return 0;
+}
+
+// elements of the last mahip_hits_sort when it sorted RUNS of records (0: it sorted records)
+extern "C" uint64_t mahip_hits_sorted_runs(mahip_ctx_t *c) { return c->gk_runs ? (uint64_t)c->n_runs : 0; }
+
 extern "C" int mahip_set_exact_ties(mahip_ctx_t *c, int mode)
 {
 	c->tie_mode = mode < 0 || mode > 2 ? 2 : mode;
@@ -1284,8 +1431,46 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	int gen = 0;
 	if (sharded) { CHK(dev_reserve(c, c->keep, (n + 16) * 4)); CHK(dev_reserve(c, c->pos, (n + 16) * 4)); }
 	CHK(ctr_zero(c));
-	bool first_hist = false;
-	if (!sharded) { // keys + the first pass's per-tile histogram in one sweep
+	bool first_hist = false, runs_done = false;
+	// ---- RUNS of records as the sort's elements (the kernels' comment): when the caller said how the records of one query's own lines stand in the input
+	// (mahip_set_run_stride: 2 with mirrored records, 1 without), the ids are dense and the three fields fit a word.  Falls back to sorting records when the
+	// input has few runs, or two runs of one read interleave.
+	static const int runs_on = getenv("MA_SORT_RUNS") ? atoi(getenv("MA_SORT_RUNS")) : 1;
+	const int bl_runs = 64 - bq - bi;
+	if (!sharded && runs_on && c->run_stride && c->n_seq && bl_runs >= RUN_MIN_LEN_BITS && bi <= 32) {
+		const int bl = bl_runs > 16 ? 16 : bl_runs;
+		const size_t nb1 = (n + RUN_TILE - 1) / RUN_TILE;
+		uint32_t *ticket; unsigned long long *state; uint32_t ticket_base, epoch;
+		CHK(scan_chain_begin(c, nb1, &state, &ticket, &ticket_base, &epoch));
+		{
+			ProfScope ps(c, "k_hit_keys", 16.0 * (double)n);
+			if (c->run_stride == 2) hipLaunchKernelGGL(k_hit_keys_runs<2>, dim3((unsigned)nb1), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), bi, bl, ctr + CT_TOTAL, state, ticket, ticket_base, epoch);
+			else hipLaunchKernelGGL(k_hit_keys_runs<1>, dim3((unsigned)nb1), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), bi, bl, ctr + CT_TOTAL, state, ticket, ticket_base, epoch);
+		}
+		CHK(ctr_fetch(c));
+		const size_t n_runs = (size_t)c->h_ctr[CT_TOTAL];
+		if (n_runs && n_runs * 4 <= n * 3) { // worth it (else: the keys of all records below, as if nothing had happened)
+			int g2 = 0;
+			CHK(radix_sort_keys(c, n_runs, bi + bl, bi + bl + bq, &g2, false));
+			CHK(radix_group_starts_begin(c, P<uint32_t>(c->goff), c->n_seq, (uint32_t)n));
+			const size_t nb2 = (n_runs + RX_TILE - 1) / RX_TILE;
+			CHK(scan_chain_begin(c, nb2, &state, &ticket, &ticket_base, &epoch));
+			HIPCHK(hipMemsetAsync(ctr + CT_OVF2, 0, 8, c->st));
+			{
+				ProfScope ps(c, "k_runs_expand", 8.0 * (double)n_runs + 4.0 * (double)n);
+				if (c->run_stride == 2) hipLaunchKernelGGL(k_runs_expand<2>, dim3((unsigned)nb2), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[g2]), (uint32_t)n_runs, bi, bl, c->n_seq, (uint32_t)n,
+				                                           P<uint32_t>(c->sidx), P<uint32_t>(c->goff), ctr, state, ticket, ticket_base, epoch);
+				else hipLaunchKernelGGL(k_runs_expand<1>, dim3((unsigned)nb2), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[g2]), (uint32_t)n_runs, bi, bl, c->n_seq, (uint32_t)n,
+				                        P<uint32_t>(c->sidx), P<uint32_t>(c->goff), ctr, state, ticket, ticket_base, epoch);
+			}
+			CHK(radix_group_starts_finish(c, P<uint32_t>(c->goff), c->n_seq));
+			CHK(ctr_fetch(c));
+			runs_done = c->h_ctr[CT_OVF2] == 0; // interleaved runs of one read (or an id outside the dictionary): sort the records instead
+			c->n_runs = runs_done ? n_runs : 0;
+		}
+		CHK(ctr_zero(c));
+	}
+	if (!sharded && !runs_done) { // keys + the first pass's per-tile histogram in one sweep
 		int sh0, bt0; unsigned tile;
 		radix_first_digit(bi, bi + bq, &sh0, &bt0, &tile);
 		if (bt0 > 0 && bt0 <= RS_MAXBITS) {
@@ -1296,7 +1481,7 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 			first_hist = true;
 		}
 	}
-	if (!first_hist) {
+	if (!first_hist && !runs_done) {
 		ProfScope ps(c, "k_hit_keys", 16.0 * (double)n); // reads qns (8 B), writes the key
 		hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), (uint32_t*)nullptr,
 		                   sharded ? P<uint32_t>(c->keep) : (uint32_t*)nullptr, ctr, c->q_beg, c->q_end, bi, 0);
@@ -1324,8 +1509,10 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 		c->soa_ready = true;
 		return 0;
 	}
+	if (runs_done) first_hist = true; // (nothing below needs keys)
 	static const int fuse_goff = getenv("MA_GOFF_FUSE") ? atoi(getenv("MA_GOFF_FUSE")) : 1;
-	if (!sharded && fuse_goff && c->n_seq) { // the group offsets come out of the sort's last pass (ids are < n_seq by contract, checked by the kernel)
+	if (runs_done) { /* sorted as runs above: sidx and goff are made */ }
+	else if (!sharded && fuse_goff && c->n_seq) { // the group offsets come out of the sort's last pass (ids are < n_seq by contract, checked by the kernel)
 		const RadixGroups grp = {P<uint32_t>(c->goff), bi, c->n_seq};
 		CHK(radix_sort_keys(c, n, bi, bi + bq, &gen, first_hist, &grp));
 	} else {
@@ -1338,7 +1525,7 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 	}
 	}
 	HIPCHK(hipGetLastError());
-	c->gather_pending = true; c->gk_gen = gen; c->gk_bi = bi;
+	c->gather_pending = true; c->gk_gen = gen; c->gk_bi = bi; c->gk_runs = runs_done;
 	c->soa_ready = true;
 	return 0;
 }
@@ -1350,6 +1537,9 @@ int hits_need_cols(mahip_ctx *c, const char *who)
 	if (!c->gather_pending) return 0;
 	const size_t n = c->n_hits;
 	ProfScope ps(c, "k_hit_gather", 76.0 * (double)n); // key 8 + record 32 + columns 32 + input position 4
+	if (c->gk_runs) hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256 * GATHER_ILP)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)nullptr, 0, n, c->n_seq, cols_of(c),
+	                                   (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)P<uint32_t>(c->sidx)); // sorted as runs: positions and group offsets are there (k_runs_expand)
+	else
 	hipLaunchKernelGGL(k_hit_gather, dim3(grid_for(n + 1, 256 * GATHER_ILP)), dim3(256), 0, c->st, c->d_aos, (const uint64_t*)P<uint64_t>(c->key[c->gk_gen]),
 	                   c->gk_bi, n, c->n_seq, cols_of(c), (uint32_t*)nullptr /* the group offsets are there already (k_hit_goff) */, P<uint32_t>(c->sidx));
 	HIPCHK(hipGetLastError());
@@ -1411,19 +1601,26 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	uint2 *sub = P<uint2>(c->sub[slot]);
 	SubFuse nofuse = {nullptr, 0, 0, 0, nullptr};
-	SubGather nog = {nullptr, nullptr, nullptr, 0, 0, sub_chunk(Rr), q_lo};
+	SubGather nog = {nullptr, 0, 0, nullptr, nullptr, 0, sub_chunk(Rr), q_lo};
 	const bool fuse_gather = c->gather_pending && R && c->n_hits && !getenv("MA_NO_GATHER_FUSE");
 	if (c->gather_pending && !fuse_gather) CHK(hits_need_cols(c, "mahip_hits_sub"));
 	if (fuse_gather) { // the sweep fetches the records itself and writes the columns on the way
-		SubGather g = {(const uint64_t*)P<uint64_t>(c->key[c->gk_gen]), c->d_aos, P<uint32_t>(c->sidx), c->gk_bi, (uint32_t)c->n_hits, sub_chunk(Rr), q_lo};
+		const uint32_t pmask = c->gk_bi >= 32 ? 0xffffffffu : (1u << c->gk_bi) - 1u;
+		const SubGather g = c->gk_runs ? SubGather{(const uint32_t*)P<uint32_t>(c->sidx), 1u, 0xffffffffu, c->d_aos, nullptr, (uint32_t)c->n_hits, sub_chunk(Rr), q_lo}
+		                               : SubGather{(const uint32_t*)P<uint64_t>(c->key[c->gk_gen]), 2u, pmask, c->d_aos, P<uint32_t>(c->sidx), (uint32_t)c->n_hits, sub_chunk(Rr), q_lo};
 		ProfScope ps(c, "k_hit_sub<gather>", (64.0 + 48.0) * (double)c->n_hits); // hit sort 64 (32 r + 32 w, counted once whatever the digit passes) + ma_hit_sub 48 B per stored hit
 		SubFork fk(c);
-		hipLaunchKernelGGL((k_hit_sub<false, 0, true>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(0), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-		hipLaunchKernelGGL((k_hit_sub<false, 1, true>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(1), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-		hipLaunchKernelGGL((k_hit_sub<false, 2, true>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(2), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+		const dim3 grd(grid_for(Rr, 4, MA_SUB_BLOCKS)), blk(256);
+		const uint32_t *gf = (const uint32_t*)P<uint32_t>(c->goff);
+		if (c->gk_runs) { // positions from sidx (k_runs_expand), which is not written again
+			hipLaunchKernelGGL((k_hit_sub<false, 0, 2>), grd, blk, 0, fk.st(0), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+			hipLaunchKernelGGL((k_hit_sub<false, 1, 2>), grd, blk, 0, fk.st(1), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+			hipLaunchKernelGGL((k_hit_sub<false, 2, 2>), grd, blk, 0, fk.st(2), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+		} else {
+			hipLaunchKernelGGL((k_hit_sub<false, 0, 1>), grd, blk, 0, fk.st(0), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+			hipLaunchKernelGGL((k_hit_sub<false, 1, 1>), grd, blk, 0, fk.st(1), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+			hipLaunchKernelGGL((k_hit_sub<false, 2, 1>), grd, blk, 0, fk.st(2), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+		}
 		fk.join();
 		c->gather_pending = false;
 	} else if (R) {
@@ -1467,11 +1664,11 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
 		ProfScope ps(c, "k_hit_sub<cut+flt>", (80.0 + 80.0 + 48.0) * (double)c->n_hits + 8.0 * R); // cut 80 + flt 80 + sub 48 B per hit
 		SubFork fk(c);
 		hipLaunchKernelGGL((k_hit_sub<true, 0>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(0), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(Rr), q_lo});
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, 0, 0, nullptr, nullptr, 0, sub_chunk(Rr), q_lo});
 		hipLaunchKernelGGL((k_hit_sub<true, 1>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(1), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(Rr), q_lo});
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, 0, 0, nullptr, nullptr, 0, sub_chunk(Rr), q_lo});
 		hipLaunchKernelGGL((k_hit_sub<true, 2>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(2), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, nullptr, nullptr, 0, 0, sub_chunk(Rr), q_lo});
+		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, 0, 0, nullptr, nullptr, 0, sub_chunk(Rr), q_lo});
 		fk.join();
 	}
 	if (R) {

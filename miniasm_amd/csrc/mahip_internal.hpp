@@ -84,6 +84,7 @@ struct mahip_ctx {
 	uint32_t n_push = 0;
 	bool sorted_here = false, hrank_ready = false, orank_ready = false; // hits grouped by mahip_hits_sort (d_aos = the unsorted input) / hrank valid / orank valid
 	bool gather_pending = false; int gk_gen = 0, gk_bi = 0; // mahip_hits_sort left the records in place: sorted keys in key[gk_gen], position in their low gk_bi bits
+	bool gk_runs = false; size_t n_runs = 0; int run_stride = 0; // sorted as RUNS of records (hits.hip: k_hit_keys_runs / k_runs_expand): the positions are in sidx already; run_stride: the caller's hint (mahip_set_run_stride)
 	bool push_ordered = false; // sharded mode: pushrows[1] holds this rank's arcs in push order
 	mahip_tie_info_t tie = {0, 0, 0, 0, 0, 0, 0};
 	uint32_t n_seq_new = 0;
@@ -190,6 +191,8 @@ struct RadixGroups { uint32_t *start; int lo; uint32_t n_id; };
 int radix_sort_keys(mahip_ctx *c, size_t n, int lo, int hi, int *gen, bool first_hist_ready = false, const RadixGroups *groups = nullptr);
 void radix_first_digit(int lo, int hi, int *shift, int *bits, unsigned *tile);
 int radix_reserve_hist(mahip_ctx *c, size_t n);
+int radix_group_starts_begin(mahip_ctx *c, uint32_t *start, uint32_t n_id, uint32_t n);  // start[id] = ~0, start[n_id] = n; a pass then notes the first slot of every id that has keys ...
+int radix_group_starts_finish(mahip_ctx *c, uint32_t *start, uint32_t n_id);           // ... and ids without keys are closed (a suffix minimum): CSR offsets
 int scan_chain_begin(mahip_ctx *c, size_t nb, unsigned long long **state, uint32_t **ticket, uint32_t *ticket_base, uint32_t *epoch);
 // the permutation the reference's (unstable) sort applies to d_keys[0..n) (input order), written to d_perm
 int reference_order(mahip_ctx *c, uint64_t *d_keys /* overwritten */, size_t n, uint32_t *d_perm);

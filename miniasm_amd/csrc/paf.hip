@@ -906,6 +906,7 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipStreamSynchronize(c->st));
 	c->hint_max_qs = c->paf_max_qs = max_qs;
+	c->run_stride = sharded ? 0 : bi_dir ? 2 : 1; // k_paf_emit wrote a line's record and its mirror side by side (hit.c:87-98): the sort may take RUNS of records (hits.hip)
 	info->n_records = n_valid; info->n_stored_lines = n_pass; info->n_hits = n_hits; info->n_seq = R; info->max_qs = max_qs; info->name_bytes = b->name_bytes; info->n_lines = L;
 	if (sharded) { info->n_records = valid_total; info->n_stored_lines = pass_total; info->n_lines = lines_total; }
 	return 0;

@@ -429,6 +429,7 @@ int ma_pipeline_run(const ma_opt_t *opt, const char *fn, const char *outfmt, int
 		GPU(mahip_set_shard(c, 0, 0xffffffffu));
 		GPU(mahip_hits_upload(c, hit, n_hits, d->n_seq));
 		GPU(mahip_set_hints(c, ma_ingest_max_qs()));
+		GPU(mahip_set_run_stride(c, (flags & 4) ? 1 : 2)); /* the host reader stores a line's record and its mirror side by side unless -b (hit.c:87-98) */
 		GPU(mahip_sync(c));
 		t2 = sys_realtime();
 		if (pthread_create(&th_free, 0, free_bg, hit) == 0) pthread_detach(th_free); /* returning 640 MB to the OS takes 60 ms: off the critical path */

@@ -1,6 +1,7 @@
 """Run the hit/graph passes stage by stage through (a) the unmodified reference library, (b) the C oracle,
 (c) the HIP library, returning comparable snapshots after every pass."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -134,6 +135,9 @@ def gpu_stages(ctx, hits, n_seq, opt, upto="trans", tie_mode=0):
     S = {"n_seq": n_seq}
     ctx.set_exact_ties(tie_mode)
     ctx.hits_upload(hits, n_seq)
+    # the sort may take RUNS of records as its elements when told how a query's own records stand in the array (mahip_set_run_stride); the hint may be wrong for
+    # the data (random hit arrays of the parity tests are not mirrored): the result must not depend on it.  MA_TEST_RUN_STRIDE=0|1|2 (default 2: ma_hit_read's layout)
+    ctx.set_run_stride(int(os.environ.get("MA_TEST_RUN_STRIDE", "2")))
     ctx.sort()
     S["sorted"] = ctx.hits_download()
     S["n_rem1"] = ctx.sub(opt.min_dp, opt.min_iden, 0, 0)
