@@ -220,7 +220,7 @@ def achievable_rates():
 # digit passes" and that row is billed to the scope that moves the records (k_hit_sub<gather>: sort 64 + ma_hit_sub 48 B per hit); what the
 # key / digit / offset kernels report is the traffic of this design (keys 16, a digit pass 8 + 16, offsets 8 B per hit): `design_GBs`.
 DESIGN_ONLY = ("k_hit_keys", "k_radix_hist", "k_radix_colscan", "k_radix_scatter", "k_hit_goff", "k_group_close", "scan_exclusive_u32", "k_arc_keys", "k_arc_permute")
-SORT_GROUP = ("k_hit_keys", "k_radix_hist", "k_radix_colscan", "k_radix_scatter", "k_hit_goff", "k_group_close", "k_hit_sub<gather>")
+SORT_GROUP = ("k_hit_keys", "k_radix_hist", "k_radix_colscan", "k_radix_scatter", "k_runs_expand", "k_hit_goff", "k_group_close", "k_hit_sub<gather>")
 # the "reduce" half of north_star's roofline target (per arc): arc sort 32 + index 16 + del_trans 16 (A + I)/A + del_multi 16 +
 # del_asymm 16 + 16 x entries probed + asg_arc_rm 32.  The timed scopes that do that work (graph.hip); the *_radix_* / permute / census scopes only
 # run when the in-register arc sort hands a sort to the radix path.

@@ -202,6 +202,14 @@ pmc)
     find gpurun_out/pmc_$ctr -name "*.csv" | head -5
   done
   python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_summary.json 2> gpurun_out/pmc_summary.log; tail -3 gpurun_out/pmc_summary.log; head -c 3000 gpurun_out/pmc_summary.json ;;
+runsab)
+  # the hit sort on RUNS of records (default) against records (MA_SORT_RUNS=0): step time and the sort group's kernels at BASELINE configs[3]; parity first
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_ingest.py -m gpu -q --tb=short -p no:cacheprovider -x 2>&1 | grep -vE "^\[M::|^\[pafgen" | tail -3
+  for v in "" "MA_SORT_RUNS=0" "" "MA_SORT_RUNS=0"; do
+    env $v timeout 900 python bench.py --steps 10 --warmup 2 --prof-steps 3 --no-cpu --no-legs --no-text > gpurun_out/bench_runsab.json 2> gpurun_out/bench_runsab.log; echo "[${v:-runs}] rc=$?"
+    python3 -c "
+import json; d=json.load(open('gpurun_out/bench_runsab.json')); r=d['roofline']; print('   ms_per_step %.3f  sort group %.3f ms frac %.3f' % (d['ms_per_step'], r['avg_launch_ms'], r['frac'])); [print('   %-26s x%-4g %.3f ms' % (k['name'], k['launches_per_step'], k['avg_ms'])) for k in d['kernels'] if k['name'] in ('k_hit_keys','k_radix_hist','k_radix_scatter','k_radix_colscan','k_runs_expand','k_group_close','k_hit_sub<gather>','k_hit_sub<cut+flt>','k_hit_cut_contained')]"
+  done ;;
 transab)
   # asg_arc_del_trans, first tier: round 5's pipelined kernel (default) against round 4's (MA_TRANS_OLD=1) on the graph-heavy input (100 M overlaps, 200 M arcs): HIP-event kernel times of bench.py
   GH="--reads 2000000 --lines 100000000 --seed 4 --model fixed"
