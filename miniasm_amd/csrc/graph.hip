@@ -205,6 +205,10 @@ __global__ __launch_bounds__(256) void k_arc_compact(ArcCols in, size_t n, const
 // arc (round 4, visit A: 1.25 against 3.6 ms at 200 M arcs) and serves the callers that bring a pre-filter of their own (keep_in).
 #define RM_ITEMS 8
 #define RM_TILE (256 * RM_ITEMS)
+// CLEAN (no read has been deleted since the arcs were last checked against seq.del: behind the reduction and behind asg_symm): only the del bits decide, so only the overlap
+// words are streamed -- u, v and len are fetched for the survivors alone.  Behind the reduction of a graph-heavy input 4 % of the arcs survive: 4 B per arc read
+// instead of 12 (round 5; round 4: 1.25 ms per 200 M arcs = 2.6 TB/s of the three columns).
+template <bool CLEAN>
 __global__ __launch_bounds__(256) void k_arc_rm_chain(ArcCols in, size_t n, const uint8_t *__restrict__ sdel, ArcCols out, uint32_t *__restrict__ d_total,
                                                        unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
 {
@@ -216,18 +220,22 @@ __global__ __launch_bounds__(256) void k_arc_rm_chain(ArcCols in, size_t n, cons
 	const size_t base = (size_t)tile * RM_TILE + (size_t)threadIdx.x * RM_ITEMS;
 	uint32_t u[RM_ITEMS], v[RM_ITEMS], ol[RM_ITEMS], keep = 0;
 	if (base + RM_ITEMS <= n) {
-		const uint4 *pu = (const uint4*)(in.u + base), *pv = (const uint4*)(in.v + base), *po = (const uint4*)(in.ol + base);
-		const uint4 a0 = pu[0], a1 = pu[1], b0 = pv[0], b1 = pv[1], c0 = po[0], c1 = po[1];
-		u[0] = a0.x, u[1] = a0.y, u[2] = a0.z, u[3] = a0.w, u[4] = a1.x, u[5] = a1.y, u[6] = a1.z, u[7] = a1.w;
-		v[0] = b0.x, v[1] = b0.y, v[2] = b0.z, v[3] = b0.w, v[4] = b1.x, v[5] = b1.y, v[6] = b1.z, v[7] = b1.w;
+		const uint4 *po = (const uint4*)(in.ol + base);
+		const uint4 c0 = po[0], c1 = po[1];
 		ol[0] = c0.x, ol[1] = c0.y, ol[2] = c0.z, ol[3] = c0.w, ol[4] = c1.x, ol[5] = c1.y, ol[6] = c1.z, ol[7] = c1.w;
+		if (!CLEAN) {
+			const uint4 *pu = (const uint4*)(in.u + base), *pv = (const uint4*)(in.v + base);
+			const uint4 a0 = pu[0], a1 = pu[1], b0 = pv[0], b1 = pv[1];
+			u[0] = a0.x, u[1] = a0.y, u[2] = a0.z, u[3] = a0.w, u[4] = a1.x, u[5] = a1.y, u[6] = a1.z, u[7] = a1.w;
+			v[0] = b0.x, v[1] = b0.y, v[2] = b0.z, v[3] = b0.w, v[4] = b1.x, v[5] = b1.y, v[6] = b1.z, v[7] = b1.w;
+		}
 	} else {
 #pragma unroll
-		for (int i = 0; i < RM_ITEMS; ++i) { const bool in_r = base + i < n; u[i] = in_r ? in.u[base + i] : 0; v[i] = in_r ? in.v[base + i] : 0; ol[i] = in_r ? in.ol[base + i] : ADEL; }
+		for (int i = 0; i < RM_ITEMS; ++i) { const bool in_r = base + i < n; ol[i] = in_r ? in.ol[base + i] : ADEL; if (!CLEAN) { u[i] = in_r ? in.u[base + i] : 0; v[i] = in_r ? in.v[base + i] : 0; } }
 	}
 #pragma unroll
 	for (int i = 0; i < RM_ITEMS; ++i)
-		if (base + i < n && !(ol[i] & ADEL) && (!sdel || (!sdel[u[i] >> 1] && !sdel[v[i] >> 1]))) keep |= 1u << i; // sdel == nullptr: no arc can touch a deleted read (arcs_clean)
+		if (base + i < n && !(ol[i] & ADEL) && (CLEAN || (!sdel[u[i] >> 1] && !sdel[v[i] >> 1]))) keep |= 1u << i;
 	const uint32_t cnt = (uint32_t)__popc(keep);
 	uint32_t tot;
 	const uint32_t ex = block_excl_scan_256(cnt, s_wave, &tot);
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256) void k_arc_rm_chain(ArcCols in, size_t n, cons
 	uint32_t p = s_prefix + ex;
 #pragma unroll
 	for (int i = 0; i < RM_ITEMS; ++i)
-		if (keep >> i & 1u) { out.u[p] = u[i]; out.v[p] = v[i]; out.len[p] = in.len[base + i]; out.ol[p] = ol[i]; ++p; }
+		if (keep >> i & 1u) { out.u[p] = CLEAN ? in.u[base + i] : u[i]; out.v[p] = CLEAN ? in.v[base + i] : v[i]; out.len[p] = in.len[base + i]; out.ol[p] = ol[i]; ++p; }
 	if (base < n && base + RM_ITEMS >= n) *d_total = p; // the last thread with arcs: its end is the total
 }
 
@@ -957,7 +965,8 @@ static int arc_cleanup(mahip_ctx *c, size_t n_in, int keep_in, int index_mode)
 		ProfScope ps(c, "k_arc_rm", 32.0 * (double)n_in); // asg_arc_rm 32 B per arc
 		// arcs_clean: nothing has deleted a read since the arcs were last checked against seq.del (ma_sg_gen's own asg_arc_rm, an earlier cleanup): only the arcs'
 		// del bits can have changed -- the cleanup behind the transitive reduction and behind asg_symm -- and the two look-ups per arc (1.45 -> ms at 200 M arcs) are moot
-		hipLaunchKernelGGL(k_arc_rm_chain, dim3((unsigned)nb), dim3(256), 0, c->st, in, n_in, c->arcs_clean ? (const uint8_t*)nullptr : (const uint8_t*)P<uint8_t>(c->sdel), out, d_tot, state, ticket, ticket_base, epoch);
+		if (c->arcs_clean) hipLaunchKernelGGL(k_arc_rm_chain<true>, dim3((unsigned)nb), dim3(256), 0, c->st, in, n_in, (const uint8_t*)nullptr, out, d_tot, state, ticket, ticket_base, epoch);
+		else hipLaunchKernelGGL(k_arc_rm_chain<false>, dim3((unsigned)nb), dim3(256), 0, c->st, in, n_in, (const uint8_t*)P<uint8_t>(c->sdel), out, d_tot, state, ticket, ticket_base, epoch);
 	} else {
 		ProfScope ps(c, "k_arc_rm", 32.0 * (double)n_in); // asg_arc_rm 32 B per arc
 		hipLaunchKernelGGL(k_arc_keep, dim3(grid_for(n_in, 256)), dim3(256), 0, c->st, in, n_in, (const uint8_t*)P<uint8_t>(c->sdel), P<uint32_t>(c->keep), keep_in);

@@ -160,28 +160,48 @@ __global__ __launch_bounds__(256) void k_hit_keys_runs(const ma_hit_t *__restric
 }
 
 // sorted runs -> sidx (input position of the record in every slot) + goff (first slot of every read with records; the others: radix_group_starts_finish).
-// A tile of RX_TILE consecutive runs covers a contiguous stretch of slots: the runs' lengths are scanned in the block, the tile's first slot comes from the tiles
-// before it (chained look-back), and the stretch is written by all threads, a slot each, through a binary search over the runs' offsets in LDS -- coalesced.
+// A tile of RX_TILE consecutive runs covers a contiguous stretch of slots: run (round j, thread t) = tile * RX_TILE + j * 256 + t, so that the lanes of a wave hold
+// consecutive runs -- coalesced key loads, and the single-record runs of neighbouring lanes (the mirrored half of the records) write neighbouring slots.  The lengths
+// are scanned in that order (wave scans + 32 partial sums), the tile's first slot comes from the tiles before it (chained look-back).  A run of fewer than RX_LONG
+// records is written by its own lane; a longer one (a query's own lines: ~ 50 records) by the whole wave, a record per lane.  (First version, visit 2 of round 5: a
+// thread per SLOT with a binary search over the runs' offsets in LDS -- 1.07 ms per 200 M records, most of it the eleven dependent LDS reads per slot.)
 #define RX_ITEMS 8
 #define RX_TILE (256 * RX_ITEMS)
+#define RX_LONG 16u
 template <int STRIDE>
 __global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict__ rkey, uint32_t n_runs, int bi, int bl, uint32_t n_seq, uint32_t n_slots,
                                                       uint32_t *__restrict__ sidx, uint32_t *__restrict__ goff, unsigned long long *__restrict__ ctr,
                                                       unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
 {
-	__shared__ uint32_t s_wave[4], s_off[RX_TILE + 1], s_pos[RX_TILE];
+	__shared__ uint32_t s_part[RX_ITEMS][4];
+	__shared__ uint64_t s_last[RX_ITEMS][4];
 	__shared__ uint32_t s_tile, s_prefix;
 	if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
 	__syncthreads();
-	const uint32_t tile = s_tile, r0 = tile * RX_TILE + threadIdx.x * RX_ITEMS;
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t tile = s_tile, r00 = tile * RX_TILE;
 	const uint64_t lmask = (1ull << bl) - 1ull, pmask = bi >= 64 ? ~0ull : (1ull << bi) - 1ull;
 	uint64_t k[RX_ITEMS];
-	uint32_t sum = 0, bad = 0;
+	uint32_t len[RX_ITEMS], incl[RX_ITEMS];
 #pragma unroll
-	for (int j = 0; j < RX_ITEMS; ++j) { k[j] = r0 + j < n_runs ? rkey[r0 + j] : 0ull; sum += r0 + j < n_runs ? (uint32_t)(k[j] & lmask) + 1u : 0u; }
-	uint64_t kprev = r0 > 0 && r0 <= n_runs ? rkey[r0 - 1] : 0ull; // (r0 == n_runs: nothing of this thread's is looked at)
-	uint32_t tot;
-	uint32_t ex = block_excl_scan_256(sum, s_wave, &tot);
+	for (int j = 0; j < RX_ITEMS; ++j) {
+		const uint32_t r = r00 + (uint32_t)j * 256u + threadIdx.x;
+		k[j] = r < n_runs ? rkey[r] : 0ull;
+		len[j] = r < n_runs ? (uint32_t)(k[j] & lmask) + 1u : 0u;
+	}
+	const uint64_t kfirst = r00 > 0 && threadIdx.x == 0 ? rkey[r00 - 1] : 0ull; // the run in front of the tile
+#pragma unroll
+	for (int j = 0; j < RX_ITEMS; ++j) {
+		uint32_t x = len[j];
+		for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= (unsigned)o) x += y; }
+		incl[j] = x;
+		if (lane == 63) { s_part[j][wave] = x; s_last[j][wave] = k[j]; }
+	}
+	__syncthreads();
+	uint32_t tot = 0, base[RX_ITEMS];
+#pragma unroll
+	for (int j = 0; j < RX_ITEMS; ++j)
+		for (unsigned w = 0; w < 4; ++w) { if (w == wave) base[j] = tot; tot += s_part[j][w]; }
 	if (threadIdx.x == 0) {
 		SC_PUBLISH(&state[tile], sc_pack(epoch, tile == 0 ? SC_INCL : SC_AGG, tot));
 		if (tile == 0) s_prefix = 0;
@@ -190,34 +210,31 @@ __global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict_
 		const uint32_t prefix = sc_look_back(state, tile, epoch, threadIdx.x);
 		if (threadIdx.x == 0) { s_prefix = prefix; SC_PUBLISH(&state[tile], sc_pack(epoch, SC_INCL, prefix + tot)); }
 	}
-#pragma unroll
-	for (int j = 0; j < RX_ITEMS; ++j) {
-		s_off[threadIdx.x * RX_ITEMS + j] = ex; s_pos[threadIdx.x * RX_ITEMS + j] = (uint32_t)(k[j] >> bl & pmask);
-		ex += r0 + j < n_runs ? (uint32_t)(k[j] & lmask) + 1u : 0u;
-	}
-	if (threadIdx.x == 255) s_off[RX_TILE] = ex;
 	__syncthreads();
 	const uint32_t S0 = s_prefix;
+	uint32_t bad = 0;
 #pragma unroll
 	for (int j = 0; j < RX_ITEMS; ++j) {
-		if (r0 + j < n_runs) {
+		const uint32_t r = r00 + (uint32_t)j * 256u + threadIdx.x;
+		const uint32_t off = S0 + base[j] + incl[j] - len[j], pos = (uint32_t)(k[j] >> bl & pmask);
+		// the run in front of this one: the lane to the left, the wave to the left, the round before, the tile before
+		uint64_t kp = (uint64_t)__shfl_up((uint32_t)(k[j] >> 32), 1, 64) << 32 | __shfl_up((uint32_t)k[j], 1, 64);
+		if (lane == 0) kp = wave > 0 ? s_last[j][wave - 1] : j > 0 ? s_last[j > 0 ? j - 1 : 0][3] : kfirst;
+		if (r < n_runs) {
 			const uint32_t qid = (uint32_t)(k[j] >> (bi + bl));
-			const bool first = r0 + j == 0;
-			const uint32_t qp = (uint32_t)(kprev >> (bi + bl));
-			if (first || qp != qid) { if (qid < n_seq) goff[qid] = S0 + s_off[threadIdx.x * RX_ITEMS + j]; else ++bad; } // ids are < n_seq by contract
-			else { // the read's previous run: it must end in front of this one (no interleaving, see above)
-				const uint64_t pend = (kprev >> bl & pmask) + (uint64_t)STRIDE * (kprev & lmask);
-				bad += (k[j] >> bl & pmask) <= pend;
-			}
-			kprev = k[j];
+			if (r == 0 || (uint32_t)(kp >> (bi + bl)) != qid) { if (qid < n_seq) goff[qid] = off; else ++bad; } // ids are < n_seq by contract
+			else bad += (k[j] >> bl & pmask) <= (kp >> bl & pmask) + (uint64_t)STRIDE * (kp & lmask); // the read's previous run must end in front of this one (no interleaving, see above)
+			if (r == n_runs - 1) bad += off + len[j] != n_slots; // the slots must add up to the records
+		}
+		const bool is_long = len[j] >= RX_LONG;
+		if (len[j] && !is_long)
+			for (uint32_t x = 0; x < len[j]; ++x) sidx[off + x] = pos + (uint32_t)STRIDE * x;
+		for (unsigned long long todo = wv_ballot(is_long); todo; todo &= todo - 1) { // the whole wave over one long run at a time
+			const int src = __ffsll((long long)todo) - 1;
+			const uint32_t o2 = __shfl(off, src, 64), p2 = __shfl(pos, src, 64), l2 = __shfl(len[j], src, 64);
+			for (uint32_t x = lane; x < l2; x += 64) sidx[o2 + x] = p2 + (uint32_t)STRIDE * x;
 		}
 	}
-	for (uint32_t j = threadIdx.x; j < tot; j += 256) { // slot S0 + j belongs to the last run whose offset is <= j
-		uint32_t lo = 0, hi = RX_TILE; // s_off[lo] <= j < s_off[hi]
-		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_off[mid] <= j) lo = mid; else hi = mid; }
-		if (S0 + j < n_slots) sidx[S0 + j] = s_pos[lo] + (uint32_t)STRIDE * (j - s_off[lo]);
-	}
-	if (r0 < n_runs && r0 + RX_ITEMS >= n_runs) bad += S0 + s_off[RX_TILE] != n_slots; // the last thread with runs: the slots must add up to the records
 	blk_add_u64(&ctr[CT_OVF2], bad);
 }
 
