@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+try:  # BEFORE anything loads libminiasm_amd.so: PyTorch-ROCm carries a HIP runtime of its own, and a process that loaded the system's first (through our library) finds
+    # "No HIP GPUs are available" when torch initialises later (round 5, visit 2: tests/test_gpu_ingest.py run without the modules that import torch at collection time).
+    # Loaded in this order the two share one runtime -- the order bench.py and the full suite have always had.
+    import torch  # noqa: F401
+except Exception:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
