@@ -208,6 +208,60 @@ __global__ __launch_bounds__(256) void k_arc_compact(ArcCols in, size_t n, const
 // CLEAN (no read has been deleted since the arcs were last checked against seq.del: behind the reduction and behind asg_symm): only the del bits decide, so only the overlap
 // words are streamed -- u, v and len are fetched for the survivors alone.  Behind the reduction of a graph-heavy input 4 % of the arcs survive: 4 B per arc read
 // instead of 12 (round 5; round 4: 1.25 ms per 200 M arcs = 2.6 TB/s of the three columns).
+// The CLEAN form chains GROUPS of RM_GROUP tiles (one block, one ticket per group): the ticket is ONE word that every block increments, and atomics on one address are
+// served one after the other -- 12.7 ns each here, which at 98 k tiles WAS the launch (1.24 ms whether three columns were streamed or one: round 5, visit 4).  Pass A
+// counts the group's survivors from the overlap words, publishes, looks back; pass B reads the words again (from the caches) and writes the survivors.
+#define RM_GROUP 16u
+__global__ __launch_bounds__(256) void k_arc_rm_clean(ArcCols in, size_t n, ArcCols out, uint32_t *__restrict__ d_total,
+                                                       unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
+{
+	__shared__ uint32_t s_wave[4];
+	__shared__ uint32_t s_tile, s_prefix;
+	if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+	__syncthreads();
+	const uint32_t grp = s_tile;
+	const size_t g0 = (size_t)grp * (RM_GROUP * RM_TILE), g1 = g0 + RM_GROUP * RM_TILE < n ? g0 + RM_GROUP * RM_TILE : n;
+	uint32_t mine = 0;
+	for (size_t b4 = g0 + (size_t)threadIdx.x * 4; b4 < g1; b4 += 1024) { // 4 words per lane and step (coalesced 16-byte loads; n's tail one by one)
+		if (b4 + 4 <= g1) { const uint4 w = *(const uint4*)(in.ol + b4); mine += !(w.x & ADEL) + !(w.y & ADEL) + !(w.z & ADEL) + !(w.w & ADEL); }
+		else for (size_t i = b4; i < g1; ++i) mine += !(in.ol[i] & ADEL);
+	}
+	uint32_t gtot;
+	(void)block_excl_scan_256(mine, s_wave, &gtot);
+	if (threadIdx.x == 0) {
+		SC_PUBLISH(&state[grp], sc_pack(epoch, grp == 0 ? SC_INCL : SC_AGG, gtot));
+		if (grp == 0) s_prefix = 0;
+	}
+	if (grp > 0 && threadIdx.x < 64) {
+		const uint32_t prefix = sc_look_back(state, grp, epoch, threadIdx.x);
+		if (threadIdx.x == 0) { s_prefix = prefix; SC_PUBLISH(&state[grp], sc_pack(epoch, SC_INCL, prefix + gtot)); }
+	}
+	__syncthreads();
+	uint32_t p0 = s_prefix; // first output slot of the current tile
+	for (size_t tb = g0; tb < g1; tb += RM_TILE) {
+		const size_t base = tb + (size_t)threadIdx.x * RM_ITEMS;
+		uint32_t ol[RM_ITEMS], keep = 0;
+		if (base + RM_ITEMS <= n) {
+			const uint4 *po = (const uint4*)(in.ol + base);
+			const uint4 c0 = po[0], c1 = po[1];
+			ol[0] = c0.x, ol[1] = c0.y, ol[2] = c0.z, ol[3] = c0.w, ol[4] = c1.x, ol[5] = c1.y, ol[6] = c1.z, ol[7] = c1.w;
+		} else {
+#pragma unroll
+			for (int i = 0; i < RM_ITEMS; ++i) ol[i] = base + i < n ? in.ol[base + i] : ADEL;
+		}
+#pragma unroll
+		for (int i = 0; i < RM_ITEMS; ++i) if (!(ol[i] & ADEL)) keep |= 1u << i;
+		uint32_t tot;
+		const uint32_t ex = block_excl_scan_256((uint32_t)__popc(keep), s_wave, &tot);
+		uint32_t p = p0 + ex;
+#pragma unroll
+		for (int i = 0; i < RM_ITEMS; ++i)
+			if (keep >> i & 1u) { out.u[p] = in.u[base + i]; out.v[p] = in.v[base + i]; out.len[p] = in.len[base + i]; out.ol[p] = ol[i]; ++p; }
+		p0 += tot;
+	}
+	if (g1 == n && g0 < n && threadIdx.x == 0) *d_total = p0; // the last group: its end is the total
+}
+
 template <bool CLEAN>
 __global__ __launch_bounds__(256) void k_arc_rm_chain(ArcCols in, size_t n, const uint8_t *__restrict__ sdel, ArcCols out, uint32_t *__restrict__ d_total,
                                                        unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
@@ -959,13 +1013,13 @@ static int arc_cleanup(mahip_ctx *c, size_t n_in, int keep_in, int index_mode)
 	if (n_in == 0) { c->n_arc = 0; return index_mode < 0 ? 0 : arc_reindex(c); }
 	ArcCols in = arcs_of(c, c->ag), out = arcs_of(c, c->ag ^ 1);
 	if (!keep_in) {
-		const size_t nb = (n_in + RM_TILE - 1) / RM_TILE;
+		const size_t nb = (n_in + RM_TILE - 1) / RM_TILE, ng = (nb + RM_GROUP - 1) / RM_GROUP;
 		uint32_t *ticket; unsigned long long *state; uint32_t ticket_base, epoch;
-		CHK(scan_chain_begin(c, nb, &state, &ticket, &ticket_base, &epoch));
+		CHK(scan_chain_begin(c, c->arcs_clean ? ng : nb, &state, &ticket, &ticket_base, &epoch));
 		ProfScope ps(c, "k_arc_rm", 32.0 * (double)n_in); // asg_arc_rm 32 B per arc
 		// arcs_clean: nothing has deleted a read since the arcs were last checked against seq.del (ma_sg_gen's own asg_arc_rm, an earlier cleanup): only the arcs'
 		// del bits can have changed -- the cleanup behind the transitive reduction and behind asg_symm -- and the two look-ups per arc (1.45 -> ms at 200 M arcs) are moot
-		if (c->arcs_clean) hipLaunchKernelGGL(k_arc_rm_chain<true>, dim3((unsigned)nb), dim3(256), 0, c->st, in, n_in, (const uint8_t*)nullptr, out, d_tot, state, ticket, ticket_base, epoch);
+		if (c->arcs_clean) hipLaunchKernelGGL(k_arc_rm_clean, dim3((unsigned)ng), dim3(256), 0, c->st, in, n_in, out, d_tot, state, ticket, ticket_base, epoch);
 		else hipLaunchKernelGGL(k_arc_rm_chain<false>, dim3((unsigned)nb), dim3(256), 0, c->st, in, n_in, (const uint8_t*)P<uint8_t>(c->sdel), out, d_tot, state, ticket, ticket_base, epoch);
 	} else {
 		ProfScope ps(c, "k_arc_rm", 32.0 * (double)n_in); // asg_arc_rm 32 B per arc

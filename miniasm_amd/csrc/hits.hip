@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void k_hit_keys_runs(const ma_hit_t *__restric
 #define RX_ITEMS 8
 #define RX_TILE (256 * RX_ITEMS)
 #define RX_LONG 16u
+#define RX_GROUP 8u // consecutive tiles per block (and per ticket)
 template <int STRIDE>
 __global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict__ rkey, uint32_t n_runs, int bi, int bl, uint32_t n_seq, uint32_t n_slots,
                                                       uint32_t *__restrict__ sidx, uint32_t *__restrict__ goff, unsigned long long *__restrict__ ctr,
@@ -175,12 +176,34 @@ __global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict_
 {
 	__shared__ uint32_t s_part[RX_ITEMS][4];
 	__shared__ uint64_t s_last[RX_ITEMS][4];
+	__shared__ uint32_t s_wave[4];
 	__shared__ uint32_t s_tile, s_prefix;
+	// The chain's element is a GROUP of RX_GROUP consecutive tiles, one block and one ticket per group: the ticket is one word that every block of the launch increments,
+	// and atomics on one address are served one after the other -- 12 - 17 ns each on this chip, which is what a launch of 50 k light tiles cost per tile (round 5, visit 4:
+	// 0.88 ms, twice its traffic's worth).  Pass A adds up the group's lengths (keys read once, coalesced), publishes, looks back; pass B reads the keys again (from the
+	// caches: 128 KB per group) and writes.
 	if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
 	__syncthreads();
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint32_t tile = s_tile, r00 = tile * RX_TILE;
+	const uint32_t grp = s_tile, g00 = grp * (RX_GROUP * RX_TILE);
 	const uint64_t lmask = (1ull << bl) - 1ull, pmask = bi >= 64 ? ~0ull : (1ull << bi) - 1ull;
+	uint32_t bad = 0, mine = 0;
+	for (uint32_t r = g00 + threadIdx.x; r < n_runs && r < g00 + RX_GROUP * RX_TILE; r += 256) mine += (uint32_t)(rkey[r] & lmask) + 1u;
+	uint32_t gtot;
+	(void)block_excl_scan_256(mine, s_wave, &gtot);
+	if (threadIdx.x == 0) {
+		SC_PUBLISH(&state[grp], sc_pack(epoch, grp == 0 ? SC_INCL : SC_AGG, gtot));
+		if (grp == 0) s_prefix = 0;
+	}
+	if (grp > 0 && threadIdx.x < 64) {
+		const uint32_t prefix = sc_look_back(state, grp, epoch, threadIdx.x);
+		if (threadIdx.x == 0) { s_prefix = prefix; SC_PUBLISH(&state[grp], sc_pack(epoch, SC_INCL, prefix + gtot)); }
+	}
+	__syncthreads();
+	uint32_t S0 = s_prefix; // first slot of the current tile
+	for (uint32_t kk = 0; kk < RX_GROUP; ++kk) {
+	const uint32_t r00 = g00 + kk * RX_TILE;
+	if (r00 >= n_runs) break; // (uniform)
 	uint64_t k[RX_ITEMS];
 	uint32_t len[RX_ITEMS], incl[RX_ITEMS];
 #pragma unroll
@@ -202,17 +225,6 @@ __global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict_
 #pragma unroll
 	for (int j = 0; j < RX_ITEMS; ++j)
 		for (unsigned w = 0; w < 4; ++w) { if (w == wave) base[j] = tot; tot += s_part[j][w]; }
-	if (threadIdx.x == 0) {
-		SC_PUBLISH(&state[tile], sc_pack(epoch, tile == 0 ? SC_INCL : SC_AGG, tot));
-		if (tile == 0) s_prefix = 0;
-	}
-	if (tile > 0 && threadIdx.x < 64) {
-		const uint32_t prefix = sc_look_back(state, tile, epoch, threadIdx.x);
-		if (threadIdx.x == 0) { s_prefix = prefix; SC_PUBLISH(&state[tile], sc_pack(epoch, SC_INCL, prefix + tot)); }
-	}
-	__syncthreads();
-	const uint32_t S0 = s_prefix;
-	uint32_t bad = 0;
 #pragma unroll
 	for (int j = 0; j < RX_ITEMS; ++j) {
 		const uint32_t r = r00 + (uint32_t)j * 256u + threadIdx.x;
@@ -234,6 +246,9 @@ __global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict_
 			const uint32_t o2 = __shfl(off, src, 64), p2 = __shfl(pos, src, 64), l2 = __shfl(len[j], src, 64);
 			for (uint32_t x = lane; x < l2; x += 64) sidx[o2 + x] = p2 + (uint32_t)STRIDE * x;
 		}
+	}
+	S0 += tot;
+	__syncthreads(); // (s_part / s_last are the next tile's)
 	}
 	blk_add_u64(&ctr[CT_OVF2], bad);
 }
@@ -1470,14 +1485,14 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 			int g2 = 0;
 			CHK(radix_sort_keys(c, n_runs, bi + bl, bi + bl + bq, &g2, false));
 			CHK(radix_group_starts_begin(c, P<uint32_t>(c->goff), c->n_seq, (uint32_t)n));
-			const size_t nb2 = (n_runs + RX_TILE - 1) / RX_TILE;
-			CHK(scan_chain_begin(c, nb2, &state, &ticket, &ticket_base, &epoch));
+			const size_t nb2 = (n_runs + RX_TILE - 1) / RX_TILE, ng2 = (nb2 + RX_GROUP - 1) / RX_GROUP;
+			CHK(scan_chain_begin(c, ng2, &state, &ticket, &ticket_base, &epoch));
 			HIPCHK(hipMemsetAsync(ctr + CT_OVF2, 0, 8, c->st));
 			{
 				ProfScope ps(c, "k_runs_expand", 8.0 * (double)n_runs + 4.0 * (double)n);
-				if (c->run_stride == 2) hipLaunchKernelGGL(k_runs_expand<2>, dim3((unsigned)nb2), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[g2]), (uint32_t)n_runs, bi, bl, c->n_seq, (uint32_t)n,
+				if (c->run_stride == 2) hipLaunchKernelGGL(k_runs_expand<2>, dim3((unsigned)ng2), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[g2]), (uint32_t)n_runs, bi, bl, c->n_seq, (uint32_t)n,
 				                                           P<uint32_t>(c->sidx), P<uint32_t>(c->goff), ctr, state, ticket, ticket_base, epoch);
-				else hipLaunchKernelGGL(k_runs_expand<1>, dim3((unsigned)nb2), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[g2]), (uint32_t)n_runs, bi, bl, c->n_seq, (uint32_t)n,
+				else hipLaunchKernelGGL(k_runs_expand<1>, dim3((unsigned)ng2), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[g2]), (uint32_t)n_runs, bi, bl, c->n_seq, (uint32_t)n,
 				                        P<uint32_t>(c->sidx), P<uint32_t>(c->goff), ctr, state, ticket, ticket_base, epoch);
 			}
 			CHK(radix_group_starts_finish(c, P<uint32_t>(c->goff), c->n_seq));

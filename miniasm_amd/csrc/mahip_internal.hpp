@@ -193,7 +193,7 @@ void radix_first_digit(int lo, int hi, int *shift, int *bits, unsigned *tile);
 int radix_reserve_hist(mahip_ctx *c, size_t n);
 int radix_group_starts_begin(mahip_ctx *c, uint32_t *start, uint32_t n_id, uint32_t n);  // start[id] = ~0, start[n_id] = n; a pass then notes the first slot of every id that has keys ...
 int radix_group_starts_finish(mahip_ctx *c, uint32_t *start, uint32_t n_id);           // ... and ids without keys are closed (a suffix minimum): CSR offsets
-int scan_chain_begin(mahip_ctx *c, size_t nb, unsigned long long **state, uint32_t **ticket, uint32_t *ticket_base, uint32_t *epoch);
+int scan_chain_begin(mahip_ctx *c, size_t nb, unsigned long long **state, uint32_t **ticket, uint32_t *ticket_base, uint32_t *epoch, size_t n_tickets = 0);
 // the permutation the reference's (unstable) sort applies to d_keys[0..n) (input order), written to d_perm
 int reference_order(mahip_ctx *c, uint64_t *d_keys /* overwritten */, size_t n, uint32_t *d_perm);
 void walk_scratch_release(mahip_ctx *c); // the host arrays of the walks go away (on a thread of their own when they are big)

@@ -154,8 +154,8 @@ static size_t scan_chain_max() { static long v = -1; if (v < 0) { const char *e 
 
 // the published words + ticket of ONE chained launch of nb tiles (k_scan_chain, graph.hip: k_arc_rm_chain): the tiles behind one ticket word; fresh memory
 // is cleared once, afterwards the launch epoch tells this launch's words from older ones
-int scan_chain_begin(mahip_ctx *c, size_t nb, unsigned long long **state, uint32_t **ticket, uint32_t *ticket_base, uint32_t *epoch)
-{
+int scan_chain_begin(mahip_ctx *c, size_t nb, unsigned long long **state, uint32_t **ticket, uint32_t *ticket_base, uint32_t *epoch, size_t n_tickets)
+{ // nb: published words (tiles); n_tickets: blocks that draw a ticket (0: one per tile; a block that works through several consecutive tiles draws one for all of them)
 	if (c->scan_tmp[0].cap < (nb + 8) * 8 + 64) { // epoch 0 is never used
 		CHK(dev_reserve(c, c->scan_tmp[0], (nb + 8) * 8 * 2 + 64));
 		HIPCHK(hipMemsetAsync(c->scan_tmp[0].p, 0, c->scan_tmp[0].cap, c->st));
@@ -165,7 +165,7 @@ int scan_chain_begin(mahip_ctx *c, size_t nb, unsigned long long **state, uint32
 	*state = (unsigned long long*)((char*)c->scan_tmp[0].p + 64);
 	if (++c->scan_epoch >= (1u << 30)) { HIPCHK(hipMemsetAsync(*state, 0, c->scan_tmp[0].cap - 64, c->st)); c->scan_epoch = 1; } // (after 2^30 launches)
 	*ticket_base = c->scan_ticket; *epoch = c->scan_epoch;
-	c->scan_ticket += (uint32_t)nb;
+	c->scan_ticket += (uint32_t)(n_tickets ? n_tickets : nb);
 	return 0;
 }
 
