@@ -222,9 +222,16 @@ __global__ __launch_bounds__(256) void k_arc_rm_clean(ArcCols in, size_t n, ArcC
 	const uint32_t grp = s_tile;
 	const size_t g0 = (size_t)grp * (RM_GROUP * RM_TILE), g1 = g0 + RM_GROUP * RM_TILE < n ? g0 + RM_GROUP * RM_TILE : n;
 	uint32_t mine = 0;
-	for (size_t b4 = g0 + (size_t)threadIdx.x * 4; b4 < g1; b4 += 1024) { // 4 words per lane and step (coalesced 16-byte loads; n's tail one by one)
-		if (b4 + 4 <= g1) { const uint4 w = *(const uint4*)(in.ol + b4); mine += !(w.x & ADEL) + !(w.y & ADEL) + !(w.z & ADEL) + !(w.w & ADEL); }
-		else for (size_t i = b4; i < g1; ++i) mine += !(in.ol[i] & ADEL);
+	for (size_t b0 = g0; b0 < g1; b0 += 8 * 1024) { // 4 words per lane and load (coalesced 16-byte loads), 8 independent loads in flight; n's tail one by one
+		uint4 w[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) { const size_t b4 = b0 + (size_t)j * 1024 + (size_t)threadIdx.x * 4; w[j] = b4 + 4 <= g1 ? *(const uint4*)(in.ol + b4) : make_uint4(ADEL, ADEL, ADEL, ADEL); }
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const size_t b4 = b0 + (size_t)j * 1024 + (size_t)threadIdx.x * 4;
+			mine += !(w[j].x & ADEL) + !(w[j].y & ADEL) + !(w[j].z & ADEL) + !(w[j].w & ADEL);
+			if (b4 < g1 && b4 + 4 > g1) for (size_t i = b4; i < g1; ++i) mine += !(in.ol[i] & ADEL);
+		}
 	}
 	uint32_t gtot;
 	(void)block_excl_scan_256(mine, s_wave, &gtot);

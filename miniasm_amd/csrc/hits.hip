@@ -188,7 +188,13 @@ __global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict_
 	const uint32_t grp = s_tile, g00 = grp * (RX_GROUP * RX_TILE);
 	const uint64_t lmask = (1ull << bl) - 1ull, pmask = bi >= 64 ? ~0ull : (1ull << bi) - 1ull;
 	uint32_t bad = 0, mine = 0;
-	for (uint32_t r = g00 + threadIdx.x; r < n_runs && r < g00 + RX_GROUP * RX_TILE; r += 256) mine += (uint32_t)(rkey[r] & lmask) + 1u;
+	for (uint32_t kk = 0; kk < RX_GROUP; kk += 2) { // 16 independent loads in flight (one load per trip, each waited for, was 64 round trips to memory per block)
+		uint64_t kk2[2 * RX_ITEMS];
+#pragma unroll
+		for (int j = 0; j < 2 * RX_ITEMS; ++j) { const uint32_t r = g00 + kk * RX_TILE + (uint32_t)j * 256u + threadIdx.x; kk2[j] = r < n_runs ? rkey[r] : ~0ull; }
+#pragma unroll
+		for (int j = 0; j < 2 * RX_ITEMS; ++j) mine += kk2[j] == ~0ull ? 0u : (uint32_t)(kk2[j] & lmask) + 1u; // (no key is all ones: the id field is < n_seq)
+	}
 	uint32_t gtot;
 	(void)block_excl_scan_256(mine, s_wave, &gtot);
 	if (threadIdx.x == 0) {
