@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256) void k_arc_compact(ArcCols in, size_t n, const
 // The CLEAN form chains GROUPS of RM_GROUP tiles (one block, one ticket per group): the ticket is ONE word that every block increments, and atomics on one address are
 // served one after the other -- 12.7 ns each here, which at 98 k tiles WAS the launch (1.24 ms whether three columns were streamed or one: round 5, visit 4).  Pass A
 // counts the group's survivors from the overlap words, publishes, looks back; pass B reads the words again (from the caches) and writes the survivors.
-#define RM_GROUP 16u
+#define RMC_ITEMS 16
+#define RMC_TILE (256 * RMC_ITEMS)
+#define RM_GROUP 8u // x RMC_TILE arcs per block and ticket
 __global__ __launch_bounds__(256) void k_arc_rm_clean(ArcCols in, size_t n, ArcCols out, uint32_t *__restrict__ d_total,
                                                        unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
 {
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void k_arc_rm_clean(ArcCols in, size_t n, ArcC
 	if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
 	__syncthreads();
 	const uint32_t grp = s_tile;
-	const size_t g0 = (size_t)grp * (RM_GROUP * RM_TILE), g1 = g0 + RM_GROUP * RM_TILE < n ? g0 + RM_GROUP * RM_TILE : n;
+	const size_t g0 = (size_t)grp * (RM_GROUP * RMC_TILE), g1 = g0 + RM_GROUP * RMC_TILE < n ? g0 + RM_GROUP * RMC_TILE : n;
 	uint32_t mine = 0;
 	for (size_t b0 = g0; b0 < g1; b0 += 8 * 1024) { // 4 words per lane and load (coalesced 16-byte loads), 8 independent loads in flight; n's tail one by one
 		uint4 w[8];
@@ -245,26 +247,35 @@ __global__ __launch_bounds__(256) void k_arc_rm_clean(ArcCols in, size_t n, ArcC
 	}
 	__syncthreads();
 	uint32_t p0 = s_prefix; // first output slot of the current tile
-	for (size_t tb = g0; tb < g1; tb += RM_TILE) {
-		const size_t base = tb + (size_t)threadIdx.x * RM_ITEMS;
-		uint32_t ol[RM_ITEMS], keep = 0;
-		if (base + RM_ITEMS <= n) {
+	// tiles of RMC_ITEMS words per thread; the next tile's words are in flight while this tile's survivors are counted and placed
+	auto load_tile = [&](size_t tb, uint32_t *w) {
+		const size_t base = tb + (size_t)threadIdx.x * RMC_ITEMS;
+		if (base + RMC_ITEMS <= g1) {
 			const uint4 *po = (const uint4*)(in.ol + base);
-			const uint4 c0 = po[0], c1 = po[1];
-			ol[0] = c0.x, ol[1] = c0.y, ol[2] = c0.z, ol[3] = c0.w, ol[4] = c1.x, ol[5] = c1.y, ol[6] = c1.z, ol[7] = c1.w;
+#pragma unroll
+			for (int q4 = 0; q4 < RMC_ITEMS / 4; ++q4) { const uint4 c = po[q4]; w[4 * q4] = c.x, w[4 * q4 + 1] = c.y, w[4 * q4 + 2] = c.z, w[4 * q4 + 3] = c.w; }
 		} else {
 #pragma unroll
-			for (int i = 0; i < RM_ITEMS; ++i) ol[i] = base + i < n ? in.ol[base + i] : ADEL;
+			for (int i = 0; i < RMC_ITEMS; ++i) w[i] = base + i < g1 ? in.ol[base + i] : ADEL;
 		}
+	};
+	uint32_t cur[RMC_ITEMS], nxt[RMC_ITEMS];
+	load_tile(g0, cur);
+	for (size_t tb = g0; tb < g1; tb += RMC_TILE) {
+		load_tile(tb + RMC_TILE, nxt); // (behind the group's end: all ADEL, nothing is read)
+		const size_t base = tb + (size_t)threadIdx.x * RMC_ITEMS;
+		uint32_t keep = 0;
 #pragma unroll
-		for (int i = 0; i < RM_ITEMS; ++i) if (!(ol[i] & ADEL)) keep |= 1u << i;
+		for (int i = 0; i < RMC_ITEMS; ++i) if (!(cur[i] & ADEL)) keep |= 1u << i;
 		uint32_t tot;
 		const uint32_t ex = block_excl_scan_256((uint32_t)__popc(keep), s_wave, &tot);
 		uint32_t p = p0 + ex;
 #pragma unroll
-		for (int i = 0; i < RM_ITEMS; ++i)
-			if (keep >> i & 1u) { out.u[p] = in.u[base + i]; out.v[p] = in.v[base + i]; out.len[p] = in.len[base + i]; out.ol[p] = ol[i]; ++p; }
+		for (int i = 0; i < RMC_ITEMS; ++i)
+			if (keep >> i & 1u) { out.u[p] = in.u[base + i]; out.v[p] = in.v[base + i]; out.len[p] = in.len[base + i]; out.ol[p] = cur[i]; ++p; }
 		p0 += tot;
+#pragma unroll
+		for (int i = 0; i < RMC_ITEMS; ++i) cur[i] = nxt[i];
 	}
 	if (g1 == n && g0 < n && threadIdx.x == 0) *d_total = p0; // the last group: its end is the total
 }
@@ -1020,7 +1031,7 @@ static int arc_cleanup(mahip_ctx *c, size_t n_in, int keep_in, int index_mode)
 	if (n_in == 0) { c->n_arc = 0; return index_mode < 0 ? 0 : arc_reindex(c); }
 	ArcCols in = arcs_of(c, c->ag), out = arcs_of(c, c->ag ^ 1);
 	if (!keep_in) {
-		const size_t nb = (n_in + RM_TILE - 1) / RM_TILE, ng = (nb + RM_GROUP - 1) / RM_GROUP;
+		const size_t nb = (n_in + RM_TILE - 1) / RM_TILE, ng = (n_in + (size_t)RM_GROUP * RMC_TILE - 1) / ((size_t)RM_GROUP * RMC_TILE);
 		uint32_t *ticket; unsigned long long *state; uint32_t ticket_base, epoch;
 		CHK(scan_chain_begin(c, c->arcs_clean ? ng : nb, &state, &ticket, &ticket_base, &epoch));
 		ProfScope ps(c, "k_arc_rm", 32.0 * (double)n_in); // asg_arc_rm 32 B per arc
