@@ -168,7 +168,14 @@ __global__ __launch_bounds__(256) void k_hit_keys_runs(const ma_hit_t *__restric
 #define RX_ITEMS 8
 #define RX_TILE (256 * RX_ITEMS)
 #define RX_LONG 16u
-#define RX_GROUP 8u // consecutive tiles per block (and per ticket)
+#ifndef RX_KEEP
+#define RX_KEEP 1 // 1: a group's keys stay in registers from the count to the writes (4 tiles, every key read once); 0: 8 tiles, the keys are read a second time (from the caches)
+#endif
+#if RX_KEEP
+#define RX_GROUP 4u // consecutive tiles per block (and per ticket)
+#else
+#define RX_GROUP 8u
+#endif
 template <int STRIDE>
 __global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict__ rkey, uint32_t n_runs, int bi, int bl, uint32_t n_seq, uint32_t n_slots,
                                                       uint32_t *__restrict__ sidx, uint32_t *__restrict__ goff, unsigned long long *__restrict__ ctr,
@@ -180,21 +187,33 @@ __global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict_
 	__shared__ uint32_t s_tile, s_prefix;
 	// The chain's element is a GROUP of RX_GROUP consecutive tiles, one block and one ticket per group: the ticket is one word that every block of the launch increments,
 	// and atomics on one address are served one after the other -- 12 - 17 ns each on this chip, which is what a launch of 50 k light tiles cost per tile (round 5, visit 4:
-	// 0.88 ms, twice its traffic's worth).  Pass A adds up the group's lengths (keys read once, coalesced), publishes, looks back; pass B reads the keys again (from the
-	// caches: 128 KB per group) and writes.
+	// 0.88 ms, twice its traffic's worth).  The block reads the group's keys ONCE (coalesced, all in flight at once), adds up the lengths, publishes, looks back, and
+	// writes tile by tile from the registers.
 	if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
 	__syncthreads();
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t grp = s_tile, g00 = grp * (RX_GROUP * RX_TILE);
 	const uint64_t lmask = (1ull << bl) - 1ull, pmask = bi >= 64 ? ~0ull : (1ull << bi) - 1ull;
 	uint32_t bad = 0, mine = 0;
-	for (uint32_t kk = 0; kk < RX_GROUP; kk += 2) { // 16 independent loads in flight (one load per trip, each waited for, was 64 round trips to memory per block)
+#if RX_KEEP
+	uint64_t kg[RX_GROUP][RX_ITEMS]; // the group's keys stay in registers from the count to the writes: every key is read once
+#pragma unroll
+	for (int kk = 0; kk < (int)RX_GROUP; ++kk)
+#pragma unroll
+		for (int j = 0; j < RX_ITEMS; ++j) { const uint32_t r = g00 + (uint32_t)kk * RX_TILE + (uint32_t)j * 256u + threadIdx.x; kg[kk][j] = r < n_runs ? rkey[r] : 0ull; }
+#pragma unroll
+	for (int kk = 0; kk < (int)RX_GROUP; ++kk)
+#pragma unroll
+		for (int j = 0; j < RX_ITEMS; ++j) { const uint32_t r = g00 + (uint32_t)kk * RX_TILE + (uint32_t)j * 256u + threadIdx.x; mine += r < n_runs ? (uint32_t)(kg[kk][j] & lmask) + 1u : 0u; }
+#else
+	for (uint32_t kk = 0; kk < RX_GROUP; kk += 2) { // 16 independent loads in flight
 		uint64_t kk2[2 * RX_ITEMS];
 #pragma unroll
 		for (int j = 0; j < 2 * RX_ITEMS; ++j) { const uint32_t r = g00 + kk * RX_TILE + (uint32_t)j * 256u + threadIdx.x; kk2[j] = r < n_runs ? rkey[r] : ~0ull; }
 #pragma unroll
 		for (int j = 0; j < 2 * RX_ITEMS; ++j) mine += kk2[j] == ~0ull ? 0u : (uint32_t)(kk2[j] & lmask) + 1u; // (no key is all ones: the id field is < n_seq)
 	}
+#endif
 	uint32_t gtot;
 	(void)block_excl_scan_256(mine, s_wave, &gtot);
 	if (threadIdx.x == 0) {
@@ -207,15 +226,20 @@ __global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict_
 	}
 	__syncthreads();
 	uint32_t S0 = s_prefix; // first slot of the current tile
-	for (uint32_t kk = 0; kk < RX_GROUP; ++kk) {
-	const uint32_t r00 = g00 + kk * RX_TILE;
+#pragma unroll
+	for (int kk = 0; kk < (int)RX_GROUP; ++kk) {
+	const uint32_t r00 = g00 + (uint32_t)kk * RX_TILE;
 	if (r00 >= n_runs) break; // (uniform)
 	uint64_t k[RX_ITEMS];
 	uint32_t len[RX_ITEMS], incl[RX_ITEMS];
 #pragma unroll
 	for (int j = 0; j < RX_ITEMS; ++j) {
 		const uint32_t r = r00 + (uint32_t)j * 256u + threadIdx.x;
+#if RX_KEEP
+		k[j] = kg[kk][j];
+#else
 		k[j] = r < n_runs ? rkey[r] : 0ull;
+#endif
 		len[j] = r < n_runs ? (uint32_t)(k[j] & lmask) + 1u : 0u;
 	}
 	const uint64_t kfirst = r00 > 0 && threadIdx.x == 0 ? rkey[r00 - 1] : 0ull; // the run in front of the tile

@@ -28,7 +28,7 @@ n = sys.argv[1]
 try:
     d = json.load(open("gpurun_out/variants/%s.json" % n))
     ks = {k["name"]: (k["launches_per_step"], k["avg_ms"]) for k in d["kernels"]}
-    print("%-12s step %.3f ms | " % (n, d["ms_per_step"]) + "  ".join("%s %gx%.3f" % (k, v[0], v[1]) for k, v in ks.items() if k in ("k_hit_sub<gather>", "k_radix_scatter", "k_radix_hist", "k_hit_keys", "k_hit_goff", "k_hit_sub<cut+flt>", "k_hit_cut_contained")) + ("  identical %s" % d.get("gfa_identical")))
+    print("%-12s step %.3f ms | " % (n, d["ms_per_step"]) + "  ".join("%s %gx%.3f" % (k, v[0], v[1]) for k, v in ks.items() if k in ("k_hit_sub<gather>", "k_radix_scatter", "k_radix_hist", "k_hit_keys", "k_runs_expand", "k_hit_sub<cut+flt>", "k_hit_cut_contained")) + ("  identical %s" % d.get("gfa_identical")))
 except Exception as e:
     print(n, "failed:", e)
 PY
