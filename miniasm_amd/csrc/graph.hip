@@ -208,76 +208,60 @@ __global__ __launch_bounds__(256) void k_arc_compact(ArcCols in, size_t n, const
 // CLEAN (no read has been deleted since the arcs were last checked against seq.del: behind the reduction and behind asg_symm): only the del bits decide, so only the overlap
 // words are streamed -- u, v and len are fetched for the survivors alone.  Behind the reduction of a graph-heavy input 4 % of the arcs survive: 4 B per arc read
 // instead of 12 (round 5; round 4: 1.25 ms per 200 M arcs = 2.6 TB/s of the three columns).
-// The CLEAN form chains GROUPS of RM_GROUP tiles (one block, one ticket per group): the ticket is ONE word that every block increments, and atomics on one address are
-// served one after the other -- 12.7 ns each here, which at 98 k tiles WAS the launch (1.24 ms whether three columns were streamed or one: round 5, visit 4).  Pass A
-// counts the group's survivors from the overlap words, publishes, looks back; pass B reads the words again (from the caches) and writes the survivors.
-#define RMC_ITEMS 16
+// The CLEAN form is THREE launches instead of a chain: a chain's ticket is ONE word that every block increments, and atomics on one address are served one after the
+// other -- 12.7 ns each here, which at 98 k tiles WAS the launch (1.24 ms whether three columns were streamed or one: round 5, visit 4); chaining groups of tiles instead
+// (one ticket per 32 k arcs) made every block of the launch publish at the same moment and look back over all the others at once (0.83 - 1.0 ms, visits 5 - 7).  So:
+// count the survivors of every group of RMC_GROUP arcs from the overlap words, scan the (few thousand) counts, read the words again and write the survivors.
+#define RMC_ITEMS 8
 #define RMC_TILE (256 * RMC_ITEMS)
-#define RM_GROUP 8u // x RMC_TILE arcs per block and ticket
-__global__ __launch_bounds__(256) void k_arc_rm_clean(ArcCols in, size_t n, ArcCols out, uint32_t *__restrict__ d_total,
-                                                       unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
+#define RMC_TILES 16u
+#define RMC_GROUP ((size_t)RMC_TILES * RMC_TILE)
+__global__ __launch_bounds__(256) void k_arc_rm_count(const uint32_t *__restrict__ aol, size_t n, uint32_t *__restrict__ cnt)
 {
 	__shared__ uint32_t s_wave[4];
-	__shared__ uint32_t s_tile, s_prefix;
-	if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
-	__syncthreads();
-	const uint32_t grp = s_tile;
-	const size_t g0 = (size_t)grp * (RM_GROUP * RMC_TILE), g1 = g0 + RM_GROUP * RMC_TILE < n ? g0 + RM_GROUP * RMC_TILE : n;
+	const size_t g0 = (size_t)blockIdx.x * RMC_GROUP, g1 = g0 + RMC_GROUP < n ? g0 + RMC_GROUP : n;
 	uint32_t mine = 0;
 	for (size_t b0 = g0; b0 < g1; b0 += 8 * 1024) { // 4 words per lane and load (coalesced 16-byte loads), 8 independent loads in flight; n's tail one by one
 		uint4 w[8];
 #pragma unroll
-		for (int j = 0; j < 8; ++j) { const size_t b4 = b0 + (size_t)j * 1024 + (size_t)threadIdx.x * 4; w[j] = b4 + 4 <= g1 ? *(const uint4*)(in.ol + b4) : make_uint4(ADEL, ADEL, ADEL, ADEL); }
+		for (int j = 0; j < 8; ++j) { const size_t b4 = b0 + (size_t)j * 1024 + (size_t)threadIdx.x * 4; w[j] = b4 + 4 <= g1 ? *(const uint4*)(aol + b4) : make_uint4(ADEL, ADEL, ADEL, ADEL); }
 #pragma unroll
 		for (int j = 0; j < 8; ++j) {
 			const size_t b4 = b0 + (size_t)j * 1024 + (size_t)threadIdx.x * 4;
 			mine += !(w[j].x & ADEL) + !(w[j].y & ADEL) + !(w[j].z & ADEL) + !(w[j].w & ADEL);
-			if (b4 < g1 && b4 + 4 > g1) for (size_t i = b4; i < g1; ++i) mine += !(in.ol[i] & ADEL);
+			if (b4 < g1 && b4 + 4 > g1) for (size_t i = b4; i < g1; ++i) mine += !(aol[i] & ADEL);
 		}
 	}
 	uint32_t gtot;
 	(void)block_excl_scan_256(mine, s_wave, &gtot);
-	if (threadIdx.x == 0) {
-		SC_PUBLISH(&state[grp], sc_pack(epoch, grp == 0 ? SC_INCL : SC_AGG, gtot));
-		if (grp == 0) s_prefix = 0;
-	}
-	if (grp > 0 && threadIdx.x < 64) {
-		const uint32_t prefix = sc_look_back(state, grp, epoch, threadIdx.x);
-		if (threadIdx.x == 0) { s_prefix = prefix; SC_PUBLISH(&state[grp], sc_pack(epoch, SC_INCL, prefix + gtot)); }
-	}
-	__syncthreads();
-	uint32_t p0 = s_prefix; // first output slot of the current tile
-	// tiles of RMC_ITEMS words per thread; the next tile's words are in flight while this tile's survivors are counted and placed
-	auto load_tile = [&](size_t tb, uint32_t *w) {
+	if (threadIdx.x == 0) cnt[blockIdx.x] = gtot;
+}
+__global__ __launch_bounds__(256) void k_arc_rm_write(ArcCols in, size_t n, ArcCols out, const uint32_t *__restrict__ pre)
+{
+	__shared__ uint32_t s_wave[4];
+	const size_t g0 = (size_t)blockIdx.x * RMC_GROUP, g1 = g0 + RMC_GROUP < n ? g0 + RMC_GROUP : n;
+	uint32_t p0 = pre[blockIdx.x]; // first output slot of the current tile
+	for (size_t tb = g0; tb < g1; tb += RMC_TILE) {
 		const size_t base = tb + (size_t)threadIdx.x * RMC_ITEMS;
-		if (base + RMC_ITEMS <= g1) {
+		uint32_t ol[RMC_ITEMS], keep = 0;
+		if (base + RMC_ITEMS <= n) {
 			const uint4 *po = (const uint4*)(in.ol + base);
-#pragma unroll
-			for (int q4 = 0; q4 < RMC_ITEMS / 4; ++q4) { const uint4 c = po[q4]; w[4 * q4] = c.x, w[4 * q4 + 1] = c.y, w[4 * q4 + 2] = c.z, w[4 * q4 + 3] = c.w; }
+			const uint4 c0 = po[0], c1 = po[1];
+			ol[0] = c0.x, ol[1] = c0.y, ol[2] = c0.z, ol[3] = c0.w, ol[4] = c1.x, ol[5] = c1.y, ol[6] = c1.z, ol[7] = c1.w;
 		} else {
 #pragma unroll
-			for (int i = 0; i < RMC_ITEMS; ++i) w[i] = base + i < g1 ? in.ol[base + i] : ADEL;
+			for (int i = 0; i < RMC_ITEMS; ++i) ol[i] = base + i < n ? in.ol[base + i] : ADEL;
 		}
-	};
-	uint32_t cur[RMC_ITEMS], nxt[RMC_ITEMS];
-	load_tile(g0, cur);
-	for (size_t tb = g0; tb < g1; tb += RMC_TILE) {
-		load_tile(tb + RMC_TILE, nxt); // (behind the group's end: all ADEL, nothing is read)
-		const size_t base = tb + (size_t)threadIdx.x * RMC_ITEMS;
-		uint32_t keep = 0;
 #pragma unroll
-		for (int i = 0; i < RMC_ITEMS; ++i) if (!(cur[i] & ADEL)) keep |= 1u << i;
+		for (int i = 0; i < RMC_ITEMS; ++i) if (!(ol[i] & ADEL)) keep |= 1u << i;
 		uint32_t tot;
 		const uint32_t ex = block_excl_scan_256((uint32_t)__popc(keep), s_wave, &tot);
 		uint32_t p = p0 + ex;
 #pragma unroll
 		for (int i = 0; i < RMC_ITEMS; ++i)
-			if (keep >> i & 1u) { out.u[p] = in.u[base + i]; out.v[p] = in.v[base + i]; out.len[p] = in.len[base + i]; out.ol[p] = cur[i]; ++p; }
+			if (keep >> i & 1u) { out.u[p] = in.u[base + i]; out.v[p] = in.v[base + i]; out.len[p] = in.len[base + i]; out.ol[p] = ol[i]; ++p; }
 		p0 += tot;
-#pragma unroll
-		for (int i = 0; i < RMC_ITEMS; ++i) cur[i] = nxt[i];
 	}
-	if (g1 == n && g0 < n && threadIdx.x == 0) *d_total = p0; // the last group: its end is the total
 }
 
 template <bool CLEAN>
@@ -1031,14 +1015,20 @@ static int arc_cleanup(mahip_ctx *c, size_t n_in, int keep_in, int index_mode)
 	if (n_in == 0) { c->n_arc = 0; return index_mode < 0 ? 0 : arc_reindex(c); }
 	ArcCols in = arcs_of(c, c->ag), out = arcs_of(c, c->ag ^ 1);
 	if (!keep_in) {
-		const size_t nb = (n_in + RM_TILE - 1) / RM_TILE, ng = (n_in + (size_t)RM_GROUP * RMC_TILE - 1) / ((size_t)RM_GROUP * RMC_TILE);
-		uint32_t *ticket; unsigned long long *state; uint32_t ticket_base, epoch;
-		CHK(scan_chain_begin(c, c->arcs_clean ? ng : nb, &state, &ticket, &ticket_base, &epoch));
 		ProfScope ps(c, "k_arc_rm", 32.0 * (double)n_in); // asg_arc_rm 32 B per arc
 		// arcs_clean: nothing has deleted a read since the arcs were last checked against seq.del (ma_sg_gen's own asg_arc_rm, an earlier cleanup): only the arcs'
-		// del bits can have changed -- the cleanup behind the transitive reduction and behind asg_symm -- and the two look-ups per arc (1.45 -> ms at 200 M arcs) are moot
-		if (c->arcs_clean) hipLaunchKernelGGL(k_arc_rm_clean, dim3((unsigned)ng), dim3(256), 0, c->st, in, n_in, out, d_tot, state, ticket, ticket_base, epoch);
-		else hipLaunchKernelGGL(k_arc_rm_chain<false>, dim3((unsigned)nb), dim3(256), 0, c->st, in, n_in, (const uint8_t*)P<uint8_t>(c->sdel), out, d_tot, state, ticket, ticket_base, epoch);
+		// del bits can have changed -- the cleanup behind the transitive reduction and behind asg_symm -- and the two look-ups per arc are moot
+		if (c->arcs_clean) {
+			const size_t ng = (n_in + RMC_GROUP - 1) / RMC_GROUP;
+			hipLaunchKernelGGL(k_arc_rm_count, dim3((unsigned)ng), dim3(256), 0, c->st, (const uint32_t*)in.ol, n_in, P<uint32_t>(c->keep));
+			CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), ng, d_tot));
+			hipLaunchKernelGGL(k_arc_rm_write, dim3((unsigned)ng), dim3(256), 0, c->st, in, n_in, out, (const uint32_t*)P<uint32_t>(c->pos));
+		} else {
+			const size_t nb = (n_in + RM_TILE - 1) / RM_TILE;
+			uint32_t *ticket; unsigned long long *state; uint32_t ticket_base, epoch;
+			CHK(scan_chain_begin(c, nb, &state, &ticket, &ticket_base, &epoch));
+			hipLaunchKernelGGL(k_arc_rm_chain<false>, dim3((unsigned)nb), dim3(256), 0, c->st, in, n_in, (const uint8_t*)P<uint8_t>(c->sdel), out, d_tot, state, ticket, ticket_base, epoch);
+		}
 	} else {
 		ProfScope ps(c, "k_arc_rm", 32.0 * (double)n_in); // asg_arc_rm 32 B per arc
 		hipLaunchKernelGGL(k_arc_keep, dim3(grid_for(n_in, 256)), dim3(256), 0, c->st, in, n_in, (const uint8_t*)P<uint8_t>(c->sdel), P<uint32_t>(c->keep), keep_in);

@@ -160,52 +160,24 @@ __global__ __launch_bounds__(256) void k_hit_keys_runs(const ma_hit_t *__restric
 }
 
 // sorted runs -> sidx (input position of the record in every slot) + goff (first slot of every read with records; the others: radix_group_starts_finish).
-// A tile of RX_TILE consecutive runs covers a contiguous stretch of slots: run (round j, thread t) = tile * RX_TILE + j * 256 + t, so that the lanes of a wave hold
-// consecutive runs -- coalesced key loads, and the single-record runs of neighbouring lanes (the mirrored half of the records) write neighbouring slots.  The lengths
-// are scanned in that order (wave scans + 32 partial sums), the tile's first slot comes from the tiles before it (chained look-back).  A run of fewer than RX_LONG
-// records is written by its own lane; a longer one (a query's own lines: ~ 50 records) by the whole wave, a record per lane.  (First version, visit 2 of round 5: a
-// thread per SLOT with a binary search over the runs' offsets in LDS -- 1.07 ms per 200 M records, most of it the eleven dependent LDS reads per slot.)
+// Three launches: the records of every GROUP of RX_GROUP x RX_TILE consecutive runs are counted (k_runs_count), the few thousand counts scanned, and k_runs_expand writes
+// a group's stretch of slots.  Inside a group, run (tile kk, round j, thread t) = group * ... + kk * RX_TILE + j * 256 + t, so that the lanes of a wave hold consecutive
+// runs -- coalesced key loads, and the single-record runs of neighbouring lanes (the mirrored half of the records) write neighbouring slots; the lengths are scanned in
+// that order (wave scans + 32 partial sums).  A run of fewer than RX_LONG records is written by its own lane; a longer one (a query's own lines: ~ 50 records) by the
+// whole wave, a record per lane.
+// (Tried on the way, round 5: a thread per SLOT with a binary search over the runs' offsets in LDS -- 1.07 ms per 200 M records, eleven dependent LDS reads per slot;
+// one launch with the tiles chained by look-back -- 0.88 ms: the ticket is ONE word every block increments, 12 - 17 ns per atomic; groups of tiles chained -- 0.78 ms,
+// and 0.96 with a group's keys held in registers: every block of the launch publishes at the same moment and looks back over all the others at once.)
 #define RX_ITEMS 8
 #define RX_TILE (256 * RX_ITEMS)
 #define RX_LONG 16u
-#ifndef RX_KEEP
-#define RX_KEEP 1 // 1: a group's keys stay in registers from the count to the writes (4 tiles, every key read once); 0: 8 tiles, the keys are read a second time (from the caches)
-#endif
-#if RX_KEEP
-#define RX_GROUP 4u // consecutive tiles per block (and per ticket)
-#else
-#define RX_GROUP 8u
-#endif
-template <int STRIDE>
-__global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict__ rkey, uint32_t n_runs, int bi, int bl, uint32_t n_seq, uint32_t n_slots,
-                                                      uint32_t *__restrict__ sidx, uint32_t *__restrict__ goff, unsigned long long *__restrict__ ctr,
-                                                      unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
+#define RX_GROUP 8u // consecutive tiles per block
+__global__ __launch_bounds__(256) void k_runs_count(const uint64_t *__restrict__ rkey, uint32_t n_runs, int bl, uint32_t *__restrict__ cnt)
 {
-	__shared__ uint32_t s_part[RX_ITEMS][4];
-	__shared__ uint64_t s_last[RX_ITEMS][4];
 	__shared__ uint32_t s_wave[4];
-	__shared__ uint32_t s_tile, s_prefix;
-	// The chain's element is a GROUP of RX_GROUP consecutive tiles, one block and one ticket per group: the ticket is one word that every block of the launch increments,
-	// and atomics on one address are served one after the other -- 12 - 17 ns each on this chip, which is what a launch of 50 k light tiles cost per tile (round 5, visit 4:
-	// 0.88 ms, twice its traffic's worth).  The block reads the group's keys ONCE (coalesced, all in flight at once), adds up the lengths, publishes, looks back, and
-	// writes tile by tile from the registers.
-	if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
-	__syncthreads();
-	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint32_t grp = s_tile, g00 = grp * (RX_GROUP * RX_TILE);
-	const uint64_t lmask = (1ull << bl) - 1ull, pmask = bi >= 64 ? ~0ull : (1ull << bi) - 1ull;
-	uint32_t bad = 0, mine = 0;
-#if RX_KEEP
-	uint64_t kg[RX_GROUP][RX_ITEMS]; // the group's keys stay in registers from the count to the writes: every key is read once
-#pragma unroll
-	for (int kk = 0; kk < (int)RX_GROUP; ++kk)
-#pragma unroll
-		for (int j = 0; j < RX_ITEMS; ++j) { const uint32_t r = g00 + (uint32_t)kk * RX_TILE + (uint32_t)j * 256u + threadIdx.x; kg[kk][j] = r < n_runs ? rkey[r] : 0ull; }
-#pragma unroll
-	for (int kk = 0; kk < (int)RX_GROUP; ++kk)
-#pragma unroll
-		for (int j = 0; j < RX_ITEMS; ++j) { const uint32_t r = g00 + (uint32_t)kk * RX_TILE + (uint32_t)j * 256u + threadIdx.x; mine += r < n_runs ? (uint32_t)(kg[kk][j] & lmask) + 1u : 0u; }
-#else
+	const uint32_t g00 = blockIdx.x * (RX_GROUP * RX_TILE);
+	const uint64_t lmask = (1ull << bl) - 1ull;
+	uint32_t mine = 0;
 	for (uint32_t kk = 0; kk < RX_GROUP; kk += 2) { // 16 independent loads in flight
 		uint64_t kk2[2 * RX_ITEMS];
 #pragma unroll
@@ -213,33 +185,30 @@ __global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict_
 #pragma unroll
 		for (int j = 0; j < 2 * RX_ITEMS; ++j) mine += kk2[j] == ~0ull ? 0u : (uint32_t)(kk2[j] & lmask) + 1u; // (no key is all ones: the id field is < n_seq)
 	}
-#endif
 	uint32_t gtot;
 	(void)block_excl_scan_256(mine, s_wave, &gtot);
-	if (threadIdx.x == 0) {
-		SC_PUBLISH(&state[grp], sc_pack(epoch, grp == 0 ? SC_INCL : SC_AGG, gtot));
-		if (grp == 0) s_prefix = 0;
-	}
-	if (grp > 0 && threadIdx.x < 64) {
-		const uint32_t prefix = sc_look_back(state, grp, epoch, threadIdx.x);
-		if (threadIdx.x == 0) { s_prefix = prefix; SC_PUBLISH(&state[grp], sc_pack(epoch, SC_INCL, prefix + gtot)); }
-	}
-	__syncthreads();
-	uint32_t S0 = s_prefix; // first slot of the current tile
-#pragma unroll
-	for (int kk = 0; kk < (int)RX_GROUP; ++kk) {
-	const uint32_t r00 = g00 + (uint32_t)kk * RX_TILE;
+	if (threadIdx.x == 0) cnt[blockIdx.x] = gtot;
+}
+template <int STRIDE>
+__global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict__ rkey, uint32_t n_runs, int bi, int bl, uint32_t n_seq, uint32_t n_slots, const uint32_t *__restrict__ gpre,
+                                                      uint32_t *__restrict__ sidx, uint32_t *__restrict__ goff, unsigned long long *__restrict__ ctr)
+{
+	__shared__ uint32_t s_part[RX_ITEMS][4];
+	__shared__ uint64_t s_last[RX_ITEMS][4];
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t g00 = blockIdx.x * (RX_GROUP * RX_TILE);
+	const uint64_t lmask = (1ull << bl) - 1ull, pmask = bi >= 64 ? ~0ull : (1ull << bi) - 1ull;
+	uint32_t bad = 0;
+	uint32_t S0 = gpre[blockIdx.x]; // first slot of the current tile
+	for (uint32_t kk = 0; kk < RX_GROUP; ++kk) {
+	const uint32_t r00 = g00 + kk * RX_TILE;
 	if (r00 >= n_runs) break; // (uniform)
 	uint64_t k[RX_ITEMS];
 	uint32_t len[RX_ITEMS], incl[RX_ITEMS];
 #pragma unroll
 	for (int j = 0; j < RX_ITEMS; ++j) {
 		const uint32_t r = r00 + (uint32_t)j * 256u + threadIdx.x;
-#if RX_KEEP
-		k[j] = kg[kk][j];
-#else
 		k[j] = r < n_runs ? rkey[r] : 0ull;
-#endif
 		len[j] = r < n_runs ? (uint32_t)(k[j] & lmask) + 1u : 0u;
 	}
 	const uint64_t kfirst = r00 > 0 && threadIdx.x == 0 ? rkey[r00 - 1] : 0ull; // the run in front of the tile
@@ -1515,15 +1484,17 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 			int g2 = 0;
 			CHK(radix_sort_keys(c, n_runs, bi + bl, bi + bl + bq, &g2, false));
 			CHK(radix_group_starts_begin(c, P<uint32_t>(c->goff), c->n_seq, (uint32_t)n));
-			const size_t nb2 = (n_runs + RX_TILE - 1) / RX_TILE, ng2 = (nb2 + RX_GROUP - 1) / RX_GROUP;
-			CHK(scan_chain_begin(c, ng2, &state, &ticket, &ticket_base, &epoch));
+			const size_t ng2 = (n_runs + (size_t)RX_GROUP * RX_TILE - 1) / ((size_t)RX_GROUP * RX_TILE);
+			CHK(dev_reserve(c, c->keep, (ng2 + 16) * 4)); CHK(dev_reserve(c, c->pos, (ng2 + 16) * 4));
 			HIPCHK(hipMemsetAsync(ctr + CT_OVF2, 0, 8, c->st));
 			{
 				ProfScope ps(c, "k_runs_expand", 8.0 * (double)n_runs + 4.0 * (double)n);
+				hipLaunchKernelGGL(k_runs_count, dim3((unsigned)ng2), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[g2]), (uint32_t)n_runs, bl, P<uint32_t>(c->keep));
+				CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), ng2, nullptr));
 				if (c->run_stride == 2) hipLaunchKernelGGL(k_runs_expand<2>, dim3((unsigned)ng2), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[g2]), (uint32_t)n_runs, bi, bl, c->n_seq, (uint32_t)n,
-				                                           P<uint32_t>(c->sidx), P<uint32_t>(c->goff), ctr, state, ticket, ticket_base, epoch);
+				                                           (const uint32_t*)P<uint32_t>(c->pos), P<uint32_t>(c->sidx), P<uint32_t>(c->goff), ctr);
 				else hipLaunchKernelGGL(k_runs_expand<1>, dim3((unsigned)ng2), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[g2]), (uint32_t)n_runs, bi, bl, c->n_seq, (uint32_t)n,
-				                        P<uint32_t>(c->sidx), P<uint32_t>(c->goff), ctr, state, ticket, ticket_base, epoch);
+				                        (const uint32_t*)P<uint32_t>(c->pos), P<uint32_t>(c->sidx), P<uint32_t>(c->goff), ctr);
 			}
 			CHK(radix_group_starts_finish(c, P<uint32_t>(c->goff), c->n_seq));
 			CHK(ctr_fetch(c));
