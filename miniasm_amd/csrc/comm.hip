@@ -315,13 +315,15 @@ extern "C" int mahip_comm_all_to_all_v(mahip_ctx_t *c, const void *d_send, void 
 	size_t soff = 0, roff = 0;
 	if (m->kind == 1) {
 		NCCLCHK(g_rccl.GroupStart());
-		for (int r = 0; r < W; ++r) {
+		int bad = 0; // a call that fails inside the group must not leave it open: close it, then report
+		for (int r = 0; r < W && !bad; ++r) {
 			const size_t sb = bytes[(size_t)me * W + r], rb = bytes[(size_t)r * W + me];
-			if (sb) NCCLCHK(g_rccl.Send((const char*)d_send + soff, sb, ncclUint8, r, m->nccl, c->st));
-			if (rb) NCCLCHK(g_rccl.Recv((char*)d_recv + roff, rb, ncclUint8, r, m->nccl, c->st));
+			if (sb && g_rccl.Send((const char*)d_send + soff, sb, ncclUint8, r, m->nccl, c->st) != 0) bad = 1;
+			if (!bad && rb && g_rccl.Recv((char*)d_recv + roff, rb, ncclUint8, r, m->nccl, c->st) != 0) bad = 1;
 			soff += sb; roff += rb;
 		}
-		NCCLCHK(g_rccl.GroupEnd());
+		const int end_rc = (int)g_rccl.GroupEnd();
+		if (bad || end_rc != 0) { mahip_set_error("mahip_comm_all_to_all_v: ncclSend / ncclRecv / ncclGroupEnd failed (%d)", end_rc); return -1; }
 		return 0;
 	}
 	size_t mine = 0;

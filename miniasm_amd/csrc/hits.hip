@@ -1158,26 +1158,35 @@ extern "C" int mahip_hits_route(mahip_ctx_t *c, uint64_t *n_total_out, uint64_t 
 	DevBuf send_rec, send_pos, recv_rec, recv_pos;
 	uint64_t row[32], mat[32 * 32], by[32 * 32];
 	int rc = 0;
+	// A rank that fails on its own must not leave the others alone in the next collective: a local failure becomes a marker in the row every rank gathers
+	// (a count no rank can hold), every rank sees it and all leave together; the receive buffers' reservation is agreed on the same way before the exchange.
+	const uint64_t FAILED = ~0ull;
 	do {
-		if ((rc = dev_reserve(c, send_rec, (n + 1) * sizeof(ma_hit_t))) != 0 || (rc = dev_reserve(c, send_pos, (n + 1) * 4)) != 0) break;
+		int lrc = 0; // this rank's own verdict so far
+		if ((lrc = dev_reserve(c, send_rec, (n + 1) * sizeof(ma_hit_t))) == 0) lrc = dev_reserve(c, send_pos, (n + 1) * 4);
 		size_t off = 0;
-		for (int h = 0; h < W && rc == 0; ++h) {
+		for (int h = 0; h < W; ++h) {
 			size_t k = 0;
-			rc = mahip_hits_raw_extract_pos(c, b[h], b[h + 1], (char*)send_rec.p + off * sizeof(ma_hit_t), (uint32_t*)send_pos.p + off, &k);
+			if (lrc == 0) lrc = mahip_hits_raw_extract_pos(c, b[h], b[h + 1], (char*)send_rec.p + off * sizeof(ma_hit_t), (uint32_t*)send_pos.p + off, &k);
 			row[h] = k; off += k;
 		}
-		if (rc) break;
-		if (off != n) { mahip_set_error("mahip_hits_route: %zu of %zu records have a query id inside the dictionary", off, n); rc = -1; break; }
-		if (n && base) hipLaunchKernelGGL(k_add_u32, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (uint32_t*)send_pos.p, n, (uint32_t)base);
+		if (lrc == 0 && off != n) { mahip_set_error("mahip_hits_route: %zu of %zu records have a query id inside the dictionary", off, n); lrc = -1; }
+		if (lrc == 0 && n && base) hipLaunchKernelGGL(k_add_u32, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (uint32_t*)send_pos.p, n, (uint32_t)base);
+		if (lrc) for (int h = 0; h < W; ++h) row[h] = FAILED;
 		if ((rc = mahip_comm_all_gather_u64(c, row, (size_t)W, mat)) != 0) break; // mat[i * W + j]: records rank i holds for rank j
+		bool any_failed = false;
+		for (int k = 0; k < W * W; ++k) any_failed |= mat[k] == FAILED;
+		if (any_failed) { if (!lrc) mahip_set_error("mahip_hits_route: another rank failed"); rc = -1; break; }
 		size_t n_my = 0;
 		for (int r = 0; r < W; ++r) n_my += mat[(size_t)r * W + me];
-		if ((rc = dev_reserve(c, recv_rec, (n_my + 1) * sizeof(ma_hit_t))) != 0 || (rc = dev_reserve(c, recv_pos, (n_my + 1) * 4)) != 0) break;
+		lrc = dev_reserve(c, recv_rec, (n_my + 1) * sizeof(ma_hit_t));
+		if (lrc == 0) lrc = dev_reserve(c, recv_pos, (n_my + 1) * 4);
+		{ uint64_t ok = lrc ? 1 : 0; if ((rc = mahip_comm_all_reduce_sum_u64(c, &ok, 1)) != 0) break; if (ok) { if (!lrc) mahip_set_error("mahip_hits_route: another rank could not reserve its receive buffers"); rc = -1; break; } }
 		for (int k = 0; k < W * W; ++k) by[k] = mat[k] * sizeof(ma_hit_t);
 		if ((rc = mahip_comm_all_to_all_v(c, send_rec.p, recv_rec.p, by)) != 0) break;
 		for (int k = 0; k < W * W; ++k) by[k] = mat[k] * 4;
 		if ((rc = mahip_comm_all_to_all_v(c, send_pos.p, recv_pos.p, by)) != 0) break;
-		HIPCHK(hipStreamSynchronize(c->st));
+		if (hipStreamSynchronize(c->st) != hipSuccess) { mahip_set_error("mahip_hits_route: stream error behind the exchange"); rc = -1; break; } // (no HIPCHK inside the block: it would return past the clean-up)
 		if (bytes_sent) *bytes_sent = (uint64_t)(n - row[me]) * (sizeof(ma_hit_t) + 4);
 		// (3) the context as a rank of the sharded head wants it
 		const uint32_t max_qs = c->paf_max_qs;
@@ -1186,7 +1195,7 @@ extern "C" int mahip_hits_route(mahip_ctx_t *c, uint64_t *n_total_out, uint64_t 
 		if ((rc = mahip_hits_adopt(c, c->aos_own.p, n_my, R)) != 0) break;
 		c->hint_max_qs = max_qs;
 		if ((rc = mahip_hits_set_positions(c, (const uint32_t*)recv_pos.p, 1, total)) != 0) break;
-		HIPCHK(hipStreamSynchronize(c->st));
+		if (hipStreamSynchronize(c->st) != hipSuccess) { mahip_set_error("mahip_hits_route: stream error"); rc = -1; break; }
 		c->shard_bounds = b;
 		if (n_total_out) *n_total_out = total;
 	} while (0);
