@@ -50,6 +50,14 @@ def test_kernels_stage_parity_on_cpu(emu_built):
     run_gpu_tests(["tests/test_gpu_parity.py"] + sel, 3000)
 
 
+@pytest.mark.parametrize("stride", ["1", "0"])
+def test_sort_does_not_depend_on_the_run_stride_hint(stride, emu_built):
+    """the hit sort takes RUNS of records when told how a query's own records stand in the array (mahip_set_run_stride; the stage tests default to 2 = ma_hit_read's
+    layout).  A hint that does not fit the data -- stride 1 on mirrored records: too few runs; random hit arrays under any stride -- must cost time, never correctness:
+    the same stage tests with the other hints (0 = no hint: one key per record)"""
+    run_gpu_tests(["tests/test_gpu_parity.py", "-k", "lognormal or noisy or sort_random or random_hit or deep_groups"], 3000, {"MA_TEST_RUN_STRIDE": stride})
+
+
 def test_kernels_with_reversed_schedule_and_guard_pages(emu_built):
     """the same kernels with lanes, waves and blocks executed in DESCENDING order (code that leans on lock-step execution or on launch order
     without a barrier breaks) and every device allocation ending at a faulting page (an out-of-bounds access crashes)"""
