@@ -104,7 +104,7 @@ def cli_digest_leg(ma, name, workdir):
         same_text = os.path.getsize(paf) == gold["paf_bytes"] and head_tail_md5(paf) == gold["paf_head_tail_md5"]
         h, n = hashlib.md5(), 0
         t0 = time.perf_counter()
-        with subprocess.Popen([ma.CLI_PATH, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE) as pr:
+        with subprocess.Popen([ma.CLI_PATH, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MA_PIPE_TIMING="2")) as pr:
             import threading
             err = []
             th = threading.Thread(target=lambda: err.append(pr.stderr.read()))
@@ -118,11 +118,21 @@ def cli_digest_leg(ma, name, workdir):
         if pr.returncode != 0:
             log("leg %s: the command line failed:" % name, (err[0] if err else b"")[-300:])
             return None
-        m = re.search(rb"\[T::ties\] (\d+) arc tie groups.*-> arc walk (\d), hit walk (\d)", err[0] if err else b"")
+        log_txt = (err[0] if err else b"").decode(errors="replace")
+        laps = {}  # where the run spent its time, from its own [T::...] lines (MA_PIPE_TIMING=2)
+        for key, pat in (("hip_runtime_s", r"\[T::init\].*HIP runtime ([0-9.]+) s"), ("file_to_hbm_s", r"\[T::ingest_gpu\] load ([0-9.]+) s"), ("parse_s", r"\[T::ingest_gpu\] parse ([0-9.]+)"),
+                         ("sg_gen_incl_tie_repair_ms", r"\[T::head\] sg_gen\s+([0-9.]+) ms"), ("tie_walk_host_ms", r"walk: host\s+([0-9.]+) ms"), ("push_order_ms", r"push order \(all of it\)\s+([0-9.]+) ms"),
+                         ("pipeline_head_ms", r"\[T::pipeline\] head ([0-9.]+) ms"), ("pipeline_tail_ms", r"\[T::pipeline\] head [0-9.]+ ms\s+tail ([0-9.]+) ms"), ("real_time_s", r"Real time: ([0-9.]+) sec")):
+            mm = re.search(pat, log_txt)
+            if mm:
+                laps[key] = float(mm.group(1))
+        mt = re.search(r"\[T::ties\] (\d+) arc tie groups \((\d+) arcs\), (\d+) push conflicts", log_txt)
+        if mt:
+            laps["arc_tie_groups"], laps["push_conflicts"] = int(mt.group(1)), int(mt.group(3))
         return {"value": cfg["lines"] / wall, "unit": "overlaps/s", "wall_s": round(wall, 3), "overlaps": cfg["lines"], "reads": cfg["reads"], "pafgen": cfg, "paf_bytes": gold["paf_bytes"],
                 "text_is_the_recorded_one": same_text, "gfa_md5": h.hexdigest(), "gfa_bytes": n, "ref_md5": gold["gfa_md5"], "ref_bytes": gold["gfa_bytes"],
                 "gfa_md5_matches_reference": same_text and (h.hexdigest(), n) == (gold["gfa_md5"], gold["gfa_bytes"]),
-                "reference_wall_s": gold["reference_wall_s"], "reference_host": gold["host"], "vs_reference_wall": round(gold["reference_wall_s"] / wall, 1), "gen_s": round(t_gen, 1),
+                "laps": laps, "reference_wall_s": gold["reference_wall_s"], "reference_host": gold["host"], "vs_reference_wall": round(gold["reference_wall_s"] / wall, 1), "gen_s": round(t_gen, 1),
                 "what": "miniasm_amd/bin/miniasm <file>: process start to the last byte of GFA (text from the page cache), raw md5 of the GFA against tests/golden/big.json -- the unmodified reference's output on "
                         "the same seeded text, recorded once by tests/golden/make_big.py (the reference needs minutes and tens of GB here: it does not run inside bench.py)"}
     finally:
@@ -180,16 +190,25 @@ def pmc_traffic(names, kernel):
     per_launch = lambda v: v["fetch_bytes_x2"] + v["write_bytes"]
     scope = {"k_hit_sub<cut+flt>": ("k_hit_sub<true,", None), "k_hit_sub": ("k_hit_sub<false,", False), "k_hit_sub<gather>": ("k_hit_sub<false,", True)}.get(kernel)
     if scope:  # a timed scope of the coverage passes = one launch of each size-class kernel: their bytes add up
-        parts = [v for k, v in names.items() if k.startswith(scope[0]) and (scope[1] is None or k.endswith(", true>") == scope[1])]
+        gathers = lambda k: k.endswith((", true>", ", 1>", ", 2>"))  # the third template argument: gather mode (a bool until round 4, 0 / 1 / 2 since)
+        parts = [v for k, v in names.items() if k.startswith(scope[0]) and (scope[1] is None or gathers(k) == scope[1])]
         return round(sum(per_launch(v) for v in parts)) if parts else None
     base = kernel.split("<")[0]
-    two = {"k_group_close": ("k_group_tile_min", "k_group_close"), "k_radix_colscan": ("k_radix_colscan_chunk", "k_radix_colscan_top")}.get(base)
-    if two:  # a scope of two small launches
-        parts = [names.get(k) for k in two]
-        if not all(parts) and base == "k_radix_colscan":
+    # a timed scope of several launches whose bytes add up
+    multi = {"k_group_close": ("k_group_tile_min", "k_group_close"), "k_radix_colscan": ("k_radix_colscan_chunk", "k_radix_colscan_top"),
+             "k_runs_expand": ("k_runs_count", "k_runs_expand"), "k_arc_rm": ("k_arc_rm_count", "k_arc_rm_write")}.get(base)
+    if multi:
+        parts = [next((v for k, v in names.items() if k.split("<")[0] == want), None) for want in multi]
+        if all(parts):
+            return round(sum(per_launch(v) for v in parts))
+        if base == "k_radix_colscan":
             return 0  # (a counter profile from before these kernels existed: 50 MB per pass, nothing against the group's 46 GB)
-        return round(sum(per_launch(v) for v in parts)) if all(parts) else None
-    hits = [v for k, v in names.items() if k.split("<")[0] in (base, {"k_hit_keys": "k_hit_keys_tiled", "k_arc_rm": "k_arc_rm_chain"}.get(base, base))]
+        if base != "k_arc_rm":
+            return None
+    alias = {"k_hit_keys": ("k_hit_keys_tiled", "k_hit_keys_runs"), "k_arc_rm": ("k_arc_rm_chain",), "k_asg_trans": ("k_asg_trans", "k_asg_trans_pipe")}.get(base, (base,))
+    hits = [v for k, v in names.items() if k.split("<")[0] in (base,) + alias]
+    if base == "k_radix_scatter" and any(k.startswith("k_radix_scatter<false") for k in names):  # the hits' keys travel without a value array; the <true, ...> launches are the (small) pair sorts of the same step
+        hits = [v for k, v in names.items() if k.startswith("k_radix_scatter<false")]
     if not hits:
         return None
     if base in ("k_arc_group_sort", "k_asg_trans"):  # a timed scope = one launch of each size-class instantiation: their bytes add up
