@@ -133,7 +133,7 @@ def cli_digest_leg(ma, name, workdir):
                 "text_is_the_recorded_one": same_text, "gfa_md5": h.hexdigest(), "gfa_bytes": n, "ref_md5": gold["gfa_md5"], "ref_bytes": gold["gfa_bytes"],
                 "gfa_md5_matches_reference": same_text and (h.hexdigest(), n) == (gold["gfa_md5"], gold["gfa_bytes"]),
                 "laps": laps, "reference_wall_s": gold["reference_wall_s"], "reference_host": gold["host"], "vs_reference_wall": round(gold["reference_wall_s"] / wall, 1), "gen_s": round(t_gen, 1),
-                "what": "miniasm_amd/bin/miniasm <file>: process start to the last byte of GFA (text from the page cache), raw md5 of the GFA against tests/golden/big.json -- the unmodified reference's output on "
+                "what": "miniasm_amd/bin/miniasm <file>: process start to the last byte of GFA (text from the page cache; the run comes BEHIND the configs[3] command-line runs of the e2e leg, and allocations that land on memory another process freed wait for the driver to clear it: `laps` shows where the time went), raw md5 of the GFA against tests/golden/big.json -- the unmodified reference's output on "
                         "the same seeded text, recorded once by tests/golden/make_big.py (the reference needs minutes and tens of GB here: it does not run inside bench.py)"}
     finally:
         try:

@@ -168,10 +168,12 @@ __global__ __launch_bounds__(256) void k_hit_keys_runs(const ma_hit_t *__restric
 // (Tried on the way, round 5: a thread per SLOT with a binary search over the runs' offsets in LDS -- 1.07 ms per 200 M records, eleven dependent LDS reads per slot;
 // one launch with the tiles chained by look-back -- 0.88 ms: the ticket is ONE word every block increments, 12 - 17 ns per atomic; groups of tiles chained -- 0.78 ms,
 // and 0.96 with a group's keys held in registers: every block of the launch publishes at the same moment and looks back over all the others at once.)
-#define RX_ITEMS 8
+#ifndef RX_ITEMS
+#define RX_ITEMS 4 // runs per thread and tile (8: 148 registers, three blocks per CU; 4: see tools/isa_stats.sh)
+#endif
 #define RX_TILE (256 * RX_ITEMS)
 #define RX_LONG 16u
-#define RX_GROUP 8u // consecutive tiles per block
+#define RX_GROUP (16384u / RX_TILE) // consecutive tiles per block: 16 k runs
 __global__ __launch_bounds__(256) void k_runs_count(const uint64_t *__restrict__ rkey, uint32_t n_runs, int bl, uint32_t *__restrict__ cnt)
 {
 	__shared__ uint32_t s_wave[4];
@@ -214,8 +216,7 @@ __global__ __launch_bounds__(256) void k_runs_expand(const uint64_t *__restrict_
 	const uint64_t kfirst = r00 > 0 && threadIdx.x == 0 ? rkey[r00 - 1] : 0ull; // the run in front of the tile
 #pragma unroll
 	for (int j = 0; j < RX_ITEMS; ++j) {
-		uint32_t x = len[j];
-		for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= (unsigned)o) x += y; }
+		const uint32_t x = (uint32_t)wv_scan_incl_i32((int)len[j], lane); // (DPP row shifts + row broadcasts: the wave is full; six ds_bpermute round trips per scan before)
 		incl[j] = x;
 		if (lane == 63) { s_part[j][wave] = x; s_last[j][wave] = k[j]; }
 	}
