@@ -20,11 +20,7 @@
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t *s_wave, uint32_t *total)
 {
 	unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	uint32_t incl = x;
-	for (int o = 1; o < 64; o <<= 1) {
-		uint32_t y = __shfl_up(incl, o, 64);
-		if (lane >= (unsigned)o) incl += y;
-	}
+	const uint32_t incl = (uint32_t)wv_scan_incl_i32((int)x, lane); // full waves: DPP row shifts + row broadcasts
 	if (lane == 63) s_wave[wave] = incl;
 	__syncthreads();
 	uint32_t base = 0, tot = 0;
