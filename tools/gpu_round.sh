@@ -231,6 +231,19 @@ initlaps)
     MA_PIPE_TIMING=2 timeout 600 miniasm_amd/bin/miniasm $f 2>&1 >/dev/null | grep -E "T::init|T::paf|T::xfer|T::ingest|T::head|T::pipeline|T::tail|ma_hit_read|Real time" | head -30
     LD_DEBUG=statistics miniasm_amd/bin/miniasm -V 2>&1 | grep -E "total startup|relocation|load" | head -4
   done ;;
+sqgh)
+  # SQ counters (instruction mix, wait cycles) of the graph phase's kernels on the graph-heavy input (200 M arcs) and of the sort group at configs[3]: three passes each (8 counter slots)
+  GH="--reads 2000000 --lines 100000000 --seed 4 --model fixed"
+  for wl in gh cfg4; do
+    case $wl in cfg4) A=""; F="k_hit_keys_runs|k_runs_expand|k_runs_count|k_radix_scatter|k_hit_sub";; gh) A="$GH"; F="k_asg_trans|k_arc_group_sort|k_arc_rm|k_sg_emit|k_sg_arcs";; esac
+    i=0
+    for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE"; do
+      i=$((i+1)); rm -rf gpurun_out/sq_${wl}_$i; mkdir -p gpurun_out/sq_${wl}_$i
+      (cd /tmp && timeout 900 rocprofv3 --pmc $set --kernel-trace -d /root/repo/gpurun_out/sq_${wl}_$i -o r --output-format csv -- python /root/repo/bench.py $A --steps 1 --warmup 1 --no-cpu --no-text --no-legs --prof-steps 0 > /root/repo/gpurun_out/sq_${wl}_$i/bench.json 2> /root/repo/gpurun_out/sq_${wl}_$i/bench.log); echo "sq $wl set $i rc=$?"
+    done
+    python tools/pmc_generic.py gpurun_out/sq_${wl}_1 gpurun_out/sq_${wl}_2 gpurun_out/sq_${wl}_3 --filter "$F" > gpurun_out/sq_summary_$wl.txt 2>&1; head -70 gpurun_out/sq_summary_$wl.txt
+    find gpurun_out/sq_${wl}_1 gpurun_out/sq_${wl}_2 gpurun_out/sq_${wl}_3 -name "*.csv" -size +8M -delete
+  done ;;
 evidence)
   # the round's evidence at the current commit (what tools/gpu_r4z.sh did in round 4): rocprofv3 kernel stats and PMC traffic of the bench command at BASELINE configs[3] and on
   # the graph-heavy input -> gpurun_out/ev/{rocprofv3_kernel_stats,pmc_traffic}_{cfg4,gh}.*; copy them to profiles/rNN_* afterwards

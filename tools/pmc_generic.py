@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Mean value per launch of every counter found in rocprofv3 --pmc counter_collection CSVs, per kernel.
-usage: pmc_generic.py <dir> [<dir> ...] [--filter substr] [--each]  -> table on stdout (--each: every launch in dispatch order)"""
-import csv, glob, os, sys, collections
+usage: pmc_generic.py <dir> [<dir> ...] [--filter regex] [--each]  -> table on stdout (--each: every launch in dispatch order)"""
+import csv, glob, os, re, sys, collections
 dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
 flt = None
 if "--filter" in sys.argv:
@@ -15,7 +15,7 @@ for d in dirs:
         with open(fn) as f:
             for row in csv.DictReader(f):
                 name = row.get("Kernel_Name", "?").split("(")[0]
-                if flt and flt not in name:
+                if flt and not re.search(flt, name):
                     continue
                 if each:
                     rows.append((int(row.get("Dispatch_Id", 0) or 0), name, row.get("Counter_Name"), float(row.get("Counter_Value", 0))))
