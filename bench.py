@@ -190,7 +190,9 @@ def pmc_traffic(names, kernel):
     per_launch = lambda v: v["fetch_bytes_x2"] + v["write_bytes"]
     scope = {"k_hit_sub<cut+flt>": ("k_hit_sub<true,", None), "k_hit_sub": ("k_hit_sub<false,", False), "k_hit_sub<gather>": ("k_hit_sub<false,", True)}.get(kernel)
     if scope:  # a timed scope of the coverage passes = one launch of each size-class kernel: their bytes add up
-        gathers = lambda k: k.endswith((", true>", ", 1>", ", 2>"))  # the third template argument: gather mode (a bool until round 4, 0 / 1 / 2 since)
+        def gathers(k):  # the THIRD template argument is the gather mode (absent in round 1's names, a bool until round 4, 0 / 1 / 2 since)
+            targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
+            return len(targs) >= 3 and targs[2] in ("true", "1", "2")
         parts = [v for k, v in names.items() if k.startswith(scope[0]) and (scope[1] is None or gathers(k) == scope[1])]
         return round(sum(per_launch(v) for v in parts)) if parts else None
     base = kernel.split("<")[0]
