@@ -205,9 +205,6 @@ __global__ __launch_bounds__(256) void k_arc_compact(ArcCols in, size_t n, const
 // arc (round 4, visit A: 1.25 against 3.6 ms at 200 M arcs) and serves the callers that bring a pre-filter of their own (keep_in).
 #define RM_ITEMS 8
 #define RM_TILE (256 * RM_ITEMS)
-// CLEAN (no read has been deleted since the arcs were last checked against seq.del: behind the reduction and behind asg_symm): only the del bits decide, so only the overlap
-// words are streamed -- u, v and len are fetched for the survivors alone.  Behind the reduction of a graph-heavy input 4 % of the arcs survive: 4 B per arc read
-// instead of 12 (round 5; round 4: 1.25 ms per 200 M arcs = 2.6 TB/s of the three columns).
 // The CLEAN form is THREE launches instead of a chain: a chain's ticket is ONE word that every block increments, and atomics on one address are served one after the
 // other -- 12.7 ns each here, which at 98 k tiles WAS the launch (1.24 ms whether three columns were streamed or one: round 5, visit 4); chaining groups of tiles instead
 // (one ticket per 32 k arcs) made every block of the launch publish at the same moment and look back over all the others at once (0.83 - 1.0 ms, visits 5 - 7).  So:
@@ -264,7 +261,7 @@ __global__ __launch_bounds__(256) void k_arc_rm_write(ArcCols in, size_t n, ArcC
 	}
 }
 
-template <bool CLEAN>
+// (the form for arcs that have to be checked against seq.del: an imported graph, a cleanup behind a cleaner that deleted reads; the clean case is k_arc_rm_count / _write above)
 __global__ __launch_bounds__(256) void k_arc_rm_chain(ArcCols in, size_t n, const uint8_t *__restrict__ sdel, ArcCols out, uint32_t *__restrict__ d_total,
                                                        unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
 {
@@ -276,22 +273,18 @@ __global__ __launch_bounds__(256) void k_arc_rm_chain(ArcCols in, size_t n, cons
 	const size_t base = (size_t)tile * RM_TILE + (size_t)threadIdx.x * RM_ITEMS;
 	uint32_t u[RM_ITEMS], v[RM_ITEMS], ol[RM_ITEMS], keep = 0;
 	if (base + RM_ITEMS <= n) {
-		const uint4 *po = (const uint4*)(in.ol + base);
-		const uint4 c0 = po[0], c1 = po[1];
+		const uint4 *pu = (const uint4*)(in.u + base), *pv = (const uint4*)(in.v + base), *po = (const uint4*)(in.ol + base);
+		const uint4 a0 = pu[0], a1 = pu[1], b0 = pv[0], b1 = pv[1], c0 = po[0], c1 = po[1];
+		u[0] = a0.x, u[1] = a0.y, u[2] = a0.z, u[3] = a0.w, u[4] = a1.x, u[5] = a1.y, u[6] = a1.z, u[7] = a1.w;
+		v[0] = b0.x, v[1] = b0.y, v[2] = b0.z, v[3] = b0.w, v[4] = b1.x, v[5] = b1.y, v[6] = b1.z, v[7] = b1.w;
 		ol[0] = c0.x, ol[1] = c0.y, ol[2] = c0.z, ol[3] = c0.w, ol[4] = c1.x, ol[5] = c1.y, ol[6] = c1.z, ol[7] = c1.w;
-		if (!CLEAN) {
-			const uint4 *pu = (const uint4*)(in.u + base), *pv = (const uint4*)(in.v + base);
-			const uint4 a0 = pu[0], a1 = pu[1], b0 = pv[0], b1 = pv[1];
-			u[0] = a0.x, u[1] = a0.y, u[2] = a0.z, u[3] = a0.w, u[4] = a1.x, u[5] = a1.y, u[6] = a1.z, u[7] = a1.w;
-			v[0] = b0.x, v[1] = b0.y, v[2] = b0.z, v[3] = b0.w, v[4] = b1.x, v[5] = b1.y, v[6] = b1.z, v[7] = b1.w;
-		}
 	} else {
 #pragma unroll
-		for (int i = 0; i < RM_ITEMS; ++i) { const bool in_r = base + i < n; ol[i] = in_r ? in.ol[base + i] : ADEL; if (!CLEAN) { u[i] = in_r ? in.u[base + i] : 0; v[i] = in_r ? in.v[base + i] : 0; } }
+		for (int i = 0; i < RM_ITEMS; ++i) { const bool in_r = base + i < n; u[i] = in_r ? in.u[base + i] : 0; v[i] = in_r ? in.v[base + i] : 0; ol[i] = in_r ? in.ol[base + i] : ADEL; }
 	}
 #pragma unroll
 	for (int i = 0; i < RM_ITEMS; ++i)
-		if (base + i < n && !(ol[i] & ADEL) && (CLEAN || (!sdel[u[i] >> 1] && !sdel[v[i] >> 1]))) keep |= 1u << i;
+		if (base + i < n && !(ol[i] & ADEL) && !sdel[u[i] >> 1] && !sdel[v[i] >> 1]) keep |= 1u << i;
 	const uint32_t cnt = (uint32_t)__popc(keep);
 	uint32_t tot;
 	const uint32_t ex = block_excl_scan_256(cnt, s_wave, &tot);
@@ -307,7 +300,7 @@ __global__ __launch_bounds__(256) void k_arc_rm_chain(ArcCols in, size_t n, cons
 	uint32_t p = s_prefix + ex;
 #pragma unroll
 	for (int i = 0; i < RM_ITEMS; ++i)
-		if (keep >> i & 1u) { out.u[p] = CLEAN ? in.u[base + i] : u[i]; out.v[p] = CLEAN ? in.v[base + i] : v[i]; out.len[p] = in.len[base + i]; out.ol[p] = ol[i]; ++p; }
+		if (keep >> i & 1u) { out.u[p] = u[i]; out.v[p] = v[i]; out.len[p] = in.len[base + i]; out.ol[p] = ol[i]; ++p; }
 	if (base < n && base + RM_ITEMS >= n) *d_total = p; // the last thread with arcs: its end is the total
 }
 
@@ -1027,7 +1020,7 @@ static int arc_cleanup(mahip_ctx *c, size_t n_in, int keep_in, int index_mode)
 			const size_t nb = (n_in + RM_TILE - 1) / RM_TILE;
 			uint32_t *ticket; unsigned long long *state; uint32_t ticket_base, epoch;
 			CHK(scan_chain_begin(c, nb, &state, &ticket, &ticket_base, &epoch));
-			hipLaunchKernelGGL(k_arc_rm_chain<false>, dim3((unsigned)nb), dim3(256), 0, c->st, in, n_in, (const uint8_t*)P<uint8_t>(c->sdel), out, d_tot, state, ticket, ticket_base, epoch);
+			hipLaunchKernelGGL(k_arc_rm_chain, dim3((unsigned)nb), dim3(256), 0, c->st, in, n_in, (const uint8_t*)P<uint8_t>(c->sdel), out, d_tot, state, ticket, ticket_base, epoch);
 		}
 	} else {
 		ProfScope ps(c, "k_arc_rm", 32.0 * (double)n_in); // asg_arc_rm 32 B per arc
