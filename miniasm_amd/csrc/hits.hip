@@ -876,8 +876,14 @@ __global__ __launch_bounds__(256) void k_hit_contained(HitCols c, size_t n, cons
 
 // resident pipeline: the second ma_hit_cut (against cut_sub) and the flag pass of ma_hit_contained (against the merged
 // intervals cls_sub) in one sweep over the hits
-__global__ __launch_bounds__(256) void k_hit_cut_contained(HitCols c, size_t n, const uint2 *__restrict__ cut_sub, int min_span,
-                                                            const uint2 *__restrict__ cls_sub, int max_hang, float int_frac, int min_ovlp,
+// (cut_sub[r], cls_sub[r]) side by side: the kernel below looks both up for the query AND the target of every hit; as one 16-byte entry a look-up is one request instead of two
+__global__ __launch_bounds__(256) void k_sub_pair(const uint2 *__restrict__ cut_sub, const uint2 *__restrict__ cls_sub, uint32_t n_seq, uint4 *__restrict__ pair)
+{
+	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	if (r < n_seq) { const uint2 a = cut_sub[r], b = cls_sub[r]; pair[r] = make_uint4(a.x, a.y, b.x, b.y); }
+}
+__global__ __launch_bounds__(256) void k_hit_cut_contained(HitCols c, size_t n, const uint4 *__restrict__ sub2 /* {cut_sub, cls_sub} per read */, int min_span,
+                                                            int max_hang, float int_frac, int min_ovlp,
                                                             uint8_t *__restrict__ r_cont, uint8_t *__restrict__ r_used, unsigned long long *__restrict__ ctr)
 {
 	uint32_t n_keep = 0;
@@ -885,11 +891,12 @@ __global__ __launch_bounds__(256) void k_hit_cut_contained(HitCols c, size_t n, 
 		uint32_t bl = c.bl[i];
 		if (bl & DEAD) continue;
 		uint32_t q = c.qid[i], t = c.tn[i], ml = c.ml[i];
-		uint2 rq = cut_sub[q], rt = cut_sub[t];
+		const uint4 pq = sub2[q], pt = sub2[t];
+		const uint2 rq = make_uint2(pq.x, pq.y), rt = make_uint2(pt.x, pt.y);
 		uint32_t qs = c.qs[i], qe = c.qe[i], ts = c.ts[i], te = c.te[i];
 		const uint32_t oqs = qs, oqe = qe, ots = ts, ote = te;
 		if (!(rq.x & DEAD) && !(rt.x & DEAD) && mc_cut(&qs, &qe, &ts, &te, ml >> 31, (int32_t)rq.x, rq.y, (int32_t)rt.x, rt.y, min_span)) {
-			uint2 sq = cls_sub[q], st = cls_sub[t];
+			const uint2 sq = make_uint2(pq.z, pq.w), st = make_uint2(pt.z, pt.w);
 			mc_arc_t a;
 			if (qs != oqs) c.qs[i] = qs; // most hits lie inside both intervals: untouched columns are not written back
 			if (qe != oqe) c.qe[i] = qe;
@@ -1746,9 +1753,11 @@ extern "C" int mahip_hits_cut_contained_flags(mahip_ctx_t *c, int cut_slot, int 
 	HIPCHK(hipMemsetAsync(c->r_used.p, 0, R, c->st));
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	if (n) {
+		CHK(dev_reserve(c, c->big1, ((size_t)R + 4) * 16)); // (the coverage passes' scratch: free here)
 		ProfScope ps(c, "k_hit_cut_contained", (80.0 + 48.0) * (double)c->n_live);
-		hipLaunchKernelGGL(k_hit_cut_contained, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, cols_of(c), n, (const uint2*)P<uint2>(c->sub[cut_slot]), min_span,
-		                   (const uint2*)P<uint2>(c->sub[0]), opt->max_hang, opt->int_frac, opt->min_ovlp, P<uint8_t>(c->r_cont), P<uint8_t>(c->r_used), ctr);
+		hipLaunchKernelGGL(k_sub_pair, dim3(grid_for(R, 256)), dim3(256), 0, c->st, (const uint2*)P<uint2>(c->sub[cut_slot]), (const uint2*)P<uint2>(c->sub[0]), R, (uint4*)c->big1.p);
+		hipLaunchKernelGGL(k_hit_cut_contained, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, cols_of(c), n, (const uint4*)c->big1.p, min_span,
+		                   opt->max_hang, opt->int_frac, opt->min_ovlp, P<uint8_t>(c->r_cont), P<uint8_t>(c->r_used), ctr);
 	}
 	HIPCHK(hipGetLastError());
 	return 0;
