@@ -887,27 +887,41 @@ __global__ __launch_bounds__(256) void k_hit_cut_contained(HitCols c, size_t n, 
                                                             uint8_t *__restrict__ r_cont, uint8_t *__restrict__ r_used, unsigned long long *__restrict__ ctr)
 {
 	uint32_t n_keep = 0;
-	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-		uint32_t bl = c.bl[i];
-		if (bl & DEAD) continue;
-		uint32_t q = c.qid[i], t = c.tn[i], ml = c.ml[i];
-		const uint4 pq = sub2[q], pt = sub2[t];
-		const uint2 rq = make_uint2(pq.x, pq.y), rt = make_uint2(pt.x, pt.y);
-		uint32_t qs = c.qs[i], qe = c.qe[i], ts = c.ts[i], te = c.te[i];
-		const uint32_t oqs = qs, oqe = qe, ots = ts, ote = te;
-		if (!(rq.x & DEAD) && !(rt.x & DEAD) && mc_cut(&qs, &qe, &ts, &te, ml >> 31, (int32_t)rq.x, rq.y, (int32_t)rt.x, rt.y, min_span)) {
-			const uint2 sq = make_uint2(pq.z, pq.w), st = make_uint2(pt.z, pt.w);
-			mc_arc_t a;
-			if (qs != oqs) c.qs[i] = qs; // most hits lie inside both intervals: untouched columns are not written back
-			if (qe != oqe) c.qe[i] = qe;
-			if (ts != ots) c.ts[i] = ts;
-			if (te != ote) c.te[i] = te;
-			++n_keep;
-			int r = mc_hit2arc(q, qs, qe, t, ts, te, ml >> 31, (int)(sq.y - (sq.x & 0x7fffffffu)), (int)(st.y - (st.x & 0x7fffffffu)), max_hang, int_frac, min_ovlp, &a);
-			if (r == MC_HT_QCONT) r_cont[q] = 1;
-			else if (r == MC_HT_TCONT) r_cont[t] = 1;
-			r_used[q] = 1; r_used[t] = 1;
-		} else c.bl[i] = bl | DEAD;
+	// CC_UNROLL hits per thread and trip: a hit is two dependent trips to memory (its columns, then the two reads' entries); one hit per thread and trip left the launch
+	// latency-bound at a third of the chip's occupancy-bandwidth product.  All columns of the trip's hits are asked for first, then all entries.
+	constexpr int CC_UNROLL = 4;
+	for (size_t base = (size_t)blockIdx.x * (256 * CC_UNROLL); base < n; base += (size_t)gridDim.x * (256 * CC_UNROLL)) {
+		uint32_t bl[CC_UNROLL], q[CC_UNROLL], t[CC_UNROLL], ml[CC_UNROLL], qs[CC_UNROLL], qe[CC_UNROLL], ts[CC_UNROLL], te[CC_UNROLL];
+		uint4 pq[CC_UNROLL], pt[CC_UNROLL];
+#pragma unroll
+		for (int u = 0; u < CC_UNROLL; ++u) {
+			const size_t i = base + (size_t)u * 256 + threadIdx.x;
+			bl[u] = i < n ? c.bl[i] : DEAD;
+			const size_t ic = i < n ? i : 0; // (clamped: the loads below are unconditional)
+			q[u] = c.qid[ic]; t[u] = c.tn[ic]; ml[u] = c.ml[ic]; qs[u] = c.qs[ic]; qe[u] = c.qe[ic]; ts[u] = c.ts[ic]; te[u] = c.te[ic];
+		}
+#pragma unroll
+		for (int u = 0; u < CC_UNROLL; ++u) { pq[u] = sub2[q[u]]; pt[u] = sub2[t[u]]; }
+#pragma unroll
+		for (int u = 0; u < CC_UNROLL; ++u) {
+			const size_t i = base + (size_t)u * 256 + threadIdx.x;
+			if (bl[u] & DEAD) continue;
+			const uint2 rq = make_uint2(pq[u].x, pq[u].y), rt = make_uint2(pt[u].x, pt[u].y);
+			uint32_t qs_ = qs[u], qe_ = qe[u], ts_ = ts[u], te_ = te[u];
+			if (!(rq.x & DEAD) && !(rt.x & DEAD) && mc_cut(&qs_, &qe_, &ts_, &te_, ml[u] >> 31, (int32_t)rq.x, rq.y, (int32_t)rt.x, rt.y, min_span)) {
+				const uint2 sq = make_uint2(pq[u].z, pq[u].w), st = make_uint2(pt[u].z, pt[u].w);
+				mc_arc_t a;
+				if (qs_ != qs[u]) c.qs[i] = qs_; // most hits lie inside both intervals: untouched columns are not written back
+				if (qe_ != qe[u]) c.qe[i] = qe_;
+				if (ts_ != ts[u]) c.ts[i] = ts_;
+				if (te_ != te[u]) c.te[i] = te_;
+				++n_keep;
+				int r = mc_hit2arc(q[u], qs_, qe_, t[u], ts_, te_, ml[u] >> 31, (int)(sq.y - (sq.x & 0x7fffffffu)), (int)(st.y - (st.x & 0x7fffffffu)), max_hang, int_frac, min_ovlp, &a);
+				if (r == MC_HT_QCONT) r_cont[q[u]] = 1;
+				else if (r == MC_HT_TCONT) r_cont[t[u]] = 1;
+				r_used[q[u]] = 1; r_used[t[u]] = 1;
+			} else c.bl[i] = bl[u] | DEAD;
+		}
 	}
 	blk_add_u64(&ctr[CT_LIVE], n_keep);
 }
