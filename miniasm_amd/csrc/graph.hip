@@ -86,22 +86,11 @@ __global__ __launch_bounds__(256) void k_sg_arcs(HitColsG h, size_t n, const uin
 { // pass A.  lazy_del != nullptr: the squeeze of ma_hit_contained was postponed; hits with a dropped endpoint are skipped here.
   // cmask: one bit per hit slot = "yields an arc" (before the endpoint test), so that passes B and C need not look at dead slots
 	uint32_t mx = 0, n_live = 0;
-	// four 256-slot rounds per trip: after containment most reads are gone, and what a slot of such a read costs is two DEPENDENT loads (its query id, that read's flag) --
-	// one slot per thread and trip left the launch waiting on them (0.5 ms for 1.2 GB at BASELINE configs[3]); the ids of four rounds are fetched together, then the four flags
-	constexpr int SG_UNROLL = 4;
-	for (size_t base = (size_t)blockIdx.x * (256 * SG_UNROLL); base < n; base += (size_t)gridDim.x * (256 * SG_UNROLL)) {
-		uint32_t qv[SG_UNROLL];
-		uint8_t gone[SG_UNROLL];
-#pragma unroll
-		for (int u = 0; u < SG_UNROLL; ++u) { const size_t i = base + (size_t)u * 256 + threadIdx.x; qv[u] = i < n ? h.qid[i] : 0u; }
-#pragma unroll
-		for (int u = 0; u < SG_UNROLL; ++u) { const size_t i = base + (size_t)u * 256 + threadIdx.x; gone[u] = i < n ? (lazy_del ? lazy_del[qv[u]] : (uint8_t)0) : (uint8_t)1; }
-#pragma unroll
-		for (int u = 0; u < SG_UNROLL; ++u) {
-		const size_t i = base + (size_t)u * 256 + threadIdx.x;
-		if (base + (size_t)u * 256 >= n) break; // (uniform: the whole round lies behind the end)
+	// (round 5, visit 15: four 256-slot rounds per trip -- the ids of four rounds fetched together, then the four flags -- ran at 1.02 ms against 0.50: left as it was)
+	for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+		const size_t i = base + threadIdx.x;
 		int cand = 0;
-		if (i < n && !gone[u]) {
+		if (i < n) {
 			mc_arc_t x;
 			uint32_t q = 0, t = 0;
 			int self_rc = 0, r = sg_candidate(h, i, slen, max_hang, int_frac, min_ovlp, lazy_del, &x, &q, &t, &self_rc);
@@ -115,7 +104,6 @@ __global__ __launch_bounds__(256) void k_sg_arcs(HitColsG h, size_t n, const uin
 		}
 		const unsigned long long m = wv_ballot(cand);
 		if ((threadIdx.x & 63) == 0) cmask[i >> 6] = m;
-		}
 	}
 	blk_max_u64(&ctr[CT_MAXLEN], mx);
 	blk_add_u64(&ctr[CT_LIVE], n_live);
