@@ -55,6 +55,8 @@ def worker(a):
     for step in range(a.steps):
         ma._chk(L.mahip_hits_adopt(ctx.h, W.hits_dev.data_ptr(), W.n_my, W.n_seq), "adopt")
         L.mahip_set_hints(ctx.h, W.max_qs)
+        if W.bounds is not None:  # a table of read ranges describes one upload (include/mahip.h): hand it over with every batch
+            ma._chk(L.mahip_set_shard_bounds(ctx.h, W.bounds, len(W.bounds) - 1), "set_shard_bounds")
         st = ma.ShardStats()
         assert L.ma_pipeline_head_sharded(ctx.h, C.byref(opt), W.n_seq, 0, C.byref(st)) == 0
         rows.append({"phase_ms": [float(x) for x in st.phase_ms], "xchg_bytes": [int(x) for x in st.xchg_bytes]})

@@ -33,6 +33,8 @@ for world, rank in ((1, 0), (2, 0), (2, 1), (8, 3)):
     for rep in range(3):
         ma._chk(L.mahip_hits_adopt(ctx.h, W.hits_dev.data_ptr(), W.n_my, W.n_seq), "adopt")
         L.mahip_set_hints(ctx.h, W.max_qs)
+        if W.bounds is not None:  # a table of read ranges describes one upload (include/mahip.h): hand it over with every batch
+            ma._chk(L.mahip_set_shard_bounds(ctx.h, W.bounds, len(W.bounds) - 1), "set_shard_bounds")
         L.mahip_set_full_input(ctx.h, 1 if world == 1 else 0)
         L.mahip_set_shard(ctx.h, q0 if world > 1 else 0, q1 if world > 1 else 0xffffffff)
         L.mahip_mark(ctx.h, 0)
