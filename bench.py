@@ -104,7 +104,7 @@ def cli_digest_leg(ma, name, workdir):
         same_text = os.path.getsize(paf) == gold["paf_bytes"] and head_tail_md5(paf) == gold["paf_head_tail_md5"]
         h, n = hashlib.md5(), 0
         t0 = time.perf_counter()
-        with subprocess.Popen([ma.CLI_PATH, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MA_PIPE_TIMING="2")) as pr:
+        with subprocess.Popen(["timeout", "900", ma.CLI_PATH, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MA_PIPE_TIMING="2")) as pr:  # (a run that does not come back must not take the bench line with it)
             import threading
             err = []
             th = threading.Thread(target=lambda: err.append(pr.stderr.read()))
@@ -412,7 +412,7 @@ def main():
             for _ in range(3):
                 with open(outp, "wb") as fo:
                     t0 = time.perf_counter()
-                    r = subprocess.run([ma.CLI_PATH, paf], stdout=fo, stderr=subprocess.PIPE)
+                    r = subprocess.run([ma.CLI_PATH, paf], stdout=fo, stderr=subprocess.PIPE, timeout=600)
                     walls.append(time.perf_counter() - t0)
                 assert r.returncode == 0, r.stderr[-300:]
             early_e2e = {"walls": walls, "md5": md5_pair(open(outp, "rb").read())[0]}
