@@ -338,7 +338,16 @@ __global__ __launch_bounds__(256) void k_hit_goff(const uint64_t *__restrict__ s
 // Tier B: one 256-thread block per read, events in LDS (<= 8192) or in global scratch (any size).
 // grid of the coverage kernels (blocks of 4 waves, one read per wave at a time); env MA_SUB_BLOCKS for experiments
 static unsigned sub_blocks() { static unsigned v = 0; if (!v) { const char *e = getenv("MA_SUB_BLOCKS"); v = e ? (unsigned)atoi(e) : 2 * MA_STREAM_BLOCKS; /* 2 x the resident capacity: the dispatcher evens out the tail (measured 2048: 0.51, 4096: 0.46, 8192: 0.45 ms; more blocks = more end-of-block atomics) */ if (v < 1) v = 1; } return v; }
+#ifndef MA_SUB_ORDER_DEFAULT
+#define MA_SUB_ORDER_DEFAULT "012"
+#endif
 #define MA_SUB_BLOCKS sub_blocks()
+// The three size classes of a coverage pass run side by side on three streams.  Which is QUEUED first matters: the first tier's blocks live for the whole launch (a wave walks
+// ~ 120 reads) and fill every slot they are given, so classes queued behind it start when its blocks retire -- a tail (rocprofv3: all three kernels span the same 5 ms although
+// the larger classes own a quarter of the hits).  MA_SUB_ORDER: "012" = first tier first (until round 5), "210" = the larger classes first.  MA_SUB_BIG_GRID: blocks of the two
+// larger classes (0: as many as the first tier's).
+static const int *sub_order() { static int o[3] = {-1, 0, 0}; if (o[0] < 0) { const char *e = getenv("MA_SUB_ORDER"); const char *d = (e && strlen(e) == 3) ? e : MA_SUB_ORDER_DEFAULT; int seen = 0; for (int k = 0; k < 3; ++k) { o[k] = d[k] - '0'; if (o[k] < 0 || o[k] > 2) o[k] = k; seen |= 1 << o[k]; } if (seen != 7) { o[0] = 0; o[1] = 1; o[2] = 2; } } return o; }
+static unsigned sub_big_grid(unsigned g0) { static long v = -1; if (v < 0) { const char *e = getenv("MA_SUB_BIG_GRID"); v = e ? atol(e) : 0; } return v > 0 && (unsigned)v < g0 ? (unsigned)v : g0; }
 // reads per bounds fetch in the larger tiers: up to SUB_CHUNK, fewer when there are not enough reads to give every wave of the grid a chunk
 static uint32_t sub_chunk(uint32_t R) { uint64_t waves = 4ull * grid_for(R, 4, MA_SUB_BLOCKS), k = waves ? R / waves : 1; return (uint32_t)(k < 1 ? 1 : k > 16 ? 16 : k); }
 #define EV_PAD 0xffffffffu
@@ -1676,15 +1685,19 @@ extern "C" int mahip_hits_sub(mahip_ctx_t *c, int min_dp, float min_iden, int en
 		SubFork fk(c);
 		const dim3 grd(grid_for(Rr, 4, MA_SUB_BLOCKS)), blk(256);
 		const uint32_t *gf = (const uint32_t*)P<uint32_t>(c->goff);
-		if (c->gk_runs) { // positions from sidx (k_runs_expand), which is not written again
-			hipLaunchKernelGGL((k_hit_sub<false, 0, 2>), grd, blk, 0, fk.st(0), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-			hipLaunchKernelGGL((k_hit_sub<false, 1, 2>), grd, blk, 0, fk.st(1), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-			hipLaunchKernelGGL((k_hit_sub<false, 2, 2>), grd, blk, 0, fk.st(2), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-		} else {
-			hipLaunchKernelGGL((k_hit_sub<false, 0, 1>), grd, blk, 0, fk.st(0), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-			hipLaunchKernelGGL((k_hit_sub<false, 1, 1>), grd, blk, 0, fk.st(1), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-			hipLaunchKernelGGL((k_hit_sub<false, 2, 1>), grd, blk, 0, fk.st(2), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
-		}
+		auto launch = [&](int cls) {
+			const dim3 gr = cls == 0 ? grd : dim3(sub_big_grid(grd.x));
+			if (c->gk_runs) { // positions from sidx (k_runs_expand), which is not written again
+				if (cls == 0) hipLaunchKernelGGL((k_hit_sub<false, 0, 2>), gr, blk, 0, fk.st(0), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+				else if (cls == 1) hipLaunchKernelGGL((k_hit_sub<false, 1, 2>), gr, blk, 0, fk.st(1), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+				else hipLaunchKernelGGL((k_hit_sub<false, 2, 2>), gr, blk, 0, fk.st(2), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+			} else {
+				if (cls == 0) hipLaunchKernelGGL((k_hit_sub<false, 0, 1>), gr, blk, 0, fk.st(0), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+				else if (cls == 1) hipLaunchKernelGGL((k_hit_sub<false, 1, 1>), gr, blk, 0, fk.st(1), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+				else hipLaunchKernelGGL((k_hit_sub<false, 2, 1>), gr, blk, 0, fk.st(2), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, nofuse, g);
+			}
+		};
+		for (int k = 0; k < 3; ++k) launch(sub_order()[k]);
 		fk.join();
 		c->gather_pending = false;
 	} else if (R) {
@@ -1727,12 +1740,16 @@ extern "C" int mahip_hits_cutflt_sub(mahip_ctx_t *c, int cut_slot, int min_span,
 	if (R) {
 		ProfScope ps(c, "k_hit_sub<cut+flt>", (80.0 + 80.0 + 48.0) * (double)c->n_hits + 8.0 * R); // cut 80 + flt 80 + sub 48 B per hit
 		SubFork fk(c);
-		hipLaunchKernelGGL((k_hit_sub<true, 0>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(0), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, 0, 0, nullptr, nullptr, 0, sub_chunk(Rr), q_lo});
-		hipLaunchKernelGGL((k_hit_sub<true, 1>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(1), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, 0, 0, nullptr, nullptr, 0, sub_chunk(Rr), q_lo});
-		hipLaunchKernelGGL((k_hit_sub<true, 2>), dim3(grid_for(Rr, 4, MA_SUB_BLOCKS)), dim3(256), 0, fk.st(2), h, (const uint32_t*)P<uint32_t>(c->goff), q_hi, min_dp, min_iden, end_clip,
-		                   sub, P<uint32_t>(c->ovf), ctr, f, SubGather{nullptr, 0, 0, nullptr, nullptr, 0, sub_chunk(Rr), q_lo});
+		const dim3 grd(grid_for(Rr, 4, MA_SUB_BLOCKS)), blk(256);
+		const uint32_t *gf = (const uint32_t*)P<uint32_t>(c->goff);
+		const SubGather nog2 = SubGather{nullptr, 0, 0, nullptr, nullptr, 0, sub_chunk(Rr), q_lo};
+		auto launch = [&](int cls) {
+			const dim3 gr = cls == 0 ? grd : dim3(sub_big_grid(grd.x));
+			if (cls == 0) hipLaunchKernelGGL((k_hit_sub<true, 0>), gr, blk, 0, fk.st(0), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, f, nog2);
+			else if (cls == 1) hipLaunchKernelGGL((k_hit_sub<true, 1>), gr, blk, 0, fk.st(1), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, f, nog2);
+			else hipLaunchKernelGGL((k_hit_sub<true, 2>), gr, blk, 0, fk.st(2), h, gf, q_hi, min_dp, min_iden, end_clip, sub, P<uint32_t>(c->ovf), ctr, f, nog2);
+		};
+		for (int k = 0; k < 3; ++k) launch(sub_order()[k]);
 		fk.join();
 	}
 	if (R) {
