@@ -35,6 +35,7 @@
 
 struct PafBufs {
 	DevBuf text, lstart, tile;
+	DevBuf glast, gmax, tfirst; // tile parser: last newline per granule / per group of granules, first line start per tile
 	DevBuf flags, num[8], tnoff, qlen, tlen, hq, ht, qslot, tslot;
 	DevBuf tab, tmin, info, slot_id, blv, scal, excl;
 	DevBuf name_off, name_len, name_pos, seq_len, names;
@@ -61,7 +62,7 @@ void paf_free(mahip_ctx *c)
 {
 	PafBufs *b = (PafBufs*)c->paf;
 	if (!b) return;
-	DevBuf *all[] = { &b->text, &b->lstart, &b->tile, &b->flags, &b->tnoff, &b->qlen, &b->tlen, &b->hq, &b->ht, &b->qslot, &b->tslot, &b->tab, &b->tmin, &b->info,
+	DevBuf *all[] = { &b->text, &b->lstart, &b->tile, &b->glast, &b->gmax, &b->tfirst, &b->flags, &b->tnoff, &b->qlen, &b->tlen, &b->hq, &b->ht, &b->qslot, &b->tslot, &b->tab, &b->tmin, &b->info,
 		&b->slot_id, &b->blv, &b->scal, &b->excl, &b->name_off, &b->name_len, &b->name_pos, &b->seq_len, &b->names };
 	for (DevBuf *d : all) dev_free(c, *d);
 	for (int k = 0; k < 8; ++k) dev_free(c, b->num[k]);
@@ -155,14 +156,30 @@ __device__ __forceinline__ uint32_t paf_num(PTR &p, uint32_t beg, uint32_t end)
 	return ovf ? (neg ? 0u : 0xffffffffu) : (uint32_t)(neg ? (uint64_t)0 - acc : acc); // LONG_MIN -> 0, LONG_MAX -> 0xffffffff
 }
 
-// FNV-1a of a name column up to its first NUL (the reference handles names as C strings); *len = bytes hashed
+// ---- name keys.  A name of 1..8 bytes IS its key (the bytes, zero-padded: names are C strings, so no byte of them is 0 and the padded word is unique);
+// any other name (empty, or longer) gets a 64-bit hash of its length and its 8-byte words.  A file whose names are all short therefore has an EXACT
+// dictionary without a single text comparison (k_dict_insert_short); as soon as one name is long the table is keyed by the mixed key and every probe
+// compares the text (k_dict_insert).  key_mix spreads either kind over the table.
+#define KEY_SEED 0x9e3779b97f4a7c15ull
+#define KEY_LENMUL 0xff51afd7ed558ccdull
+#define KEY_MUL 0xd6e8feb86659fd93ull
+__host__ __device__ __forceinline__ uint64_t key_mix(uint64_t z) { z ^= z >> 33; z *= 0xff51afd7ed558ccdull; z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ull; z ^= z >> 33; return z; }
+__host__ __device__ __forceinline__ uint64_t key_step(uint64_t h, uint64_t w) { h = (h ^ w) * KEY_MUL; return h ^ (h >> 29); }
+__host__ __device__ __forceinline__ bool key_is_short(uint32_t len) { return len - 1u < 8u; }
+
+// key of a name column up to its first NUL (the reference handles names as C strings); *len = its bytes.  Byte-wise form (any PTR): the slow paths
 template <typename PTR>
 __device__ __forceinline__ uint64_t paf_name(PTR &p, uint32_t beg, uint32_t end, uint32_t *len)
 {
-	uint64_t h = FNV_OFF;
 	uint32_t pos = beg;
-	for (; pos < end; ++pos) { const unsigned ch = p[pos]; if (ch == 0) break; h = (h ^ ch) * FNV_PRIME; }
-	*len = pos - beg;
+	for (; pos < end; ++pos) if (p[pos] == 0) break;
+	const uint32_t l = pos - beg;
+	*len = l;
+	uint64_t h = KEY_SEED ^ ((uint64_t)l * KEY_LENMUL), w = 0;
+	for (uint32_t k = 0; k < l; ++k) {
+		w |= (uint64_t)p[beg + k] << (8 * (k & 7));
+		if ((k & 7) == 7 || k + 1 == l) { if (l <= 8) return w; h = key_step(h, w); w = 0; }
+	}
 	return h;
 }
 
@@ -260,6 +277,310 @@ __global__ __launch_bounds__(256) void k_paf_bl_fill(const uint32_t *__restrict_
 	if (i < L && !f_hasbl[i]) bl[i] = pos[i] ? blv[pos[i] - 1] : 0u;
 }
 
+// ------------------------------------------------------------------------------------------------ tile parser (round 6)
+// The lane-per-line parser above walks every byte of its line twice in divergent loops: 2 100 scalar + 1 340 vector instructions per 64 lines, bound by the
+// CU's ONE scalar unit (profiles/r04_sq_counters_cfg4.txt: 12.6 ms per 100 M lines).  This one has no per-byte loop at all:
+//   * the text is cut into tiles of K KiB (K from the mean line length: about 240 lines a tile); a tile owns the lines that END in it and keeps the up to
+//     960 bytes in front of it in LDS as well, where its first line may start;
+//   * while the 16-byte pieces travel from HBM to LDS their TABs and newlines are found by SWAR compares and leave as one BIT per byte (two 2-KiB arrays);
+//   * newline ranks (a block scan of popcounts) give every line of the tile a lane; the lane finds its 11 column ends with count-trailing-zeros on a
+//     64-bit window of the TAB bits and converts each number from the 8 bytes at its start: XOR '0', shift the digits to the top, check "all <= 9" and fold
+//     them with three multiply-adds per half -- straight-line code, every lane in step;
+//   * anything the straight line does not cover -- a sign, blanks, junk behind the digits, more than 8 digits, an empty column, a NUL in a name, a name of more
+//     than 64 bytes, a line that starts more than 960 bytes in front of its tile -- marks the line ODD, and k_paf_parse_odd runs the byte-wise routine above
+//     on exactly those lines (the reference's strtol semantics live there, and only there).
+// Line i is the line that ends with the i-th newline; a text without a final newline gets a virtual one at position n.
+#define PAF_GRAN 1024u        // granule of the newline census: one wave, 64 x 16 bytes
+#define PAF_OVER 960u         // bytes in front of a tile that are staged with it
+#define PAF_BGRP 12           // log2 of the granules per group of the "last newline" look-up
+#define PF_ODD 0x80u          // flags: the line waits for k_paf_parse_odd
+#define PF_QCONT 0x10u        // flags: stored line whose (short) query name equals that of the stored line in front of it
+#define PC_LONG CT_NSHORT     // stored lines with a name that is not 1..8 bytes
+#define PC_ODD CT_NASYMM
+
+__device__ __forceinline__ uint32_t eq_mask(uint32_t v, uint32_t c4) { v ^= c4; const uint32_t t = (v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu; return ~(t | v | 0x7F7F7F7Fu); } // 0x80 in every byte of v that equals c
+__device__ __forceinline__ uint32_t nib4(uint32_t m) { return ((m >> 7) * 0x204081u) >> 21 & 0xFu; } // the four flags of a word as bits 0..3 (the products land on distinct bits: no carries)
+__device__ __forceinline__ uint32_t mask16(const uint4 v, uint32_t c4) { return nib4(eq_mask(v.x, c4)) | nib4(eq_mask(v.y, c4)) << 4 | nib4(eq_mask(v.z, c4)) << 8 | nib4(eq_mask(v.w, c4)) << 12; }
+
+// granule g = bytes [1024 g, 1024 g + 1024), one wave: cnt[g] = its newlines, last[g] = offset of the byte behind its last newline (0: it has none)
+__global__ __launch_bounds__(256) void k_paf_gran_count(const unsigned char *__restrict__ text, size_t n, int open, uint32_t n_gran, uint32_t *__restrict__ cnt, uint32_t *__restrict__ last)
+{
+	const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (g >= n_gran) return; // the whole wave
+	const size_t off = (size_t)g * PAF_GRAN + lane * 16u;
+	uint32_t m = 0;
+	if (off < n) m = mask16(load16(text, off, n), 0x0A0A0A0Au);
+	if (open && n >= off && n < off + 16) m |= 1u << (uint32_t)(n - off);
+	const uint32_t c = wv_sum_u32((uint32_t)__popc(m));
+	const unsigned long long has = __ballot(m != 0);
+	if (lane == 0) { cnt[g] = c; if (!has) last[g] = 0; }
+	if (has && (int)lane == 63 - __clzll((long long)has)) last[g] = lane * 16u + (32u - (uint32_t)__clz((int)m));
+}
+// bmax[b] = byte behind the last newline of granules [4096 b, 4096 b + 4096) (0: none), one wave per group
+__global__ __launch_bounds__(64) void k_paf_gran_bmax(const uint32_t *__restrict__ last, uint32_t n_gran, unsigned long long *__restrict__ bmax)
+{
+	const uint32_t b = blockIdx.x, lane = threadIdx.x;
+	const long g_lo = (long)b << PAF_BGRP;
+	long g_hi = g_lo + (1l << PAF_BGRP); if (g_hi > (long)n_gran) g_hi = (long)n_gran;
+	unsigned long long r = 0;
+	for (long top = g_hi; top > g_lo && r == 0; top -= 64) { // 64 granules per step, from the back
+		const long g = top - 1 - (long)lane;
+		const uint32_t l = g >= g_lo ? last[g] : 0u;
+		const unsigned long long has = __ballot(l != 0);
+		if (has) { const int src = __ffsll((long long)has) - 1; const uint32_t lv = wv_bcast(l, src); r = (unsigned long long)(top - 1 - src) * PAF_GRAN + lv; }
+	}
+	if (lane == 0) bmax[b] = r;
+}
+// first[t] = start of the first line that ends in tile t = byte behind the last newline in front of the tile (0: the text starts it)
+__global__ __launch_bounds__(256) void k_paf_tile_first(const uint32_t *__restrict__ last, const unsigned long long *__restrict__ bmax, uint32_t K, uint32_t n_tiles, unsigned long long *__restrict__ first)
+{
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	if (t >= n_tiles) return;
+	long g = (long)t * (long)K - 1;
+	const long g_lo = g >= 0 ? (g >> PAF_BGRP) << PAF_BGRP : 0;
+	unsigned long long r = 0;
+	for (; g >= g_lo; --g) { const uint32_t l = last[g]; if (l) { r = (unsigned long long)g * PAF_GRAN + l; break; } }
+	if (r == 0) for (long b = (g_lo >> PAF_BGRP) - 1; b >= 0; --b) if (bmax[b]) { r = bmax[b]; break; }
+	first[t] = r;
+}
+
+struct TileArgs {
+	const unsigned char *text; size_t n; int open;
+	uint32_t K, n_gran, n_tiles, L;
+	const uint32_t *goff;            // [n_gran + 1] newlines in front of every granule
+	const unsigned long long *first; // [n_tiles]
+	int min_span, min_match;
+};
+
+// the 8 bytes at LDS offset pos (any alignment) as lo | hi << 32
+__device__ __forceinline__ uint64_t lds_get8(const uint32_t *__restrict__ w, uint32_t pos)
+{
+	const uint32_t i = pos >> 2, sh = (pos & 3u) * 8u;
+	const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2];
+	const uint32_t lo = (uint32_t)(((uint64_t)w1 << 32 | w0) >> sh), hi = (uint32_t)(((uint64_t)w2 << 32 | w1) >> sh);
+	return (uint64_t)hi << 32 | lo;
+}
+// distance from pos to the first TAB at or behind it: exact below 33 (two words of bits) / below 64 (three), at least that otherwise
+__device__ __forceinline__ uint32_t tab_dist2(const uint32_t *__restrict__ tb, uint32_t pos)
+{
+	const uint32_t i = pos >> 5, sh = pos & 31u;
+	const uint64_t x = ((uint64_t)tb[i + 1] << 32 | tb[i]) >> sh;
+	return x ? (uint32_t)__builtin_ctzll(x) : 64u - sh; // (none among the 64 - sh >= 33 bits the two words hold)
+}
+__device__ __forceinline__ uint32_t tab_dist3(const uint32_t *__restrict__ tb, uint32_t pos)
+{
+	const uint32_t i = pos >> 5, sh = pos & 31u;
+	uint64_t x = ((uint64_t)tb[i + 1] << 32 | tb[i]) >> sh;
+	if (sh) x |= (uint64_t)tb[i + 2] << (64u - sh);
+	return x ? (uint32_t)__builtin_ctzll(x) : 64u;
+}
+// a column of 1..8 digits at v (its first byte lowest) -> its value; *bad collects 0x80 flags of bytes that are not digits
+__device__ __forceinline__ uint32_t num8(uint64_t v, uint32_t len, uint32_t *bad)
+{
+	v ^= 0x3030303030303030ull;            // '0'..'9' -> 0..9
+	v <<= 8u * (8u - len);                 // the column's last digit into the top byte; what stood behind the column falls out, leading zeros come in
+	uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+	*bad |= (lo + 0x76767676u) | lo | (hi + 0x76767676u) | hi; // a byte > 9 sets its top bit (a carry can only leave a byte that has set it already)
+	lo = (lo & 0x00ff00ffu) * 10u + ((lo >> 8) & 0x00ff00ffu); // d0 d1 | d2 d3
+	lo = (lo & 0xffffu) * 100u + (lo >> 16);
+	hi = (hi & 0x00ff00ffu) * 10u + ((hi >> 8) & 0x00ff00ffu);
+	hi = (hi & 0xffffu) * 100u + (hi >> 16);
+	return lo * 10000u + hi;
+}
+// key of the name [pos, pos + len) in LDS (paf_name's function, on words); *nul: a NUL among its bytes
+__device__ __forceinline__ uint64_t lds_name_key(const uint32_t *__restrict__ w, uint32_t pos, uint32_t len, uint32_t *nul)
+{
+	if (len <= 8) {
+		const uint64_t m = len == 8 ? ~0ull : (1ull << (8u * len)) - 1ull;
+		const uint64_t v = lds_get8(w, pos), f = v | ~m;
+		*nul |= ((f - 0x0101010101010101ull) & ~f & 0x8080808080808080ull) != 0;
+		return len ? (v & m) : KEY_SEED;
+	}
+	uint64_t h = KEY_SEED ^ ((uint64_t)len * KEY_LENMUL);
+	for (uint32_t k = 0; k < len; k += 8) {
+		const uint32_t rem = len - k;
+		const uint64_t m = rem >= 8 ? ~0ull : (1ull << (8u * rem)) - 1ull;
+		const uint64_t v = lds_get8(w, pos + k), f = v | ~m;
+		*nul |= ((f - 0x0101010101010101ull) & ~f & 0x8080808080808080ull) != 0;
+		h = key_step(h, v & m);
+	}
+	return h;
+}
+
+template <int CH> // a block stages up to CH * 16 KiB of text: CH * 64 bytes per thread in the newline ranking
+__global__ __launch_bounds__(256) void k_paf_parse_tile(const TileArgs a, PafCols o, uint64_t *__restrict__ lstart, unsigned long long *__restrict__ ctr)
+{
+	constexpr uint32_t REG = (uint32_t)CH * 16384u;
+	extern __shared__ __attribute__((aligned(16))) unsigned char s_text[]; // the text: REG + 32; behind it:
+	uint16_t *s_tb = (uint16_t*)(s_text + REG + 32);        // REG / 16 + 8: TAB bits, one u16 per 16-byte piece
+	uint16_t *s_nb = s_tb + REG / 16 + 8;                   // the same for newlines
+	uint32_t *s_lend = (uint32_t*)(s_nb + REG / 16 + 8);    // [0] end of the line in front of the batch, [1 + j] newline of the batch's j-th line
+	__shared__ uint32_t s_w[4];
+	const uint32_t *tw = (const uint32_t*)s_text, *tb = (const uint32_t*)s_tb;
+	const unsigned lane = threadIdx.x & 63;
+	uint32_t c_valid = 0, c_pass = 0, c_nobl = 0, c_long = 0, c_odd = 0;
+	uint64_t c_mq = 0;
+	for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+		const uint32_t g0 = t * a.K, g1 = g0 + a.K < a.n_gran ? g0 + a.K : a.n_gran;
+		const uint32_t line0 = a.goff[g0], tot = a.goff[g1] - line0; // the lines that end in this tile
+		if (tot == 0) continue; // the whole block
+		const uint64_t tb0 = (uint64_t)g0 * PAF_GRAN, te0 = (uint64_t)g1 * PAF_GRAN;
+		const uint64_t first = a.first[t];
+		uint64_t lo = tb0 > PAF_OVER ? tb0 - PAF_OVER : 0;
+		const bool long_first = first < lo; // the first line starts further in front than the block keeps: its bytes are not all here
+		if (!long_first) lo = first;
+		lo &= ~(uint64_t)63;
+		const uint32_t len = (uint32_t)(te0 - lo); // <= REG, a multiple of 64
+		for (uint32_t p = threadIdx.x; p * 16u < len; p += 256u) {
+			const uint64_t off = lo + (uint64_t)p * 16u;
+			const uint4 v = off < a.n ? load16(a.text, off, a.n) : make_uint4(0, 0, 0, 0);
+			uint32_t mt = mask16(v, 0x09090909u), mn = mask16(v, 0x0A0A0A0Au);
+			if (a.open && a.n >= off && a.n < off + 16) mn |= 1u << (uint32_t)(a.n - off);
+			if (off < first) { // bytes of lines that ended in front of this tile
+				const uint32_t keep = off + 16 <= first ? 0u : 0xffffu << (uint32_t)(first - off);
+				mt &= keep; mn &= keep;
+			}
+			*(uint4*)(s_text + p * 16u) = v;
+			s_tb[p] = (uint16_t)mt; s_nb[p] = (uint16_t)mn;
+		}
+		for (uint32_t p = len / 16u + threadIdx.x; p < REG / 16u; p += 256u) s_nb[p] = 0; // (the ranking below reads the whole array)
+		__syncthreads();
+		// ---- ranks of the newlines: thread x looks after bytes [64 CH x, 64 CH (x + 1))
+		unsigned long long nlm[CH];
+		uint32_t cnt = 0;
+#pragma unroll
+		for (int r = 0; r < CH; ++r) { nlm[r] = *(const unsigned long long*)(s_nb + 4u * (threadIdx.x * CH + r)); cnt += (uint32_t)__popcll(nlm[r]); }
+		uint32_t tot_here;
+		const uint32_t rank0 = block_excl_scan_256(cnt, s_w, &tot_here);
+		if (threadIdx.x == 0) s_lend[0] = long_first ? 0u : (uint32_t)(first - lo) - 1u; // (a long first line never uses it)
+		for (uint32_t base = 0; base < tot; base += 256u) {
+			{
+				uint32_t r = rank0;
+#pragma unroll
+				for (int q = 0; q < CH; ++q)
+					for (unsigned long long m = nlm[q]; m; m &= m - 1, ++r)
+						if (r - base < 256u) s_lend[1u + r - base] = (threadIdx.x * CH + q) * 64u + (uint32_t)__builtin_ctzll(m);
+			}
+			__syncthreads();
+			const uint32_t r = base + threadIdx.x;
+			const bool act = r < tot;
+			const uint32_t i = line0 + r;
+			uint32_t fl = 0, mine = 0;
+			uint64_t hq = 0, ht = 0;
+			if (act) {
+				const uint32_t pe = s_lend[1u + threadIdx.x], ps = s_lend[threadIdx.x] + 1u;
+				const bool lf = long_first && r == 0;
+				lstart[i] = lf ? first : lo + ps;
+				if (i + 1 == a.L) lstart[i + 1] = lo + pe + 1;
+				bool odd = lf;
+				if (!lf) {
+					uint32_t e1 = pe;
+					if (e1 - ps > 1 && s_text[e1 - 1] == '\r') --e1;
+					// ---- column ends
+					uint32_t fb[11], fe[11], ncol = 0, pos = ps;
+					bool more = true, amb = false;
+#pragma unroll
+					for (int k = 0; k < 11; ++k) {
+						const bool name = k == 0 || k == 5;
+						const uint32_t d = name ? tab_dist3(tb, pos) : tab_dist2(tb, pos);
+						uint32_t end = pos + d;
+						const bool lastc = end >= e1; // no TAB before the line ends: the last column
+						amb |= more && !lastc && d >= (name ? 64u : 33u); // the window ended before the column did
+						end = lastc ? e1 : end;
+						fb[k] = pos; fe[k] = end;
+						ncol += more;
+						more = more && !lastc;
+						pos = more ? end + 1u : e1;
+					}
+					const uint32_t valid = ncol >= 10, hasbl = ncol >= 11;
+					odd = amb;
+					uint32_t ql = 0, qs = 0, qe = 0, tl = 0, ts = 0, te = 0, ml = 0, bl = 0, rev = 0, tnoff = 0, qlen = 0, tlen = 0, pass = 0;
+					if (valid && !amb) {
+						uint32_t bad = 0, lbad = 0, nul = 0;
+#define PAF_NUM(k) ({ const uint32_t l_ = fe[k] - fb[k]; lbad |= (l_ - 1u) > 7u; num8(lds_get8(tw, fb[k]), (l_ - 1u) > 7u ? 8u : l_, &bad); })
+						ql = PAF_NUM(1); qs = PAF_NUM(2); qe = PAF_NUM(3);
+						tl = PAF_NUM(6); ts = PAF_NUM(7); te = PAF_NUM(8);
+						ml = PAF_NUM(9) & 0x7fffffffu;
+						if (hasbl) bl = PAF_NUM(10);
+#undef PAF_NUM
+						rev = fe[4] > fb[4] && s_text[fb[4]] == '-';
+						tnoff = fb[5] - ps;
+						qlen = fe[0] - fb[0]; tlen = fe[5] - fb[5];
+						if (qlen > 64 || tlen > 64) lbad = 1;
+						else { hq = lds_name_key(tw, fb[0], qlen, &nul); ht = lds_name_key(tw, fb[5], tlen, &nul); }
+						odd = (bad & 0x80808080u) != 0 || lbad || nul;
+						pass = !(qe - qs < (uint32_t)a.min_span || te - ts < (uint32_t)a.min_span || (int)ml < a.min_match); // hit.c:85
+					}
+					if (!odd) {
+						fl = valid | pass << 1 | hasbl << 2 | rev << 3;
+						c_valid += valid; c_pass += pass; c_nobl += valid && !hasbl;
+						if (pass) {
+							const uint32_t lng = !key_is_short(qlen) || !key_is_short(tlen);
+							c_long += lng;
+							mine = key_is_short(qlen);
+							const uint64_t mq = qs > ts ? qs : ts;
+							c_mq = mq > c_mq ? mq : c_mq;
+						}
+						o.ql[i] = ql; o.qs[i] = qs; o.qe[i] = qe; o.tl[i] = tl; o.ts[i] = ts; o.te[i] = te; o.ml[i] = ml; o.bl[i] = bl;
+						o.tnoff[i] = tnoff; o.qlen[i] = qlen; o.tlen[i] = tlen; o.hq[i] = hq; o.ht[i] = ht;
+					}
+				}
+				if (odd) { fl = PF_ODD; ++c_odd; }
+			}
+			// does the line continue the run of one query name?  (the lane below holds the line in front; lane 0 of a wave starts a run)
+			const uint32_t p_mine = wv_prev_lane_u32(mine, 0u, lane), p_lo = wv_prev_lane_u32((uint32_t)hq, 0u, lane), p_hi = wv_prev_lane_u32((uint32_t)(hq >> 32), 0u, lane);
+			if (mine && p_mine && p_lo == (uint32_t)hq && p_hi == (uint32_t)(hq >> 32)) fl |= PF_QCONT;
+			if (act) o.flags[i] = (uint8_t)fl;
+			__syncthreads();
+			if (base + 256u < tot) { if (threadIdx.x == 0) s_lend[0] = s_lend[256]; __syncthreads(); }
+		}
+	}
+	blk_add_u64(&ctr[PC_VALID], c_valid);
+	blk_add_u64(&ctr[PC_PASS], c_pass);
+	blk_add_u64(&ctr[PC_NOBL], c_nobl);
+	blk_add_u64(&ctr[PC_LONG], c_long);
+	blk_add_u64(&ctr[PC_ODD], c_odd);
+	blk_max_u64(&ctr[PC_MAXQS], c_mq);
+}
+
+// the lines the tile parser left (flags == PF_ODD): the byte-wise routine, straight from global memory
+__global__ __launch_bounds__(256) void k_paf_parse_odd(const unsigned char *__restrict__ text, const uint64_t *__restrict__ lstart, uint32_t L, int min_span, int min_match, PafCols o,
+                                                        unsigned long long *__restrict__ ctr)
+{
+	__shared__ uint32_t s_fs[256 * 12];
+	uint32_t c_valid = 0, c_pass = 0, c_nobl = 0, c_long = 0;
+	uint64_t c_mq = 0;
+	for (uint32_t base = blockIdx.x * 256u; base < L; base += gridDim.x * 256u) {
+		const uint32_t i = base + threadIdx.x;
+		if (i >= L || o.flags[i] != PF_ODD) continue;
+		const uint64_t ls = lstart[i];
+		const uint32_t l = (uint32_t)(lstart[i + 1] - 1 - ls);
+		PafLine r;
+		const FsCols fs = { s_fs + threadIdx.x };
+		paf_line(text + ls, l, fs, r);
+		const uint32_t pass = r.valid && !(r.qe - r.qs < (uint32_t)min_span || r.te - r.ts < (uint32_t)min_span || (int)r.ml < min_match); // hit.c:85
+		c_valid += r.valid; c_pass += pass; c_nobl += r.valid && !r.hasbl;
+		o.flags[i] = (uint8_t)(r.valid | pass << 1 | r.hasbl << 2 | r.rev << 3);
+		o.ql[i] = r.ql; o.qs[i] = r.qs; o.qe[i] = r.qe; o.tl[i] = r.tl; o.ts[i] = r.ts; o.te[i] = r.te; o.ml[i] = r.ml; o.bl[i] = r.bl;
+		o.tnoff[i] = r.tnoff; o.qlen[i] = r.qlen; o.tlen[i] = r.tlen; o.hq[i] = r.hq; o.ht[i] = r.ht;
+		if (pass) {
+			c_long += !key_is_short(r.qlen) || !key_is_short(r.tlen);
+			const uint64_t mq = r.qs > r.ts ? r.qs : r.ts;
+			c_mq = mq > c_mq ? mq : c_mq;
+		}
+	}
+	blk_add_u64(&ctr[PC_VALID], c_valid);
+	blk_add_u64(&ctr[PC_PASS], c_pass);
+	blk_add_u64(&ctr[PC_NOBL], c_nobl);
+	blk_add_u64(&ctr[PC_LONG], c_long);
+	blk_max_u64(&ctr[PC_MAXQS], c_mq);
+}
+__global__ __launch_bounds__(256) void k_paf_hasbl(const uint8_t *__restrict__ flags, uint32_t L, uint32_t *__restrict__ f_hasbl)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < L) f_hasbl[i] = flags[i] >> 2 & 1u;
+}
+
 // ------------------------------------------------------------------------------------------------ name dictionary
 
 __device__ __forceinline__ bool name_eq(const unsigned char *__restrict__ a, const unsigned char *__restrict__ b, uint32_t len)
@@ -289,8 +610,9 @@ __device__ __forceinline__ uint32_t dict_probe(const unsigned char *__restrict__
                                                uint64_t h, uint32_t len, uint32_t occ, uint64_t noff, uint32_t *fresh)
 {
 	const unsigned char *nm = text + noff;
-	const uint32_t tag = (uint32_t)(h >> 32);
-	uint32_t s = (uint32_t)h & mask;
+	const uint64_t hm = key_mix(h); // (a short name's key is its bytes: mixed before it picks a slot)
+	const uint32_t tag = (uint32_t)(hm >> 32);
+	uint32_t s = (uint32_t)hm & mask;
 	for (uint32_t probe = 0; probe < PAF_PROBE_LIMIT; ++probe, s = (s + 1) & mask) {
 		unsigned long long e = tab[s];
 		if (e == PAF_EMPTY) {
@@ -361,6 +683,65 @@ __global__ __launch_bounds__(256) void k_dict_insert(const unsigned char *__rest
 	blk_add_u64(&ctr[PC_DISTINCT], fresh);
 }
 
+// ---- the dictionary of a file whose names are all 1..8 bytes (PC_LONG == 0): the key IS the name, so a slot that holds the key holds the name -- no text is
+// compared and none is fetched.  Slot = 16 bytes { key, ~(smallest occurrence), - }: all zero = free, claimed by a 64-bit CAS on the key; the occurrence word is
+// kept by atomicMax of the complement (so that zeroed memory is "none yet") and a probe touches it only when its own occurrence is smaller than what the same
+// 16-byte fetch showed.  One random fetch per name occurrence (round 5's probe: five -- slot word, info word, the first inserter's text, tmin, own text).
+// Run heads come from the parser (PF_QCONT), which compared the keys while it had them.
+struct __attribute__((aligned(16))) DSlot { unsigned long long key; uint32_t inv_occ, pad; };
+__device__ __forceinline__ uint32_t dict_probe_short(DSlot *__restrict__ tab, uint32_t mask, uint64_t key, uint32_t occ, uint32_t *fresh)
+{
+	uint32_t s = (uint32_t)key_mix(key) & mask;
+	for (uint32_t probe = 0; probe < PAF_PROBE_LIMIT; ++probe, s = (s + 1) & mask) {
+		const uint4 e = *(const uint4*)&tab[s];
+		unsigned long long k = (unsigned long long)e.y << 32 | e.x;
+		uint32_t seen = e.z;
+		if (k == 0) {
+			k = atomicCAS(&tab[s].key, 0ull, (unsigned long long)key);
+			if (k == 0) { ++*fresh; k = key; }
+			seen = 0;
+		}
+		if (k == key) {
+			if (seen < ~occ) atomicMax(&tab[s].inv_occ, ~occ);
+			return s;
+		}
+	}
+	return 0xffffffffu;
+}
+__global__ __launch_bounds__(256) void k_dict_insert_short(PafCols o, uint32_t L, DSlot *__restrict__ tab, uint32_t mask, unsigned long long *__restrict__ ctr)
+{
+	uint32_t fail = 0, fresh = 0;
+	const unsigned lane = threadIdx.x & 63;
+	for (uint32_t base = blockIdx.x * 256u; base < L; base += gridDim.x * 256u) { // wave-uniform
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t fl = i < L ? o.flags[i] : 0u;
+		const bool stored = (fl & 2u) != 0;
+		const bool head = stored && (!(fl & PF_QCONT) || lane == 0);
+		uint32_t qslot = 0xffffffffu;
+		if (head) qslot = dict_probe_short(tab, mask, o.hq[i], i * 2u, &fresh);
+		const unsigned long long heads = __ballot(head);
+		{ // a continuing lane: the slot of the nearest head to its left (lane 0 is one whenever it is stored)
+			const unsigned long long left = heads & ((1ull << lane) - 1ull);
+			const int src = left ? 63 - __builtin_clzll(left) : (int)lane;
+			const uint32_t got = __shfl(qslot, src, 64);
+			if (stored && !head) qslot = got;
+		}
+		if (stored) {
+			const uint32_t tslot = dict_probe_short(tab, mask, o.ht[i], i * 2u + 1u, &fresh);
+			if (qslot == 0xffffffffu || tslot == 0xffffffffu) fail = 1;
+			o.qslot[i] = qslot; o.tslot[i] = tslot;
+		}
+	}
+	blk_add_u64(&ctr[PC_OVERFLOW], fail);
+	blk_add_u64(&ctr[PC_DISTINCT], fresh);
+}
+// what the rest of the dictionary code reads: tmin[slot] = first appearance of the slot's name (~0: free slot)
+__global__ __launch_bounds__(256) void k_dict_short_tmin(const DSlot *__restrict__ tab, uint32_t cap, uint32_t *__restrict__ tmin)
+{
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s < cap) tmin[s] = tab[s].key ? ~tab[s].inv_occ : 0xffffffffu;
+}
+
 // ---- -R (ma_hit_no_cont, hit.c:38-68) on the parsed columns: reads that are clearly contained are excluded BEFORE ids are given out
 // (hit.c:86), so the exclusion is a property of NAMES: a line's verdict flags the name's table slot, lines that touch a flagged name are
 // dropped, and first appearances are taken over the lines that are left.
@@ -392,11 +773,11 @@ __global__ __launch_bounds__(256) void k_excl_count(const uint8_t *__restrict__ 
 	blk_add_u64(&ctr[PC_VALID], n);
 }
 
-// a name gets an id if some STORED line carries it (with -R a name may sit in the table without such a line)
-__global__ __launch_bounds__(256) void k_dict_flag(const unsigned long long *__restrict__ tab, const uint32_t *__restrict__ tmin, uint32_t cap, uint32_t *__restrict__ keep)
+// a name gets an id if some STORED line carries it (with -R a name may sit in the table without such a line); tmin is ~0 in free slots as well
+__global__ __launch_bounds__(256) void k_dict_flag(const uint32_t *__restrict__ tmin, uint32_t cap, uint32_t *__restrict__ keep)
 {
 	uint32_t s = blockIdx.x * 256u + threadIdx.x;
-	if (s < cap) keep[s] = tab[s] != PAF_EMPTY && tmin[s] != 0xffffffffu;
+	if (s < cap) keep[s] = tmin[s] != 0xffffffffu;
 }
 __global__ __launch_bounds__(256) void k_dict_collect(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ tmin, uint32_t cap,
                                                        uint64_t *__restrict__ key, uint32_t *__restrict__ val)
@@ -551,6 +932,81 @@ __global__ __launch_bounds__(256) void k_paf_emit(PafCols o, const uint32_t *__r
 	}
 }
 
+// ids + record slots + records in ONE pass (until round 5: k_paf_ids, a scan, k_paf_emit -- the columns read twice, ids and counts written and read back):
+// a tile of 1 024 lines looks up its ids, counts its records, learns where they go from the tiles in front of it (chained look-back, scan.hip) and writes them.
+#define EM_ITEMS 4u
+#define EM_TILE (256u * EM_ITEMS)
+__global__ __launch_bounds__(256) void k_paf_emit_chain(PafCols o, const uint32_t *__restrict__ slot_id, uint32_t L, int bi_dir, uint4 *__restrict__ rec, uint32_t *__restrict__ d_total,
+                                                         unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
+{
+	__shared__ uint32_t s_wave[4];
+	__shared__ uint32_t s_tile, s_prefix;
+	if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+	__syncthreads();
+	const uint32_t tile = s_tile;
+	const size_t base = (size_t)tile * EM_TILE + (size_t)threadIdx.x * EM_ITEMS;
+	uint32_t fl[EM_ITEMS], qid[EM_ITEMS], tid[EM_ITEMS], cnt[EM_ITEMS], sum = 0;
+	const bool full = base + EM_ITEMS <= L;
+	if (full) {
+		const uint32_t f4 = *(const uint32_t*)(o.flags + base);
+		const uint4 q4 = *(const uint4*)(o.qslot + base), t4 = *(const uint4*)(o.tslot + base);
+		fl[0] = f4 & 0xffu; fl[1] = f4 >> 8 & 0xffu; fl[2] = f4 >> 16 & 0xffu; fl[3] = f4 >> 24;
+		qid[0] = q4.x; qid[1] = q4.y; qid[2] = q4.z; qid[3] = q4.w;
+		tid[0] = t4.x; tid[1] = t4.y; tid[2] = t4.z; tid[3] = t4.w;
+	} else {
+#pragma unroll
+		for (unsigned k = 0; k < EM_ITEMS; ++k) { const bool in = base + k < L; fl[k] = in ? o.flags[base + k] : 0u; qid[k] = in ? o.qslot[base + k] : 0u; tid[k] = in ? o.tslot[base + k] : 0u; }
+	}
+#pragma unroll
+	for (unsigned k = 0; k < EM_ITEMS; ++k) {
+		cnt[k] = 0;
+		if (fl[k] & 2u) {
+			qid[k] = slot_id[qid[k]]; tid[k] = slot_id[tid[k]];
+			cnt[k] = 1u + (bi_dir && qid[k] != tid[k]); // hit.c:87-98
+		}
+		sum += cnt[k];
+	}
+	uint32_t tot;
+	const uint32_t ex = block_excl_scan_256(sum, s_wave, &tot);
+	if (threadIdx.x == 0) {
+		SC_PUBLISH(&state[tile], sc_pack(epoch, tile == 0 ? SC_INCL : SC_AGG, tot));
+		if (tile == 0) s_prefix = 0;
+	}
+	if (tile > 0 && threadIdx.x < 64) {
+		const uint32_t prefix = sc_look_back(state, tile, epoch, threadIdx.x);
+		if (threadIdx.x == 0) { s_prefix = prefix; SC_PUBLISH(&state[tile], sc_pack(epoch, SC_INCL, prefix + tot)); }
+	}
+	__syncthreads();
+	uint32_t p = s_prefix + ex;
+	if (sum) {
+		uint32_t qs[EM_ITEMS], qe[EM_ITEMS], ts[EM_ITEMS], te[EM_ITEMS], ml[EM_ITEMS], bl[EM_ITEMS];
+		if (full) {
+			const uint4 a = *(const uint4*)(o.qs + base), b = *(const uint4*)(o.qe + base), c = *(const uint4*)(o.ts + base), d = *(const uint4*)(o.te + base),
+			            e = *(const uint4*)(o.ml + base), f = *(const uint4*)(o.bl + base);
+			qs[0] = a.x; qs[1] = a.y; qs[2] = a.z; qs[3] = a.w; qe[0] = b.x; qe[1] = b.y; qe[2] = b.z; qe[3] = b.w;
+			ts[0] = c.x; ts[1] = c.y; ts[2] = c.z; ts[3] = c.w; te[0] = d.x; te[1] = d.y; te[2] = d.z; te[3] = d.w;
+			ml[0] = e.x; ml[1] = e.y; ml[2] = e.z; ml[3] = e.w; bl[0] = f.x; bl[1] = f.y; bl[2] = f.z; bl[3] = f.w;
+		} else {
+#pragma unroll
+			for (unsigned k = 0; k < EM_ITEMS; ++k) { const bool in = base + k < L; const size_t j = in ? base + k : 0; qs[k] = o.qs[j]; qe[k] = o.qe[j]; ts[k] = o.ts[j]; te[k] = o.te[j]; ml[k] = o.ml[j]; bl[k] = o.bl[j]; }
+		}
+#pragma unroll
+		for (unsigned k = 0; k < EM_ITEMS; ++k) {
+			if (!cnt[k]) continue;
+			const uint32_t mlrev = ml[k] | (fl[k] >> 3 & 1u) << 31, b31 = bl[k] & 0x7fffffffu;
+			uint4 *r = rec + (size_t)p * 2;
+			r[0] = make_uint4(qs[k], qid[k], qe[k], tid[k]);   // qns = qid<<32 | qs ; qe ; tn
+			r[1] = make_uint4(ts[k], te[k], mlrev, b31);       // ts ; te ; ml|rev ; bl|del=0
+			if (cnt[k] == 2) {
+				r[2] = make_uint4(ts[k], tid[k], te[k], qid[k]);
+				r[3] = make_uint4(qs[k], qe[k], mlrev, b31);
+			}
+			p += cnt[k];
+		}
+	}
+	if (base < L && base + EM_ITEMS >= L) *d_total = p; // the thread with the last line: its end is the total
+}
+
 // ------------------------------------------------------------------------------------------------ host entries
 
 static int paf_reserve_text(mahip_ctx *c, size_t nbytes)
@@ -628,18 +1084,27 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 	b->n_seq = 0; b->name_bytes = 0;
 
 	// ---- line starts
-	const size_t n_tiles = (n + PAF_TILE - 1) / PAF_TILE;
-	if (n_tiles > 0x7fffffffull) { mahip_set_error("mahip_paf_parse: text too large"); return -1; }
-	CHK(dev_reserve(c, b->tile, (n_tiles + 8) * 4));
+	const bool old_path = []{ const char *e = getenv("MA_PAF_OLD"); return e && atoi(e) != 0; }(); // round 5's kernels (lane-per-line parser, text-comparing dictionary, ids / scan / emit): the A/B switch
 	CHK(dev_reserve(c, b->scal, 64));
 	CHK(ctr_zero(c));
 	uint32_t L = 0;
-	if (n) {
+	int open_line = 0;
+	uint32_t n_gran = 0, tile_k = 1, n_tiles = 0;
+	if (n) { // same decision as the kernels': L = newlines + an unterminated tail
+		unsigned char last = 0;
+		HIPCHK(hipMemcpyAsync(&last, text + n - 1, 1, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));
+		open_line = last != '\n';
+	}
+	if (n && old_path) {
+		const size_t n_tiles4k = (n + PAF_TILE - 1) / PAF_TILE;
+		if (n_tiles4k > 0x7fffffffull) { mahip_set_error("mahip_paf_parse: text too large"); return -1; }
+		CHK(dev_reserve(c, b->tile, (n_tiles4k + 8) * 4));
 		{
 			ProfScope ps(c, "k_paf_nl_count", (double)n);
-			hipLaunchKernelGGL(k_paf_nl_count, dim3((unsigned)n_tiles), dim3(256), 0, c->st, text, n, P<uint32_t>(b->tile));
+			hipLaunchKernelGGL(k_paf_nl_count, dim3((unsigned)n_tiles4k), dim3(256), 0, c->st, text, n, P<uint32_t>(b->tile));
 		}
-		CHK(scan_exclusive_u32(c, P<uint32_t>(b->tile), P<uint32_t>(b->tile), n_tiles, P<uint32_t>(b->scal)));
+		CHK(scan_exclusive_u32(c, P<uint32_t>(b->tile), P<uint32_t>(b->tile), n_tiles4k, P<uint32_t>(b->scal)));
 		uint32_t n_nl = 0;
 		HIPCHK(hipMemcpyAsync(&n_nl, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(hipStreamSynchronize(c->st));
@@ -647,17 +1112,40 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 		CHK(dev_reserve(c, b->lstart, ((size_t)n_nl + 4) * 8));
 		{
 			ProfScope ps(c, "k_paf_nl_pos", (double)n + 8.0 * (double)n_nl);
-			hipLaunchKernelGGL(k_paf_nl_pos, dim3((unsigned)n_tiles), dim3(256), 0, c->st, text, n, (const uint32_t*)P<uint32_t>(b->tile), (const uint32_t*)P<uint32_t>(b->scal), P<uint64_t>(b->lstart), ctr);
-		}
-		int open_line = 0;
-		{ // same decision as the kernel's, from the host's view of the counts: L = newlines + unterminated tail
-			unsigned char last = 0;
-			HIPCHK(hipMemcpyAsync(&last, text + n - 1, 1, hipMemcpyDeviceToHost, c->st));
-			HIPCHK(hipStreamSynchronize(c->st));
-			open_line = last != '\n';
+			hipLaunchKernelGGL(k_paf_nl_pos, dim3((unsigned)n_tiles4k), dim3(256), 0, c->st, text, n, (const uint32_t*)P<uint32_t>(b->tile), (const uint32_t*)P<uint32_t>(b->scal), P<uint64_t>(b->lstart), ctr);
 		}
 		L = n_nl + (uint32_t)open_line;
-		if (!open_line) { // terminated text: line L-1 ends at the last newline; lstart[L] was written by the scatter
+	} else if (n) { // newline census per KiB; the tile parser writes the line starts itself
+		const size_t ng = (n + 1 + PAF_GRAN - 1) / PAF_GRAN; // position n (where an unterminated text gets its virtual newline) lies in a granule
+		if (ng > 0x7ffffff0ull) { mahip_set_error("mahip_paf_parse: text too large"); return -1; }
+		n_gran = (uint32_t)ng;
+		CHK(dev_reserve(c, b->tile, ((size_t)n_gran + 8) * 4)); CHK(dev_reserve(c, b->glast, ((size_t)n_gran + 8) * 4));
+		{
+			ProfScope ps(c, "k_paf_nl_count", (double)n);
+			hipLaunchKernelGGL(k_paf_gran_count, dim3((n_gran + 3) / 4), dim3(256), 0, c->st, text, n, open_line, n_gran, P<uint32_t>(b->tile), P<uint32_t>(b->glast));
+		}
+		CHK(scan_exclusive_u32(c, P<uint32_t>(b->tile), P<uint32_t>(b->tile), n_gran, P<uint32_t>(b->tile) + n_gran)); // goff[n_gran] = all newlines
+		uint64_t n_nl = 0;
+		{
+			uint32_t t32 = 0;
+			HIPCHK(hipMemcpyAsync(&t32, P<uint32_t>(b->tile) + n_gran, 4, hipMemcpyDeviceToHost, c->st));
+			HIPCHK(hipStreamSynchronize(c->st));
+			n_nl = t32;
+		}
+		if (n_nl + 1 >= 0x7fffffffull) { mahip_set_error("mahip_paf_parse: more than 2^31 lines"); return -1; }
+		L = (uint32_t)n_nl; // (the virtual newline is counted)
+		CHK(dev_reserve(c, b->lstart, ((size_t)L + 4) * 8));
+		if (L) {
+			// tile = K granules with about 240 lines (a lane per line, 256 lanes); at most what a block stages (15 KiB + 1 KiB in front with 16 KiB of LDS text, 31 + 1 with 32)
+			double k = 240.0 * ((double)n / (double)L) / (double)PAF_GRAN;
+			if (const char *e = getenv("MA_PAF_TILE_K")) k = atof(e);
+			tile_k = k < 1.0 ? 1u : k > 31.0 ? 31u : (uint32_t)k;
+			n_tiles = (n_gran + tile_k - 1) / tile_k;
+			const uint32_t n_grp = (n_gran >> PAF_BGRP) + 1;
+			CHK(dev_reserve(c, b->gmax, ((size_t)n_grp + 1) * 8)); CHK(dev_reserve(c, b->tfirst, ((size_t)n_tiles + 1) * 8));
+			hipLaunchKernelGGL(k_paf_gran_bmax, dim3(n_grp), dim3(64), 0, c->st, (const uint32_t*)P<uint32_t>(b->glast), n_gran, P<unsigned long long>(b->gmax));
+			hipLaunchKernelGGL(k_paf_tile_first, dim3(grid_for(n_tiles, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(b->glast), (const unsigned long long*)P<unsigned long long>(b->gmax), tile_k, n_tiles,
+			                   P<unsigned long long>(b->tfirst));
 		}
 	}
 	PafCols o;
@@ -674,11 +1162,11 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 		o.tnoff = P<uint32_t>(b->tnoff); o.qlen = P<uint32_t>(b->qlen); o.tlen = P<uint32_t>(b->tlen);
 		o.hq = P<uint64_t>(b->hq); o.ht = P<uint64_t>(b->ht); o.qslot = P<uint32_t>(b->qslot); o.tslot = P<uint32_t>(b->tslot);
 	}
-	size_t n_valid = 0, n_pass = 0, n_nobl = 0;
+	size_t n_valid = 0, n_pass = 0, n_nobl = 0, n_long = 0;
 	uint32_t max_qs = 0;
 	if (L) {
 		CHK(dev_reserve(c, c->keep, ((size_t)L + 16) * 4)); CHK(dev_reserve(c, c->pos, ((size_t)L + 16) * 4));
-		{
+		if (old_path) {
 			ProfScope ps(c, "k_paf_parse", (double)n + 61.0 * (double)L);
 			// LDS tile: 1.5 x the mean text of 256 lines, in 4 KiB steps (blocks whose lines are longer read global memory)
 			uint32_t lds_bytes = (uint32_t)((double)n / (double)L * 256.0 * 1.5);
@@ -686,12 +1174,31 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 			if (lds_bytes < 8192u) lds_bytes = 8192u;
 			if (lds_bytes > PAF_LDS_BYTES) lds_bytes = PAF_LDS_BYTES;
 			hipLaunchKernelGGL(k_paf_parse, dim3(grid_for(L, 256)), dim3(256), lds_bytes + 32, c->st, text, n, (const uint64_t*)P<uint64_t>(b->lstart), L, min_span, min_match, o, P<uint32_t>(c->keep), ctr, lds_bytes);
+		} else {
+			ProfScope ps(c, "k_paf_parse", (double)n + 69.0 * (double)L);
+			TileArgs ta;
+			ta.text = text; ta.n = n; ta.open = open_line; ta.K = tile_k; ta.n_gran = n_gran; ta.n_tiles = n_tiles; ta.L = L;
+			ta.goff = (const uint32_t*)P<uint32_t>(b->tile); ta.first = (const unsigned long long*)P<unsigned long long>(b->tfirst);
+			ta.min_span = min_span; ta.min_match = min_match;
+			const int ch = tile_k <= 15 ? 1 : 2;
+			const uint32_t reg = (uint32_t)ch * 16384u, lds = reg + 32 + 2 * (reg / 16 + 8) * 2 + 260 * 4;
+			uint32_t per_cu = (160u * 1024u) / (lds + 64u); if (per_cu > 8) per_cu = 8; // blocks a CU holds: the grid is what fits the chip, a block works through tiles (one set of counter atomics per block)
+			const unsigned grid = grid_for(n_tiles, 1, 256u * per_cu);
+			if (ch == 1) hipLaunchKernelGGL(k_paf_parse_tile<1>, dim3(grid), dim3(256), lds, c->st, ta, o, P<uint64_t>(b->lstart), ctr);
+			else hipLaunchKernelGGL(k_paf_parse_tile<2>, dim3(grid), dim3(256), lds, c->st, ta, o, P<uint64_t>(b->lstart), ctr);
 		}
 		CHK(ctr_fetch(c));
+		if (!old_path && c->h_ctr[PC_ODD]) { // lines the straight-line parser does not cover: the byte-wise routine on them (the counters add up)
+			ProfScope ps(c, "k_paf_parse_odd", 0.0);
+			hipLaunchKernelGGL(k_paf_parse_odd, dim3(grid_for(L, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, text, (const uint64_t*)P<uint64_t>(b->lstart), L, min_span, min_match, o, ctr);
+			CHK(ctr_fetch(c));
+		}
 		n_valid = (size_t)c->h_ctr[PC_VALID]; n_pass = (size_t)c->h_ctr[PC_PASS]; n_nobl = (size_t)c->h_ctr[PC_NOBL];
+		n_long = old_path ? n_pass : (size_t)c->h_ctr[PC_LONG];
 		max_qs = (uint32_t)c->h_ctr[PC_MAXQS];
 		if (n_nobl && !sharded) { // stale bl: rare (PAF writers emit 12+ columns)
 			CHK(dev_reserve(c, b->blv, ((size_t)L + 4) * 4));
+			if (!old_path) hipLaunchKernelGGL(k_paf_hasbl, dim3(grid_for(L, 256)), dim3(256), 0, c->st, (const uint8_t*)o.flags, L, P<uint32_t>(c->keep));
 			CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), L, nullptr));
 			hipLaunchKernelGGL(k_paf_bl_compact, dim3(grid_for(L, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (const uint32_t*)o.bl, L, P<uint32_t>(b->blv));
 			hipLaunchKernelGGL(k_paf_bl_fill, dim3(grid_for(L, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (const uint32_t*)P<uint32_t>(b->blv), L, o.bl);
@@ -714,6 +1221,7 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 			uint32_t n_has = 0, last_bl = 0;
 			if (L) {
 				CHK(dev_reserve(c, b->blv, ((size_t)L + 4) * 4));
+				if (!old_path) hipLaunchKernelGGL(k_paf_hasbl, dim3(grid_for(L, 256)), dim3(256), 0, c->st, (const uint8_t*)o.flags, L, P<uint32_t>(c->keep));
 				CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), L, P<uint32_t>(b->scal)));
 				hipLaunchKernelGGL(k_paf_bl_compact, dim3(grid_for(L, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (const uint32_t*)o.bl, L, P<uint32_t>(b->blv));
 				HIPCHK(hipMemcpyAsync(&n_has, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
@@ -738,14 +1246,19 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 		const uint32_t cap_max = pow2_at_least(4 * (uint64_t)n_pass + 65536); // load <= 1/2 whatever the file holds
 		uint32_t cap = pow2_at_least(n_pass / 16 + 65536);
 		if (const char *e = getenv("MA_DICT_CAP_LOG2")) { int l2 = atoi(e); if (l2 >= 4 && l2 <= 31) cap = 1u << l2; } // tests: force the growth path
+		const bool short_names = !old_path && n_long == 0 && !getenv("MA_DICT_EXACT_TEXT"); // every name is its own key: no text compared (k_dict_insert_short)
 		for (int attempt = 0;; ++attempt) {
-			CHK(dev_reserve(c, b->tab, (size_t)cap * 8)); CHK(dev_reserve(c, b->tmin, (size_t)cap * 4)); CHK(dev_reserve(c, b->slot_id, (size_t)cap * 4));
-			CHK(dev_reserve(c, b->info, (size_t)cap * 8));
-			HIPCHK(hipMemsetAsync(b->tab.p, 0xff, (size_t)cap * 8, c->st));
-			HIPCHK(hipMemsetAsync(b->info.p, 0xff, (size_t)cap * 8, c->st));
-			HIPCHK(hipMemsetAsync(b->tmin.p, 0xff, (size_t)cap * 4, c->st));
+			CHK(dev_reserve(c, b->tab, (size_t)cap * (short_names ? 16 : 8))); CHK(dev_reserve(c, b->tmin, (size_t)cap * 4)); CHK(dev_reserve(c, b->slot_id, (size_t)cap * 4));
 			CHK(ctr_zero(c));
-			{
+			if (short_names) {
+				HIPCHK(hipMemsetAsync(b->tab.p, 0, (size_t)cap * 16, c->st));
+				ProfScope ps(c, "k_dict_insert", 2.0 * 40.0 * (double)n_pass);
+				hipLaunchKernelGGL(k_dict_insert_short, dim3(grid_for(L, 256, 8192)), dim3(256), 0, c->st, o, L, (DSlot*)b->tab.p, cap - 1, ctr);
+			} else {
+				CHK(dev_reserve(c, b->info, (size_t)cap * 8));
+				HIPCHK(hipMemsetAsync(b->tab.p, 0xff, (size_t)cap * 8, c->st));
+				HIPCHK(hipMemsetAsync(b->info.p, 0xff, (size_t)cap * 8, c->st));
+				HIPCHK(hipMemsetAsync(b->tmin.p, 0xff, (size_t)cap * 4, c->st));
 				ProfScope ps(c, "k_dict_insert", 2.0 * 40.0 * (double)n_pass);
 				hipLaunchKernelGGL(k_dict_insert, dim3(grid_for(L, 256, 8192)), dim3(256), 0, c->st, text, (const uint64_t*)P<uint64_t>(b->lstart), L, o,
 				                   P<unsigned long long>(b->tab), P<uint32_t>(b->tmin), P<unsigned long long>(b->info), cap - 1, ctr);
@@ -758,6 +1271,7 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 			if (want <= cap) want = cap < 0x10000000u ? cap << 3 : cap_max; // a probe sequence ran out: the count is incomplete
 			cap = want < cap_max ? want : cap_max;
 		}
+		if (short_names) hipLaunchKernelGGL(k_dict_short_tmin, dim3(grid_for(cap, 256)), dim3(256), 0, c->st, (const DSlot*)b->tab.p, cap, P<uint32_t>(b->tmin));
 		if (no_cont) { // hit.c:38-68 + hit.c:86
 			CHK(dev_reserve(c, b->excl, (size_t)cap + 16));
 			HIPCHK(hipMemsetAsync(b->excl.p, 0, cap, c->st));
@@ -771,7 +1285,7 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 			info->n_excl = (uint32_t)c->h_ctr[PC_VALID];
 		}
 		CHK(dev_reserve(c, c->keep, ((size_t)cap + 16) * 4)); CHK(dev_reserve(c, c->pos, ((size_t)cap + 16) * 4));
-		hipLaunchKernelGGL(k_dict_flag, dim3(grid_for(cap, 256)), dim3(256), 0, c->st, (const unsigned long long*)P<unsigned long long>(b->tab), (const uint32_t*)P<uint32_t>(b->tmin), cap, P<uint32_t>(c->keep));
+		hipLaunchKernelGGL(k_dict_flag, dim3(grid_for(cap, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(b->tmin), cap, P<uint32_t>(c->keep));
 		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), cap, P<uint32_t>(b->scal)));
 		HIPCHK(hipMemcpyAsync(&R, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(hipStreamSynchronize(c->st));
@@ -861,7 +1375,7 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 			DevBuf used_local;
 			if (cap_used) {
 				if ((rc = dev_reserve(c, used_local, (size_t)cap_used * 4 + 16)) != 0) break;
-				hipLaunchKernelGGL(k_dict_flag, dim3(grid_for(cap_used, 256)), dim3(256), 0, c->st, (const unsigned long long*)P<unsigned long long>(b->tab), (const uint32_t*)P<uint32_t>(b->tmin), cap_used, (uint32_t*)used_local.p);
+				hipLaunchKernelGGL(k_dict_flag, dim3(grid_for(cap_used, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(b->tmin), cap_used, (uint32_t*)used_local.p);
 			}
 			if ((rc = dev_reserve(c, c->keep, ((size_t)Rg + 16) * 4)) != 0) { dev_free(c, used_local); break; }
 			if (Rg) hipLaunchKernelGGL(k_merge_assign, dim3(grid_for(Rg, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->val[gen]), Rg, (const unsigned long long*)gtab, (const unsigned long long*)gkey,
@@ -887,7 +1401,7 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 
 	// ---- records: hit (+ mirrored hit) per stored line, in line order
 	size_t n_hits = 0;
-	if (n_pass) {
+	if (n_pass && old_path) {
 		CHK(dev_reserve(c, c->keep, ((size_t)L + 16) * 4)); CHK(dev_reserve(c, c->pos, ((size_t)L + 16) * 4));
 		hipLaunchKernelGGL(k_paf_ids, dim3(grid_for(L, 256)), dim3(256), 0, c->st, o, slot_to_id, L, bi_dir, P<uint32_t>(c->keep));
 		uint32_t nh = 0;
@@ -895,13 +1409,34 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 		HIPCHK(hipMemcpyAsync(&nh, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(hipStreamSynchronize(c->st));
 		n_hits = nh;
-	}
-	CHK(mahip_hits_adopt(c, nullptr, n_hits, R)); // resets the per-upload state and sizes the read arrays
-	CHK(dev_reserve(c, c->aos_own, (n_hits + 1) * sizeof(ma_hit_t)));
-	c->d_aos = (const ma_hit_t*)c->aos_own.p;
-	if (n_hits) {
-		ProfScope ps(c, "k_paf_emit", 45.0 * (double)n_pass + 32.0 * (double)n_hits);
-		hipLaunchKernelGGL(k_paf_emit, dim3(grid_for(L, 256)), dim3(256), 0, c->st, o, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), L, (uint4*)c->aos_own.p);
+		CHK(mahip_hits_adopt(c, nullptr, n_hits, R)); // resets the per-upload state and sizes the read arrays
+		CHK(dev_reserve(c, c->aos_own, (n_hits + 1) * sizeof(ma_hit_t)));
+		c->d_aos = (const ma_hit_t*)c->aos_own.p;
+		if (n_hits) {
+			ProfScope ps(c, "k_paf_emit", 45.0 * (double)n_pass + 32.0 * (double)n_hits);
+			hipLaunchKernelGGL(k_paf_emit, dim3(grid_for(L, 256)), dim3(256), 0, c->st, o, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), L, (uint4*)c->aos_own.p);
+		}
+	} else if (n_pass) { // one pass: ids, record slots (chained tiles), records
+		const size_t max_hits = bi_dir ? 2 * n_pass : n_pass;
+		if (max_hits >= 0xffffffffull) { mahip_set_error("mahip_paf_parse: more than 2^32 records"); return -1; }
+		CHK(dev_reserve(c, c->aos_own, (max_hits + 1) * sizeof(ma_hit_t)));
+		const size_t nb = ((size_t)L + EM_TILE - 1) / EM_TILE;
+		uint32_t *ticket; unsigned long long *state; uint32_t ticket_base, epoch;
+		CHK(scan_chain_begin(c, nb, &state, &ticket, &ticket_base, &epoch));
+		uint32_t nh = 0;
+		{
+			ProfScope ps(c, "k_paf_emit", 37.0 * (double)n_pass + 32.0 * (double)max_hits);
+			hipLaunchKernelGGL(k_paf_emit_chain, dim3((unsigned)nb), dim3(256), 0, c->st, o, slot_to_id, L, bi_dir, (uint4*)c->aos_own.p, P<uint32_t>(b->scal), state, ticket, ticket_base, epoch);
+		}
+		HIPCHK(hipMemcpyAsync(&nh, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));
+		n_hits = nh;
+		CHK(mahip_hits_adopt(c, nullptr, n_hits, R)); // resets the per-upload state and sizes the read arrays
+		c->d_aos = (const ma_hit_t*)c->aos_own.p;
+	} else {
+		CHK(mahip_hits_adopt(c, nullptr, 0, R));
+		CHK(dev_reserve(c, c->aos_own, sizeof(ma_hit_t)));
+		c->d_aos = (const ma_hit_t*)c->aos_own.p;
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipStreamSynchronize(c->st));

@@ -174,6 +174,62 @@ def test_ingest_fuzz_against_host_reader(tmpdir_s):
     ctx.close()
 
 
+def _good_line(rnd, names, tags=""):
+    a, b = rnd.randint(0, 3000), rnd.randint(0, 3000)
+    return "%s\t9000\t%d\t%d\t%s\t%s\t8000\t%d\t%d\t%d\t%d\t255%s" % (rnd.choice(names), a, a + rnd.randint(2100, 5000), rnd.choice("+-"), rnd.choice(names), b,
+                                                                     b + rnd.randint(2100, 5000), rnd.randint(150, 900), rnd.randint(1000, 4000), tags)
+
+
+def test_tile_parser_shapes(tmpdir_s, monkeypatch):
+    """the tile parser (csrc/paf.hip: k_paf_parse_tile) cuts the text into tiles of K KiB and gives every line that ENDS in a tile a lane of its block: texts whose size
+    sits on and around tile and granule borders, with and without a final newline; lines longer than the 960 bytes a block keeps in front of its tile, longer than a tile,
+    longer than many tiles; thousands of empty lines in one tile (more lines than lanes: batches); long lines on average (the 32 KiB form of the kernel); names of 8, 9,
+    64 and 65 bytes (key = the bytes / a hash of the words / the byte-wise routine); every tile size the host may choose, forced"""
+    rnd = random.Random(77)
+    short = ["r%d" % i for i in range(60)] + ["abcdefgh", "abcdefg", "x"]
+    mixed = short + ["abcdefghi", "m54119_180101_0001/12345/0_9000", "n" * 64, "n" * 63 + "x", "n" * 65, "n" * 200]
+    ctx = ma.Ctx(0)
+    opt = ma.default_opt()
+    cases = []
+    base_lines = [_good_line(rnd, short) for _ in range(1200)]
+    body = "\n".join(base_lines)
+    for cut in (1024, 1023, 1025, 2048, 15 * 1024, 15 * 1024 + 1, 16384, 16383, 31 * 1024, 32768, 40000):
+        cases.append(("cut%d" % cut, body[:cut]))
+        cases.append(("cut%dnl" % cut, body[:cut - 1] + "\n"))
+    # long lines: tags of 1 KB, 3 KB, 20 KB, 70 KB between ordinary lines; a long line first, a long line last
+    for k, tl in enumerate((900, 1000, 3000, 20000, 70000)):
+        ls = [_good_line(rnd, mixed) for _ in range(300)]
+        for _ in range(6):
+            ls.insert(rnd.randint(0, len(ls)), _good_line(rnd, mixed, "\tcg:Z:" + "M" * tl))
+        ls.insert(0, _good_line(rnd, mixed, "\tcg:Z:" + "I" * tl))
+        ls.append(_good_line(rnd, mixed, "\tcg:Z:" + "D" * tl))
+        cases.append(("long%d" % k, "\n".join(ls) + ("\n" if k & 1 else "")))
+    # more lines than lanes in a tile: runs of empty lines, one-byte lines
+    cases.append(("empties", "\n" * 5000 + body[:3000] + "\n" * 3000 + "\n".join(base_lines[:40]) + "\n" + "x\n" * 2000))
+    # long on average: 30 bytes of tags on every line -> K > 15
+    cases.append(("tagged", "\n".join(_good_line(rnd, mixed, "\ttp:A:S\tcm:i:%d\ts1:i:%d\tdv:f:0.0123\trl:i:55" % (rnd.randint(0, 999), rnd.randint(0, 9999))) for _ in range(3000)) + "\n"))
+    cases.append(("mixednames", "\n".join(_good_line(rnd, mixed) for _ in range(4000))))
+    for name, txt in cases:
+        p = os.path.join(tmpdir_s, "gi_tile_%s.paf" % name)
+        open(p, "wb").write(txt.encode("latin-1"))
+        _same_as_host(ctx, p, opt)
+    for k in ("1", "2", "7", "15", "16", "31"):
+        monkeypatch.setenv("MA_PAF_TILE_K", k)
+        for name in ("long3", "empties", "tagged", "cut16384", "cut32768nl"):
+            _same_as_host(ctx, os.path.join(tmpdir_s, "gi_tile_%s.paf" % name), opt)
+    monkeypatch.delenv("MA_PAF_TILE_K")
+    # round 5's kernels stay behind a switch: same result
+    monkeypatch.setenv("MA_PAF_OLD", "1")
+    for name in ("long3", "mixednames", "empties"):
+        _same_as_host(ctx, os.path.join(tmpdir_s, "gi_tile_%s.paf" % name), opt)
+    monkeypatch.delenv("MA_PAF_OLD")
+    # short names only, but the text-comparing dictionary forced: same ids
+    monkeypatch.setenv("MA_DICT_EXACT_TEXT", "1")
+    _same_as_host(ctx, os.path.join(tmpdir_s, "gi_tile_cut40000.paf"), opt)
+    monkeypatch.delenv("MA_DICT_EXACT_TEXT")
+    ctx.close()
+
+
 def test_cli_falls_back_to_host_reader_when_text_stage_does_not_fit(tmpdir_s, monkeypatch):
     """a text the device stage refuses (here: an artificial cap) is parsed by the host reader instead: same output, a warning"""
     import subprocess
