@@ -299,22 +299,33 @@ __global__ __launch_bounds__(256) void k_paf_bl_fill(const uint32_t *__restrict_
 #define PC_ODD CT_NASYMM
 
 __device__ __forceinline__ uint32_t eq_mask(uint32_t v, uint32_t c4) { v ^= c4; const uint32_t t = (v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu; return ~(t | v | 0x7F7F7F7Fu); } // 0x80 in every byte of v that equals c
-__device__ __forceinline__ uint32_t nib4(uint32_t m) { return ((m >> 7) * 0x204081u) >> 21 & 0xFu; } // the four flags of a word as bits 0..3 (the products land on distinct bits: no carries)
-__device__ __forceinline__ uint32_t mask16(const uint4 v, uint32_t c4) { return nib4(eq_mask(v.x, c4)) | nib4(eq_mask(v.y, c4)) << 4 | nib4(eq_mask(v.z, c4)) << 8 | nib4(eq_mask(v.w, c4)) << 12; }
+// the flags of two masks as one byte: newline flags -> bits 0..3, TAB flags -> bits 4..7 (one multiply gathers both: the partial products land on 32 distinct bits)
+__device__ __forceinline__ uint32_t nib8(uint32_t m_nl, uint32_t m_tab) { return (((m_nl >> 7) | (m_tab >> 3)) * 0x204081u) >> 21 & 0xFFu; }
+// TAB bits (low half) and newline bits (high half) of a 16-byte piece
+__device__ __forceinline__ uint32_t masks16(const uint4 v)
+{
+	const uint32_t a = nib8(eq_mask(v.x, 0x0A0A0A0Au), eq_mask(v.x, 0x09090909u)), b = nib8(eq_mask(v.y, 0x0A0A0A0Au), eq_mask(v.y, 0x09090909u));
+	const uint32_t c = nib8(eq_mask(v.z, 0x0A0A0A0Au), eq_mask(v.z, 0x09090909u)), d = nib8(eq_mask(v.w, 0x0A0A0A0Au), eq_mask(v.w, 0x09090909u));
+	const uint32_t nl = (a & 15u) | (b & 15u) << 4 | (c & 15u) << 8 | (d & 15u) << 12, tb = a >> 4 | (b >> 4) << 4 | (c >> 4) << 8 | (d >> 4) << 12;
+	return tb | nl << 16;
+}
 
-// granule g = bytes [1024 g, 1024 g + 1024), one wave: cnt[g] = its newlines, last[g] = offset of the byte behind its last newline (0: it has none)
-__global__ __launch_bounds__(256) void k_paf_gran_count(const unsigned char *__restrict__ text, size_t n, int open, uint32_t n_gran, uint32_t *__restrict__ cnt, uint32_t *__restrict__ last)
+// granule g = bytes [1024 g, 1024 g + 1024), one wave: cnt[g] = its newlines, last[g] = offset of the byte behind its last newline (0: it has none).
+// (The text ends with a newline -- the host appends one to a text that does not -- and is followed by zeros up to the next 16 bytes.)
+__global__ __launch_bounds__(256) void k_paf_gran_count(const unsigned char *__restrict__ text, size_t n, uint32_t n_gran, uint32_t *__restrict__ cnt, uint32_t *__restrict__ last)
 {
 	const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (g >= n_gran) return; // the whole wave
 	const size_t off = (size_t)g * PAF_GRAN + lane * 16u;
-	uint32_t m = 0;
-	if (off < n) m = mask16(load16(text, off, n), 0x0A0A0A0Au);
-	if (open && n >= off && n < off + 16) m |= 1u << (uint32_t)(n - off);
-	const uint32_t c = wv_sum_u32((uint32_t)__popc(m));
-	const unsigned long long has = __ballot(m != 0);
+	uint32_t mx = 0, my = 0, mz = 0, mw = 0;
+	if (off < n) { const uint4 v = *(const uint4*)(text + off); mx = eq_mask(v.x, 0x0A0A0A0Au); my = eq_mask(v.y, 0x0A0A0A0Au); mz = eq_mask(v.z, 0x0A0A0A0Au); mw = eq_mask(v.w, 0x0A0A0A0Au); }
+	const uint32_t c = wv_sum_u32((uint32_t)(__popc(mx) + __popc(my) + __popc(mz) + __popc(mw)));
+	const unsigned long long has = __ballot((mx | my | mz | mw) != 0);
 	if (lane == 0) { cnt[g] = c; if (!has) last[g] = 0; }
-	if (has && (int)lane == 63 - __clzll((long long)has)) last[g] = lane * 16u + (32u - (uint32_t)__clz((int)m));
+	if (has && (int)lane == 63 - __clzll((long long)has)) { // the lane with the granule's last newline: byte index of its highest flag + 1
+		const uint32_t w = mw ? 3u : mz ? 2u : my ? 1u : 0u, m = mw ? mw : mz ? mz : my ? my : mx;
+		last[g] = lane * 16u + w * 4u + ((31u - (uint32_t)__clz((int)m)) >> 3) + 1u;
+	}
 }
 // bmax[b] = byte behind the last newline of granules [4096 b, 4096 b + 4096) (0: none), one wave per group
 __global__ __launch_bounds__(64) void k_paf_gran_bmax(const uint32_t *__restrict__ last, uint32_t n_gran, unsigned long long *__restrict__ bmax)
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(256) void k_paf_tile_first(const uint32_t *__restri
 }
 
 struct TileArgs {
-	const unsigned char *text; size_t n; int open;
+	const unsigned char *text; size_t n; // (ends with a newline, zeros behind it)
 	uint32_t K, n_gran, n_tiles, L;
 	const uint32_t *goff;            // [n_gran + 1] newlines in front of every granule
 	const unsigned long long *first; // [n_tiles]
@@ -433,15 +444,11 @@ __global__ __launch_bounds__(256) void k_paf_parse_tile(const TileArgs a, PafCol
 		const uint32_t len = (uint32_t)(te0 - lo); // <= REG, a multiple of 64
 		for (uint32_t p = threadIdx.x; p * 16u < len; p += 256u) {
 			const uint64_t off = lo + (uint64_t)p * 16u;
-			const uint4 v = off < a.n ? load16(a.text, off, a.n) : make_uint4(0, 0, 0, 0);
-			uint32_t mt = mask16(v, 0x09090909u), mn = mask16(v, 0x0A0A0A0Au);
-			if (a.open && a.n >= off && a.n < off + 16) mn |= 1u << (uint32_t)(a.n - off);
-			if (off < first) { // bytes of lines that ended in front of this tile
-				const uint32_t keep = off + 16 <= first ? 0u : 0xffffu << (uint32_t)(first - off);
-				mt &= keep; mn &= keep;
-			}
+			const uint4 v = off < a.n ? *(const uint4*)(a.text + off) : make_uint4(0, 0, 0, 0);
+			uint32_t m = masks16(v);
+			if (off < first) m &= off + 16 <= first ? 0u : (0xffffu << (uint32_t)(first - off) & 0xffffu) * 0x10001u; // bytes of lines that ended in front of this tile
 			*(uint4*)(s_text + p * 16u) = v;
-			s_tb[p] = (uint16_t)mt; s_nb[p] = (uint16_t)mn;
+			s_tb[p] = (uint16_t)m; s_nb[p] = (uint16_t)(m >> 16);
 		}
 		for (uint32_t p = len / 16u + threadIdx.x; p < REG / 16u; p += 256u) s_nb[p] = 0; // (the ranking below reads the whole array)
 		__syncthreads();
@@ -1090,6 +1097,7 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 	uint32_t L = 0;
 	int open_line = 0;
 	uint32_t n_gran = 0, tile_k = 1, n_tiles = 0;
+	size_t n_eff = n; // the tile parser's text: n + the appended newline
 	if (n) { // same decision as the kernels': L = newlines + an unterminated tail
 		unsigned char last = 0;
 		HIPCHK(hipMemcpyAsync(&last, text + n - 1, 1, hipMemcpyDeviceToHost, c->st));
@@ -1116,13 +1124,18 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 		}
 		L = n_nl + (uint32_t)open_line;
 	} else if (n) { // newline census per KiB; the tile parser writes the line starts itself
-		const size_t ng = (n + 1 + PAF_GRAN - 1) / PAF_GRAN; // position n (where an unterminated text gets its virtual newline) lies in a granule
+		// every line ends with a newline: a text that does not gets one (the buffer has 64 spare bytes; the line's sentinel n + 1 is what k_paf_nl_pos gives it),
+		// and zeros follow, so that the kernels read whole 16-byte pieces
+		HIPCHK(hipMemsetAsync((void*)(text + n), 0, 64, c->st));
+		if (open_line) HIPCHK(hipMemsetAsync((void*)(text + n), '\n', 1, c->st));
+		n_eff = n + (size_t)open_line;
+		const size_t ng = (n_eff + PAF_GRAN - 1) / PAF_GRAN;
 		if (ng > 0x7ffffff0ull) { mahip_set_error("mahip_paf_parse: text too large"); return -1; }
 		n_gran = (uint32_t)ng;
 		CHK(dev_reserve(c, b->tile, ((size_t)n_gran + 8) * 4)); CHK(dev_reserve(c, b->glast, ((size_t)n_gran + 8) * 4));
 		{
 			ProfScope ps(c, "k_paf_nl_count", (double)n);
-			hipLaunchKernelGGL(k_paf_gran_count, dim3((n_gran + 3) / 4), dim3(256), 0, c->st, text, n, open_line, n_gran, P<uint32_t>(b->tile), P<uint32_t>(b->glast));
+			hipLaunchKernelGGL(k_paf_gran_count, dim3((n_gran + 3) / 4), dim3(256), 0, c->st, text, n_eff, n_gran, P<uint32_t>(b->tile), P<uint32_t>(b->glast));
 		}
 		CHK(scan_exclusive_u32(c, P<uint32_t>(b->tile), P<uint32_t>(b->tile), n_gran, P<uint32_t>(b->tile) + n_gran)); // goff[n_gran] = all newlines
 		uint64_t n_nl = 0;
@@ -1177,7 +1190,7 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 		} else {
 			ProfScope ps(c, "k_paf_parse", (double)n + 69.0 * (double)L);
 			TileArgs ta;
-			ta.text = text; ta.n = n; ta.open = open_line; ta.K = tile_k; ta.n_gran = n_gran; ta.n_tiles = n_tiles; ta.L = L;
+			ta.text = text; ta.n = n_eff; ta.K = tile_k; ta.n_gran = n_gran; ta.n_tiles = n_tiles; ta.L = L;
 			ta.goff = (const uint32_t*)P<uint32_t>(b->tile); ta.first = (const unsigned long long*)P<unsigned long long>(b->tfirst);
 			ta.min_span = min_span; ta.min_match = min_match;
 			const int ch = tile_k <= 15 ? 1 : 2;

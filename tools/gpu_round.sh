@@ -117,6 +117,20 @@ parseprof)
   find gpurun_out/parseprof -name "*trace*.csv" -size +8M -delete ;;
 shardsort)
   timeout 900 python tools/shard_sort_probe.py 2>&1 | grep -E "^rank|Error|error" ;;
+texttiming)
+  # where a text -> GFA step spends its time: the ingest's and the pipeline's own laps (MA_PIPE_TIMING) around the from_text leg
+  MA_PIPE_TIMING=1 timeout 900 python bench.py --no-cpu --no-legs --steps 4 --warmup 1 --prof-steps 0 > gpurun_out/bench_texttiming.json 2> gpurun_out/bench_texttiming.log; echo "rc=$?"
+  grep -E "T::ingest_gpu|T::paf|T::head|T::tail|T::pipe" gpurun_out/bench_texttiming.log | tail -40
+  python3 -c "import json; d=json.load(open('gpurun_out/bench_texttiming.json')); print('   step %.3f ms, from_text %.2f ms/step' % (d['ms_per_step'], d['from_text']['ms_per_step']))" ;;
+sqtext)
+  # SQ counters (instruction mix, wait cycles) of the ingest kernels: three passes (8 counter slots)
+  i=0
+  for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE"; do
+    i=$((i+1)); rm -rf gpurun_out/sqt_$i; mkdir -p gpurun_out/sqt_$i
+    (cd /tmp && timeout 900 rocprofv3 --pmc $set --kernel-trace -d /root/repo/gpurun_out/sqt_$i -o r --output-format csv -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu --no-text --no-legs --prof-steps 0 > /root/repo/gpurun_out/sqt_$i/bench.json 2> /root/repo/gpurun_out/sqt_$i/bench.log); echo "sq set $i rc=$?"
+  done
+  python tools/pmc_generic.py gpurun_out/sqt_1 gpurun_out/sqt_2 gpurun_out/sqt_3 --filter "k_paf|k_dict_insert" > gpurun_out/sq_summary_text.txt 2>&1; head -90 gpurun_out/sq_summary_text.txt
+  find gpurun_out/sqt_1 gpurun_out/sqt_2 gpurun_out/sqt_3 -name "*.csv" -size +8M -delete ;;
 benchtext)
   timeout 900 python bench.py --no-cpu --no-legs --steps 6 --warmup 2 --prof-steps 0 > gpurun_out/bench_text.json 2> gpurun_out/bench_text.log; echo "rc=$?"
   python3 -c "import json; d=json.load(open('gpurun_out/bench_text.json')); print('   step %.3f ms, from_text %.2f ms/step, parse+dictionary %.3f s' % (d['ms_per_step'], d['from_text']['ms_per_step'], d['setup']['parse_dictionary_s']))" ;;
