@@ -312,19 +312,29 @@ __device__ __forceinline__ uint32_t masks16(const uint4 v)
 
 // granule g = bytes [1024 g, 1024 g + 1024), one wave: cnt[g] = its newlines, last[g] = offset of the byte behind its last newline (0: it has none).
 // (The text ends with a newline -- the host appends one to a text that does not -- and is followed by zeros up to the next 16 bytes.)
+#define PAF_GC_PER_WAVE 8u
 __global__ __launch_bounds__(256) void k_paf_gran_count(const unsigned char *__restrict__ text, size_t n, uint32_t n_gran, uint32_t *__restrict__ cnt, uint32_t *__restrict__ last)
-{
-	const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-	if (g >= n_gran) return; // the whole wave
-	const size_t off = (size_t)g * PAF_GRAN + lane * 16u;
-	uint32_t mx = 0, my = 0, mz = 0, mw = 0;
-	if (off < n) { const uint4 v = *(const uint4*)(text + off); mx = eq_mask(v.x, 0x0A0A0A0Au); my = eq_mask(v.y, 0x0A0A0A0Au); mz = eq_mask(v.z, 0x0A0A0A0Au); mw = eq_mask(v.w, 0x0A0A0A0Au); }
-	const uint32_t c = wv_sum_u32((uint32_t)(__popc(mx) + __popc(my) + __popc(mz) + __popc(mw)));
-	const unsigned long long has = __ballot((mx | my | mz | mw) != 0);
-	if (lane == 0) { cnt[g] = c; if (!has) last[g] = 0; }
-	if (has && (int)lane == 63 - __clzll((long long)has)) { // the lane with the granule's last newline: byte index of its highest flag + 1
-		const uint32_t w = mw ? 3u : mz ? 2u : my ? 1u : 0u, m = mw ? mw : mz ? mz : my ? my : mx;
-		last[g] = lane * 16u + w * 4u + ((31u - (uint32_t)__clz((int)m)) >> 3) + 1u;
+{ // a wave takes PAF_GC_PER_WAVE consecutive granules and has all their loads in flight at once (one granule per wave: 5.9 M waves of one load each, 1.4 ms for 6 GB)
+	const uint32_t g0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * PAF_GC_PER_WAVE, lane = threadIdx.x & 63;
+	if (g0 >= n_gran) return; // the whole wave
+	uint4 v[PAF_GC_PER_WAVE];
+#pragma unroll
+	for (uint32_t k = 0; k < PAF_GC_PER_WAVE; ++k) {
+		const size_t off = (size_t)(g0 + k) * PAF_GRAN + lane * 16u;
+		v[k] = off < n ? *(const uint4*)(text + off) : make_uint4(0, 0, 0, 0);
+	}
+#pragma unroll
+	for (uint32_t k = 0; k < PAF_GC_PER_WAVE; ++k) {
+		const uint32_t g = g0 + k;
+		if (g >= n_gran) break; // the whole wave
+		const uint32_t mx = eq_mask(v[k].x, 0x0A0A0A0Au), my = eq_mask(v[k].y, 0x0A0A0A0Au), mz = eq_mask(v[k].z, 0x0A0A0A0Au), mw = eq_mask(v[k].w, 0x0A0A0A0Au);
+		const uint32_t c = wv_sum_u32((uint32_t)(__popc(mx) + __popc(my) + __popc(mz) + __popc(mw)));
+		const unsigned long long has = __ballot((mx | my | mz | mw) != 0);
+		if (lane == 0) { cnt[g] = c; if (!has) last[g] = 0; }
+		if (has && (int)lane == 63 - __clzll((long long)has)) { // the lane with the granule's last newline: byte index of its highest flag + 1
+			const uint32_t w = mw ? 3u : mz ? 2u : my ? 1u : 0u, m = mw ? mw : mz ? mz : my ? my : mx;
+			last[g] = lane * 16u + w * 4u + ((31u - (uint32_t)__clz((int)m)) >> 3) + 1u;
+		}
 	}
 }
 // bmax[b] = byte behind the last newline of granules [4096 b, 4096 b + 4096) (0: none), one wave per group
@@ -431,25 +441,51 @@ __global__ __launch_bounds__(256) void k_paf_parse_tile(const TileArgs a, PafCol
 	const unsigned lane = threadIdx.x & 63;
 	uint32_t c_valid = 0, c_pass = 0, c_nobl = 0, c_long = 0, c_odd = 0;
 	uint64_t c_mq = 0;
-	for (uint32_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
+	// A block works through tiles blockIdx.x, + gridDim.x, ...; the pieces of the NEXT tile are on their way from HBM (in registers) while the lines of this one are
+	// parsed: the trip to memory is paid once per block, not once per tile.
+	constexpr int NP = 4 * CH; // 16-byte pieces per thread
+	struct Geom { uint32_t line0, tot, len; uint64_t first, lo; bool long_first; };
+	auto geom = [&](uint32_t t) {
+		Geom g;
 		const uint32_t g0 = t * a.K, g1 = g0 + a.K < a.n_gran ? g0 + a.K : a.n_gran;
-		const uint32_t line0 = a.goff[g0], tot = a.goff[g1] - line0; // the lines that end in this tile
-		if (tot == 0) continue; // the whole block
+		g.line0 = a.goff[g0]; g.tot = a.goff[g1] - g.line0; // the lines that end in this tile
 		const uint64_t tb0 = (uint64_t)g0 * PAF_GRAN, te0 = (uint64_t)g1 * PAF_GRAN;
-		const uint64_t first = a.first[t];
+		g.first = a.first[t];
 		uint64_t lo = tb0 > PAF_OVER ? tb0 - PAF_OVER : 0;
-		const bool long_first = first < lo; // the first line starts further in front than the block keeps: its bytes are not all here
-		if (!long_first) lo = first;
-		lo &= ~(uint64_t)63;
-		const uint32_t len = (uint32_t)(te0 - lo); // <= REG, a multiple of 64
-		for (uint32_t p = threadIdx.x; p * 16u < len; p += 256u) {
+		g.long_first = g.first < lo; // the first line starts further in front than the block keeps: its bytes are not all here
+		if (!g.long_first) lo = g.first;
+		g.lo = lo & ~(uint64_t)63;
+		g.len = g.tot ? (uint32_t)(te0 - g.lo) : 0u; // <= REG, a multiple of 64; a tile in which no line ends is not loaded at all
+		return g;
+	};
+	uint4 pv[NP];
+	auto fetch = [&](const Geom &g) {
+#pragma unroll
+		for (int q = 0; q < NP; ++q) {
+			const uint32_t p = threadIdx.x + 256u * (uint32_t)q;
+			const uint64_t off = g.lo + (uint64_t)p * 16u;
+			pv[q] = p * 16u < g.len && off < a.n ? *(const uint4*)(a.text + off) : make_uint4(0, 0, 0, 0);
+		}
+	};
+	uint32_t t = blockIdx.x;
+	Geom cur = {};
+	if (t < a.n_tiles) { cur = geom(t); fetch(cur); }
+	for (; t < a.n_tiles; t += gridDim.x) {
+		const uint32_t line0 = cur.line0, tot = cur.tot, len = cur.len;
+		const uint64_t first = cur.first, lo = cur.lo;
+		const bool long_first = cur.long_first;
+#pragma unroll
+		for (int q = 0; q < NP; ++q) {
+			const uint32_t p = threadIdx.x + 256u * (uint32_t)q;
+			if (p * 16u >= len) break;
 			const uint64_t off = lo + (uint64_t)p * 16u;
-			const uint4 v = off < a.n ? *(const uint4*)(a.text + off) : make_uint4(0, 0, 0, 0);
-			uint32_t m = masks16(v);
+			uint32_t m = masks16(pv[q]);
 			if (off < first) m &= off + 16 <= first ? 0u : (0xffffu << (uint32_t)(first - off) & 0xffffu) * 0x10001u; // bytes of lines that ended in front of this tile
-			*(uint4*)(s_text + p * 16u) = v;
+			*(uint4*)(s_text + p * 16u) = pv[q];
 			s_tb[p] = (uint16_t)m; s_nb[p] = (uint16_t)(m >> 16);
 		}
+		if (t + gridDim.x < a.n_tiles) { cur = geom(t + gridDim.x); fetch(cur); } // in flight until the next turn of the loop
+		if (tot == 0) continue; // the whole block (nothing was written, nothing is read)
 		for (uint32_t p = len / 16u + threadIdx.x; p < REG / 16u; p += 256u) s_nb[p] = 0; // (the ranking below reads the whole array)
 		__syncthreads();
 		// ---- ranks of the newlines: thread x looks after bytes [64 CH x, 64 CH (x + 1))
@@ -953,16 +989,26 @@ __global__ __launch_bounds__(256) void k_paf_emit_chain(PafCols o, const uint32_
 	const uint32_t tile = s_tile;
 	const size_t base = (size_t)tile * EM_TILE + (size_t)threadIdx.x * EM_ITEMS;
 	uint32_t fl[EM_ITEMS], qid[EM_ITEMS], tid[EM_ITEMS], cnt[EM_ITEMS], sum = 0;
+	uint32_t qs[EM_ITEMS], qe[EM_ITEMS], ts[EM_ITEMS], te[EM_ITEMS], ml[EM_ITEMS], bl[EM_ITEMS];
 	const bool full = base + EM_ITEMS <= L;
-	if (full) {
+	if (full) { // everything the tile reads in a row is asked for at once: the columns are on their way while the ids are looked up and the tiles in front are waited for
 		const uint32_t f4 = *(const uint32_t*)(o.flags + base);
 		const uint4 q4 = *(const uint4*)(o.qslot + base), t4 = *(const uint4*)(o.tslot + base);
+		const uint4 a = *(const uint4*)(o.qs + base), b = *(const uint4*)(o.qe + base), c = *(const uint4*)(o.ts + base), d = *(const uint4*)(o.te + base),
+		            e = *(const uint4*)(o.ml + base), f = *(const uint4*)(o.bl + base);
 		fl[0] = f4 & 0xffu; fl[1] = f4 >> 8 & 0xffu; fl[2] = f4 >> 16 & 0xffu; fl[3] = f4 >> 24;
 		qid[0] = q4.x; qid[1] = q4.y; qid[2] = q4.z; qid[3] = q4.w;
 		tid[0] = t4.x; tid[1] = t4.y; tid[2] = t4.z; tid[3] = t4.w;
+		qs[0] = a.x; qs[1] = a.y; qs[2] = a.z; qs[3] = a.w; qe[0] = b.x; qe[1] = b.y; qe[2] = b.z; qe[3] = b.w;
+		ts[0] = c.x; ts[1] = c.y; ts[2] = c.z; ts[3] = c.w; te[0] = d.x; te[1] = d.y; te[2] = d.z; te[3] = d.w;
+		ml[0] = e.x; ml[1] = e.y; ml[2] = e.z; ml[3] = e.w; bl[0] = f.x; bl[1] = f.y; bl[2] = f.z; bl[3] = f.w;
 	} else {
 #pragma unroll
-		for (unsigned k = 0; k < EM_ITEMS; ++k) { const bool in = base + k < L; fl[k] = in ? o.flags[base + k] : 0u; qid[k] = in ? o.qslot[base + k] : 0u; tid[k] = in ? o.tslot[base + k] : 0u; }
+		for (unsigned k = 0; k < EM_ITEMS; ++k) {
+			const bool in = base + k < L; const size_t j = in ? base + k : 0;
+			fl[k] = in ? o.flags[j] : 0u; qid[k] = o.qslot[j]; tid[k] = o.tslot[j];
+			qs[k] = o.qs[j]; qe[k] = o.qe[j]; ts[k] = o.ts[j]; te[k] = o.te[j]; ml[k] = o.ml[j]; bl[k] = o.bl[j];
+		}
 	}
 #pragma unroll
 	for (unsigned k = 0; k < EM_ITEMS; ++k) {
@@ -985,31 +1031,18 @@ __global__ __launch_bounds__(256) void k_paf_emit_chain(PafCols o, const uint32_
 	}
 	__syncthreads();
 	uint32_t p = s_prefix + ex;
-	if (sum) {
-		uint32_t qs[EM_ITEMS], qe[EM_ITEMS], ts[EM_ITEMS], te[EM_ITEMS], ml[EM_ITEMS], bl[EM_ITEMS];
-		if (full) {
-			const uint4 a = *(const uint4*)(o.qs + base), b = *(const uint4*)(o.qe + base), c = *(const uint4*)(o.ts + base), d = *(const uint4*)(o.te + base),
-			            e = *(const uint4*)(o.ml + base), f = *(const uint4*)(o.bl + base);
-			qs[0] = a.x; qs[1] = a.y; qs[2] = a.z; qs[3] = a.w; qe[0] = b.x; qe[1] = b.y; qe[2] = b.z; qe[3] = b.w;
-			ts[0] = c.x; ts[1] = c.y; ts[2] = c.z; ts[3] = c.w; te[0] = d.x; te[1] = d.y; te[2] = d.z; te[3] = d.w;
-			ml[0] = e.x; ml[1] = e.y; ml[2] = e.z; ml[3] = e.w; bl[0] = f.x; bl[1] = f.y; bl[2] = f.z; bl[3] = f.w;
-		} else {
 #pragma unroll
-			for (unsigned k = 0; k < EM_ITEMS; ++k) { const bool in = base + k < L; const size_t j = in ? base + k : 0; qs[k] = o.qs[j]; qe[k] = o.qe[j]; ts[k] = o.ts[j]; te[k] = o.te[j]; ml[k] = o.ml[j]; bl[k] = o.bl[j]; }
+	for (unsigned k = 0; k < EM_ITEMS; ++k) {
+		if (!cnt[k]) continue;
+		const uint32_t mlrev = ml[k] | (fl[k] >> 3 & 1u) << 31, b31 = bl[k] & 0x7fffffffu;
+		uint4 *r = rec + (size_t)p * 2;
+		r[0] = make_uint4(qs[k], qid[k], qe[k], tid[k]);   // qns = qid<<32 | qs ; qe ; tn
+		r[1] = make_uint4(ts[k], te[k], mlrev, b31);       // ts ; te ; ml|rev ; bl|del=0
+		if (cnt[k] == 2) {
+			r[2] = make_uint4(ts[k], tid[k], te[k], qid[k]);
+			r[3] = make_uint4(qs[k], qe[k], mlrev, b31);
 		}
-#pragma unroll
-		for (unsigned k = 0; k < EM_ITEMS; ++k) {
-			if (!cnt[k]) continue;
-			const uint32_t mlrev = ml[k] | (fl[k] >> 3 & 1u) << 31, b31 = bl[k] & 0x7fffffffu;
-			uint4 *r = rec + (size_t)p * 2;
-			r[0] = make_uint4(qs[k], qid[k], qe[k], tid[k]);   // qns = qid<<32 | qs ; qe ; tn
-			r[1] = make_uint4(ts[k], te[k], mlrev, b31);       // ts ; te ; ml|rev ; bl|del=0
-			if (cnt[k] == 2) {
-				r[2] = make_uint4(ts[k], tid[k], te[k], qid[k]);
-				r[3] = make_uint4(qs[k], qe[k], mlrev, b31);
-			}
-			p += cnt[k];
-		}
+		p += cnt[k];
 	}
 	if (base < L && base + EM_ITEMS >= L) *d_total = p; // the thread with the last line: its end is the total
 }
@@ -1135,7 +1168,7 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 		CHK(dev_reserve(c, b->tile, ((size_t)n_gran + 8) * 4)); CHK(dev_reserve(c, b->glast, ((size_t)n_gran + 8) * 4));
 		{
 			ProfScope ps(c, "k_paf_nl_count", (double)n);
-			hipLaunchKernelGGL(k_paf_gran_count, dim3((n_gran + 3) / 4), dim3(256), 0, c->st, text, n_eff, n_gran, P<uint32_t>(b->tile), P<uint32_t>(b->glast));
+			hipLaunchKernelGGL(k_paf_gran_count, dim3((n_gran + 4 * PAF_GC_PER_WAVE - 1) / (4 * PAF_GC_PER_WAVE)), dim3(256), 0, c->st, text, n_eff, n_gran, P<uint32_t>(b->tile), P<uint32_t>(b->glast));
 		}
 		CHK(scan_exclusive_u32(c, P<uint32_t>(b->tile), P<uint32_t>(b->tile), n_gran, P<uint32_t>(b->tile) + n_gran)); // goff[n_gran] = all newlines
 		uint64_t n_nl = 0;

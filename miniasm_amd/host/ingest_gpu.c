@@ -67,9 +67,13 @@ int ma_hit_ingest_loaded_excl(mahip_ctx_t *c, int min_span, int min_match, sdict
 	/* the dictionary: the names in one block (the dictionary's arena) and the sd_seq_t records the device wrote for that block -- two copies, no
 	 * per-name work on the host */
 	{
-		char *names = (char*)malloc(info.name_bytes ? info.name_bytes : 1);
-		sd_seq_t *seq = (sd_seq_t*)malloc(((size_t)info.n_seq + 1) * sizeof(sd_seq_t));
+		char *names = 0;
+		sd_seq_t *seq = 0;
 		uint64_t tl = 0;
+		if (!ma_sd_recycle(d, info.name_bytes, info.n_seq, &names, &seq)) { /* (the same dictionary filled again keeps its blocks) */
+			names = (char*)ma_big_alloc(info.name_bytes ? info.name_bytes : 1);
+			seq = (sd_seq_t*)ma_big_alloc(((size_t)info.n_seq + 1) * sizeof(sd_seq_t));
+		}
 		GPU(mahip_paf_seqs(c, names, seq, &tl));
 		ma_sd_adopt(d, names, info.name_bytes, info.n_seq, seq);
 		tot_len = (size_t)tl;

@@ -46,7 +46,9 @@ ma_ug_t *ma_ug_from_device(mahip_ctx_t *c); /* unitigs of the graph resident in 
 void ma_sd_reindex(sdict_t *d);    /* build the name index from seq[] (for dictionaries assembled by hand) */
 void ma_sd_drop_index(sdict_t *d);
 void ma_sd_fill(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, const uint32_t *lens); /* bulk fill; the dictionary owns arena */
-void ma_sd_adopt(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, sd_seq_t *seq);         /* records ready-made; the dictionary owns both blocks */
+void ma_sd_adopt(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, sd_seq_t *seq);
+int ma_sd_recycle(sdict_t *d, size_t arena_len, uint32_t n_seq, char **arena, sd_seq_t **seq); /* the dictionary's own blocks, if they can hold the next fill */
+void *ma_big_alloc(size_t n); /* 2 MiB-aligned, huge pages advised; free() releases it */         /* records ready-made; the dictionary owns both blocks */
 
 /* the process-wide GPU context of the per-symbol entry points; exits with an error if no GPU is usable */
 mahip_ctx_t *ma_gpu(void);

@@ -8,6 +8,7 @@
  */
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include "miniasm_amd.h"
 #include "ma_host.h"
 
@@ -16,7 +17,7 @@ typedef struct {
 	uint32_t *id;            /* id+1, 0 = empty */
 	uint32_t *hv;            /* cached hash */
 	char *arena;             /* names of a bulk fill live in ONE block (device-side ingest): freed as a whole */
-	size_t arena_len;
+	size_t arena_len, arena_cap; /* bytes in use / bytes the block has (0: arena_len) */
 } sd_index_t;
 
 static inline int in_arena(const sd_index_t *ix, const char *p) { return ix && ix->arena && p >= ix->arena && p < ix->arena + ix->arena_len; }
@@ -128,7 +129,7 @@ void ma_sd_fill(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, const
 		if (!in_arena(ix, d->seq[i].name)) free(d->seq[i].name);
 	if (ix == 0) { ix = (sd_index_t*)calloc(1, sizeof(sd_index_t)); d->h = ix; }
 	free(ix->arena);
-	ix->arena = arena; ix->arena_len = arena_len;
+	ix->arena = arena; ix->arena_len = arena_len; ix->arena_cap = arena_len;
 	ix_table(ix, 0);
 	d->n_seq = d->m_seq = n_seq;
 	d->seq = (sd_seq_t*)realloc(d->seq, ((size_t)n_seq + 1) * sizeof(sd_seq_t));
@@ -139,20 +140,52 @@ void ma_sd_fill(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, const
 	}
 }
 
+/* a big block the host is about to fill once: 2 MiB-aligned and advised to use huge pages, so that writing it for the first time costs a page fault per 2 MiB,
+ * not per 4 KiB (the 50 MB of a 2 M-read dictionary: 12 000 faults, most of the 9 ms the download took in round 5); release with free() */
+void *ma_big_alloc(size_t n)
+{
+	void *p = 0;
+	if (n >= ((size_t)4 << 20)) {
+		const size_t b = (n + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+		if (posix_memalign(&p, (size_t)2 << 20, b) == 0) { (void)madvise(p, b, MADV_HUGEPAGE); return p; }
+	}
+	return malloc(n ? n : 1);
+}
+
+/* A dictionary that is filled again from the device (the same sdict_t for the next input) keeps its two blocks when they are big enough: nothing is freed,
+ * nothing is mapped, no page is touched for the first time.  Returns 1 and the blocks to fill (then call ma_sd_adopt with exactly these); 0: allocate. */
+int ma_sd_recycle(sdict_t *d, size_t arena_len, uint32_t n_seq, char **arena, sd_seq_t **seq)
+{
+	sd_index_t *ix = (sd_index_t*)d->h;
+	uint32_t i;
+	if (ix == 0 || ix->arena == 0 || d->seq == 0) return 0;
+	if ((ix->arena_cap ? ix->arena_cap : ix->arena_len) < arena_len || d->m_seq < n_seq) return 0;
+	for (i = 0; i < d->n_seq; ++i) /* names that came by sd_put since the last fill */
+		if (!in_arena(ix, d->seq[i].name)) free(d->seq[i].name);
+	d->n_seq = 0;
+	*arena = ix->arena; *seq = d->seq;
+	return 1;
+}
+
 /* the same with the records ready-made (csrc/paf.hip: k_dict_seqs wrote them for this arena): the dictionary takes both blocks over */
 void ma_sd_adopt(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, sd_seq_t *seq)
 {
 	uint32_t i;
 	sd_index_t *ix = (sd_index_t*)d->h;
-	for (i = 0; i < d->n_seq; ++i)
-		if (!in_arena(ix, d->seq[i].name)) free(d->seq[i].name);
+	const int same = ix && ix->arena == arena && d->seq == seq; /* its own blocks, filled again (ma_sd_recycle): the old records are gone already */
+	if (!same)
+		for (i = 0; i < d->n_seq; ++i)
+			if (!in_arena(ix, d->seq[i].name)) free(d->seq[i].name);
 	if (ix == 0) { ix = (sd_index_t*)calloc(1, sizeof(sd_index_t)); d->h = ix; }
-	free(ix->arena);
-	ix->arena = arena; ix->arena_len = arena_len;
+	if (!same) {
+		free(ix->arena);
+		ix->arena = arena; ix->arena_cap = arena_len;
+		free(d->seq);
+		d->seq = seq; d->m_seq = n_seq;
+	}
+	ix->arena_len = arena_len;
 	ix_table(ix, 0);
-	free(d->seq);
-	d->seq = seq;
-	d->n_seq = d->m_seq = n_seq;
+	d->n_seq = n_seq;
 }
 
 int32_t sd_get(const sdict_t *d, const char *name)
