@@ -110,6 +110,9 @@ def lib():
         L.mahip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
         L.mahip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
         L.mahip_paf_release.argtypes = [vp]
+        L.mahip_hits_sorted_runs.restype = C.c_uint64
+        L.mahip_hits_sorted_runs.argtypes = [vp]
+        L.mahip_first_launch.argtypes = [vp]
         L.mahip_paf_load_fd.argtypes = [vp, i32, sz]
         L.mahip_paf_load_mem.argtypes = [vp, vp, sz]
         L.mahip_hits_raw_download.argtypes = [vp, vp]
@@ -214,6 +217,10 @@ class Ctx:
 
     def sort(self):
         _chk(lib().mahip_hits_sort(self.h), "hits_sort")
+
+    def sorted_runs(self):
+        """elements of the last sort if it sorted RUNS of records (hits.hip), else 0: lets a test say which path it took"""
+        return int(lib().mahip_hits_sorted_runs(self.h))
 
     def index(self):
         _chk(lib().mahip_hits_index(self.h), "hits_index")

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_key_compact(const uint64_t *__restrict_
 #define RUN_MIN_LEN_BITS 10 // a run has at most RUN_SLAB records
 template <int STRIDE>
 __global__ __launch_bounds__(256) void k_hit_keys_runs(const ma_hit_t *__restrict__ h, size_t n, uint64_t *__restrict__ key, int bi, int bl, unsigned long long *__restrict__ d_total,
-                                                        unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
+                                                        unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch, uint32_t n_seq, unsigned long long *__restrict__ d_bad)
 {
 	__shared__ uint32_t s_wave[4];
 	__shared__ uint32_t s_tile, s_prefix;
@@ -117,6 +117,12 @@ __global__ __launch_bounds__(256) void k_hit_keys_runs(const ma_hit_t *__restric
 	unsigned long long hm[16];
 #pragma unroll
 	for (int it = 0; it < 16; ++it) { const uint32_t p = (uint32_t)it * 64u + lane; q[it] = p < nvalid ? (uint32_t)(h[wbase + p].qns >> 32) : 0u; }
+	{ // an id outside the dictionary (a caller's contract violation) would lose its high bits in the packed key and look like another read's: say so, the caller sorts records then
+		uint32_t qmax = 0;
+#pragma unroll
+		for (int it = 0; it < 16; ++it) qmax = q[it] > qmax ? q[it] : qmax;
+		if (wv_ballot(qmax >= n_seq) && lane == 0) atomicAdd(d_bad, 1ull);
+	}
 	uint32_t cnt = 0, pre[16]; // pre[it]: heads of the wave in front of round it
 #pragma unroll
 	for (int it = 0; it < 16; ++it) {
@@ -346,7 +352,20 @@ static unsigned sub_blocks() { static unsigned v = 0; if (!v) { const char *e = 
 // ~ 120 reads) and fill every slot they are given, so classes queued behind it start when its blocks retire -- a tail (rocprofv3: all three kernels span the same 5 ms although
 // the larger classes own a quarter of the hits).  MA_SUB_ORDER: "012" = first tier first (until round 5), "210" = the larger classes first.  MA_SUB_BIG_GRID: blocks of the two
 // larger classes (0: as many as the first tier's).
-static const int *sub_order() { static int o[3] = {-1, 0, 0}; if (o[0] < 0) { const char *e = getenv("MA_SUB_ORDER"); const char *d = (e && strlen(e) == 3) ? e : MA_SUB_ORDER_DEFAULT; int seen = 0; for (int k = 0; k < 3; ++k) { o[k] = d[k] - '0'; if (o[k] < 0 || o[k] > 2) o[k] = k; seen |= 1 << o[k]; } if (seen != 7) { o[0] = 0; o[1] = 1; o[2] = 2; } } return o; }
+struct SubOrder { int o[3]; };
+static const int *sub_order()
+{ // (a function-local static with an initialiser: built once, by one thread -- several host threads drive contexts of their own)
+	static const SubOrder so = [] {
+		SubOrder r;
+		const char *e = getenv("MA_SUB_ORDER");
+		const char *d = (e && strlen(e) == 3) ? e : MA_SUB_ORDER_DEFAULT;
+		int seen = 0;
+		for (int k = 0; k < 3; ++k) { r.o[k] = d[k] - '0'; if (r.o[k] < 0 || r.o[k] > 2) r.o[k] = k; seen |= 1 << r.o[k]; }
+		if (seen != 7) { r.o[0] = 0; r.o[1] = 1; r.o[2] = 2; }
+		return r;
+	}();
+	return so.o;
+}
 static unsigned sub_big_grid(unsigned g0) { static long v = -1; if (v < 0) { const char *e = getenv("MA_SUB_BIG_GRID"); v = e ? atol(e) : 0; } return v > 0 && (unsigned)v < g0 ? (unsigned)v : g0; }
 // reads per bounds fetch in the larger tiers: up to SUB_CHUNK, fewer when there are not enough reads to give every wave of the grid a chunk
 static uint32_t sub_chunk(uint32_t R) { uint64_t waves = 4ull * grid_for(R, 4, MA_SUB_BLOCKS), k = waves ? R / waves : 1; return (uint32_t)(k < 1 ? 1 : k > 16 ? 16 : k); }
@@ -910,7 +929,7 @@ __global__ __launch_bounds__(256) void k_hit_cut_contained(HitCols c, size_t n, 
 			q[u] = c.qid[ic]; t[u] = c.tn[ic]; ml[u] = c.ml[ic]; qs[u] = c.qs[ic]; qe[u] = c.qe[ic]; ts[u] = c.ts[ic]; te[u] = c.te[ic];
 		}
 #pragma unroll
-		for (int u = 0; u < CC_UNROLL; ++u) { pq[u] = sub2[q[u]]; pt[u] = sub2[t[u]]; }
+		for (int u = 0; u < CC_UNROLL; ++u) { const bool dead = (bl[u] & DEAD) != 0; pq[u] = sub2[dead ? 0u : q[u]]; pt[u] = sub2[dead ? 0u : t[u]]; } // (a dead slot's entries are not used: entry 0, whatever its columns hold)
 #pragma unroll
 		for (int u = 0; u < CC_UNROLL; ++u) {
 			const size_t i = base + (size_t)u * 256 + threadIdx.x;
@@ -1515,12 +1534,12 @@ extern "C" int mahip_hits_sort(mahip_ctx_t *c)
 		CHK(scan_chain_begin(c, nb1, &state, &ticket, &ticket_base, &epoch));
 		{
 			ProfScope ps(c, "k_hit_keys", 16.0 * (double)n);
-			if (c->run_stride == 2) hipLaunchKernelGGL(k_hit_keys_runs<2>, dim3((unsigned)nb1), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), bi, bl, ctr + CT_TOTAL, state, ticket, ticket_base, epoch);
-			else hipLaunchKernelGGL(k_hit_keys_runs<1>, dim3((unsigned)nb1), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), bi, bl, ctr + CT_TOTAL, state, ticket, ticket_base, epoch);
+			if (c->run_stride == 2) hipLaunchKernelGGL(k_hit_keys_runs<2>, dim3((unsigned)nb1), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), bi, bl, ctr + CT_TOTAL, state, ticket, ticket_base, epoch, c->n_seq, ctr + CT_OVF);
+			else hipLaunchKernelGGL(k_hit_keys_runs<1>, dim3((unsigned)nb1), dim3(256), 0, c->st, c->d_aos, n, P<uint64_t>(c->key[0]), bi, bl, ctr + CT_TOTAL, state, ticket, ticket_base, epoch, c->n_seq, ctr + CT_OVF);
 		}
 		CHK(ctr_fetch(c));
 		const size_t n_runs = (size_t)c->h_ctr[CT_TOTAL];
-		if (n_runs && n_runs * 4 <= n * 3) { // worth it (else: the keys of all records below, as if nothing had happened)
+		if (n_runs && n_runs * 4 <= n * 3 && c->h_ctr[CT_OVF] == 0) { // worth it (else: the keys of all records below, as if nothing had happened)
 			int g2 = 0;
 			CHK(radix_sort_keys(c, n_runs, bi + bl, bi + bl + bq, &g2, false));
 			CHK(radix_group_starts_begin(c, P<uint32_t>(c->goff), c->n_seq, (uint32_t)n));

@@ -87,6 +87,37 @@ def test_sort_random_keys_and_ties(gpu_ctx):
             assert got.tobytes() == exp.tobytes(), "reference tie order differs for n=%d" % n
 
 
+def test_runs_sort_takes_no_ids_from_outside_the_dictionary(gpu_ctx):
+    """the sort on RUNS of records packs query id | position | length into one word: an id >= n_seq (a caller's contract violation) would lose its high bits there and
+    pass for another read's.  k_hit_keys_runs sees it and the sort falls back to records, where the id is reported or carried in full; and the helper says
+    which path a sort took"""
+    rng = np.random.default_rng(12)
+    n, nq = 40000, 3000
+    q = np.repeat(rng.permutation(nq)[: n // 40], 40).astype(np.uint64)  # runs of 40 records: the runs path is worth it
+    h = np.zeros(n, dtype=ma.HIT_DT)
+    h["qns"] = (q << 32) | rng.integers(0, 5000, n).astype(np.uint64)
+    h["qe"] = np.arange(n)
+    h["tn"] = rng.integers(0, nq, n)
+    gpu_ctx.set_exact_ties(0)
+    gpu_ctx.hits_upload(h, nq)
+    gpu_ctx.set_run_stride(1)
+    gpu_ctx.sort()
+    assert gpu_ctx.sorted_runs() > 0, "runs of 40 records under stride 1: the runs path was expected"
+    exp = h.copy()
+    R.orc().orc_hit_sort(n, exp.ctypes.data)
+    assert gpu_ctx.hits_download().tobytes() == exp.tobytes()
+    bad = h.copy()
+    bad["qns"][1234] = (np.uint64(nq + 4096 + 7) << np.uint64(32)) | np.uint64(5)  # 12 id bits: 7191 would read as 3095 & 4095
+    gpu_ctx.hits_upload(bad, nq)
+    gpu_ctx.set_run_stride(1)
+    try:
+        gpu_ctx.sort()
+    except Exception:
+        pass  # the record path may refuse such an input outright
+    assert gpu_ctx.sorted_runs() == 0, "an id outside the dictionary went through the runs path"
+    gpu_ctx.set_exact_ties(2)
+
+
 def test_sort_with_keys_wider_than_64_bits(gpu_ctx):
     """query id, query start and input position together need 65..67 bits: the packed key drops the low position bits and the gather
     picks the record among the 2^drop neighbours (rank inside the run of equal keys); beyond that the (key, value) pair sort takes over"""
