@@ -43,6 +43,7 @@ int ma_pipeline_run_sharded(const ma_opt_t *opt, const char *fn, const char *out
 /* one rank's part of it, for a context that already has a communicator of any kind (collective; rank 0 writes `out`) */
 int ma_pipeline_run_rank(mahip_ctx_t *c, const ma_opt_t *opt, const char *fn, const char *outfmt, int stage, int flags, FILE *out, int share_gpu);
 ma_ug_t *ma_ug_from_device(mahip_ctx_t *c); /* unitigs of the graph resident in c (unitig_gfa.c over csrc/ug.hip) */
+void ma_ug_print_mem(const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, char **buf, size_t *len); /* ma_ug_print's text in one malloc'ed block */
 void ma_sd_reindex(sdict_t *d);    /* build the name index from seq[] (for dictionaries assembled by hand) */
 void ma_sd_drop_index(sdict_t *d);
 void ma_sd_fill(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, const uint32_t *lens); /* bulk fill; the dictionary owns arena */

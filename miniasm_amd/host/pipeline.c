@@ -262,6 +262,15 @@ struct ma_tail_job {
 	double t_fetch[5];
 };
 
+typedef struct { sd_seq_t *dst; const sd_seq_t *src; const uint32_t *old; uint32_t lo, hi; } view_job_t;
+static void *view_worker(void *arg)
+{
+	view_job_t *v = (view_job_t*)arg;
+	uint32_t k;
+	for (k = v->lo; k < v->hi; ++k) v->dst[k] = v->src[v->old[k]], v->dst[k].del = 0, v->dst[k].aux = 0;
+	return 0;
+}
+
 ma_tail_job_t *ma_pipeline_tail_fetch(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, const uint32_t st[4])
 {
 	ma_tail_job_t *j = (ma_tail_job_t*)calloc(1, sizeof(ma_tail_job_t));
@@ -274,13 +283,25 @@ ma_tail_job_t *ma_pipeline_tail_fetch(mahip_ctx_t *c, const ma_opt_t *opt, const
 	if (j->squeezed) { /* O(survivors): the device hands over the list of surviving old ids */
 		uint32_t k, n_new = mahip_n_seq_new(c), *old = (uint32_t*)malloc((n_new ? n_new : 1) * 4);
 		GPU(mahip_survivors_download(c, old));
-		j->view.seq = (sd_seq_t*)malloc((n_new ? n_new : 1) * sizeof(sd_seq_t));
-		for (k = 0; k < n_new; ++k) j->view.seq[k] = d->seq[old[k]], j->view.seq[k].del = 0, j->view.seq[k].aux = 0;
+		j->view.seq = (sd_seq_t*)ma_big_alloc(((size_t)n_new + 1) * sizeof(sd_seq_t));
+		if (n_new < 200000) {
+			for (k = 0; k < n_new; ++k) j->view.seq[k] = d->seq[old[k]], j->view.seq[k].del = 0, j->view.seq[k].aux = 0;
+		} else { /* millions of survivors (a graph-heavy input keeps every read): the records are picked by a few threads, each touching its own part of the fresh block */
+			view_job_t vj[8];
+			pthread_t th[8];
+			int t, T = ma_ingest_threads(), ok[8];
+			if (T > 8) T = 8;
+			if (T < 1) T = 1;
+			for (t = 0; t < T; ++t) { vj[t].dst = j->view.seq; vj[t].src = d->seq; vj[t].old = old; vj[t].lo = (uint32_t)((uint64_t)n_new * (uint64_t)t / (uint64_t)T); vj[t].hi = (uint32_t)((uint64_t)n_new * (uint64_t)(t + 1) / (uint64_t)T); }
+			for (t = 1; t < T; ++t) { ok[t] = pthread_create(&th[t], 0, view_worker, &vj[t]) == 0; if (!ok[t]) view_worker(&vj[t]); }
+			view_worker(&vj[0]);
+			for (t = 1; t < T; ++t) if (ok[t]) pthread_join(th[t], 0);
+		}
 		j->view.n_seq = n_new;
 		free(old);
 	}
 	if (j->have_sub) {
-		j->sub = (ma_sub_t*)calloc(j->view.n_seq ? j->view.n_seq : 1, sizeof(ma_sub_t));
+		j->sub = (ma_sub_t*)ma_big_alloc(((size_t)j->view.n_seq + 1) * sizeof(ma_sub_t)); /* (written in full by the download) */
 		GPU(mahip_sub_download(c, 0, j->sub, j->squeezed));
 	}
 	j->t_fetch[1] = sys_realtime();
@@ -307,7 +328,9 @@ ma_tail_job_t *ma_pipeline_tail_fetch(mahip_ctx_t *c, const ma_opt_t *opt, const
 	return j;
 }
 
-int ma_pipeline_tail_finish(ma_tail_job_t *j, FILE *out)
+/* out != 0: the text goes to the stream; out == 0: into one malloc'ed block (*buf, *len) -- the unitig GFA, tens of MB on a graph-heavy input, is put together by
+ * the formatter's own threads (ma_ug_print_mem), everything else through a memory stream */
+static int tail_finish_to(ma_tail_job_t *j, FILE *out, char **buf, size_t *len)
 {
 	const sdict_t *d = j->d;
 	const char *outfmt = j->outfmt;
@@ -316,6 +339,8 @@ int ma_pipeline_tail_finish(ma_tail_job_t *j, FILE *out)
 	ma_sub_t *sub = j->sub;
 	const int timing = getenv("MA_PIPE_TIMING") != 0;
 	double t0 = sys_realtime();
+	FILE *ms = 0;
+	if (out == 0 && !(j->ug && strcmp(outfmt, "bed") != 0 && strcmp(outfmt, "paf") != 0)) { ms = open_memstream(buf, len); if (ms == 0) return -1; out = ms; }
 	if (strcmp(outfmt, "bed") == 0) {
 		if (sub) print_subs(view, sub, out);
 	} else if (strcmp(outfmt, "paf") == 0) {
@@ -326,8 +351,10 @@ int ma_pipeline_tail_finish(ma_tail_job_t *j, FILE *out)
 			ma_ug_seq(j->ug, squeezed ? view : d, sub, g_reads_fn);
 			if (squeezed) ma_sd_drop_index(view);
 		}
-		ma_ug_print(j->ug, view, sub, out);
+		if (out) ma_ug_print(j->ug, view, sub, out);
+		else ma_ug_print_mem(j->ug, view, sub, buf, len);
 	} else if (j->sg) ma_sg_print(j->sg, view, sub, out);
+	if (ms) fclose(ms);
 	if (timing) fprintf(stderr, "[T::tail] text %.3f ms\n", (sys_realtime() - t0) * 1e3);
 	ma_ug_destroy(j->ug);
 	asg_destroy(j->sg);
@@ -338,20 +365,14 @@ int ma_pipeline_tail_finish(ma_tail_job_t *j, FILE *out)
 	return 0;
 }
 
+int ma_pipeline_tail_finish(ma_tail_job_t *j, FILE *out) { return tail_finish_to(j, out, 0, 0); }
+
 int ma_pipeline_tail(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, const uint32_t st[4], FILE *out)
 {
 	return ma_pipeline_tail_finish(ma_pipeline_tail_fetch(c, opt, d, outfmt, stage, st), out);
 }
 
-int ma_pipeline_tail_finish_mem(ma_tail_job_t *j, char **buf, size_t *len)
-{
-	FILE *fp = open_memstream(buf, len);
-	int rc;
-	if (fp == 0) return -1;
-	rc = ma_pipeline_tail_finish(j, fp);
-	fclose(fp);
-	return rc;
-}
+int ma_pipeline_tail_finish_mem(ma_tail_job_t *j, char **buf, size_t *len) { return tail_finish_to(j, 0, buf, len); }
 
 int ma_pipeline_device(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, FILE *out)
 {
@@ -368,22 +389,19 @@ int ma_pipeline_device(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, co
 /* same, with the output text returned in a malloc'ed buffer (bench.py / tests) */
 int ma_pipeline_device_mem(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, int flags, char **buf, size_t *len)
 {
-	FILE *fp = open_memstream(buf, len);
+	uint32_t st[4];
 	int rc;
-	if (fp == 0) return -1;
-	rc = ma_pipeline_device(c, opt, d, outfmt, stage, flags, fp);
-	fclose(fp);
+	double t0 = sys_realtime(), t1;
+	ma_pipeline_head(c, opt, d, outfmt, stage, flags, st);
+	t1 = sys_realtime();
+	rc = tail_finish_to(ma_pipeline_tail_fetch(c, opt, d, outfmt, stage, st), 0, buf, len);
+	if (getenv("MA_PIPE_TIMING")) fprintf(stderr, "[T::pipeline] head %.3f ms  tail %.3f ms\n", (t1 - t0) * 1e3, (sys_realtime() - t1) * 1e3);
 	return rc;
 }
 
 int ma_pipeline_tail_mem(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, const char *outfmt, int stage, const uint32_t st[4], char **buf, size_t *len)
 {
-	FILE *fp = open_memstream(buf, len);
-	int rc;
-	if (fp == 0) return -1;
-	rc = ma_pipeline_tail(c, opt, d, outfmt, stage, st, fp);
-	fclose(fp);
-	return rc;
+	return tail_finish_to(ma_pipeline_tail_fetch(c, opt, d, outfmt, stage, st), 0, buf, len);
 }
 
 static void *gpu_warmup(void *arg) { (void)arg; (void)ma_gpu(); return 0; }

@@ -221,7 +221,23 @@ static void *fmt_worker(void *arg)
 
 #define FMT_MAX_THREADS 16
 #define FMT_SEG_READS 2048u
-void ma_ug_print(const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, FILE *fp) /* asm.c:77-116 */
+typedef struct { fmt_job_t *job; int T, t; char *dst; } fmt_copy_t;
+static void *fmt_copy_worker(void *arg) /* thread t copies ITS three pieces to their places: the pages of a fresh block are first touched by sixteen threads, not one */
+{
+	fmt_copy_t *q = (fmt_copy_t*)arg;
+	size_t off_u = 0, off_l = 0, off_s = 0;
+	int t;
+	for (t = 0; t < q->T; ++t) off_l += q->job[t].units.n;
+	off_s = off_l;
+	for (t = 0; t < q->T; ++t) off_s += q->job[t].links.n;
+	for (t = 0; t < q->t; ++t) { off_u += q->job[t].units.n; off_l += q->job[t].links.n; off_s += q->job[t].summary.n; }
+	memcpy(q->dst + off_u, q->job[q->t].units.s, q->job[q->t].units.n);
+	memcpy(q->dst + off_l, q->job[q->t].links.s, q->job[q->t].links.n);
+	memcpy(q->dst + off_s, q->job[q->t].summary.s, q->job[q->t].summary.n);
+	return 0;
+}
+/* asm.c:77-116: the text goes to fp, or (fp == 0) into one malloc'ed block *buf of *len bytes */
+static void ug_print_to(const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, FILE *fp, char **buf, size_t *len)
 {
 	const uint32_t nu = (uint32_t)ug->u.n, nl = ug->g->n_arc;
 	uint64_t tot = 0, acc = 0;
@@ -277,12 +293,34 @@ void ma_ug_print(const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, FILE 
 	fmt_worker(&job[0]);
 	for (t = 1; t < T; ++t) if (started[t]) pthread_join(th[t], 0);
 	t_fmt = timing ? sys_realtime() : 0;
-	for (t = 0; t < T; ++t) { job[t].units.fp = fp; ob_flush(&job[t].units); }
-	for (t = 0; t < T; ++t) { job[t].links.fp = fp; ob_flush(&job[t].links); }
-	for (t = 0; t < T; ++t) { job[t].summary.fp = fp; ob_flush(&job[t].summary); }
+	if (fp) {
+		for (t = 0; t < T; ++t) { job[t].units.fp = fp; ob_flush(&job[t].units); }
+		for (t = 0; t < T; ++t) { job[t].links.fp = fp; ob_flush(&job[t].links); }
+		for (t = 0; t < T; ++t) { job[t].summary.fp = fp; ob_flush(&job[t].summary); }
+	} else { /* one block, every thread copies what it formatted */
+		fmt_copy_t cp[FMT_MAX_THREADS];
+		size_t total = 0;
+		char *dst;
+		for (t = 0; t < T; ++t) total += job[t].units.n + job[t].links.n + job[t].summary.n;
+		dst = (char*)ma_big_alloc(total + 1);
+		for (t = 0; t < T; ++t) { cp[t].job = job; cp[t].T = T; cp[t].t = t; cp[t].dst = dst; }
+		for (t = 1; t < T; ++t) {
+			started[t] = pthread_create(&th[t], 0, fmt_copy_worker, &cp[t]) == 0;
+			if (!started[t]) fmt_copy_worker(&cp[t]);
+		}
+		fmt_copy_worker(&cp[0]);
+		for (t = 1; t < T; ++t) if (started[t]) pthread_join(th[t], 0);
+		for (t = 0; t < T; ++t) { free(job[t].units.s); free(job[t].links.s); free(job[t].summary.s); }
+		dst[total] = 0;
+		*buf = dst; *len = total;
+	}
 	free(seg);
-	if (timing) fprintf(stderr, "[T::ug_print] %d threads: format %.3f ms, write %.3f ms\n", T, (t_fmt - t_begin) * 1e3, (sys_realtime() - t_fmt) * 1e3);
+	if (timing) fprintf(stderr, "[T::ug_print] %d threads: format %.3f ms, %s %.3f ms\n", T, (t_fmt - t_begin) * 1e3, fp ? "write" : "copy into one block", (sys_realtime() - t_fmt) * 1e3);
 }
+
+void ma_ug_print(const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, FILE *fp) { ug_print_to(ug, d, sub, fp, 0, 0); }
+/* the same text in one malloc'ed block (free() it): what a caller that wants the GFA in memory gets without a stream in between */
+void ma_ug_print_mem(const ma_ug_t *ug, const sdict_t *d, const ma_sub_t *sub, char **buf, size_t *len) { ug_print_to(ug, d, sub, 0, buf, len); }
 
 /* ---------------------------------------------------------------------------------------------- unitig sequences
  * reference asm.c:216-290 (ma_ug_seq): every read placed on a unitig contributes the first `len` bases of its kept

@@ -131,6 +131,11 @@ sqtext)
   done
   python tools/pmc_generic.py gpurun_out/sqt_1 gpurun_out/sqt_2 gpurun_out/sqt_3 --filter "k_paf|k_dict_insert" > gpurun_out/sq_summary_text.txt 2>&1; head -90 gpurun_out/sq_summary_text.txt
   find gpurun_out/sqt_1 gpurun_out/sqt_2 gpurun_out/sqt_3 -name "*.csv" -size +8M -delete ;;
+ghtiming)
+  # the graph-heavy input (200 M arcs, every read survives, 87 MB of GFA): where a pass spends its time outside the kernels (MA_PIPE_TIMING laps of the tail)
+  MA_PIPE_TIMING=1 timeout 900 python bench.py --reads 2000000 --lines 100000000 --seed 4 --model fixed --no-cpu --no-legs --no-text --steps 6 --warmup 2 --prof-steps 0 > gpurun_out/bench_ghtiming.json 2> gpurun_out/bench_ghtiming.log; echo "rc=$?"
+  grep -E "T::tail|T::pipe|T::ug" gpurun_out/bench_ghtiming.log | tail -24
+  python3 -c "import json; d=json.load(open('gpurun_out/bench_ghtiming.json')); print('   step %.3f ms' % d['ms_per_step'], d.get('latency'))" ;;
 benchtext)
   timeout 900 python bench.py --no-cpu --no-legs --steps 6 --warmup 2 --prof-steps 0 > gpurun_out/bench_text.json 2> gpurun_out/bench_text.log; echo "rc=$?"
   python3 -c "import json; d=json.load(open('gpurun_out/bench_text.json')); print('   step %.3f ms, from_text %.2f ms/step, parse+dictionary %.3f s' % (d['ms_per_step'], d['from_text']['ms_per_step'], d['setup']['parse_dictionary_s']))" ;;
