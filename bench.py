@@ -471,7 +471,7 @@ def main():
             self.W = W
             self.hctx = hctx or ctx  # the context the hit passes run on
             self.out = {"n": 0, "rc": 0, "buf": None}
-            self.head_wall, self.tail_wall, self.last_stats = [], [], None  # sharded mode: wall time of each head on this rank / of each tail on rank 0
+            self.head_wall, self.tail_wall, self.fetch_wall, self.last_stats = [], [], [], None  # wall time of each head on this rank / of each tail (rank 0)
             self.q = queue.Queue(maxsize=1)  # one batch may wait while another is being finished
             self.worker = None
             # --tail-ctx: the device tail of a batch (graph cleaning, unitigs, downloads -- many small launches and counter fetches) moves to a
@@ -525,7 +525,9 @@ def main():
                 ma._chk(L.mahip_hits_set_positions(self.hctx.h, C.c_void_p(W.pos_dev.data_ptr()), 1, W.n_all), "set_positions")
             st = (C.c_uint32 * 4)(0, 0, 0, 0)
             if world == 1:  # single GPU: the C pipeline's device half
+                t_h = time.perf_counter()
                 assert L.ma_pipeline_head(self.hctx.h, C.byref(opt), W.d, b"ug", 100, 0, C.byref(st)) == 0
+                self.head_wall.append(time.perf_counter() - t_h)
             else:  # sharded: device passes + RCCL exchanges on every rank (host/sharded.c), graph cleaning + unitigs + GFA on rank 0
                 stats = ShardStats()
                 t_h = time.perf_counter()
@@ -540,12 +542,27 @@ def main():
                 ma._chk(L.mahip_tail_handoff(self.hctx.h, self.ctx2.h), "tail_handoff")
                 self.q.put((st,))
                 return
+            t_f = time.perf_counter()
             job = L.ma_pipeline_tail_fetch(self.hctx.h, C.byref(opt), W.d, b"ug", 100, C.byref(st))
             assert job
+            self.fetch_wall.append(time.perf_counter() - t_f)
             if self.worker:
                 self.q.put(job)
             else:
                 self._finish(job)
+
+        def phases(self):
+            """where a pass of this runner spends its time, host-side wall clocks (means over the steps so far; the tail's laps are those of the LAST pass, from the C
+            pipeline's own stamps): the head is the device half on the first context, the tail's device part (cleaners, unitigs) runs on the second context beside the
+            next head, its host part (text) on the worker thread"""
+            laps = (C.c_double * 8)()
+            L.ma_pipeline_last_laps(C.byref(laps))
+            mean = lambda a: round(sum(a) / len(a) * 1e3, 3) if a else None
+            return {"head_wall_ms": mean(self.head_wall), "tail_wall_ms": mean(self.tail_wall) if self.tail_wall else mean(self.fetch_wall),
+                    "tail_last_pass_ms": {"survivors_names_intervals_to_host": round(laps[0], 3), "device_cleaners": round(laps[1], 3), "unitigs_to_host": round(laps[2], 3),
+                                          "text": round(laps[3], 3), "text_format": round(laps[4], 3), "text_assemble": round(laps[5], 3)},
+                    "note": "wall clocks on the host: head = ma_pipeline_head (sort .. reduced graph, ends with a counter fetch); tail = second context + worker thread (its device part waits for "
+                            "the GPU beside the next pass's head); a pass costs max(head, tail) when both are kept busy"}
 
         def fence(self):
             if self.worker:
@@ -581,6 +598,8 @@ def main():
                 self.ctx2 = None
 
     L.mahip_tail_handoff.argtypes = [vp, vp]
+    L.ma_pipeline_last_laps.argtypes = [C.POINTER(C.c_double * 8)]
+    L.ma_pipeline_last_laps.restype = None
     L.ma_shard_phases.argtypes = [C.c_int]
     run = Runner(W)
     if args.inflight > 1 and world == 1:
@@ -616,6 +635,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
     total_lines = float(W.n_lines)
+    main_phases = run.phases() if (rank == 0 and world == 1) else None
     gfa = run.output() if rank == 0 else b""
     tie = ctx.tie_stats() if rank == 0 else None
 
@@ -658,6 +678,9 @@ def main():
             tr = pmc_traffic(pmc, k["name"])
             # the bytes the launch really moved (rocprofv3 PMC profile of this command) / this run's launch time: cannot exceed the peak
             k["counter_GBs"] = round(tr / (k["avg_ms"] * 1e-3) / 1e9, 1) if tr and k["avg_ms"] > 0 else None
+            k["frac_counter"] = round(k["counter_GBs"] / HBM_PEAK_GBS, 4) if k["counter_GBs"] else None  # the fraction to read: bytes the launch moved / its time / peak
+            if k.get("alg_GBs") and k["alg_GBs"] > HBM_PEAK_GBS:
+                k["alg_GBs_is_accounting"] = "SURVEY 8(d) bytes of the reference passes this fused launch replaces, not bytes it moved: read frac_counter" 
         dom = next((k for k in kernels if k["alg_GBs"]), None)
         if dom:
             traffic = pmc_traffic(pmc, dom["name"])
@@ -761,7 +784,7 @@ def main():
                 t = r.timed(1, steps)
                 out = r.output()
                 ti = ctx.tie_stats()
-                res = {"value": w.n_lines * steps / t, "unit": "overlaps/s", "ms_per_step": t / steps * 1e3, "overlaps": w.n_lines, "reads": w.n_seq, "stored_hits": w.n_all,
+                res = {"value": w.n_lines * steps / t, "unit": "overlaps/s", "ms_per_step": t / steps * 1e3, "phases": r.phases(), "overlaps": w.n_lines, "reads": w.n_seq, "stored_hits": w.n_all,
                        "gfa_bytes": len(out), "gfa_md5": hashlib.md5(out).hexdigest(), "tie_groups": ti["arc_tie_groups"],
                        "tie_path": "arc walk%s" % (" + hit walk" if ti["hit_walk"] else "") if ti["arc_walk"] else "stable order (no arc ties)"}
                 if prof_steps:  # HIP events around every timed scope of a few extra steps: where this input's time goes, and the reduce group's roofline
@@ -872,6 +895,21 @@ def main():
             "tie_path": None if not tie else ("arc walk%s" % (" + hit walk" if tie["hit_walk"] else "") if tie["arc_walk"] else "unrepaired" if tie["unrepaired"] else "stable order (census: no arc ties => provably the reference's order)"),
             "phases": phases, "roofline": roof, "cpu_baseline": cpu, "latency": latency, "e2e": e2e, "from_text": from_text, "legs": legs, "kernels": kernels[:14],
             "setup": {"gen_s": t_gen, "file_to_hbm_s": W.t_load, "file_to_hbm_GBs": W.size / W.t_load / 1e9, "parse_dictionary_s": W.t_parse, "hbm_bytes_held": ctx.mem_bytes()},
+        }
+        if out["phases"] is None:
+            out["phases"] = main_phases
+        # the line's last object (a reader that only sees the tail of the line sees this): one number per leg
+        rg = (roof or {}).get("reduce_group") or {}
+        out["summary"] = {
+            "ms_per_step": round(out["ms_per_step"], 4), "overlaps_per_s": round(out["value"]), "gfa_identical": out["gfa_identical"],
+            "latency_ms": latency and latency["ms"], "from_text_ms_per_step": from_text and round(from_text["ms_per_step"], 3),
+            "e2e_wall_s": e2e and round(e2e["wall_s"], 4), "e2e_vs_reference_wall": e2e and e2e["vs_reference_wall"] and round(e2e["vs_reference_wall"], 1),
+            "roofline_frac_sort_group": roof and roof.get("frac"), "roofline_frac_counter_sort_group": roof and roof.get("frac_counter"),
+            "roofline_frac_reduce_group": rg.get("frac"), "roofline_frac_counter_reduce_group": rg.get("frac_counter"),
+            "cpu_reference_overlaps_per_s": cpu and round(cpu["value"]),
+            "legs_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in legs.items() if isinstance(v, dict) and "ms_per_step" in v},
+            "legs_wall_s": {k: round(v["wall_s"], 3) for k, v in legs.items() if isinstance(v, dict) and "wall_s" in v},
+            "legs_identical": {k: v.get("gfa_identical", v.get("gfa_md5_matches_reference", v.get("gfa_md5_matches_recorded_reference"))) for k, v in legs.items() if isinstance(v, dict)},
         }
         print(json.dumps(out), flush=True)
     W.close(L)

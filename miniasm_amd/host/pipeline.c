@@ -262,6 +262,12 @@ struct ma_tail_job {
 	double t_fetch[5];
 };
 
+/* wall-clock laps (ms) of the most recent tail: [0] survivors' names + intervals to the host, [1] device cleaners, [2] unitigs / graph to the host, [3] text (all of it),
+ * [4] of which formatting, [5] of which putting the pieces together (write / copy).  One set per process (bench.py reads it after its closing fence): a report, not a contract */
+static double g_tail_laps[8];
+double g_fmt_laps[2]; /* unitig_gfa.c: format, write / copy of the last ma_ug_print */
+void ma_pipeline_last_laps(double out[8]) { int i; for (i = 0; i < 8; ++i) out[i] = g_tail_laps[i]; }
+
 typedef struct { sd_seq_t *dst; const sd_seq_t *src; const uint32_t *old; uint32_t lo, hi; } view_job_t;
 static void *view_worker(void *arg)
 {
@@ -323,6 +329,7 @@ ma_tail_job_t *ma_pipeline_tail_fetch(mahip_ctx_t *c, const ma_opt_t *opt, const
 		}
 	}
 	j->t_fetch[3] = sys_realtime();
+	g_tail_laps[0] = (j->t_fetch[1] - j->t_fetch[0]) * 1e3; g_tail_laps[1] = j->t_fetch[2] > 0 ? (j->t_fetch[2] - j->t_fetch[1]) * 1e3 : 0; g_tail_laps[2] = j->t_fetch[2] > 0 ? (j->t_fetch[3] - j->t_fetch[2]) * 1e3 : 0;
 	if (getenv("MA_PIPE_TIMING") && j->have_graph && strcmp(outfmt, "paf") != 0 && strcmp(outfmt, "bed") != 0)
 		fprintf(stderr, "[T::tail] names+sub %.3f  device cleaners %.3f  unitigs/graph to host %.3f ms\n", (j->t_fetch[1]-j->t_fetch[0])*1e3, (j->t_fetch[2]-j->t_fetch[1])*1e3, (j->t_fetch[3]-j->t_fetch[2])*1e3);
 	return j;
@@ -355,6 +362,7 @@ static int tail_finish_to(ma_tail_job_t *j, FILE *out, char **buf, size_t *len)
 		else ma_ug_print_mem(j->ug, view, sub, buf, len);
 	} else if (j->sg) ma_sg_print(j->sg, view, sub, out);
 	if (ms) fclose(ms);
+	g_tail_laps[3] = (sys_realtime() - t0) * 1e3; g_tail_laps[4] = g_fmt_laps[0]; g_tail_laps[5] = g_fmt_laps[1];
 	if (timing) fprintf(stderr, "[T::tail] text %.3f ms\n", (sys_realtime() - t0) * 1e3);
 	ma_ug_destroy(j->ug);
 	asg_destroy(j->sg);
