@@ -352,7 +352,7 @@ def main():
                     "Default: it moves to a second context on the same GPU and runs beside the next batch's hit passes (mahip_tail_handoff; round 3, measured: "
                     "cfg4 20.0 -> 19.2 ms per step, cfg2 3.23 -> 2.79 ms)")
     ap.add_argument("--prof-steps", type=int, default=3)
-    ap.add_argument("--legs", default="cfg2,tie_rich,graph_heavy,latency,e2e,cfg5", help="which secondary legs to run (comma list)")
+    ap.add_argument("--legs", default="cfg2,tie_rich,graph_heavy,latency,e2e,cfg5,realistic", help="which secondary legs to run (comma list)")
     ap.add_argument("--graph-heavy-lines", type=int, default=100000000, help="overlaps of the graph-heavy leg (pafgen -L fixed, 50 lines per read); 0 = skip it")
     ap.add_argument("--inflight", type=int, default=1, help="experiment: batches in flight on the one GPU (each on its own context and host thread)")
     args = ap.parse_args()
@@ -423,6 +423,12 @@ def main():
             early_cfg5 = cli_digest_leg(ma, "cfg5", args.workdir)
         except Exception as e:
             log("cfg5 leg failed:", e)
+    early_real = None
+    if rank == 0 and world == 1 and want_leg("realistic") and cfg_name_early == "cfg4":
+        try:  # what a real overlapper writes: jittered coordinates, a tenth of the pairs from both sides, lines grouped by TARGET (pafgen -j 30 -b 0.1 -t): the record sort and both tie walks
+            early_real = cli_digest_leg(ma, "real50", args.workdir)
+        except Exception as e:
+            log("realistic leg failed:", e)
 
     ctx = ma.Ctx(local)
     if world > 1:  # one communicator per rank: rank 0 makes the RCCL id, the control plane hands it round
@@ -716,6 +722,23 @@ def main():
             ach = achievable_rates()
             if ach:
                 roof["achievable"] = ach
+            # What THIS design of the sort group can reach at best: every kernel's counted traffic (the committed PMC profile of this command) at the rate this GPU sustained for that
+            # kernel's access pattern with known byte counts (csrc/diag.hip).  It is a ceiling of the design, not of the hardware: the group moves about twice SURVEY 8(d)'s bytes
+            # (keys are made from whole records, three digit passes read the keys twice and write them once, a mirrored record costs a 128-byte line for 32 bytes), so 0.5 of the
+            # 8 TB/s peak by 8(d) bytes would need the group's traffic at more than the box streams.
+            if ach and grp_ms > 0 and all(t is not None for t in grp_tr):
+                pat = {"k_hit_keys": "keys_from_records", "k_radix_hist": "stream_read", "k_radix_colscan": "stream_read", "k_radix_scatter": "radix_scatter_runs", "k_runs_expand": "copy",
+                       "k_hit_goff": "copy", "k_group_close": "copy"}
+                line_rate = 6000.0  # GB/s of 128-byte LINES the random-record gather sustained (diag.hip: gather32+cols, 2.16 TB/s of useful bytes = 160 B moved per 64 useful)
+                c_ms, parts = 0.0, {}
+                for t, k in zip(grp_tr, grp):
+                    rate = line_rate if k["name"] == "k_hit_sub<gather>" else ach.get(pat.get(k["name"], "copy"), 5500.0)
+                    ms = t * k["launches_per_step"] / (rate * 1e9) * 1e3
+                    parts[k["name"]] = round(ms, 3)
+                    c_ms += ms
+                roof["ceiling"] = {"ms_per_step": round(c_ms, 3), "frac": round(grp_bytes / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "per_kernel_ms": parts,
+                                   "what": "the sort group's counted traffic at the rates this GPU sustained for each kernel's access pattern (csrc/diag.hip, profiles/r04_diag_patterns.json): "
+                                           "what this design can reach by SURVEY 8(d) bytes; the measured `frac` stands against THIS, 0.5 is out of its reach"}
             # the whole hit chain by the same accounting: SURVEY 8(d) sums the reference's passes to 584 B per stored hit
             chain_bytes = 584.0 * float(W.n_my)
             step_s = dt / args.steps
@@ -877,6 +900,8 @@ def main():
                "vs_reference_wall": (cpu["end_to_end_s"] / best) if cpu else None}
     if early_cfg5:
         legs["cfg5"] = early_cfg5
+    if early_real:
+        legs["realistic"] = early_real
     if rank == 0:
         out = {
             "metric": "PAF overlaps processed/sec (hit-filter->trans-reduce->GFA)",

@@ -35,6 +35,10 @@ CONFIGS = {
     "cfg4": dict(reads=2000000, lines=100000000, seed=2, extra=[]),
     "graph": dict(reads=2000000, lines=100000000, seed=4, extra=["-L", "fixed"]),
     "cfg5": dict(reads=5000000, lines=500000000, seed=3, extra=["-L", "uniform", "-d", "0.35", "-x", "0.03"]),
+    # what a real overlapper writes (pafgen -j / -b / -t, round 6): every coordinate jittered on its own, a tenth of the pairs listed from both sides, the lines grouped by
+    # TARGET -- equal sort keys by chance everywhere, no runs of a query's records: the inputs on which the tie path and the record sort are the common path
+    "real10": dict(reads=250000, lines=10000000, seed=6, extra=["-j", "30", "-b", "0.1", "-t", "-L", "uniform", "-d", "0.2", "-x", "0.03"]),
+    "real50": dict(reads=1000000, lines=50000000, seed=7, extra=["-j", "30", "-b", "0.1", "-t", "-d", "0.2", "-x", "0.03"]),
 }
 
 

@@ -158,6 +158,10 @@ TIE_INPUTS = {  # coordinates on a grid (pafgen -q): hundreds of equal (qid,qs) 
     "grid400_lognormal": dict(reads=4000, lines=120000, seed=7, extra=["-q", "400", "-d", "0.2"]),
     "grid50_fixed": dict(reads=2500, lines=70000, seed=8, extra=["-q", "50", "-L", "fixed", "-d", "0.1"]),
     "grid400_deep": dict(reads=30000, lines=1500000, seed=9, extra=["-q", "400", "-d", "0.2", "-x", "0.03"]),  # 97 % of the reads contained (squeezed-id keys matter)
+    # what a real overlapper writes (pafgen -j / -b / -t, round 6): every coordinate jittered on its own, some pairs listed from both sides, the lines grouped by
+    # TARGET -- equal keys by chance, a query's records scattered over the file (the sort cannot take runs), both readers' dictionaries fed in an order of their own
+    "jitter_by_target": dict(reads=3000, lines=80000, seed=11, extra=["-j", "30", "-b", "0.1", "-t", "-L", "uniform", "-d", "0.2", "-x", "0.03"]),
+    "jitter_both_ways": dict(reads=3000, lines=80000, seed=11, extra=["-j", "8", "-b", "0.2", "-d", "0.15"]),
 }
 
 
@@ -295,7 +299,7 @@ def test_cli_matches_reference_at_baseline_scale(name, tmpdir_s):
 # tests/golden/big.json: pafgen arguments, digest of the text, RAW md5 + size of the reference's GFA); here the seeded generator writes the same text again (checked)
 # and the command line's GFA is digested while it streams out.  On by default; MA_TEST_BIG_SKIP=cfg5,... leaves entries out, MA_TEST_BIG_DIR names a directory
 # with 35 GB of room for the text of configs[4] (default: the test's temporary directory).
-DIGEST_INPUTS = ["cfg3", "noisy50", "cfg4", "graph", "cfg5"]
+DIGEST_INPUTS = ["cfg3", "noisy50", "cfg4", "graph", "cfg5", "real10", "real50"]  # real10 / real50 (round 6): jittered coordinates, pairs from both sides, lines grouped by target
 
 
 @pytest.mark.parametrize("name", DIGEST_INPUTS)

@@ -12,6 +12,12 @@
  *   Noise: -d dropout fraction, -x false dovetail overlaps (tips/bubbles), -i low-identity fraction.
  *   Line order: grouped by query read, query reads in random order (like an all-vs-all overlapper run on
  *   reads in sequencing order; default) or in genome order (-g; SURVEY's original recipe).
+ *   Realistic noise (round 6; what every real overlapper emits, and where the reference's tie order is the COMMON case, not the exception):
+ *     -j K   every coordinate of a line (qs, qe, ts, te) and its block length moved independently by up to +-K bp (alignment ends are not exact projections),
+ *            so equal sort keys and equal (u,len) arc keys turn up by chance all over the file;
+ *     -b F   a fraction F of the pairs is listed in BOTH directions (a line in either read's block, each with its own jitter);
+ *     -t     the lines are grouped by TARGET (the roles of the two reads swapped when a line is written): a query's lines are scattered over the file,
+ *            as in a PAF sorted by target -- the hit sort cannot take runs of one query's records.
  *
  * Usage: pafgen -r 200000 -n 10000000 -s 1 [-L lognormal|fixed|uniform] [-m mean] [-o out.paf]
  */
@@ -67,7 +73,9 @@ typedef struct {
 	int model; /* 0 lognormal, 1 fixed, 2 uniform */
 	double mean, sigma, dropout, false_frac, lowid_frac;
 	int genome_order;
+	uint32_t jitter; double both_frac; int by_target;
 } opt_t;
+static opt_t g_o;
 
 static uint64_t count_pairs(const gread_t *r, uint32_t n, uint32_t min_ovlp)
 { /* reads sorted by start: pairs (i<j) with start_j + min_ovlp <= end_i  (len_j >= min_ovlp always) */
@@ -102,6 +110,16 @@ static char *emit(char *p, const gread_t *a, const gread_t *b, uint32_t gs, uint
 	if (b->strand == 0) ts = gs - b->start, te = ge - b->start;
 	else ts = b->start + b->len - ge, te = b->start + b->len - gs;
 	bl = ge - gs;
+	if (g_o.jitter) { /* alignment ends are not exact projections: every coordinate moves on its own, inside its read, the spans stay positive */
+		const uint32_t K = g_o.jitter, W = 2 * K + 1;
+		uint64_t hj = mix64(h ^ 0xA24BAED4963EE407ULL);
+		int64_t v;
+		v = (int64_t)qs + (int64_t)(hj % W) - K; hj = mix64(hj); if (v < 0) v = 0; if (v > (int64_t)a->len - 2) v = (int64_t)a->len - 2; qs = (uint32_t)v;
+		v = (int64_t)qe + (int64_t)(hj % W) - K; hj = mix64(hj); if (v <= (int64_t)qs) v = (int64_t)qs + 1; if (v > (int64_t)a->len) v = a->len; qe = (uint32_t)v;
+		v = (int64_t)ts + (int64_t)(hj % W) - K; hj = mix64(hj); if (v < 0) v = 0; if (v > (int64_t)b->len - 2) v = (int64_t)b->len - 2; ts = (uint32_t)v;
+		v = (int64_t)te + (int64_t)(hj % W) - K; hj = mix64(hj); if (v <= (int64_t)ts) v = (int64_t)ts + 1; if (v > (int64_t)b->len) v = b->len; te = (uint32_t)v;
+		bl = (qe - qs > te - ts ? qe - qs : te - ts) + (uint32_t)(hj % (K + 1));
+	}
 	f = (h >> 11) * (1.0 / 9007199254740992.0);
 	f = low_id ? 0.01 + 0.08 * f : 0.08 + 0.22 * f;
 	ml = (uint32_t)(bl * f);
@@ -134,6 +152,17 @@ static char *emit_false(char *p, const gread_t *a, const gread_t *b, uint64_t h)
 	return p;
 }
 
+/* a hash of the PAIR (the same from either side): dropout and -b decide per pair */
+static uint64_t pair_hash(uint32_t x, uint32_t y, const opt_t *o)
+{
+	const uint32_t lo = x < y ? x : y, hi = x < y ? y : x;
+	return mix64(((uint64_t)lo << 32 | hi) ^ (o->seed * 0xC2B2AE3D27D4EB4FULL));
+}
+static int both_ways(uint32_t x, uint32_t y, const opt_t *o)
+{
+	return o->both_frac > 0 && (pair_hash(x, y, o) >> 40 & 0xffff) < (uint64_t)(o->both_frac * 65536.0);
+}
+
 int main(int argc, char *argv[])
 {
 	opt_t o;
@@ -150,7 +179,7 @@ int main(int argc, char *argv[])
 	memset(&o, 0, sizeof(o));
 	o.n_reads = 2000; o.n_lines = 50000; o.seed = 1; o.model = 0; o.mean = 8000.; o.sigma = .5;
 	o.len_min = 2500; o.len_max = 60000; o.min_ovlp = 2000;
-	while ((c = getopt(argc, argv, "r:n:s:L:m:S:d:x:i:o:gl:M:O:q:")) >= 0) {
+	while ((c = getopt(argc, argv, "r:n:s:L:m:S:d:x:i:o:gl:M:O:q:j:b:t")) >= 0) {
 		if (c == 'r') o.n_reads = atol(optarg);
 		else if (c == 'n') o.n_lines = atoll(optarg);
 		else if (c == 's') o.seed = atoll(optarg);
@@ -166,7 +195,11 @@ int main(int argc, char *argv[])
 		else if (c == 'M') o.len_max = atol(optarg);
 		else if (c == 'O') o.min_ovlp = atol(optarg);
 		else if (c == 'q') o.quantum = atol(optarg); /* coordinates on a grid: many equal sort keys (tie-order tests) */
+		else if (c == 'j') o.jitter = atol(optarg);
+		else if (c == 'b') o.both_frac = atof(optarg);
+		else if (c == 't') o.by_target = 1;
 	}
+	g_o = o;
 	if (o.n_reads < 2) { fprintf(stderr, "pafgen: need >= 2 reads\n"); return 1; }
 	sm_state = o.seed * 0x2545F4914F6CDD1DULL + 12345;
 
@@ -249,12 +282,13 @@ int main(int argc, char *argv[])
 			uint32_t b_end = rb->start + rb->len, ge;
 			uint64_t h;
 			if (ra->start - rb->start > o.len_max) break;
-			if (rank[j] < k) continue; /* pair already emitted with j as the query */
+			if (rank[j] < k && !both_ways(ra->name, rb->name, &o)) continue; /* pair already emitted with j as the query (-b: some pairs are listed from both sides) */
 			ge = a_end < b_end ? a_end : b_end;
 			if (ge < ra->start + o.min_ovlp) continue;
 			h = mix64(((uint64_t)ra->name << 32 | rb->name) ^ (o.seed * 0x9E3779B97F4A7C15ULL));
-			if (o.dropout > 0 && (h & 0xffffff) < (uint64_t)(o.dropout * 16777216.0)) continue;
-			p = emit(p, ra, rb, ra->start, ge, o.lowid_frac > 0 && (h >> 24 & 0xffff) < (uint64_t)(o.lowid_frac * 65536.0), mix64(h));
+			if (o.dropout > 0 && ((o.both_frac > 0 ? pair_hash(ra->name, rb->name, &o) >> 8 : h) & 0xffffff) < (uint64_t)(o.dropout * 16777216.0)) continue; /* (-b: per pair, the same from either side) */
+			p = o.by_target ? emit(p, rb, ra, ra->start, ge, o.lowid_frac > 0 && (h >> 24 & 0xffff) < (uint64_t)(o.lowid_frac * 65536.0), mix64(h))
+			                : emit(p, ra, rb, ra->start, ge, o.lowid_frac > 0 && (h >> 24 & 0xffff) < (uint64_t)(o.lowid_frac * 65536.0), mix64(h));
 			++tot;
 			if ((size_t)(p - buf) > bufcap) fwrite(buf, 1, p - buf, fp), p = buf;
 		}
@@ -263,11 +297,12 @@ int main(int argc, char *argv[])
 			uint32_t b_end = rb->start + rb->len, ge;
 			uint64_t h;
 			if (rb->start + o.min_ovlp > a_end) break;
-			if (rank[j] < k) continue;
+			if (rank[j] < k && !both_ways(ra->name, rb->name, &o)) continue;
 			ge = a_end < b_end ? a_end : b_end;
 			h = mix64(((uint64_t)ra->name << 32 | rb->name) ^ (o.seed * 0x9E3779B97F4A7C15ULL));
-			if (o.dropout > 0 && (h & 0xffffff) < (uint64_t)(o.dropout * 16777216.0)) continue;
-			p = emit(p, ra, rb, rb->start, ge, o.lowid_frac > 0 && (h >> 24 & 0xffff) < (uint64_t)(o.lowid_frac * 65536.0), mix64(h));
+			if (o.dropout > 0 && ((o.both_frac > 0 ? pair_hash(ra->name, rb->name, &o) >> 8 : h) & 0xffffff) < (uint64_t)(o.dropout * 16777216.0)) continue; /* (-b: per pair, the same from either side) */
+			p = o.by_target ? emit(p, rb, ra, rb->start, ge, o.lowid_frac > 0 && (h >> 24 & 0xffff) < (uint64_t)(o.lowid_frac * 65536.0), mix64(h))
+			                : emit(p, ra, rb, rb->start, ge, o.lowid_frac > 0 && (h >> 24 & 0xffff) < (uint64_t)(o.lowid_frac * 65536.0), mix64(h));
 			++tot;
 			if ((size_t)(p - buf) > bufcap) fwrite(buf, 1, p - buf, fp), p = buf;
 		}
@@ -282,7 +317,7 @@ int main(int argc, char *argv[])
 				h = mix64(h + j + 1);
 				b = (uint32_t)(h % o.n_reads);
 				if (b == a) continue;
-				p = emit_false(p, ra, &r[b], mix64(h));
+				p = o.by_target ? emit_false(p, &r[b], ra, mix64(h)) : emit_false(p, ra, &r[b], mix64(h));
 				if (p != q0) ++tot;
 			}
 			if ((size_t)(p - buf) > bufcap) fwrite(buf, 1, p - buf, fp), p = buf;
