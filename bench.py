@@ -655,7 +655,7 @@ def main():
         run.head_wall, run.tail_wall = [], []
     for _ in range(args.prof_steps):  # a step is collective in the sharded mode: EVERY rank runs it, rank 0 is the one instrumented
         run.step()
-    run.fence()
+        run.fence()  # an instrumented step runs ALONE: with the previous pass's device tail on the second context beside it, whichever kernel it lands on is stretched by several ms (round 6: k_asg_trans 10.4 instead of 2.5 ms)
     phases = None
     if world > 1:  # where a sharded step spends its time: device time per phase (HIP events between the phases of host/sharded.c), maximum over the ranks
         L.ma_shard_phases(0)
@@ -815,7 +815,7 @@ def main():
                     ctx.prof_reset()
                     for _ in range(prof_steps):
                         r.step()
-                    r.fence()
+                        r.fence()  # (alone on the device: see the main workload's instrumented steps)
                     recs = ctx.prof_get()
                     ctx.prof_enable(False)
                     kt = kernel_table(recs, prof_steps)

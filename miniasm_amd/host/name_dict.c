@@ -140,12 +140,16 @@ void ma_sd_fill(sdict_t *d, char *arena, size_t arena_len, uint32_t n_seq, const
 	}
 }
 
-/* a big block the host is about to fill once: 2 MiB-aligned and advised to use huge pages, so that writing it for the first time costs a page fault per 2 MiB,
- * not per 4 KiB (the 50 MB of a 2 M-read dictionary: 12 000 faults, most of the 9 ms the download took in round 5); release with free() */
+/* a big block the host is about to fill once (release with free()).  MA_HOST_THP=1: 2 MiB-aligned and advised to use huge pages -- a page fault per 2 MiB instead of
+ * per 4 KiB when it is first written.  Opt-in only, like the tie walk's arrays (csrc/radix.hip): where the kernel compacts memory on such a fault (defrag = madvise) the
+ * first touch stalls for tens of ms at unpredictable moments (round 6: the graph-heavy pass swung between 32 and 53 ms with it).  What pays without it is that the
+ * block is first touched by SEVERAL threads (unitig_gfa.c: the formatter's threads copy their pieces; pipeline.c: the survivors' view) */
 void *ma_big_alloc(size_t n)
 {
+	static int thp = -1;
 	void *p = 0;
-	if (n >= ((size_t)4 << 20)) {
+	if (thp < 0) { const char *e = getenv("MA_HOST_THP"); thp = e && atoi(e) != 0; }
+	if (thp && n >= ((size_t)4 << 20)) {
 		const size_t b = (n + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
 		if (posix_memalign(&p, (size_t)2 << 20, b) == 0) { (void)madvise(p, b, MADV_HUGEPAGE); return p; }
 	}

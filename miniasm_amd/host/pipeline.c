@@ -307,7 +307,7 @@ ma_tail_job_t *ma_pipeline_tail_fetch(mahip_ctx_t *c, const ma_opt_t *opt, const
 		free(old);
 	}
 	if (j->have_sub) {
-		j->sub = (ma_sub_t*)ma_big_alloc(((size_t)j->view.n_seq + 1) * sizeof(ma_sub_t)); /* (written in full by the download) */
+		j->sub = (ma_sub_t*)calloc(j->view.n_seq ? j->view.n_seq : 1, sizeof(ma_sub_t)); /* (a plain block: the runtime's copy into fresh huge-page memory took twice as long and held the other context's launches up) */
 		GPU(mahip_sub_download(c, 0, j->sub, j->squeezed));
 	}
 	j->t_fetch[1] = sys_realtime();
