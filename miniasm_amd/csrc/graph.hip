@@ -348,6 +348,50 @@ __global__ __launch_bounds__(256) void k_arc_push_conflicts(const uint64_t *__re
 	for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x + 1; p < n; p += (size_t)gridDim.x * 256) cnt += skey[p] == skey[p - 1];
 	blk_add_u64(&ctr[ST_PUSH_CONFLICTS], cnt);
 }
+// ---- which push conflicts can the reference's arc sort SEE?  (round 6)
+// A conflict = two arcs x, y, neighbours in the stable push order, from hits with equal (qid,qs): only the reference's (unstable) hit sort knows which of them ma_sg_gen
+// pushes first.  asg_arc_sort is an MSD radix sort (ksort.h:149-183): as long as x and y carry the same digit, a level's walk only tells elements apart by their digit,
+// so pushing y before x lands every OTHER element where it landed before and x, y in each other's places.  At the level of their first differing byte they sit in one
+// bucket B (the arcs that share the key bytes above it); there the walk may take another course -- for the elements of B only, and what it leaves open is only the order
+// inside groups of EQUAL keys.  So the swap can change the result only if B holds a tie group; and not even then if B has at most RS_MIN_SIZE = 64 elements, because
+// such a bucket is insertion-sorted (ksort.h:182), stably: equal keys keep the order they came in, which a swap of two arcs with DIFFERENT keys does not touch.  x and y
+// with equal keys are a tie group themselves.  A conflict that fails the test is invisible; if all of them are, the stable push order gives the reference's graph and
+// the walk over the hit keys (seconds at BASELINE configs[4], 0.48 of the 0.94 s of the 50 M-line realistic input) is not needed.  Runs of more than two tied hits: the
+// bucket of any two members lies inside the larger of the buckets of the neighbouring pairs between them (common prefixes are an ultrametric), so neighbours suffice.
+// S = the arcs' keys with squeezed ids, ascending (the stable sort's output); tp[i] = pairs j < i with S[j] == S[j+1].
+__global__ __launch_bounds__(256) void k_tie_pair_flags(const uint64_t *__restrict__ S, size_t n, uint32_t *__restrict__ f)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) f[i] = i + 1 < n && S[i] == S[i + 1];
+}
+__device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *__restrict__ S, uint32_t n, uint64_t x)
+{ // first position whose key is >= x
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (S[mid] < x) lo = mid + 1; else hi = mid; }
+	return lo;
+}
+__global__ __launch_bounds__(256) void k_arc_push_conflicts_seen(const uint64_t *__restrict__ skey, const uint32_t *__restrict__ perm, ArcCols a /* push sequence */, const int32_t *__restrict__ map,
+                                                                  const uint64_t *__restrict__ S, const uint32_t *__restrict__ tp, uint32_t n, unsigned long long *__restrict__ ctr)
+{
+	uint32_t cnt = 0;
+	for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x + 1; p < n; p += (size_t)gridDim.x * 256) {
+		if (skey[p] != skey[p - 1]) continue;
+		const uint32_t ia = perm[p - 1], ib = perm[p];
+		uint32_t ua = a.u[ia], ub = a.u[ib];
+		if (map) { ua = (uint32_t)map[ua >> 1] << 1 | (ua & 1); ub = (uint32_t)map[ub >> 1] << 1 | (ub & 1); }
+		const uint64_t ka = (uint64_t)ua << 32 | a.len[ia], kb = (uint64_t)ub << 32 | a.len[ib];
+		if (ka == kb) { ++cnt; continue; }
+		const int sh = ((63 - __clzll((long long)(ka ^ kb))) / 8 + 1) * 8; // bits below the shared prefix
+		uint32_t r0 = 0, r1 = n;
+		if (sh < 64) {
+			const uint64_t lo = ka >> sh << sh, hi = lo + (1ull << sh);
+			r0 = lower_bound_u64(S, n, lo);
+			r1 = hi > lo ? lower_bound_u64(S, n, hi) : n; // (the top bucket ends with the array)
+		}
+		if (r1 - r0 > 64u && tp[r1 - 1] > tp[r0]) ++cnt;
+	}
+	blk_add_u64(&ctr[ST_PUSH_SEEN], cnt);
+}
 // sort key of a pushed arc in the reference's hit order
 __global__ __launch_bounds__(256) void k_arc_push_keys(const uint32_t *__restrict__ aslot, const uint32_t *__restrict__ hrank, size_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
 {
@@ -1094,15 +1138,34 @@ static int push_stable_order(mahip_ctx *c, size_t m, int *gen, uint64_t *conflic
 	return 0;
 }
 
-// exact: where two consecutive arcs come from hits with equal keys, the reference's (unstable) hit order decides: walk over the hits
-static int push_order(mahip_ctx *c, size_t m, bool exact, int *gen)
+// exact: where two consecutive arcs come from hits with equal keys, the reference's (unstable) hit order decides: walk over the hits -- unless the arc sort cannot
+// see any of those pairs (k_arc_push_conflicts_seen).  pushed / sorted: the arcs in push-sequence (slot) order and stably sorted by (u,len), when the caller has both
+static int push_order(mahip_ctx *c, size_t m, bool exact, int *gen, const ArcCols *pushed = nullptr, const ArcCols *sorted = nullptr)
 {
 	uint64_t conf = 0;
 	TieLaps tl(c);
 	CHK(push_stable_order(c, m, gen, &conf));
 	tl.lap("stable push order + conflicts");
 	c->tie.push_conflicts = conf;
-	if (exact && conf) {
+	c->tie.push_conflicts_seen = conf;
+	static const bool filter_on = !(getenv("MA_TIE_NO_FILTER") && atoi(getenv("MA_TIE_NO_FILTER")) != 0); // A/B handle: walk whenever there is a conflict (until round 5)
+	if (exact && conf && pushed && sorted && filter_on && m < 0xffffffffull) {
+		unsigned long long *ctr = P<unsigned long long>(c->ctr);
+		const int32_t *map = c->has_map ? (const int32_t*)P<int32_t>(c->map) : (const int32_t*)nullptr;
+		uint64_t *S = P<uint64_t>(c->key[*gen ^ 1]); // (the other generation was the sort's scratch)
+		CHK(dev_reserve(c, c->keep, (m + 16) * 4)); CHK(dev_reserve(c, c->pos, (m + 16) * 4));
+		hipLaunchKernelGGL(k_arc_keys_ref, dim3(grid_for(m, 256)), dim3(256), 0, c->st, *sorted, m, map, S);
+		hipLaunchKernelGGL(k_tie_pair_flags, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint64_t*)S, m, P<uint32_t>(c->keep));
+		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), m, nullptr));
+		HIPCHK(hipMemsetAsync(ctr + ST_PUSH_SEEN, 0, 8, c->st));
+		hipLaunchKernelGGL(k_arc_push_conflicts_seen, dim3(grid_for(m, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[*gen]), (const uint32_t*)P<uint32_t>(c->val[*gen]),
+		                   *pushed, map, (const uint64_t*)S, (const uint32_t*)P<uint32_t>(c->pos), (uint32_t)m, ctr);
+		CHK(ctr_fetch(c));
+		c->tie.push_conflicts_seen = c->h_ctr[ST_PUSH_SEEN];
+		tl.lap("conflicts the arc sort can see");
+	}
+	if (exact && c->tie.push_conflicts_seen) {
+		const int g_keep = *gen; (void)g_keep;
 		CHK(hits_reference_rank(c, false)); // uses key[]/val[] as scratch
 		for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }
 		hipLaunchKernelGGL(k_arc_push_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->aslot), (const uint32_t*)P<uint32_t>(c->hrank), m,
@@ -1226,7 +1289,8 @@ extern "C" int mahip_sg_finish(mahip_ctx_t *c, uint32_t *n_arc)
 			// (1) the push order: arcs leave ma_sg_gen in the order ma_hit_sort left the hits in (asm.c:18-35)
 			if (want_slots) {
 				int g2 = 0;
-				CHK(push_order(c, m, true, &g2));
+				const bool have_sorted = c->tie_mode != 1 || sharded; // `out` holds the stable sort's result (forced mode skips that sort: it walks unconditionally)
+				CHK(push_order(c, m, true, &g2, &in, have_sorted ? &out : nullptr));
 				hipLaunchKernelGGL(k_arc_permute, dim3(grid_for(m, 256)), dim3(256), 0, c->st, in, m, (const uint32_t*)P<uint32_t>(c->val[g2]), out);
 				c->ag ^= 1; // `out` now holds the arcs in the reference's push order
 				in = arcs_of(c, c->ag); out = arcs_of(c, c->ag ^ 1);

@@ -86,7 +86,7 @@ struct mahip_ctx {
 	bool gather_pending = false; int gk_gen = 0, gk_bi = 0; // mahip_hits_sort left the records in place: sorted keys in key[gk_gen], position in their low gk_bi bits
 	bool gk_runs = false; size_t n_runs = 0; int run_stride = 0; // sorted as RUNS of records (hits.hip: k_hit_keys_runs / k_runs_expand): the positions are in sidx already; run_stride: the caller's hint (mahip_set_run_stride)
 	bool push_ordered = false; // sharded mode: pushrows[1] holds this rank's arcs in push order
-	mahip_tie_info_t tie = {0, 0, 0, 0, 0, 0, 0};
+	mahip_tie_info_t tie = {0, 0, 0, 0, 0, 0, 0, 0};
 	uint32_t n_seq_new = 0;
 
 	// ---- arcs (dense SoA, two generations for compaction) ----
@@ -169,7 +169,7 @@ static inline bool xchg_needs_sync(const mahip_ctx *c) { return c->own_stream &&
 enum { CT_LIVE = 0, CT_REMAIN, CT_TOTDP, CT_TOTLEN, CT_OVF, CT_NRED, CT_NMULTI, CT_NASYMM, CT_NSHORT, CT_MAXQID, CT_MAXQS, CT_TOTAL, CT_OVF2, CT_MAXLEN, CT_CUT, CT_TRINNER /* iterations of asg.c:169's loop */, CT_PROBED /* list entries asg.c:131 looked at */, CT_N };
 static_assert(CT_N <= 48, "a named counter would overlap the sticky counters");
 // slots [CT_STICKY, 64) are not touched by ctr_zero: the tie census keeps its results there until they are read
-enum { CT_STICKY = 48, ST_ARC_TIE_GROUPS = 48, ST_ARC_TIE_ARCS, ST_PUSH_CONFLICTS, ST_HIT_TIES };
+enum { CT_STICKY = 48, ST_ARC_TIE_GROUPS = 48, ST_ARC_TIE_ARCS, ST_PUSH_CONFLICTS, ST_HIT_TIES, ST_PUSH_SEEN };
 // words [CT_XCHG, CT_XCHG + CT_XCHG_WORDS): scratch of the collectives (comm.hip: all-reduce of counters, all-gather of u64) -- behind the 64 words the mailbox publishes, so that no
 // counter, named or sticky, can ever share a word with it (it used to be `ctr + 16`, which CT_PROBED had reached)
 enum { CT_WORDS = 64, CT_XCHG = 64, CT_XCHG_WORDS = 32, CT_ALLOC_WORDS = CT_XCHG + CT_XCHG_WORDS };

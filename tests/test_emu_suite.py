@@ -71,6 +71,12 @@ def test_kernels_graph_api_on_cpu(emu_built):
     run_gpu_tests(["tests/test_gpu_graph_api.py", "tests/test_gpu_graph_fuzz.py"] + ([] if FULL else ["-k", "not noisy_big"]), 1800)
 
 
+def test_tie_filter_on_cpu(emu_built):
+    """tests/test_gpu_cli.py: push conflicts the reference's arc sort cannot see -- the hit walk is skipped, every dump equals the reference's byte for byte; and the
+    realistic inputs (jittered coordinates, lines grouped by target) through both walks"""
+    run_gpu_tests(["tests/test_gpu_cli.py", "-k", "out_of_sight or (tie_rich and jitter and default)"], 3000)
+
+
 def test_kernels_ingest_on_cpu(emu_built):
     """tests/test_gpu_ingest.py: device PAF parser + dictionary against the host reader and the reference"""
     run_gpu_tests(["tests/test_gpu_ingest.py"], 1800)

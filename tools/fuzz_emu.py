@@ -16,6 +16,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "miniasm_ref")
 EMU = os.path.join(ROOT, "tests", "emu", "_build", "miniasm")
 PAFGEN = os.path.join(ROOT, "miniasm_amd", "bin", "pafgen")
 TIES = False
+REAL = False
 
 
 def run(binary, args, paf, env=None, stdin=None):
@@ -39,7 +40,13 @@ def rand_case(rng):
         gen += ["-i", "%.2f" % rng.choice([0.1, 0.3])]
     if rng.random() < 0.3:
         gen += ["-g"]
-    if rng.random() < (1.0 if TIES else 0.4):
+    if REAL:  # what a real overlapper writes: jittered coordinates (equal keys by chance), pairs from both sides, lines grouped by target
+        gen += ["-j", str(rng.choice([1, 3, 8, 30, 100]))]
+        if rng.random() < 0.6:
+            gen += ["-b", "%.2f" % rng.choice([0.05, 0.2, 0.5, 1.0])]
+        if rng.random() < 0.5:
+            gen += ["-t"]
+    elif rng.random() < (1.0 if TIES else 0.4):
         gen += ["-q", str(rng.choice([4, 16, 64, 256]))]  # coordinates on a grid: equal sort keys everywhere
     if rng.random() < 0.3:
         gen += ["-m", str(rng.choice([1500, 3000, 20000]))]
@@ -175,12 +182,14 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--ranks", type=int, default=0, help="also run every case as MA_GPUS=N (shared-memory double)")
     ap.add_argument("--ties", action="store_true", help="every input on a coordinate grid (equal sort keys everywhere: tie census, push conflicts, both walks)")
+    ap.add_argument("--real", action="store_true", help="realistic noise: pafgen -j (jitter) / -b (both directions) / -t (grouped by target): equal keys by chance, conflicts mostly out of the arc sort's sight")
     ap.add_argument("--env", action="append", default=[], help="KEY=VALUE for the runs of the CPU build (e.g. MA_HOST_PARSE=1, MA_NO_FUSE=1, MA_EXACT_TIES=1, MA_THREADS=3)")
     ap.add_argument("--keep", default=None, help="directory for failing inputs")
     ap.add_argument("--emu", default=None, help="the CPU build's miniasm (default tests/emu/_build/miniasm; point it at a copy to keep fuzzing across rebuilds)")
     a = ap.parse_args()
-    global EMU, TIES
+    global EMU, TIES, REAL
     TIES = a.ties
+    REAL = a.real
     if a.emu:
         EMU = a.emu
     for p in (REF, EMU, PAFGEN):
@@ -219,11 +228,11 @@ def main():
             for ln in err1.decode(errors="replace").splitlines():
                 if ln.startswith("[T::ties]") and "arc tie groups" in ln:
                     import re
-                    mm = re.search(r"(\d+) arc tie groups .*?, (\d+) push conflicts", ln)
+                    mm = re.search(r"(\d+) arc tie groups .*?, (\d+) push conflicts \((\d+) of them in sight", ln)
                     if not mm:
                         continue
-                    groups, conf = int(mm.group(1)), int(mm.group(2))
-                    key = "no arc ties" if groups == 0 else "arc walk" if conf == 0 else "arc walk + hit walk"
+                    groups, conf, seen = int(mm.group(1)), int(mm.group(2)), int(mm.group(3))
+                    key = "no arc ties" if groups == 0 else "arc walk" if conf == 0 else "arc walk, conflicts out of sight" if seen == 0 else "arc walk + hit walk"
                     paths[key] = paths.get(key, 0) + 1
             ok = rc0 == rc1 and out0 == out1 and b"runtime error" not in err1 and b"AddressSanitizer" not in err1  # the last clause: a sanitizer build of tests/emu (make B=_build_san CXX="g++ -fsanitize=address,undefined" CC="gcc -fsanitize=address,undefined")
             if not ok:
