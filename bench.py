@@ -171,7 +171,7 @@ def pmc_profile(workload):
     FETCH_SIZE and WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md's HBM section prescribes).  PMC counters cannot be
     read from inside this process: the figures are attached only when the workload is the profiled one, and are labelled with the file
     and the commit the profile was taken at (its `_meta`)."""
-    for rnd in ("r05", "r04", "r03", "r03a", "r02", "r01"):  # the newest profile of this workload
+    for rnd in ("r06", "r05", "r04", "r03", "r03a", "r02", "r01"):  # the newest profile of this workload
         path = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, workload))
         try:
             d = json.load(open(path))
