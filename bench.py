@@ -126,9 +126,11 @@ def cli_digest_leg(ma, name, workdir):
             mm = re.search(pat, log_txt)
             if mm:
                 laps[key] = float(mm.group(1))
-        mt = re.search(r"\[T::ties\] (\d+) arc tie groups \((\d+) arcs\), (\d+) push conflicts", log_txt)
+        mt = re.search(r"\[T::ties\] (\d+) arc tie groups \((\d+) arcs\), (\d+) push conflicts(?: \((\d+) of them in sight)?", log_txt)
         if mt:
             laps["arc_tie_groups"], laps["push_conflicts"] = int(mt.group(1)), int(mt.group(3))
+            if mt.group(4) is not None:
+                laps["push_conflicts_in_sight_of_the_arc_sort"] = int(mt.group(4))
         return {"value": cfg["lines"] / wall, "unit": "overlaps/s", "wall_s": round(wall, 3), "overlaps": cfg["lines"], "reads": cfg["reads"], "pafgen": cfg, "paf_bytes": gold["paf_bytes"],
                 "text_is_the_recorded_one": same_text, "gfa_md5": h.hexdigest(), "gfa_bytes": n, "ref_md5": gold["gfa_md5"], "ref_bytes": gold["gfa_bytes"],
                 "gfa_md5_matches_reference": same_text and (h.hexdigest(), n) == (gold["gfa_md5"], gold["gfa_bytes"]),
