@@ -139,13 +139,14 @@ extern "C" int mahip_comm_init_shm(mahip_ctx_t *c, const char *name, int rank, i
 	snprintf(m->name, sizeof(m->name), "/%s", name);
 	m->map_bytes = 4096 + (size_t)world * SHM_SLOT_BYTES;
 	int fd = -1;
-	for (int tries = 0; tries < 20000 && fd < 0; ++tries) { // rank 0 creates, the others wait for it
+	for (int tries = 0; tries < 180000 && fd < 0; ++tries) { // rank 0 creates, the others wait for it -- up to three minutes: eight processes that start together on a fresh box (first import of
+		// the Python stack, the HIP runtime coming up eight times) have been seen to be more than 20 s apart (round 6: the projection's N = 8 run lost a rank to the old limit)
 		fd = rank == 0 ? shm_open(m->name, O_CREAT | O_RDWR, 0600) : shm_open(m->name, O_RDWR, 0600);
 		if (fd < 0) usleep(1000);
 	}
 	if (fd < 0) { mahip_set_error("mahip_comm_init_shm: shm_open(%s) failed", m->name); delete m; return -1; }
 	if (rank == 0 && ftruncate(fd, (off_t)m->map_bytes) != 0) { close(fd); mahip_set_error("mahip_comm_init_shm: ftruncate failed"); delete m; return -1; }
-	if (rank != 0) for (int tries = 0; tries < 20000; ++tries) { off_t sz = lseek(fd, 0, SEEK_END); if ((size_t)sz >= m->map_bytes) break; usleep(1000); }
+	if (rank != 0) for (int tries = 0; tries < 180000; ++tries) { off_t sz = lseek(fd, 0, SEEK_END); if ((size_t)sz >= m->map_bytes) break; usleep(1000); }
 	void *p = mmap(nullptr, m->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
 	close(fd);
 	if (p == MAP_FAILED) { mahip_set_error("mahip_comm_init_shm: mmap failed"); delete m; return -1; }

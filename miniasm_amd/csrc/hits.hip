@@ -1189,17 +1189,25 @@ extern "C" int mahip_hits_route(mahip_ctx_t *c, uint64_t *n_total_out, uint64_t 
 	if (total >= 0xffffffffull) { mahip_set_error("mahip_hits_route: too many hits"); return -1; }
 	std::vector<uint32_t> b((size_t)W + 1, R);
 	b[0] = 0;
+	int lrc_pre = 0; // this rank's own failures in front of the first exchange: they travel as the FAILED marker below, so that all ranks leave together
 	if (R) {
-		CHK(dev_reserve(c, c->keep, ((size_t)R + 16) * 4));
-		HIPCHK(hipMemsetAsync(c->keep.p, 0, (size_t)R * 4, c->st));
-		if (n) hipLaunchKernelGGL(k_qid_count, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, R, P<uint32_t>(c->keep));
+		// every step of this rank that can fail on its own is agreed on before the collective behind it: a rank that returned here alone would leave the others in the all-reduce
+		lrc_pre = dev_reserve(c, c->keep, ((size_t)R + 16) * 4);
+		if (lrc_pre == 0 && hipMemsetAsync(c->keep.p, 0, (size_t)R * 4, c->st) != hipSuccess) { mahip_set_error("mahip_hits_route: hipMemsetAsync failed"); lrc_pre = -1; }
+		if (lrc_pre == 0 && n) hipLaunchKernelGGL(k_qid_count, dim3(grid_for(n, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, n, R, P<uint32_t>(c->keep));
+		{
+			uint64_t bad = lrc_pre ? 1 : 0;
+			CHK(mahip_comm_all_reduce_sum_u64(c, &bad, 1));
+			if (bad) { if (!lrc_pre) mahip_set_error("mahip_hits_route: another rank could not count its hits"); return -1; }
+		}
 		CHK(mahip_comm_all_reduce_sum_u32(c, c->keep.p, R));
 		std::vector<uint32_t> cnt(R);
-		HIPCHK(hipMemcpyAsync(cnt.data(), c->keep.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->st));
-		HIPCHK(hipStreamSynchronize(c->st));
+		if (hipMemcpyAsync(cnt.data(), c->keep.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->st) != hipSuccess || hipStreamSynchronize(c->st) != hipSuccess) {
+			mahip_set_error("mahip_hits_route: the summed hit counts did not come down"); lrc_pre = -1; // (the marker in the row gathered below tells the others)
+		}
 		unsigned long long run = 0;
 		int r = 1;
-		for (uint32_t q = 0; q < R && r < W; ++q) { // as mahip_hits_balance: rank r starts behind the read that completes r/W of the hits
+		for (uint32_t q = 0; q < R && r < W && lrc_pre == 0; ++q) { // as mahip_hits_balance: rank r starts behind the read that completes r/W of the hits
 			run += cnt[q];
 			while (r < W && run * (unsigned long long)W >= (unsigned long long)total * (unsigned long long)r) b[r++] = q + 1;
 		}
@@ -1212,8 +1220,8 @@ extern "C" int mahip_hits_route(mahip_ctx_t *c, uint64_t *n_total_out, uint64_t 
 	// (a count no rank can hold), every rank sees it and all leave together; the receive buffers' reservation is agreed on the same way before the exchange.
 	const uint64_t FAILED = ~0ull;
 	do {
-		int lrc = 0; // this rank's own verdict so far
-		if ((lrc = dev_reserve(c, send_rec, (n + 1) * sizeof(ma_hit_t))) == 0) lrc = dev_reserve(c, send_pos, (n + 1) * 4);
+		int lrc = lrc_pre; // this rank's own verdict so far
+		if (lrc == 0 && (lrc = dev_reserve(c, send_rec, (n + 1) * sizeof(ma_hit_t))) == 0) lrc = dev_reserve(c, send_pos, (n + 1) * 4);
 		size_t off = 0;
 		for (int h = 0; h < W; ++h) {
 			size_t k = 0;

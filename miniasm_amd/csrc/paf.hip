@@ -1005,7 +1005,9 @@ __global__ __launch_bounds__(256) void k_paf_emit_chain(PafCols o, const uint32_
 	for (unsigned k = 0; k < EM_ROWS; ++k) {
 		cnt[k] = 0;
 		if (fl[k] & 2u) {
+#ifndef EXP_EMIT_NO_LOOKUP // (experiment: what the pass costs without its random fetches -- the ids are wrong then)
 			qid[k] = slot_id[qid[k]]; tid[k] = slot_id[tid[k]];
+#endif
 			cnt[k] = 1u + (bi_dir && qid[k] != tid[k]); // hit.c:87-98
 		}
 		const uint32_t incl = (uint32_t)wv_scan_incl_i32((int)cnt[k], lane);

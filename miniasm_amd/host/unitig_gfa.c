@@ -213,6 +213,13 @@ typedef struct { const ma_ug_t *ug; const sdict_t *d; const ma_sub_t *sub; const
 static void *fmt_worker(void *arg)
 {
 	fmt_job_t *j = (fmt_job_t*)arg;
+	{ /* room for the whole share up front (an `a` line is about 40 bytes, an `L` line 45, an `x` line 70): a buffer that grows by doubling copies its text again and again and touches twice the pages */
+		size_t k, reads = 0;
+		for (k = j->s_lo; k < j->s_hi; ++k) reads += (size_t)(j->seg[k].j1 - j->seg[k].j0) + 2;
+		ob_need(&j->units, reads * 52 + 4096);
+		ob_need(&j->links, (size_t)(j->l_hi - j->l_lo) * 56 + 4096);
+		ob_need(&j->summary, (size_t)(j->u_hi - j->u_lo) * 96 + 4096);
+	}
 	fmt_units(&j->units, j->ug, j->d, j->sub, j->seg, j->s_lo, j->s_hi);
 	fmt_links(&j->links, j->ug, j->l_lo, j->l_hi);
 	fmt_summary(&j->summary, j->ug, j->d, j->sub, j->u_lo, j->u_hi);
