@@ -428,8 +428,11 @@ __device__ __forceinline__ uint64_t lds_name_key(const uint32_t *__restrict__ w,
 	return h;
 }
 
+#ifndef PAF_TILE_WAVES
+#define PAF_TILE_WAVES 1 // __launch_bounds__' second argument (waves per SIMD the register allocation has to leave room for): an experiment handle
+#endif
 template <int CH> // a block stages up to CH * 16 KiB of text: CH * 64 bytes per thread in the newline ranking
-__global__ __launch_bounds__(256) void k_paf_parse_tile(const TileArgs a, PafCols o, uint64_t *__restrict__ lstart, unsigned long long *__restrict__ ctr)
+__global__ __launch_bounds__(256, PAF_TILE_WAVES) void k_paf_parse_tile(const TileArgs a, PafCols o, uint64_t *__restrict__ lstart, unsigned long long *__restrict__ ctr)
 {
 	constexpr uint32_t REG = (uint32_t)CH * 16384u;
 	extern __shared__ __attribute__((aligned(16))) unsigned char s_text[]; // the text: REG + 32; behind it:
@@ -519,7 +522,8 @@ __global__ __launch_bounds__(256) void k_paf_parse_tile(const TileArgs a, PafCol
 				if (!lf) {
 					uint32_t e1 = pe;
 					if (e1 - ps > 1 && s_text[e1 - 1] == '\r') --e1;
-					// ---- column ends
+					// ---- column ends (all eleven first, then what they hold: converting each column as soon as its end is known -- 22 registers fewer on paper -- made hipcc
+					// interleave less: 99 registers and 4.12 ms instead of 96 and 3.85; capping the registers for six waves a SIMD spills: 5.9 ms)
 					uint32_t fb[11], fe[11], ncol = 0, pos = ps;
 					bool more = true, amb = false;
 #pragma unroll
@@ -980,7 +984,9 @@ __global__ __launch_bounds__(256) void k_paf_emit(PafCols o, const uint32_t *__r
 // A lane has a LINE (row r of the tile = lines 64 r .. 64 r + 63, wave w takes rows w, w + 4, ...): a line's 32 or 64 bytes of records leave from one lane, so the
 // lanes of a store instruction fill neighbouring 64-byte stretches (four lines per lane, as the first version had it, put them 256 bytes apart: 4.7 ms against
 // the 4.1 of the three launches it replaced).
-#define EM_ROWS 4u
+#ifndef EM_ROWS
+#define EM_ROWS 16u // rows per tile: a tile draws ONE ticket from one word (12 - 17 ns each, serial): 1 row 5.57 ms, 2: 4.59, 4: 4.09, 8: 3.96 per 100 M lines
+#endif
 #define EM_TILE (256u * EM_ROWS)
 __global__ __launch_bounds__(256) void k_paf_emit_chain(PafCols o, const uint32_t *__restrict__ slot_id, uint32_t L, int bi_dir, uint4 *__restrict__ rec, uint32_t *__restrict__ d_total,
                                                          unsigned long long *state, uint32_t *ticket, uint32_t ticket_base, uint32_t epoch)
@@ -993,13 +999,11 @@ __global__ __launch_bounds__(256) void k_paf_emit_chain(PafCols o, const uint32_
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const size_t tbase = (size_t)tile * EM_TILE;
 	uint32_t fl[EM_ROWS], qid[EM_ROWS], tid[EM_ROWS], cnt[EM_ROWS], ex[EM_ROWS];
-	uint32_t qs[EM_ROWS], qe[EM_ROWS], ts[EM_ROWS], te[EM_ROWS], ml[EM_ROWS], bl[EM_ROWS];
 #pragma unroll
-	for (unsigned k = 0; k < EM_ROWS; ++k) { // everything the tile reads in a row is asked for at once: the columns are on their way while the ids are looked up and the tiles in front are waited for
+	for (unsigned k = 0; k < EM_ROWS; ++k) {
 		const size_t i = tbase + (size_t)(k * 4u + wave) * 64u + lane;
 		const bool in = i < L; const size_t j = in ? i : 0;
 		fl[k] = in ? o.flags[j] : 0u; qid[k] = o.qslot[j]; tid[k] = o.tslot[j];
-		qs[k] = o.qs[j]; qe[k] = o.qe[j]; ts[k] = o.ts[j]; te[k] = o.te[j]; ml[k] = o.ml[j]; bl[k] = o.bl[j];
 	}
 #pragma unroll
 	for (unsigned k = 0; k < EM_ROWS; ++k) {
@@ -1031,15 +1035,17 @@ __global__ __launch_bounds__(256) void k_paf_emit_chain(PafCols o, const uint32_
 	__syncthreads();
 	const uint32_t p0 = s_prefix;
 #pragma unroll
-	for (unsigned k = 0; k < EM_ROWS; ++k) {
+	for (unsigned k = 0; k < EM_ROWS; ++k) { // (the six number columns are fetched here, a row ahead of its stores: asking for all of them up front bought nothing and costs 6 registers a row)
 		if (!cnt[k]) continue;
-		const uint32_t mlrev = ml[k] | (fl[k] >> 3 & 1u) << 31, b31 = bl[k] & 0x7fffffffu;
+		const size_t i = tbase + (size_t)(k * 4u + wave) * 64u + lane;
+		const uint32_t qs = o.qs[i], qe = o.qe[i], ts = o.ts[i], te = o.te[i];
+		const uint32_t mlrev = o.ml[i] | (fl[k] >> 3 & 1u) << 31, b31 = o.bl[i] & 0x7fffffffu;
 		uint4 *r = rec + (size_t)(p0 + s_row[k * 4u + wave] + ex[k]) * 2;
-		r[0] = make_uint4(qs[k], qid[k], qe[k], tid[k]);   // qns = qid<<32 | qs ; qe ; tn
-		r[1] = make_uint4(ts[k], te[k], mlrev, b31);       // ts ; te ; ml|rev ; bl|del=0
+		r[0] = make_uint4(qs, qid[k], qe, tid[k]);   // qns = qid<<32 | qs ; qe ; tn
+		r[1] = make_uint4(ts, te, mlrev, b31);       // ts ; te ; ml|rev ; bl|del=0
 		if (cnt[k] == 2) {
-			r[2] = make_uint4(ts[k], tid[k], te[k], qid[k]);
-			r[3] = make_uint4(qs[k], qe[k], mlrev, b31);
+			r[2] = make_uint4(ts, tid[k], te, qid[k]);
+			r[3] = make_uint4(qs, qe, mlrev, b31);
 		}
 	}
 	if (threadIdx.x == 0 && tbase < L && tbase + EM_TILE >= L) *d_total = p0 + s_row[4 * EM_ROWS]; // the last tile: its end is the total
