@@ -20,6 +20,7 @@ INPUTS = {  # name -> pafgen arguments (all arc-tie-free: checked when the golde
     "lognormal": dict(reads=3000, lines=80000, seed=41, extra=[]),
     "fixed": dict(reads=2500, lines=70000, seed=42, extra=["-L", "fixed"]),
     "noisy": dict(reads=4000, lines=90000, seed=63, extra=["-L", "uniform", "-d", "0.35", "-x", "0.03"]),
+    "longnames": dict(reads=3000, lines=80000, seed=41, extra=["-N", "m64011_190830_220126/"]),  # names as real PacBio / ONT files carry them (the dictionary compares text)
 }
 
 EXTRA_ARGS = [["-1"], ["-2", "-p", "sg"], ["-b"], ["-R"], ["-R", "-p", "paf"], ["-R", "-h", "4000", "-p", "bed"], ["-c", "2", "-s", "1500", "-h", "500", "-I", "0.7", "-g", "500", "-e", "3", "-d", "30000"],

@@ -67,7 +67,8 @@ def _adversarial(path, seed=5):
 
 def test_ingest_clean_inputs(tmpdir_s):
     ctx = ma.Ctx(0)
-    for reads, lines, seed, extra in ((3000, 80000, 41, []), (20000, 1000000, 3, ["-L", "uniform", "-d", "0.2"]), (50, 200, 9, [])):
+    for reads, lines, seed, extra in ((3000, 80000, 41, []), (20000, 1000000, 3, ["-L", "uniform", "-d", "0.2"]), (50, 200, 9, []),
+                                      (3000, 80000, 42, ["-N", "m64011_190830_220126/"]), (20000, 1000000, 4, ["-N", "m64011_190830_220126/", "-j", "20", "-b", "0.1", "-t"])):  # names of the length real files carry: the text-comparing dictionary, the hashed keys
         paf = R.pafgen(os.path.join(tmpdir_s, "gi_%d.paf" % seed), reads, lines, seed, extra)
         assert _same_as_host(ctx, paf) > 0
         _same_as_host(ctx, paf, bi_dir=False)

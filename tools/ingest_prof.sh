@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 P=/tmp/ingest_prof.paf
-[ -f $P ] || miniasm_amd/bin/pafgen -r ${READS:-2000000} -n ${LINES:-100000000} -s 2 -o $P 2>/dev/null
+[ -f $P ] || miniasm_amd/bin/pafgen -r ${READS:-2000000} -n ${LINES:-100000000} -s 2 $GENEXTRA -o $P 2>/dev/null
 cat > /tmp/ingest_prof.py <<'PY'
 import sys, time
 sys.path.insert(0, '/root/repo')

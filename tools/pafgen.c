@@ -16,6 +16,8 @@
  *     -j K   every coordinate of a line (qs, qe, ts, te) and its block length moved independently by up to +-K bp (alignment ends are not exact projections),
  *            so equal sort keys and equal (u,len) arc keys turn up by chance all over the file;
  *     -b F   a fraction F of the pairs is listed in BOTH directions (a line in either read's block, each with its own jitter);
+ *     -N P   read names are P followed by the read's number and "/ccs" (default: "r" and the bare number): -N m64011_190830_220126/ gives names of the length real
+ *            PacBio / ONT files carry (the device dictionary keys names of up to 8 bytes by their bytes and compares the text of longer ones);
  *     -t     the lines are grouped by TARGET (the roles of the two reads swapped when a line is written): a query's lines are scattered over the file,
  *            as in a PAF sorted by target -- the hit sort cannot take runs of one query's records.
  *
@@ -58,12 +60,21 @@ static int cmp_u64(const void *a, const void *b)
 	return x < y ? -1 : x > y;
 }
 
+static const char *g_name_prefix; /* -N */
 /* fast unsigned -> decimal */
 static inline char *put_u32(char *p, uint32_t x)
 {
 	char tmp[12]; int n = 0;
 	do { tmp[n++] = '0' + x % 10; x /= 10; } while (x);
 	while (n) *p++ = tmp[--n];
+	return p;
+}
+static inline char *put_name(char *p, uint32_t x)
+{
+	if (g_name_prefix == 0) { *p++ = 'r'; return put_u32(p, x); }
+	{ const char *q = g_name_prefix; while (*q) *p++ = *q++; }
+	p = put_u32(p, x);
+	*p++ = '/'; *p++ = 'c'; *p++ = 'c'; *p++ = 's';
 	return p;
 }
 
@@ -74,6 +85,7 @@ typedef struct {
 	double mean, sigma, dropout, false_frac, lowid_frac;
 	int genome_order;
 	uint32_t jitter; double both_frac; int by_target;
+	const char *name_prefix;
 } opt_t;
 static opt_t g_o;
 
@@ -123,10 +135,10 @@ static char *emit(char *p, const gread_t *a, const gread_t *b, uint32_t gs, uint
 	f = (h >> 11) * (1.0 / 9007199254740992.0);
 	f = low_id ? 0.01 + 0.08 * f : 0.08 + 0.22 * f;
 	ml = (uint32_t)(bl * f);
-	*p++ = 'r'; p = put_u32(p, a->name); *p++ = '\t';
+	p = put_name(p, a->name); *p++ = '\t';
 	p = put_u32(p, a->len); *p++ = '\t'; p = put_u32(p, qs); *p++ = '\t'; p = put_u32(p, qe); *p++ = '\t';
 	*p++ = a->strand == b->strand ? '+' : '-'; *p++ = '\t';
-	*p++ = 'r'; p = put_u32(p, b->name); *p++ = '\t';
+	p = put_name(p, b->name); *p++ = '\t';
 	p = put_u32(p, b->len); *p++ = '\t'; p = put_u32(p, ts); *p++ = '\t'; p = put_u32(p, te); *p++ = '\t';
 	p = put_u32(p, ml); *p++ = '\t'; p = put_u32(p, bl); *p++ = '\t';
 	*p++ = '2'; *p++ = '5'; *p++ = '5'; *p++ = '\n';
@@ -142,10 +154,10 @@ static char *emit_false(char *p, const gread_t *a, const gread_t *b, uint64_t h)
 	qs = a->len - x, qe = a->len;
 	if (!rev) ts = 0, te = x; else ts = b->len - x, te = b->len;
 	ml = (uint32_t)(x * (0.08 + 0.22 * ((h >> 11 & 0xfffff) / 1048576.0)));
-	*p++ = 'r'; p = put_u32(p, a->name); *p++ = '\t';
+	p = put_name(p, a->name); *p++ = '\t';
 	p = put_u32(p, a->len); *p++ = '\t'; p = put_u32(p, qs); *p++ = '\t'; p = put_u32(p, qe); *p++ = '\t';
 	*p++ = rev ? '-' : '+'; *p++ = '\t';
-	*p++ = 'r'; p = put_u32(p, b->name); *p++ = '\t';
+	p = put_name(p, b->name); *p++ = '\t';
 	p = put_u32(p, b->len); *p++ = '\t'; p = put_u32(p, ts); *p++ = '\t'; p = put_u32(p, te); *p++ = '\t';
 	p = put_u32(p, ml); *p++ = '\t'; p = put_u32(p, x); *p++ = '\t';
 	*p++ = '2'; *p++ = '5'; *p++ = '5'; *p++ = '\n';
@@ -179,7 +191,7 @@ int main(int argc, char *argv[])
 	memset(&o, 0, sizeof(o));
 	o.n_reads = 2000; o.n_lines = 50000; o.seed = 1; o.model = 0; o.mean = 8000.; o.sigma = .5;
 	o.len_min = 2500; o.len_max = 60000; o.min_ovlp = 2000;
-	while ((c = getopt(argc, argv, "r:n:s:L:m:S:d:x:i:o:gl:M:O:q:j:b:t")) >= 0) {
+	while ((c = getopt(argc, argv, "r:n:s:L:m:S:d:x:i:o:gl:M:O:q:j:b:tN:")) >= 0) {
 		if (c == 'r') o.n_reads = atol(optarg);
 		else if (c == 'n') o.n_lines = atoll(optarg);
 		else if (c == 's') o.seed = atoll(optarg);
@@ -198,8 +210,10 @@ int main(int argc, char *argv[])
 		else if (c == 'j') o.jitter = atol(optarg);
 		else if (c == 'b') o.both_frac = atof(optarg);
 		else if (c == 't') o.by_target = 1;
+		else if (c == 'N') o.name_prefix = optarg;
 	}
 	g_o = o;
+	g_name_prefix = o.name_prefix && strlen(o.name_prefix) < 200 ? o.name_prefix : 0;
 	if (o.n_reads < 2) { fprintf(stderr, "pafgen: need >= 2 reads\n"); return 1; }
 	sm_state = o.seed * 0x2545F4914F6CDD1DULL + 12345;
 
