@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void k_paf_bl_fill(const uint32_t *__restrict_
 #define PAF_OVER 960u         // bytes in front of a tile that are staged with it
 #define PAF_BGRP 12           // log2 of the granules per group of the "last newline" look-up
 #define PF_ODD 0x80u          // flags: the line waits for k_paf_parse_odd
-#define PF_QCONT 0x10u        // flags: stored line whose (short) query name equals that of the stored line in front of it
+#define PF_QCONT 0x10u        // flags: stored line whose query name (short or long) equals that of the stored line in front of it
 #define PC_LONG CT_NSHORT     // stored lines with a name that is not 1..8 bytes
 #define PC_ODD CT_NASYMM
 
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256, PAF_TILE_WAVES) void k_paf_parse_tile(const Ti
 			const uint32_t r = base + threadIdx.x;
 			const bool act = r < tot;
 			const uint32_t i = line0 + r;
-			uint32_t fl = 0, mine = 0;
+			uint32_t fl = 0, mine = 0, x_ps = 0, x_qlen = 0; // (x_*: where this lane's query name stands in LDS and how long it is, for the lane above)
 			uint64_t hq = 0, ht = 0;
 			if (act) {
 				const uint32_t pe = s_lend[1u + threadIdx.x], ps = s_lend[threadIdx.x] + 1u;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256, PAF_TILE_WAVES) void k_paf_parse_tile(const Ti
 						if (pass) {
 							const uint32_t lng = !key_is_short(qlen) || !key_is_short(tlen);
 							c_long += lng;
-							mine = key_is_short(qlen);
+							mine = 1; x_ps = ps; x_qlen = qlen;
 							const uint64_t mq = qs > ts ? qs : ts;
 							c_mq = mq > c_mq ? mq : c_mq;
 						}
@@ -576,7 +576,15 @@ __global__ __launch_bounds__(256, PAF_TILE_WAVES) void k_paf_parse_tile(const Ti
 			}
 			// does the line continue the run of one query name?  (the lane below holds the line in front; lane 0 of a wave starts a run)
 			const uint32_t p_mine = wv_prev_lane_u32(mine, 0u, lane), p_lo = wv_prev_lane_u32((uint32_t)hq, 0u, lane), p_hi = wv_prev_lane_u32((uint32_t)(hq >> 32), 0u, lane);
-			if (mine && p_mine && p_lo == (uint32_t)hq && p_hi == (uint32_t)(hq >> 32)) fl |= PF_QCONT;
+			const uint32_t p_len = wv_prev_lane_u32(x_qlen, 0u, lane), p_ps = wv_prev_lane_u32(x_ps, 0u, lane);
+			bool cont = mine && p_mine && p_len == x_qlen && p_lo == (uint32_t)hq && p_hi == (uint32_t)(hq >> 32);
+			if (cont && !key_is_short(x_qlen)) // a hashed key: the bytes decide (both names are in LDS: the one place where comparing them costs nothing)
+				for (uint32_t k = 0; k < x_qlen && cont; k += 8) {
+					const uint32_t rem = x_qlen - k;
+					const uint64_t m = rem >= 8 ? ~0ull : (1ull << (8u * rem)) - 1ull;
+					cont = ((lds_get8(tw, x_ps + k) ^ lds_get8(tw, p_ps + k)) & m) == 0;
+				}
+			if (cont) fl |= PF_QCONT;
 			if (act) o.flags[i] = (uint8_t)fl;
 			__syncthreads();
 			if (base + 256u < tot) { if (threadIdx.x == 0) s_lend[0] = s_lend[256]; __syncthreads(); }
@@ -645,15 +653,19 @@ __device__ __forceinline__ bool name_eq(const unsigned char *__restrict__ a, con
 // (Round 3 tried 32-byte slots that carry the first 16 bytes of the name, so that the sector that answers a probe also settles the comparison: with
 // agent-scope accesses to keep the eight L2s honest and a table four times the bytes it was SLOWER -- 17.0 against 11.5 ms per 100 M lines
 // (profiles/r03_experiments.txt) -- and was taken out again.)
-// One thread per stored line: query name, then target name.  Slot word = tag(32) | occurrence of the name's first
-// inserter; tmin[slot] = smallest occurrence (2*line + column) of the name = its first appearance in the file.
-// info[slot] = text offset << 24 | length of the slot's name, written by the inserter right after its CAS: a prober that finds it compares
-// the bytes after ONE dependent fetch; one that does not see it yet (the store is not ordered with the CAS, a stale L1 line) goes the
-// long way through the occurrence (line start, column offset, length: three more random fetches) -- both ways read the same bytes.
+// One thread per stored line: query name, then target name.  A slot is two words: w0 = tag(32) | an occurrence (2*line + column) of the slot's name -- the
+// claimant's at first, the SMALLEST seen so far in the end = the name's first appearance in the file --, info = text offset << 24 | length of the slot's name,
+// written by the claimant right after its CAS: a prober that finds it compares the bytes after ONE dependent fetch; one that does not see it yet (the store is
+// not ordered with the CAS, a stale line) goes the long way through the occurrence (line start, column offset, length: three more random fetches) -- both ways
+// read the same bytes.
 #define PAF_INFO_LEN_BITS 24
 // the slot of one name occurrence (probe, insert if new); 0xffffffff: the probe sequence ran out
+// (Round 6: the slot's two words sit side by side -- one 16-byte fetch answers "whose slot" and "where is its text" --, and the low half of the first word is the SMALLEST
+// occurrence seen so far, kept by a 64-bit atomicMin (every writer of a slot carries the slot's tag in the high half): the separate info and tmin arrays, two of a
+// probe's five random fetches, are gone.  tmin[] is written once, behind the pass (k_dict_exact_tmin), for the code that ranks the names.)
+struct __attribute__((aligned(16))) XSlot { unsigned long long w0, info; };
 __device__ __forceinline__ uint32_t dict_probe(const unsigned char *__restrict__ text, const uint64_t *__restrict__ lstart, const PafCols &o,
-                                               unsigned long long *__restrict__ tab, uint32_t *__restrict__ tmin, unsigned long long *__restrict__ info, uint32_t mask,
+                                               XSlot *__restrict__ tab, uint32_t mask,
                                                uint64_t h, uint32_t len, uint32_t occ, uint64_t noff, uint32_t *fresh)
 {
 	const unsigned char *nm = text + noff;
@@ -661,31 +673,38 @@ __device__ __forceinline__ uint32_t dict_probe(const unsigned char *__restrict__
 	const uint32_t tag = (uint32_t)(hm >> 32);
 	uint32_t s = (uint32_t)hm & mask;
 	for (uint32_t probe = 0; probe < PAF_PROBE_LIMIT; ++probe, s = (s + 1) & mask) {
-		unsigned long long e = tab[s];
+		const uint4 raw = *(const uint4*)&tab[s];
+		unsigned long long e = (unsigned long long)raw.y << 32 | raw.x, inf = (unsigned long long)raw.w << 32 | raw.z;
 		if (e == PAF_EMPTY) {
-			e = atomicCAS(&tab[s], PAF_EMPTY, (unsigned long long)tag << 32 | occ);
+			e = atomicCAS(&tab[s].w0, PAF_EMPTY, (unsigned long long)tag << 32 | occ);
 			if (e == PAF_EMPTY) {
-				if (len < (1u << PAF_INFO_LEN_BITS) && noff < (1ull << (64 - PAF_INFO_LEN_BITS))) info[s] = noff << PAF_INFO_LEN_BITS | len;
-				atomicMin(&tmin[s], occ); ++*fresh;
+				if (len < (1u << PAF_INFO_LEN_BITS) && noff < (1ull << (64 - PAF_INFO_LEN_BITS))) tab[s].info = noff << PAF_INFO_LEN_BITS | len;
+				++*fresh;
 				return s;
 			}
+			inf = PAF_EMPTY; // (somebody else's slot by now: its second word was not in the fetch)
 		}
 		if ((uint32_t)(e >> 32) == tag) {
-			const unsigned long long inf = info[s];
 			bool same;
 			if (inf != PAF_EMPTY) same = (uint32_t)(inf & ((1u << PAF_INFO_LEN_BITS) - 1)) == len && name_eq(nm, text + (inf >> PAF_INFO_LEN_BITS), len);
-			else {
+			else { // the long way, through an occurrence of the slot's name (any will do: the low half only ever moves to another occurrence of the same name)
 				const uint32_t r = (uint32_t)e, rl = r >> 1;
 				const uint32_t rlen = (r & 1) ? o.tlen[rl] : o.qlen[rl];
 				same = rlen == len && name_eq(nm, text + lstart[rl] + ((r & 1) ? o.tnoff[rl] : 0u), len);
 			}
 			if (same) {
-				if (tmin[s] > occ) atomicMin(&tmin[s], occ);
+				if ((uint32_t)e > occ) atomicMin(&tab[s].w0, (unsigned long long)tag << 32 | occ);
 				return s;
 			}
 		}
 	}
 	return 0xffffffffu;
+}
+// what the rest of the dictionary code reads: tmin[slot] = first appearance of the slot's name (~0: free slot)
+__global__ __launch_bounds__(256) void k_dict_exact_tmin(const XSlot *__restrict__ tab, uint32_t cap, uint32_t *__restrict__ tmin)
+{
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s < cap) { const unsigned long long e = tab[s].w0; tmin[s] = e == PAF_EMPTY ? 0xffffffffu : (uint32_t)e; }
 }
 
 // A PAF file lists a query's overlaps together (the reference's own all-vs-all pipeline writes them so; so does every overlapper that works query by
@@ -694,14 +713,14 @@ __device__ __forceinline__ uint32_t dict_probe(const unsigned char *__restrict__
 // head of its run: its occurrence number is the run's smallest, so tmin is right as well).  Round 2 probed once per name occurrence: 200 M probes and
 // 68 GB of fetches for 100 M lines; the query column now costs one probe per run and wave.  Target names change from line to line and probe as before.
 __global__ __launch_bounds__(256) void k_dict_insert(const unsigned char *__restrict__ text, const uint64_t *__restrict__ lstart, uint32_t L, PafCols o,
-                                                      unsigned long long *__restrict__ tab, uint32_t *__restrict__ tmin, unsigned long long *__restrict__ info,
-                                                      uint32_t mask, unsigned long long *__restrict__ ctr)
-{
+                                                      XSlot *__restrict__ tab, uint32_t mask, unsigned long long *__restrict__ ctr, int runs_flagged)
+{ // runs_flagged: the tile parser compared every line's query name with the line in front (PF_QCONT, bytes in LDS); else (round 5's parser) it is done here, on the text
 	uint32_t fail = 0, fresh = 0;
 	const unsigned lane = threadIdx.x & 63;
 	for (uint32_t base = blockIdx.x * 256u; base < L; base += gridDim.x * 256u) { // wave-uniform: the lanes talk to each other below
 		const uint32_t i = base + threadIdx.x;
-		const bool stored = i < L && (o.flags[i] & 2);
+		const uint32_t fl = i < L ? o.flags[i] : 0u;
+		const bool stored = (fl & 2u) != 0;
 		const uint64_t ls = stored ? lstart[i] : 0;
 		const uint64_t hq = stored ? o.hq[i] : 0;
 		const uint32_t qlen = stored ? o.qlen[i] : 0;
@@ -710,9 +729,9 @@ __global__ __launch_bounds__(256) void k_dict_insert(const unsigned char *__rest
 		const uint32_t qlen_l = __shfl_up(qlen, 1, 64);
 		const uint64_t ls_l = (uint64_t)__shfl_up((uint32_t)(ls >> 32), 1, 64) << 32 | __shfl_up((uint32_t)ls, 1, 64);
 		const int stored_l = __shfl_up((int)stored, 1, 64);
-		const bool cont = stored && lane > 0 && stored_l && hq_l == hq && qlen_l == qlen && name_eq(text + ls, text + ls_l, qlen);
+		const bool cont = stored && lane > 0 && stored_l && (runs_flagged ? (fl & PF_QCONT) != 0 : hq_l == hq && qlen_l == qlen && name_eq(text + ls, text + ls_l, qlen));
 		uint32_t qslot = 0xffffffffu;
-		if (stored && !cont) qslot = dict_probe(text, lstart, o, tab, tmin, info, mask, hq, qlen, i * 2u, ls, &fresh);
+		if (stored && !cont) qslot = dict_probe(text, lstart, o, tab, mask, hq, qlen, i * 2u, ls, &fresh);
 		const unsigned long long heads = __ballot(stored && !cont);
 		{ // a continuing lane: the slot of the nearest head to its left (there is one: lane 0 never continues)
 			const unsigned long long left = heads & ((1ull << lane) - 1ull);
@@ -721,7 +740,7 @@ __global__ __launch_bounds__(256) void k_dict_insert(const unsigned char *__rest
 			if (cont) qslot = got;
 		}
 		if (stored) {
-			const uint32_t tslot = dict_probe(text, lstart, o, tab, tmin, info, mask, o.ht[i], o.tlen[i], i * 2u + 1u, ls + o.tnoff[i], &fresh);
+			const uint32_t tslot = dict_probe(text, lstart, o, tab, mask, o.ht[i], o.tlen[i], i * 2u + 1u, ls + o.tnoff[i], &fresh);
 			if (qslot == 0xffffffffu || tslot == 0xffffffffu) fail = 1;
 			o.qslot[i] = qslot; o.tslot[i] = tslot;
 		}
@@ -1298,20 +1317,16 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 		if (const char *e = getenv("MA_DICT_CAP_LOG2")) { int l2 = atoi(e); if (l2 >= 4 && l2 <= 31) cap = 1u << l2; } // tests: force the growth path
 		const bool short_names = !old_path && n_long == 0 && !getenv("MA_DICT_EXACT_TEXT"); // every name is its own key: no text compared (k_dict_insert_short)
 		for (int attempt = 0;; ++attempt) {
-			CHK(dev_reserve(c, b->tab, (size_t)cap * (short_names ? 16 : 8))); CHK(dev_reserve(c, b->tmin, (size_t)cap * 4)); CHK(dev_reserve(c, b->slot_id, (size_t)cap * 4));
+			CHK(dev_reserve(c, b->tab, (size_t)cap * 16)); CHK(dev_reserve(c, b->tmin, (size_t)cap * 4)); CHK(dev_reserve(c, b->slot_id, (size_t)cap * 4));
 			CHK(ctr_zero(c));
 			if (short_names) {
 				HIPCHK(hipMemsetAsync(b->tab.p, 0, (size_t)cap * 16, c->st));
 				ProfScope ps(c, "k_dict_insert", 2.0 * 40.0 * (double)n_pass);
 				hipLaunchKernelGGL(k_dict_insert_short, dim3(grid_for(L, 256, 8192)), dim3(256), 0, c->st, o, L, (DSlot*)b->tab.p, cap - 1, ctr);
 			} else {
-				CHK(dev_reserve(c, b->info, (size_t)cap * 8));
-				HIPCHK(hipMemsetAsync(b->tab.p, 0xff, (size_t)cap * 8, c->st));
-				HIPCHK(hipMemsetAsync(b->info.p, 0xff, (size_t)cap * 8, c->st));
-				HIPCHK(hipMemsetAsync(b->tmin.p, 0xff, (size_t)cap * 4, c->st));
+				HIPCHK(hipMemsetAsync(b->tab.p, 0xff, (size_t)cap * 16, c->st));
 				ProfScope ps(c, "k_dict_insert", 2.0 * 40.0 * (double)n_pass);
-				hipLaunchKernelGGL(k_dict_insert, dim3(grid_for(L, 256, 8192)), dim3(256), 0, c->st, text, (const uint64_t*)P<uint64_t>(b->lstart), L, o,
-				                   P<unsigned long long>(b->tab), P<uint32_t>(b->tmin), P<unsigned long long>(b->info), cap - 1, ctr);
+				hipLaunchKernelGGL(k_dict_insert, dim3(grid_for(L, 256, 8192)), dim3(256), 0, c->st, text, (const uint64_t*)P<uint64_t>(b->lstart), L, o, (XSlot*)b->tab.p, cap - 1, ctr, old_path ? 0 : 1);
 			}
 			CHK(ctr_fetch(c));
 			const uint64_t distinct = c->h_ctr[PC_DISTINCT];
@@ -1322,6 +1337,7 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 			cap = want < cap_max ? want : cap_max;
 		}
 		if (short_names) hipLaunchKernelGGL(k_dict_short_tmin, dim3(grid_for(cap, 256)), dim3(256), 0, c->st, (const DSlot*)b->tab.p, cap, P<uint32_t>(b->tmin));
+		else hipLaunchKernelGGL(k_dict_exact_tmin, dim3(grid_for(cap, 256)), dim3(256), 0, c->st, (const XSlot*)b->tab.p, cap, P<uint32_t>(b->tmin));
 		if (no_cont) { // hit.c:38-68 + hit.c:86
 			CHK(dev_reserve(c, b->excl, (size_t)cap + 16));
 			HIPCHK(hipMemsetAsync(b->excl.p, 0, cap, c->st));
