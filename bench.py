@@ -118,19 +118,7 @@ def cli_digest_leg(ma, name, workdir):
         if pr.returncode != 0:
             log("leg %s: the command line failed:" % name, (err[0] if err else b"")[-300:])
             return None
-        log_txt = (err[0] if err else b"").decode(errors="replace")
-        laps = {}  # where the run spent its time, from its own [T::...] lines (MA_PIPE_TIMING=2)
-        for key, pat in (("hip_runtime_s", r"\[T::init\].*HIP runtime ([0-9.]+) s"), ("file_to_hbm_s", r"\[T::ingest_gpu\] load ([0-9.]+) s"), ("parse_s", r"\[T::ingest_gpu\] parse ([0-9.]+)"),
-                         ("sg_gen_incl_tie_repair_ms", r"\[T::head\] sg_gen\s+([0-9.]+) ms"), ("tie_walk_host_ms", r"walk: host\s+([0-9.]+) ms"), ("push_order_ms", r"push order \(all of it\)\s+([0-9.]+) ms"),
-                         ("pipeline_head_ms", r"\[T::pipeline\] head ([0-9.]+) ms"), ("pipeline_tail_ms", r"\[T::pipeline\] head [0-9.]+ ms\s+tail ([0-9.]+) ms"), ("real_time_s", r"Real time: ([0-9.]+) sec")):
-            mm = re.search(pat, log_txt)
-            if mm:
-                laps[key] = float(mm.group(1))
-        mt = re.search(r"\[T::ties\] (\d+) arc tie groups \((\d+) arcs\), (\d+) push conflicts(?: \((\d+) of them in sight)?", log_txt)
-        if mt:
-            laps["arc_tie_groups"], laps["push_conflicts"] = int(mt.group(1)), int(mt.group(3))
-            if mt.group(4) is not None:
-                laps["push_conflicts_in_sight_of_the_arc_sort"] = int(mt.group(4))
+        laps = cli_laps((err[0] if err else b"").decode(errors="replace"))
         return {"value": cfg["lines"] / wall, "unit": "overlaps/s", "wall_s": round(wall, 3), "overlaps": cfg["lines"], "reads": cfg["reads"], "pafgen": cfg, "paf_bytes": gold["paf_bytes"],
                 "text_is_the_recorded_one": same_text, "gfa_md5": h.hexdigest(), "gfa_bytes": n, "ref_md5": gold["gfa_md5"], "ref_bytes": gold["gfa_bytes"],
                 "gfa_md5_matches_reference": same_text and (h.hexdigest(), n) == (gold["gfa_md5"], gold["gfa_bytes"]),
@@ -142,6 +130,24 @@ def cli_digest_leg(ma, name, workdir):
             os.remove(paf)  # 30 GB
         except OSError:
             pass
+
+
+def cli_laps(log_txt):
+    """where a command-line run spent its time, from its own [T::...] lines (MA_PIPE_TIMING set)"""
+    laps = {}
+    for key, pat in (("hip_runtime_s", r"\[T::init\].*HIP runtime ([0-9.]+) s"), ("context_s", r"\[T::init\].*pinned mailbox\) ([0-9.]+) s"), ("file_to_hbm_s", r"\[T::ingest_gpu\] load ([0-9.]+) s"),
+                     ("parse_s", r"\[T::ingest_gpu\] parse ([0-9.]+)"), ("dictionary_s", r"dictionary\+release ([0-9.]+) s"),
+                     ("sg_gen_incl_tie_repair_ms", r"\[T::head\] sg_gen\s+([0-9.]+) ms"), ("tie_walk_host_ms", r"walk: host\s+([0-9.]+) ms"), ("push_order_ms", r"push order \(all of it\)\s+([0-9.]+) ms"),
+                     ("pipeline_head_ms", r"\[T::pipeline\] head ([0-9.]+) ms"), ("pipeline_tail_ms", r"\[T::pipeline\] head [0-9.]+ ms\s+tail ([0-9.]+) ms"), ("real_time_s", r"Real time: ([0-9.]+) sec")):
+        mm = re.search(pat, log_txt)
+        if mm:
+            laps[key] = float(mm.group(1))
+    mt = re.search(r"\[T::ties\] (\d+) arc tie groups \((\d+) arcs\), (\d+) push conflicts(?: \((\d+) of them in sight)?", log_txt)
+    if mt:
+        laps["arc_tie_groups"], laps["push_conflicts"] = int(mt.group(1)), int(mt.group(3))
+        if mt.group(4) is not None:
+            laps["push_conflicts_in_sight_of_the_arc_sort"] = int(mt.group(4))
+    return laps
 
 
 def run_reference(paf, out_path, runs=1):
@@ -350,6 +356,7 @@ def main():
     ap.add_argument("--no-text", action="store_true", help="skip the text-resident leg (device-side parse inside the step)")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (cfg2, tie-rich input, CLI end to end)")
     ap.add_argument("--no-overlap", action="store_true", help="run each pass's host tail before the next pass's device part starts")
+    ap.add_argument("--tail-one-stage", action="store_true", help="A/B: the tail of a batch (device part, then text) on ONE worker thread, as in round 5; default: two stages on two threads")
     ap.add_argument("--no-tail-ctx", action="store_true", help="keep the latency-bound rest of a batch (cleaners, unitigs, downloads) on the context that runs the hit passes.  "
                     "Default: it moves to a second context on the same GPU and runs beside the next batch's hit passes (mahip_tail_handoff; round 3, measured: "
                     "cfg4 20.0 -> 19.2 ms per step, cfg2 3.23 -> 2.79 ms)")
@@ -410,14 +417,15 @@ def main():
     if rank == 0 and world == 1 and want_leg("e2e"):
         try:  # the command line, process start -> GFA on disk (north_star's ">= 10x reference wall-clock" is about this)
             outp = os.path.join(args.workdir, "cli_%s.gfa" % cfg_name_early)
-            walls = []
+            walls, laps_all = [], []
             for _ in range(3):
                 with open(outp, "wb") as fo:
                     t0 = time.perf_counter()
-                    r = subprocess.run([ma.CLI_PATH, paf], stdout=fo, stderr=subprocess.PIPE, timeout=600)
+                    r = subprocess.run([ma.CLI_PATH, paf], stdout=fo, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, MA_PIPE_TIMING="1"))  # (a dozen stamps on stderr)
                     walls.append(time.perf_counter() - t0)
                 assert r.returncode == 0, r.stderr[-300:]
-            early_e2e = {"walls": walls, "md5": md5_pair(open(outp, "rb").read())[0]}
+                laps_all.append(cli_laps(r.stderr.decode(errors="replace")))
+            early_e2e = {"walls": walls, "laps": laps_all[walls.index(min(walls))], "md5": md5_pair(open(outp, "rb").read())[0]}
         except Exception as e:
             log("e2e leg failed:", e)
     if rank == 0 and world == 1 and want_leg("cfg5") and cfg_name_early == "cfg4":
@@ -481,7 +489,9 @@ def main():
             self.out = {"n": 0, "rc": 0, "buf": None}
             self.head_wall, self.tail_wall, self.fetch_wall, self.last_stats = [], [], [], None  # wall time of each head on this rank / of each tail (rank 0)
             self.q = queue.Queue(maxsize=1)  # one batch may wait while another is being finished
-            self.worker = None
+            self.q_text = queue.Queue(maxsize=1)  # second stage of the tail: the device part of batch k+1 (second context) runs beside the text of batch k (host threads)
+            self.worker, self.worker_text = None, None
+            self.fetch2_wall, self.text_wall = [], []
             # --tail-ctx: the device tail of a batch (graph cleaning, unitigs, downloads -- many small launches and counter fetches) moves to a
             # second context and to the worker thread; this thread goes straight on to the next batch's hit passes
             self.ctx2 = ma.Ctx(local) if (args.tail_ctx and overlap and rank == 0) else None
@@ -489,6 +499,9 @@ def main():
             if overlap and rank == 0:
                 self.worker = threading.Thread(target=self._work, daemon=True)
                 self.worker.start()
+                if self.ctx2 and not args.tail_one_stage:
+                    self.worker_text = threading.Thread(target=self._work_text, daemon=True)
+                    self.worker_text.start()
 
         def _finish(self, job, t_start=None):
             b, l = vp(0), C.c_size_t(0)
@@ -512,14 +525,34 @@ def main():
                         finally:
                             self.ctx2_free.release()
                         assert job
+                        self.fetch2_wall.append(time.perf_counter() - t_tail)
                     if job is not None:
-                        self._finish(job, t_tail)
+                        if self.worker_text:
+                            self.q_text.put((job, t_tail))
+                        else:
+                            self._finish(job, t_tail)
                 except Exception as e:  # never leave the fence waiting on a dead worker
                     self.out["rc"] = self.out["rc"] or -1
                     log("host tail failed:", e)
                 finally:
                     self.q.task_done()
                 if job is None:
+                    return
+
+        def _work_text(self):
+            while True:
+                item = self.q_text.get()
+                try:
+                    if item is not None:
+                        t0 = time.perf_counter()
+                        self._finish(*item)
+                        self.text_wall.append(time.perf_counter() - t0)
+                except Exception as e:
+                    self.out["rc"] = self.out["rc"] or -1
+                    log("host tail (text) failed:", e)
+                finally:
+                    self.q_text.task_done()
+                if item is None:
                     return
 
         def step(self):
@@ -567,14 +600,16 @@ def main():
             L.ma_pipeline_last_laps(C.byref(laps))
             mean = lambda a: round(sum(a) / len(a) * 1e3, 3) if a else None
             return {"head_wall_ms": mean(self.head_wall), "tail_wall_ms": mean(self.tail_wall) if self.tail_wall else mean(self.fetch_wall),
+                    "tail_device_stage_ms": mean(self.fetch2_wall), "tail_text_stage_ms": mean(self.text_wall),
                     "tail_last_pass_ms": {"survivors_names_intervals_to_host": round(laps[0], 3), "device_cleaners": round(laps[1], 3), "unitigs_to_host": round(laps[2], 3),
                                           "text": round(laps[3], 3), "text_format": round(laps[4], 3), "text_assemble": round(laps[5], 3)},
                     "note": "wall clocks on the host: head = ma_pipeline_head (sort .. reduced graph, ends with a counter fetch); tail = second context + worker thread (its device part waits for "
-                            "the GPU beside the next pass's head); a pass costs max(head, tail) when both are kept busy"}
+                            "the GPU beside the next pass's head), in two stages on two threads (device part of pass k+1 beside the text of pass k); a stream of passes costs max(head, tail device stage, tail text stage) each"}
 
         def fence(self):
             if self.worker:
                 self.q.join()  # every host tail handed over so far is complete
+                self.q_text.join()
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
@@ -598,6 +633,10 @@ def main():
                 self.q.put(None)
                 self.worker.join()
                 self.worker = None
+            if self.worker_text:
+                self.q_text.put(None)
+                self.worker_text.join()
+                self.worker_text = None
             if self.out["buf"]:
                 L.free_buf(self.out["buf"])
                 self.out["buf"] = None
@@ -902,6 +941,7 @@ def main():
         best = min(early_e2e["walls"])
         e2e = {"value": W.n_lines / best, "unit": "overlaps/s", "wall_s": best, "wall_s_all": [round(x, 4) for x in early_e2e["walls"]],
                "what": "miniasm_amd/bin/miniasm <file> > out.gfa: process start to GFA on disk, warm page cache, best of 3 back-to-back runs, taken BEFORE this script holds device memory",
+               "laps": early_e2e.get("laps"),
                "gfa_identical": (early_e2e["md5"] == parity["ref_md5"]) if parity else None,
                "gfa_md5_matches_recorded_reference": (early_e2e["md5"] == recorded_reference(cfg_name)["gfa_md5"]) if recorded_reference(cfg_name) else None,
                "vs_reference_wall": (cpu["end_to_end_s"] / best) if cpu else None}
@@ -919,7 +959,7 @@ def main():
                 "BASELINE configs[3]" if cfg_name == "cfg4" else "BASELINE configs[1]" if cfg_name == "cfg2" else cfg_name,
                 args.model, args.seed, W.n_lines, W.n_seq, W.n_all / max(W.n_seq, 1), " (sharded by query-read range)" if world > 1 else "", len(gfa)),
                 "global_overlaps": W.n_lines, "per_gpu_hits": W.n_my,
-                "pipelining": ("device tail (cleaners, unitigs) on a second context + host tail (GFA text) of pass k overlap the hit passes of pass k+1; all K outputs complete inside the timed region" if args.tail_ctx else
+                "pipelining": ("device tail (cleaners, unitigs) on a second context + host tail (GFA text) of pass k overlap the hit passes of pass k+1%s; all K outputs complete inside the timed region" % ("" if args.tail_one_stage else " (and each other: two worker threads)") if args.tail_ctx else
                                "host tail of pass k (GFA text) overlaps the device part of pass k+1; all K outputs complete inside the timed region") if overlap else "none (--no-overlap)",
                 "parallelism": "read-range shards x%d, RCCL all-gather of sub/flags/arcs from C (host/sharded.c)" % world if world > 1 else "single GPU" + (", %d batches in flight" % args.inflight if args.inflight > 1 else "")},
             "gfa_identical": parity["gfa_identical"] if parity else None, "parity": parity,
