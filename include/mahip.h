@@ -125,8 +125,11 @@ typedef struct {
 	uint64_t hit_ties;         /* hits with the same (qid,qs) as their predecessor (only counted when needed, else 0) */
 	int arc_walk, hit_walk;    /* 1 if the reference's arc / hit order was computed on the host for the last graph */
 	int unrepaired;            /* 1 if tie groups exist and the stable order was kept (mode 0, or a shard) */
-	uint64_t push_conflicts_seen; /* of push_conflicts: those the reference's arc sort can turn into a difference (both arcs in a bucket of its radix passes that is
-	                                 * longer than its insertion-sort cut-off AND holds a tie group, csrc/graph.hip); 0 of them => the hit walk is not needed and not done */
+	uint64_t push_conflicts_seen; /* of push_conflicts: those the reference's arc sort can turn into a difference (the two arcs part in a bucket of its radix passes that
+	                                 * is walked and holds a tie group, or in an insertion-sorted one where one of them has a twin, csrc/graph.hip); 0 of them => the hit
+	                                 * walk is not needed and not done */
+	uint64_t hit_walk_reads;      /* hit_walk: reads inside whose hit groups the walk's order was taken (the reads with a conflict in sight; every other read keeps the
+	                                 * stable order); 0 = the whole order was taken */
 } mahip_tie_info_t;
 int mahip_tie_stats(mahip_ctx_t *c, mahip_tie_info_t *out);
 /* hit.c:19-22 ma_hit_sort.  The resident layout is GROUPED by query id (stable LSD radix sort on the id bits -> SoA + group offsets),

@@ -66,7 +66,7 @@ class Asg(C.Structure):  # asg.h:17-23
 
 class TieInfo(C.Structure):  # include/mahip.h: mahip_tie_info_t
     _fields_ = [("arc_tie_groups", C.c_uint64), ("arc_tie_arcs", C.c_uint64), ("push_conflicts", C.c_uint64), ("hit_ties", C.c_uint64),
-                ("arc_walk", C.c_int), ("hit_walk", C.c_int), ("unrepaired", C.c_int), ("push_conflicts_seen", C.c_uint64)]
+                ("arc_walk", C.c_int), ("hit_walk", C.c_int), ("unrepaired", C.c_int), ("push_conflicts_seen", C.c_uint64), ("hit_walk_reads", C.c_uint64)]
 
 
 class ProfRec(C.Structure):

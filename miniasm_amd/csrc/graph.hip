@@ -353,8 +353,11 @@ __global__ __launch_bounds__(256) void k_arc_push_conflicts(const uint64_t *__re
 // pushes first.  asg_arc_sort is an MSD radix sort (ksort.h:149-183): as long as x and y carry the same digit, a level's walk only tells elements apart by their digit,
 // so pushing y before x lands every OTHER element where it landed before and x, y in each other's places.  At the level of their first differing byte they sit in one
 // bucket B (the arcs that share the key bytes above it); there the walk may take another course -- for the elements of B only, and what it leaves open is only the order
-// inside groups of EQUAL keys.  So the swap can change the result only if B holds a tie group; and not even then if B has at most RS_MIN_SIZE = 64 elements, because
-// such a bucket is insertion-sorted (ksort.h:182), stably: equal keys keep the order they came in, which a swap of two arcs with DIFFERENT keys does not touch.  x and y
+// inside groups of EQUAL keys.  So the swap can change the result only if B holds a tie group.  If B has at most RS_MIN_SIZE = 64 elements, it -- or a bucket above it
+// that is as small -- is not walked but insertion-sorted (ksort.h:182), stably: equal keys keep the order they came in.  x and y have come in in each other's places
+// (not as neighbours any more: the walks above do not keep the order of their input), so what the swap can change there is the order of x, or of y, against ANOTHER arc
+// with the same key that came in between the two: visible if x or y belongs to a tie group, invisible otherwise.  (Until the last day of round 6 the rule read "a small
+// bucket never shows a swap of two different keys" -- which forgot that third arc.)  x and y
 // with equal keys are a tie group themselves.  A conflict that fails the test is invisible; if all of them are, the stable push order gives the reference's graph and
 // the walk over the hit keys (seconds at BASELINE configs[4], 0.48 of the 0.94 s of the 50 M-line realistic input) is not needed.  Runs of more than two tied hits: the
 // bucket of any two members lies inside the larger of the buckets of the neighbouring pairs between them (common prefixes are an ultrametric), so neighbours suffice.
@@ -371,8 +374,9 @@ __device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *__restrict__
 	return lo;
 }
 __global__ __launch_bounds__(256) void k_arc_push_conflicts_seen(const uint64_t *__restrict__ skey, const uint32_t *__restrict__ perm, ArcCols a /* push sequence */, const int32_t *__restrict__ map,
-                                                                  const uint64_t *__restrict__ S, const uint32_t *__restrict__ tp, uint32_t n, unsigned long long *__restrict__ ctr)
-{
+                                                                  const uint64_t *__restrict__ S, const uint32_t *__restrict__ tp, uint32_t n, unsigned long long *__restrict__ ctr,
+                                                                  uint32_t *__restrict__ want)
+{ // want: a bit per read id (the ids of the hit keys), set for the reads that have a conflict in sight -- the hit walk's order is taken inside their hit groups only
 	uint32_t cnt = 0;
 	for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x + 1; p < n; p += (size_t)gridDim.x * 256) {
 		if (skey[p] != skey[p - 1]) continue;
@@ -380,7 +384,8 @@ __global__ __launch_bounds__(256) void k_arc_push_conflicts_seen(const uint64_t 
 		uint32_t ua = a.u[ia], ub = a.u[ib];
 		if (map) { ua = (uint32_t)map[ua >> 1] << 1 | (ua & 1); ub = (uint32_t)map[ub >> 1] << 1 | (ub & 1); }
 		const uint64_t ka = (uint64_t)ua << 32 | a.len[ia], kb = (uint64_t)ub << 32 | a.len[ib];
-		if (ka == kb) { ++cnt; continue; }
+		const uint32_t rd = (uint32_t)(skey[p] >> 32);
+		if (ka == kb) { ++cnt; atomicOr(&want[rd >> 5], 1u << (rd & 31)); continue; }
 		const int sh = ((63 - __clzll((long long)(ka ^ kb))) / 8 + 1) * 8; // bits below the shared prefix
 		uint32_t r0 = 0, r1 = n;
 		if (sh < 64) {
@@ -388,7 +393,13 @@ __global__ __launch_bounds__(256) void k_arc_push_conflicts_seen(const uint64_t 
 			r0 = lower_bound_u64(S, n, lo);
 			r1 = hi > lo ? lower_bound_u64(S, n, hi) : n; // (the top bucket ends with the array)
 		}
-		if (r1 - r0 > 64u && tp[r1 - 1] > tp[r0]) ++cnt;
+		bool seen;
+		if (r1 - r0 > 64u) seen = tp[r1 - 1] > tp[r0]; // a walked bucket with a tie group in it
+		else { // insertion-sorted: is x or y one of several arcs with its key?
+			const uint32_t pa = lower_bound_u64(S, n, ka), pb = lower_bound_u64(S, n, kb);
+			seen = (pa + 1 < n && S[pa + 1] == ka) || (pb + 1 < n && S[pb + 1] == kb);
+		}
+		if (seen) { ++cnt; atomicOr(&want[rd >> 5], 1u << (rd & 31)); }
 	}
 	blk_add_u64(&ctr[ST_PUSH_SEEN], cnt);
 }
@@ -1143,6 +1154,7 @@ static int push_stable_order(mahip_ctx *c, size_t m, int *gen, uint64_t *conflic
 static int push_order(mahip_ctx *c, size_t m, bool exact, int *gen, const ArcCols *pushed = nullptr, const ArcCols *sorted = nullptr)
 {
 	uint64_t conf = 0;
+	bool want_known = false; // c->wantb says which reads' hit order matters
 	TieLaps tl(c);
 	CHK(push_stable_order(c, m, gen, &conf));
 	tl.lap("stable push order + conflicts");
@@ -1158,15 +1170,20 @@ static int push_order(mahip_ctx *c, size_t m, bool exact, int *gen, const ArcCol
 		hipLaunchKernelGGL(k_tie_pair_flags, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint64_t*)S, m, P<uint32_t>(c->keep));
 		CHK(scan_exclusive_u32(c, P<uint32_t>(c->keep), P<uint32_t>(c->pos), m, nullptr));
 		HIPCHK(hipMemsetAsync(ctr + ST_PUSH_SEEN, 0, 8, c->st));
+		const size_t want_bytes = ((size_t)c->n_seq / 32 + 2) * 4;
+		CHK(dev_reserve(c, c->wantb, want_bytes));
+		HIPCHK(hipMemsetAsync(c->wantb.p, 0, want_bytes, c->st));
 		hipLaunchKernelGGL(k_arc_push_conflicts_seen, dim3(grid_for(m, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[*gen]), (const uint32_t*)P<uint32_t>(c->val[*gen]),
-		                   *pushed, map, (const uint64_t*)S, (const uint32_t*)P<uint32_t>(c->pos), (uint32_t)m, ctr);
+		                   *pushed, map, (const uint64_t*)S, (const uint32_t*)P<uint32_t>(c->pos), (uint32_t)m, ctr, P<uint32_t>(c->wantb));
 		CHK(ctr_fetch(c));
 		c->tie.push_conflicts_seen = c->h_ctr[ST_PUSH_SEEN];
+		want_known = true;
 		tl.lap("conflicts the arc sort can see");
 	}
 	if (exact && c->tie.push_conflicts_seen) {
 		const int g_keep = *gen; (void)g_keep;
-		CHK(hits_reference_rank(c, false)); // uses key[]/val[] as scratch
+		static const bool walk_all = getenv("MA_TIE_WALK_ALL") && atoi(getenv("MA_TIE_WALK_ALL")) != 0; // A/B handle: the whole hit order although only some reads' is needed
+		CHK(hits_reference_rank(c, false, want_known && !walk_all)); // uses key[]/val[] as scratch
 		for (int k = 0; k < 2; ++k) { CHK(dev_reserve(c, c->key[k], (m + 1) * 8)); CHK(dev_reserve(c, c->val[k], (m + 1) * 4)); }
 		hipLaunchKernelGGL(k_arc_push_keys, dim3(grid_for(m, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->aslot), (const uint32_t*)P<uint32_t>(c->hrank), m,
 		                   P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]));

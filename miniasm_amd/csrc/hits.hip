@@ -1414,9 +1414,26 @@ static int hits_reference_rank_global(mahip_ctx *c)
 
 // c->hrank[slot] = position of the slot's record in the order the reference's ma_hit_sort (hit.c:19-22) leaves the input in.
 // Both orders are sorted by key, so hrank is the identity outside runs of equal keys.
-int hits_reference_rank(mahip_ctx *c, bool collective_ok)
+// stretch of each listed read's hits in the stably sorted keys (ids ascending): seg[2 s] = first position, seg[2 s + 1] = number
+__global__ __launch_bounds__(256) void k_read_stretches(const uint64_t *__restrict__ skey, uint32_t n, const uint32_t *__restrict__ ids, uint32_t n_ids, uint32_t *__restrict__ seg)
+{
+	const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+	if (s >= n_ids) return;
+	uint32_t b[2];
+	for (int k = 0; k < 2; ++k) {
+		const uint64_t x = (uint64_t)(ids[s] + (uint32_t)k) << 32; // (id + 1 does not wrap: ids are below 2^32 - 1)
+		uint32_t lo = 0, hi = n;
+		while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (skey[mid] < x) lo = mid + 1; else hi = mid; }
+		b[k] = lo;
+	}
+	seg[2 * s] = b[0]; seg[2 * s + 1] = b[1] - b[0];
+}
+
+int hits_reference_rank(mahip_ctx *c, bool collective_ok, bool wanted_only)
 { // collective_ok: the caller is the orchestrated tie repair (mahip_sg_push_fix, which host/sharded.c enters on ALL ranks after an all-reduce);
 	// any other way in must not start a collective one rank alone would wait in for ever
+	// wanted_only: c->wantb marks the reads inside whose hit groups the order is needed (graph.hip: push_order); the other slots get their rank in the STABLE order, and
+	// c->hrank is then not "the reference's order" for anybody else: hrank_ready stays false
 	if (c->hrank_ready) return 0;
 	const size_t n = c->n_hits, N = c->n_in; // slots of this context / records of the input
 	if (!c->sorted_here || !c->sidx.p || !c->d_aos) { mahip_set_error("hits_reference_rank: the hits were not sorted by this context"); return -1; }
@@ -1436,13 +1453,46 @@ int hits_reference_rank(mahip_ctx *c, bool collective_ok)
 	hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(N, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, N, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
 	                   (uint32_t*)nullptr, P<unsigned long long>(c->ctr), 0u, 0xffffffffu, 0, 1); // key = qid<<32 | qs, input order
 	tl0.lap("hit keys (+ buffers)");
-	CHK(reference_order(c, P<uint64_t>(c->key[0]), N, P<uint32_t>(c->val[1])));
+	bool restricted = false;
+	c->tie.hit_walk_reads = 0;
+	if (wanted_only && c->wantb.p && c->n_seq && N < 0xffffffffull) do {
+		// the wanted reads (a bit per read id) -> host: their list and the running count the walk asks ("any wanted read among ids lo .. hi?")
+		const uint32_t R = c->n_seq, nw = (R + 31) / 32;
+		std::vector<uint32_t> bits(nw), wcum((size_t)R + 1), ids;
+		HIPCHK(hipMemcpyAsync(bits.data(), c->wantb.p, (size_t)nw * 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));
+		wcum[0] = 0;
+		for (uint32_t r = 0; r < R; ++r) { const uint32_t wnt = bits[r >> 5] >> (r & 31) & 1u; wcum[r + 1] = wcum[r] + wnt; if (wnt) ids.push_back(r); }
+		const size_t W = ids.size();
+		if (W == 0 || W > R / 4) break; // (nobody: cannot be, the caller saw conflicts; a quarter of the reads: the restriction buys little -- the whole walk)
+		// the stable order (what every other read keeps) and where the wanted reads' hits stand in it
+		const int bs = hits_qs_bits(c), bq = bitlen(R - 1);
+		int g = 0;
+		CHK(radix_sort_pairs(c, N, 0, bs, 32, 32 + (bq ? bq : 1), &g));
+		CHK(dev_reserve(c, c->wseg, W * 12 + 64));
+		uint32_t *d_ids = (uint32_t*)c->wseg.p, *d_seg = d_ids + W;
+		HIPCHK(hipMemcpyAsync(d_ids, ids.data(), W * 4, hipMemcpyHostToDevice, c->st));
+		hipLaunchKernelGGL(k_read_stretches, dim3(grid_for(W, 256)), dim3(256), 0, c->st, (const uint64_t*)P<uint64_t>(c->key[g]), (uint32_t)N, (const uint32_t*)d_ids, (uint32_t)W, d_seg);
+		std::vector<uint32_t> seg(2 * W), pos(W), len(W);
+		HIPCHK(hipMemcpyAsync(seg.data(), d_seg, W * 8, hipMemcpyDeviceToHost, c->st));
+		if (g != 1) HIPCHK(hipMemcpyAsync(c->val[1].p, c->val[0].p, N * 4, hipMemcpyDeviceToDevice, c->st)); // the stable order where reference_order patches it
+		HIPCHK(hipStreamSynchronize(c->st));
+		for (size_t s = 0; s < W; ++s) pos[s] = seg[2 * s], len[s] = seg[2 * s + 1];
+		hipLaunchKernelGGL(k_hit_keys, dim3(grid_for(N, 256, MA_STREAM_BLOCKS)), dim3(256), 0, c->st, c->d_aos, N, P<uint64_t>(c->key[0]), P<uint32_t>(c->val[0]),
+		                   (uint32_t*)nullptr, P<unsigned long long>(c->ctr), 0u, 0xffffffffu, 0, 1); // (the sort consumed them) the keys in input order again: what the walk walks
+		tl0.lap("stable order + the wanted reads' stretches");
+		WalkWanted w = { wcum.data(), R, pos.data(), len.data(), W };
+		CHK(reference_order(c, P<uint64_t>(c->key[0]), N, P<uint32_t>(c->val[1]), &w));
+		c->tie.hit_walk_reads = W;
+		restricted = true;
+	} while (0);
+	if (!restricted) CHK(reference_order(c, P<uint64_t>(c->key[0]), N, P<uint32_t>(c->val[1])));
 	TieLaps tl(c);
 	hipLaunchKernelGGL(k_perm_invert, dim3(grid_for(N, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->val[1]), N, P<uint32_t>(c->val[0]));
 	hipLaunchKernelGGL(k_hit_rank, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->sidx), (const uint32_t*)P<uint32_t>(c->val[0]), n, P<uint32_t>(c->hrank));
 	HIPCHK(hipGetLastError());
 	tl.lap("hit ranks on the device");
-	c->hrank_ready = true;
+	c->hrank_ready = !restricted;
 	c->tie.hit_walk = 1;
 	return 0;
 }

@@ -309,7 +309,7 @@ extern "C" void mahip_destroy(mahip_ctx_t *c)
 	DevBuf *all[] = { &c->aos_own, &c->goff, &c->sub[0], &c->sub[1], &c->r_cont, &c->r_used, &c->r_del, &c->r_live, &c->map, &c->surv,
 		&c->au[0], &c->au[1], &c->av[0], &c->av[1], &c->alen[0], &c->alen[1], &c->aol[0], &c->aol[1], &c->idx, &c->sdel, &c->slen,
 		&c->keep, &c->pos, &c->gs_tmp, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->hist, &c->scan_tmp[0], &c->scan_tmp[1], &c->scan_tmp[2],
-		&c->ctr, &c->ovf, &c->big0, &c->big1, &c->marks, &c->sgmask, &c->sidx, &c->hrank, &c->orank, &c->aslot, &c->apos, &c->pushrows[0], &c->pushrows[1], &c->xb[0], &c->xb[1], &c->gpos, &c->tdig };
+		&c->ctr, &c->ovf, &c->big0, &c->big1, &c->marks, &c->sgmask, &c->sidx, &c->hrank, &c->orank, &c->aslot, &c->apos, &c->pushrows[0], &c->pushrows[1], &c->xb[0], &c->xb[1], &c->gpos, &c->tdig, &c->wantb, &c->wseg };
 	for (DevBuf *b : all) dev_free(c, *b);
 	for (int k = 0; k < 8; ++k) dev_free(c, c->col[k]);
 	c->hwalk.drop(); c->hdig.drop();

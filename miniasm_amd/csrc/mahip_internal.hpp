@@ -86,7 +86,7 @@ struct mahip_ctx {
 	bool gather_pending = false; int gk_gen = 0, gk_bi = 0; // mahip_hits_sort left the records in place: sorted keys in key[gk_gen], position in their low gk_bi bits
 	bool gk_runs = false; size_t n_runs = 0; int run_stride = 0; // sorted as RUNS of records (hits.hip: k_hit_keys_runs / k_runs_expand): the positions are in sidx already; run_stride: the caller's hint (mahip_set_run_stride)
 	bool push_ordered = false; // sharded mode: pushrows[1] holds this rank's arcs in push order
-	mahip_tie_info_t tie = {0, 0, 0, 0, 0, 0, 0, 0};
+	mahip_tie_info_t tie = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 	uint32_t n_seq_new = 0;
 
 	// ---- arcs (dense SoA, two generations for compaction) ----
@@ -108,6 +108,8 @@ struct mahip_ctx {
 	DevBuf keep, pos;         // u32 flags / scanned positions
 	BigHost hwalk, hdig;      // host side of the tie walk: the packed elements and, when they do not hold it, the top level's digits; dropped by walk_scratch_release()
 	DevBuf tdig;              // u8 [n] tie walk: the keys' top digit when it does not fit into the packed element (radix.hip: reference_order)
+	DevBuf wantb;             // u32 [n_seq / 32] tie walk: the reads whose hit order the arc sort can see (graph.hip: k_arc_push_conflicts_seen)
+	DevBuf wseg;              // tie walk: the wanted reads' ids / stretches / order on their way between host and device
 	DevBuf key[2], val[2];    // radix sort ping-pong
 	DevBuf hist;              // radix block histograms
 	DevBuf scan_tmp[3];       // scan levels
@@ -195,10 +197,14 @@ int radix_group_starts_begin(mahip_ctx *c, uint32_t *start, uint32_t n_id, uint3
 int radix_group_starts_finish(mahip_ctx *c, uint32_t *start, uint32_t n_id);           // ... and ids without keys are closed (a suffix minimum): CSR offsets
 int scan_chain_begin(mahip_ctx *c, size_t nb, unsigned long long **state, uint32_t **ticket, uint32_t *ticket_base, uint32_t *epoch, size_t n_tickets = 0);
 // the permutation the reference's (unstable) sort applies to d_keys[0..n) (input order), written to d_perm
-int reference_order(mahip_ctx *c, uint64_t *d_keys /* overwritten */, size_t n, uint32_t *d_perm);
+// The restricted tie walk: the reference's order is wanted inside the hit groups of some reads only (graph.hip: the reads whose push conflicts the arc sort can see).
+// wcum[id] = wanted ids below id (host, n_ids + 1 words); seg_pos / seg_len: where each wanted read's hits stand in any order sorted by key (host, n_seg entries).
+struct WalkWanted { const uint32_t *wcum; uint64_t n_ids; const uint32_t *seg_pos, *seg_len; size_t n_seg; };
+// w == nullptr: d_perm <- the whole order.  w: d_perm holds the STABLE order on entry and only the wanted reads' stretches are replaced
+int reference_order(mahip_ctx *c, uint64_t *d_keys /* overwritten */, size_t n, uint32_t *d_perm, const WalkWanted *w = nullptr);
 void walk_scratch_release(mahip_ctx *c); // the host arrays of the walks go away (on a thread of their own when they are big)
 // position of every hit slot in the reference's order -> c->hrank (hits.hip)
-int hits_reference_rank(mahip_ctx *c, bool collective_ok);
+int hits_reference_rank(mahip_ctx *c, bool collective_ok, bool wanted_only = false);
 // bits of the largest query start of the input records
 int hits_qs_bits(mahip_ctx *c);
 // make sure the SoA columns exist (the gather after mahip_hits_sort is lazy)

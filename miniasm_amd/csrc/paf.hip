@@ -1145,6 +1145,18 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 	unsigned long long *ctr = P<unsigned long long>(c->ctr);
 	memset(info, 0, sizeof(*info));
 	b->n_seq = 0; b->name_bytes = 0;
+	// MA_PIPE_TIMING=2: wall-clock laps of this function's parts on stderr (each lap waits for the stream: a diagnostic, it changes what it measures by the waits)
+	const bool laps = []{ const char *e = getenv("MA_PIPE_TIMING"); return e && atoi(e) >= 2; }();
+	struct timespec lap_t0;
+	if (laps) clock_gettime(CLOCK_MONOTONIC, &lap_t0);
+	auto lap = [&](const char *what) {
+		if (!laps) return;
+		(void)hipStreamSynchronize(c->st);
+		struct timespec t1;
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		fprintf(stderr, "[T::paf_parse] %-28s %9.3f ms\n", what, ((double)(t1.tv_sec - lap_t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - lap_t0.tv_nsec)) * 1e3);
+		lap_t0 = t1;
+	};
 
 	// ---- line starts
 	const bool old_path = []{ const char *e = getenv("MA_PAF_OLD"); return e && atoi(e) != 0; }(); // round 5's kernels (lane-per-line parser, text-comparing dictionary, ids / scan / emit): the A/B switch
@@ -1217,6 +1229,7 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 			                   P<unsigned long long>(b->tfirst));
 		}
 	}
+	lap("line census");
 	PafCols o;
 	{
 		const size_t Lr = (size_t)L + 4;
@@ -1235,6 +1248,7 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 	uint32_t max_qs = 0;
 	if (L) {
 		CHK(dev_reserve(c, c->keep, ((size_t)L + 16) * 4)); CHK(dev_reserve(c, c->pos, ((size_t)L + 16) * 4));
+		lap("columns reserved");
 		if (old_path) {
 			ProfScope ps(c, "k_paf_parse", (double)n + 61.0 * (double)L);
 			// LDS tile: 1.5 x the mean text of 256 lines, in 4 KiB steps (blocks whose lines are longer read global memory)
@@ -1273,6 +1287,7 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 			hipLaunchKernelGGL(k_paf_bl_fill, dim3(grid_for(L, 256)), dim3(256), 0, c->st, (const uint32_t*)P<uint32_t>(c->keep), (const uint32_t*)P<uint32_t>(c->pos), (const uint32_t*)P<uint32_t>(b->blv), L, o.bl);
 		}
 	}
+	lap("fields");
 	uint64_t nobl_total = n_nobl;
 	if (sharded) { // what the ranges have to know of each other before names and records can be numbered
 		uint64_t mine[5] = { L, n_valid, n_pass, n_nobl, max_qs }, all[5 * 32];
@@ -1376,6 +1391,7 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 		b->name_bytes = nb;
 	}
 	b->n_seq = R;
+	lap("dictionary");
 	const uint32_t *slot_to_id = P<uint32_t>(b->slot_id); // table slot -> id, for the records
 	if (sharded) { // ---- the ranks' name tables -> one dictionary (kernels above)
 		const uint32_t R_loc = R;
@@ -1497,8 +1513,10 @@ static int paf_parse_impl(mahip_ctx_t *c, int min_span, int min_match, int bi_di
 		HIPCHK(hipMemcpyAsync(&nh, b->scal.p, 4, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(hipStreamSynchronize(c->st));
 		n_hits = nh;
+		lap("records");
 		CHK(mahip_hits_adopt(c, nullptr, n_hits, R)); // resets the per-upload state and sizes the read arrays
 		c->d_aos = (const ma_hit_t*)c->aos_own.p;
+		lap("adopt");
 	} else {
 		CHK(mahip_hits_adopt(c, nullptr, 0, R));
 		CHK(dev_reserve(c, c->aos_own, sizeof(ma_hit_t)));

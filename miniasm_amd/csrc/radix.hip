@@ -390,6 +390,7 @@ int radix_reserve_hist(mahip_ctx *c, size_t n)
 // packing, 0.2 s of unpacking and 20 GB of freshly faulted host memory around a 3 s walk).
 extern "C" int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm);
 extern "C" int ma_refsort_packed(uint64_t *pk, size_t n, int bl, int bi, int shift_top, const uint8_t *dig_top);
+extern "C" int ma_refsort_packed_wanted(uint64_t *pk, size_t n, int bl, int bi, int shift_top, const uint8_t *dig_top, const uint32_t *wcum, uint64_t n_ids);
 
 __global__ __launch_bounds__(256) void k_key_bounds(const uint64_t *__restrict__ key, size_t n, unsigned long long *__restrict__ ctr)
 {
@@ -416,6 +417,12 @@ __global__ __launch_bounds__(256) void k_perm_from_packed(const uint64_t *__rest
 {
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	if (i < n) perm[i] = (uint32_t)(pk[i] & mask);
+}
+// restricted walk: block s writes the order of the s-th wanted read's hits (ord[off[s] ..)) over the stable order at the read's stretch pos[s] ..
+__global__ __launch_bounds__(256) void k_perm_patch(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ off, const uint32_t *__restrict__ ord, uint32_t *__restrict__ perm)
+{
+	const uint32_t p = pos[blockIdx.x], o0 = off[blockIdx.x], o1 = off[blockIdx.x + 1];
+	for (uint32_t j = o0 + threadIdx.x; j < o1; j += 256) perm[p + (j - o0)] = ord[j];
 }
 
 static int bitlen64(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; }
@@ -464,7 +471,7 @@ void walk_scratch_release(mahip_ctx *c)
 }
 
 // d_perm[j] <- input position of the j-th record in the reference's order.  d_keys is overwritten.
-int reference_order(mahip_ctx *c, uint64_t *d_keys, size_t n, uint32_t *d_perm)
+int reference_order(mahip_ctx *c, uint64_t *d_keys, size_t n, uint32_t *d_perm, const WalkWanted *w)
 {
 	if (n == 0) return 0;
 	TieLaps tl(c);
@@ -494,11 +501,40 @@ int reference_order(mahip_ctx *c, uint64_t *d_keys, size_t n, uint32_t *d_perm)
 		if (xfer_copy(c, d_keys, hk, n * 8, 0) != 0) rc = -1;
 		if (rc == 0 && hd) { if (xfer_copy(c, c->tdig.p, hd, n, 0) != 0) rc = -1; memset(hd + n, 0, 16); }
 		tl.lap("walk: packed keys to the host");
-		if (rc == 0 && ma_refsort_packed(hk, n, bl, bi, shift_top, hd) != 0) rc = -1;
-		tl.lap("walk: host");
-		if (rc == 0 && xfer_copy(c, d_keys, hk, n * 8, 1) != 0) rc = -1;
-		if (rc == 0) hipLaunchKernelGGL(k_perm_from_packed, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint64_t*)d_keys, n, bi >= 64 ? ~0ull : (1ull << bi) - 1, d_perm);
-		tl.lap("walk: order to the device");
+		const uint64_t imask = bi >= 64 ? ~0ull : (1ull << bi) - 1;
+		if (w && w->n_seg) { // only the wanted reads' stretches come out in the reference's order (host/refsort.c: ma_refsort_packed_wanted), and only they go back up
+			if (rc == 0 && ma_refsort_packed_wanted(hk, n, bl, bi, shift_top, hd, w->wcum, w->n_ids) != 0) rc = -1;
+			tl.lap("walk: host (wanted reads only)");
+			if (rc == 0) {
+				const size_t S = w->n_seg;
+				size_t tot = 0;
+				for (size_t s = 0; s < S; ++s) tot += w->seg_len[s];
+				// one block: pos[S] | off[S + 1] | ord[tot]
+				std::vector<uint32_t> blk(2 * S + 1 + tot);
+				uint32_t *pos = blk.data(), *off = pos + S, *ord = off + S + 1;
+				size_t o = 0;
+				for (size_t s = 0; s < S; ++s) {
+					pos[s] = w->seg_pos[s]; off[s] = (uint32_t)o;
+					const uint64_t *src = hk + w->seg_pos[s];
+					for (uint32_t j = 0; j < w->seg_len[s]; ++j) ord[o++] = (uint32_t)(src[j] & imask);
+				}
+				off[S] = (uint32_t)o;
+				if (dev_reserve(c, c->wseg, blk.size() * 4 + 64) != 0) rc = -1;
+				if (rc == 0 && xfer_copy(c, c->wseg.p, blk.data(), blk.size() * 4, 1) != 0) rc = -1;
+				if (rc == 0) {
+					const uint32_t *d = (const uint32_t*)c->wseg.p;
+					hipLaunchKernelGGL(k_perm_patch, dim3((unsigned)S), dim3(256), 0, c->st, d, d + S, d + 2 * S + 1, d_perm);
+					HIPCHK(hipStreamSynchronize(c->st)); // (blk goes away)
+				}
+			}
+			tl.lap("walk: the wanted stretches to the device");
+		} else {
+			if (rc == 0 && ma_refsort_packed(hk, n, bl, bi, shift_top, hd) != 0) rc = -1;
+			tl.lap("walk: host");
+			if (rc == 0 && xfer_copy(c, d_keys, hk, n * 8, 1) != 0) rc = -1;
+			if (rc == 0) hipLaunchKernelGGL(k_perm_from_packed, dim3(grid_for(n, 256)), dim3(256), 0, c->st, (const uint64_t*)d_keys, n, imask, d_perm);
+			tl.lap("walk: order to the device");
+		}
 	} else { // keys too wide (or MA_REFSORT_KEYS, for the tests): the raw keys go down, the host packs what it can
 		uint64_t *hk = (uint64_t*)malloc(n * 8);
 		uint32_t *hp = (uint32_t*)malloc(n * 4);

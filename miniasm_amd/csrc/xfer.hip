@@ -72,10 +72,11 @@ static void *xfer_worker(void *arg)
 	return 0;
 }
 
+extern "C" int ma_cpu_budget(void);
 static int xfer_workers(int to_device)
 {
 	const char *s = getenv("MA_XFER_THREADS");
-	long n = s ? atol(s) : sysconf(_SC_NPROCESSORS_ONLN) / 2;
+	long n = s ? atol(s) : ma_cpu_budget(); // (the control group's CPU quota counts, not the machine's core count: host/ingest_mt.c)
 	// device -> host ends in a memcpy into pageable memory that is usually fresh (a page fault and a cleared page per 4 KB): 8 workers reach 21 GB/s, 16 reach 31
 	// (8 GB of tie-walk keys, BASELINE configs[4], profiles/r03_tiewalk.txt); host -> device is at 45 GB/s with 8 and no faster with 16
 	const long most = to_device ? 8 : 16;

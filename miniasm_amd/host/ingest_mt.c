@@ -202,10 +202,61 @@ static void *reader(void *arg)
 	return 0;
 }
 
+/* How many CPUs this process can keep busy at once: the online CPUs, cut by a CPU quota of the control group it runs in (cgroup v2 cpu.max, v1 cfs_quota_us).  A
+ * container is often given a machine's 256 CPUs to look at and 16 CPUs' worth of time: threads beyond the quota only make the scheduler stop ALL of the process's
+ * threads for the rest of each 100 ms period -- the one that feeds the GPU included (round 6: the tie walk's bucket phase took 1.2 s on 16, 32, 64 and 128 threads alike,
+ * cpu.stat showed the throttling). */
+static long quota_cpus(const char *path_max, const char *path_quota, const char *path_period)
+{
+	char buf[128];
+	FILE *f;
+	long q = -1, per = 100000;
+	if (path_max && (f = fopen(path_max, "r")) != 0) { /* "max 100000" or "1600000 100000" */
+		if (fgets(buf, sizeof(buf), f) && buf[0] != 'm') { if (sscanf(buf, "%ld %ld", &q, &per) < 1) q = -1; }
+		fclose(f);
+	} else if (path_quota && (f = fopen(path_quota, "r")) != 0) {
+		if (fscanf(f, "%ld", &q) != 1) q = -1;
+		fclose(f);
+		if ((f = fopen(path_period, "r")) != 0) { if (fscanf(f, "%ld", &per) != 1) per = 100000; fclose(f); }
+	}
+	if (q <= 0 || per <= 0) return 0;
+	return (q + per - 1) / per;
+}
+
+int ma_cpu_budget(void)
+{
+	static int cached;
+	long n, q;
+	char line[512], path[640];
+	FILE *f;
+	if (cached) return cached;
+	n = sysconf(_SC_NPROCESSORS_ONLN);
+	if (n < 1) n = 1;
+	if ((q = quota_cpus("/sys/fs/cgroup/cpu.max", 0, 0)) > 0 && q < n) n = q;
+	if ((q = quota_cpus(0, "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")) > 0 && q < n) n = q;
+	if ((f = fopen("/proc/self/cgroup", "r")) != 0) { /* v2 without a private cgroup namespace: "0::/path" -- the group's own file and its ancestors' */
+		while (fgets(line, sizeof(line), f))
+			if (strncmp(line, "0::/", 4) == 0) {
+				char *e = line + strlen(line);
+				while (e > line && (e[-1] == '\n' || e[-1] == '/')) *--e = 0;
+				while (strlen(line) > 4) {
+					snprintf(path, sizeof(path), "/sys/fs/cgroup%s/cpu.max", line + 3);
+					if ((q = quota_cpus(path, 0, 0)) > 0 && q < n) n = q;
+					e = strrchr(line + 3, '/');
+					if (!e || e == line + 3) break;
+					*e = 0;
+				}
+			}
+		fclose(f);
+	}
+	cached = (int)n;
+	return cached;
+}
+
 int ma_ingest_threads(void)
 {
 	const char *s = getenv("MA_THREADS");
-	long n = s ? atol(s) : sysconf(_SC_NPROCESSORS_ONLN);
+	long n = s ? atol(s) : ma_cpu_budget();
 	if (!s && n > 16) n = 16; /* the sequential id-merge grows with the chunk count: 16 is the measured sweet spot (EPYC 9575F) */
 	if (n < 1) n = 1;
 	if (n > MT_MAX_THREADS) n = MT_MAX_THREADS;

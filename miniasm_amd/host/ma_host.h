@@ -73,7 +73,8 @@ int ma_hit_ingest_loaded_excl(mahip_ctx_t *c, int min_span, int min_match, sdict
 int ma_paf_load_file(mahip_ctx_t *c, const char *fn); /* plain / gzip / "-": text into HBM */
 int ma_hit_ingest_loaded(mahip_ctx_t *c, int min_span, int min_match, sdict_t *d, size_t *n_hits, int bi_dir, int release);
 int ma_gpu_parse_enabled(void); /* 0 when MA_HOST_PARSE=1 */
-int ma_ingest_threads(void); /* MA_THREADS or the number of online cores, capped */
+int ma_cpu_budget(void);     /* CPUs the process can keep busy: online CPUs cut by the control group's CPU quota */
+int ma_ingest_threads(void); /* MA_THREADS or ma_cpu_budget(), capped */
 uint32_t ma_ingest_max_qs(void); /* largest query start stored by the last ma_hit_ingest */
 
 /* literal emulation of the reference's in-place MSD radix sort (ksort.h:134-183) on arcs keyed by ul */
@@ -83,6 +84,7 @@ typedef struct { uint64_t key; uint32_t idx, pad; } ma_ki_t;
 void ma_refsort_ki(ma_ki_t *a, size_t n, int n_threads);
 int ma_refsort_perm(const uint64_t *keys, size_t n, uint32_t *perm); /* perm[i] = input position of the i-th record in reference order */
 int ma_refsort_packed(uint64_t *pk, size_t n, int bl, int bi, int shift_top, const uint8_t *dig_top); /* the same on elements the caller packed (key above input position), in place */
+int ma_refsort_packed_wanted(uint64_t *pk, size_t n, int bl, int bi, int shift_top, const uint8_t *dig_top, const uint32_t *wcum, uint64_t n_ids); /* ... exact only inside the hit groups of the wanted reads */
 
 #ifdef __cplusplus
 }

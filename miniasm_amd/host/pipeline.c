@@ -140,8 +140,10 @@ int ma_pipeline_head(mahip_ctx_t *c, const ma_opt_t *opt, const sdict_t *d, cons
 		if (getenv("MA_PIPE_TIMING")) { /* what the tie census found and what was done about it */
 			mahip_tie_info_t ti;
 			mahip_tie_stats(c, &ti);
-			fprintf(stderr, "[T::ties] %llu arc tie groups (%llu arcs), %llu push conflicts (%llu of them in sight of the arc sort) -> arc walk %d, hit walk %d%s\n", (unsigned long long)ti.arc_tie_groups,
-			        (unsigned long long)ti.arc_tie_arcs, (unsigned long long)ti.push_conflicts, (unsigned long long)ti.push_conflicts_seen, ti.arc_walk, ti.hit_walk,
+			char reads[64] = "";
+			if (ti.hit_walk && ti.hit_walk_reads) snprintf(reads, sizeof(reads), " (its order taken for %llu reads)", (unsigned long long)ti.hit_walk_reads);
+			fprintf(stderr, "[T::ties] %llu arc tie groups (%llu arcs), %llu push conflicts (%llu of them in sight of the arc sort) -> arc walk %d, hit walk %d%s%s\n", (unsigned long long)ti.arc_tie_groups,
+			        (unsigned long long)ti.arc_tie_arcs, (unsigned long long)ti.push_conflicts, (unsigned long long)ti.push_conflicts_seen, ti.arc_walk, ti.hit_walk, reads,
 			        ti.unrepaired ? " (NOT repaired: stable order kept)" : "");
 		}
 		free(len); free(sdel);

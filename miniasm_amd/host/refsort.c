@@ -28,6 +28,9 @@ static int rs_timing = -1;
 #define RS_T0 double t0_ = rs_now()
 #define RS_LAP(what) do { if (rs_timing < 0) rs_timing = getenv("MA_REFSORT_TIMING") != 0; if (rs_timing) { double t1_ = rs_now(); fprintf(stderr, "[T::refsort] %-12s %.3f s\n", what, t1_ - t0_); t0_ = t1_; } } while (0)
 
+static int rs_late_flag = -1;
+static int rs_late(void) { if (rs_late_flag < 0) rs_late_flag = getenv("MA_REFSORT_LATE") != 0; return rs_late_flag; }
+
 #define RS_MAX_THREADS 128
 #define RS_SMALL 64           /* RS_MIN_SIZE ksort.h:132 */
 /* The walk touches the 256 bucket heads in an order the hardware prefetchers cannot follow (they track a few dozen streams), so every
@@ -44,47 +47,94 @@ typedef struct { int bi, bl; uint64_t lomask; } rs_cfg_t;
 
 typedef struct { void *a; size_t n; int shift; } rs_task_t;
 
+/* Two stacks: a range of TASK_BIG elements or more starts with a walk that one thread does alone (tens of ms) before it has anything to share, so those are taken
+ * first -- on one stack with their own children they sat at the bottom until every small task was gone, and the sort ended on a handful of lone walks. */
+#define TASK_BIG ((size_t)1 << 20)
 typedef struct rs_pool_s {
 	pthread_mutex_t mu;
 	pthread_cond_t cv;
-	rs_task_t *q;
-	size_t nq, mq, elem;
+	rs_task_t *q[2]; /* [0] small, [1] big */
+	size_t nq[2], mq[2], elem;
 	int busy, n_threads;
 	rs_cfg_t cfg;
 	void (*run)(struct rs_pool_s*, void*, size_t, int);
+	double st_busy, st_max, st_big, st_t0, st_last_big; /* MA_REFSORT_TIMING: seconds inside tasks (all / the longest / the big ones), when the last big one ended */
+	size_t st_n, st_nbig;
+	/* The RESTRICTED sort (ma_refsort_packed_wanted).  The caller needs the reference's order only inside the hit groups of some reads (key's high word = read id):
+	 * wcum[id] = wanted ids below id.  A level's walk is always done whole -- where an element lands depends on every element of the range -- but a bucket it leaves
+	 * behind is only sorted further if a wanted read's hits are in it; the others stay as the walk left them (NOT sorted: the caller must not look there).
+	 * top_start / top_base / top_shift: the packed words do not carry the top level's digit (refsort.c: ma_refsort_packed): it is the top-level bucket an element stands in. */
+	const uint32_t *wcum;
+	uint64_t n_ids;
+	const size_t *top_start;
+	const void *top_base;
+	int top_shift;
 } rs_pool_t;
 
 static void pool_push(rs_pool_t *p, void *a, size_t n, int shift)
 {
+	const int w = n >= TASK_BIG;
 	pthread_mutex_lock(&p->mu);
-	if (p->nq == p->mq) {
-		p->mq = p->mq ? p->mq << 1 : 1024;
-		p->q = (rs_task_t*)realloc(p->q, p->mq * sizeof(rs_task_t));
+	if (p->nq[w] == p->mq[w]) {
+		p->mq[w] = p->mq[w] ? p->mq[w] << 1 : 1024;
+		p->q[w] = (rs_task_t*)realloc(p->q[w], p->mq[w] * sizeof(rs_task_t));
 	}
-	p->q[p->nq].a = a, p->q[p->nq].n = n, p->q[p->nq].shift = shift;
-	++p->nq;
+	p->q[w][p->nq[w]].a = a, p->q[w][p->nq[w]].n = n, p->q[w][p->nq[w]].shift = shift;
+	++p->nq[w];
 	pthread_cond_signal(&p->cv);
 	pthread_mutex_unlock(&p->mu);
 }
 
+/* The digit array of a range below the top level (refsort_body.h: level): a worker thread keeps ONE block for all the ranges it is handed (a range's array is dead
+ * when its walk is over, and everything a range calls afterwards is shorter) -- 20 000 blocks of 50 KB allocated and freed by 64 threads at once was time spent in
+ * the allocator's locks and in page faults, not in the sort.  Outside a worker thread (one thread sorts alone): malloc / free as before. */
+static __thread const uint32_t *tl_wcum; /* the restriction of the call in progress on this thread (ma_refsort_packed_wanted; handed to the pool where one is set up) */
+static __thread uint64_t tl_n_ids;
+static __thread int tl_top_apart;        /* the call in progress sorts words that do not carry the top level's digit */
+static __thread uint8_t *tl_dig;
+static __thread size_t tl_dig_cap;
+static __thread int tl_worker;
+static uint8_t *rs_dig_get(size_t n)
+{
+	if (!tl_worker) return (uint8_t*)malloc(n + 16);
+	if (tl_dig_cap < n + 16) {
+		free(tl_dig);
+		tl_dig_cap = n + 16 < ((size_t)1 << 16) ? (size_t)1 << 16 : n + 16;
+		tl_dig = (uint8_t*)malloc(tl_dig_cap);
+		if (tl_dig == 0) tl_dig_cap = 0;
+	}
+	return tl_dig;
+}
+static void rs_dig_put(uint8_t *d) { if (!tl_worker) free(d); }
+
 static void *pool_worker(void *arg)
 {
 	rs_pool_t *p = (rs_pool_t*)arg;
+	tl_worker = 1;
 	pthread_mutex_lock(&p->mu);
 	for (;;) {
-		while (p->nq == 0 && p->busy > 0) pthread_cond_wait(&p->cv, &p->mu);
-		if (p->nq == 0) break; /* nothing queued, nobody running: done */
+		while (p->nq[0] + p->nq[1] == 0 && p->busy > 0) pthread_cond_wait(&p->cv, &p->mu);
+		if (p->nq[0] + p->nq[1] == 0) break; /* nothing queued, nobody running: done */
 		{
-			rs_task_t t = p->q[--p->nq];
+			const int w = p->nq[1] != 0;
+			rs_task_t t = p->q[w][--p->nq[w]];
+			const double ts = rs_timing > 0 ? rs_now() : 0;
 			++p->busy;
 			pthread_mutex_unlock(&p->mu);
 			p->run(p, t.a, t.n, t.shift);
 			pthread_mutex_lock(&p->mu);
 			--p->busy;
-			if (p->busy == 0 && p->nq == 0) pthread_cond_broadcast(&p->cv);
+			if (rs_timing > 0) {
+				const double te = rs_now(), dt = te - ts;
+				p->st_busy += dt; ++p->st_n;
+				if (dt > p->st_max) p->st_max = dt;
+				if (w) { p->st_big += dt; ++p->st_nbig; p->st_last_big = te - p->st_t0; }
+			}
+			if (p->busy == 0 && p->nq[0] + p->nq[1] == 0) pthread_cond_broadcast(&p->cv);
 		}
 	}
 	pthread_mutex_unlock(&p->mu);
+	free(tl_dig); tl_dig = 0; tl_dig_cap = 0; tl_worker = 0;
 	return 0;
 }
 
@@ -207,8 +257,8 @@ static int bits_of64(uint64_t x) { int b = 0; while (x) ++b, x >>= 1; return b; 
 static int refsort_threads(void)
 {
 	const char *s = getenv("MA_THREADS");
-	long n = s ? atol(s) : sysconf(_SC_NPROCESSORS_ONLN);
-	if (!s && n > 64) n = 64; /* (32 until round 3: at BASELINE configs[4] the buckets below the top level were 1.4 s on 32 threads of the GPU box's 256 cores) */
+	long n = s ? atol(s) : ma_cpu_budget(); /* (what the control group allows, not what the machine has: ingest_mt.c) */
+	if (!s && n > 64) n = 64;
 	return n < 1 ? 1 : n > RS_MAX_THREADS ? RS_MAX_THREADS : (int)n;
 }
 
@@ -290,6 +340,7 @@ int ma_refsort_packed(uint64_t *pk, size_t n, int bl, int bi, int shift_top, con
 		else {
 			fill_t f;
 			if (shift_top < 32 || (shift_top & 7) || (shift_top - 32) + bl + bi > 64 || dig_top == 0 || n <= RS_SMALL) return -1; /* (<= 64 records: ksort.h:182 sorts by insertion -- the caller uses ma_refsort_perm) */
+			tl_top_apart = 1;
 			if (nt > 1 && n >= (1u << 17)) {
 				memset(&f, 0, sizeof(f));
 				f.dig = (uint8_t*)dig_top;
@@ -301,8 +352,22 @@ int ma_refsort_packed(uint64_t *pk, size_t n, int bl, int bi, int shift_top, con
 				for (i = 0; i < n; ++i) ++cnt[dig_top[i]];
 				packed_sort_from_top(pk, n, &cfg, 1, cnt, dig_top, shift_top);
 			}
+			tl_top_apart = 0;
 		}
 		RS_LAP("sort");
 	}
 	return 0;
+}
+
+/* ma_refsort_packed, but the order is only wanted inside the hit groups of the reads with wcum[id + 1] != wcum[id] (wcum: n_ids + 1 counts, wcum[0] = 0; the key's
+ * high word is the read id).  Afterwards pk[] holds the reference's order at the positions of THOSE reads' hits; everywhere else it is a permutation of the input that
+ * is sorted down to some level only.  Every read's hits still stand in the stretch they occupy in any sorted order if a wanted read shares the stretch's bucket at the
+ * levels above the read id -- the caller takes the positions of a wanted read's stretch from a sorted copy of its own. */
+int ma_refsort_packed_wanted(uint64_t *pk, size_t n, int bl, int bi, int shift_top, const uint8_t *dig_top, const uint32_t *wcum, uint64_t n_ids)
+{
+	int rc;
+	tl_wcum = wcum; tl_n_ids = n_ids;
+	rc = ma_refsort_packed(pk, n, bl, bi, shift_top, dig_top);
+	tl_wcum = 0; tl_n_ids = 0;
+	return rc;
 }

@@ -19,6 +19,26 @@ static void RS_NAME(insertion)(RS_T *a, size_t n, const rs_cfg_t *cfg) /* ksort.
 
 static void RS_NAME(level)(rs_pool_t *pool, RS_T *a, size_t n, int shift);
 
+/* restricted sort (rs_pool_t): does the range *e stands in -- the elements that agree with it on the key's bits from P up -- hold a hit of a wanted read? */
+static inline int RS_NAME(wanted)(const rs_pool_t *pool, const RS_T *e, int P)
+{
+	uint64_t key, id, lo, hi;
+	if (!pool->wcum) return 1;
+	key = RS_ORIG(*e, &pool->cfg);
+	if (pool->top_start) { /* the top digit = the top-level bucket the element stands in */
+		const size_t at = (size_t)(e - (const RS_T*)pool->top_base);
+		int b0 = 0, b1 = 256;
+		while (b1 - b0 > 1) { const int mid = (b0 + b1) >> 1; if (pool->top_start[mid] <= at) b0 = mid; else b1 = mid; }
+		key |= (uint64_t)b0 << pool->top_shift;
+	}
+	id = key >> 32;
+	if (P <= 32) lo = id, hi = id + 1;
+	else { const int w = P - 32; lo = w >= 32 ? 0 : id >> w << w; hi = w >= 32 ? pool->n_ids : lo + (1ull << w); }
+	if (lo >= pool->n_ids) return 0;
+	if (hi > pool->n_ids) hi = pool->n_ids;
+	return pool->wcum[hi] != pool->wcum[lo];
+}
+
 /* the buckets a level leaves behind (ksort.h:177-182): radix again when larger than 64, else the stable insertion sort */
 static void RS_NAME(dispatch)(rs_pool_t *pool, RS_T *a, const size_t *start, int shift)
 {
@@ -27,6 +47,7 @@ static void RS_NAME(dispatch)(rs_pool_t *pool, RS_T *a, const size_t *start, int
 	if (!shift) return;
 	for (k = 0; k < 256; ++k) {
 		size_t cnt = start[k + 1] - start[k];
+		if (cnt > 1 && !RS_NAME(wanted)(pool, a + start[k], shift)) continue;
 		if (cnt > RS_SMALL) {
 			if (pool->n_threads > 1 && cnt >= TASK_MIN) pool_push(pool, a + start[k], cnt, next);
 			else RS_NAME(level)(pool, a + start[k], cnt, next);
@@ -91,13 +112,29 @@ static void RS_NAME(permute_top)(rs_pool_t *pool, RS_T *a, const size_t *cnt, co
 {
 	RS_NAME(bk_t) b[256];
 	size_t start[257];
+	/* A bucket the walk has left is final -- it is full, so no element that belongs there is still on its way, and the walk writes to the heads of buckets
+	 * that are not full only.  With worker threads around it is handed over THEN (ksort.h:177-182 does not care when: the ranges are disjoint), and the buckets
+	 * below the top level are sorted beside the walk instead of behind it (BASELINE configs[4]: top walk 1.68 s, then buckets 1.23 s on 64 threads).  The
+	 * buckets too small for a task of their own wait in `later` for this thread. */
+	const int early = pool->n_threads > 1 && shift != 0 && !rs_late(), next = shift > 8 ? shift - 8 : 0; /* (MA_REFSORT_LATE=1: the A/B switch) */
+	uint8_t later[256];
+	int n_later = 0;
 	int k;
 	start[0] = 0;
 	for (k = 0; k < 256; ++k) start[k + 1] = start[k] + cnt[k];
 	for (k = 0; k < 256; ++k) b[k].head = start[k], b[k].nd = dig[start[k]], b[k].pad = 0;
 	for (k = 0; k < 256;) {
 		unsigned d;
-		if (b[k].head == start[k + 1]) { ++k; continue; }
+		if (b[k].head == start[k + 1]) {
+			if (early) {
+				const size_t c = start[k + 1] - start[k];
+				if (c > 1 && !RS_NAME(wanted)(pool, a + start[k], shift)) {}
+				else if (c >= TASK_MIN) pool_push(pool, a + start[k], c, next);
+				else if (c > 1) later[n_later++] = (uint8_t)k;
+			}
+			++k;
+			continue;
+		}
 		d = b[k].nd;
 		if (d == (unsigned)k) { /* already home -- and so, in a PAF-ordered input, are most of its neighbours: the whole stretch at once, eight digits per step */
 			size_t p = b[k].head + 1;
@@ -133,7 +170,12 @@ static void RS_NAME(permute_top)(rs_pool_t *pool, RS_T *a, const size_t *cnt, co
 			b[k].nd = dig[++b[k].head];
 		}
 	}
-	RS_NAME(dispatch)(pool, a, start, shift);
+	if (!early) { RS_NAME(dispatch)(pool, a, start, shift); return; }
+	for (k = 0; k < n_later; ++k) {
+		const size_t c = start[later[k] + 1] - start[later[k]];
+		if (c > RS_SMALL) RS_NAME(level)(pool, a + start[later[k]], c, next);
+		else RS_NAME(insertion)(a + start[later[k]], c, &pool->cfg);
+	}
 }
 
 /* the cycle-leader permutation of one level (ksort.h:153-176) given the digit counts in tail[]; then the buckets below */
@@ -195,6 +237,7 @@ static void RS_NAME(level_small)(rs_pool_t *pool, RS_T *a, size_t n, int shift)
 	next = shift > 8 ? shift - 8 : 0;
 	for (k = lo; k <= hi; ++k) { /* ksort.h:177-182 */
 		const size_t c = cnt[k];
+		if (c > 1 && pool->wcum && !RS_NAME(wanted)(pool, a + start[k], shift)) continue;
 		if (c > RS_SMALL) RS_NAME(level_small)(pool, a + start[k], c, next);
 		else if (c > 1) RS_NAME(insertion)(a + start[k], c, cfg);
 	}
@@ -208,7 +251,7 @@ static void RS_NAME(level)(rs_pool_t *pool, RS_T *a, size_t n, int shift)
 	if (n <= RS_SHORT) { RS_NAME(level_small)(pool, a, n, shift); return; }
 	/* A level on which the digit does not vary leaves the range untouched and recurses into the same range (n > 64
 	 * here).  One sweep gives the varying bits and, optimistically, the histogram of the current digit. */
-	uint8_t *dig = n >= RS_DIG_MIN ? (uint8_t*)malloc(n + 16) : 0; /* a big range (the 65 536-read buckets below the top level of a 10^9-hit input): the digit walk */
+	uint8_t *dig = n >= RS_DIG_MIN ? rs_dig_get(n) : 0; /* a big range (the 65 536-read buckets below the top level of a 10^9-hit input): the digit walk */
 	for (;;) {
 		uint64_t diff = 0;
 		const uint64_t k0 = RS_ORIG(a[0], cfg);
@@ -218,11 +261,11 @@ static void RS_NAME(level)(rs_pool_t *pool, RS_T *a, size_t n, int shift)
 		memset(tail, 0, sizeof(tail));
 		if (dig) for (i = 0; i < n; ++i) { const unsigned dg = (unsigned)(RS_WORD(a[i]) >> sh & m); diff |= RS_ORIG(a[i], cfg) ^ k0; dig[i] = (uint8_t)dg; ++tail[dg]; }
 		else for (i = 0; i < n; ++i) diff |= RS_ORIG(a[i], cfg) ^ k0, ++tail[RS_WORD(a[i]) >> sh & m];
-		if (diff == 0) { free(dig); return; } /* all keys equal: every remaining level is the identity */
+		if (diff == 0) { if (dig) rs_dig_put(dig); return; } /* all keys equal: every remaining level is the identity */
 		if ((diff >> shift & 0xff) != 0) break;
 		while (shift > 0 && (diff >> shift & 0xff) == 0) shift -= 8;
 	}
-	if (dig) { memset(dig + n, 0, 16); RS_NAME(permute_top)(pool, a, tail, dig, shift); free(dig); }
+	if (dig) { memset(dig + n, 0, 16); RS_NAME(permute_top)(pool, a, tail, dig, shift); rs_dig_put(dig); }
 	else RS_NAME(permute)(pool, a, tail, shift);
 }
 
@@ -259,6 +302,14 @@ static void RS_NAME(sort_from_top)(RS_T *a, size_t n, const rs_cfg_t *cfg, int n
 	(void)n;
 	memset(&p, 0, sizeof(p));
 	p.cfg = *cfg; p.run = RS_NAME(task); p.elem = sizeof(RS_T);
+	size_t tstart[257];
+	p.wcum = tl_wcum; p.n_ids = tl_n_ids;
+	if (p.wcum && tl_top_apart) { /* (restricted sort: the buckets of this level say what the words leave out) */
+		int k;
+		tstart[0] = 0;
+		for (k = 0; k < 256; ++k) tstart[k + 1] = tstart[k] + cnt[k];
+		p.top_start = tstart; p.top_base = a; p.top_shift = shift;
+	}
 	pthread_mutex_init(&p.mu, 0);
 	pthread_cond_init(&p.cv, 0);
 	if (n_threads > RS_MAX_THREADS) n_threads = RS_MAX_THREADS;
@@ -266,18 +317,22 @@ static void RS_NAME(sort_from_top)(RS_T *a, size_t n, const rs_cfg_t *cfg, int n
 	{
 		RS_T0;
 		th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
+		if (rs_timing < 0) rs_timing = getenv("MA_REFSORT_TIMING") != 0;
 		++p.busy; /* the top-level walk below produces tasks: workers must not leave while it runs */
 		for (t = 0; t < n_threads; ++t) pthread_create(&th[t], 0, pool_worker, &p);
 		if (dig) RS_NAME(permute_top)(&p, a, cnt, dig, shift);
 		else { size_t tail[256]; memcpy(tail, cnt, sizeof(tail)); RS_NAME(permute)(&p, a, tail, shift); }
 		RS_LAP(" top walk");
+		p.st_t0 = rs_now();
 		pthread_mutex_lock(&p.mu);
 		--p.busy;
 		pthread_cond_broadcast(&p.cv);
 		pthread_mutex_unlock(&p.mu);
 		for (t = 0; t < n_threads; ++t) pthread_join(th[t], 0);
 		RS_LAP(" buckets");
-		free(th); free(p.q);
+		if (rs_timing > 0) fprintf(stderr, "[T::refsort]  tasks: %lu (%lu big), %.3f s inside them on %d threads (big ones %.3f s, the last of them done %.3f s after the walk), longest %.3f s\n",
+		                           (unsigned long)p.st_n, (unsigned long)p.st_nbig, p.st_busy, n_threads, p.st_big, p.st_last_big, p.st_max);
+		free(th); free(p.q[0]); free(p.q[1]);
 	}
 	pthread_mutex_destroy(&p.mu);
 	pthread_cond_destroy(&p.cv);
@@ -289,6 +344,7 @@ static void RS_NAME(sort)(RS_T *a, size_t n, const rs_cfg_t *cfg, int n_threads)
 	rs_pool_t p;
 	memset(&p, 0, sizeof(p));
 	p.cfg = *cfg; p.n_threads = 1; p.run = RS_NAME(task); p.elem = sizeof(RS_T);
+	p.wcum = tl_wcum; p.n_ids = tl_n_ids;
 	if (n <= RS_SMALL) { RS_NAME(insertion)(a, n, cfg); return; } /* ksort.h:182 */
 	if (n_threads <= 1 || n < (1u << 17)) { RS_NAME(level)(&p, a, n, 56); return; }
 	{

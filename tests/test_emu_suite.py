@@ -74,7 +74,7 @@ def test_kernels_graph_api_on_cpu(emu_built):
 def test_tie_filter_on_cpu(emu_built):
     """tests/test_gpu_cli.py: push conflicts the reference's arc sort cannot see -- the hit walk is skipped, every dump equals the reference's byte for byte; and the
     realistic inputs (jittered coordinates, lines grouped by target) through both walks"""
-    run_gpu_tests(["tests/test_gpu_cli.py", "-k", "out_of_sight or (tie_rich and jitter and default)"], 3000)
+    run_gpu_tests(["tests/test_gpu_cli.py", "-k", "out_of_sight or in_sight_only or (tie_rich and jitter and default)"], 3000)
 
 
 def test_kernels_ingest_on_cpu(emu_built):

@@ -197,17 +197,18 @@ def test_tie_rich_input_is_byte_identical(name, mode, tmpdir_s, monkeypatch):
     assert out == ref_out
 
 
-UNSEEN_INPUTS = [  # (reads, lines, seed, extra): arc tie groups AND push conflicts, but no conflict in a bucket of the reference's arc sort that is longer than its insertion-sort cut-off and holds a tie group
-    (400, 9000, 2, ["-j", "8", "-b", "0.2", "-d", "0.15"]), (400, 9000, 2, ["-j", "3", "-d", "0.2", "-x", "0.03", "-L", "uniform"]), (400, 9000, 7, ["-j", "3", "-d", "0.2", "-x", "0.03", "-L", "uniform"]),
-    (800, 20000, 6, ["-j", "8", "-b", "0.2", "-d", "0.15"]), (1500, 40000, 6, ["-j", "8", "-b", "0.2", "-d", "0.15"])]
+UNSEEN_INPUTS = [  # (reads, lines, seed, extra): arc tie groups AND push conflicts, none of them in sight of the reference's arc sort (csrc/graph.hip: k_arc_push_conflicts_seen)
+    (400, 9000, 8, ["-j", "8", "-b", "0.2", "-d", "0.15"]), (400, 9000, 10, ["-j", "3", "-d", "0.2", "-x", "0.03", "-L", "uniform"]), (800, 20000, 2, ["-j", "8", "-b", "0.2", "-d", "0.15"]),
+    (800, 20000, 9, ["-j", "8", "-b", "0.2", "-d", "0.15"]), (1000, 25000, 8, ["-j", "30", "-b", "0.1", "-t"])]
 
 
 @pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("case", range(len(UNSEEN_INPUTS)))
 def test_conflicts_out_of_sight_skip_the_hit_walk(case, tmpdir_s, monkeypatch):
     """Two arcs pushed from hits with equal (qid,qs) are a push conflict: only the reference's unstable hit sort knows which comes first.  The arc sort can turn that into a
-    difference only if both arcs lie in a bucket of its radix passes that is longer than the insertion-sort cut-off (ksort.h:182) and holds a group of equal keys
-    (csrc/graph.hip: k_arc_push_conflicts_seen).  These inputs have tie groups (the arc walk runs) and conflicts -- all of them out of sight, in reads without a tie group:
+    difference only if the two arcs part in a bucket of its radix passes that is walked (longer than the insertion-sort cut-off, ksort.h:182) and holds a group of equal
+    keys, or in an insertion-sorted bucket where one of the two has a twin (csrc/graph.hip: k_arc_push_conflicts_seen).  These inputs have tie groups (the arc walk runs)
+    and conflicts -- all of them out of sight:
     the walk over the hit keys is skipped and every dump still equals the reference's byte for byte; with the filter off (MA_TIE_NO_FILTER=1) the walk runs and gives the
     same bytes."""
     import re
@@ -228,6 +229,40 @@ def test_conflicts_out_of_sight_skip_the_hit_walk(case, tmpdir_s, monkeypatch):
             groups, conf, seen, arc_walk, hit_walk = (int(x) for x in m.groups())
             assert groups > 0 and conf > 0 and arc_walk == 1, "the input is supposed to have tie groups and conflicts"
             assert (seen, hit_walk) == ((0, 0) if filt else (conf, 1)), (seen, hit_walk, conf)
+
+
+SEEN_INPUTS = [  # (reads, lines, seed, extra): conflicts IN sight, in a few of the reads
+    (3000, 80000, 5, ["-q", "16", "-L", "uniform", "-d", "0.3", "-x", "0.03"]), (20000, 600000, 11, ["-j", "30", "-b", "0.1", "-t"]), (4000, 120000, 7, ["-q", "400", "-d", "0.2"]),
+    (30000, 900000, 12, ["-j", "8", "-b", "0.5"])]
+
+
+@pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("case", range(len(SEEN_INPUTS)))
+def test_hit_walk_takes_its_order_for_the_reads_in_sight_only(case, tmpdir_s, monkeypatch):
+    """With conflicts in sight the walk over the hit keys runs, but its order is taken inside the hit groups of the reads that HAVE such a conflict only (host/refsort.c:
+    ma_refsort_packed_wanted sorts the buckets below a level only where one of those reads is; every other read keeps the stable order): same bytes as the reference, and
+    the same as with the whole order taken (MA_TIE_WALK_ALL=1)."""
+    import re
+    reads, lines, seed, extra = SEEN_INPUTS[case]
+    paf = R.pafgen(os.path.join(tmpdir_s, "seen_%d.paf" % case), reads, lines, seed, extra)
+    monkeypatch.setenv("MA_PIPE_TIMING", "1")
+    for args in (["-p", "sg"], ["-p", "ug"]):
+        ref_out, _ = R.run_cli(R.REF_BIN, args, paf)
+        for walk_all in (False, True):
+            if walk_all:
+                monkeypatch.setenv("MA_TIE_WALK_ALL", "1")
+            else:
+                monkeypatch.delenv("MA_TIE_WALK_ALL", raising=False)
+            out, log = R.run_cli(ma.CLI_PATH, args, paf)
+            assert out == ref_out, "case %d %s (walk all: %s): bytes differ from the reference" % (case, " ".join(args), walk_all)
+            m = re.search(r"\[T::ties\] (\d+) arc tie groups .* \((\d+) of them in sight of the arc sort\) -> arc walk 1, hit walk 1( \(its order taken for (\d+) reads\))?", log)
+            assert m, log[-500:]
+            assert int(m.group(2)) > 0
+            if walk_all:
+                assert m.group(3) is None
+            else:
+                assert m.group(3) and 0 < int(m.group(4)) <= int(m.group(2)) and int(m.group(4)) < reads // 4
+    monkeypatch.delenv("MA_TIE_WALK_ALL", raising=False)
 
 
 @pytest.mark.skipif(not R.have_ref(), reason="oracle/_ref not built")

@@ -97,3 +97,56 @@ def test_stable_hit_order_differs_only_inside_tie_runs(tmpdir_s):
     out = np.empty_like(ref)
     out[hrank] = hits[sidx]                                # export through hrank = the reference's array
     assert out.tobytes() == ref.tobytes()
+
+
+def _packed(keys, bl, bi, shift_top):
+    """the elements radix.hip: k_pack_keys sends down: (hi << bl | lo) << bi | input position; with shift_top >= 32 hi goes without its bits from shift_top - 32 up and
+    the key's digit at shift_top travels in a byte array of its own (16 zero bytes behind it)"""
+    hi, lo = keys >> np.uint64(32), keys & np.uint64(0xffffffff)
+    dig = None
+    if shift_top >= 0:
+        dig = np.zeros(len(keys) + 16, dtype=np.uint8)
+        dig[:len(keys)] = ((keys >> np.uint64(shift_top)) & np.uint64(0xff)).astype(np.uint8)
+        hi = hi & np.uint64((1 << (shift_top - 32)) - 1)
+    pk = ((hi << np.uint64(bl) | lo) << np.uint64(bi)) | np.arange(len(keys), dtype=np.uint64)
+    return np.ascontiguousarray(pk), dig
+
+
+@pytest.mark.parametrize("n,n_ids,top_apart,threads", [(300000, 200000, False, "4"), (300000, 200000, True, "4"), (40000, 3000, True, "1"), (500000, 70000, True, "8"), (200000, 100, False, "3")])
+def test_restricted_walk_gives_the_wanted_reads_their_order(n, n_ids, top_apart, threads, monkeypatch):
+    """ma_refsort_packed_wanted (the tie walk restricted to the reads whose conflicts the arc sort can see) leaves, at the positions of a WANTED read's hits, exactly what
+    the whole sort leaves there -- for every subset of wanted reads, with the words carrying the whole key or not its top digit, on one thread and on several"""
+    monkeypatch.setenv("MA_THREADS", threads)
+    L = ma.lib()
+    L.ma_refsort_packed.restype = C.c_int
+    L.ma_refsort_packed.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.ma_refsort_packed_wanted.restype = C.c_int
+    L.ma_refsort_packed_wanted.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
+    rng = np.random.default_rng(n + n_ids)
+    ids = rng.integers(0, n_ids, n, dtype=np.uint64)
+    ids[: n // 3] = np.sort(ids[: n // 3])  # a PAF lists a query's lines together: stretches of one id
+    qs = rng.choice(np.array([0, 0, 0, 5, 17, 300, 301, 4000, 16383], dtype=np.uint64), n)  # equal keys everywhere
+    keys = ids << np.uint64(32) | qs
+    bh, bl, bi = int(n_ids - 1).bit_length(), 14, int(n - 1).bit_length()
+    shift_top = ((32 + bh - 1) & ~7) if top_apart else -1
+    if top_apart and shift_top < 32:
+        pytest.skip("ids of one byte: no digit to take apart")
+    full, dig = _packed(keys, bl, bi, shift_top)
+    dptr = dig.ctypes.data if dig is not None else None
+    assert L.ma_refsort_packed(full.ctypes.data, n, bl, bi, shift_top, dptr) == 0
+    order = np.argsort(keys, kind="stable")
+    start = np.searchsorted(keys[order], np.arange(n_ids + 1, dtype=np.uint64) << np.uint64(32))  # where a read's hits stand in ANY sorted order
+    for frac in (0.0005, 0.02, 0.5):
+        want = rng.random(n_ids) < frac
+        want[int(ids[0])] = True
+        wcum = np.zeros(n_ids + 1, dtype=np.uint32)
+        wcum[1:] = np.cumsum(want)
+        part, _ = _packed(keys, bl, bi, shift_top)
+        assert L.ma_refsort_packed_wanted(part.ctypes.data, n, bl, bi, shift_top, dptr, wcum.ctypes.data, n_ids) == 0
+        sel = np.zeros(n, dtype=bool)
+        for r in np.flatnonzero(want):
+            sel[start[r]:start[r + 1]] = True
+        assert sel.any() and (part[sel] == full[sel]).all(), frac
+        assert (np.sort(part) == np.sort(full)).all()  # still a permutation of the input
+        if frac < 0.001:
+            assert (part != full).any()  # (and the work was left out: what nobody asked for is not in order)
