@@ -673,8 +673,10 @@ __device__ __forceinline__ uint32_t dict_probe(const unsigned char *__restrict__
 	const uint32_t tag = (uint32_t)(hm >> 32);
 	uint32_t s = (uint32_t)hm & mask;
 	for (uint32_t probe = 0; probe < PAF_PROBE_LIMIT; ++probe, s = (s + 1) & mask) {
-		const uint4 raw = *(const uint4*)&tab[s];
-		unsigned long long e = (unsigned long long)raw.y << 32 | raw.x, inf = (unsigned long long)raw.w << 32 | raw.z;
+		// (two 64-bit words, not four 32-bit ones: a word another thread is claiming must be seen whole -- as the halves of a uint4 the CPU test build read it in two pieces, and a
+		// torn tag sent the probe on to a second slot for the same name: one run of the command line in a thousand)
+		const ulonglong2 raw = *(const ulonglong2*)&tab[s];
+		unsigned long long e = raw.x, inf = raw.y;
 		if (e == PAF_EMPTY) {
 			e = atomicCAS(&tab[s].w0, PAF_EMPTY, (unsigned long long)tag << 32 | occ);
 			if (e == PAF_EMPTY) {
@@ -759,9 +761,9 @@ __device__ __forceinline__ uint32_t dict_probe_short(DSlot *__restrict__ tab, ui
 {
 	uint32_t s = (uint32_t)key_mix(key) & mask;
 	for (uint32_t probe = 0; probe < PAF_PROBE_LIMIT; ++probe, s = (s + 1) & mask) {
-		const uint4 e = *(const uint4*)&tab[s];
-		unsigned long long k = (unsigned long long)e.y << 32 | e.x;
-		uint32_t seen = e.z;
+		const ulonglong2 e = *(const ulonglong2*)&tab[s]; // (64-bit words: a key being claimed is seen whole or not at all, see dict_probe)
+		unsigned long long k = e.x;
+		uint32_t seen = (uint32_t)e.y;
 		if (k == 0) {
 			k = atomicCAS(&tab[s].key, 0ull, (unsigned long long)key);
 			if (k == 0) { ++*fresh; k = key; }

@@ -5,7 +5,7 @@ for cfg in "real10 250000 10000000 6 -L uniform" "real50 1000000 50000000 7"; do
   set -- $cfg; name=$1; r=$2; n=$3; s=$4; shift 4
   miniasm_amd/bin/pafgen -r $r -n $n -s $s -j 30 -b 0.1 -t "$@" -d 0.2 -x 0.03 -o /tmp/$name.paf 2>/dev/null
   for k in 1 2; do
-    t0=$(date +%s.%N); MA_PIPE_TIMING=2 timeout 900 miniasm_amd/bin/miniasm /tmp/$name.paf 2> gpurun_out/$name.log | md5sum; t1=$(date +%s.%N)
+    t0=$(date +%s.%N); MA_REFSORT_TIMING=1 MA_PIPE_TIMING=2 timeout 900 miniasm_amd/bin/miniasm /tmp/$name.paf 2> gpurun_out/$name.log | md5sum; t1=$(date +%s.%N)
     python3 -c "print('$name run $k: %.3f s wall' % ($t1 - $t0))"
   done
   grep -E "T::ties|T::refsort|T::head\] (sort|sg_gen)|T::ingest|walk:|Real time|T::pipeline" gpurun_out/$name.log | head -40
