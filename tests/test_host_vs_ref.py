@@ -516,3 +516,35 @@ def test_dictionary_bulk_fill_arena_semantics():
         assert L.sd_get(d, b"read4999") == 2499 and L.sd_get(d, b"read4998") == -1 and L.sd_get(d, b"late_comer") == -1
         L.sd_destroy(d)
     libc.free(C.c_void_p(arena))
+
+
+def test_cpu_budget_is_what_the_control_group_grants():
+    """host/ingest_mt.c: ma_cpu_budget() = the online CPUs cut by the control group's CPU quota (cgroup v2 cpu.max / v1 cfs_quota_us): the thread pools of the host side size
+    themselves by it (a container that shows 256 CPUs and grants 16 throttles every thread of a process that runs 64)"""
+    import math
+    L = ma.lib()
+    L.ma_cpu_budget.restype = C.c_int
+    L.ma_ingest_threads.restype = C.c_int
+    b = L.ma_cpu_budget()
+    n = os.cpu_count()
+    assert 1 <= b <= n
+    want = n
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            want = min(want, math.ceil(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        if q > 0:
+            want = min(want, math.ceil(q / per))
+    except (OSError, ValueError):
+        pass
+    assert b <= want  # (the group's own file and its ancestors' may cut it further)
+    if "MA_THREADS" not in os.environ:
+        assert 1 <= L.ma_ingest_threads() <= min(b, 16)
